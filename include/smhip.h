@@ -1,0 +1,155 @@
+/* smhip.h -- C ABI of the MI355X (gfx950) scan-matching backend.
+ *
+ * This is the drop-in boundary for StaticMapping's per-frame registration hot
+ * path.  Nothing like it exists in the reference: the reference
+ * reaches its registrators through the C++ class
+ *   static_map::registrator::Interface      /root/reference/registrators/interface.h:67-116
+ * created by
+ *   CreateMatcher(const MatcherOptions&)    /root/reference/registrators/interface.cc:139-173
+ * The C++ mirror of that class lives in include/smhip/registrator.h and is a
+ * thin adapter over the entry points below; INTEGRATION.md shows the lines a
+ * maintainer adds to interface.cc to select it.
+ *
+ * Conventions
+ *   - plain C types only; no exceptions cross the boundary; every call returns
+ *     an smhip_status (0 = ok) and smhip_last_error(h) gives the text;
+ *   - 4x4 transforms are COLUMN-major doubles (Eigen::Matrix4d storage), and
+ *     map SOURCE-frame points into the TARGET frame
+ *     (pose_source = pose_target * align_result, builder/map_builder.cc:354);
+ *   - a handle owns one HIP stream (or borrows the caller's), all its device
+ *     buffers and a fixed number of independent "pair slots"; slot 0 is what the
+ *     single-pair registrator::Interface adapter uses, slots 0..B-1 are used by
+ *     the batched / sharded benchmark path.  One thread per handle; different
+ *     handles are independent (the reference runs up to 6 matchers
+ *     concurrently, builder/map_builder.cc:655,706-708).
+ */
+#ifndef SMHIP_H_
+#define SMHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int smhip_status;
+enum {
+  SMHIP_OK = 0,
+  SMHIP_ERR_INVALID_ARGUMENT = 1,
+  SMHIP_ERR_NO_DEVICE = 2,      /* no gfx950 device / HIP runtime failure at create */
+  SMHIP_ERR_HIP = 3,            /* a HIP call failed; see smhip_last_error */
+  SMHIP_ERR_NOT_READY = 4,      /* Align before SetInputSource/SetInputTarget */
+  SMHIP_ERR_NO_NORMALS = 5,     /* IcpFast target without normals (icp_fast.cc:430 CHECK) */
+  SMHIP_ERR_NO_MATCH = 6,       /* no finite correspondence (icp_fast.cc:81 CHECK(!values.empty())) */
+  SMHIP_ERR_CAPACITY = 7        /* cloud larger than the handle was created for */
+};
+
+typedef struct smhip_context* smhip_handle;
+
+/* nn_mode values */
+enum {
+  SMHIP_NN_BRUTE = 0,           /* LDS-tiled exact brute force (BASELINE config #2) */
+  SMHIP_NN_GRID = 1             /* bit-rank voxel grid, exact with brute-force fallback */
+};
+
+/* Options of the IcpFast-equivalent matcher.  max_iteration / dist_outlier_ratio
+ * mirror IcpFast::options_ (/root/reference/registrators/icp_fast.h:56-60) and
+ * are the names registered at icp_fast.cc:407-419. */
+typedef struct smhip_icp_options {
+  int32_t max_iteration;        /* default 100 */
+  float dist_outlier_ratio;     /* default 0.7f */
+  int32_t early_exit;           /* 1 = CheckConvergence enabled (reference behaviour, icp_fast.cc:377-405);
+                                   0 = run exactly max_iteration iterations (throughput runs) */
+  int32_t nn_mode;              /* SMHIP_NN_GRID (default) or SMHIP_NN_BRUTE */
+  float grid_cell;              /* voxel edge in metres for SMHIP_NN_GRID (default 0.5) */
+  int32_t grid_max_ring;        /* largest ring searched in the grid before the brute-force fallback (default 4) */
+  int32_t check_every;          /* host polls the device "all done" word every this many iterations (default 8) */
+  int32_t reserved[8];
+} smhip_icp_options;
+
+/* Per-call statistics (all optional to read). */
+typedef struct smhip_icp_stats {
+  int32_t iterations;           /* iterations executed by this pair */
+  int32_t kept;                 /* correspondences kept by the trimmed-distance filter in the last iteration */
+  double limit_d2;              /* the quantile (squared distance) of the last iteration */
+  int32_t fallback_queries;     /* queries resolved by the brute-force fallback, summed over iterations */
+  int32_t status;               /* per-pair smhip_status */
+} smhip_icp_stats;
+
+/* Kernel-time breakdown collected when profiling is enabled (HIP events on the
+ * handle's stream around every launch).  Names follow the reference's
+ * REGISTER_BLOCK labels where one exists (icp_fast.cc:103,171,261,484). */
+typedef struct smhip_icp_profile {
+  double ms_prepare;            /* target centring + grid build (replaces kd-tree build, icp_fast.cc:464-467) */
+  double ms_find_closests;      /* "FindClosests": NN kernels, summed over launches */
+  double ms_error_elements;     /* "ErrorElements"+"ComputePointToPlane" accumulate kernel */
+  double ms_solve;              /* select + 6x6 solve + convergence kernel */
+  int32_t launches_find_closests;
+  int32_t launches_error_elements;
+  int32_t launches_solve;
+  int32_t reserved;
+} smhip_icp_profile;
+
+/* ---- library / device ------------------------------------------------- */
+int smhip_version(void);
+const char* smhip_status_string(smhip_status s);
+/* number of visible HIP devices whose gcnArchName starts with "gfx950"; <0 on runtime failure */
+int smhip_device_count(void);
+
+/* ---- handle ------------------------------------------------------------ */
+/* stream: a hipStream_t to borrow (e.g. torch's current stream) or NULL to own one.
+ * pair_slots >= 1; max_source_points / max_target_points size the device arena once
+ * (no hipMalloc happens inside Align). */
+smhip_status smhip_create(int device, void* stream, int pair_slots, int max_source_points,
+                          int max_target_points, smhip_handle* out);
+smhip_status smhip_destroy(smhip_handle h);
+const char* smhip_last_error(smhip_handle h);
+void smhip_icp_default_options(smhip_icp_options* o);
+smhip_status smhip_icp_set_options(smhip_handle h, const smhip_icp_options* o);
+smhip_status smhip_synchronize(smhip_handle h);
+
+/* ---- inputs (host memory; copied to the device immediately) ------------
+ * replaces IcpFast::SetInputSource / SetInputTarget (icp_fast.cc:421-453), which
+ * deep-copy the caller's EigenPointCloud (3xN column-major f64 = xyzxyz...). */
+smhip_status smhip_set_source_f64(smhip_handle h, int slot, const double* xyz_colmajor_3xN, int n);
+smhip_status smhip_set_target_f64(smhip_handle h, int slot, const double* xyz_colmajor_3xN,
+                                  const double* normals_colmajor_3xN, int n);
+/* float32 points with a stride in floats: stride 4 = KITTI .bin rows (ros_node/kitti_reader.cc:91-121),
+ * stride 5 = data::InnerPointType AoS {x,y,z,intensity,factor} (builder/data/cloud_types.h:46-56). */
+smhip_status smhip_set_source_f32(smhip_handle h, int slot, const float* xyz, int stride_floats, int n);
+smhip_status smhip_set_target_f32(smhip_handle h, int slot, const float* xyz, int xyz_stride_floats,
+                                  const float* normals, int normals_stride_floats, int n);
+/* Re-use slot `from`'s device-resident clouds in slot `to` (benchmark replication; no host copy). */
+smhip_status smhip_copy_slot(smhip_handle h, int from, int to);
+
+/* ---- IcpFast::Align (icp_fast.cc:455-529) ------------------------------
+ * Aligns slots [0, npairs).  guesses/results: npairs * 16 doubles, column-major.
+ * scores: exp(-mean sqrt(d2)) over kept matches of the last iteration (icp_fast.cc:518-521).
+ * stats may be NULL.  Blocking: returns after the results are in host memory. */
+smhip_status smhip_icp_align(smhip_handle h, const double guess[16], double result[16], double* score,
+                             smhip_icp_stats* stats);
+smhip_status smhip_icp_align_batch(smhip_handle h, int npairs, const double* guesses, double* results,
+                                   double* scores, smhip_icp_stats* stats);
+/* Asynchronous halves of the batch call: enqueue leaves everything on the stream (needs
+ * early_exit = 0 or accepts running all max_iteration launches), fetch blocks and copies out. */
+smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* guesses);
+smhip_status smhip_icp_fetch_batch(smhip_handle h, int npairs, double* results, double* scores,
+                                   smhip_icp_stats* stats);
+
+/* ---- introspection for parity tests ------------------------------------
+ * Matches of the LAST executed iteration of `slot` (FindClosests output, icp_fast.cc:169-180):
+ * ids index the target cloud in the caller's order, d2 are squared distances (float32). */
+smhip_status smhip_icp_get_matches(smhip_handle h, int slot, int32_t* ids, float* d2, int n);
+/* One FindClosests pass only: transform the slot's source by T (column-major 4x4, applied AFTER
+ * centring exactly as Align does) and return ids / d2 without running ICP. */
+smhip_status smhip_icp_find_closests(smhip_handle h, int slot, const double T[16], int32_t* ids, float* d2, int n);
+
+/* ---- profiling ----------------------------------------------------------- */
+smhip_status smhip_icp_enable_profile(smhip_handle h, int enable);
+smhip_status smhip_icp_get_profile(smhip_handle h, smhip_icp_profile* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMHIP_H_ */

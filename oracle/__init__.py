@@ -1,0 +1,12 @@
+"""CPU oracle for the registration hot path -- TEST INFRASTRUCTURE ONLY.
+
+Nothing under `oracle/` is product code.  Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import,
+call, link or execute anything in here, and only as the *checker*.
+
+PARITY UNPINNED: the reference (EdwardLiuyc/StaticMapping) ships no test,
+golden vector or known-answer fixture for any registrator
+and cannot be compiled in this image (Eigen / PCL / libnabo / libpointmatcher /
+glog are absent), so these restatements are anchored on the reference's source
+text (file:line cited per function) and on self-consistency KATs only.
+"""

@@ -1,0 +1,88 @@
+"""ctypes view of the C ABI in include/smhip.h.  No compute happens in Python."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from . import build as _build
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+
+
+class IcpOptions(ctypes.Structure):
+    _fields_ = [("max_iteration", ctypes.c_int32), ("dist_outlier_ratio", ctypes.c_float),
+                ("early_exit", ctypes.c_int32), ("nn_mode", ctypes.c_int32), ("grid_cell", ctypes.c_float),
+                ("grid_max_ring", ctypes.c_int32), ("check_every", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 8)]
+
+
+class IcpStats(ctypes.Structure):
+    _fields_ = [("iterations", ctypes.c_int32), ("kept", ctypes.c_int32), ("limit_d2", ctypes.c_double),
+                ("fallback_queries", ctypes.c_int32), ("status", ctypes.c_int32)]
+
+
+class IcpProfile(ctypes.Structure):
+    _fields_ = [("ms_prepare", ctypes.c_double), ("ms_find_closests", ctypes.c_double),
+                ("ms_error_elements", ctypes.c_double), ("ms_solve", ctypes.c_double),
+                ("launches_find_closests", ctypes.c_int32), ("launches_error_elements", ctypes.c_int32),
+                ("launches_solve", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+# name -> (restype, argtypes): every symbol include/smhip.h declares
+SIGNATURES = {
+    "smhip_version": (ctypes.c_int, []),
+    "smhip_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "smhip_device_count": (ctypes.c_int, []),
+    "smhip_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    ctypes.POINTER(ctypes.c_void_p)]),
+    "smhip_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "smhip_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "smhip_icp_default_options": (None, [ctypes.POINTER(IcpOptions)]),
+    "smhip_icp_set_options": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(IcpOptions)]),
+    "smhip_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
+    "smhip_set_source_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, ctypes.c_int]),
+    "smhip_set_target_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p, ctypes.c_int]),
+    "smhip_set_source_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int]),
+    "smhip_set_target_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_float_p, ctypes.c_int, c_float_p,
+                                            ctypes.c_int, ctypes.c_int]),
+    "smhip_copy_slot": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "smhip_icp_align": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p, ctypes.POINTER(IcpStats)]),
+    "smhip_icp_align_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p, c_double_p,
+                                             ctypes.POINTER(IcpStats)]),
+    "smhip_icp_enqueue_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p]),
+    "smhip_icp_fetch_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p,
+                                             ctypes.POINTER(IcpStats)]),
+    "smhip_icp_get_matches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int32_p, c_float_p, ctypes.c_int]),
+    "smhip_icp_find_closests": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_int32_p, c_float_p,
+                                               ctypes.c_int]),
+    "smhip_icp_enable_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "smhip_icp_get_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(IcpProfile)]),
+}
+
+_LIB = None
+
+
+def library_path() -> str:
+    return _build.LIB_PATH
+
+
+def load_library():
+    """dlopen staticmapping_amd/lib/libsmhip.so.  Fails loudly: there is no CPU fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "There is deliberately no CPU fallback for the registration hot path.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError = header/library drift, also loud
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib

@@ -1,0 +1,798 @@
+// icp_kernels.hip -- hand-written gfx950 kernels for the IcpFast hot path.
+//
+// Kernel inventory (SURVEY.md §2b ids in brackets; reference lines are in /root/reference):
+//   tgt_reduce / grid_setup / grid_mark / grid_rank / grid_count / grid_cscan / grid_scatter
+//        target centring (icp_fast.cc:457-463) + the search structure that replaces the
+//        libnabo kd-tree rebuilt on every Align (icp_fast.cc:464-467)
+//   nn_grid, nn_brute   [K1]  ApplyTransform + FindClosests      (icp_fast.cc:486-493, 169-180)
+//   accumulate          [K2/K3] GetDistsQuantile bin + ErrorElements + point-to-plane sums
+//                                                               (icp_fast.cc:65-90, 100-166, 256-303)
+//   finalize            [K2/K4] exact quantile inside the boundary bin, 6x6 solve, SE(3) update,
+//                       CheckConvergence, score                  (icp_fast.cc:204-254, 306-323, 377-405, 513-523)
+//
+// Everything here is HBM/L2-bound gather, scan and reduction work: wave64 shuffles + LDS, no MFMA.
+#include "smhip_device.h"
+
+namespace smhip {
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_down(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t t = __shfl_up(v, off, 64);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+
+// Block-wide exclusive scan of one value per thread (blockDim.x multiple of 64, <= 1024).
+// Returns the exclusive prefix; *total receives the block sum.  s_w needs 17 words.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  uint32_t inc = wave_incl_scan(v, lane);
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int w = 0; w < nwave; ++w) { uint32_t t = s_w[w]; s_w[w] = run; run += t; }
+    s_w[16] = run;
+  }
+  __syncthreads();
+  uint32_t excl = inc - v + s_w[wave];
+  *total = s_w[16];
+  __syncthreads();
+  return excl;
+}
+
+// ------------------------------------------------------------------------------------------
+// target preparation
+// ------------------------------------------------------------------------------------------
+// Partial sums (f64) and bbox (f32, exact) of the raw target; grid = (kTgtReduceBlocks, pairs).
+__global__ __launch_bounds__(256) void tgt_reduce(IcpDev b) {
+  const int pair = blockIdx.y;
+  const int nt = b.in[pair].nt;
+  const float4* tp = b.tgt_p + (size_t)pair * b.nt_cap;
+  double sx = 0, sy = 0, sz = 0;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  const int chunk = (nt + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * chunk, hi = min(nt, lo + chunk);
+  for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+    float4 p = tp[j];
+    sx += p.x; sy += p.y; sz += p.z;
+    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+  }
+  __shared__ double s_sum[4][3];
+  __shared__ float s_mn[4][3], s_mx[4][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+  for (int d = 0; d < 3; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+  if (lane == 0) {
+    s_sum[wave][0] = sx; s_sum[wave][1] = sy; s_sum[wave][2] = sz;
+    for (int d = 0; d < 3; ++d) { s_mn[wave][d] = mn[d]; s_mx[wave][d] = mx[d]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* out = b.tpart + ((size_t)pair * kTgtReduceBlocks + blockIdx.x) * 16;
+    for (int d = 0; d < 3; ++d) {
+      out[d] = s_sum[0][d] + s_sum[1][d] + s_sum[2][d] + s_sum[3][d];
+      out[3 + d] = fminf(fminf(s_mn[0][d], s_mn[1][d]), fminf(s_mn[2][d], s_mn[3][d]));
+      out[6 + d] = fmaxf(fmaxf(s_mx[0][d], s_mx[1][d]), fmaxf(s_mx[2][d], s_mx[3][d]));
+    }
+  }
+}
+
+__device__ __forceinline__ void mat4_mul_rm(const double* a, const double* c, double* out) {
+  double r[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += a[4 * i + k] * c[4 * k + j];
+      r[4 * i + j] = s;
+    }
+  for (int i = 0; i < 16; ++i) out[i] = r[i];
+}
+
+// One thread per pair: mean, grid geometry, G = T(-mu) * guess, loop state reset.
+__global__ void grid_setup(IcpDev b, int npairs) {
+  const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= npairs) return;
+  PairState* st = &b.state[pair];
+  const double* part = b.tpart + (size_t)pair * kTgtReduceBlocks * 16;
+  double s[3] = {0, 0, 0};
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int k = 0; k < kTgtReduceBlocks; ++k)
+    for (int d = 0; d < 3; ++d) {
+      s[d] += part[16 * k + d];
+      mn[d] = fminf(mn[d], (float)part[16 * k + 3 + d]);
+      mx[d] = fmaxf(mx[d], (float)part[16 * k + 6 + d]);
+    }
+  const PairInput* in = &b.in[pair];
+  const int nt = in->nt;
+  st->ns = in->ns; st->nt = nt; st->has_normals = in->has_normals;
+  for (int i = 0; i < 16; ++i) st->guess[i] = in->guess[i];
+  double mu[3];
+  for (int d = 0; d < 3; ++d) { mu[d] = s[d] / nt; st->mu[d] = mu[d]; }        // icp_fast.cc:457-458
+  // centred bbox, the same rounding the mark/scatter kernels apply to every point
+  float cmin[3], cmax[3];
+  for (int d = 0; d < 3; ++d) { cmin[d] = (float)((double)mn[d] - mu[d]); cmax[d] = (float)((double)mx[d] - mu[d]); }
+  float h = b.grid_cell;
+  int nx, ny, nz, wx;
+  for (;;) {
+    const float inv = 1.0f / h;
+    nx = (int)floorf((cmax[0] - cmin[0]) * inv) + 2;
+    ny = (int)floorf((cmax[1] - cmin[1]) * inv) + 2;
+    nz = (int)floorf((cmax[2] - cmin[2]) * inv) + 2;
+    wx = (nx + 31) >> 5;
+    const double words = (double)wx * ny * nz;
+    if (words <= (double)kMaxGridWords && nx < 32768 && ny < 32768 && nz < 32768) break;
+    h *= 1.25992105f;   // 2^(1/3): halve the cell count
+  }
+  st->h = h; st->inv_h = 1.0f / h;
+  for (int d = 0; d < 3; ++d) st->origin[d] = cmin[d] - 0.5f * h;
+  st->nx = nx; st->ny = ny; st->nz = nz; st->wx = wx; st->nw = wx * ny * nz;
+  // G = T(-mu) * guess   (icp_fast.cc:469), T_iter = I (:473)
+  double Tmi[16] = {1, 0, 0, -mu[0], 0, 1, 0, -mu[1], 0, 0, 1, -mu[2], 0, 0, 0, 1};
+  mat4_mul_rm(Tmi, st->guess, st->G);
+  for (int i = 0; i < 16; ++i) st->T_iter[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  for (int i = 0; i < 12; ++i) st->M[i] = st->G[i];
+  st->quat[0][0] = 1; st->quat[0][1] = st->quat[0][2] = st->quat[0][3] = 0;      // :478-479
+  st->trans[0][0] = st->trans[0][1] = st->trans[0][2] = 0;
+  st->n_hist = 1;
+  st->iter = 0; st->done = 0; st->status = 0;
+  st->unresolved_count = 0; st->blist_count = 0; st->fallback_total = 0;
+  st->kept = 0; st->limit_key = 0; st->score = 0; st->nocc = 0;
+}
+
+__device__ __forceinline__ float3 centre_point(const float4 p, const double* mu) {
+  return make_float3((float)((double)p.x - mu[0]), (float)((double)p.y - mu[1]), (float)((double)p.z - mu[2]));
+}
+
+__global__ __launch_bounds__(256) void grid_mark(IcpDev b) {
+  const int pair = blockIdx.y;
+  const PairState* st = &b.state[pair];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= st->nt) return;
+  const float3 c = centre_point(b.tgt_p[(size_t)pair * b.nt_cap + j], st->mu);
+  int ix = (int)floorf((c.x - st->origin[0]) * st->inv_h);
+  int iy = (int)floorf((c.y - st->origin[1]) * st->inv_h);
+  int iz = (int)floorf((c.z - st->origin[2]) * st->inv_h);
+  ix = min(max(ix, 0), st->nx - 1); iy = min(max(iy, 0), st->ny - 1); iz = min(max(iz, 0), st->nz - 1);
+  const uint32_t w = (uint32_t)((iz * st->ny + iy) * st->wx + (ix >> 5));
+  const uint32_t bit = ix & 31;
+  atomicOr(&b.bits[(size_t)pair * kMaxGridWords + w], 1u << bit);
+  b.tcell[(size_t)pair * b.nt_cap + j] = (w << 5) | bit;
+}
+
+// One 1024-thread block per pair: words[w] = {bits, exclusive popcount rank}; nocc.
+__global__ __launch_bounds__(1024) void grid_rank(IcpDev b) {
+  const int pair = blockIdx.x;
+  PairState* st = &b.state[pair];
+  const int nw = st->nw;
+  const uint32_t* bits = b.bits + (size_t)pair * kMaxGridWords;
+  uint2* words = b.words + (size_t)pair * kMaxGridWords;
+  __shared__ uint32_t s_w[17];
+  const int per = (nw + blockDim.x - 1) / blockDim.x;
+  const int lo = min(nw, (int)threadIdx.x * per), hi = min(nw, lo + per);
+  uint32_t c = 0;
+  for (int w = lo; w < hi; ++w) c += __popc(bits[w]);
+  uint32_t total;
+  uint32_t run = block_excl_scan(c, s_w, &total);
+  for (int w = lo; w < hi; ++w) {
+    const uint32_t v = bits[w];
+    words[w] = make_uint2(v, run);
+    run += __popc(v);
+  }
+  if (threadIdx.x == 0) st->nocc = (int)total;
+}
+
+__global__ __launch_bounds__(256) void grid_count(IcpDev b) {
+  const int pair = blockIdx.y;
+  const PairState* st = &b.state[pair];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= st->nt) return;
+  const uint32_t cell = b.tcell[(size_t)pair * b.nt_cap + j];
+  const uint2 wd = b.words[(size_t)pair * kMaxGridWords + (cell >> 5)];
+  const uint32_t slot = wd.y + __popc(wd.x & ((1u << (cell & 31)) - 1u));
+  const uint32_t ord = atomicAdd(&b.ccount[(size_t)pair * (b.nt_cap + 1) + slot], 1u);
+  b.tslot[(size_t)pair * b.nt_cap + j] = slot;
+  b.tord[(size_t)pair * b.nt_cap + j] = ord;
+}
+
+__global__ __launch_bounds__(1024) void grid_cscan(IcpDev b) {
+  const int pair = blockIdx.x;
+  const PairState* st = &b.state[pair];
+  const int n = st->nocc;
+  const uint32_t* cnt = b.ccount + (size_t)pair * (b.nt_cap + 1);
+  uint32_t* cs = b.cstart + (size_t)pair * (b.nt_cap + 1);
+  __shared__ uint32_t s_w[17];
+  const int per = (n + blockDim.x - 1) / blockDim.x;
+  const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+  uint32_t c = 0;
+  for (int k = lo; k < hi; ++k) c += cnt[k];
+  uint32_t total;
+  uint32_t run = block_excl_scan(c, s_w, &total);
+  for (int k = lo; k < hi; ++k) { cs[k] = run; run += cnt[k]; }
+  if (threadIdx.x == 0) cs[n] = total;
+}
+
+__global__ __launch_bounds__(256) void grid_scatter(IcpDev b) {
+  const int pair = blockIdx.y;
+  const PairState* st = &b.state[pair];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= st->nt) return;
+  const size_t o = (size_t)pair * b.nt_cap;
+  const float3 c = centre_point(b.tgt_p[o + j], st->mu);
+  const uint32_t pos = b.cstart[(size_t)pair * (b.nt_cap + 1) + b.tslot[o + j]] + b.tord[o + j];
+  b.tq[o + pos] = make_float4(c.x, c.y, c.z, __int_as_float(j));
+  float4 n = b.tgt_n[o + j];
+  n.w = 0.f;
+  b.tn[o + pos] = n;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: transform + exact 1-NN
+// ------------------------------------------------------------------------------------------
+struct Best { float d2; int j; int orig; };
+
+__device__ __forceinline__ void test_candidate(const float4 t, int j, float qx, float qy, float qz, Best& best) {
+  const float dx = qx - t.x, dy = qy - t.y, dz = qz - t.z;
+  const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+  const int orig = __float_as_int(t.w);
+  // ties broken towards the smaller ORIGINAL target index, so the result does not depend
+  // on the (atomic) order of points inside a cell
+  if (d < best.d2 || (d == best.d2 && orig < best.orig)) { best.d2 = d; best.j = j; best.orig = orig; }
+}
+
+__device__ __forceinline__ void transform_point(const double* M, const float4 s, double& px, double& py, double& pz) {
+  const double x = s.x, y = s.y, z = s.z;
+  px = fma(M[0], x, fma(M[1], y, fma(M[2], z, M[3])));      // ApplyTransform, cloud_types.cc:288-302
+  py = fma(M[4], x, fma(M[5], y, fma(M[6], z, M[7])));
+  pz = fma(M[8], x, fma(M[9], y, fma(M[10], z, M[11])));
+}
+
+// candidates of the cells x in [xa, xb] of row (y, z): one contiguous run of the sorted target
+__device__ __forceinline__ void search_row(const uint2* __restrict__ words, const uint32_t* __restrict__ cstart,
+                                           const float4* __restrict__ tq, int rowbase, int xa, int xb,
+                                           float qx, float qy, float qz, Best& best) {
+  const int w0 = xa >> 5, w1 = xb >> 5;
+  const uint2 a = words[rowbase + w0];
+  const uint2 c = (w1 == w0) ? a : words[rowbase + w1];
+  const uint32_t s_begin = a.y + __popc(a.x & ((1u << (xa & 31)) - 1u));
+  const uint32_t s_end = c.y + __popc(c.x & (0xffffffffu >> (31 - (xb & 31))));
+  if (s_end > s_begin) {
+    const uint32_t j0 = cstart[s_begin], j1 = cstart[s_end];
+    for (uint32_t j = j0; j < j1; ++j) test_candidate(tq[j], (int)j, qx, qy, qz, best);
+  }
+}
+
+__global__ __launch_bounds__(kNnThreads) void nn_grid(IcpDev b) {
+  const int pair = blockIdx.y;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  const int ns = st->ns;
+  if ((int)(blockIdx.x * kNnThreads) >= ns) return;
+  __shared__ uint32_t s_hist[kHistBins];
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+  __syncthreads();
+  const int i = blockIdx.x * kNnThreads + threadIdx.x;
+  if (i < ns) {
+    const size_t so = (size_t)pair * b.ns_cap;
+    double px, py, pz;
+    transform_point(st->M, b.src[so + i], px, py, pz);
+    const float qx = (float)px, qy = (float)py, qz = (float)pz;
+    Best best = {INFINITY, -1, 0x7fffffff};
+    bool resolved = true;
+    if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) {
+      best.d2 = INFINITY;   // NaN / inf input: no match (libnabo InvalidValue analogue)
+    } else {
+      const uint2* words = b.words + (size_t)pair * kMaxGridWords;
+      const uint32_t* cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
+      const float4* tq = b.tq + (size_t)pair * b.nt_cap;
+      const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
+      const float h = st->h, inv_h = st->inv_h;
+      const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
+      const float lim = 1.0e6f;
+      const int cx = (int)floorf(fminf(fmaxf((qx - ox) * inv_h, -lim), lim));
+      const int cy = (int)floorf(fminf(fmaxf((qy - oy) * inv_h, -lim), lim));
+      const int cz = (int)floorf(fminf(fmaxf((qz - oz) * inv_h, -lim), lim));
+      int rp = 0;   // radius already searched (0 = nothing)
+      resolved = false;
+      for (int r = 1; r <= b.max_ring; r = (r < 2 ? 2 : r * 2)) {
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, nx - 1);
+        const int y0 = max(cy - r, 0), y1 = min(cy + r, ny - 1);
+        const int z0 = max(cz - r, 0), z1 = min(cz + r, nz - 1);
+        if (x0 <= x1 && y0 <= y1 && z0 <= z1) {
+          for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y) {
+              const int rowbase = (z * ny + y) * wx;
+              const bool inner = rp > 0 && abs(y - cy) <= rp && abs(z - cz) <= rp;
+              if (!inner) {
+                search_row(words, cstart, tq, rowbase, x0, x1, qx, qy, qz, best);
+              } else {   // cells [cx-rp, cx+rp] of this row were searched in an earlier ring
+                const int xl1 = min(cx - rp - 1, nx - 1), xr0 = max(cx + rp + 1, 0);
+                if (x0 <= xl1) search_row(words, cstart, tq, rowbase, x0, xl1, qx, qy, qz, best);
+                if (xr0 <= x1) search_row(words, cstart, tq, rowbase, xr0, x1, qx, qy, qz, best);
+              }
+            }
+        }
+        // Every target point outside the block [c-r, c+r]^3 is at least g away, where g is the
+        // distance to the nearest block face that still has grid beyond it.
+        float g = INFINITY;
+        if (cx - r > 0) g = fminf(g, qx - (ox + (float)(cx - r) * h));
+        if (cx + r < nx - 1) g = fminf(g, (ox + (float)(cx + r + 1) * h) - qx);
+        if (cy - r > 0) g = fminf(g, qy - (oy + (float)(cy - r) * h));
+        if (cy + r < ny - 1) g = fminf(g, (oy + (float)(cy + r + 1) * h) - qy);
+        if (cz - r > 0) g = fminf(g, qz - (oz + (float)(cz - r) * h));
+        if (cz + r < nz - 1) g = fminf(g, (oz + (float)(cz + r + 1) * h) - qz);
+        g -= 1.0e-3f * h;   // fp32 slack for the cell assignment of points sitting on a face
+        if (g == INFINITY || (g > 0.f && best.d2 <= g * g)) { resolved = true; break; }
+        rp = r;
+      }
+    }
+    b.d2[so + i] = best.d2;
+    b.idx[so + i] = best.j;
+    if (resolved) {
+      const uint32_t key = __float_as_uint(best.d2);
+      if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
+    } else {
+      const uint32_t pos = atomicAdd(&st->unresolved_count, 1u);
+      b.ulist[so + pos] = i;
+    }
+  }
+  __syncthreads();
+  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
+    const uint32_t v = s_hist[k];
+    if (v) atomicAdd(&gh[k], v);
+  }
+}
+
+// LDS-tiled exact brute force.  ALL = true: every source point (SMHIP_NN_BRUTE);
+// ALL = false: only the queries the grid kernel could not certify (fallback list).
+template <bool ALL>
+__global__ __launch_bounds__(kNnThreads) void nn_brute(IcpDev b) {
+  const int pair = blockIdx.y;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  const int count = ALL ? st->ns : (int)st->unresolved_count;
+  if ((int)(blockIdx.x * kNnThreads) >= count) return;
+  __shared__ float4 s_t[kBruteTile];
+  __shared__ uint32_t s_hist[kHistBins];
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+  const size_t so = (size_t)pair * b.ns_cap;
+  const int e = blockIdx.x * kNnThreads + threadIdx.x;
+  const bool active = e < count;
+  const int i = active ? (ALL ? e : b.ulist[so + e]) : 0;
+  float qx = 0, qy = 0, qz = 0;
+  Best best = {INFINITY, -1, 0x7fffffff};
+  bool valid = false;
+  if (active) {
+    double px, py, pz;
+    transform_point(st->M, b.src[so + i], px, py, pz);
+    qx = (float)px; qy = (float)py; qz = (float)pz;
+    valid = isfinite(qx) && isfinite(qy) && isfinite(qz);
+  }
+  const float4* tq = b.tq + (size_t)pair * b.nt_cap;
+  const int nt = st->nt;
+  for (int base = 0; base < nt; base += kBruteTile) {
+    const int m = min(kBruteTile, nt - base);
+    for (int k = threadIdx.x; k < m; k += kNnThreads) s_t[k] = tq[base + k];
+    __syncthreads();
+    if (valid) {
+#pragma unroll 4
+      for (int k = 0; k < m; ++k) test_candidate(s_t[k], base + k, qx, qy, qz, best);
+    }
+    __syncthreads();
+  }
+  if (active) {
+    b.d2[so + i] = best.d2;
+    b.idx[so + i] = best.j;
+    const uint32_t key = __float_as_uint(best.d2);
+    if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
+  }
+  __syncthreads();
+  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
+    const uint32_t v = s_hist[k];
+    if (v) atomicAdd(&gh[k], v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2/K3: quantile bin + point-to-plane accumulation
+// ------------------------------------------------------------------------------------------
+// rank of the quantile element: values.size() * quantile truncated (icp_fast.cc:86); quantile == 1
+// takes the maximum (:82-84), i.e. rank n-1.
+__device__ __forceinline__ int quantile_rank(uint32_t n_valid, float rho) {
+  const double q = (double)rho;
+  if (q >= 1.0) return (int)n_valid - 1;
+  int k = (int)((double)n_valid * q);
+  return min(k, (int)n_valid - 1);
+}
+
+// Finds the level-1 histogram bin holding the rank-k element.  All threads of a 256-thread block
+// call it; results land in shared memory: s_out[0] = bin, s_out[1] = #elements below the bin,
+// s_out[2] = n_valid, s_out[3] = k.
+__device__ __forceinline__ void find_quantile_bin(const uint32_t* __restrict__ gh, float rho, uint32_t* s_w, uint32_t* s_out) {
+  constexpr int per = kHistBins / 256;
+  uint32_t c[per];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < per; ++k) { c[k] = gh[threadIdx.x * per + k]; sum += c[k]; }
+  uint32_t total;
+  const uint32_t excl = block_excl_scan(sum, s_w, &total);
+  if (threadIdx.x == 0) { s_out[0] = 0xffffffffu; s_out[1] = 0; s_out[2] = total; s_out[3] = 0; }
+  __syncthreads();
+  if (total > 0) {
+    const uint32_t k = (uint32_t)quantile_rank(total, rho);
+    if (excl <= k && k < excl + sum) {
+      uint32_t run = excl;
+#pragma unroll
+      for (int t = 0; t < per; ++t) {
+        if (k < run + c[t]) { s_out[0] = threadIdx.x * per + t; s_out[1] = run; s_out[3] = k; break; }
+        run += c[t];
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// J = [p x n ; n], r = (p - q) . n ; acc += upper(J J^T), J r, sqrt(d2), 1     (icp_fast.cc:182-202, 256-303)
+__device__ __forceinline__ void accumulate_pair(const IcpDev& b, const PairState* st, int pair, int i, float d2v, double* acc) {
+  const size_t so = (size_t)pair * b.ns_cap, to = (size_t)pair * b.nt_cap;
+  double px, py, pz;
+  transform_point(st->M, b.src[so + i], px, py, pz);
+  const int j = b.idx[so + i];
+  const float4 q4 = b.tq[to + j];
+  const float4 n4 = b.tn[to + j];
+  const double nx = n4.x, ny = n4.y, nz = n4.z;
+  double J[6];
+  J[0] = py * nz - pz * ny;
+  J[1] = pz * nx - px * nz;
+  J[2] = px * ny - py * nx;
+  J[3] = nx; J[4] = ny; J[5] = nz;
+  const double r = (px - (double)q4.x) * nx + (py - (double)q4.y) * ny + (pz - (double)q4.z) * nz;
+  int c = 0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int e = a; e < 6; ++e) acc[c++] += J[a] * J[e];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;     // b = -sum(J r): sign applied at solve time
+  acc[27] += sqrt((double)d2v);
+  acc[28] += 1.0;
+}
+
+// Block reduction of kAccCols-3 = 29 doubles; thread 0 ends up with the totals in acc[].
+__device__ __forceinline__ void block_reduce29(double* acc, double (*s_red)[29]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 29; ++c) acc[c] = wave_sum(acc[c]);
+  if (lane == 0)
+#pragma unroll
+    for (int c = 0; c < 29; ++c) s_red[wave][c] = acc[c];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nwave = blockDim.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 29; ++c) {
+      double s = 0;
+      for (int w = 0; w < nwave; ++w) s += s_red[w][c];
+      acc[c] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b) {
+  const int pair = blockIdx.y;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  const int ns = st->ns;
+  const int base = blockIdx.x * kAccChunk;
+  if (base >= ns) return;
+  __shared__ uint32_t s_w[17];
+  __shared__ uint32_t s_q[4];
+  __shared__ double s_red[4][29];
+  find_quantile_bin(b.hist + (size_t)pair * kHistBins, b.rho, s_w, s_q);
+  const uint32_t qbin = s_q[0];
+  double acc[29];
+#pragma unroll
+  for (int c = 0; c < 29; ++c) acc[c] = 0.0;
+  const size_t so = (size_t)pair * b.ns_cap;
+#pragma unroll 1
+  for (int it = 0; it < kAccItems; ++it) {
+    const int i = base + it * kAccThreads + threadIdx.x;
+    if (i < ns) {
+      const float d = b.d2[so + i];
+      const uint32_t key = __float_as_uint(d);
+      if (key < 0x7f800000u) {
+        const uint32_t bin = key >> kHistShift;
+        if (bin < qbin) {
+          accumulate_pair(b, st, pair, i, d, acc);
+        } else if (bin == qbin) {
+          const uint32_t pos = atomicAdd(&st->blist_count, 1u);
+          b.blist[so + pos] = i;
+        }
+      }
+    }
+  }
+  block_reduce29(acc, s_red);
+  if (threadIdx.x == 0) {
+    double* out = b.partials + ((size_t)pair * b.acc_blocks + blockIdx.x) * kAccCols;
+#pragma unroll
+    for (int c = 0; c < 29; ++c) out[c] = acc[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: exact quantile, solve, update, convergence
+// ------------------------------------------------------------------------------------------
+__device__ void jacobi_eig6(double* A, double* V, double* w) {
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) V[6 * i + j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0;
+    for (int i = 0; i < 6; ++i) for (int j = i + 1; j < 6; ++j) off += A[6 * i + j] * A[6 * i + j];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 6; ++p)
+      for (int q = p + 1; q < 6; ++q) {
+        const double apq = A[6 * p + q];
+        if (fabs(apq) < 1e-300) continue;
+        const double theta = (A[6 * q + q] - A[6 * p + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 6; ++k) { const double akp = A[6 * k + p], akq = A[6 * k + q]; A[6 * k + p] = c * akp - s * akq; A[6 * k + q] = s * akp + c * akq; }
+        for (int k = 0; k < 6; ++k) { const double apk = A[6 * p + k], aqk = A[6 * q + k]; A[6 * p + k] = c * apk - s * aqk; A[6 * q + k] = s * apk + c * aqk; }
+        for (int k = 0; k < 6; ++k) { const double vkp = V[6 * k + p], vkq = V[6 * k + q]; V[6 * k + p] = c * vkp - s * vkq; V[6 * k + q] = s * vkp + c * vkq; }
+      }
+  }
+  for (int i = 0; i < 6; ++i) w[i] = A[6 * i + i];
+}
+
+// SolvePossiblyUnderdeterminedLinearSystem (icp_fast.cc:204-254): Cholesky when A is numerically
+// invertible, otherwise the minimum-norm solution of the rank-reduced system (pseudo-inverse).
+__device__ void solve6(const double* A, const double* rhs, double* x) {
+  double L[36];
+  for (int i = 0; i < 36; ++i) L[i] = 0;
+  double dmax = 0;
+  for (int i = 0; i < 6; ++i) dmax = fmax(dmax, fabs(A[6 * i + i]));
+  bool ok = dmax > 0 && isfinite(dmax);
+  for (int i = 0; i < 6 && ok; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = A[6 * i + j];
+      for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
+      if (i == j) {
+        if (!(s > 1e-13 * dmax)) { ok = false; break; }
+        L[6 * i + i] = sqrt(s);
+      } else {
+        L[6 * i + j] = s / L[6 * j + j];
+      }
+    }
+  if (ok) {
+    double y[6];
+    for (int i = 0; i < 6; ++i) { double s = rhs[i]; for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k]; y[i] = s / L[6 * i + i]; }
+    for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k]; x[i] = s / L[6 * i + i]; }
+    return;
+  }
+  double E[36], V[36], w[6];
+  for (int i = 0; i < 36; ++i) E[i] = A[i];
+  jacobi_eig6(E, V, w);
+  double wmax = 0;
+  for (int i = 0; i < 6; ++i) wmax = fmax(wmax, fabs(w[i]));
+  const double thresh = 2.220446049250313e-16 * 6 * wmax;
+  for (int i = 0; i < 6; ++i) x[i] = 0;
+  for (int k = 0; k < 6; ++k) {
+    if (!(fabs(w[k]) > thresh)) continue;
+    double c = 0;
+    for (int i = 0; i < 6; ++i) c += V[6 * i + k] * rhs[i];
+    c /= w[k];
+    for (int i = 0; i < 6; ++i) x[i] += c * V[6 * i + k];
+  }
+}
+
+__device__ void quat_from_rot(const double* T, double* q) {   // Eigen::Quaterniond(Matrix3d), T row-major 4x4
+  const double r00 = T[0], r01 = T[1], r02 = T[2], r10 = T[4], r11 = T[5], r12 = T[6], r20 = T[8], r21 = T[9], r22 = T[10];
+  const double tr = r00 + r11 + r22;
+  if (tr > 0) {
+    const double s = sqrt(tr + 1.0) * 2;
+    q[0] = 0.25 * s; q[1] = (r21 - r12) / s; q[2] = (r02 - r20) / s; q[3] = (r10 - r01) / s;
+  } else if (r00 >= r11 && r00 >= r22) {
+    const double s = sqrt(1.0 + r00 - r11 - r22) * 2;
+    q[0] = (r21 - r12) / s; q[1] = 0.25 * s; q[2] = (r01 + r10) / s; q[3] = (r02 + r20) / s;
+  } else if (r11 >= r22) {
+    const double s = sqrt(1.0 + r11 - r00 - r22) * 2;
+    q[0] = (r02 - r20) / s; q[1] = (r01 + r10) / s; q[2] = 0.25 * s; q[3] = (r12 + r21) / s;
+  } else {
+    const double s = sqrt(1.0 + r22 - r00 - r11) * 2;
+    q[0] = (r10 - r01) / s; q[1] = (r02 + r20) / s; q[2] = (r12 + r21) / s; q[3] = 0.25 * s;
+  }
+}
+
+__device__ double quat_angular_distance(const double* a, const double* c) {
+  const double w = a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3];
+  const double x = -a[0] * c[1] + a[1] * c[0] - a[2] * c[3] + a[3] * c[2];
+  const double y = -a[0] * c[2] + a[2] * c[0] - a[3] * c[1] + a[1] * c[3];
+  const double z = -a[0] * c[3] + a[3] * c[0] - a[1] * c[2] + a[2] * c[1];
+  return 2.0 * atan2(sqrt(x * x + y * y + z * z), fabs(w));
+}
+
+__global__ __launch_bounds__(256) void finalize(IcpDev b) {
+  const int pair = blockIdx.x;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  __shared__ uint32_t s_w[17];
+  __shared__ uint32_t s_q[4];
+  __shared__ uint32_t s_h[256];
+  __shared__ uint32_t s_sel[2];
+  __shared__ double s_red[4][29];
+  __shared__ double s_tot[29];
+  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
+  find_quantile_bin(gh, b.rho, s_w, s_q);
+  const uint32_t qbin = s_q[0], below = s_q[1], n_valid = s_q[2], krank = s_q[3];
+  const size_t so = (size_t)pair * b.ns_cap;
+  const int nb = (int)st->blist_count;
+  const int ns = st->ns;
+  double acc[29];
+#pragma unroll
+  for (int c = 0; c < 29; ++c) acc[c] = 0.0;
+  uint32_t limit_key = 0;
+  if (n_valid > 0) {
+    // exact rank (krank - below) inside the boundary bin: radix select on the low 20 key bits
+    uint32_t rank = krank - below;
+    uint32_t prefix = 0, mask = 0;
+    const int shifts[3] = {12, 4, 0};
+    const int widths[3] = {8, 8, 4};
+    for (int pass = 0; pass < 3; ++pass) {
+      const int shift = shifts[pass];
+      const uint32_t nd = 1u << widths[pass];
+      s_h[threadIdx.x] = 0;
+      __syncthreads();
+      for (int e = threadIdx.x; e < nb; e += blockDim.x) {
+        const uint32_t key = __float_as_uint(b.d2[so + b.blist[so + e]]) & 0xfffffu;
+        if ((key & mask) == prefix) atomicAdd(&s_h[(key >> shift) & (nd - 1u)], 1u);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t run = 0, d = 0;
+        for (; d < nd; ++d) { if (rank < run + s_h[d]) break; run += s_h[d]; }
+        if (d >= nd) d = nd - 1;
+        s_sel[0] = d; s_sel[1] = run;
+      }
+      __syncthreads();
+      prefix |= s_sel[0] << shift;
+      mask |= (nd - 1u) << shift;
+      rank -= s_sel[1];
+      __syncthreads();
+    }
+    limit_key = (qbin << kHistShift) | prefix;
+    // weights = (d2 <= limit)  (icp_fast.cc:497-498) for the boundary-bin entries
+    for (int e = threadIdx.x; e < nb; e += blockDim.x) {
+      const int i = b.blist[so + e];
+      const float d = b.d2[so + i];
+      if (__float_as_uint(d) <= limit_key) accumulate_pair(b, st, pair, i, d, acc);
+    }
+  }
+  block_reduce29(acc, s_red);
+  if (threadIdx.x == 0)
+    for (int c = 0; c < 29; ++c) s_tot[c] = acc[c];
+  __syncthreads();
+  // add the per-block partial sums of the accumulate kernel in a fixed order
+  const int nblk = (ns + kAccChunk - 1) / kAccChunk;
+  if (threadIdx.x < 29) {
+    double s = s_tot[threadIdx.x];
+    const double* part = b.partials + (size_t)pair * b.acc_blocks * kAccCols + threadIdx.x;
+    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * kAccCols];
+    s_tot[threadIdx.x] = s;
+  }
+  // reset the per-iteration scratch for the next iteration
+  for (int k = threadIdx.x; k < kHistBins; k += blockDim.x) gh[k] = 0;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+
+  st->fallback_total += st->unresolved_count;
+  st->unresolved_count = 0;
+  st->blist_count = 0;
+  st->limit_key = limit_key;
+  const double kept = s_tot[28];
+  st->kept = (int)kept;
+  if (n_valid == 0 || kept < 1.0) {       // icp_fast.cc:81 CHECK(!values.empty()) / :113 "no point to minimize"
+    st->status = 6;                        // SMHIP_ERR_NO_MATCH
+    st->done = 1;
+    for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) st->result[4 * c + r] = st->guess[4 * r + c];
+    st->score = 0;
+    atomicAdd(b.done_count, 1u);
+    return;
+  }
+  double A[36], rhs[6], x[6];
+  {
+    int c = 0;
+    for (int a = 0; a < 6; ++a)
+      for (int e = a; e < 6; ++e) { A[6 * a + e] = s_tot[c]; A[6 * e + a] = s_tot[c]; ++c; }
+    for (int a = 0; a < 6; ++a) rhs[a] = -s_tot[21 + a];                       // b = -(wF * dot), :302
+  }
+  solve6(A, rhs, x);                                                          // :304
+  // transform = AngleAxis(|x[0:3]|, x[0:3] / |x[0:3]|), translation = x[3:6]    :306-312
+  double dT[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  {
+    const double ang = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    const double ax = x[0] / ang, ay = x[1] / ang, az = x[2] / ang;
+    const double c = cos(ang), s = sin(ang), v = 1.0 - c;
+    double R[9] = {c + v * ax * ax, v * ax * ay - s * az, v * ax * az + s * ay,
+                   v * ax * ay + s * az, c + v * ay * ay, v * ay * az - s * ax,
+                   v * ax * az - s * ay, v * ay * az + s * ax, c + v * az * az};
+    bool has_nan = false;
+    for (int i = 0; i < 9; ++i) has_nan |= isnan(R[i]);
+    for (int i = 0; i < 3; ++i) has_nan |= isnan(x[3 + i]);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) dT[4 * i + j] = has_nan ? ((i == j) ? 1.0 : 0.0) : R[3 * i + j];   // :315-321
+    dT[3] = x[3]; dT[7] = x[4]; dT[11] = x[5];
+  }
+  double Tn[16];
+  mat4_mul_rm(dT, st->T_iter, Tn);                                            // :506-510
+  for (int i = 0; i < 16; ++i) st->T_iter[i] = Tn[i];
+  double Mn[16];
+  mat4_mul_rm(Tn, st->G, Mn);
+  for (int i = 0; i < 12; ++i) st->M[i] = Mn[i];
+  const int it = ++st->iter;                                                  // :513
+  // history ring (latest at n_hist-1, at most 5 kept)
+  int nh = st->n_hist;
+  if (nh == 5) {
+    for (int k = 0; k < 4; ++k) {
+      for (int c = 0; c < 4; ++c) st->quat[k][c] = st->quat[k + 1][c];
+      for (int c = 0; c < 3; ++c) st->trans[k][c] = st->trans[k + 1][c];
+    }
+    nh = 4;
+  }
+  quat_from_rot(Tn, st->quat[nh]);
+  st->trans[nh][0] = Tn[3]; st->trans[nh][1] = Tn[7]; st->trans[nh][2] = Tn[11];
+  st->n_hist = ++nh;
+  bool converged = false;
+  if (b.early_exit && nh > 4) {                                               // :377-405 (kSmoothLength = 4)
+    double rd = 0, td = 0;
+    for (int k = nh - 1; k >= nh - 4; --k) {
+      rd += fabs(quat_angular_distance(st->quat[k], st->quat[k - 1]));
+      const double dx = st->trans[k][0] - st->trans[k - 1][0], dy = st->trans[k][1] - st->trans[k - 1][1], dz = st->trans[k][2] - st->trans[k - 1][2];
+      td += sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    converged = (rd / 4 < 1e-3) && (td / 4 < 1e-2);
+  }
+  if (converged || it >= b.max_iteration) {                                   // :516-522
+    st->score = exp(-s_tot[27] / kept);
+    // result = T_mean * T_iter * T_mean^-1 * guess  (:527), written column-major
+    double Tm[16] = {1, 0, 0, st->mu[0], 0, 1, 0, st->mu[1], 0, 0, 1, st->mu[2], 0, 0, 0, 1};
+    double Rm[16];
+    mat4_mul_rm(Tm, Mn, Rm);
+    for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) st->result[4 * c + r] = Rm[4 * r + c];
+    st->done = 1;
+    atomicAdd(b.done_count, 1u);
+  }
+}
+
+// Slot-to-slot copy of the uploaded clouds (benchmark replication).
+__global__ void copy_slot(IcpDev b, float4* src, float4* tp, float4* tn, int from, int to) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < b.ns_cap) src[(size_t)to * b.ns_cap + i] = src[(size_t)from * b.ns_cap + i];
+  if (i < b.nt_cap) {
+    tp[(size_t)to * b.nt_cap + i] = tp[(size_t)from * b.nt_cap + i];
+    tn[(size_t)to * b.nt_cap + i] = tn[(size_t)from * b.nt_cap + i];
+  }
+}
+
+}  // namespace smhip

@@ -1,0 +1,549 @@
+// smhip_api.hip -- host side of the C ABI declared in include/smhip.h.
+//
+// One smhip_context = one matcher instance in the sense of
+// static_map::registrator::Interface (/root/reference/registrators/interface.h:67-116):
+// it owns a stream, a device arena sized at creation (no hipMalloc inside Align) and
+// `slots` independent scan pairs.  The IcpFast loop (icp_fast.cc:455-529) stays resident on
+// the device; the host only enqueues launches and, when early exit is on, polls one word
+// every `check_every` iterations.
+#include "icp_kernels.hip"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/smhip.h"
+
+using namespace smhip;
+
+struct smhip_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  IcpDev dev{};
+  smhip_icp_options opts{};
+  std::vector<int> ns, nt, has_normals;
+  PairInput* in_pinned = nullptr;
+  PairState* state_pinned = nullptr;
+  float4* stage = nullptr;       // pinned staging for uploads, 2 * max(ns_cap, nt_cap)
+  uint32_t* done_pinned = nullptr;
+  int32_t* ids_pinned = nullptr;
+  float* d2_pinned = nullptr;
+  int32_t* ids_dev = nullptr;    // scratch for exported matches
+  std::vector<void*> allocs;
+  std::string err;
+  int last_npairs = 0;
+  // profiling
+  bool profile = false;
+  struct Ev { hipEvent_t a, b; int cat; };
+  std::vector<Ev> ev_pool;
+  size_t ev_used = 0;
+  smhip_icp_profile prof{};
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+#define HIPCHK(h, expr)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                       \
+      return SMHIP_ERR_HIP;                                                               \
+    }                                                                                     \
+  } while (0)
+
+template <typename T>
+smhip_status dev_alloc(smhip_context* h, T** p, size_t count) {
+  void* v = nullptr;
+  HIPCHK(h, hipMalloc(&v, count * sizeof(T)));
+  h->allocs.push_back(v);
+  *p = reinterpret_cast<T*>(v);
+  return SMHIP_OK;
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// profiling brackets: category 0 prepare, 1 find_closests, 2 error_elements, 3 solve
+struct Bracket {
+  smhip_context* h;
+  smhip_context::Ev* ev = nullptr;
+  Bracket(smhip_context* h_, int cat) : h(h_) {
+    if (!h->profile) return;
+    if (h->ev_used == h->ev_pool.size()) {
+      smhip_context::Ev e{};
+      if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+      h->ev_pool.push_back(e);
+    }
+    ev = &h->ev_pool[h->ev_used++];
+    ev->cat = cat;
+    (void)hipEventRecord(ev->a, h->stream);
+  }
+  ~Bracket() {
+    if (ev) (void)hipEventRecord(ev->b, h->stream);
+  }
+};
+
+void collect_profile(smhip_context* h) {
+  if (!h->profile) return;
+  for (size_t k = 0; k < h->ev_used; ++k) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, h->ev_pool[k].a, h->ev_pool[k].b) != hipSuccess) continue;
+    switch (h->ev_pool[k].cat) {
+      case 0: h->prof.ms_prepare += ms; break;
+      case 1: h->prof.ms_find_closests += ms; h->prof.launches_find_closests++; break;
+      case 2: h->prof.ms_error_elements += ms; h->prof.launches_error_elements++; break;
+      case 3: h->prof.ms_solve += ms; h->prof.launches_solve++; break;
+    }
+  }
+  h->ev_used = 0;
+}
+
+smhip_status check_slot(smhip_context* h, int slot) {
+  if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
+  if (slot < 0 || slot >= h->dev.slots) { h->err = "slot out of range"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  return SMHIP_OK;
+}
+
+// target centring + search-structure build for pairs [0, np)
+smhip_status enqueue_prepare(smhip_context* h, int np, int nt_max) {
+  IcpDev& d = h->dev;
+  Bracket br(h, 0);
+  HIPCHK(h, hipMemcpyAsync(const_cast<PairInput*>(d.in), h->in_pinned, sizeof(PairInput) * np, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemsetAsync(d.bits, 0, sizeof(uint32_t) * (size_t)kMaxGridWords * np, h->stream));
+  HIPCHK(h, hipMemsetAsync(d.ccount, 0, sizeof(uint32_t) * (size_t)(d.nt_cap + 1) * np, h->stream));
+  HIPCHK(h, hipMemsetAsync(d.hist, 0, sizeof(uint32_t) * (size_t)kHistBins * np, h->stream));
+  HIPCHK(h, hipMemsetAsync(d.done_count, 0, sizeof(uint32_t), h->stream));
+  const dim3 gpts(ceil_div(nt_max, 256), np);
+  hipLaunchKernelGGL(tgt_reduce, dim3(kTgtReduceBlocks, np), dim3(256), 0, h->stream, d);
+  hipLaunchKernelGGL(grid_setup, dim3(ceil_div(np, 64)), dim3(64), 0, h->stream, d, np);
+  hipLaunchKernelGGL(grid_mark, gpts, dim3(256), 0, h->stream, d);
+  hipLaunchKernelGGL(grid_rank, dim3(np), dim3(1024), 0, h->stream, d);
+  hipLaunchKernelGGL(grid_count, gpts, dim3(256), 0, h->stream, d);
+  hipLaunchKernelGGL(grid_cscan, dim3(np), dim3(1024), 0, h->stream, d);
+  hipLaunchKernelGGL(grid_scatter, gpts, dim3(256), 0, h->stream, d);
+  HIPCHK(h, hipGetLastError());
+  return SMHIP_OK;
+}
+
+smhip_status enqueue_find_closests(smhip_context* h, int np, int ns_max) {
+  IcpDev& d = h->dev;
+  const dim3 g(ceil_div(ns_max, kNnThreads), np);
+  if (h->opts.nn_mode == SMHIP_NN_GRID) {
+    { Bracket br(h, 1); hipLaunchKernelGGL(nn_grid, g, dim3(kNnThreads), 0, h->stream, d); }
+    { Bracket br(h, 1); hipLaunchKernelGGL(nn_brute<false>, g, dim3(kNnThreads), 0, h->stream, d); }
+  } else {
+    Bracket br(h, 1);
+    hipLaunchKernelGGL(nn_brute<true>, g, dim3(kNnThreads), 0, h->stream, d);
+  }
+  return SMHIP_OK;
+}
+
+smhip_status fill_inputs(smhip_context* h, int np, const double* guesses, int* ns_max, int* nt_max) {
+  *ns_max = 0; *nt_max = 0;
+  for (int p = 0; p < np; ++p) {
+    if (h->ns[p] <= 0 || h->nt[p] <= 0) { h->err = "Align before SetInputSource/SetInputTarget"; return SMHIP_ERR_NOT_READY; }
+    if (!h->has_normals[p]) { h->err = "IcpFast target has no normals (icp_fast.cc:430)"; return SMHIP_ERR_NO_NORMALS; }
+    PairInput& in = h->in_pinned[p];
+    const double* g = guesses + 16 * p;
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) in.guess[4 * r + c] = g[4 * c + r];   // column-major in
+    in.ns = h->ns[p]; in.nt = h->nt[p]; in.has_normals = 1; in.pad = 0;
+    *ns_max = std::max(*ns_max, h->ns[p]);
+    *nt_max = std::max(*nt_max, h->nt[p]);
+  }
+  return SMHIP_OK;
+}
+
+void sync_options(smhip_context* h) {
+  h->dev.max_iteration = std::max(1, h->opts.max_iteration);
+  h->dev.early_exit = h->opts.early_exit;
+  h->dev.max_ring = std::max(1, h->opts.grid_max_ring);
+  h->dev.rho = h->opts.dist_outlier_ratio;
+  h->dev.grid_cell = h->opts.grid_cell > 0 ? h->opts.grid_cell : 0.5f;
+}
+
+__global__ void export_matches(IcpDev b, int pair, int32_t* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.state[pair].ns) return;
+  const int j = b.idx[(size_t)pair * b.ns_cap + i];
+  out[i] = j < 0 ? -1 : __float_as_int(b.tq[(size_t)pair * b.nt_cap + j].w);
+}
+
+smhip_status fetch_matches(smhip_context* h, int slot, int32_t* ids, float* d2, int n) {
+  if (n > h->ns[slot]) { h->err = "n exceeds the slot's source size"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  hipLaunchKernelGGL(export_matches, dim3(ceil_div(n, 256)), dim3(256), 0, h->stream, h->dev, slot, h->ids_dev);
+  HIPCHK(h, hipMemcpyAsync(h->ids_pinned, h->ids_dev, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d2_pinned, h->dev.d2 + (size_t)slot * h->dev.ns_cap, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (ids) std::memcpy(ids, h->ids_pinned, sizeof(int32_t) * n);
+  if (d2) std::memcpy(d2, h->d2_pinned, sizeof(float) * n);
+  return SMHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smhip_version(void) { return 100; }
+
+const char* smhip_status_string(smhip_status s) {
+  switch (s) {
+    case SMHIP_OK: return "ok";
+    case SMHIP_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case SMHIP_ERR_NO_DEVICE: return "no gfx950 device";
+    case SMHIP_ERR_HIP: return "HIP runtime error";
+    case SMHIP_ERR_NOT_READY: return "source/target not set";
+    case SMHIP_ERR_NO_NORMALS: return "target has no normals";
+    case SMHIP_ERR_NO_MATCH: return "no finite correspondence";
+    case SMHIP_ERR_CAPACITY: return "cloud exceeds handle capacity";
+    default: return "unknown";
+  }
+}
+
+int smhip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+  int good = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ++good;
+  }
+  return good;
+}
+
+void smhip_icp_default_options(smhip_icp_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->max_iteration = 100;          // icp_fast.h:58
+  o->dist_outlier_ratio = 0.7f;    // icp_fast.h:59
+  o->early_exit = 1;
+  o->nn_mode = SMHIP_NN_GRID;
+  o->grid_cell = 0.5f;
+  o->grid_max_ring = 4;
+  o->check_every = 8;
+}
+
+smhip_status smhip_create(int device, void* stream, int pair_slots, int max_source_points, int max_target_points,
+                          smhip_handle* out) {
+  if (!out || pair_slots < 1 || max_source_points < 1 || max_target_points < 1) return SMHIP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SMHIP_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SMHIP_ERR_NO_DEVICE;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SMHIP_ERR_NO_DEVICE;   // gfx950-only code objects
+  if (hipSetDevice(device) != hipSuccess) return SMHIP_ERR_NO_DEVICE;
+  smhip_context* h = new smhip_context();
+  h->device = device;
+  if (stream) { h->stream = reinterpret_cast<hipStream_t>(stream); h->own_stream = false; }
+  else {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return SMHIP_ERR_HIP; }
+    h->own_stream = true;
+  }
+  smhip_icp_default_options(&h->opts);
+  IcpDev& d = h->dev;
+  d.slots = pair_slots; d.ns_cap = max_source_points; d.nt_cap = max_target_points;
+  d.acc_blocks = ceil_div(max_source_points, kAccChunk);
+  const size_t B = pair_slots, NS = max_source_points, NT = max_target_points;
+  smhip_status s = SMHIP_OK;
+  auto A = [&](smhip_status r) { if (s == SMHIP_OK) s = r; };
+  A(dev_alloc(h, &d.state, B));
+  A(dev_alloc(h, const_cast<PairInput**>(&d.in), B));
+  A(dev_alloc(h, const_cast<float4**>(&d.src), B * NS));
+  A(dev_alloc(h, const_cast<float4**>(&d.tgt_p), B * NT));
+  A(dev_alloc(h, const_cast<float4**>(&d.tgt_n), B * NT));
+  A(dev_alloc(h, &d.tq, B * NT));
+  A(dev_alloc(h, &d.tn, B * NT));
+  A(dev_alloc(h, &d.tcell, B * NT));
+  A(dev_alloc(h, &d.tslot, B * NT));
+  A(dev_alloc(h, &d.tord, B * NT));
+  A(dev_alloc(h, &d.bits, B * kMaxGridWords));
+  A(dev_alloc(h, &d.words, B * kMaxGridWords));
+  A(dev_alloc(h, &d.ccount, B * (NT + 1)));
+  A(dev_alloc(h, &d.cstart, B * (NT + 1)));
+  A(dev_alloc(h, &d.d2, B * NS));
+  A(dev_alloc(h, &d.idx, B * NS));
+  A(dev_alloc(h, &d.hist, B * kHistBins));
+  A(dev_alloc(h, &d.ulist, B * NS));
+  A(dev_alloc(h, &d.blist, B * NS));
+  A(dev_alloc(h, &d.partials, B * d.acc_blocks * kAccCols));
+  A(dev_alloc(h, &d.tpart, B * kTgtReduceBlocks * 16));
+  A(dev_alloc(h, &d.done_count, 4));
+  A(dev_alloc(h, &h->ids_dev, NS));
+  if (s == SMHIP_OK) {
+    const size_t stage_n = 2 * std::max(NS, NT);
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->stage), stage_n * sizeof(float4)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h->in_pinned), B * sizeof(PairInput)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h->state_pinned), B * sizeof(PairState)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h->done_pinned), 64) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h->ids_pinned), NS * sizeof(int32_t)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h->d2_pinned), NS * sizeof(float)) != hipSuccess)
+      s = SMHIP_ERR_HIP;
+  }
+  if (s == SMHIP_OK && hipMemsetAsync(d.state, 0, B * sizeof(PairState), h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
+  if (s == SMHIP_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
+  if (s != SMHIP_OK) { smhip_destroy(h); return s; }
+  h->ns.assign(B, 0); h->nt.assign(B, 0); h->has_normals.assign(B, 0);
+  sync_options(h);
+  *out = h;
+  return SMHIP_OK;
+}
+
+smhip_status smhip_destroy(smhip_handle h) {
+  if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->stage) (void)hipHostFree(h->stage);
+  if (h->in_pinned) (void)hipHostFree(h->in_pinned);
+  if (h->state_pinned) (void)hipHostFree(h->state_pinned);
+  if (h->done_pinned) (void)hipHostFree(h->done_pinned);
+  if (h->ids_pinned) (void)hipHostFree(h->ids_pinned);
+  if (h->d2_pinned) (void)hipHostFree(h->d2_pinned);
+  for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return SMHIP_OK;
+}
+
+const char* smhip_last_error(smhip_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+smhip_status smhip_icp_set_options(smhip_handle h, const smhip_icp_options* o) {
+  if (!h || !o) return SMHIP_ERR_INVALID_ARGUMENT;
+  if (!(o->dist_outlier_ratio >= 0.f && o->dist_outlier_ratio <= 1.f)) {     // icp_fast.cc:68 CHECK
+    h->err = "dist_outlier_ratio must be in [0, 1]";
+    return SMHIP_ERR_INVALID_ARGUMENT;
+  }
+  if (o->nn_mode != SMHIP_NN_BRUTE && o->nn_mode != SMHIP_NN_GRID) { h->err = "bad nn_mode"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  h->opts = *o;
+  if (h->opts.check_every < 1) h->opts.check_every = 8;
+  sync_options(h);
+  return SMHIP_OK;
+}
+
+smhip_status smhip_synchronize(smhip_handle h) {
+  if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SMHIP_OK;
+}
+
+// ---- uploads ---------------------------------------------------------------------------
+static smhip_status upload(smhip_handle h, const float4* dst_dev, const float4* staged, int n) {
+  HIPCHK(h, hipMemcpyAsync(const_cast<float4*>(dst_dev), staged, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  return SMHIP_OK;
+}
+
+smhip_status smhip_set_source_f64(smhip_handle h, int slot, const double* xyz, int n) {
+  smhip_status s = check_slot(h, slot);
+  if (s) return s;
+  if (!xyz || n <= 0) { h->err = "empty source cloud"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  if (n > h->dev.ns_cap) { h->err = "source larger than max_source_points"; return SMHIP_ERR_CAPACITY; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));   // staging buffer reuse
+  for (int i = 0; i < n; ++i) h->stage[i] = make_float4((float)xyz[3 * i], (float)xyz[3 * i + 1], (float)xyz[3 * i + 2], 0.f);
+  s = upload(h, h->dev.src + (size_t)slot * h->dev.ns_cap, h->stage, n);
+  if (s) return s;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->ns[slot] = n;
+  return SMHIP_OK;
+}
+
+smhip_status smhip_set_source_f32(smhip_handle h, int slot, const float* xyz, int stride, int n) {
+  smhip_status s = check_slot(h, slot);
+  if (s) return s;
+  if (!xyz || n <= 0 || stride < 3) { h->err = "empty source cloud / bad stride"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  if (n > h->dev.ns_cap) { h->err = "source larger than max_source_points"; return SMHIP_ERR_CAPACITY; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < n; ++i) h->stage[i] = make_float4(xyz[(size_t)stride * i], xyz[(size_t)stride * i + 1], xyz[(size_t)stride * i + 2], 0.f);
+  s = upload(h, h->dev.src + (size_t)slot * h->dev.ns_cap, h->stage, n);
+  if (s) return s;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->ns[slot] = n;
+  return SMHIP_OK;
+}
+
+smhip_status smhip_set_target_f64(smhip_handle h, int slot, const double* xyz, const double* nrm, int n) {
+  smhip_status s = check_slot(h, slot);
+  if (s) return s;
+  if (!xyz || n <= 0) { h->err = "empty target cloud"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  if (n > h->dev.nt_cap) { h->err = "target larger than max_target_points"; return SMHIP_ERR_CAPACITY; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  float4* sp = h->stage;
+  float4* sn = h->stage + std::max(h->dev.ns_cap, h->dev.nt_cap);
+  for (int i = 0; i < n; ++i) {
+    sp[i] = make_float4((float)xyz[3 * i], (float)xyz[3 * i + 1], (float)xyz[3 * i + 2], 0.f);
+    sn[i] = nrm ? make_float4((float)nrm[3 * i], (float)nrm[3 * i + 1], (float)nrm[3 * i + 2], 0.f) : make_float4(0, 0, 0, 0);
+  }
+  s = upload(h, h->dev.tgt_p + (size_t)slot * h->dev.nt_cap, sp, n);
+  if (s) return s;
+  s = upload(h, h->dev.tgt_n + (size_t)slot * h->dev.nt_cap, sn, n);
+  if (s) return s;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->nt[slot] = n;
+  h->has_normals[slot] = nrm != nullptr;
+  return SMHIP_OK;
+}
+
+smhip_status smhip_set_target_f32(smhip_handle h, int slot, const float* xyz, int stride, const float* nrm, int nstride, int n) {
+  smhip_status s = check_slot(h, slot);
+  if (s) return s;
+  if (!xyz || n <= 0 || stride < 3 || (nrm && nstride < 3)) { h->err = "empty target cloud / bad stride"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  if (n > h->dev.nt_cap) { h->err = "target larger than max_target_points"; return SMHIP_ERR_CAPACITY; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  float4* sp = h->stage;
+  float4* sn = h->stage + std::max(h->dev.ns_cap, h->dev.nt_cap);
+  for (int i = 0; i < n; ++i) {
+    sp[i] = make_float4(xyz[(size_t)stride * i], xyz[(size_t)stride * i + 1], xyz[(size_t)stride * i + 2], 0.f);
+    sn[i] = nrm ? make_float4(nrm[(size_t)nstride * i], nrm[(size_t)nstride * i + 1], nrm[(size_t)nstride * i + 2], 0.f) : make_float4(0, 0, 0, 0);
+  }
+  s = upload(h, h->dev.tgt_p + (size_t)slot * h->dev.nt_cap, sp, n);
+  if (s) return s;
+  s = upload(h, h->dev.tgt_n + (size_t)slot * h->dev.nt_cap, sn, n);
+  if (s) return s;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->nt[slot] = n;
+  h->has_normals[slot] = nrm != nullptr;
+  return SMHIP_OK;
+}
+
+smhip_status smhip_copy_slot(smhip_handle h, int from, int to) {
+  smhip_status s = check_slot(h, from);
+  if (s) return s;
+  s = check_slot(h, to);
+  if (s) return s;
+  if (from == to) return SMHIP_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  IcpDev& d = h->dev;
+  hipLaunchKernelGGL(copy_slot, dim3(ceil_div(std::max(d.ns_cap, d.nt_cap), 256)), dim3(256), 0, h->stream, d,
+                     const_cast<float4*>(d.src), const_cast<float4*>(d.tgt_p), const_cast<float4*>(d.tgt_n), from, to);
+  HIPCHK(h, hipGetLastError());
+  h->ns[to] = h->ns[from]; h->nt[to] = h->nt[from]; h->has_normals[to] = h->has_normals[from];
+  return SMHIP_OK;
+}
+
+// ---- Align -------------------------------------------------------------------------------
+smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* guesses) {
+  if (!h || !guesses || npairs < 1 || npairs > h->dev.slots) {
+    if (h) h->err = "bad npairs / guesses";
+    return SMHIP_ERR_INVALID_ARGUMENT;
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  int ns_max = 0, nt_max = 0;
+  // in_pinned may still be in flight from a previous enqueue on this stream
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  smhip_status s = fill_inputs(h, npairs, guesses, &ns_max, &nt_max);
+  if (s) return s;
+  s = enqueue_prepare(h, npairs, nt_max);
+  if (s) return s;
+  IcpDev& d = h->dev;
+  const int max_it = d.max_iteration;
+  for (int it = 0; it < max_it; ++it) {
+    s = enqueue_find_closests(h, npairs, ns_max);
+    if (s) return s;
+    { Bracket br(h, 2); hipLaunchKernelGGL(accumulate, dim3(ceil_div(ns_max, kAccChunk), npairs), dim3(kAccThreads), 0, h->stream, d); }
+    { Bracket br(h, 3); hipLaunchKernelGGL(finalize, dim3(npairs), dim3(256), 0, h->stream, d); }
+    if (d.early_exit && (it + 1) % h->opts.check_every == 0 && it + 1 < max_it) {
+      HIPCHK(h, hipMemcpyAsync(h->done_pinned, d.done_count, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      if (*h->done_pinned >= (uint32_t)npairs) break;
+    }
+  }
+  HIPCHK(h, hipGetLastError());
+  h->last_npairs = npairs;
+  return SMHIP_OK;
+}
+
+smhip_status smhip_icp_fetch_batch(smhip_handle h, int npairs, double* results, double* scores, smhip_icp_stats* stats) {
+  if (!h || npairs < 1 || npairs > h->dev.slots) return SMHIP_ERR_INVALID_ARGUMENT;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(h->state_pinned, h->dev.state, sizeof(PairState) * npairs, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  collect_profile(h);
+  smhip_status worst = SMHIP_OK;
+  for (int p = 0; p < npairs; ++p) {
+    const PairState& st = h->state_pinned[p];
+    if (results) std::memcpy(results + 16 * p, st.result, sizeof(double) * 16);
+    if (scores) scores[p] = st.score;
+    if (stats) {
+      stats[p].iterations = st.iter;
+      stats[p].kept = st.kept;
+      float lim; uint32_t key = st.limit_key; std::memcpy(&lim, &key, 4);
+      stats[p].limit_d2 = lim;
+      stats[p].fallback_queries = (int32_t)st.fallback_total;
+      stats[p].status = st.status;
+    }
+    if (st.status != SMHIP_OK && worst == SMHIP_OK) { worst = st.status; h->err = "pair failed: no finite correspondence"; }
+    if (!st.done && worst == SMHIP_OK) { worst = SMHIP_ERR_HIP; h->err = "pair did not finish (internal)"; }
+  }
+  return worst;
+}
+
+smhip_status smhip_icp_align_batch(smhip_handle h, int npairs, const double* guesses, double* results, double* scores,
+                                   smhip_icp_stats* stats) {
+  smhip_status s = smhip_icp_enqueue_batch(h, npairs, guesses);
+  if (s) return s;
+  return smhip_icp_fetch_batch(h, npairs, results, scores, stats);
+}
+
+smhip_status smhip_icp_align(smhip_handle h, const double guess[16], double result[16], double* score, smhip_icp_stats* stats) {
+  return smhip_icp_align_batch(h, 1, guess, result, score, stats);
+}
+
+smhip_status smhip_icp_get_matches(smhip_handle h, int slot, int32_t* ids, float* d2, int n) {
+  smhip_status s = check_slot(h, slot);
+  if (s) return s;
+  HIPCHK(h, hipSetDevice(h->device));
+  return fetch_matches(h, slot, ids, d2, n);
+}
+
+smhip_status smhip_icp_find_closests(smhip_handle h, int slot, const double T[16], int32_t* ids, float* d2, int n) {
+  smhip_status s = check_slot(h, slot);
+  if (s) return s;
+  if (!T) return SMHIP_ERR_INVALID_ARGUMENT;
+  if (slot != 0) { h->err = "find_closests works on slot 0"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  int ns_max = 0, nt_max = 0;
+  // normals are irrelevant for the NN pass
+  const int had = h->has_normals[0];
+  h->has_normals[0] = 1;
+  s = fill_inputs(h, 1, T, &ns_max, &nt_max);
+  h->has_normals[0] = had;
+  if (s) return s;
+  s = enqueue_prepare(h, 1, nt_max);
+  if (s) return s;
+  s = enqueue_find_closests(h, 1, ns_max);
+  if (s) return s;
+  s = fetch_matches(h, 0, ids, d2, n);
+  // leave the per-iteration scratch clean
+  HIPCHK(h, hipMemsetAsync(h->dev.hist, 0, sizeof(uint32_t) * kHistBins, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->ev_used = 0;
+  return s;
+}
+
+smhip_status smhip_icp_enable_profile(smhip_handle h, int enable) {
+  if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
+  h->profile = enable != 0;
+  h->prof = smhip_icp_profile{};
+  h->ev_used = 0;
+  return SMHIP_OK;
+}
+
+smhip_status smhip_icp_get_profile(smhip_handle h, smhip_icp_profile* out) {
+  if (!h || !out) return SMHIP_ERR_INVALID_ARGUMENT;
+  *out = h->prof;
+  return SMHIP_OK;
+}
+
+}  // extern "C"

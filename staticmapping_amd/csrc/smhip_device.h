@@ -1,0 +1,100 @@
+// smhip_device.h -- device-side data layout shared by the HIP kernels and the host shim.
+// MI355X / gfx950 only (wave64, 160 KiB LDS, 8 XCDs); no portability layer on purpose.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace smhip {
+
+constexpr int kHistBins = 2048;          // level-1 histogram of d2 keys: float bits >> 20 (8 exp + 3 mantissa bits)
+constexpr int kHistShift = 20;
+constexpr int kNnThreads = 256;          // one query per thread, 4 waves per workgroup
+constexpr int kAccThreads = 256;
+constexpr int kAccItems = 8;             // source points per thread in the accumulate kernel
+constexpr int kAccChunk = kAccThreads * kAccItems;
+constexpr int kAccCols = 32;             // 21 (A upper) + 6 (b) + 1 (sum sqrt d2) + 1 (count) padded to 32
+constexpr int kMaxGridWords = 1 << 16;   // 32-cell words per pair (2 Mi cells)
+constexpr int kTgtReduceBlocks = 32;     // partial blocks for the target mean / bbox
+constexpr int kBruteTile = 1024;         // target points staged in LDS per tile (16 KiB as float4)
+
+// Per-pair device state.  Everything an iteration needs and everything the host reads back.
+struct PairState {
+  // transforms, row-major
+  double M[12];          // T_iter * G : applied to the raw source every iteration
+  double T_iter[16];
+  double G[16];          // T(-mu) * guess
+  double mu[3];          // target mean (icp_fast.cc:457-458)
+  double guess[16];      // row-major copy of the caller's guess
+  // CheckConvergence history (icp_fast.cc:377-405): last 5 entries
+  double quat[5][4];
+  double trans[5][3];
+  int32_t n_hist;
+  // loop control
+  int32_t iter;
+  int32_t done;
+  int32_t status;
+  int32_t ns;
+  int32_t nt;
+  int32_t has_normals;
+  // grid geometry (bit-rank voxel grid over the centred target)
+  float origin[3];
+  float h;
+  float inv_h;
+  int32_t nx, ny, nz, wx, nw;
+  int32_t nocc;
+  // selection / lists
+  uint32_t unresolved_count;
+  uint32_t blist_count;
+  uint32_t fallback_total;
+  int32_t kept;
+  uint32_t limit_key;
+  // outputs
+  double score;
+  double result[16];     // column-major (Eigen layout)
+};
+
+// Host-written per-pair inputs of one Align call.
+struct PairInput {
+  double guess[16];      // row-major
+  int32_t ns;
+  int32_t nt;
+  int32_t has_normals;
+  int32_t pad;
+};
+
+// Pointers + capacities handed to every kernel by value.
+struct IcpDev {
+  int32_t slots, ns_cap, nt_cap;
+  int32_t acc_blocks;        // ceil(ns_cap / kAccChunk)
+  PairState* state;
+  const PairInput* in;
+  const float4* src;         // [slots][ns_cap] raw source xyz (w unused)
+  const float4* tgt_p;       // [slots][nt_cap] raw target xyz
+  const float4* tgt_n;       // [slots][nt_cap] raw target normals
+  float4* tq;                // [slots][nt_cap] centred target, cell-sorted; w = original index bits
+  float4* tn;                // [slots][nt_cap] normals, same order
+  uint32_t* tcell;           // [slots][nt_cap] (word << 5) | bit
+  uint32_t* tslot;           // [slots][nt_cap] occupied-cell slot
+  uint32_t* tord;            // [slots][nt_cap] ordinal inside the cell
+  uint32_t* bits;            // [slots][kMaxGridWords]
+  uint2* words;              // [slots][kMaxGridWords] {occupancy bits, exclusive rank}
+  uint32_t* ccount;          // [slots][nt_cap + 1]
+  uint32_t* cstart;          // [slots][nt_cap + 1]
+  float* d2;                 // [slots][ns_cap]
+  int32_t* idx;              // [slots][ns_cap] index into tq/tn (sorted order)
+  uint32_t* hist;            // [slots][kHistBins]
+  int32_t* ulist;            // [slots][ns_cap] unresolved queries (brute-force fallback)
+  int32_t* blist;            // [slots][ns_cap] queries whose d2 falls in the quantile's histogram bin
+  double* partials;          // [slots][acc_blocks][kAccCols]
+  double* tpart;             // [slots][kTgtReduceBlocks][16]
+  uint32_t* done_count;      // number of finished pairs
+  // options
+  int32_t max_iteration;
+  int32_t early_exit;
+  int32_t max_ring;
+  float rho;                 // dist_outlier_ratio as float (widened to double exactly like the reference)
+  float grid_cell;
+};
+
+}  // namespace smhip

@@ -1,0 +1,175 @@
+"""Python view of the IcpFast-equivalent matcher; mirrors registrator::Interface
+(/root/reference/registrators/interface.h:67-116): SetInputSource / SetInputTarget /
+Align / GetFitnessScore, with 4x4 numpy matrices in the usual (row, col) indexing.
+All compute happens inside libsmhip.so on the GPU."""
+from __future__ import annotations
+
+import ctypes
+import numpy as np
+
+from . import _capi
+
+NN_BRUTE = 0
+NN_GRID = 1
+
+
+class SmhipError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"smhip status {status}: {msg}")
+        self.status = status
+
+
+def se3_error(Ta: np.ndarray, Tb: np.ndarray):
+    """(rotation angle of Ra Rb^T [rad], |ta - tb| [m]) -- the metric of BASELINE.json."""
+    R = Ta[:3, :3] @ Tb[:3, :3].T
+    c = np.clip((np.trace(R) - 1.0) / 2.0, -1.0, 1.0)
+    s = np.linalg.norm([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / 2.0
+    return float(np.arctan2(s, c)), float(np.linalg.norm(Ta[:3, 3] - Tb[:3, 3]))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class IcpFastHip:
+    """One matcher instance = one smhip handle with `pair_slots` independent scan pairs.
+
+    Slot 0 plays the role of the reference's single source/target pair; the other
+    slots exist for the batched / sharded throughput path.
+    """
+
+    def __init__(self, device: int = 0, pair_slots: int = 1, max_source_points: int = 131072,
+                 max_target_points: int = 131072, stream: int | None = None, **options):
+        self._lib = _capi.load_library()
+        self._h = ctypes.c_void_p()
+        st = self._lib.smhip_create(device, ctypes.c_void_p(stream) if stream else None, pair_slots,
+                                    max_source_points, max_target_points, ctypes.byref(self._h))
+        if st != 0:
+            self._h = ctypes.c_void_p()
+            raise SmhipError(st, self._lib.smhip_status_string(st).decode())
+        self.pair_slots = pair_slots
+        self.final_score_ = float("nan")
+        self.last_stats = None
+        self._opts = _capi.IcpOptions()
+        self._lib.smhip_icp_default_options(ctypes.byref(self._opts))
+        if options:
+            self.set_options(**options)
+
+    # -- lifetime --------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.smhip_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st: int):
+        if st != 0:
+            raise SmhipError(st, self._lib.smhip_last_error(self._h).decode())
+
+    # -- options (names of icp_fast.cc:407-419 + backend knobs) ----------
+    def set_options(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self._opts, k):
+                raise KeyError(f"unknown option {k}")     # interface.cc:66-67 CHECK on unknown names
+            setattr(self._opts, k, v)
+        self._check(self._lib.smhip_icp_set_options(self._h, ctypes.byref(self._opts)))
+
+    # -- inputs ----------------------------------------------------------
+    def set_input_source(self, points, slot: int = 0):
+        """points: [N,3+] array; float32 arrays are uploaded as-is (InnerPointType / KITTI rows),
+        anything else goes through the float64 EigenPointCloud entry point."""
+        a = np.asarray(points)
+        if a.dtype == np.float32 and a.ndim == 2 and a.flags.c_contiguous:
+            self._check(self._lib.smhip_set_source_f32(self._h, slot, a.ctypes.data_as(_capi.c_float_p), a.shape[1], a.shape[0]))
+        else:
+            a = _f64(a[:, :3])
+            self._check(self._lib.smhip_set_source_f64(self._h, slot, a.ctypes.data_as(_capi.c_double_p), a.shape[0]))
+
+    def set_input_target(self, points, normals=None, slot: int = 0):
+        p = _f64(np.asarray(points)[:, :3])
+        n = None if normals is None else _f64(np.asarray(normals)[:, :3])
+        self._check(self._lib.smhip_set_target_f64(
+            self._h, slot, p.ctypes.data_as(_capi.c_double_p),
+            n.ctypes.data_as(_capi.c_double_p) if n is not None else None, p.shape[0]))
+
+    def copy_slot(self, src_slot: int, dst_slot: int):
+        self._check(self._lib.smhip_copy_slot(self._h, src_slot, dst_slot))
+
+    # -- Align -----------------------------------------------------------
+    def align(self, guess=None):
+        """IcpFast::Align for slot 0.  Returns (ok, result 4x4)."""
+        res, scores, stats = self.align_batch(1, None if guess is None else [guess])
+        self.final_score_ = float(scores[0])
+        return True, res[0]
+
+    def get_fitness_score(self) -> float:
+        return self.final_score_
+
+    @staticmethod
+    def _pack_guesses(npairs, guesses):
+        g = np.empty((npairs, 16), dtype=np.float64)
+        for p in range(npairs):
+            G = np.eye(4) if guesses is None else np.asarray(guesses[p], dtype=np.float64)
+            g[p] = G.T.reshape(-1)          # column-major
+        return g
+
+    def align_batch(self, npairs: int, guesses=None):
+        g = self._pack_guesses(npairs, guesses)
+        res = np.zeros((npairs, 16))
+        scores = np.zeros(npairs)
+        stats = (_capi.IcpStats * npairs)()
+        st = self._lib.smhip_icp_align_batch(self._h, npairs, g.ctypes.data_as(_capi.c_double_p),
+                                             res.ctypes.data_as(_capi.c_double_p),
+                                             scores.ctypes.data_as(_capi.c_double_p), stats)
+        self.last_stats = [dict(iterations=s.iterations, kept=s.kept, limit_d2=s.limit_d2,
+                                fallback_queries=s.fallback_queries, status=s.status) for s in stats]
+        self._check(st)
+        return res.reshape(npairs, 4, 4).transpose(0, 2, 1).copy(), scores, self.last_stats
+
+    def enqueue_batch(self, npairs: int, guesses=None):
+        g = self._pack_guesses(npairs, guesses)
+        self._check(self._lib.smhip_icp_enqueue_batch(self._h, npairs, g.ctypes.data_as(_capi.c_double_p)))
+
+    def fetch_batch(self, npairs: int):
+        res = np.zeros((npairs, 16))
+        scores = np.zeros(npairs)
+        stats = (_capi.IcpStats * npairs)()
+        st = self._lib.smhip_icp_fetch_batch(self._h, npairs, res.ctypes.data_as(_capi.c_double_p),
+                                             scores.ctypes.data_as(_capi.c_double_p), stats)
+        self.last_stats = [dict(iterations=s.iterations, kept=s.kept, limit_d2=s.limit_d2,
+                                fallback_queries=s.fallback_queries, status=s.status) for s in stats]
+        self._check(st)
+        return res.reshape(npairs, 4, 4).transpose(0, 2, 1).copy(), scores, self.last_stats
+
+    def synchronize(self):
+        self._check(self._lib.smhip_synchronize(self._h))
+
+    # -- introspection ---------------------------------------------------
+    def get_matches(self, n: int, slot: int = 0):
+        ids = np.zeros(n, dtype=np.int32)
+        d2 = np.zeros(n, dtype=np.float32)
+        self._check(self._lib.smhip_icp_get_matches(self._h, slot, ids.ctypes.data_as(_capi.c_int32_p),
+                                                    d2.ctypes.data_as(_capi.c_float_p), n))
+        return ids, d2
+
+    def find_closests(self, T, n: int):
+        Tc = _f64(np.asarray(T).T).reshape(-1)
+        ids = np.zeros(n, dtype=np.int32)
+        d2 = np.zeros(n, dtype=np.float32)
+        self._check(self._lib.smhip_icp_find_closests(self._h, 0, Tc.ctypes.data_as(_capi.c_double_p),
+                                                      ids.ctypes.data_as(_capi.c_int32_p),
+                                                      d2.ctypes.data_as(_capi.c_float_p), n))
+        return ids, d2
+
+    def enable_profile(self, on: bool = True):
+        self._check(self._lib.smhip_icp_enable_profile(self._h, int(on)))
+
+    def get_profile(self) -> dict:
+        p = _capi.IcpProfile()
+        self._check(self._lib.smhip_icp_get_profile(self._h, ctypes.byref(p)))
+        return {k: getattr(p, k) for k, _ in p._fields_ if k != "reserved"}

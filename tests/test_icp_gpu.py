@@ -1,0 +1,252 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Tolerances: indices bit-exact up to fp32 near-ties, SE(3) within
+BASELINE.json's 1e-4 rad / 1e-3 m."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROT_TOL = 1e-4      # rad, BASELINE.json north_star
+TRANS_TOL = 1e-3    # m
+
+
+@pytest.fixture(scope="module")
+def smhip():
+    import staticmapping_amd as sm
+    from staticmapping_amd import _capi
+    lib = _capi.load_library()
+    assert lib.smhip_device_count() >= 1, "no gfx950 device visible"
+    return sm
+
+
+def _oracle_nn(q, src, T):
+    from oracle import cref
+    mu = q.mean(axis=0)
+    P = src @ T[:3, :3].T + T[:3, 3] - mu
+    return cref.nn(q - mu, P)
+
+
+@pytest.mark.parametrize("mode", ["grid", "brute"])
+def test_find_closests_matches_exact_nn(smhip, velo20k, mode):
+    """K1 alone: identical ids (>= 99.99 %) and squared distances."""
+    c = velo20k
+    src = c["src"][:, :3].astype(np.float64)
+    m = smhip.IcpFastHip(max_source_points=len(src), max_target_points=len(c["q"]),
+                         nn_mode=1 if mode == "grid" else 0)
+    m.set_input_source(c["src"])
+    m.set_input_target(c["q"], c["n"])
+    ids, d2 = m.find_closests(c["guess"], len(src))
+    ids_o, d2_o = _oracle_nn(c["q"], src, c["guess"])
+    same = ids == ids_o
+    assert same.mean() >= 0.9999
+    # where ids differ the distances must be a near-tie
+    assert np.allclose(d2[~same], d2_o[~same], rtol=1e-4, atol=1e-9)
+    assert np.allclose(d2, d2_o, rtol=2e-4, atol=1e-8)
+    m.close()
+
+
+def test_grid_equals_brute_bitwise(smhip, velo20k):
+    """Both searches are exact with the same tie rule, so they agree bit for bit."""
+    c = velo20k
+    out = []
+    for mode in (0, 1):
+        m = smhip.IcpFastHip(max_source_points=len(c["src"]), max_target_points=len(c["q"]), nn_mode=mode)
+        m.set_input_source(c["src"])
+        m.set_input_target(c["q"], c["n"])
+        out.append(m.find_closests(np.eye(4), len(c["src"])))
+        m.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+
+
+def _align_both(smhip, case, guess, **opts):
+    from oracle import cref
+    src = case["src"][:, :3].astype(np.float64)
+    m = smhip.IcpFastHip(max_source_points=len(src), max_target_points=len(case["q"]), **opts)
+    m.set_input_source(case["src"])
+    m.set_input_target(case["q"], case["n"])
+    ok, R = m.align(guess)
+    ref = cref.icp_fast_align(src, case["q"], case["n"], guess=guess,
+                              max_iteration=opts.get("max_iteration", 100),
+                              dist_outlier_ratio=opts.get("dist_outlier_ratio", 0.7),
+                              early_exit=bool(opts.get("early_exit", 1)))
+    stats = m.last_stats[0]
+    score = m.get_fitness_score()
+    m.close()
+    return ok, R, score, stats, ref
+
+
+def test_cfg1_plumbing_parity(smhip, cfg1):
+    ok, R, score, stats, ref = _align_both(smhip, cfg1, np.eye(4))
+    da, dt = smhip.se3_error(R, ref["result"])
+    assert ok and da < ROT_TOL and dt < TRANS_TOL
+    assert stats["iterations"] == ref["iterations"]
+    assert abs(score - ref["score"]) < 1e-4
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_velodyne20k_parity_early_exit(smhip, velo20k, mode):
+    ok, R, score, stats, ref = _align_both(smhip, velo20k, velo20k["guess"], nn_mode=mode)
+    da, dt = smhip.se3_error(R, ref["result"])
+    assert da < ROT_TOL and dt < TRANS_TOL, (da, dt)
+    assert stats["iterations"] == ref["iterations"]
+    assert abs(score - ref["score"]) < 1e-4
+
+
+def test_cfg2_full_size_parity_20_iterations(smhip, cfg2):
+    """BASELINE config #2 at full size: 120k-pt pair, exactly 20 iterations."""
+    ok, R, score, stats, ref = _align_both(smhip, cfg2, cfg2["guess"], max_iteration=20, early_exit=0)
+    da, dt = smhip.se3_error(R, ref["result"])
+    assert da < ROT_TOL and dt < TRANS_TOL, (da, dt)
+    assert stats["iterations"] == 20 == ref["iterations"]
+    assert abs(score - ref["score"]) < 1e-4
+    # and the answer is the true motion (1.6 mm / 3e-5 rad in the oracle)
+    da, dt = smhip.se3_error(R, cfg2["T"])
+    assert da < 5e-4 and dt < 5e-3
+
+
+def test_cfg2_identity_guess_parity(smhip, cfg2):
+    """Identity guess: trimmed ICP slides into the ground-dominated basin on CPU and GPU alike."""
+    ok, R, score, stats, ref = _align_both(smhip, cfg2, np.eye(4))
+    da, dt = smhip.se3_error(R, ref["result"])
+    assert da < ROT_TOL and dt < TRANS_TOL, (da, dt)
+    assert stats["iterations"] == ref["iterations"]
+
+
+def test_quantile_kept_count_is_exact(smhip, velo20k):
+    """kept = #(d2 <= values[int(n * 0.7f)]) -- the nth_element rank rule (icp_fast.cc:86-89, 497)."""
+    c = velo20k
+    m = smhip.IcpFastHip(max_source_points=len(c["src"]), max_target_points=len(c["q"]),
+                         max_iteration=1, early_exit=0)
+    m.set_input_source(c["src"])
+    m.set_input_target(c["q"], c["n"])
+    m.align(c["guess"])
+    ids, d2 = m.get_matches(len(c["src"]))
+    st = m.last_stats[0]
+    k = int(len(d2) * float(np.float32(0.7)))
+    limit = np.partition(d2, k)[k]
+    assert np.float32(st["limit_d2"]) == limit
+    assert st["kept"] == int((d2 <= limit).sum())
+    m.close()
+
+
+def test_ratio_one_keeps_everything(smhip, cfg1):
+    ok, R, score, stats, ref = _align_both(smhip, cfg1, np.eye(4), dist_outlier_ratio=1.0, max_iteration=5, early_exit=0)
+    assert stats["kept"] == len(cfg1["src"])
+    da, dt = smhip.se3_error(R, ref["result"])
+    assert da < ROT_TOL and dt < TRANS_TOL
+
+
+def test_identical_clouds_give_identity(smhip, cfg1):
+    """x = 0 -> NaN rotation -> identity rule (icp_fast.cc:315-321)."""
+    m = smhip.IcpFastHip(max_source_points=len(cfg1["q"]), max_target_points=len(cfg1["q"]))
+    m.set_input_source(cfg1["q"])
+    m.set_input_target(cfg1["q"], cfg1["n"])
+    ok, R = m.align()
+    assert np.allclose(R, np.eye(4), atol=1e-5)
+    assert m.get_fitness_score() > 0.999
+    m.close()
+
+
+def test_far_source_uses_fallback_and_stays_exact(smhip, velo20k):
+    """Queries far outside the target's grid go through the brute-force fallback; ids stay exact."""
+    c = velo20k
+    T = np.eye(4); T[:3, 3] = (150.0, -90.0, 30.0)
+    m = smhip.IcpFastHip(max_source_points=4096, max_target_points=len(c["q"]))
+    m.set_input_source(c["src"][:4096])
+    m.set_input_target(c["q"], c["n"])
+    ids, d2 = m.find_closests(T, 4096)
+    ids_o, d2_o = _oracle_nn(c["q"], c["src"][:4096, :3].astype(np.float64), T)
+    assert (ids == ids_o).mean() >= 0.999
+    assert np.allclose(d2, d2_o, rtol=2e-4)
+    m.close()
+
+
+def test_nan_points_are_ignored(smhip, cfg1):
+    src = cfg1["src"].copy()
+    src[::97, 0] = np.nan
+    m = smhip.IcpFastHip(max_source_points=len(src), max_target_points=len(cfg1["q"]))
+    m.set_input_source(src)
+    m.set_input_target(cfg1["q"], cfg1["n"])
+    ok, R = m.align()
+    from oracle import cref
+    good = np.isfinite(src[:, 0])
+    ref = cref.icp_fast_align(src[good, :3].astype(np.float64), cfg1["q"], cfg1["n"])
+    da, dt = smhip.se3_error(R, ref["result"])
+    assert da < ROT_TOL and dt < TRANS_TOL
+    m.close()
+
+
+def test_tiny_and_ragged_clouds(smhip):
+    rng = np.random.default_rng(5)
+    q = rng.uniform(-1, 1, (37, 3)); q[:, 2] *= 0.01
+    n = np.tile([0, 0, 1.0], (37, 1))
+    src = q[:11] + [0.01, 0.0, 0.02]
+    m = smhip.IcpFastHip(max_source_points=64, max_target_points=64, max_iteration=6, early_exit=0)
+    m.set_input_source(src)
+    m.set_input_target(q, n)
+    ok, R = m.align()
+    from oracle import cref
+    ref = cref.icp_fast_align(src, q, n, max_iteration=6, early_exit=False)
+    da, dt = smhip.se3_error(R, ref["result"])
+    assert da < 1e-3 and dt < 1e-3          # 7 kept points: fp32 distances move the trim boundary
+    m.close()
+
+
+def test_error_conventions(smhip, cfg1):
+    m = smhip.IcpFastHip(max_source_points=1000, max_target_points=1000)
+    with pytest.raises(smhip.SmhipError) as e:      # Align before SetInput*
+        m.align()
+    assert e.value.status == 4
+    with pytest.raises(smhip.SmhipError) as e:      # larger than the arena
+        m.set_input_source(cfg1["src"])
+    assert e.value.status == 7
+    m.set_input_source(cfg1["src"][:1000])
+    m.set_input_target(cfg1["q"][:1000], None)
+    with pytest.raises(smhip.SmhipError) as e:      # CHECK(HasNormals()) icp_fast.cc:430
+        m.align()
+    assert e.value.status == 5
+    with pytest.raises(KeyError):                   # unknown option name (interface.cc:66-67)
+        m.set_options(no_such_option=1)
+    with pytest.raises(smhip.SmhipError):
+        m.set_options(dist_outlier_ratio=1.5)
+    m.close()
+
+
+def test_batch_slots_equal_single_runs(smhip, velo20k, cfg1):
+    """Independent scan pairs in one launch give the same transforms as one-at-a-time runs."""
+    cases = [velo20k, cfg1, velo20k]
+    guesses = [velo20k["guess"], np.eye(4), np.eye(4)]
+    cap_s = max(len(c["src"]) for c in cases); cap_t = max(len(c["q"]) for c in cases)
+    mb = smhip.IcpFastHip(pair_slots=3, max_source_points=cap_s, max_target_points=cap_t)
+    for s, c in enumerate(cases):
+        mb.set_input_source(c["src"], slot=s)
+        mb.set_input_target(c["q"], c["n"], slot=s)
+    Rb, sb, stb = mb.align_batch(3, guesses)
+    mb.close()
+    for s, c in enumerate(cases):
+        m1 = smhip.IcpFastHip(max_source_points=cap_s, max_target_points=cap_t)
+        m1.set_input_source(c["src"]); m1.set_input_target(c["q"], c["n"])
+        ok, R1 = m1.align(guesses[s])
+        assert stb[s]["iterations"] == m1.last_stats[0]["iterations"]
+        da, dt = smhip.se3_error(Rb[s], R1)
+        assert da < 1e-7 and dt < 1e-6
+        m1.close()
+
+
+def test_rigid_motion_equivariance_full_size(smhip, cfg2):
+    """Size-independent property at full size: moving the target frame by W moves the result by W
+    (Align(W q, W n; W guess) = W Align(q, n; guess))."""
+    from staticmapping_amd import synth
+    W = synth.make_pose(t=(3.0, -2.0, 0.5), rpy_deg=(2.0, -1.0, 30.0))
+    c = cfg2
+    m = smhip.IcpFastHip(max_source_points=len(c["src"]), max_target_points=len(c["q"]), max_iteration=20, early_exit=0)
+    m.set_input_source(c["src"]); m.set_input_target(c["q"], c["n"])
+    ok, R0 = m.align(c["guess"])
+    qW = c["q"] @ W[:3, :3].T + W[:3, 3]
+    nW = c["n"] @ W[:3, :3].T
+    m.set_input_target(qW, nW)
+    ok, R1 = m.align(W @ c["guess"])
+    da, dt = smhip.se3_error(R1, W @ R0)
+    assert da < ROT_TOL and dt < TRANS_TOL, (da, dt)
+    m.close()

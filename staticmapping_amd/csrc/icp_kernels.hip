@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void grid_scatter(IcpDev b) {
   float4 n = b.tgt_n[o + j];
   n.w = 0.f;
   b.tn[o + pos] = n;
+  b.tslot[o + j] = pos;      // from here on: original index -> sorted position
 }
 
 // ------------------------------------------------------------------------------------------
@@ -355,6 +356,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_grid(IcpDev b) {
     } else {
       const uint32_t pos = atomicAdd(&st->unresolved_count, 1u);
       b.ulist[so + pos] = i;
+      b.ukeys[so + pos] = ~0ull;
     }
   }
   __syncthreads();
@@ -414,6 +416,58 @@ __global__ __launch_bounds__(kNnThreads) void nn_brute(IcpDev b) {
     const uint32_t v = s_hist[k];
     if (v) atomicAdd(&gh[k], v);
   }
+}
+
+// Fallback for the few queries the grid search could not certify (far / sparse regions).
+// The work (U queries x nt targets) is spread over the whole chip: block (slice, pair) stages one
+// slice of the target in LDS and sweeps ALL unresolved queries of the pair over it; the per-query
+// winner is merged with a 64-bit atomicMin on (d2 bits << 32 | original index).
+__global__ __launch_bounds__(kNnThreads) void nn_fallback_scan(IcpDev b) {
+  const int pair = blockIdx.y;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  const int U = (int)st->unresolved_count;
+  if (U == 0) return;
+  __shared__ float4 s_t[kBruteTile];
+  const int nt = st->nt;
+  const int per = (nt + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per, hi = min(nt, lo + per);
+  if (lo >= hi) return;
+  const size_t so = (size_t)pair * b.ns_cap;
+  const float4* tq = b.tq + (size_t)pair * b.nt_cap;
+  for (int base = lo; base < hi; base += kBruteTile) {
+    const int m = min(kBruteTile, hi - base);
+    __syncthreads();
+    for (int k = threadIdx.x; k < m; k += kNnThreads) s_t[k] = tq[base + k];
+    __syncthreads();
+    for (int e = threadIdx.x; e < U; e += kNnThreads) {
+      double px, py, pz;
+      transform_point(st->M, b.src[so + b.ulist[so + e]], px, py, pz);
+      const float qx = (float)px, qy = (float)py, qz = (float)pz;
+      Best best = {INFINITY, -1, 0x7fffffff};
+#pragma unroll 8
+      for (int k = 0; k < m; ++k) test_candidate(s_t[k], base + k, qx, qy, qz, best);
+      const unsigned long long key = ((unsigned long long)__float_as_uint(best.d2) << 32) | (uint32_t)best.orig;
+      atomicMin(&b.ukeys[so + e], key);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kNnThreads) void nn_fallback_resolve(IcpDev b) {
+  const int pair = blockIdx.y;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  const int U = (int)st->unresolved_count;
+  const int e = blockIdx.x * kNnThreads + threadIdx.x;
+  if (e >= U) return;
+  const size_t so = (size_t)pair * b.ns_cap;
+  const int i = b.ulist[so + e];
+  const unsigned long long key = b.ukeys[so + e];
+  const uint32_t dbits = (uint32_t)(key >> 32);
+  const uint32_t orig = (uint32_t)(key & 0xffffffffu);
+  b.d2[so + i] = __uint_as_float(dbits);
+  b.idx[so + i] = (int)b.tslot[(size_t)pair * b.nt_cap + orig];
+  if (dbits < 0x7f800000u) atomicAdd(&b.hist[(size_t)pair * kHistBins + (dbits >> kHistShift)], 1u);
 }
 
 // ------------------------------------------------------------------------------------------

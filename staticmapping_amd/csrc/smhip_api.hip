@@ -137,7 +137,8 @@ smhip_status enqueue_find_closests(smhip_context* h, int np, int ns_max) {
   const dim3 g(ceil_div(ns_max, kNnThreads), np);
   if (h->opts.nn_mode == SMHIP_NN_GRID) {
     { Bracket br(h, 1); hipLaunchKernelGGL(nn_grid, g, dim3(kNnThreads), 0, h->stream, d); }
-    { Bracket br(h, 1); hipLaunchKernelGGL(nn_brute<false>, g, dim3(kNnThreads), 0, h->stream, d); }
+    { Bracket br(h, 1); hipLaunchKernelGGL(nn_fallback_scan, dim3(kFallbackSlices, np), dim3(kNnThreads), 0, h->stream, d); }
+    { Bracket br(h, 1); hipLaunchKernelGGL(nn_fallback_resolve, g, dim3(kNnThreads), 0, h->stream, d); }
   } else {
     Bracket br(h, 1);
     hipLaunchKernelGGL(nn_brute<true>, g, dim3(kNnThreads), 0, h->stream, d);
@@ -271,6 +272,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, &d.idx, B * NS));
   A(dev_alloc(h, &d.hist, B * kHistBins));
   A(dev_alloc(h, &d.ulist, B * NS));
+  A(dev_alloc(h, &d.ukeys, B * NS));
   A(dev_alloc(h, &d.blist, B * NS));
   A(dev_alloc(h, &d.partials, B * d.acc_blocks * kAccCols));
   A(dev_alloc(h, &d.tpart, B * kTgtReduceBlocks * 16));

@@ -16,7 +16,8 @@ constexpr int kAccChunk = kAccThreads * kAccItems;
 constexpr int kAccCols = 32;             // 21 (A upper) + 6 (b) + 1 (sum sqrt d2) + 1 (count) padded to 32
 constexpr int kMaxGridWords = 1 << 16;   // 32-cell words per pair (2 Mi cells)
 constexpr int kTgtReduceBlocks = 32;     // partial blocks for the target mean / bbox
-constexpr int kBruteTile = 1024;         // target points staged in LDS per tile (16 KiB as float4)
+constexpr int kBruteTile = 1024;
+constexpr int kFallbackSlices = 64;      // target slices the fallback sweep is spread over         // target points staged in LDS per tile (16 KiB as float4)
 
 // Per-pair device state.  Everything an iteration needs and everything the host reads back.
 struct PairState {
@@ -85,6 +86,7 @@ struct IcpDev {
   int32_t* idx;              // [slots][ns_cap] index into tq/tn (sorted order)
   uint32_t* hist;            // [slots][kHistBins]
   int32_t* ulist;            // [slots][ns_cap] unresolved queries (brute-force fallback)
+  unsigned long long* ukeys; // [slots][ns_cap] fallback winners: (d2 bits << 32) | original target index
   int32_t* blist;            // [slots][ns_cap] queries whose d2 falls in the quantile's histogram bin
   double* partials;          // [slots][acc_blocks][kAccCols]
   double* tpart;             // [slots][kTgtReduceBlocks][16]

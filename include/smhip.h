@@ -82,13 +82,14 @@ typedef struct smhip_icp_stats {
  * REGISTER_BLOCK labels where one exists (icp_fast.cc:103,171,261,484). */
 typedef struct smhip_icp_profile {
   double ms_prepare;            /* target centring + grid build (replaces kd-tree build, icp_fast.cc:464-467) */
-  double ms_find_closests;      /* "FindClosests": NN kernels, summed over launches */
+  double ms_find_closests;      /* "FindClosests": all NN kernels (main + fallback), summed over launches */
   double ms_error_elements;     /* "ErrorElements"+"ComputePointToPlane" accumulate kernel */
   double ms_solve;              /* select + 6x6 solve + convergence kernel */
   int32_t launches_find_closests;
   int32_t launches_error_elements;
   int32_t launches_solve;
-  int32_t reserved;
+  int32_t launches_nn_main;     /* launches of the dominant NN kernel alone */
+  double ms_nn_main;            /* its summed duration (subset of ms_find_closests) */
 } smhip_icp_profile;
 
 /* ---- library / device ------------------------------------------------- */
@@ -136,6 +137,19 @@ smhip_status smhip_icp_align_batch(smhip_handle h, int npairs, const double* gue
 smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* guesses);
 smhip_status smhip_icp_fetch_batch(smhip_handle h, int npairs, double* results, double* scores,
                                    smhip_icp_stats* stats);
+
+/* Device-resident copy of the last results: writes npairs * 18 doubles to device memory at
+ * dev_out (16 column-major transform + score + iterations) on the handle's stream, so a collective
+ * (RCCL gather of the poses) can consume them without a host round trip. */
+smhip_status smhip_icp_export_results_device(smhip_handle h, int npairs, void* dev_out);
+
+/* ---- target preparation (host) -------------------------------------------
+ * EigenPointCloud::CalculateNormals (builder/data/cloud_types.cc:347-368): kd-box subsampling +
+ * unconstrained-LS normals.  The reference's CALLER runs it before SetInputTarget
+ * (builder/map_builder.cc:286,389), so it is a free function, not part of Align.
+ * xyz: 3xN column-major; outputs need room for n points; *n_out = surviving points. */
+smhip_status smhip_calculate_normals_f64(const double* xyz_colmajor_3xN, int n, double* out_xyz,
+                                         double* out_normals, int* n_out);
 
 /* ---- introspection for parity tests ------------------------------------
  * Matches of the LAST executed iteration of `slot` (FindClosests output, icp_fast.cc:169-180):

@@ -27,7 +27,8 @@ class IcpProfile(ctypes.Structure):
     _fields_ = [("ms_prepare", ctypes.c_double), ("ms_find_closests", ctypes.c_double),
                 ("ms_error_elements", ctypes.c_double), ("ms_solve", ctypes.c_double),
                 ("launches_find_closests", ctypes.c_int32), ("launches_error_elements", ctypes.c_int32),
-                ("launches_solve", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("launches_solve", ctypes.c_int32), ("launches_nn_main", ctypes.c_int32),
+                ("ms_nn_main", ctypes.c_double)]
 
 
 # name -> (restype, argtypes): every symbol include/smhip.h declares
@@ -54,6 +55,8 @@ SIGNATURES = {
     "smhip_icp_enqueue_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p]),
     "smhip_icp_fetch_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p,
                                              ctypes.POINTER(IcpStats)]),
+    "smhip_icp_export_results_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "smhip_calculate_normals_f64": (ctypes.c_int, [c_double_p, ctypes.c_int, c_double_p, c_double_p, c_int32_p]),
     "smhip_icp_get_matches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int32_p, c_float_p, ctypes.c_int]),
     "smhip_icp_find_closests": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_int32_p, c_float_p,
                                                ctypes.c_int]),

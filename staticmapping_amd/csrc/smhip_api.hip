@@ -98,6 +98,8 @@ void collect_profile(smhip_context* h) {
     switch (h->ev_pool[k].cat) {
       case 0: h->prof.ms_prepare += ms; break;
       case 1: h->prof.ms_find_closests += ms; h->prof.launches_find_closests++; break;
+      case 4: h->prof.ms_find_closests += ms; h->prof.launches_find_closests++;
+              h->prof.ms_nn_main += ms; h->prof.launches_nn_main++; break;
       case 2: h->prof.ms_error_elements += ms; h->prof.launches_error_elements++; break;
       case 3: h->prof.ms_solve += ms; h->prof.launches_solve++; break;
     }
@@ -136,11 +138,11 @@ smhip_status enqueue_find_closests(smhip_context* h, int np, int ns_max) {
   IcpDev& d = h->dev;
   const dim3 g(ceil_div(ns_max, kNnThreads), np);
   if (h->opts.nn_mode == SMHIP_NN_GRID) {
-    { Bracket br(h, 1); hipLaunchKernelGGL(nn_grid, g, dim3(kNnThreads), 0, h->stream, d); }
+    { Bracket br(h, 4); hipLaunchKernelGGL(nn_grid, g, dim3(kNnThreads), 0, h->stream, d); }
     { Bracket br(h, 1); hipLaunchKernelGGL(nn_fallback_scan, dim3(kFallbackSlices, np), dim3(kNnThreads), 0, h->stream, d); }
     { Bracket br(h, 1); hipLaunchKernelGGL(nn_fallback_resolve, g, dim3(kNnThreads), 0, h->stream, d); }
   } else {
-    Bracket br(h, 1);
+    Bracket br(h, 4);
     hipLaunchKernelGGL(nn_brute<true>, g, dim3(kNnThreads), 0, h->stream, d);
   }
   return SMHIP_OK;
@@ -499,6 +501,24 @@ smhip_status smhip_icp_align_batch(smhip_handle h, int npairs, const double* gue
 
 smhip_status smhip_icp_align(smhip_handle h, const double guess[16], double result[16], double* score, smhip_icp_stats* stats) {
   return smhip_icp_align_batch(h, 1, guess, result, score, stats);
+}
+
+__global__ void export_results(IcpDev b, int npairs, double* out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npairs) return;
+  const PairState* st = &b.state[p];
+  for (int k = 0; k < 16; ++k) out[18 * p + k] = st->result[k];
+  out[18 * p + 16] = st->score;
+  out[18 * p + 17] = (double)st->iter;
+}
+
+smhip_status smhip_icp_export_results_device(smhip_handle h, int npairs, void* dev_out) {
+  if (!h || !dev_out || npairs < 1 || npairs > h->dev.slots) return SMHIP_ERR_INVALID_ARGUMENT;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(export_results, dim3(ceil_div(npairs, 64)), dim3(64), 0, h->stream, h->dev, npairs,
+                     reinterpret_cast<double*>(dev_out));
+  HIPCHK(h, hipGetLastError());
+  return SMHIP_OK;
 }
 
 smhip_status smhip_icp_get_matches(smhip_handle h, int slot, int32_t* ids, float* d2, int n) {

@@ -31,6 +31,23 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+def calculate_normals(points):
+    """Host-side EigenPointCloud::CalculateNormals (cloud_types.cc:347-368) from libsmhip.so:
+    returns (kept_points [M,3], normals [M,3]).  Leaves whose normal is not finite (singular
+    M, which the reference does not check) are dropped here so IcpFast never sees NaN."""
+    lib = _capi.load_library()
+    p = _f64(np.asarray(points)[:, :3])
+    n = p.shape[0]
+    op = np.zeros((n, 3)); on = np.zeros((n, 3)); m = ctypes.c_int32()
+    st = lib.smhip_calculate_normals_f64(p.ctypes.data_as(_capi.c_double_p), n, op.ctypes.data_as(_capi.c_double_p),
+                                         on.ctypes.data_as(_capi.c_double_p), ctypes.byref(m))
+    if st != 0:
+        raise SmhipError(st, lib.smhip_status_string(st).decode())
+    op, on = op[:m.value], on[:m.value]
+    ok = np.isfinite(on).all(axis=1)
+    return op[ok].copy(), on[ok].copy()
+
+
 class IcpFastHip:
     """One matcher instance = one smhip handle with `pair_slots` independent scan pairs.
 
@@ -165,6 +182,10 @@ class IcpFastHip:
                                                       ids.ctypes.data_as(_capi.c_int32_p),
                                                       d2.ctypes.data_as(_capi.c_float_p), n))
         return ids, d2
+
+    def export_results_device(self, npairs: int, dev_ptr: int):
+        """Write npairs x 18 doubles (16 col-major transform, score, iterations) to device memory."""
+        self._check(self._lib.smhip_icp_export_results_device(self._h, npairs, ctypes.c_void_p(dev_ptr)))
 
     def enable_profile(self, on: bool = True):
         self._check(self._lib.smhip_icp_enable_profile(self._h, int(on)))

@@ -65,7 +65,9 @@ typedef struct smhip_icp_options {
   float grid_cell;              /* voxel edge in metres for SMHIP_NN_GRID (default 0.5) */
   int32_t grid_max_ring;        /* largest ring searched in the grid before the brute-force fallback (default 4) */
   int32_t check_every;          /* host polls the device "all done" word every this many iterations (default 8) */
-  int32_t reserved[8];
+  int32_t tile_margin;          /* cells added around a wave's bounding block in the tile phase (default 1) */
+  int32_t use_tile;             /* 1 (default): wave-tile phase + ring search on the rest; 0: ring search only */
+  int32_t reserved[6];
 } smhip_icp_options;
 
 /* Per-call statistics (all optional to read). */
@@ -75,6 +77,8 @@ typedef struct smhip_icp_stats {
   double limit_d2;              /* the quantile (squared distance) of the last iteration */
   int32_t fallback_queries;     /* queries resolved by the brute-force fallback, summed over iterations */
   int32_t status;               /* per-pair smhip_status */
+  int32_t hard_queries;         /* queries the tile phase handed to the ring search, summed over iterations */
+  int32_t reserved;
 } smhip_icp_stats;
 
 /* Kernel-time breakdown collected when profiling is enabled (HIP events on the
@@ -116,7 +120,9 @@ smhip_status smhip_synchronize(smhip_handle h);
 smhip_status smhip_set_source_f64(smhip_handle h, int slot, const double* xyz_colmajor_3xN, int n);
 smhip_status smhip_set_target_f64(smhip_handle h, int slot, const double* xyz_colmajor_3xN,
                                   const double* normals_colmajor_3xN, int n);
-/* float32 points with a stride in floats: stride 4 = KITTI .bin rows (ros_node/kitti_reader.cc:91-121),
+/* The source is re-ordered along a Morton curve on upload (spatially coherent wavefronts); ids / d2
+ * returned by smhip_icp_get_matches are in the CALLER's order again.
+ * float32 points with a stride in floats: stride 4 = KITTI .bin rows (ros_node/kitti_reader.cc:91-121),
  * stride 5 = data::InnerPointType AoS {x,y,z,intensity,factor} (builder/data/cloud_types.h:46-56). */
 smhip_status smhip_set_source_f32(smhip_handle h, int slot, const float* xyz, int stride_floats, int n);
 smhip_status smhip_set_target_f32(smhip_handle h, int slot, const float* xyz, int xyz_stride_floats,

@@ -157,7 +157,7 @@ __global__ void grid_setup(IcpDev b, int npairs) {
   st->trans[0][0] = st->trans[0][1] = st->trans[0][2] = 0;
   st->n_hist = 1;
   st->iter = 0; st->done = 0; st->status = 0;
-  st->unresolved_count = 0; st->blist_count = 0; st->fallback_total = 0;
+  st->unresolved_count = 0; st->blist_count = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
   st->kept = 0; st->limit_key = 0; st->score = 0; st->nocc = 0;
 }
 
@@ -245,21 +245,49 @@ __global__ __launch_bounds__(256) void grid_scatter(IcpDev b) {
   float4 n = b.tgt_n[o + j];
   n.w = 0.f;
   b.tn[o + pos] = n;
-  b.tslot[o + j] = pos;      // from here on: original index -> sorted position
+}
+
+// One thread per occupied cell: order the cell's points by original index so that sorted
+// positions (and with them the NN tie rule) do not depend on the atomic order of grid_count.
+__global__ __launch_bounds__(256) void grid_sort_cells(IcpDev b) {
+  const int pair = blockIdx.y;
+  const PairState* st = &b.state[pair];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= st->nocc) return;
+  const uint32_t* cs = b.cstart + (size_t)pair * (b.nt_cap + 1);
+  const uint32_t j0 = cs[c], j1 = cs[c + 1];
+  float4* tq = b.tq + (size_t)pair * b.nt_cap;
+  float4* tn = b.tn + (size_t)pair * b.nt_cap;
+  for (uint32_t a = j0 + 1; a < j1; ++a) {       // insertion sort; cells hold a handful of points
+    const float4 kq = tq[a], kn = tn[a];
+    const int key = __float_as_int(kq.w);
+    uint32_t p = a;
+    while (p > j0 && __float_as_int(tq[p - 1].w) > key) { tq[p] = tq[p - 1]; tn[p] = tn[p - 1]; --p; }
+    tq[p] = kq; tn[p] = kn;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
 // K1: transform + exact 1-NN
 // ------------------------------------------------------------------------------------------
-struct Best { float d2; int j; int orig; };
+// Tie rule everywhere: among equidistant targets the smallest SORTED position j wins.  Positions
+// are deterministic (cells in linear order, points inside a cell ordered by original index, see
+// grid_sort_cells), so brute force, tile search, ring search and fallback agree bit for bit.
+struct Best { float d2; int j; };
 
-__device__ __forceinline__ void test_candidate(const float4 t, int j, float qx, float qy, float qz, Best& best) {
+__device__ __forceinline__ float dist2(const float4 t, float qx, float qy, float qz) {
   const float dx = qx - t.x, dy = qy - t.y, dz = qz - t.z;
-  const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-  const int orig = __float_as_int(t.w);
-  // ties broken towards the smaller ORIGINAL target index, so the result does not depend
-  // on the (atomic) order of points inside a cell
-  if (d < best.d2 || (d == best.d2 && orig < best.orig)) { best.d2 = d; best.j = j; best.orig = orig; }
+  return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+// candidates visited in ascending j: strict "<" keeps the smallest j among ties
+__device__ __forceinline__ void test_ascending(const float4 t, int j, float qx, float qy, float qz, Best& best) {
+  const float d = dist2(t, qx, qy, qz);
+  if (d < best.d2) { best.d2 = d; best.j = j; }
+}
+// arbitrary visiting order: explicit tie rule
+__device__ __forceinline__ void test_any_order(const float4 t, int j, float qx, float qy, float qz, Best& best) {
+  const float d = dist2(t, qx, qy, qz);
+  if (d < best.d2 || (d == best.d2 && j < best.j)) { best.d2 = d; best.j = j; }
 }
 
 __device__ __forceinline__ void transform_point(const double* M, const float4 s, double& px, double& py, double& pz) {
@@ -269,54 +297,244 @@ __device__ __forceinline__ void transform_point(const double* M, const float4 s,
   pz = fma(M[8], x, fma(M[9], y, fma(M[10], z, M[11])));
 }
 
-// candidates of the cells x in [xa, xb] of row (y, z): one contiguous run of the sorted target
-__device__ __forceinline__ void search_row(const uint2* __restrict__ words, const uint32_t* __restrict__ cstart,
-                                           const float4* __restrict__ tq, int rowbase, int xa, int xb,
-                                           float qx, float qy, float qz, Best& best) {
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// occupied-cell slots [s_begin, s_end) of the cells x in [xa, xb] of one grid row
+__device__ __forceinline__ void row_slots(const uint2* __restrict__ words, int rowbase, int xa, int xb,
+                                          uint32_t& s_begin, uint32_t& s_end) {
   const int w0 = xa >> 5, w1 = xb >> 5;
   const uint2 a = words[rowbase + w0];
   const uint2 c = (w1 == w0) ? a : words[rowbase + w1];
-  const uint32_t s_begin = a.y + __popc(a.x & ((1u << (xa & 31)) - 1u));
-  const uint32_t s_end = c.y + __popc(c.x & (0xffffffffu >> (31 - (xb & 31))));
-  if (s_end > s_begin) {
-    const uint32_t j0 = cstart[s_begin], j1 = cstart[s_end];
-    for (uint32_t j = j0; j < j1; ++j) test_candidate(tq[j], (int)j, qx, qy, qz, best);
-  }
+  s_begin = a.y + __popc(a.x & ((1u << (xa & 31)) - 1u));
+  s_end = c.y + __popc(c.x & (0xffffffffu >> (31 - (xb & 31))));
 }
 
-__global__ __launch_bounds__(kNnThreads) void nn_grid(IcpDev b) {
+// distance from q to the nearest face of the cell block [X0,X1]x[Y0,Y1]x[Z0,Z1] that still has grid
+// beyond it: every target point outside the block is at least that far away.  INFINITY = the block
+// covers the whole grid (exhaustive).  A small fp32 slack covers points sitting on a cell face.
+__device__ __forceinline__ float block_guarantee(const PairState* st, float qx, float qy, float qz,
+                                                 int X0, int X1, int Y0, int Y1, int Z0, int Z1) {
+  const float h = st->h;
+  float g = INFINITY;
+  if (X0 > 0) g = fminf(g, qx - (st->origin[0] + (float)X0 * h));
+  if (X1 < st->nx - 1) g = fminf(g, (st->origin[0] + (float)(X1 + 1) * h) - qx);
+  if (Y0 > 0) g = fminf(g, qy - (st->origin[1] + (float)Y0 * h));
+  if (Y1 < st->ny - 1) g = fminf(g, (st->origin[1] + (float)(Y1 + 1) * h) - qy);
+  if (Z0 > 0) g = fminf(g, qz - (st->origin[2] + (float)Z0 * h));
+  if (Z1 < st->nz - 1) g = fminf(g, (st->origin[2] + (float)(Z1 + 1) * h) - qz);
+  return g - 1.0e-3f * h;
+}
+
+__device__ __forceinline__ int cell_coord(float q, float o, float inv_h) {
+  return (int)floorf(fminf(fmaxf((q - o) * inv_h, -1.0e6f), 1.0e6f));
+}
+
+// Phase A -- wave-tile search.  The source is Morton-ordered at upload, so the 64 queries of a
+// wave sit in a handful of neighbouring cells.  The wave takes the bounding block of its queries'
+// cells, grown by `margin` cells, stages every target point of that block in LDS with coalesced
+// loads (one contiguous run of the cell-sorted target per grid row), and all 64 lanes sweep the
+// staged candidates with broadcast LDS reads -- no divergent global gathers, no per-lane loops.
+// A lane is certified when its best distance is within its distance to the block faces; the
+// others (sparse regions, d > margin * h) go to the hard list for the ring search.
+__global__ __launch_bounds__(kNnThreads) void nn_tile(IcpDev b) {
   const int pair = blockIdx.y;
   PairState* st = &b.state[pair];
   if (st->done) return;
   const int ns = st->ns;
-  if ((int)(blockIdx.x * kNnThreads) >= ns) return;
+  const int base = blockIdx.x * (kNnThreads * kTileChunks);
+  if (base >= ns) return;
+  __shared__ uint32_t s_hist[kHistBins];
+  __shared__ float4 s_cand[kNnThreads / 64][kTileCap];
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t so = (size_t)pair * b.ns_cap;
+  const uint2* __restrict__ words = b.words + (size_t)pair * kMaxGridWords;
+  const uint32_t* __restrict__ cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
+  const float4* __restrict__ tq = b.tq + (size_t)pair * b.nt_cap;
+  const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
+  const float inv_h = st->inv_h;
+  const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
+  const int margin = b.tile_margin;
+  float4* cand = s_cand[wave];
+
+  for (int chunk = 0; chunk < kTileChunks; ++chunk) {
+    const int i0 = base + (chunk * (kNnThreads / 64) + wave) * 64;
+    if (i0 >= ns) break;                          // wave-uniform
+    const int i = i0 + lane;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    bool valid = false;
+    if (i < ns) {
+      double px, py, pz;
+      transform_point(st->M, b.src[so + i], px, py, pz);
+      qx = (float)px; qy = (float)py; qz = (float)pz;
+      valid = isfinite(qx) && isfinite(qy) && isfinite(qz);
+    }
+    const int cx = cell_coord(qx, ox, inv_h), cy = cell_coord(qy, oy, inv_h), cz = cell_coord(qz, oz, inv_h);
+    const int big = 0x3fffffff;
+    const int X0 = wave_min_i(valid ? cx : big) - margin, X1 = wave_max_i(valid ? cx : -big) + margin;
+    const int Y0 = wave_min_i(valid ? cy : big) - margin, Y1 = wave_max_i(valid ? cy : -big) + margin;
+    const int Z0 = wave_min_i(valid ? cz : big) - margin, Z1 = wave_max_i(valid ? cz : -big) + margin;
+    Best best = {INFINITY, -1};
+    bool certified = !valid;                      // NaN / inf input: no match, nothing to search
+    if (X1 >= X0) {                               // at least one valid lane (wave-uniform)
+      const int x0 = max(X0, 0), x1 = min(X1, nx - 1);
+      const int y0 = max(Y0, 0), y1 = min(Y1, ny - 1);
+      const int z0 = max(Z0, 0), z1 = min(Z1, nz - 1);
+      const int nry = y1 - y0 + 1, nrz = z1 - z0 + 1;
+      const int rows = (x0 <= x1 && nry > 0 && nrz > 0) ? nry * nrz : 0;
+      const bool too_big = rows > kTileMaxRows;   // incoherent wave: leave everything to the ring search
+      if (!too_big) {
+        int rb = 0;                 // first grid row of the current pass
+        uint32_t skip = 0;          // candidates of row rb already swept (a single row larger than kTileCap)
+        while (rb < rows) {
+          // one grid row per lane: its run [j0, j0 + cnt) of the cell-sorted target
+          const int r = rb + lane;
+          uint32_t j0 = 0, cnt = 0;
+          if (r < rows) {
+            const int y = y0 + r % nry, z = z0 + r / nry;
+            uint32_t sb, se;
+            row_slots(words, (z * ny + y) * wx, x0, x1, sb, se);
+            if (se > sb) { j0 = cstart[sb]; cnt = cstart[se] - j0; }
+          }
+          if (lane == 0) { j0 += skip; cnt -= skip; }
+          const uint32_t incl = wave_incl_scan(cnt, lane);
+          // rows [0, m) of this pass fit in the LDS stage together (incl is monotone)
+          const int m = __popcll(__ballot(incl <= (uint32_t)kTileCap));
+          uint32_t total;
+          if (m == 0) {             // row rb alone overflows the stage: sweep it in kTileCap pieces
+            total = kTileCap;
+            const uint32_t rj0 = __shfl(j0, 0, 64);
+            for (uint32_t k = lane; k < total; k += 64) {
+              float4 t = tq[rj0 + k];
+              t.w = __int_as_float((int)(rj0 + k));
+              cand[k] = t;
+            }
+            skip += total;
+          } else {
+            total = __shfl(incl, m - 1, 64);
+            const uint32_t off = incl - cnt;
+            unsigned long long todo = __ballot(cnt > 0 && lane < m);
+            while (todo) {          // the wave copies one row at a time, 64 points per load instruction
+              const int rr = __ffsll((long long)todo) - 1;
+              todo &= todo - 1;
+              const uint32_t rj0 = __shfl(j0, rr, 64), rc = __shfl(cnt, rr, 64), ro = __shfl(off, rr, 64);
+              for (uint32_t k = lane; k < rc; k += 64) {
+                float4 t = tq[rj0 + k];
+                t.w = __int_as_float((int)(rj0 + k));
+                cand[ro + k] = t;
+              }
+            }
+            rb += m;
+            skip = 0;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          // sweep: every lane tests every staged candidate (LDS broadcast reads), ascending j
+#pragma unroll 4
+          for (uint32_t k = 0; k < total; ++k) {
+            const float4 t = cand[k];
+            test_ascending(t, __float_as_int(t.w), qx, qy, qz, best);
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (valid) {
+          const float g = block_guarantee(st, qx, qy, qz, X0, X1, Y0, Y1, Z0, Z1);
+          certified = (g == INFINITY) || (g > 0.f && best.d2 <= g * g);
+        }
+      } else {
+        best.d2 = INFINITY; best.j = -2;          // -2: nothing was covered, the ring search starts at r = 1
+      }
+    }
+    if (i < ns) {
+      b.d2[so + i] = valid ? best.d2 : INFINITY;
+      b.idx[so + i] = valid ? best.j : -1;
+      if (certified) {
+        const uint32_t key = __float_as_uint(valid ? best.d2 : INFINITY);
+        if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
+      }
+    }
+    // wave-aggregated, order-preserving append of the uncertified lanes to the hard list
+    const bool hard = (i < ns) && !certified;
+    const unsigned long long hm = __ballot(hard);
+    if (hm) {
+      uint32_t basepos = 0;
+      if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
+      basepos = __shfl(basepos, 0, 64);
+      if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
+    }
+  }
+  __syncthreads();
+  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
+    const uint32_t v = s_hist[k];
+    if (v) atomicAdd(&gh[k], v);
+  }
+}
+
+// candidates of the cells x in [xa, xb] of row (y, z): one contiguous run of the sorted target
+__device__ __forceinline__ void search_row(const uint2* __restrict__ words, const uint32_t* __restrict__ cstart,
+                                           const float4* __restrict__ tq, int rowbase, int xa, int xb,
+                                           float qx, float qy, float qz, Best& best) {
+  uint32_t sb, se;
+  row_slots(words, rowbase, xa, xb, sb, se);
+  if (se > sb) {
+    const uint32_t j0 = cstart[sb], j1 = cstart[se];
+    for (uint32_t j = j0; j < j1; ++j) test_any_order(tq[j], (int)j, qx, qy, qz, best);
+  }
+}
+
+// Phase B -- per-query ring search over the hard list (HARD = true), or over every source point
+// (HARD = false: the tile phase is skipped, e.g. for tests).  Rings r = r0, 2 r0, ... <= max_ring;
+// cells already covered by an earlier ring / by the tile phase are skipped.  What is still
+// uncertified afterwards goes to the brute-force fallback list.
+template <bool HARD>
+__global__ __launch_bounds__(kNnThreads) void nn_ring(IcpDev b) {
+  const int pair = blockIdx.y;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  const int count = HARD ? (int)st->hard_count : st->ns;
+  if ((int)(blockIdx.x * kNnThreads) >= count) return;
   __shared__ uint32_t s_hist[kHistBins];
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
   __syncthreads();
-  const int i = blockIdx.x * kNnThreads + threadIdx.x;
-  if (i < ns) {
+  const int e = blockIdx.x * kNnThreads + threadIdx.x;
+  if (e < count) {
     const size_t so = (size_t)pair * b.ns_cap;
+    const int i = HARD ? b.hlist[so + e] : e;
     double px, py, pz;
     transform_point(st->M, b.src[so + i], px, py, pz);
     const float qx = (float)px, qy = (float)py, qz = (float)pz;
-    Best best = {INFINITY, -1, 0x7fffffff};
+    Best best = {INFINITY, -1};
     bool resolved = true;
-    if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) {
-      best.d2 = INFINITY;   // NaN / inf input: no match (libnabo InvalidValue analogue)
-    } else {
+    if (isfinite(qx) && isfinite(qy) && isfinite(qz)) {
       const uint2* words = b.words + (size_t)pair * kMaxGridWords;
       const uint32_t* cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
       const float4* tq = b.tq + (size_t)pair * b.nt_cap;
       const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
-      const float h = st->h, inv_h = st->inv_h;
+      const float inv_h = st->inv_h;
       const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
-      const float lim = 1.0e6f;
-      const int cx = (int)floorf(fminf(fmaxf((qx - ox) * inv_h, -lim), lim));
-      const int cy = (int)floorf(fminf(fmaxf((qy - oy) * inv_h, -lim), lim));
-      const int cz = (int)floorf(fminf(fmaxf((qz - oz) * inv_h, -lim), lim));
-      int rp = 0;   // radius already searched (0 = nothing)
+      const int cx = cell_coord(qx, ox, inv_h), cy = cell_coord(qy, oy, inv_h), cz = cell_coord(qz, oz, inv_h);
+      int rp = 0;           // radius already covered
+      int r = 1;
+      if (HARD && b.idx[so + i] != -2) {   // the tile phase covered at least [c - margin, c + margin]^3 and left its best
+        rp = b.tile_margin;
+        r = 2 * rp;
+        best.d2 = b.d2[so + i];
+        best.j = b.idx[so + i];
+      }
       resolved = false;
-      for (int r = 1; r <= b.max_ring; r = (r < 2 ? 2 : r * 2)) {
+      for (; r <= b.max_ring; r *= 2) {
         const int x0 = max(cx - r, 0), x1 = min(cx + r, nx - 1);
         const int y0 = max(cy - r, 0), y1 = min(cy + r, ny - 1);
         const int z0 = max(cz - r, 0), z1 = min(cz + r, nz - 1);
@@ -327,23 +545,14 @@ __global__ __launch_bounds__(kNnThreads) void nn_grid(IcpDev b) {
               const bool inner = rp > 0 && abs(y - cy) <= rp && abs(z - cz) <= rp;
               if (!inner) {
                 search_row(words, cstart, tq, rowbase, x0, x1, qx, qy, qz, best);
-              } else {   // cells [cx-rp, cx+rp] of this row were searched in an earlier ring
+              } else {
                 const int xl1 = min(cx - rp - 1, nx - 1), xr0 = max(cx + rp + 1, 0);
                 if (x0 <= xl1) search_row(words, cstart, tq, rowbase, x0, xl1, qx, qy, qz, best);
                 if (xr0 <= x1) search_row(words, cstart, tq, rowbase, xr0, x1, qx, qy, qz, best);
               }
             }
         }
-        // Every target point outside the block [c-r, c+r]^3 is at least g away, where g is the
-        // distance to the nearest block face that still has grid beyond it.
-        float g = INFINITY;
-        if (cx - r > 0) g = fminf(g, qx - (ox + (float)(cx - r) * h));
-        if (cx + r < nx - 1) g = fminf(g, (ox + (float)(cx + r + 1) * h) - qx);
-        if (cy - r > 0) g = fminf(g, qy - (oy + (float)(cy - r) * h));
-        if (cy + r < ny - 1) g = fminf(g, (oy + (float)(cy + r + 1) * h) - qy);
-        if (cz - r > 0) g = fminf(g, qz - (oz + (float)(cz - r) * h));
-        if (cz + r < nz - 1) g = fminf(g, (oz + (float)(cz + r + 1) * h) - qz);
-        g -= 1.0e-3f * h;   // fp32 slack for the cell assignment of points sitting on a face
+        const float g = block_guarantee(st, qx, qy, qz, cx - r, cx + r, cy - r, cy + r, cz - r, cz + r);
         if (g == INFINITY || (g > 0.f && best.d2 <= g * g)) { resolved = true; break; }
         rp = r;
       }
@@ -367,24 +576,21 @@ __global__ __launch_bounds__(kNnThreads) void nn_grid(IcpDev b) {
   }
 }
 
-// LDS-tiled exact brute force.  ALL = true: every source point (SMHIP_NN_BRUTE);
-// ALL = false: only the queries the grid kernel could not certify (fallback list).
-template <bool ALL>
+// LDS-tiled exact brute force over every source point (SMHIP_NN_BRUTE, BASELINE config #2).
 __global__ __launch_bounds__(kNnThreads) void nn_brute(IcpDev b) {
   const int pair = blockIdx.y;
   PairState* st = &b.state[pair];
   if (st->done) return;
-  const int count = ALL ? st->ns : (int)st->unresolved_count;
+  const int count = st->ns;
   if ((int)(blockIdx.x * kNnThreads) >= count) return;
   __shared__ float4 s_t[kBruteTile];
   __shared__ uint32_t s_hist[kHistBins];
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
   const size_t so = (size_t)pair * b.ns_cap;
-  const int e = blockIdx.x * kNnThreads + threadIdx.x;
-  const bool active = e < count;
-  const int i = active ? (ALL ? e : b.ulist[so + e]) : 0;
+  const int i = blockIdx.x * kNnThreads + threadIdx.x;
+  const bool active = i < count;
   float qx = 0, qy = 0, qz = 0;
-  Best best = {INFINITY, -1, 0x7fffffff};
+  Best best = {INFINITY, -1};
   bool valid = false;
   if (active) {
     double px, py, pz;
@@ -396,13 +602,13 @@ __global__ __launch_bounds__(kNnThreads) void nn_brute(IcpDev b) {
   const int nt = st->nt;
   for (int base = 0; base < nt; base += kBruteTile) {
     const int m = min(kBruteTile, nt - base);
+    __syncthreads();
     for (int k = threadIdx.x; k < m; k += kNnThreads) s_t[k] = tq[base + k];
     __syncthreads();
     if (valid) {
-#pragma unroll 4
-      for (int k = 0; k < m; ++k) test_candidate(s_t[k], base + k, qx, qy, qz, best);
+#pragma unroll 8
+      for (int k = 0; k < m; ++k) test_ascending(s_t[k], base + k, qx, qy, qz, best);
     }
-    __syncthreads();
   }
   if (active) {
     b.d2[so + i] = best.d2;
@@ -418,10 +624,10 @@ __global__ __launch_bounds__(kNnThreads) void nn_brute(IcpDev b) {
   }
 }
 
-// Fallback for the few queries the grid search could not certify (far / sparse regions).
+// Fallback for the few queries no ring could certify (far outside the target / very sparse).
 // The work (U queries x nt targets) is spread over the whole chip: block (slice, pair) stages one
 // slice of the target in LDS and sweeps ALL unresolved queries of the pair over it; the per-query
-// winner is merged with a 64-bit atomicMin on (d2 bits << 32 | original index).
+// winner is merged with a 64-bit atomicMin on (d2 bits << 32 | sorted position).
 __global__ __launch_bounds__(kNnThreads) void nn_fallback_scan(IcpDev b) {
   const int pair = blockIdx.y;
   PairState* st = &b.state[pair];
@@ -444,10 +650,10 @@ __global__ __launch_bounds__(kNnThreads) void nn_fallback_scan(IcpDev b) {
       double px, py, pz;
       transform_point(st->M, b.src[so + b.ulist[so + e]], px, py, pz);
       const float qx = (float)px, qy = (float)py, qz = (float)pz;
-      Best best = {INFINITY, -1, 0x7fffffff};
+      Best best = {INFINITY, -1};
 #pragma unroll 8
-      for (int k = 0; k < m; ++k) test_candidate(s_t[k], base + k, qx, qy, qz, best);
-      const unsigned long long key = ((unsigned long long)__float_as_uint(best.d2) << 32) | (uint32_t)best.orig;
+      for (int k = 0; k < m; ++k) test_ascending(s_t[k], base + k, qx, qy, qz, best);
+      const unsigned long long key = ((unsigned long long)__float_as_uint(best.d2) << 32) | (uint32_t)best.j;
       atomicMin(&b.ukeys[so + e], key);
     }
   }
@@ -464,9 +670,8 @@ __global__ __launch_bounds__(kNnThreads) void nn_fallback_resolve(IcpDev b) {
   const int i = b.ulist[so + e];
   const unsigned long long key = b.ukeys[so + e];
   const uint32_t dbits = (uint32_t)(key >> 32);
-  const uint32_t orig = (uint32_t)(key & 0xffffffffu);
   b.d2[so + i] = __uint_as_float(dbits);
-  b.idx[so + i] = (int)b.tslot[(size_t)pair * b.nt_cap + orig];
+  b.idx[so + i] = (int)(uint32_t)(key & 0xffffffffu);
   if (dbits < 0x7f800000u) atomicAdd(&b.hist[(size_t)pair * kHistBins + (dbits >> kHistShift)], 1u);
 }
 
@@ -762,6 +967,8 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
 
   st->fallback_total += st->unresolved_count;
   st->unresolved_count = 0;
+  st->hard_total += st->hard_count;
+  st->hard_count = 0;
   st->blist_count = 0;
   st->limit_key = limit_key;
   const double kept = s_tot[28];

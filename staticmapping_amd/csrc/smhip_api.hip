@@ -35,6 +35,9 @@ struct smhip_context {
   int32_t* ids_pinned = nullptr;
   float* d2_pinned = nullptr;
   int32_t* ids_dev = nullptr;    // scratch for exported matches
+  float* d2_dev = nullptr;
+  std::vector<uint64_t> mkeys, mkeys2;   // Morton sort scratch
+  std::vector<int32_t> morder, morder2;
   std::vector<void*> allocs;
   std::string err;
   int last_npairs = 0;
@@ -130,6 +133,7 @@ smhip_status enqueue_prepare(smhip_context* h, int np, int nt_max) {
   hipLaunchKernelGGL(grid_count, gpts, dim3(256), 0, h->stream, d);
   hipLaunchKernelGGL(grid_cscan, dim3(np), dim3(1024), 0, h->stream, d);
   hipLaunchKernelGGL(grid_scatter, gpts, dim3(256), 0, h->stream, d);
+  hipLaunchKernelGGL(grid_sort_cells, gpts, dim3(256), 0, h->stream, d);
   HIPCHK(h, hipGetLastError());
   return SMHIP_OK;
 }
@@ -138,14 +142,69 @@ smhip_status enqueue_find_closests(smhip_context* h, int np, int ns_max) {
   IcpDev& d = h->dev;
   const dim3 g(ceil_div(ns_max, kNnThreads), np);
   if (h->opts.nn_mode == SMHIP_NN_GRID) {
-    { Bracket br(h, 4); hipLaunchKernelGGL(nn_grid, g, dim3(kNnThreads), 0, h->stream, d); }
+    if (d.use_tile) {
+      { Bracket br(h, 4); hipLaunchKernelGGL(nn_tile, dim3(ceil_div(ns_max, kNnThreads * kTileChunks), np), dim3(kNnThreads), 0, h->stream, d); }
+      { Bracket br(h, 1); hipLaunchKernelGGL(nn_ring<true>, g, dim3(kNnThreads), 0, h->stream, d); }
+    } else {
+      Bracket br(h, 4);
+      hipLaunchKernelGGL(nn_ring<false>, g, dim3(kNnThreads), 0, h->stream, d);
+    }
     { Bracket br(h, 1); hipLaunchKernelGGL(nn_fallback_scan, dim3(kFallbackSlices, np), dim3(kNnThreads), 0, h->stream, d); }
     { Bracket br(h, 1); hipLaunchKernelGGL(nn_fallback_resolve, g, dim3(kNnThreads), 0, h->stream, d); }
   } else {
     Bracket br(h, 4);
-    hipLaunchKernelGGL(nn_brute<true>, g, dim3(kNnThreads), 0, h->stream, d);
+    hipLaunchKernelGGL(nn_brute, g, dim3(kNnThreads), 0, h->stream, d);
   }
   return SMHIP_OK;
+}
+
+// Morton (Z-order) permutation of a staged cloud: consecutive points end up spatially close, which
+// is what makes the 64 queries of a wavefront share their candidate set in nn_tile.
+inline uint64_t spread21(uint64_t v) {
+  v &= 0x1fffffull;
+  v = (v | (v << 32)) & 0x1f00000000ffffull;
+  v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+  v = (v | (v << 8)) & 0x100f00f00f00f00full;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+
+void morton_permute(smhip_context* h, float4* pts, int n) {
+  float mn[3] = {INFINITY, INFINITY, INFINITY};
+  for (int i = 0; i < n; ++i) {
+    if (std::isfinite(pts[i].x)) mn[0] = std::min(mn[0], pts[i].x);
+    if (std::isfinite(pts[i].y)) mn[1] = std::min(mn[1], pts[i].y);
+    if (std::isfinite(pts[i].z)) mn[2] = std::min(mn[2], pts[i].z);
+  }
+  const float inv = 1.0f / 0.0625f;     // 6.25 cm quantum
+  auto quant = [&](float v, float lo) -> uint64_t {
+    if (!std::isfinite(v) || !std::isfinite(lo)) return 0;
+    const float q = (v - lo) * inv;
+    return (uint64_t)std::min(std::max(q, 0.0f), 2097151.0f);
+  };
+  h->mkeys.resize(n); h->mkeys2.resize(n); h->morder.resize(n); h->morder2.resize(n);
+  for (int i = 0; i < n; ++i) {
+    h->mkeys[i] = spread21(quant(pts[i].x, mn[0])) | (spread21(quant(pts[i].y, mn[1])) << 1) | (spread21(quant(pts[i].z, mn[2])) << 2);
+    h->morder[i] = i;
+  }
+  // LSD radix sort, 4 passes of 16 bits (63-bit keys)
+  std::vector<uint32_t> cnt(65536);
+  uint64_t* ka = h->mkeys.data(); uint64_t* kb = h->mkeys2.data();
+  int32_t* oa = h->morder.data(); int32_t* ob = h->morder2.data();
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 16 * pass;
+    std::fill(cnt.begin(), cnt.end(), 0u);
+    for (int i = 0; i < n; ++i) cnt[(ka[i] >> shift) & 0xffff]++;
+    uint32_t run = 0;
+    for (auto& c : cnt) { const uint32_t t = c; c = run; run += t; }
+    for (int i = 0; i < n; ++i) { const uint32_t p = cnt[(ka[i] >> shift) & 0xffff]++; kb[p] = ka[i]; ob[p] = oa[i]; }
+    std::swap(ka, kb); std::swap(oa, ob);
+  }
+  // apply (after 4 passes the result is back in mkeys/morder); w keeps the caller's index
+  float4* tmp = pts + n;                 // second half of the staging buffer
+  for (int i = 0; i < n; ++i) { tmp[i] = pts[oa[i]]; tmp[i].w = __builtin_bit_cast(float, (int32_t)oa[i]); }
+  std::memcpy(pts, tmp, sizeof(float4) * (size_t)n);
 }
 
 smhip_status fill_inputs(smhip_context* h, int np, const double* guesses, int* ns_max, int* nt_max) {
@@ -169,20 +228,26 @@ void sync_options(smhip_context* h) {
   h->dev.max_ring = std::max(1, h->opts.grid_max_ring);
   h->dev.rho = h->opts.dist_outlier_ratio;
   h->dev.grid_cell = h->opts.grid_cell > 0 ? h->opts.grid_cell : 0.5f;
+  h->dev.tile_margin = std::min(std::max(1, h->opts.tile_margin), 8);
+  h->dev.use_tile = h->opts.use_tile;
 }
 
-__global__ void export_matches(IcpDev b, int pair, int32_t* out) {
+// FindClosests output in the caller's order: source i was uploaded from caller index src.w,
+// target position j holds caller index tq.w.
+__global__ void export_matches(IcpDev b, int pair, int32_t* out_ids, float* out_d2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.state[pair].ns) return;
+  const int orig = __float_as_int(b.src[(size_t)pair * b.ns_cap + i].w);
   const int j = b.idx[(size_t)pair * b.ns_cap + i];
-  out[i] = j < 0 ? -1 : __float_as_int(b.tq[(size_t)pair * b.nt_cap + j].w);
+  out_ids[orig] = j < 0 ? -1 : __float_as_int(b.tq[(size_t)pair * b.nt_cap + j].w);
+  out_d2[orig] = b.d2[(size_t)pair * b.ns_cap + i];
 }
 
 smhip_status fetch_matches(smhip_context* h, int slot, int32_t* ids, float* d2, int n) {
-  if (n > h->ns[slot]) { h->err = "n exceeds the slot's source size"; return SMHIP_ERR_INVALID_ARGUMENT; }
-  hipLaunchKernelGGL(export_matches, dim3(ceil_div(n, 256)), dim3(256), 0, h->stream, h->dev, slot, h->ids_dev);
+  if (n != h->ns[slot]) { h->err = "n must equal the slot's source size"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  hipLaunchKernelGGL(export_matches, dim3(ceil_div(n, 256)), dim3(256), 0, h->stream, h->dev, slot, h->ids_dev, h->d2_dev);
   HIPCHK(h, hipMemcpyAsync(h->ids_pinned, h->ids_dev, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->d2_pinned, h->dev.d2 + (size_t)slot * h->dev.ns_cap, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d2_pinned, h->d2_dev, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (ids) std::memcpy(ids, h->ids_pinned, sizeof(int32_t) * n);
   if (d2) std::memcpy(d2, h->d2_pinned, sizeof(float) * n);
@@ -230,6 +295,8 @@ void smhip_icp_default_options(smhip_icp_options* o) {
   o->grid_cell = 0.5f;
   o->grid_max_ring = 4;
   o->check_every = 8;
+  o->tile_margin = 1;
+  o->use_tile = 1;
 }
 
 smhip_status smhip_create(int device, void* stream, int pair_slots, int max_source_points, int max_target_points,
@@ -273,6 +340,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, &d.d2, B * NS));
   A(dev_alloc(h, &d.idx, B * NS));
   A(dev_alloc(h, &d.hist, B * kHistBins));
+  A(dev_alloc(h, &d.hlist, B * NS));
   A(dev_alloc(h, &d.ulist, B * NS));
   A(dev_alloc(h, &d.ukeys, B * NS));
   A(dev_alloc(h, &d.blist, B * NS));
@@ -280,6 +348,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, &d.tpart, B * kTgtReduceBlocks * 16));
   A(dev_alloc(h, &d.done_count, 4));
   A(dev_alloc(h, &h->ids_dev, NS));
+  A(dev_alloc(h, &h->d2_dev, NS));
   if (s == SMHIP_OK) {
     const size_t stage_n = 2 * std::max(NS, NT);
     if (hipHostMalloc(reinterpret_cast<void**>(&h->stage), stage_n * sizeof(float4)) != hipSuccess ||
@@ -352,6 +421,7 @@ smhip_status smhip_set_source_f64(smhip_handle h, int slot, const double* xyz, i
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));   // staging buffer reuse
   for (int i = 0; i < n; ++i) h->stage[i] = make_float4((float)xyz[3 * i], (float)xyz[3 * i + 1], (float)xyz[3 * i + 2], 0.f);
+  morton_permute(h, h->stage, n);
   s = upload(h, h->dev.src + (size_t)slot * h->dev.ns_cap, h->stage, n);
   if (s) return s;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -367,6 +437,7 @@ smhip_status smhip_set_source_f32(smhip_handle h, int slot, const float* xyz, in
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < n; ++i) h->stage[i] = make_float4(xyz[(size_t)stride * i], xyz[(size_t)stride * i + 1], xyz[(size_t)stride * i + 2], 0.f);
+  morton_permute(h, h->stage, n);
   s = upload(h, h->dev.src + (size_t)slot * h->dev.ns_cap, h->stage, n);
   if (s) return s;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -485,6 +556,8 @@ smhip_status smhip_icp_fetch_batch(smhip_handle h, int npairs, double* results, 
       stats[p].limit_d2 = lim;
       stats[p].fallback_queries = (int32_t)st.fallback_total;
       stats[p].status = st.status;
+      stats[p].hard_queries = (int32_t)st.hard_total;
+      stats[p].reserved = 0;
     }
     if (st.status != SMHIP_OK && worst == SMHIP_OK) { worst = st.status; h->err = "pair failed: no finite correspondence"; }
     if (!st.done && worst == SMHIP_OK) { worst = SMHIP_ERR_HIP; h->err = "pair did not finish (internal)"; }

@@ -17,7 +17,10 @@ constexpr int kAccCols = 32;             // 21 (A upper) + 6 (b) + 1 (sum sqrt d
 constexpr int kMaxGridWords = 1 << 16;   // 32-cell words per pair (2 Mi cells)
 constexpr int kTgtReduceBlocks = 32;     // partial blocks for the target mean / bbox
 constexpr int kBruteTile = 1024;
-constexpr int kFallbackSlices = 64;      // target slices the fallback sweep is spread over         // target points staged in LDS per tile (16 KiB as float4)
+constexpr int kFallbackSlices = 64;
+constexpr int kTileChunks = 8;           // wave-tiles each wave of nn_tile processes (2048 queries per block)
+constexpr int kTileCap = 512;            // target points one wave stages in LDS per pass (8 KiB)
+constexpr int kTileMaxRows = 1024;       // larger blocks (incoherent waves) go straight to the ring search      // target slices the fallback sweep is spread over         // target points staged in LDS per tile (16 KiB as float4)
 
 // Per-pair device state.  Everything an iteration needs and everything the host reads back.
 struct PairState {
@@ -48,6 +51,8 @@ struct PairState {
   uint32_t unresolved_count;
   uint32_t blist_count;
   uint32_t fallback_total;
+  uint32_t hard_count;
+  uint32_t hard_total;
   int32_t kept;
   uint32_t limit_key;
   // outputs
@@ -85,6 +90,7 @@ struct IcpDev {
   float* d2;                 // [slots][ns_cap]
   int32_t* idx;              // [slots][ns_cap] index into tq/tn (sorted order)
   uint32_t* hist;            // [slots][kHistBins]
+  int32_t* hlist;            // [slots][ns_cap] queries the tile phase could not certify (ring search)
   int32_t* ulist;            // [slots][ns_cap] unresolved queries (brute-force fallback)
   unsigned long long* ukeys; // [slots][ns_cap] fallback winners: (d2 bits << 32) | original target index
   int32_t* blist;            // [slots][ns_cap] queries whose d2 falls in the quantile's histogram bin
@@ -95,6 +101,8 @@ struct IcpDev {
   int32_t max_iteration;
   int32_t early_exit;
   int32_t max_ring;
+  int32_t tile_margin;       // cells added around a wave's bounding block in nn_tile
+  int32_t use_tile;          // 0 = skip the tile phase (ring search over every query)
   float rho;                 // dist_outlier_ratio as float (widened to double exactly like the reference)
   float grid_cell;
 };

@@ -144,7 +144,8 @@ class IcpFastHip:
                                              res.ctypes.data_as(_capi.c_double_p),
                                              scores.ctypes.data_as(_capi.c_double_p), stats)
         self.last_stats = [dict(iterations=s.iterations, kept=s.kept, limit_d2=s.limit_d2,
-                                fallback_queries=s.fallback_queries, status=s.status) for s in stats]
+                                fallback_queries=s.fallback_queries, status=s.status,
+                                hard_queries=s.hard_queries) for s in stats]
         self._check(st)
         return res.reshape(npairs, 4, 4).transpose(0, 2, 1).copy(), scores, self.last_stats
 
@@ -159,7 +160,8 @@ class IcpFastHip:
         st = self._lib.smhip_icp_fetch_batch(self._h, npairs, res.ctypes.data_as(_capi.c_double_p),
                                              scores.ctypes.data_as(_capi.c_double_p), stats)
         self.last_stats = [dict(iterations=s.iterations, kept=s.kept, limit_d2=s.limit_d2,
-                                fallback_queries=s.fallback_queries, status=s.status) for s in stats]
+                                fallback_queries=s.fallback_queries, status=s.status,
+                                hard_queries=s.hard_queries) for s in stats]
         self._check(st)
         return res.reshape(npairs, 4, 4).transpose(0, 2, 1).copy(), scores, self.last_stats
 

@@ -26,13 +26,21 @@ def _oracle_nn(q, src, T):
     return cref.nn(q - mu, P)
 
 
-@pytest.mark.parametrize("mode", ["grid", "brute"])
+NN_VARIANTS = {
+    "tile": dict(nn_mode=1, use_tile=1),                    # wave-tile phase + ring search + fallback (default)
+    "tile_margin2": dict(nn_mode=1, use_tile=1, tile_margin=2, grid_cell=0.25),
+    "ring": dict(nn_mode=1, use_tile=0),                    # per-query ring search only
+    "ring_small": dict(nn_mode=1, use_tile=0, grid_max_ring=1),   # most queries through the brute fallback
+    "brute": dict(nn_mode=0),
+}
+
+
+@pytest.mark.parametrize("mode", list(NN_VARIANTS))
 def test_find_closests_matches_exact_nn(smhip, velo20k, mode):
     """K1 alone: identical ids (>= 99.99 %) and squared distances."""
     c = velo20k
     src = c["src"][:, :3].astype(np.float64)
-    m = smhip.IcpFastHip(max_source_points=len(src), max_target_points=len(c["q"]),
-                         nn_mode=1 if mode == "grid" else 0)
+    m = smhip.IcpFastHip(max_source_points=len(src), max_target_points=len(c["q"]), **NN_VARIANTS[mode])
     m.set_input_source(c["src"])
     m.set_input_target(c["q"], c["n"])
     ids, d2 = m.find_closests(c["guess"], len(src))
@@ -45,18 +53,19 @@ def test_find_closests_matches_exact_nn(smhip, velo20k, mode):
     m.close()
 
 
-def test_grid_equals_brute_bitwise(smhip, velo20k):
-    """Both searches are exact with the same tie rule, so they agree bit for bit."""
+def test_all_search_variants_agree_bitwise(smhip, velo20k):
+    """Every variant is exact with the same tie rule, so they agree bit for bit."""
     c = velo20k
-    out = []
-    for mode in (0, 1):
-        m = smhip.IcpFastHip(max_source_points=len(c["src"]), max_target_points=len(c["q"]), nn_mode=mode)
+    out = {}
+    for name, opts in NN_VARIANTS.items():
+        m = smhip.IcpFastHip(max_source_points=len(c["src"]), max_target_points=len(c["q"]), **opts)
         m.set_input_source(c["src"])
         m.set_input_target(c["q"], c["n"])
-        out.append(m.find_closests(np.eye(4), len(c["src"])))
+        out[name] = m.find_closests(np.eye(4), len(c["src"]))
         m.close()
-    assert np.array_equal(out[0][0], out[1][0])
-    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    for name in out:
+        assert np.array_equal(out[name][0], out["brute"][0]), name
+        assert np.array_equal(out[name][1].view(np.uint32), out["brute"][1].view(np.uint32)), name
 
 
 def _align_both(smhip, case, guess, **opts):
@@ -84,9 +93,9 @@ def test_cfg1_plumbing_parity(smhip, cfg1):
     assert abs(score - ref["score"]) < 1e-4
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", ["tile", "ring", "brute"])
 def test_velodyne20k_parity_early_exit(smhip, velo20k, mode):
-    ok, R, score, stats, ref = _align_both(smhip, velo20k, velo20k["guess"], nn_mode=mode)
+    ok, R, score, stats, ref = _align_both(smhip, velo20k, velo20k["guess"], **NN_VARIANTS[mode])
     da, dt = smhip.se3_error(R, ref["result"])
     assert da < ROT_TOL and dt < TRANS_TOL, (da, dt)
     assert stats["iterations"] == ref["iterations"]

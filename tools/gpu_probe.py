@@ -14,6 +14,8 @@ cells = [float(x) for x in kv.get("cell", "0.5").split(",")]
 rings = [int(x) for x in kv.get("ring", "4").split(",")]
 mortons = [int(x) for x in kv.get("morton", "0").split(",")]
 modes = [int(x) for x in kv.get("mode", "1").split(",")]
+tiles = [int(x) for x in kv.get("tile", "1").split(",")]
+margins = [int(x) for x in kv.get("margin", "1").split(",")]
 
 
 def morton_order(p, cell=0.25):
@@ -40,8 +42,10 @@ for mode in modes:
     b = b0[morton_order(b0[:, :3].astype(np.float64))] if morton else b0
     for cell in cells:
       for ring in rings:
-        for B in batches:
-            m = sm.IcpFastHip(pair_slots=B, max_source_points=len(b), max_target_points=len(q),
+       for tile in tiles:
+        for margin in margins:
+         for B in batches:
+            m = sm.IcpFastHip(pair_slots=B, max_source_points=len(b), max_target_points=len(q), use_tile=tile, tile_margin=margin,
                               max_iteration=20, early_exit=0, nn_mode=mode, grid_cell=cell, grid_max_ring=ring)
             m.set_input_source(b); m.set_input_target(q, n)
             for s in range(1, B): m.copy_slot(0, s)
@@ -51,7 +55,7 @@ for mode in modes:
             for _ in range(reps): R, sc, st = m.align_batch(B, g)
             dt = (time.time() - t) / reps
             m.enable_profile(True); m.align_batch(B, g); p = m.get_profile(); m.enable_profile(False)
-            print(f"mode={'grid' if mode else 'brute'} morton={morton} cell={cell} ring={ring} B={B} {dt*1e3:.2f} ms/batch "
-                  f"{B/dt:.1f} align/s fallback={st[0]['fallback_queries']} err={sm.se3_error(R[0], T)}", flush=True)
+            print(f"mode={'grid' if mode else 'brute'} tile={tile} margin={margin} cell={cell} ring={ring} B={B} {dt*1e3:.2f} ms/batch "
+                  f"{B/dt:.1f} align/s hard={st[0]['hard_queries']} fallback={st[0]['fallback_queries']} err={sm.se3_error(R[0], T)}", flush=True)
             print("   ", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in p.items()}, flush=True)
             m.close()

@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic scan pairs (replicated over the slots)")
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--nn-mode", choices=["grid", "brute"], default="grid")
-    ap.add_argument("--cell", type=float, default=0.35)
+    ap.add_argument("--cell", type=float, default=0.25)
     ap.add_argument("--ring", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -188,7 +188,7 @@ def main():
                        "pairs_per_gpu": B, "global_pairs_per_step": n_total, "source_points": ns,
                        "target_points": nt, "iterations": ICP_ITERS, "nn_mode": args.nn_mode,
                        "grid_cell_m": args.cell, "parallelism": f"pairs round-robin over {world} GPU(s), one RCCL gather of poses"},
-            "roofline": {"bound": "hbm", "kernel": "nn_grid" if args.nn_mode == "grid" else "nn_brute",
+            "roofline": {"bound": "hbm", "kernel": "nn_ball" if args.nn_mode == "grid" else "nn_brute",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "bytes_per_launch": nn_bytes, "avg_launch_ms": round(nn_ms, 4),

@@ -62,12 +62,16 @@ typedef struct smhip_icp_options {
   int32_t early_exit;           /* 1 = CheckConvergence enabled (reference behaviour, icp_fast.cc:377-405);
                                    0 = run exactly max_iteration iterations (throughput runs) */
   int32_t nn_mode;              /* SMHIP_NN_GRID (default) or SMHIP_NN_BRUTE */
-  float grid_cell;              /* voxel edge in metres for SMHIP_NN_GRID (default 0.5) */
+  float grid_cell;              /* voxel edge in metres for SMHIP_NN_GRID (default 0.25) */
   int32_t grid_max_ring;        /* largest ring searched in the grid before the brute-force fallback (default 4) */
   int32_t check_every;          /* host polls the device "all done" word every this many iterations (default 8) */
-  int32_t tile_margin;          /* cells added around a wave's bounding block in the tile phase (default 1) */
-  int32_t use_tile;             /* 1 (default): wave-tile phase + ring search on the rest; 0: ring search only */
-  int32_t reserved[6];
+  int32_t use_ball;             /* 1 (default): ball-bounded search seeded by the previous iteration's match, with
+                                   certified trimming (matches beyond the quantile carry a proven lower bound
+                                   instead of an exact distance); 0: exact ring search for every query */
+  int32_t exact_matches;        /* 1: refine every lower bound to the exact match in every iteration (default 0;
+                                   the transform / score are identical either way, only rejected matches differ) */
+  float ball_radius;            /* largest search radius of the ball search in metres (default 0.5) */
+  int32_t reserved[5];
 } smhip_icp_options;
 
 /* Per-call statistics (all optional to read). */
@@ -77,8 +81,8 @@ typedef struct smhip_icp_stats {
   double limit_d2;              /* the quantile (squared distance) of the last iteration */
   int32_t fallback_queries;     /* queries resolved by the brute-force fallback, summed over iterations */
   int32_t status;               /* per-pair smhip_status */
-  int32_t hard_queries;         /* queries the tile phase handed to the ring search, summed over iterations */
-  int32_t reserved;
+  int32_t hard_queries;         /* matches recorded as lower bounds by the ball search, summed over iterations */
+  int32_t refined_iterations;   /* iterations in which those bounds had to be refined to exact matches */
 } smhip_icp_stats;
 
 /* Kernel-time breakdown collected when profiling is enabled (HIP events on the
@@ -159,7 +163,9 @@ smhip_status smhip_calculate_normals_f64(const double* xyz_colmajor_3xN, int n, 
 
 /* ---- introspection for parity tests ------------------------------------
  * Matches of the LAST executed iteration of `slot` (FindClosests output, icp_fast.cc:169-180):
- * ids index the target cloud in the caller's order, d2 are squared distances (float32). */
+ * ids index the target cloud in the caller's order, d2 are squared distances (float32).  Every match
+ * the trimmed-distance filter KEPT is exact; with use_ball = 1 and exact_matches = 0 a rejected match
+ * may carry a certified lower bound (> the quantile) and the best target seen so far instead. */
 smhip_status smhip_icp_get_matches(smhip_handle h, int slot, int32_t* ids, float* d2, int n);
 /* One FindClosests pass only: transform the slot's source by T (column-major 4x4, applied AFTER
  * centring exactly as Align does) and return ids / d2 without running ICP. */

@@ -15,13 +15,14 @@ class IcpOptions(ctypes.Structure):
     _fields_ = [("max_iteration", ctypes.c_int32), ("dist_outlier_ratio", ctypes.c_float),
                 ("early_exit", ctypes.c_int32), ("nn_mode", ctypes.c_int32), ("grid_cell", ctypes.c_float),
                 ("grid_max_ring", ctypes.c_int32), ("check_every", ctypes.c_int32),
-                ("tile_margin", ctypes.c_int32), ("use_tile", ctypes.c_int32), ("reserved", ctypes.c_int32 * 6)]
+                ("use_ball", ctypes.c_int32), ("exact_matches", ctypes.c_int32), ("ball_radius", ctypes.c_float),
+                ("reserved", ctypes.c_int32 * 5)]
 
 
 class IcpStats(ctypes.Structure):
     _fields_ = [("iterations", ctypes.c_int32), ("kept", ctypes.c_int32), ("limit_d2", ctypes.c_double),
                 ("fallback_queries", ctypes.c_int32), ("status", ctypes.c_int32), ("hard_queries", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("refined_iterations", ctypes.c_int32)]
 
 
 class IcpProfile(ctypes.Structure):

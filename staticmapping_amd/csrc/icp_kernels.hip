@@ -158,6 +158,8 @@ __global__ void grid_setup(IcpDev b, int npairs) {
   st->n_hist = 1;
   st->iter = 0; st->done = 0; st->status = 0;
   st->unresolved_count = 0; st->blist_count = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
+  st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0;
+  st->rcap2 = b.ball_radius * b.ball_radius;
   st->kept = 0; st->limit_key = 0; st->score = 0; st->nocc = 0;
 }
 
@@ -338,134 +340,97 @@ __device__ __forceinline__ int cell_coord(float q, float o, float inv_h) {
   return (int)floorf(fminf(fmaxf((q - o) * inv_h, -1.0e6f), 1.0e6f));
 }
 
-// Phase A -- wave-tile search.  The source is Morton-ordered at upload, so the 64 queries of a
-// wave sit in a handful of neighbouring cells.  The wave takes the bounding block of its queries'
-// cells, grown by `margin` cells, stages every target point of that block in LDS with coalesced
-// loads (one contiguous run of the cell-sorted target per grid row), and all 64 lanes sweep the
-// staged candidates with broadcast LDS reads -- no divergent global gathers, no per-lane loops.
-// A lane is certified when its best distance is within its distance to the block faces; the
-// others (sparse regions, d > margin * h) go to the hard list for the ring search.
-__global__ __launch_bounds__(kNnThreads) void nn_tile(IcpDev b) {
+__device__ __forceinline__ void search_row(const uint2* __restrict__ words, const uint32_t* __restrict__ cstart,
+                                           const float4* __restrict__ tq, int rowbase, int xa, int xb,
+                                           float qx, float qy, float qz, Best& best);
+
+// Phase A -- ball-bounded search, one query per lane.
+//
+// Two facts make the per-iteration search tiny:
+//  (1) temporal coherence: the target is static during Align, so last iteration's match t_prev is
+//      still a target point and |q - t_prev| bounds the new nearest distance from above;
+//  (2) certified trimming: IcpFast only uses matches with d2 <= the 0.7-quantile
+//      (icp_fast.cc:496-498).  A query whose nearest neighbour is provably farther than the radius
+//      R_cap actually searched is recorded with the LOWER bound R_cap^2; as long as the quantile
+//      comes out below every such bound (checked by nn_validate before anything consumes it) the
+//      kept set, A, b, limit and score are exactly those of a full exact search.  If the check
+//      fails (first iteration from a poor guess, dist_outlier_ratio = 1, ...) the ring search and
+//      the brute-force fallback make every match exact, as they always do for find_closests.
+// So each lane visits only the cells meeting the ball (q, min(|q - t_prev|, R_cap)): typically
+// 1-2 cells per axis once ICP has settled.
+__global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b) {
   const int pair = blockIdx.y;
   PairState* st = &b.state[pair];
   if (st->done) return;
   const int ns = st->ns;
-  const int base = blockIdx.x * (kNnThreads * kTileChunks);
+  const int base = blockIdx.x * (kNnThreads * kBallItems);
   if (base >= ns) return;
   __shared__ uint32_t s_hist[kHistBins];
-  __shared__ float4 s_cand[kNnThreads / 64][kTileCap];
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   const size_t so = (size_t)pair * b.ns_cap;
   const uint2* __restrict__ words = b.words + (size_t)pair * kMaxGridWords;
   const uint32_t* __restrict__ cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
   const float4* __restrict__ tq = b.tq + (size_t)pair * b.nt_cap;
   const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
-  const float inv_h = st->inv_h;
+  const float h = st->h, inv_h = st->inv_h;
   const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
-  const int margin = b.tile_margin;
-  float4* cand = s_cand[wave];
+  const float r2cap = st->rcap2;
+  const bool have_prev = st->iter > 0;
+  uint32_t min_lb = 0xffffffffu;
 
-  for (int chunk = 0; chunk < kTileChunks; ++chunk) {
-    const int i0 = base + (chunk * (kNnThreads / 64) + wave) * 64;
-    if (i0 >= ns) break;                          // wave-uniform
-    const int i = i0 + lane;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    bool valid = false;
+  for (int it = 0; it < kBallItems; ++it) {
+    const int i = base + it * kNnThreads + threadIdx.x;
+    bool hard = false;
     if (i < ns) {
       double px, py, pz;
       transform_point(st->M, b.src[so + i], px, py, pz);
-      qx = (float)px; qy = (float)py; qz = (float)pz;
-      valid = isfinite(qx) && isfinite(qy) && isfinite(qz);
-    }
-    const int cx = cell_coord(qx, ox, inv_h), cy = cell_coord(qy, oy, inv_h), cz = cell_coord(qz, oz, inv_h);
-    const int big = 0x3fffffff;
-    const int X0 = wave_min_i(valid ? cx : big) - margin, X1 = wave_max_i(valid ? cx : -big) + margin;
-    const int Y0 = wave_min_i(valid ? cy : big) - margin, Y1 = wave_max_i(valid ? cy : -big) + margin;
-    const int Z0 = wave_min_i(valid ? cz : big) - margin, Z1 = wave_max_i(valid ? cz : -big) + margin;
-    Best best = {INFINITY, -1};
-    bool certified = !valid;                      // NaN / inf input: no match, nothing to search
-    if (X1 >= X0) {                               // at least one valid lane (wave-uniform)
-      const int x0 = max(X0, 0), x1 = min(X1, nx - 1);
-      const int y0 = max(Y0, 0), y1 = min(Y1, ny - 1);
-      const int z0 = max(Z0, 0), z1 = min(Z1, nz - 1);
-      const int nry = y1 - y0 + 1, nrz = z1 - z0 + 1;
-      const int rows = (x0 <= x1 && nry > 0 && nrz > 0) ? nry * nrz : 0;
-      const bool too_big = rows > kTileMaxRows;   // incoherent wave: leave everything to the ring search
-      if (!too_big) {
-        int rb = 0;                 // first grid row of the current pass
-        uint32_t skip = 0;          // candidates of row rb already swept (a single row larger than kTileCap)
-        while (rb < rows) {
-          // one grid row per lane: its run [j0, j0 + cnt) of the cell-sorted target
-          const int r = rb + lane;
-          uint32_t j0 = 0, cnt = 0;
-          if (r < rows) {
-            const int y = y0 + r % nry, z = z0 + r / nry;
-            uint32_t sb, se;
-            row_slots(words, (z * ny + y) * wx, x0, x1, sb, se);
-            if (se > sb) { j0 = cstart[sb]; cnt = cstart[se] - j0; }
+      const float qx = (float)px, qy = (float)py, qz = (float)pz;
+      Best best = {INFINITY, -1};
+      float d2out = INFINITY;
+      if (isfinite(qx) && isfinite(qy) && isfinite(qz)) {
+        float R2 = r2cap;
+        if (have_prev) {
+          const int jp = b.idx[so + i];
+          if (jp >= 0) {
+            best.d2 = dist2(tq[jp], qx, qy, qz);
+            best.j = jp;
+            R2 = fminf(R2, best.d2);
           }
-          if (lane == 0) { j0 += skip; cnt -= skip; }
-          const uint32_t incl = wave_incl_scan(cnt, lane);
-          // rows [0, m) of this pass fit in the LDS stage together (incl is monotone)
-          const int m = __popcll(__ballot(incl <= (uint32_t)kTileCap));
-          uint32_t total;
-          if (m == 0) {             // row rb alone overflows the stage: sweep it in kTileCap pieces
-            total = kTileCap;
-            const uint32_t rj0 = __shfl(j0, 0, 64);
-            for (uint32_t k = lane; k < total; k += 64) {
-              float4 t = tq[rj0 + k];
-              t.w = __int_as_float((int)(rj0 + k));
-              cand[k] = t;
-            }
-            skip += total;
-          } else {
-            total = __shfl(incl, m - 1, 64);
-            const uint32_t off = incl - cnt;
-            unsigned long long todo = __ballot(cnt > 0 && lane < m);
-            while (todo) {          // the wave copies one row at a time, 64 points per load instruction
-              const int rr = __ffsll((long long)todo) - 1;
-              todo &= todo - 1;
-              const uint32_t rj0 = __shfl(j0, rr, 64), rc = __shfl(cnt, rr, 64), ro = __shfl(off, rr, 64);
-              for (uint32_t k = lane; k < rc; k += 64) {
-                float4 t = tq[rj0 + k];
-                t.w = __int_as_float((int)(rj0 + k));
-                cand[ro + k] = t;
-              }
-            }
-            rb += m;
-            skip = 0;
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          // sweep: every lane tests every staged candidate (LDS broadcast reads), ascending j
-#pragma unroll 4
-          for (uint32_t k = 0; k < total; ++k) {
-            const float4 t = cand[k];
-            test_ascending(t, __float_as_int(t.w), qx, qy, qz, best);
-          }
-          __builtin_amdgcn_wave_barrier();
         }
-        if (valid) {
-          const float g = block_guarantee(st, qx, qy, qz, X0, X1, Y0, Y1, Z0, Z1);
-          certified = (g == INFINITY) || (g > 0.f && best.d2 <= g * g);
+        // every target point within sqrt(R2) of q lies in a cell meeting [q - Rs, q + Rs]^3
+        const float Rs = sqrtf(R2) * 1.0001f + 1.0e-3f * h;
+        const int x0 = max(cell_coord(qx - Rs, ox, inv_h), 0), x1 = min(cell_coord(qx + Rs, ox, inv_h), nx - 1);
+        const int y0 = max(cell_coord(qy - Rs, oy, inv_h), 0), y1 = min(cell_coord(qy + Rs, oy, inv_h), ny - 1);
+        const int z0 = max(cell_coord(qz - Rs, oz, inv_h), 0), z1 = min(cell_coord(qz + Rs, oz, inv_h), nz - 1);
+        if (x0 <= x1) {
+          const float slack = 2.0e-3f * h;
+          for (int z = z0; z <= z1; ++z) {
+            const float zl = oz + (float)z * h;
+            const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + h)) - slack, 0.f);
+            for (int y = y0; y <= y1; ++y) {
+              const float yl = oy + (float)y * h;
+              const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + h)) - slack, 0.f);
+              if (fmaf(dy, dy, dz * dz) > fminf(best.d2, R2)) continue;     // the row cannot hold anything useful
+              search_row(words, cstart, tq, (z * ny + y) * wx, x0, x1, qx, qy, qz, best);
+            }
+          }
         }
-      } else {
-        best.d2 = INFINITY; best.j = -2;          // -2: nothing was covered, the ring search starts at r = 1
+        if (best.d2 <= R2) {
+          d2out = best.d2;                      // exact: everything within sqrt(R2) was seen
+        } else {
+          d2out = R2;                           // certified lower bound: nothing lies within sqrt(R2)
+          hard = true;
+          min_lb = min(min_lb, __float_as_uint(R2));
+        }
       }
+      b.d2[so + i] = d2out;
+      b.idx[so + i] = best.j;
+      const uint32_t key = __float_as_uint(d2out);
+      if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
     }
-    if (i < ns) {
-      b.d2[so + i] = valid ? best.d2 : INFINITY;
-      b.idx[so + i] = valid ? best.j : -1;
-      if (certified) {
-        const uint32_t key = __float_as_uint(valid ? best.d2 : INFINITY);
-        if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
-      }
-    }
-    // wave-aggregated, order-preserving append of the uncertified lanes to the hard list
-    const bool hard = (i < ns) && !certified;
+    // wave-aggregated append of the lower-bounded queries to the hard list
     const unsigned long long hm = __ballot(hard);
     if (hm) {
       uint32_t basepos = 0;
@@ -474,6 +439,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_tile(IcpDev b) {
       if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
     }
   }
+  if (min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
   __syncthreads();
   uint32_t* gh = b.hist + (size_t)pair * kHistBins;
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
@@ -494,24 +460,31 @@ __device__ __forceinline__ void search_row(const uint2* __restrict__ words, cons
   }
 }
 
-// Phase B -- per-query ring search over the hard list (HARD = true), or over every source point
-// (HARD = false: the tile phase is skipped, e.g. for tests).  Rings r = r0, 2 r0, ... <= max_ring;
-// cells already covered by an earlier ring / by the tile phase are skipped.  What is still
+// Phase B -- exact per-query ring search.  HARD = true: refinement of the lower-bounded queries of
+// nn_ball, run only when nn_validate found that the quantile may reach one of the bounds (or when
+// every match must be exact); HARD = false: over every source point (nn_ball skipped).
+// Rings r = 1, 2, 4, ... <= max_ring; cells covered by an earlier ring are skipped.  What is still
 // uncertified afterwards goes to the brute-force fallback list.
 template <bool HARD>
 __global__ __launch_bounds__(kNnThreads) void nn_ring(IcpDev b) {
   const int pair = blockIdx.y;
   PairState* st = &b.state[pair];
   if (st->done) return;
+  if (HARD && !st->refine) return;
   const int count = HARD ? (int)st->hard_count : st->ns;
   if ((int)(blockIdx.x * kNnThreads) >= count) return;
   __shared__ uint32_t s_hist[kHistBins];
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
   __syncthreads();
   const int e = blockIdx.x * kNnThreads + threadIdx.x;
+  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
   if (e < count) {
     const size_t so = (size_t)pair * b.ns_cap;
     const int i = HARD ? b.hlist[so + e] : e;
+    if (HARD) {   // take the lower bound back out of the histogram
+      const uint32_t old = __float_as_uint(b.d2[so + i]);
+      if (old < 0x7f800000u) atomicSub(&gh[old >> kHistShift], 1u);
+    }
     double px, py, pz;
     transform_point(st->M, b.src[so + i], px, py, pz);
     const float qx = (float)px, qy = (float)py, qz = (float)pz;
@@ -526,15 +499,8 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring(IcpDev b) {
       const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
       const int cx = cell_coord(qx, ox, inv_h), cy = cell_coord(qy, oy, inv_h), cz = cell_coord(qz, oz, inv_h);
       int rp = 0;           // radius already covered
-      int r = 1;
-      if (HARD && b.idx[so + i] != -2) {   // the tile phase covered at least [c - margin, c + margin]^3 and left its best
-        rp = b.tile_margin;
-        r = 2 * rp;
-        best.d2 = b.d2[so + i];
-        best.j = b.idx[so + i];
-      }
       resolved = false;
-      for (; r <= b.max_ring; r *= 2) {
+      for (int r = 1; r <= b.max_ring; r *= 2) {
         const int x0 = max(cx - r, 0), x1 = min(cx + r, nx - 1);
         const int y0 = max(cy - r, 0), y1 = min(cy + r, ny - 1);
         const int z0 = max(cz - r, 0), z1 = min(cz + r, nz - 1);
@@ -569,7 +535,6 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring(IcpDev b) {
     }
   }
   __syncthreads();
-  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
     const uint32_t v = s_hist[k];
     if (v) atomicAdd(&gh[k], v);
@@ -712,6 +677,25 @@ __device__ __forceinline__ void find_quantile_bin(const uint32_t* __restrict__ g
     }
   }
   __syncthreads();
+}
+
+// One block per pair, between nn_ball and the refinement kernels: does the quantile stay below
+// every lower bound nn_ball recorded?  If not (or if every match must be exact) switch the ring
+// search + fallback on for this iteration.
+__global__ __launch_bounds__(256) void nn_validate(IcpDev b) {
+  const int pair = blockIdx.x;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  __shared__ uint32_t s_w[17];
+  __shared__ uint32_t s_q[4];
+  find_quantile_bin(b.hist + (size_t)pair * kHistBins, b.rho, s_w, s_q);
+  if (threadIdx.x == 0) {
+    const bool any = st->hard_count > 0;
+    // a bound sharing the quantile's bin is not provably above it: refine (conservative)
+    const bool below = (st->min_lb_key >> kHistShift) <= s_q[0];
+    st->refine = (any && (b.exact_all || below || s_q[2] == 0)) ? 1 : 0;
+    if (st->refine) st->refine_total += 1;
+  }
 }
 
 // J = [p x n ; n], r = (p - q) . n ; acc += upper(J J^T), J r, sqrt(d2), 1     (icp_fast.cc:182-202, 256-303)
@@ -969,6 +953,14 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   st->unresolved_count = 0;
   st->hard_total += st->hard_count;
   st->hard_count = 0;
+  st->min_lb_key = 0xffffffffu;
+  st->refine = 0;
+  {   // next search radius: 1.5 x the quantile distance, clamped to [0.05 m, ball_radius]
+    const float lim = sqrtf(__uint_as_float(limit_key));
+    float rc = fminf(fmaxf(1.5f * lim, 0.05f), b.ball_radius);
+    if (!(n_valid > 0)) rc = b.ball_radius;
+    st->rcap2 = rc * rc;
+  }
   st->blist_count = 0;
   st->limit_key = limit_key;
   const double kept = s_tot[28];

@@ -142,8 +142,9 @@ smhip_status enqueue_find_closests(smhip_context* h, int np, int ns_max) {
   IcpDev& d = h->dev;
   const dim3 g(ceil_div(ns_max, kNnThreads), np);
   if (h->opts.nn_mode == SMHIP_NN_GRID) {
-    if (d.use_tile) {
-      { Bracket br(h, 4); hipLaunchKernelGGL(nn_tile, dim3(ceil_div(ns_max, kNnThreads * kTileChunks), np), dim3(kNnThreads), 0, h->stream, d); }
+    if (d.use_ball) {
+      { Bracket br(h, 4); hipLaunchKernelGGL(nn_ball, dim3(ceil_div(ns_max, kNnThreads * kBallItems), np), dim3(kNnThreads), 0, h->stream, d); }
+      { Bracket br(h, 1); hipLaunchKernelGGL(nn_validate, dim3(np), dim3(256), 0, h->stream, d); }
       { Bracket br(h, 1); hipLaunchKernelGGL(nn_ring<true>, g, dim3(kNnThreads), 0, h->stream, d); }
     } else {
       Bracket br(h, 4);
@@ -228,8 +229,9 @@ void sync_options(smhip_context* h) {
   h->dev.max_ring = std::max(1, h->opts.grid_max_ring);
   h->dev.rho = h->opts.dist_outlier_ratio;
   h->dev.grid_cell = h->opts.grid_cell > 0 ? h->opts.grid_cell : 0.5f;
-  h->dev.tile_margin = std::min(std::max(1, h->opts.tile_margin), 8);
-  h->dev.use_tile = h->opts.use_tile;
+  h->dev.use_ball = h->opts.use_ball;
+  h->dev.exact_all = h->opts.exact_matches;
+  h->dev.ball_radius = h->opts.ball_radius > 0 ? h->opts.ball_radius : 0.5f;
 }
 
 // FindClosests output in the caller's order: source i was uploaded from caller index src.w,
@@ -292,11 +294,12 @@ void smhip_icp_default_options(smhip_icp_options* o) {
   o->dist_outlier_ratio = 0.7f;    // icp_fast.h:59
   o->early_exit = 1;
   o->nn_mode = SMHIP_NN_GRID;
-  o->grid_cell = 0.5f;
-  o->grid_max_ring = 4;
+  o->grid_cell = 0.25f;
+  o->grid_max_ring = 8;
   o->check_every = 8;
-  o->tile_margin = 1;
-  o->use_tile = 1;
+  o->use_ball = 1;
+  o->exact_matches = 0;
+  o->ball_radius = 0.5f;
 }
 
 smhip_status smhip_create(int device, void* stream, int pair_slots, int max_source_points, int max_target_points,
@@ -557,7 +560,7 @@ smhip_status smhip_icp_fetch_batch(smhip_handle h, int npairs, double* results, 
       stats[p].fallback_queries = (int32_t)st.fallback_total;
       stats[p].status = st.status;
       stats[p].hard_queries = (int32_t)st.hard_total;
-      stats[p].reserved = 0;
+      stats[p].refined_iterations = (int32_t)st.refine_total;
     }
     if (st.status != SMHIP_OK && worst == SMHIP_OK) { worst = st.status; h->err = "pair failed: no finite correspondence"; }
     if (!st.done && worst == SMHIP_OK) { worst = SMHIP_ERR_HIP; h->err = "pair did not finish (internal)"; }
@@ -617,7 +620,10 @@ smhip_status smhip_icp_find_closests(smhip_handle h, int slot, const double T[16
   if (s) return s;
   s = enqueue_prepare(h, 1, nt_max);
   if (s) return s;
+  const int exact_was = h->dev.exact_all;
+  h->dev.exact_all = 1;                 // FindClosests contract: every match exact
   s = enqueue_find_closests(h, 1, ns_max);
+  h->dev.exact_all = exact_was;
   if (s) return s;
   s = fetch_matches(h, 0, ids, d2, n);
   // leave the per-iteration scratch clean

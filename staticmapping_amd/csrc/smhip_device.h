@@ -14,13 +14,11 @@ constexpr int kAccThreads = 256;
 constexpr int kAccItems = 8;             // source points per thread in the accumulate kernel
 constexpr int kAccChunk = kAccThreads * kAccItems;
 constexpr int kAccCols = 32;             // 21 (A upper) + 6 (b) + 1 (sum sqrt d2) + 1 (count) padded to 32
-constexpr int kMaxGridWords = 1 << 16;   // 32-cell words per pair (2 Mi cells)
+constexpr int kMaxGridWords = 1 << 18;   // 32-cell words per pair (8 Mi cells)
 constexpr int kTgtReduceBlocks = 32;     // partial blocks for the target mean / bbox
 constexpr int kBruteTile = 1024;
 constexpr int kFallbackSlices = 64;
-constexpr int kTileChunks = 8;           // wave-tiles each wave of nn_tile processes (2048 queries per block)
-constexpr int kTileCap = 512;            // target points one wave stages in LDS per pass (8 KiB)
-constexpr int kTileMaxRows = 1024;       // larger blocks (incoherent waves) go straight to the ring search      // target slices the fallback sweep is spread over         // target points staged in LDS per tile (16 KiB as float4)
+constexpr int kBallItems = 4;            // queries per thread in nn_ball (1024 per block: fewer histogram flushes)      // target slices the fallback sweep is spread over         // target points staged in LDS per tile (16 KiB as float4)
 
 // Per-pair device state.  Everything an iteration needs and everything the host reads back.
 struct PairState {
@@ -51,8 +49,12 @@ struct PairState {
   uint32_t unresolved_count;
   uint32_t blist_count;
   uint32_t fallback_total;
-  uint32_t hard_count;
+  uint32_t hard_count;       // queries nn_ball recorded with a lower bound this iteration
   uint32_t hard_total;
+  uint32_t min_lb_key;       // smallest such bound (float bits)
+  int32_t refine;            // 1 = this iteration's bounds must be refined to exact matches
+  uint32_t refine_total;
+  float rcap2;               // squared search-radius cap of nn_ball for the next iteration
   int32_t kept;
   uint32_t limit_key;
   // outputs
@@ -101,8 +103,9 @@ struct IcpDev {
   int32_t max_iteration;
   int32_t early_exit;
   int32_t max_ring;
-  int32_t tile_margin;       // cells added around a wave's bounding block in nn_tile
-  int32_t use_tile;          // 0 = skip the tile phase (ring search over every query)
+  int32_t use_ball;          // 1 = ball-bounded search with certified trimming; 0 = ring search over every query
+  int32_t exact_all;         // 1 = every match exact (no lower bounds survive), e.g. find_closests
+  float ball_radius;         // largest search radius of nn_ball (first iteration / clamp)
   float rho;                 // dist_outlier_ratio as float (widened to double exactly like the reference)
   float grid_cell;
 };

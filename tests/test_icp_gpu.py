@@ -27,10 +27,11 @@ def _oracle_nn(q, src, T):
 
 
 NN_VARIANTS = {
-    "tile": dict(nn_mode=1, use_tile=1),                    # wave-tile phase + ring search + fallback (default)
-    "tile_margin2": dict(nn_mode=1, use_tile=1, tile_margin=2, grid_cell=0.25),
-    "ring": dict(nn_mode=1, use_tile=0),                    # per-query ring search only
-    "ring_small": dict(nn_mode=1, use_tile=0, grid_max_ring=1),   # most queries through the brute fallback
+    "ball": dict(nn_mode=1, use_ball=1),                    # ball search + certified trimming (default)
+    "ball_exact": dict(nn_mode=1, use_ball=1, exact_matches=1),
+    "ball_small": dict(nn_mode=1, use_ball=1, ball_radius=0.1, grid_cell=0.5),   # validation fails early on -> refinement path
+    "ring": dict(nn_mode=1, use_ball=0),                    # per-query ring search only
+    "ring_small": dict(nn_mode=1, use_ball=0, grid_max_ring=1),   # most queries through the brute fallback
     "brute": dict(nn_mode=0),
 }
 
@@ -93,7 +94,7 @@ def test_cfg1_plumbing_parity(smhip, cfg1):
     assert abs(score - ref["score"]) < 1e-4
 
 
-@pytest.mark.parametrize("mode", ["tile", "ring", "brute"])
+@pytest.mark.parametrize("mode", list(NN_VARIANTS))
 def test_velodyne20k_parity_early_exit(smhip, velo20k, mode):
     ok, R, score, stats, ref = _align_both(smhip, velo20k, velo20k["guess"], **NN_VARIANTS[mode])
     da, dt = smhip.se3_error(R, ref["result"])
@@ -125,18 +126,29 @@ def test_cfg2_identity_guess_parity(smhip, cfg2):
 def test_quantile_kept_count_is_exact(smhip, velo20k):
     """kept = #(d2 <= values[int(n * 0.7f)]) -- the nth_element rank rule (icp_fast.cc:86-89, 497)."""
     c = velo20k
-    m = smhip.IcpFastHip(max_source_points=len(c["src"]), max_target_points=len(c["q"]),
-                         max_iteration=1, early_exit=0)
-    m.set_input_source(c["src"])
-    m.set_input_target(c["q"], c["n"])
-    m.align(c["guess"])
-    ids, d2 = m.get_matches(len(c["src"]))
-    st = m.last_stats[0]
-    k = int(len(d2) * float(np.float32(0.7)))
-    limit = np.partition(d2, k)[k]
-    assert np.float32(st["limit_d2"]) == limit
-    assert st["kept"] == int((d2 <= limit).sum())
-    m.close()
+    ids_x, d2_x = None, None
+    for exact in (1, 0):
+        m = smhip.IcpFastHip(max_source_points=len(c["src"]), max_target_points=len(c["q"]),
+                             max_iteration=3, early_exit=0, exact_matches=exact)
+        m.set_input_source(c["src"])
+        m.set_input_target(c["q"], c["n"])
+        m.align(c["guess"])
+        ids, d2 = m.get_matches(len(c["src"]))
+        st = m.last_stats[0]
+        k = int(len(d2) * float(np.float32(0.7)))
+        limit = np.partition(d2, k)[k]
+        assert np.float32(st["limit_d2"]) == limit
+        assert st["kept"] == int((d2 <= limit).sum())
+        if exact:
+            ids_x, d2_x, lim_x = ids, d2, limit
+        else:
+            # certified trimming: same quantile, identical kept matches, bounds only on rejected ones
+            assert limit == lim_x
+            kept = d2_x <= lim_x
+            assert np.array_equal(ids[kept], ids_x[kept])
+            assert np.array_equal(d2[kept].view(np.uint32), d2_x[kept].view(np.uint32))
+            assert (d2[~kept] > limit).all() and (d2[~kept] <= d2_x[~kept]).all()
+        m.close()
 
 
 def test_ratio_one_keeps_everything(smhip, cfg1):

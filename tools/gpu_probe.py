@@ -10,12 +10,12 @@ from oracle import cref
 n_points = int(sys.argv[1]) if len(sys.argv) > 1 else 120000
 batches = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["1", "16", "64"])]
 kv = dict(a.split("=") for a in sys.argv[3:])
-cells = [float(x) for x in kv.get("cell", "0.5").split(",")]
-rings = [int(x) for x in kv.get("ring", "4").split(",")]
+cells = [float(x) for x in kv.get("cell", "0.25").split(",")]
+rings = [int(x) for x in kv.get("ring", "8").split(",")]
 mortons = [int(x) for x in kv.get("morton", "0").split(",")]
 modes = [int(x) for x in kv.get("mode", "1").split(",")]
-tiles = [int(x) for x in kv.get("tile", "1").split(",")]
-margins = [int(x) for x in kv.get("margin", "1").split(",")]
+tiles = [int(x) for x in kv.get("ball", "1").split(",")]
+margins = [float(x) for x in kv.get("radius", "0.5").split(",")]
 
 
 def morton_order(p, cell=0.25):
@@ -45,7 +45,7 @@ for mode in modes:
        for tile in tiles:
         for margin in margins:
          for B in batches:
-            m = sm.IcpFastHip(pair_slots=B, max_source_points=len(b), max_target_points=len(q), use_tile=tile, tile_margin=margin,
+            m = sm.IcpFastHip(pair_slots=B, max_source_points=len(b), max_target_points=len(q), use_ball=tile, ball_radius=margin,
                               max_iteration=20, early_exit=0, nn_mode=mode, grid_cell=cell, grid_max_ring=ring)
             m.set_input_source(b); m.set_input_target(q, n)
             for s in range(1, B): m.copy_slot(0, s)
@@ -55,7 +55,7 @@ for mode in modes:
             for _ in range(reps): R, sc, st = m.align_batch(B, g)
             dt = (time.time() - t) / reps
             m.enable_profile(True); m.align_batch(B, g); p = m.get_profile(); m.enable_profile(False)
-            print(f"mode={'grid' if mode else 'brute'} tile={tile} margin={margin} cell={cell} ring={ring} B={B} {dt*1e3:.2f} ms/batch "
-                  f"{B/dt:.1f} align/s hard={st[0]['hard_queries']} fallback={st[0]['fallback_queries']} err={sm.se3_error(R[0], T)}", flush=True)
+            print(f"mode={'grid' if mode else 'brute'} ball={tile} radius={margin} cell={cell} ring={ring} B={B} {dt*1e3:.2f} ms/batch "
+                  f"{B/dt:.1f} align/s hard={st[0]['hard_queries']} refined={st[0]['refined_iterations']} fallback={st[0]['fallback_queries']} err={sm.se3_error(R[0], T)}", flush=True)
             print("   ", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in p.items()}, flush=True)
             m.close()

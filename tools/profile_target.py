@@ -6,7 +6,7 @@ import staticmapping_amd as sm
 from staticmapping_amd import synth
 from oracle import cref
 kv = dict(a.split("=") for a in sys.argv[1:])
-B = int(kv.get("B", 64)); reps = int(kv.get("reps", 2)); cell = float(kv.get("cell", 0.35)); ring = int(kv.get("ring", 8))
+B = int(kv.get("B", 64)); reps = int(kv.get("reps", 2)); cell = float(kv.get("cell", 0.25)); ring = int(kv.get("ring", 8))
 mode = int(kv.get("mode", 1)); n_points = int(kv.get("n", 120000))
 a, b, T = synth.scan_pair("cfg2", n_points=n_points)
 q, n, _ = cref.calculate_normals(a[:, :3].astype(np.float64))

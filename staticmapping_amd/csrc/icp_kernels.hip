@@ -61,6 +61,20 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, u
   return excl;
 }
 
+// XCD-aware work mapping for the heavy per-point kernels.  They are launched as a 1-D grid of
+// nblk * 8 * ceil(npairs / 8) workgroups; the dispatcher deals consecutive workgroup ids round-robin
+// over the 8 XCDs (observed, MI355X_MICROARCH.md), so XCD k = id % 8 walks the pairs k, k + 8, ... one
+// after the other and every block of a pair runs on the same XCD: the pair's grid words, sorted
+// target and match arrays stay in that XCD's 4 MiB L2 instead of being spread over all eight.
+// Only speed depends on the placement, never correctness.
+__device__ __forceinline__ bool xcd_block(int nblk, int npairs, int& pair, int& blk) {
+  const int id = blockIdx.x;
+  const int j = id >> 3;
+  pair = (j / nblk) * 8 + (id & 7);
+  blk = j % nblk;
+  return pair < npairs;
+}
+
 // ------------------------------------------------------------------------------------------
 // target preparation
 // ------------------------------------------------------------------------------------------
@@ -158,7 +172,7 @@ __global__ void grid_setup(IcpDev b, int npairs) {
   st->n_hist = 1;
   st->iter = 0; st->done = 0; st->status = 0;
   st->unresolved_count = 0; st->blist_count = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
-  st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0;
+  st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0;
   st->rcap2 = b.ball_radius * b.ball_radius;
   st->kept = 0; st->limit_key = 0; st->score = 0; st->nocc = 0;
 }
@@ -184,6 +198,7 @@ __global__ __launch_bounds__(256) void grid_mark(IcpDev b) {
 }
 
 // One 1024-thread block per pair: words[w] = {bits, exclusive popcount rank}; nocc.
+// Tiles of 4096 words, 16-byte coalesced loads, running carry between tiles.
 __global__ __launch_bounds__(1024) void grid_rank(IcpDev b) {
   const int pair = blockIdx.x;
   PairState* st = &b.state[pair];
@@ -191,18 +206,29 @@ __global__ __launch_bounds__(1024) void grid_rank(IcpDev b) {
   const uint32_t* bits = b.bits + (size_t)pair * kMaxGridWords;
   uint2* words = b.words + (size_t)pair * kMaxGridWords;
   __shared__ uint32_t s_w[17];
-  const int per = (nw + blockDim.x - 1) / blockDim.x;
-  const int lo = min(nw, (int)threadIdx.x * per), hi = min(nw, lo + per);
-  uint32_t c = 0;
-  for (int w = lo; w < hi; ++w) c += __popc(bits[w]);
-  uint32_t total;
-  uint32_t run = block_excl_scan(c, s_w, &total);
-  for (int w = lo; w < hi; ++w) {
-    const uint32_t v = bits[w];
-    words[w] = make_uint2(v, run);
-    run += __popc(v);
+  uint32_t carry = 0;
+  for (int t0 = 0; t0 < nw; t0 += 4096) {
+    const int w = t0 + (int)threadIdx.x * 4;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (w + 3 < nw) v = *reinterpret_cast<const uint4*>(bits + w);      // kMaxGridWords keeps this 16-B aligned
+    else {
+      if (w < nw) v.x = bits[w];
+      if (w + 1 < nw) v.y = bits[w + 1];
+      if (w + 2 < nw) v.z = bits[w + 2];
+    }
+    const uint32_t c0 = __popc(v.x), c1 = __popc(v.y), c2 = __popc(v.z), c3 = __popc(v.w);
+    uint32_t total;
+    uint32_t run = carry + block_excl_scan(c0 + c1 + c2 + c3, s_w, &total);
+    if (w < nw) words[w] = make_uint2(v.x, run);
+    run += c0;
+    if (w + 1 < nw) words[w + 1] = make_uint2(v.y, run);
+    run += c1;
+    if (w + 2 < nw) words[w + 2] = make_uint2(v.z, run);
+    run += c2;
+    if (w + 3 < nw) words[w + 3] = make_uint2(v.w, run);
+    carry += total;
   }
-  if (threadIdx.x == 0) st->nocc = (int)total;
+  if (threadIdx.x == 0) st->nocc = (int)carry;
 }
 
 __global__ __launch_bounds__(256) void grid_count(IcpDev b) {
@@ -358,13 +384,23 @@ __device__ __forceinline__ void search_row(const uint2* __restrict__ words, cons
 //      the brute-force fallback make every match exact, as they always do for find_closests.
 // So each lane visits only the cells meeting the ball (q, min(|q - t_prev|, R_cap)): typically
 // 1-2 cells per axis once ICP has settled.
-__global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b) {
-  const int pair = blockIdx.y;
+//
+// Optional two-launch split (two_pass, off by default: measured slower, 9.0 vs 6.8 ms per
+// 64-pair batch -- the kernel is bound by divergent vector-memory issue, not by VALU divergence):
+// DEFERRED = false sweeps every query but only
+// searches those whose previous match already lies inside the cap (small balls, 1-2 cells per
+// axis); the others (no previous match, or previous distance beyond the cap: the future rejects)
+// are compacted into the deferred list, which the DEFERRED = true launch searches with the full
+// cap radius -- full wavefronts of equally expensive queries instead of one slow lane per wave.
+template <bool DEFERRED>
+__global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
+  int pair, blk;
+  if (!xcd_block(nblk, b.npairs, pair, blk)) return;
   PairState* st = &b.state[pair];
   if (st->done) return;
-  const int ns = st->ns;
-  const int base = blockIdx.x * (kNnThreads * kBallItems);
-  if (base >= ns) return;
+  const int count = DEFERRED ? (int)st->deferred_count : st->ns;
+  const int base = blk * (kNnThreads * kBallItems);
+  if (base >= count) return;
   __shared__ uint32_t s_hist[kHistBins];
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
   __syncthreads();
@@ -381,9 +417,11 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b) {
   uint32_t min_lb = 0xffffffffu;
 
   for (int it = 0; it < kBallItems; ++it) {
-    const int i = base + it * kNnThreads + threadIdx.x;
-    bool hard = false;
-    if (i < ns) {
+    const int e = base + it * kNnThreads + threadIdx.x;
+    bool hard = false, defer = false;
+    int i = -1;
+    if (e < count) {
+      i = DEFERRED ? b.dlist[so + e] : e;
       double px, py, pz;
       transform_point(st->M, b.src[so + i], px, py, pz);
       const float qx = (float)px, qy = (float)py, qz = (float)pz;
@@ -399,38 +437,52 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b) {
             R2 = fminf(R2, best.d2);
           }
         }
-        // every target point within sqrt(R2) of q lies in a cell meeting [q - Rs, q + Rs]^3
-        const float Rs = sqrtf(R2) * 1.0001f + 1.0e-3f * h;
-        const int x0 = max(cell_coord(qx - Rs, ox, inv_h), 0), x1 = min(cell_coord(qx + Rs, ox, inv_h), nx - 1);
-        const int y0 = max(cell_coord(qy - Rs, oy, inv_h), 0), y1 = min(cell_coord(qy + Rs, oy, inv_h), ny - 1);
-        const int z0 = max(cell_coord(qz - Rs, oz, inv_h), 0), z1 = min(cell_coord(qz + Rs, oz, inv_h), nz - 1);
-        if (x0 <= x1) {
-          const float slack = 2.0e-3f * h;
-          for (int z = z0; z <= z1; ++z) {
-            const float zl = oz + (float)z * h;
-            const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + h)) - slack, 0.f);
-            for (int y = y0; y <= y1; ++y) {
-              const float yl = oy + (float)y * h;
-              const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + h)) - slack, 0.f);
-              if (fmaf(dy, dy, dz * dz) > fminf(best.d2, R2)) continue;     // the row cannot hold anything useful
-              search_row(words, cstart, tq, (z * ny + y) * wx, x0, x1, qx, qy, qz, best);
+        defer = !DEFERRED && b.two_pass && !(best.d2 <= r2cap);
+        if (!defer) {
+          // every target point within sqrt(R2) of q lies in a cell meeting [q - Rs, q + Rs]^3
+          const float Rs = sqrtf(R2) * 1.0001f + 1.0e-3f * h;
+          const int x0 = max(cell_coord(qx - Rs, ox, inv_h), 0), x1 = min(cell_coord(qx + Rs, ox, inv_h), nx - 1);
+          const int y0 = max(cell_coord(qy - Rs, oy, inv_h), 0), y1 = min(cell_coord(qy + Rs, oy, inv_h), ny - 1);
+          const int z0 = max(cell_coord(qz - Rs, oz, inv_h), 0), z1 = min(cell_coord(qz + Rs, oz, inv_h), nz - 1);
+          if (x0 <= x1) {
+            const float slack = 2.0e-3f * h;
+            for (int z = z0; z <= z1; ++z) {
+              const float zl = oz + (float)z * h;
+              const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + h)) - slack, 0.f);
+              for (int y = y0; y <= y1; ++y) {
+                const float yl = oy + (float)y * h;
+                const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + h)) - slack, 0.f);
+                if (fmaf(dy, dy, dz * dz) > fminf(best.d2, R2)) continue;     // the row cannot hold anything useful
+                search_row(words, cstart, tq, (z * ny + y) * wx, x0, x1, qx, qy, qz, best);
+              }
             }
           }
-        }
-        if (best.d2 <= R2) {
-          d2out = best.d2;                      // exact: everything within sqrt(R2) was seen
-        } else {
-          d2out = R2;                           // certified lower bound: nothing lies within sqrt(R2)
-          hard = true;
-          min_lb = min(min_lb, __float_as_uint(R2));
+          if (best.d2 <= R2) {
+            d2out = best.d2;                      // exact: everything within sqrt(R2) was seen
+          } else {
+            d2out = R2;                           // certified lower bound: nothing lies within sqrt(R2)
+            hard = true;
+            min_lb = min(min_lb, __float_as_uint(R2));
+          }
         }
       }
-      b.d2[so + i] = d2out;
-      b.idx[so + i] = best.j;
-      const uint32_t key = __float_as_uint(d2out);
-      if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
+      if (!defer) {
+        b.d2[so + i] = d2out;
+        b.idx[so + i] = best.j;
+        const uint32_t key = __float_as_uint(d2out);
+        if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
+      }
     }
-    // wave-aggregated append of the lower-bounded queries to the hard list
+    // wave-aggregated, order-preserving appends
+    if (!DEFERRED) {
+      const unsigned long long dm = __ballot(defer);
+      if (dm) {
+        uint32_t basepos = 0;
+        if (lane == 0) basepos = atomicAdd(&st->deferred_count, (uint32_t)__popcll(dm));
+        basepos = __shfl(basepos, 0, 64);
+        if (defer) b.dlist[so + basepos + __popcll(dm & ((1ull << lane) - 1ull))] = i;
+      }
+    }
     const unsigned long long hm = __ballot(hard);
     if (hm) {
       uint32_t basepos = 0;
@@ -476,9 +528,8 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring(IcpDev b) {
   __shared__ uint32_t s_hist[kHistBins];
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
   __syncthreads();
-  const int e = blockIdx.x * kNnThreads + threadIdx.x;
   uint32_t* gh = b.hist + (size_t)pair * kHistBins;
-  if (e < count) {
+  for (int e = blockIdx.x * kNnThreads + threadIdx.x; e < count; e += gridDim.x * kNnThreads) {
     const size_t so = (size_t)pair * b.ns_cap;
     const int i = HARD ? b.hlist[so + e] : e;
     if (HARD) {   // take the lower bound back out of the histogram
@@ -629,15 +680,15 @@ __global__ __launch_bounds__(kNnThreads) void nn_fallback_resolve(IcpDev b) {
   PairState* st = &b.state[pair];
   if (st->done) return;
   const int U = (int)st->unresolved_count;
-  const int e = blockIdx.x * kNnThreads + threadIdx.x;
-  if (e >= U) return;
   const size_t so = (size_t)pair * b.ns_cap;
-  const int i = b.ulist[so + e];
-  const unsigned long long key = b.ukeys[so + e];
-  const uint32_t dbits = (uint32_t)(key >> 32);
-  b.d2[so + i] = __uint_as_float(dbits);
-  b.idx[so + i] = (int)(uint32_t)(key & 0xffffffffu);
-  if (dbits < 0x7f800000u) atomicAdd(&b.hist[(size_t)pair * kHistBins + (dbits >> kHistShift)], 1u);
+  for (int e = blockIdx.x * kNnThreads + threadIdx.x; e < U; e += gridDim.x * kNnThreads) {
+    const int i = b.ulist[so + e];
+    const unsigned long long key = b.ukeys[so + e];
+    const uint32_t dbits = (uint32_t)(key >> 32);
+    b.d2[so + i] = __uint_as_float(dbits);
+    b.idx[so + i] = (int)(uint32_t)(key & 0xffffffffu);
+    if (dbits < 0x7f800000u) atomicAdd(&b.hist[(size_t)pair * kHistBins + (dbits >> kHistShift)], 1u);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -744,12 +795,13 @@ __device__ __forceinline__ void block_reduce29(double* acc, double (*s_red)[29])
   }
 }
 
-__global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b) {
-  const int pair = blockIdx.y;
+__global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
+  int pair, blk;
+  if (!xcd_block(nblk, b.npairs, pair, blk)) return;
   PairState* st = &b.state[pair];
   if (st->done) return;
   const int ns = st->ns;
-  const int base = blockIdx.x * kAccChunk;
+  const int base = blk * kAccChunk;
   if (base >= ns) return;
   __shared__ uint32_t s_w[17];
   __shared__ uint32_t s_q[4];
@@ -779,7 +831,7 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b) {
   }
   block_reduce29(acc, s_red);
   if (threadIdx.x == 0) {
-    double* out = b.partials + ((size_t)pair * b.acc_blocks + blockIdx.x) * kAccCols;
+    double* out = b.partials + ((size_t)pair * b.acc_blocks + blk) * kAccCols;
 #pragma unroll
     for (int c = 0; c < 29; ++c) out[c] = acc[c];
   }
@@ -886,6 +938,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   __shared__ uint32_t s_sel[2];
   __shared__ double s_red[4][29];
   __shared__ double s_tot[29];
+  __shared__ double s_part[8][32];
   uint32_t* gh = b.hist + (size_t)pair * kHistBins;
   find_quantile_bin(gh, b.rho, s_w, s_q);
   const uint32_t qbin = s_q[0], below = s_q[1], n_valid = s_q[2], krank = s_q[3];
@@ -912,11 +965,13 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
         if ((key & mask) == prefix) atomicAdd(&s_h[(key >> shift) & (nd - 1u)], 1u);
       }
       __syncthreads();
-      if (threadIdx.x == 0) {
-        uint32_t run = 0, d = 0;
-        for (; d < nd; ++d) { if (rank < run + s_h[d]) break; run += s_h[d]; }
-        if (d >= nd) d = nd - 1;
-        s_sel[0] = d; s_sel[1] = run;
+      {   // the digit whose cumulative count crosses `rank`, found by all 256 threads at once
+        const uint32_t v = threadIdx.x < nd ? s_h[threadIdx.x] : 0u;
+        uint32_t tot;
+        const uint32_t excl = block_excl_scan(v, s_w, &tot);
+        if (threadIdx.x == 0) { s_sel[0] = nd - 1; s_sel[1] = tot - s_h[nd - 1]; }
+        __syncthreads();
+        if (v > 0 && excl <= rank && rank < excl + v) { s_sel[0] = threadIdx.x; s_sel[1] = excl; }
       }
       __syncthreads();
       prefix |= s_sel[0] << shift;
@@ -936,12 +991,20 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   if (threadIdx.x == 0)
     for (int c = 0; c < 29; ++c) s_tot[c] = acc[c];
   __syncthreads();
-  // add the per-block partial sums of the accumulate kernel in a fixed order
+  // add the per-block partial sums of the accumulate kernel: 8 thread groups take every 8th block,
+  // then one thread per column folds the 8 group sums -- a fixed order, so the result is reproducible
   const int nblk = (ns + kAccChunk - 1) / kAccChunk;
+  {
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    double s = 0;
+    const double* part = b.partials + (size_t)pair * b.acc_blocks * kAccCols + col;
+    for (int k = grp; k < nblk; k += 8) s += part[(size_t)k * kAccCols];
+    s_part[grp][col] = s;
+  }
+  __syncthreads();
   if (threadIdx.x < 29) {
     double s = s_tot[threadIdx.x];
-    const double* part = b.partials + (size_t)pair * b.acc_blocks * kAccCols + threadIdx.x;
-    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * kAccCols];
+    for (int g = 0; g < 8; ++g) s += s_part[g][threadIdx.x];
     s_tot[threadIdx.x] = s;
   }
   // reset the per-iteration scratch for the next iteration
@@ -953,6 +1016,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   st->unresolved_count = 0;
   st->hard_total += st->hard_count;
   st->hard_count = 0;
+  st->deferred_count = 0;
   st->min_lb_key = 0xffffffffu;
   st->refine = 0;
   {   // next search radius: 1.5 x the quantile distance, clamped to [0.05 m, ball_radius]

@@ -119,6 +119,7 @@ smhip_status check_slot(smhip_context* h, int slot) {
 // target centring + search-structure build for pairs [0, np)
 smhip_status enqueue_prepare(smhip_context* h, int np, int nt_max) {
   IcpDev& d = h->dev;
+  d.npairs = np;
   Bracket br(h, 0);
   HIPCHK(h, hipMemcpyAsync(const_cast<PairInput*>(d.in), h->in_pinned, sizeof(PairInput) * np, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemsetAsync(d.bits, 0, sizeof(uint32_t) * (size_t)kMaxGridWords * np, h->stream));
@@ -143,15 +144,18 @@ smhip_status enqueue_find_closests(smhip_context* h, int np, int ns_max) {
   const dim3 g(ceil_div(ns_max, kNnThreads), np);
   if (h->opts.nn_mode == SMHIP_NN_GRID) {
     if (d.use_ball) {
-      { Bracket br(h, 4); hipLaunchKernelGGL(nn_ball, dim3(ceil_div(ns_max, kNnThreads * kBallItems), np), dim3(kNnThreads), 0, h->stream, d); }
+      const int nblk = ceil_div(ns_max, kNnThreads * kBallItems);
+      const dim3 gx(nblk * 8 * ceil_div(np, 8));
+      { Bracket br(h, 4); hipLaunchKernelGGL(nn_ball<false>, gx, dim3(kNnThreads), 0, h->stream, d, nblk); }
+      if (d.two_pass) { Bracket br(h, 4); hipLaunchKernelGGL(nn_ball<true>, gx, dim3(kNnThreads), 0, h->stream, d, nblk); }
       { Bracket br(h, 1); hipLaunchKernelGGL(nn_validate, dim3(np), dim3(256), 0, h->stream, d); }
-      { Bracket br(h, 1); hipLaunchKernelGGL(nn_ring<true>, g, dim3(kNnThreads), 0, h->stream, d); }
+      { Bracket br(h, 1); hipLaunchKernelGGL(nn_ring<true>, dim3(32, np), dim3(kNnThreads), 0, h->stream, d); }
     } else {
       Bracket br(h, 4);
       hipLaunchKernelGGL(nn_ring<false>, g, dim3(kNnThreads), 0, h->stream, d);
     }
     { Bracket br(h, 1); hipLaunchKernelGGL(nn_fallback_scan, dim3(kFallbackSlices, np), dim3(kNnThreads), 0, h->stream, d); }
-    { Bracket br(h, 1); hipLaunchKernelGGL(nn_fallback_resolve, g, dim3(kNnThreads), 0, h->stream, d); }
+    { Bracket br(h, 1); hipLaunchKernelGGL(nn_fallback_resolve, dim3(32, np), dim3(kNnThreads), 0, h->stream, d); }
   } else {
     Bracket br(h, 4);
     hipLaunchKernelGGL(nn_brute, g, dim3(kNnThreads), 0, h->stream, d);
@@ -230,6 +234,7 @@ void sync_options(smhip_context* h) {
   h->dev.rho = h->opts.dist_outlier_ratio;
   h->dev.grid_cell = h->opts.grid_cell > 0 ? h->opts.grid_cell : 0.5f;
   h->dev.use_ball = h->opts.use_ball;
+  h->dev.two_pass = h->opts.reserved[0];
   h->dev.exact_all = h->opts.exact_matches;
   h->dev.ball_radius = h->opts.ball_radius > 0 ? h->opts.ball_radius : 0.5f;
 }
@@ -343,6 +348,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, &d.d2, B * NS));
   A(dev_alloc(h, &d.idx, B * NS));
   A(dev_alloc(h, &d.hist, B * kHistBins));
+  A(dev_alloc(h, &d.dlist, B * NS));
   A(dev_alloc(h, &d.hlist, B * NS));
   A(dev_alloc(h, &d.ulist, B * NS));
   A(dev_alloc(h, &d.ukeys, B * NS));
@@ -528,7 +534,11 @@ smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* g
   for (int it = 0; it < max_it; ++it) {
     s = enqueue_find_closests(h, npairs, ns_max);
     if (s) return s;
-    { Bracket br(h, 2); hipLaunchKernelGGL(accumulate, dim3(ceil_div(ns_max, kAccChunk), npairs), dim3(kAccThreads), 0, h->stream, d); }
+    {
+      const int nblk = ceil_div(ns_max, kAccChunk);
+      Bracket br(h, 2);
+      hipLaunchKernelGGL(accumulate, dim3(nblk * 8 * ceil_div(npairs, 8)), dim3(kAccThreads), 0, h->stream, d, nblk);
+    }
     { Bracket br(h, 3); hipLaunchKernelGGL(finalize, dim3(npairs), dim3(256), 0, h->stream, d); }
     if (d.early_exit && (it + 1) % h->opts.check_every == 0 && it + 1 < max_it) {
       HIPCHK(h, hipMemcpyAsync(h->done_pinned, d.done_count, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));

@@ -49,6 +49,7 @@ struct PairState {
   uint32_t unresolved_count;
   uint32_t blist_count;
   uint32_t fallback_total;
+  uint32_t deferred_count;   // queries nn_ball<false> left to the cap-radius launch
   uint32_t hard_count;       // queries nn_ball recorded with a lower bound this iteration
   uint32_t hard_total;
   uint32_t min_lb_key;       // smallest such bound (float bits)
@@ -74,6 +75,7 @@ struct PairInput {
 // Pointers + capacities handed to every kernel by value.
 struct IcpDev {
   int32_t slots, ns_cap, nt_cap;
+  int32_t npairs;            // pairs of the current call (XCD-aware kernels pad the grid to a multiple of 8)
   int32_t acc_blocks;        // ceil(ns_cap / kAccChunk)
   PairState* state;
   const PairInput* in;
@@ -92,6 +94,7 @@ struct IcpDev {
   float* d2;                 // [slots][ns_cap]
   int32_t* idx;              // [slots][ns_cap] index into tq/tn (sorted order)
   uint32_t* hist;            // [slots][kHistBins]
+  int32_t* dlist;            // [slots][ns_cap] deferred queries (searched with the cap radius by nn_ball<true>)
   int32_t* hlist;            // [slots][ns_cap] queries the tile phase could not certify (ring search)
   int32_t* ulist;            // [slots][ns_cap] unresolved queries (brute-force fallback)
   unsigned long long* ukeys; // [slots][ns_cap] fallback winners: (d2 bits << 32) | original target index
@@ -104,6 +107,7 @@ struct IcpDev {
   int32_t early_exit;
   int32_t max_ring;
   int32_t use_ball;          // 1 = ball-bounded search with certified trimming; 0 = ring search over every query
+  int32_t two_pass;          // 1 = nn_ball defers cap-radius queries to a second, compacted launch
   int32_t exact_all;         // 1 = every match exact (no lower bounds survive), e.g. find_closests
   float ball_radius;         // largest search radius of nn_ball (first iteration / clamp)
   float rho;                 // dist_outlier_ratio as float (widened to double exactly like the reference)

@@ -71,7 +71,9 @@ typedef struct smhip_icp_options {
   int32_t exact_matches;        /* 1: refine every lower bound to the exact match in every iteration (default 0;
                                    the transform / score are identical either way, only rejected matches differ) */
   float ball_radius;            /* largest search radius of the ball search in metres (default 0.5) */
-  int32_t reserved[5];
+  float ball_cap_factor;        /* next iteration's search-radius cap = factor x this iteration's quantile distance (default 1.5) */
+  int32_t two_pass;             /* 1: compact the cap-radius queries into a second launch (default 0: measured slower) */
+  int32_t reserved[3];
 } smhip_icp_options;
 
 /* Per-call statistics (all optional to read). */

@@ -83,6 +83,9 @@ struct Builder {
     double nn = 0;
     for (int a = 0; a < 3; ++a) { lf.n[a] = inv[3 * a] * b[0] + inv[3 * a + 1] * b[1] + inv[3 * a + 2] * b[2]; nn += lf.n[a] * lf.n[a]; }
     nn = std::sqrt(nn);
+    // The reference does not check M for singularity (a plane through the sensor origin gives inf/NaN
+    // here and would poison A in IcpFast); such leaves are dropped instead of kept with a NaN normal.
+    if (!(nn > 0.0) || !std::isfinite(nn)) return;
     for (int a = 0; a < 3; ++a) { lf.n[a] /= nn; lf.p[a] = mean[a]; }   // :101-102
     lf.key = indices[first];                                             // :96-98: k = indices[first]
     leaves.push_back(lf);

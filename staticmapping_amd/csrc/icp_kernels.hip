@@ -1019,9 +1019,9 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   st->deferred_count = 0;
   st->min_lb_key = 0xffffffffu;
   st->refine = 0;
-  {   // next search radius: 1.5 x the quantile distance, clamped to [0.05 m, ball_radius]
+  {   // next search radius: cap_factor x the quantile distance, clamped to [0.05 m, ball_radius]
     const float lim = sqrtf(__uint_as_float(limit_key));
-    float rc = fminf(fmaxf(1.5f * lim, 0.05f), b.ball_radius);
+    float rc = fminf(fmaxf(b.cap_factor * lim, 0.05f), b.ball_radius);
     if (!(n_valid > 0)) rc = b.ball_radius;
     st->rcap2 = rc * rc;
   }

@@ -234,7 +234,8 @@ void sync_options(smhip_context* h) {
   h->dev.rho = h->opts.dist_outlier_ratio;
   h->dev.grid_cell = h->opts.grid_cell > 0 ? h->opts.grid_cell : 0.5f;
   h->dev.use_ball = h->opts.use_ball;
-  h->dev.two_pass = h->opts.reserved[0];
+  h->dev.two_pass = h->opts.two_pass;
+  h->dev.cap_factor = h->opts.ball_cap_factor > 1.0f ? h->opts.ball_cap_factor : 1.5f;
   h->dev.exact_all = h->opts.exact_matches;
   h->dev.ball_radius = h->opts.ball_radius > 0 ? h->opts.ball_radius : 0.5f;
 }
@@ -305,6 +306,8 @@ void smhip_icp_default_options(smhip_icp_options* o) {
   o->use_ball = 1;
   o->exact_matches = 0;
   o->ball_radius = 0.5f;
+  o->ball_cap_factor = 1.5f;
+  o->two_pass = 0;
 }
 
 smhip_status smhip_create(int device, void* stream, int pair_slots, int max_source_points, int max_target_points,

@@ -110,6 +110,7 @@ struct IcpDev {
   int32_t two_pass;          // 1 = nn_ball defers cap-radius queries to a second, compacted launch
   int32_t exact_all;         // 1 = every match exact (no lower bounds survive), e.g. find_closests
   float ball_radius;         // largest search radius of nn_ball (first iteration / clamp)
+  float cap_factor;          // next cap = cap_factor x quantile distance
   float rho;                 // dist_outlier_ratio as float (widened to double exactly like the reference)
   float grid_cell;
 };

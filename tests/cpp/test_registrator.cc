@@ -1,0 +1,67 @@
+// Drives the C++ registrator::Interface mirror exactly the way builder/map_builder.cc:281-333 drives
+// the reference: CreateMatcher(options) -> target->CalculateNormals() -> SetInputTarget ->
+// SetInputSource -> Align(guess, result) -> GetFitnessScore().  Clouds come from KITTI-layout .bin
+// files (float32 x,y,z,intensity) written by the pytest wrapper; the result goes to stdout as JSON.
+#define SMHIP_REGISTRATOR_THROW_ON_CHECK 1
+#include <cstdio>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "smhip/registrator.h"
+
+using smhip::data::InnerPointCloudData;
+using smhip::data::InnerPointType;
+namespace reg = smhip::registrator;
+
+static std::vector<InnerPointType> ReadKittiBin(const char* path) {   // ros_node/kitti_reader.cc:91-121
+  std::ifstream f(path, std::ios::binary);
+  std::vector<InnerPointType> pts;
+  float v[4];
+  int i = 0;
+  while (f.read(reinterpret_cast<char*>(v), sizeof(v))) {
+    InnerPointType p; p.x = v[0]; p.y = v[1]; p.z = v[2]; p.intensity = v[3]; p.factor = 0.f;
+    pts.push_back(p); ++i;
+  }
+  for (size_t k = 0; k < pts.size(); ++k) pts[k].factor = static_cast<float>(k) / pts.size();   // data_collector.h:202-204
+  return pts;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 4) { std::fprintf(stderr, "usage: %s target.bin source.bin guess_tx [xml]\n", argv[0]); return 2; }
+  reg::MatcherOptions opt;
+  opt.type = reg::kFastIcp;
+  opt.registrator_options_node = argc > 4 ? argv[4] : "";
+  // unknown option names are a CHECK failure (interface.cc:66-67)
+  bool unknown_caught = false;
+  try {
+    reg::MatcherOptions bad = opt;
+    bad.registrator_options_node = "<param name=\"no_such_option\"> 1 </param>";
+    reg::CreateMatcher(bad);
+  } catch (const std::exception&) { unknown_caught = true; }
+  // wrong type -> nullptr (interface.cc:158-160)
+  reg::MatcherOptions wrong; wrong.type = reg::kLegoLoam;
+  const bool wrong_null = reg::CreateMatcher(wrong) == nullptr;
+
+  auto matcher = reg::CreateMatcher(opt, true);
+  if (!matcher) return 3;
+  InnerPointCloudData::Ptr target(new InnerPointCloudData(ReadKittiBin(argv[1])));
+  InnerPointCloudData::Ptr source(new InnerPointCloudData(ReadKittiBin(argv[2])));
+  // target without normals is a CHECK failure (icp_fast.cc:430)
+  bool no_normals_caught = false;
+  try { matcher->SetInputTarget(target); } catch (const std::exception&) { no_normals_caught = true; }
+  target->CalculateNormals();                       // map_builder.cc:286
+  matcher->SetInputTarget(target);                  // :317
+  matcher->SetInputSource(source);                  // :329
+  reg::Matrix4d guess = reg::Matrix4d::Identity(), result;
+  guess(0, 3) = std::atof(argv[3]);
+  const bool ok = matcher->Align(guess, result);    // :333
+  std::printf("{\"ok\": %s, \"score\": %.17g, \"type\": %d, \"unknown_option_check\": %s, \"wrong_type_null\": %s, "
+              "\"no_normals_check\": %s, \"target_points\": %d, \"result\": [",
+              ok ? "true" : "false", matcher->GetFitnessScore(), (int)matcher->GetType(), unknown_caught ? "true" : "false",
+              wrong_null ? "true" : "false", no_normals_caught ? "true" : "false", target->GetEigenCloud()->size());
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) std::printf("%.17g%s", result(r, c), (r == 3 && c == 3) ? "" : ", ");
+  std::printf("]}\n");
+  return 0;
+}

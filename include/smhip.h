@@ -173,6 +173,45 @@ smhip_status smhip_icp_get_matches(smhip_handle h, int slot, int32_t* ids, float
  * centring exactly as Align does) and return ids / d2 without running ICP. */
 smhip_status smhip_icp_find_closests(smhip_handle h, int slot, const double T[16], int32_t* ids, float* d2, int n);
 
+/* ---- registrators::Ndt (pclomp NDT, /root/reference/registrators/ndt.cc:29-64) -------------------
+ * Uses slot 0's clouds (upload them with smhip_set_source_f32 / smhip_set_target_f32: the reference's
+ * Ndt converts the InnerPointType AoS to pcl::PointXYZ, ndt.cc:44-51; the target needs no normals).
+ * Defaults are the wrapper's: resolution 1.0 (ndt.cc:31), KDTREE neighbourhood (ndt.cc:33), step 0.1,
+ * outlier ratio 0.55, transformation epsilon 0.1, 35 iterations (pclomp/ndt_omp_impl.hpp:47-76). */
+typedef struct smhip_ndt_options {
+  float resolution;
+  float step_size;
+  float outlier_ratio;
+  float transformation_epsilon;
+  int32_t max_iterations;
+  int32_t min_points_per_voxel;      /* voxel_grid_covariance_omp.h:204 */
+  float min_covar_eigvalue_mult;     /* voxel_grid_covariance_omp.h:205 */
+  int32_t reserved[5];
+} smhip_ndt_options;
+
+typedef struct smhip_ndt_stats {
+  int32_t iterations;                /* nr_iterations_ */
+  int32_t derivative_calls;          /* computeDerivatives evaluations (1 + one per Newton iteration) */
+  int32_t voxels;                    /* occupied voxels of the target */
+  int32_t status;
+  double trans_probability;          /* score / N (ndt_omp_impl.hpp:170) */
+  double pairs_last;                 /* (point, voxel) pairs of the last evaluation = N * mean neighbours */
+} smhip_ndt_stats;
+
+void smhip_ndt_default_options(smhip_ndt_options* o);
+smhip_status smhip_ndt_set_options(smhip_handle h, const smhip_ndt_options* o);
+/* Ndt::Align: voxel grid build + Newton iterations + getFitnessScore.  *score = mean squared 1-NN
+ * distance of the aligned source to the raw target (LOWER is better, unlike the ICP score). */
+smhip_status smhip_ndt_align(smhip_handle h, const double guess[16], double result[16], double* score,
+                             smhip_ndt_stats* stats);
+/* parity-test hooks: VoxelGridCovariance::applyFilter output and one computeDerivatives evaluation
+ * at pose6 = (tx, ty, tz, rx, ry, rz).  icovs hold xx xy xz yy yz zz as float; hess is row-major 6x6. */
+smhip_status smhip_ndt_build_voxels(smhip_handle h, int* n_voxels);
+smhip_status smhip_ndt_get_voxels(smhip_handle h, int capacity, int32_t* keys, int32_t* counts, double* means,
+                                  float* icovs, float* centroids);
+smhip_status smhip_ndt_compute_derivatives(smhip_handle h, const double pose6[6], int compute_hessian,
+                                           double* score, double grad[6], double hess[36]);
+
 /* ---- profiling ----------------------------------------------------------- */
 smhip_status smhip_icp_enable_profile(smhip_handle h, int enable);
 smhip_status smhip_icp_get_profile(smhip_handle h, smhip_icp_profile* out);

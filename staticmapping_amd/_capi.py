@@ -33,6 +33,18 @@ class IcpProfile(ctypes.Structure):
                 ("ms_nn_main", ctypes.c_double)]
 
 
+class NdtOptions(ctypes.Structure):
+    _fields_ = [("resolution", ctypes.c_float), ("step_size", ctypes.c_float), ("outlier_ratio", ctypes.c_float),
+                ("transformation_epsilon", ctypes.c_float), ("max_iterations", ctypes.c_int32),
+                ("min_points_per_voxel", ctypes.c_int32), ("min_covar_eigvalue_mult", ctypes.c_float),
+                ("reserved", ctypes.c_int32 * 5)]
+
+
+class NdtStats(ctypes.Structure):
+    _fields_ = [("iterations", ctypes.c_int32), ("derivative_calls", ctypes.c_int32), ("voxels", ctypes.c_int32),
+                ("status", ctypes.c_int32), ("trans_probability", ctypes.c_double), ("pairs_last", ctypes.c_double)]
+
+
 # name -> (restype, argtypes): every symbol include/smhip.h declares
 SIGNATURES = {
     "smhip_version": (ctypes.c_int, []),
@@ -62,6 +74,12 @@ SIGNATURES = {
     "smhip_icp_get_matches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int32_p, c_float_p, ctypes.c_int]),
     "smhip_icp_find_closests": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_int32_p, c_float_p,
                                                ctypes.c_int]),
+    "smhip_ndt_default_options": (None, [ctypes.POINTER(NdtOptions)]),
+    "smhip_ndt_set_options": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(NdtOptions)]),
+    "smhip_ndt_align": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p, ctypes.POINTER(NdtStats)]),
+    "smhip_ndt_build_voxels": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
+    "smhip_ndt_get_voxels": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int32_p, c_int32_p, c_double_p, c_float_p, c_float_p]),
+    "smhip_ndt_compute_derivatives": (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int, c_double_p, c_double_p, c_double_p]),
     "smhip_icp_enable_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "smhip_icp_get_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(IcpProfile)]),
 }

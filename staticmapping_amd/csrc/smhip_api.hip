@@ -21,7 +21,10 @@
 
 using namespace smhip;
 
+struct smhip_ndt_state;
+
 struct smhip_context {
+  smhip_ndt_state* ndt = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -380,10 +383,13 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   return SMHIP_OK;
 }
 
+extern "C" void smhip_internal_free_ndt(smhip_context* h);
+
 smhip_status smhip_destroy(smhip_handle h) {
   if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  smhip_internal_free_ndt(h);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->stage) (void)hipHostFree(h->stage);
   if (h->in_pinned) (void)hipHostFree(h->in_pinned);
@@ -661,3 +667,23 @@ smhip_status smhip_icp_get_profile(smhip_handle h, smhip_icp_profile* out) {
 }
 
 }  // extern "C"
+
+// ---- registrators::Ndt --------------------------------------------------------------------------
+#include "smhip_ndt_api.hip"
+
+namespace {
+NdtHost& ndt_of(smhip_context* h) {
+  if (!h->ndt) { h->ndt = new smhip_ndt_state(); smhip_ndt_default_options(&h->ndt->n.opts); }
+  return h->ndt->n;
+}
+}  // namespace
+
+extern "C" void smhip_internal_free_ndt(smhip_context* h) {
+  if (!h || !h->ndt) return;
+  NdtHost& n = h->ndt->n;
+  if (n.out_pinned) (void)hipHostFree(n.out_pinned);
+  if (n.info_pinned) (void)hipHostFree(n.info_pinned);
+  if (n.fit_pinned) (void)hipHostFree(n.fit_pinned);
+  delete h->ndt;
+  h->ndt = nullptr;
+}

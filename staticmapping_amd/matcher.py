@@ -196,3 +196,69 @@ class IcpFastHip:
         p = _capi.IcpProfile()
         self._check(self._lib.smhip_icp_get_profile(self._h, ctypes.byref(p)))
         return {k: getattr(p, k) for k, _ in p._fields_ if k != "reserved"}
+
+
+class NdtHip(IcpFastHip):
+    """registrators::Ndt (pclomp NDT) on the GPU: mirrors Ndt::Align (/root/reference/registrators/ndt.cc:38-64).
+    Clouds are float32 [N,3+] arrays (the reference converts InnerPointType -> pcl::PointXYZ); the
+    target needs no normals.  get_fitness_score() is PCL's getFitnessScore(): mean squared 1-NN
+    distance, LOWER is better."""
+
+    def __init__(self, device: int = 0, max_source_points: int = 131072, max_target_points: int = 524288,
+                 stream: int | None = None, **ndt_options):
+        super().__init__(device=device, pair_slots=1, max_source_points=max_source_points,
+                         max_target_points=max_target_points, stream=stream)
+        self._nopts = _capi.NdtOptions()
+        self._lib.smhip_ndt_default_options(ctypes.byref(self._nopts))
+        if ndt_options:
+            self.set_ndt_options(**ndt_options)
+        self.last_ndt_stats = None
+
+    def set_ndt_options(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self._nopts, k):
+                raise KeyError(f"unknown option {k}")
+            setattr(self._nopts, k, v)
+        self._check(self._lib.smhip_ndt_set_options(self._h, ctypes.byref(self._nopts)))
+
+    def set_input_source(self, points, slot: int = 0):
+        a = np.ascontiguousarray(np.asarray(points, dtype=np.float32))
+        self._check(self._lib.smhip_set_source_f32(self._h, 0, a.ctypes.data_as(_capi.c_float_p), a.shape[1], a.shape[0]))
+
+    def set_input_target(self, points, normals=None, slot: int = 0):
+        a = np.ascontiguousarray(np.asarray(points, dtype=np.float32))
+        self._check(self._lib.smhip_set_target_f32(self._h, 0, a.ctypes.data_as(_capi.c_float_p), a.shape[1], None, 0, a.shape[0]))
+
+    def align(self, guess=None):
+        G = np.eye(4) if guess is None else np.asarray(guess, dtype=np.float64)
+        g = np.ascontiguousarray(G.T).reshape(-1)
+        res = np.zeros(16)
+        score = ctypes.c_double()
+        st = _capi.NdtStats()
+        self._check(self._lib.smhip_ndt_align(self._h, g.ctypes.data_as(_capi.c_double_p), res.ctypes.data_as(_capi.c_double_p),
+                                              ctypes.byref(score), ctypes.byref(st)))
+        self.final_score_ = score.value
+        self.last_ndt_stats = {k: getattr(st, k) for k, _ in st._fields_}
+        return True, res.reshape(4, 4).T.copy()
+
+    # -- parity-test hooks ---------------------------------------------------------------------
+    def build_voxels(self) -> int:
+        n = ctypes.c_int()
+        self._check(self._lib.smhip_ndt_build_voxels(self._h, ctypes.byref(n)))
+        return n.value
+
+    def get_voxels(self, n: int):
+        keys = np.zeros(n, np.int32); counts = np.zeros(n, np.int32)
+        means = np.zeros((n, 3)); icov = np.zeros((n, 6), np.float32); cent = np.zeros((n, 3), np.float32)
+        self._check(self._lib.smhip_ndt_get_voxels(self._h, n, keys.ctypes.data_as(_capi.c_int32_p), counts.ctypes.data_as(_capi.c_int32_p),
+                                                   means.ctypes.data_as(_capi.c_double_p), icov.ctypes.data_as(_capi.c_float_p),
+                                                   cent.ctypes.data_as(_capi.c_float_p)))
+        return keys, counts, means, icov, cent
+
+    def compute_derivatives(self, pose6, compute_hessian: bool = True):
+        p = _f64(pose6)
+        score = ctypes.c_double(); g = np.zeros(6); H = np.zeros(36)
+        self._check(self._lib.smhip_ndt_compute_derivatives(self._h, p.ctypes.data_as(_capi.c_double_p), int(compute_hessian),
+                                                            ctypes.byref(score), g.ctypes.data_as(_capi.c_double_p),
+                                                            H.ctypes.data_as(_capi.c_double_p)))
+        return score.value, g, H.reshape(6, 6)

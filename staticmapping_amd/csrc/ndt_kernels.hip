@@ -113,7 +113,9 @@ __global__ __launch_bounds__(256) void ndt_voxel_mark(NdtDev d) {
     int i0, i1, i2;
     if (ndt_voxel_of(g, p.x, p.y, p.z, i0, i1, i2)) {
       const uint32_t w = (uint32_t)((i2 * g->div_b[1] + i1) * g->wx + (i0 >> 5));
-      atomicOr(&d.bits[w], 1u << (i0 & 31));
+      // hundreds of points share a voxel: look before the atomic so only the first few actually issue it
+      // (a plain, L1-cached load: a stale zero only costs a redundant atomic)
+      if (!(d.bits[w] & (1u << (i0 & 31)))) atomicOr(&d.bits[w], 1u << (i0 & 31));
       code = (w << 5) | (uint32_t)(i0 & 31);
     }
   }
@@ -144,13 +146,31 @@ __global__ __launch_bounds__(1024) void ndt_voxel_rank(NdtDev d) {
 
 __global__ __launch_bounds__(256) void ndt_voxel_count(NdtDev d) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= d.nt) return;
-  const uint32_t code = d.vidx[j];
-  if (code == 0xffffffffu) { d.vslot[j] = 0xffffffffu; return; }
-  const uint2 wd = d.words[code >> 5];
-  const uint32_t slot = wd.y + __popc(wd.x & ((1u << (code & 31)) - 1u));
-  d.vslot[j] = slot;
-  d.vord[j] = atomicAdd(&d.vcount[slot], 1u);
+  const int lane = threadIdx.x & 63;
+  uint32_t slot = 0xffffffffu;
+  if (j < d.nt) {
+    const uint32_t code = d.vidx[j];
+    if (code != 0xffffffffu) {
+      const uint2 wd = d.words[code >> 5];
+      slot = wd.y + __popc(wd.x & ((1u << (code & 31)) - 1u));
+    }
+  }
+  // consecutive points of a scan fall into the same 1 m voxel in long runs: one atomic per
+  // (wave, voxel) instead of one per point
+  uint32_t ord = 0;
+  unsigned long long todo = __ballot(slot != 0xffffffffu);
+  for (int round = 0; round < 4 && todo; ++round) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t s = __shfl(slot, leader, 64);
+    const unsigned long long same = __ballot(slot == s);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&d.vcount[s], (uint32_t)__popcll(same));
+    base = __shfl(base, leader, 64);
+    if (slot == s) ord = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  if ((todo >> lane) & 1ull) ord = atomicAdd(&d.vcount[slot], 1u);   // incoherent input order: one atomic each
+  if (j < d.nt) { d.vslot[j] = slot; d.vord[j] = ord; }
 }
 
 __global__ __launch_bounds__(1024) void ndt_voxel_cscan(NdtDev d) {
@@ -398,12 +418,22 @@ __global__ __launch_bounds__(kNdtDerivThreads) void ndt_derivatives(NdtDev d, Nd
   }
 }
 
-__global__ void ndt_reduce(NdtDev d, int nblocks) {
-  const int c = threadIdx.x;
-  if (c >= kNdtDerivCols) return;
-  double t = 0;
-  for (int k = 0; k < nblocks; ++k) t += d.partials[(size_t)k * kNdtDerivCols + c];   // fixed order
-  d.out[c] = t;
+// 16 thread groups take every 16th block, then one thread per column folds the group sums:
+// a fixed order, so repeated evaluations at the same pose are bitwise identical.
+__global__ __launch_bounds__(16 * 64) void ndt_reduce(NdtDev d, int nblocks) {
+  __shared__ double s_g[16][kNdtDerivCols];
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  if (c < kNdtDerivCols) {
+    double t = 0;
+    for (int k = grp; k < nblocks; k += 16) t += d.partials[(size_t)k * kNdtDerivCols + c];
+    s_g[grp][c] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNdtDerivCols) {
+    double t = 0;
+    for (int g = 0; g < 16; ++g) t += s_g[g][threadIdx.x];
+    d.out[threadIdx.x] = t;
+  }
 }
 
 // mean of the squared NN distances of slot 0 (pcl::Registration::getFitnessScore, ndt.cc:60)

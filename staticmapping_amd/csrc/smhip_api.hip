@@ -137,7 +137,7 @@ smhip_status enqueue_prepare(smhip_context* h, int np, int nt_max) {
   hipLaunchKernelGGL(grid_count, gpts, dim3(256), 0, h->stream, d);
   hipLaunchKernelGGL(grid_cscan, dim3(np), dim3(1024), 0, h->stream, d);
   hipLaunchKernelGGL(grid_scatter, gpts, dim3(256), 0, h->stream, d);
-  hipLaunchKernelGGL(grid_sort_cells, gpts, dim3(256), 0, h->stream, d);
+  if (d.sort_cells) hipLaunchKernelGGL(grid_sort_cells, gpts, dim3(256), 0, h->stream, d);
   HIPCHK(h, hipGetLastError());
   return SMHIP_OK;
 }
@@ -237,6 +237,7 @@ void sync_options(smhip_context* h) {
   h->dev.rho = h->opts.dist_outlier_ratio;
   h->dev.grid_cell = h->opts.grid_cell > 0 ? h->opts.grid_cell : 0.5f;
   h->dev.use_ball = h->opts.use_ball;
+  h->dev.sort_cells = 1;
   h->dev.two_pass = h->opts.two_pass;
   h->dev.cap_factor = h->opts.ball_cap_factor > 1.0f ? h->opts.ball_cap_factor : 1.5f;
   h->dev.exact_all = h->opts.exact_matches;

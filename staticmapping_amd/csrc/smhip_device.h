@@ -106,6 +106,7 @@ struct IcpDev {
   int32_t max_iteration;
   int32_t early_exit;
   int32_t max_ring;
+  int32_t sort_cells;        // 1 = order points inside a cell by caller index (deterministic tie rule)
   int32_t use_ball;          // 1 = ball-bounded search with certified trimming; 0 = ring search over every query
   int32_t two_pass;          // 1 = nn_ball defers cap-radius queries to a second, compacted launch
   int32_t exact_all;         // 1 = every match exact (no lower bounds survive), e.g. find_closests

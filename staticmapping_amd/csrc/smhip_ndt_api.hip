@@ -203,7 +203,7 @@ smhip_status ndt_derivs(smhip_context* h, const double* p, const float* T, bool 
   P.compute_hessian = hess ? 1 : 0;
   const int blocks = std::min(kNdtMaxDerivBlocks, std::max(1, ceil_div(n.dev.ns, kNdtDerivThreads)));
   hipLaunchKernelGGL(ndt_derivatives, dim3(blocks), dim3(kNdtDerivThreads), 0, h->stream, n.dev, P);
-  hipLaunchKernelGGL(ndt_reduce, dim3(1), dim3(64), 0, h->stream, n.dev, blocks);
+  hipLaunchKernelGGL(ndt_reduce, dim3(1), dim3(16 * 64), 0, h->stream, n.dev, blocks);
   HIPCHK(h, hipMemcpyAsync(n.out_pinned, n.dev.out, sizeof(double) * kNdtDerivCols, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipGetLastError());
@@ -380,12 +380,13 @@ smhip_status smhip_ndt_align(smhip_handle h, const double guess[16], double resu
     s = fill_inputs(h, 1, result, &ns_max, &nt_max);
     h->has_normals[0] = had;
     if (s) return s;
+    // distances only: no tie-order requirement (skip the per-cell sort) and no previous match to seed a
+    // ball search -> plain exact ring search (r = 1 certifies almost every query against a dense submap)
+    const int sort_was = h->dev.sort_cells, ball_was = h->dev.use_ball;
+    h->dev.sort_cells = 0; h->dev.use_ball = 0;
     s = enqueue_prepare(h, 1, nt_max);
-    if (s) return s;
-    const int exact_was = h->dev.exact_all;
-    h->dev.exact_all = 1;
-    s = enqueue_find_closests(h, 1, ns_max);
-    h->dev.exact_all = exact_was;
+    if (s == SMHIP_OK) s = enqueue_find_closests(h, 1, ns_max);
+    h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was;
     if (s) return s;
     hipLaunchKernelGGL(fitness_partial, dim3(64), dim3(256), 0, h->stream, h->dev.d2, h->ns[0], n.fit_dev);
     HIPCHK(h, hipMemsetAsync(h->dev.hist, 0, sizeof(uint32_t) * kHistBins, h->stream));

@@ -56,7 +56,24 @@ int main(int argc, char** argv) {
   reg::Matrix4d guess = reg::Matrix4d::Identity(), result;
   guess(0, 3) = std::atof(argv[3]);
   const bool ok = matcher->Align(guess, result);    // :333
-  std::printf("{\"ok\": %s, \"score\": %.17g, \"type\": %d, \"unknown_option_check\": %s, \"wrong_type_null\": %s, "
+  // the same clouds through registrators::Ndt (type 5): no normals needed, InnerCloud AoS upload
+  reg::MatcherOptions nopt; nopt.type = reg::kNdt;
+  auto ndt = reg::CreateMatcher(nopt);
+  reg::Matrix4d nres = reg::Matrix4d::Identity();
+  bool ndt_ok = false; double ndt_score = -1; int ndt_type = -1;
+  if (ndt) {
+    InnerPointCloudData::Ptr target2(new InnerPointCloudData(ReadKittiBin(argv[1])));
+    ndt->SetInputTarget(target2);
+    ndt->SetInputSource(source);
+    ndt_ok = ndt->Align(guess, nres);
+    ndt_score = ndt->GetFitnessScore();
+    ndt_type = (int)ndt->GetType();
+  }
+  std::printf("{\"ndt_ok\": %s, \"ndt_score\": %.17g, \"ndt_type\": %d, \"ndt_result\": [", ndt_ok ? "true" : "false", ndt_score, ndt_type);
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) std::printf("%.17g%s", nres(r, c), (r == 3 && c == 3) ? "" : ", ");
+  std::printf("], ");
+  std::printf("\"ok\": %s, \"score\": %.17g, \"type\": %d, \"unknown_option_check\": %s, \"wrong_type_null\": %s, "
               "\"no_normals_check\": %s, \"target_points\": %d, \"result\": [",
               ok ? "true" : "false", matcher->GetFitnessScore(), (int)matcher->GetType(), unknown_caught ? "true" : "false",
               wrong_null ? "true" : "false", no_normals_caught ? "true" : "false", target->GetEigenCloud()->size());

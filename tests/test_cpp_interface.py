@@ -51,3 +51,11 @@ def test_cpp_interface_matches_python_path_and_oracle(tmp_path, velo20k):
     # the C++ path keeps leaves with non-finite normals exactly like the reference does; allow for that
     assert da < 1e-4 and dt < 1e-3, (da, dt)
     assert abs(res["score"] - ref["score"]) < 1e-3
+    # registrators::Ndt through the same C++ surface vs the numpy restatement
+    from oracle import ndt as ondt
+    assert res["ndt_ok"] and res["ndt_type"] == 5
+    nref = ondt.ndt_align(c["src"], c["tgt"], guess=c["guess"])
+    Rn = np.array(res["ndt_result"]).reshape(4, 4)
+    da, dt = sm.se3_error(Rn, nref["result"])
+    assert da < 1e-4 and dt < 1e-3, (da, dt)
+    assert abs(res["ndt_score"] - nref["score"]) <= 1e-3 * nref["score"]

@@ -348,6 +348,93 @@ class NdtHip : public Interface {
   smhip_ndt_stats stats_{};
 };
 
+// GPU replacement of registrator::IcpUsingPointMatcher (icp_pointmatcher.cc:104-247): the
+// libpointmatcher chain RandomSampling(0.9) -> SamplingSurfaceNormal(knn 7, method 1) -> KDTree(1-NN)
+// -> TrimmedDist(0.7) -> PointToPlane -> Counter(150) + Differential(1e-3, 1e-2, 4), followed by the
+// post-hoc score over the full reading against the raw reference (:112-143); Align returns score >= 0.6.
+class IcpPointMatcherHip : public Interface {
+ public:
+  explicit IcpPointMatcherHip(int device = 0, int max_points = 1 << 18) : device_(device), max_points_(max_points) {
+    this->type_ = kIcpPM;
+    SMHIP_REG_REGISTRATOR_INNER_OPTION("device_id", OptionItemDataType::kInt32, device_);
+    SMHIP_REG_REGISTRATOR_INNER_OPTION("random_sampling_prob", OptionItemDataType::kFloat32, prob_);
+    SMHIP_REG_REGISTRATOR_INNER_OPTION("random_seed", OptionItemDataType::kInt32, seed_);
+  }
+  ~IcpPointMatcherHip() override { if (handle_) smhip_destroy(handle_); }
+  void InitWithOptions() override { EnsureHandle(); }
+
+  void SetInputSource(InnerCloudPtr cloud) override {               // icp_pointmatcher.cc:84-92
+    if (!cloud || cloud->Empty()) { std::fprintf(stderr, "[ERROR] Empty cloud.\n"); return; }
+    reading_ = DropNan(cloud->GetInnerCloud());
+  }
+  void SetInputTarget(InnerCloudPtr cloud) override {               // :94-102
+    if (!cloud || cloud->Empty()) { std::fprintf(stderr, "[ERROR] Empty cloud.\n"); return; }
+    reference_ = DropNan(cloud->GetInnerCloud());
+  }
+  bool Align(const Matrix4d& guess, Matrix4d& result) override {    // :104-149
+    if (reading_.empty() || reference_.empty()) return false;
+    EnsureHandle();
+    // reading filter: RandomSampling (seeded here; the reference uses std::rand())
+    std::vector<float> sampled;
+    sampled.reserve(reading_.size());
+    uint32_t state = static_cast<uint32_t>(seed_) * 2654435761u + 12345u;
+    for (size_t i = 0; i + 2 < reading_.size(); i += 3) {
+      state = state * 1664525u + 1013904223u;
+      const float r = static_cast<float>(state >> 8) * (1.0f / 16777216.0f);
+      if (prob_ >= 1.0f || r < prob_) { sampled.push_back(reading_[i]); sampled.push_back(reading_[i + 1]); sampled.push_back(reading_[i + 2]); }
+    }
+    // reference filter: SamplingSurfaceNormal == CalculateNormals
+    data::EigenPointCloud ref;
+    ref.points.assign(reference_.begin(), reference_.end());
+    ref.CalculateNormals();
+    smhip_icp_options o; smhip_icp_default_options(&o);
+    o.max_iteration = 150; o.dist_outlier_ratio = 0.7f; o.early_exit = 1;
+    if (smhip_icp_set_options(handle_, &o) != SMHIP_OK ||
+        smhip_set_source_f32(handle_, 0, sampled.data(), 3, static_cast<int>(sampled.size() / 3)) != SMHIP_OK ||
+        smhip_set_target_f64(handle_, 0, ref.points.data(), ref.normals.data(), ref.size()) != SMHIP_OK) return Fail(guess, result);
+    double score = 0.0;
+    if (smhip_icp_align(handle_, guess.data(), result.data(), &score, &stats_) != SMHIP_OK) return Fail(guess, result);
+    // final score: the FULL reading transformed by `result` against the RAW reference, one trimmed pass (:112-143)
+    std::vector<double> raw(reference_.begin(), reference_.end()), up(raw.size(), 0.0);
+    for (size_t i = 2; i < up.size(); i += 3) up[i] = 1.0;
+    o.max_iteration = 1; o.early_exit = 0;
+    Matrix4d ignored;
+    if (smhip_icp_set_options(handle_, &o) != SMHIP_OK ||
+        smhip_set_source_f32(handle_, 0, reading_.data(), 3, static_cast<int>(reading_.size() / 3)) != SMHIP_OK ||
+        smhip_set_target_f64(handle_, 0, raw.data(), up.data(), static_cast<int>(raw.size() / 3)) != SMHIP_OK ||
+        smhip_icp_align(handle_, result.data(), ignored.data(), &score, nullptr) != SMHIP_OK) return Fail(guess, result);
+    this->final_score_ = score;                                      // :143
+    return this->final_score_ >= 0.6;                                // :145-148
+  }
+
+ private:
+  static std::vector<float> DropNan(const std::vector<data::InnerPointType>& in) {   // InnerCloudToPmPoints, :43-71
+    std::vector<float> out;
+    out.reserve(3 * in.size());
+    for (const auto& p : in)
+      if (!(p.x != p.x) && !(p.y != p.y) && !(p.z != p.z)) { out.push_back(p.x); out.push_back(p.y); out.push_back(p.z); }
+    return out;
+  }
+  bool Fail(const Matrix4d& guess, Matrix4d& result) {
+    std::fprintf(stderr, "[ERROR] IcpPointMatcherHip::Align: %s\n", smhip_last_error(handle_));
+    result = guess;
+    return false;
+  }
+  void EnsureHandle() {
+    if (!handle_) {
+      const smhip_status s = smhip_create(device_, nullptr, 1, max_points_, max_points_, &handle_);
+      SMHIP_CHECK(s == SMHIP_OK, "no usable MI355X (gfx950) device: there is no CPU fallback");
+    }
+  }
+  std::vector<float> reading_, reference_;     // xyz of the non-NaN points
+  float prob_ = 0.9f;                           // icp_pointmatcher.cc:172
+  int32_t seed_ = 0;
+  int32_t device_ = 0;
+  int max_points_;
+  smhip_handle handle_ = nullptr;
+  smhip_icp_stats stats_{};
+};
+
 // interface.cc:139-173.  kFastIcp selects the HIP matcher; the matchers that have no HIP
 // implementation yet report "Wrong type" exactly like an unknown enum value does there.
 inline std::shared_ptr<Interface> CreateMatcher(const MatcherOptions& options, bool verbose = false) {
@@ -358,6 +445,9 @@ inline std::shared_ptr<Interface> CreateMatcher(const MatcherOptions& options, b
       break;
     case kNdt:
       matcher.reset(new NdtHip(options.device));
+      break;
+    case kIcpPM:
+      matcher.reset(new IcpPointMatcherHip(options.device));
       break;
     default:
       std::fprintf(stderr, "[ERROR] Wrong type\n");

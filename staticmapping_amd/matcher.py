@@ -262,3 +262,68 @@ class NdtHip(IcpFastHip):
                                                             ctypes.byref(score), g.ctypes.data_as(_capi.c_double_p),
                                                             H.ctypes.data_as(_capi.c_double_p)))
         return score.value, g, H.reshape(6, 6)
+
+
+class IcpPointMatcherHip:
+    """registrators::IcpUsingPointMatcher (/root/reference/registrators/icp_pointmatcher.cc:104-247) on the
+    same GPU engine: IcpFast is the author's restatement of exactly this libpointmatcher chain.
+
+      reading filter   RandomSampling(prob 0.9)                       :171-176   (seeded here; std::rand() there)
+      reference filter SamplingSurfaceNormal(knn 7, method 1)         :178-184   = CalculateNormals
+      matcher          KDTree knn 1 (exact here, eps 3.16 there)      :187-193
+      outlier filter   TrimmedDist(0.7)                               :196-200
+      minimiser        PointToPlane                                   :207-209
+      checkers         Counter(150) + Differential(1e-3, 1e-2, 4)     :212-224
+    After compute() the score is recomputed by matching the FULL transformed reading against the RAW
+    reference with the same trimmed filter (:112-143) and Align returns score >= 0.6 (:145-148).
+    """
+
+    def __init__(self, device: int = 0, max_points: int = 262144, prob: float = 0.9, seed: int | None = 0, **options):
+        self._m = IcpFastHip(device=device, pair_slots=1, max_source_points=max_points, max_target_points=max_points, **options)
+        self.prob = prob
+        self.seed = seed
+        self.final_score_ = float("nan")
+        self._reading = None
+        self._reference = None
+        self.last_mask = None
+
+    def close(self):
+        self._m.close()
+
+    def set_input_source(self, points):
+        a = np.asarray(points, dtype=np.float32)
+        self._reading = a[~np.isnan(a[:, :3]).any(axis=1)]          # InnerCloudToPmPoints drops NaN points, :57-66
+
+    def set_input_target(self, points):
+        a = np.asarray(points, dtype=np.float32)
+        self._reference = a[~np.isnan(a[:, :3]).any(axis=1)]
+
+    def sampling_mask(self, n: int) -> np.ndarray:
+        if self.prob >= 1.0:
+            return np.ones(n, dtype=bool)
+        return np.random.default_rng(self.seed).random(n) < self.prob
+
+    def align(self, guess=None):
+        if self._reading is None or self._reference is None:
+            raise SmhipError(4, "Align before SetInputSource/SetInputTarget")
+        m = self._m
+        G = np.eye(4) if guess is None else np.asarray(guess, dtype=np.float64)
+        # ---- pm_icp_.compute(reading, reference, guess)                                :107-110
+        self.last_mask = self.sampling_mask(len(self._reading))
+        q, n = calculate_normals(self._reference[:, :3].astype(np.float64))
+        m.set_options(max_iteration=150, dist_outlier_ratio=0.7, early_exit=1)
+        m.set_input_source(np.ascontiguousarray(self._reading[self.last_mask]))
+        m.set_input_target(q, n)
+        _, result = m.align(G)
+        self.iterations = m.last_stats[0]["iterations"]
+        # ---- final score: full reading, raw reference, one trimmed matching pass        :112-143
+        m.set_options(max_iteration=1, early_exit=0)
+        m.set_input_source(np.ascontiguousarray(self._reading))
+        ref = self._reference[:, :3].astype(np.float64)
+        m.set_input_target(ref, np.zeros_like(ref) + [0.0, 0.0, 1.0])     # normals unused by the score
+        m.align(result)
+        self.final_score_ = m.get_fitness_score()
+        return self.final_score_ >= 0.6, result                                        # :145-148
+
+    def get_fitness_score(self) -> float:
+        return self.final_score_

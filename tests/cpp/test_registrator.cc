@@ -69,7 +69,24 @@ int main(int argc, char** argv) {
     ndt_score = ndt->GetFitnessScore();
     ndt_type = (int)ndt->GetType();
   }
-  std::printf("{\"ndt_ok\": %s, \"ndt_score\": %.17g, \"ndt_type\": %d, \"ndt_result\": [", ndt_ok ? "true" : "false", ndt_score, ndt_type);
+  // registrators::IcpUsingPointMatcher (type 1) with sampling off so the run is reproducible
+  reg::MatcherOptions popt; popt.type = reg::kIcpPM;
+  popt.registrator_options_node = "<param name=\"random_sampling_prob\"> 1.0 </param>";
+  auto pm = reg::CreateMatcher(popt);
+  reg::Matrix4d pres = reg::Matrix4d::Identity();
+  bool pm_ok = false; double pm_score = -1;
+  if (pm) {
+    InnerPointCloudData::Ptr target3(new InnerPointCloudData(ReadKittiBin(argv[1])));
+    pm->SetInputTarget(target3);
+    pm->SetInputSource(source);
+    pm_ok = pm->Align(guess, pres);
+    pm_score = pm->GetFitnessScore();
+  }
+  std::printf("{\"pm_ok\": %s, \"pm_score\": %.17g, \"pm_result\": [", pm_ok ? "true" : "false", pm_score);
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) std::printf("%.17g%s", pres(r, c), (r == 3 && c == 3) ? "" : ", ");
+  std::printf("], ");
+  std::printf("\"ndt_ok\": %s, \"ndt_score\": %.17g, \"ndt_type\": %d, \"ndt_result\": [", ndt_ok ? "true" : "false", ndt_score, ndt_type);
   for (int r = 0; r < 4; ++r)
     for (int c = 0; c < 4; ++c) std::printf("%.17g%s", nres(r, c), (r == 3 && c == 3) ? "" : ", ");
   std::printf("], ");

@@ -51,6 +51,14 @@ def test_cpp_interface_matches_python_path_and_oracle(tmp_path, velo20k):
     # the C++ path keeps leaves with non-finite normals exactly like the reference does; allow for that
     assert da < 1e-4 and dt < 1e-3, (da, dt)
     assert abs(res["score"] - ref["score"]) < 1e-3
+    # registrators::IcpUsingPointMatcher chain (sampling off) vs its restatement
+    from oracle import icp_pointmatcher as opm
+    ok_o, R_o, score_o, _ = opm.align(c["src"], c["tgt"], c["guess"], np.ones(len(c["src"]), bool),
+                                      normals_fn=lambda p: sm.calculate_normals(p) + (None,))
+    Rp = np.array(res["pm_result"]).reshape(4, 4)
+    da, dt = sm.se3_error(Rp, R_o)
+    assert da < 1e-4 and dt < 1e-3, (da, dt)
+    assert abs(res["pm_score"] - score_o) < 1e-4 and res["pm_ok"] == ok_o
     # registrators::Ndt through the same C++ surface vs the numpy restatement
     from oracle import ndt as ondt
     assert res["ndt_ok"] and res["ndt_type"] == 5

@@ -73,7 +73,8 @@ typedef struct smhip_icp_options {
   float ball_radius;            /* largest search radius of the ball search in metres (default 0.5) */
   float ball_cap_factor;        /* next iteration's search-radius cap = factor x this iteration's quantile distance (default 1.5) */
   int32_t two_pass;             /* 1: compact the cap-radius queries into a second launch (default 0: measured slower) */
-  int32_t reserved[3];
+  int32_t no_lds_table;         /* 1: voxel lookups from global memory (nn_ball) instead of LDS row tables (nn_ball_lds) */
+  int32_t reserved[2];
 } smhip_icp_options;
 
 /* Per-call statistics (all optional to read). */

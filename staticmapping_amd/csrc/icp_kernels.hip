@@ -432,8 +432,8 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
         if (have_prev) {
           const int jp = b.idx[so + i];
           if (jp >= 0) {
-            best.d2 = dist2(tq[jp], qx, qy, qz);
-            best.j = jp;
+            if (b.ablate >= 3) { best.d2 = 0.01f * r2cap; best.j = jp; }
+            else { best.d2 = dist2(tq[jp], qx, qy, qz); best.j = jp; }
             R2 = fminf(R2, best.d2);
           }
         }
@@ -453,6 +453,13 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
                 const float yl = oy + (float)y * h;
                 const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + h)) - slack, 0.f);
                 if (fmaf(dy, dy, dz * dz) > fminf(best.d2, R2)) continue;     // the row cannot hold anything useful
+                if (b.ablate >= 2) continue;
+                if (b.ablate == 1) {   // lookups only
+                  uint32_t sb, se;
+                  row_slots(words, (z * ny + y) * wx, x0, x1, sb, se);
+                  if (se > sb) { const uint32_t j0 = cstart[sb], j1 = cstart[se]; if (j1 - j0 > 100000u) best.j = (int)j0; }
+                  continue;
+                }
                 search_row(words, cstart, tq, (z * ny + y) * wx, x0, x1, qx, qy, qz, best);
               }
             }
@@ -492,6 +499,246 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
     }
   }
   if (min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
+  __syncthreads();
+  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
+    const uint32_t v = s_hist[k];
+    if (v) atomicAdd(&gh[k], v);
+  }
+}
+
+// nn_ball with the voxel lookups served from LDS.  The profile of nn_ball (profiles/r01b_pmc_*) shows
+// the texture-address path ~85 % busy with ~38 divergent vector-memory instructions per 64 queries,
+// a third of them the words -> cstart lookups.  Here a workgroup (256 Morton-consecutive queries)
+// first takes the bounding box of all its search balls and stages, with coalesced loads, a dense table
+//     tab[row][x] = position in the sorted target of the first point of the row's cells >= x
+// for every grid row / column of that box (+1 column).  A lane's candidates for cells [xa, xb] of a row
+// are then tab[row][xa] .. tab[row][xb + 1]: two LDS reads instead of 3-4 dependent global loads.
+// Blocks whose box does not fit (sparse, far-range queries) use the global lookups of nn_ball.
+//
+// Latency shape (the kernel is latency-bound: waves spend ~80 % waiting): per round of 256 queries the
+// dependent global-memory levels are  (1) src[i] and idx[i] together (prefetched one round ahead),
+// (2) the previous match tq[idx] in flight WHILE the row tables are staged (words, then cstart) from
+// a box that only needs q +- R_cap, (3) the candidates.  A workgroup runs kBallItems rounds so the
+// histogram flush and the prefetch are amortised.
+__device__ __forceinline__ void sweep_run(const float4* __restrict__ tq, uint32_t j0, uint32_t j1,
+                                          float qx, float qy, float qz, Best& best) {
+  uint32_t j = j0;
+  for (; j + 4 <= j1; j += 4) {     // four independent loads in flight per lane
+    const float4 t0 = tq[j], t1 = tq[j + 1], t2 = tq[j + 2], t3 = tq[j + 3];
+    test_ascending(t0, (int)j, qx, qy, qz, best);
+    test_ascending(t1, (int)j + 1, qx, qy, qz, best);
+    test_ascending(t2, (int)j + 2, qx, qy, qz, best);
+    test_ascending(t3, (int)j + 3, qx, qy, qz, best);
+  }
+  for (; j < j1; ++j) test_ascending(tq[j], (int)j, qx, qy, qz, best);
+}
+
+__global__ __launch_bounds__(kNnThreads) void nn_ball_lds(IcpDev b, int nblk) {
+  int pair, blk;
+  if (!xcd_block(nblk, b.npairs, pair, blk)) return;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  const int ns = st->ns;
+  const int base0 = blk * (kNnThreads * kBallItems);
+  if (base0 >= ns) return;
+  __shared__ uint32_t s_hist[kHistBins];
+  __shared__ uint32_t s_tab[kLdsTableCap];
+  __shared__ float4 s_pts[kLdsPointCap];
+  __shared__ uint32_t s_roff[kLdsRowCap + 1];
+  __shared__ uint32_t s_w[17];
+  __shared__ int s_box[2][6];
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+  if (threadIdx.x < 6) { s_box[0][threadIdx.x] = threadIdx.x < 3 ? 0x3fffffff : -0x3fffffff; s_box[1][threadIdx.x] = s_box[0][threadIdx.x]; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const size_t so = (size_t)pair * b.ns_cap;
+  const uint2* __restrict__ words = b.words + (size_t)pair * kMaxGridWords;
+  const uint32_t* __restrict__ cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
+  const float4* __restrict__ tq = b.tq + (size_t)pair * b.nt_cap;
+  const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
+  const float h = st->h, inv_h = st->inv_h;
+  const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx, nw = st->nw;
+  const float r2cap = st->rcap2;
+  const float Rcap_s = sqrtf(r2cap) * 1.0001f + 1.0e-3f * h;
+  const bool have_prev = st->iter > 0;
+  uint32_t min_lb = 0xffffffffu;
+
+  // level 1 of round 0
+  int i = base0 + threadIdx.x;
+  float4 s_cur = make_float4(0, 0, 0, 0);
+  int jp_cur = -1;
+  if (i < ns) { s_cur = b.src[so + i]; if (have_prev) jp_cur = b.idx[so + i]; }
+
+  for (int it = 0; it < kBallItems; ++it) {
+    const int base = base0 + it * kNnThreads;
+    if (base >= ns) break;                               // block-uniform
+    i = base + threadIdx.x;
+    int* box = s_box[it & 1];
+    // prefetch level 1 of the next round
+    const int i_next = i + kNnThreads;
+    float4 s_next = make_float4(0, 0, 0, 0);
+    int jp_next = -1;
+    if (it + 1 < kBallItems && i_next < ns) { s_next = b.src[so + i_next]; if (have_prev) jp_next = b.idx[so + i_next]; }
+    // query
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    bool valid = false;
+    if (i < ns) {
+      double px, py, pz;
+      transform_point(st->M, s_cur, px, py, pz);
+      qx = (float)px; qy = (float)py; qz = (float)pz;
+      valid = isfinite(qx) && isfinite(qy) && isfinite(qz);
+    }
+    // level 2a: previous match in flight
+    float4 tprev = make_float4(0, 0, 0, 0);
+    const bool has_jp = valid && jp_cur >= 0;
+    if (has_jp) tprev = tq[jp_cur];
+    // box of the round from q +- R_cap (does not need the previous match)
+    int bx0 = 1, bx1 = 0, by0 = 1, by1 = 0, bz0 = 1, bz1 = 0;
+    if (valid) {
+      bx0 = max(cell_coord(qx - Rcap_s, ox, inv_h), 0); bx1 = min(cell_coord(qx + Rcap_s, ox, inv_h), nx - 1);
+      by0 = max(cell_coord(qy - Rcap_s, oy, inv_h), 0); by1 = min(cell_coord(qy + Rcap_s, oy, inv_h), ny - 1);
+      bz0 = max(cell_coord(qz - Rcap_s, oz, inv_h), 0); bz1 = min(cell_coord(qz + Rcap_s, oz, inv_h), nz - 1);
+    }
+    const bool inbox = valid && bx0 <= bx1 && by0 <= by1 && bz0 <= bz1;
+    {
+      const int big = 0x3fffffff;
+      const int mx0 = wave_min_i(inbox ? bx0 : big), mx1 = wave_max_i(inbox ? bx1 : -big);
+      const int my0 = wave_min_i(inbox ? by0 : big), my1 = wave_max_i(inbox ? by1 : -big);
+      const int mz0 = wave_min_i(inbox ? bz0 : big), mz1 = wave_max_i(inbox ? bz1 : -big);
+      if (lane == 0 && mx0 <= mx1) {
+        atomicMin(&box[0], mx0); atomicMin(&box[1], my0); atomicMin(&box[2], mz0);
+        atomicMax(&box[3], mx1); atomicMax(&box[4], my1); atomicMax(&box[5], mz1);
+      }
+    }
+    __syncthreads();                                      // (A) box complete; previous round's table reads done
+    const int X0 = box[0], Y0 = box[1], Z0 = box[2];
+    const int nxl = box[3] - X0 + 2, nyl = box[4] - Y0 + 1, nzl = box[5] - Z0 + 1;     // one extra x column
+    const bool any = box[3] >= X0;
+    const long long entries = any ? (long long)nxl * nyl * nzl : 0;
+    const bool use_lds = any && entries <= kLdsTableCap;
+    // level 2b/3: stage the row tables
+    if (use_lds) {
+      const float inv_nxl = 1.0f / (float)nxl, inv_nyl = 1.0f / (float)nyl;    // entries <= 2048: exact via float
+      for (int e = threadIdx.x; e < (int)entries; e += kNnThreads) {
+        const int r = (int)(((float)e + 0.5f) * inv_nxl);
+        const int x = X0 + (e - r * nxl);
+        const int zz = (int)(((float)r + 0.5f) * inv_nyl);
+        const int y = Y0 + (r - zz * nyl), z = Z0 + zz;
+        const int widx = (z * ny + y) * wx + (x >> 5);
+        uint32_t val = (uint32_t)st->nt;
+        if (widx < nw) {
+          const uint2 wd = words[widx];
+          val = cstart[wd.y + __popc(wd.x & ((1u << (x & 31)) - 1u))];
+        }
+        s_tab[e] = val;
+      }
+    }
+    // reset the other round's box while nobody reads it
+    if (threadIdx.x < 6) s_box[(it + 1) & 1][threadIdx.x] = threadIdx.x < 3 ? 0x3fffffff : -0x3fffffff;
+    // stage the box's target points: every grid row of the box is ONE contiguous run of tq
+    const int rows = use_lds ? nyl * nzl : 0;
+    bool pts_lds = use_lds && rows <= kLdsRowCap;
+    if (use_lds) __syncthreads();                         // (A2) table visible
+    if (pts_lds) {
+      uint32_t len = 0;
+      if ((int)threadIdx.x < rows) len = s_tab[threadIdx.x * nxl + nxl - 1] - s_tab[threadIdx.x * nxl];
+      uint32_t total;
+      const uint32_t off = block_excl_scan(len, s_w, &total);      // kLdsRowCap <= blockDim
+      if ((int)threadIdx.x < rows) s_roff[threadIdx.x] = off;
+      if (threadIdx.x == 0) s_roff[rows] = total;
+      __syncthreads();
+      pts_lds = total <= (uint32_t)kLdsPointCap;
+      if (pts_lds) {
+        for (uint32_t k = threadIdx.x; k < total; k += kNnThreads) {
+          int lo = 0, hi = rows - 1;                               // last row with roff <= k
+          while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_roff[mid] <= k) lo = mid; else hi = mid - 1; }
+          const uint32_t j = s_tab[lo * nxl] + (k - s_roff[lo]);
+          float4 t = tq[j];
+          t.w = __int_as_float((int)j);
+          s_pts[k] = t;
+        }
+      }
+    }
+    // consume the previous match
+    Best best = {INFINITY, -1};
+    float R2 = r2cap;
+    if (has_jp) {
+      const float dub = dist2(tprev, qx, qy, qz);
+      R2 = fminf(R2, dub);
+      // Candidates are swept in ascending position with a strict "<" (first minimum = smallest position).
+      // The seed is bumped by one ulp so that the seed point itself, which lies inside the ball whenever
+      // dub <= R2 and is therefore swept again, replaces it under the same rule.
+      best.d2 = __uint_as_float(__float_as_uint(dub) + 1u);
+      best.j = jp_cur;
+    }
+    int x0 = 1, x1 = 0, y0 = 1, y1 = 0, z0 = 1, z1 = 0;
+    if (valid) {
+      const float Rs = sqrtf(R2) * 1.0001f + 1.0e-3f * h;
+      x0 = max(cell_coord(qx - Rs, ox, inv_h), 0); x1 = min(cell_coord(qx + Rs, ox, inv_h), nx - 1);
+      y0 = max(cell_coord(qy - Rs, oy, inv_h), 0); y1 = min(cell_coord(qy + Rs, oy, inv_h), ny - 1);
+      z0 = max(cell_coord(qz - Rs, oz, inv_h), 0); z1 = min(cell_coord(qz + Rs, oz, inv_h), nz - 1);
+    }
+    __syncthreads();                                      // (B) table staged
+    // level 3/4: search
+    bool hard = false;
+    if (i < ns) {
+      float d2out = INFINITY;
+      if (valid) {
+        if (x0 <= x1) {
+          const float slack = 2.0e-3f * h;
+          for (int z = z0; z <= z1; ++z) {
+            const float zl = oz + (float)z * h;
+            const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + h)) - slack, 0.f);
+            for (int y = y0; y <= y1; ++y) {
+              const float yl = oy + (float)y * h;
+              const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + h)) - slack, 0.f);
+              if (fmaf(dy, dy, dz * dz) > fminf(best.d2, R2)) continue;
+              if (pts_lds) {
+                const int r = (z - Z0) * nyl + (y - Y0);
+                const int rb = r * nxl - X0;
+                const uint32_t g0 = s_tab[rb + X0];
+                const uint32_t k0 = s_roff[r] + (s_tab[rb + x0] - g0), k1 = s_roff[r] + (s_tab[rb + x1 + 1] - g0);
+                for (uint32_t k = k0; k < k1; ++k) {
+                  const float4 t = s_pts[k];
+                  test_ascending(t, __float_as_int(t.w), qx, qy, qz, best);
+                }
+              } else if (use_lds) {
+                const int rb = ((z - Z0) * nyl + (y - Y0)) * nxl - X0;
+                sweep_run(tq, s_tab[rb + x0], s_tab[rb + x1 + 1], qx, qy, qz, best);
+              } else {
+                uint32_t sb, se;
+                row_slots(words, (z * ny + y) * wx, x0, x1, sb, se);
+                if (se > sb) sweep_run(tq, cstart[sb], cstart[se], qx, qy, qz, best);
+              }
+            }
+          }
+        }
+        if (best.d2 <= R2) {
+          d2out = best.d2;
+        } else {
+          d2out = R2;
+          hard = true;
+          min_lb = min(min_lb, __float_as_uint(R2));
+        }
+      }
+      b.d2[so + i] = d2out;
+      b.idx[so + i] = best.j;
+      const uint32_t key = __float_as_uint(d2out);
+      if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
+    }
+    const unsigned long long hm = __ballot(hard);
+    if (hm) {
+      uint32_t basepos = 0;
+      if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
+      basepos = __shfl(basepos, 0, 64);
+      if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
+    }
+    s_cur = s_next; jp_cur = jp_next;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) min_lb = min(min_lb, (uint32_t)__shfl_xor((int)min_lb, off, 64));
+  if (lane == 0 && min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
   __syncthreads();
   uint32_t* gh = b.hist + (size_t)pair * kHistBins;
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {

@@ -149,7 +149,13 @@ smhip_status enqueue_find_closests(smhip_context* h, int np, int ns_max) {
     if (d.use_ball) {
       const int nblk = ceil_div(ns_max, kNnThreads * kBallItems);
       const dim3 gx(nblk * 8 * ceil_div(np, 8));
-      { Bracket br(h, 4); hipLaunchKernelGGL(nn_ball<false>, gx, dim3(kNnThreads), 0, h->stream, d, nblk); }
+      if (d.lds_table && !d.two_pass) {
+        Bracket br(h, 4);
+        hipLaunchKernelGGL(nn_ball_lds, gx, dim3(kNnThreads), 0, h->stream, d, nblk);
+      } else {
+        Bracket br(h, 4);
+        hipLaunchKernelGGL(nn_ball<false>, gx, dim3(kNnThreads), 0, h->stream, d, nblk);
+      }
       if (d.two_pass) { Bracket br(h, 4); hipLaunchKernelGGL(nn_ball<true>, gx, dim3(kNnThreads), 0, h->stream, d, nblk); }
       { Bracket br(h, 1); hipLaunchKernelGGL(nn_validate, dim3(np), dim3(256), 0, h->stream, d); }
       { Bracket br(h, 1); hipLaunchKernelGGL(nn_ring<true>, dim3(32, np), dim3(kNnThreads), 0, h->stream, d); }
@@ -239,6 +245,8 @@ void sync_options(smhip_context* h) {
   h->dev.use_ball = h->opts.use_ball;
   h->dev.sort_cells = 1;
   h->dev.two_pass = h->opts.two_pass;
+  h->dev.lds_table = h->opts.no_lds_table ? 0 : 1;
+  { const char* a = std::getenv("SMHIP_ABLATE"); h->dev.ablate = a ? std::atoi(a) : 0; }
   h->dev.cap_factor = h->opts.ball_cap_factor > 1.0f ? h->opts.ball_cap_factor : 1.5f;
   h->dev.exact_all = h->opts.exact_matches;
   h->dev.ball_radius = h->opts.ball_radius > 0 ? h->opts.ball_radius : 0.5f;

@@ -18,6 +18,9 @@ constexpr int kMaxGridWords = 1 << 18;   // 32-cell words per pair (8 Mi cells)
 constexpr int kTgtReduceBlocks = 32;     // partial blocks for the target mean / bbox
 constexpr int kBruteTile = 1024;
 constexpr int kFallbackSlices = 64;
+constexpr int kLdsTableCap = 2048;        // u32 entries of the per-workgroup row table in nn_ball_lds (8 KiB)
+constexpr int kLdsPointCap = 1024;        // target points staged per round (16 KiB)
+constexpr int kLdsRowCap = 256;           // grid rows of the box whose runs are staged (<= workgroup size)
 constexpr int kBallItems = 4;            // queries per thread in nn_ball (1024 per block: fewer histogram flushes)      // target slices the fallback sweep is spread over         // target points staged in LDS per tile (16 KiB as float4)
 
 // Per-pair device state.  Everything an iteration needs and everything the host reads back.
@@ -108,6 +111,8 @@ struct IcpDev {
   int32_t max_ring;
   int32_t sort_cells;        // 1 = order points inside a cell by caller index (deterministic tie rule)
   int32_t use_ball;          // 1 = ball-bounded search with certified trimming; 0 = ring search over every query
+  int32_t lds_table;         // 1 = nn_ball_lds (row tables staged in LDS), 0 = nn_ball (global lookups)
+  int32_t ablate;            // development only (env SMHIP_ABLATE): skip parts of nn_ball to time the rest
   int32_t two_pass;          // 1 = nn_ball defers cap-radius queries to a second, compacted launch
   int32_t exact_all;         // 1 = every match exact (no lower bounds survive), e.g. find_closests
   float ball_radius;         // largest search radius of nn_ball (first iteration / clamp)

@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=64, help="scan pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=128, help="scan pairs per GPU per step")
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic scan pairs (replicated over the slots)")
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--nn-mode", choices=["grid", "brute"], default="grid")
@@ -188,7 +188,7 @@ def main():
                        "pairs_per_gpu": B, "global_pairs_per_step": n_total, "source_points": ns,
                        "target_points": nt, "iterations": ICP_ITERS, "nn_mode": args.nn_mode,
                        "grid_cell_m": args.cell, "parallelism": f"pairs round-robin over {world} GPU(s), one RCCL gather of poses"},
-            "roofline": {"bound": "hbm", "kernel": "nn_ball" if args.nn_mode == "grid" else "nn_brute",
+            "roofline": {"bound": "hbm", "kernel": "nn_ball_lds" if args.nn_mode == "grid" else "nn_brute",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "bytes_per_launch": nn_bytes, "avg_launch_ms": round(nn_ms, 4),

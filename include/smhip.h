@@ -74,7 +74,9 @@ typedef struct smhip_icp_options {
   float ball_cap_factor;        /* next iteration's search-radius cap = factor x this iteration's quantile distance (default 1.5) */
   int32_t two_pass;             /* 1: compact the cap-radius queries into a second launch (default 0: measured slower) */
   int32_t no_lds_table;         /* 1: voxel lookups from global memory (nn_ball) instead of LDS row tables (nn_ball_lds) */
-  int32_t reserved[2];
+  int32_t no_overlap;           /* 1: keep a batch on one stream (default 0: batches of >= 16 pairs are split over two
+                                   streams so one half's latency-bound launches hide behind the other half's NN) */
+  int32_t reserved[1];
 } smhip_icp_options;
 
 /* Per-call statistics (all optional to read). */

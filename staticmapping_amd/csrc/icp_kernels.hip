@@ -67,12 +67,13 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, u
 // after the other and every block of a pair runs on the same XCD: the pair's grid words, sorted
 // target and match arrays stay in that XCD's 4 MiB L2 instead of being spread over all eight.
 // Only speed depends on the placement, never correctness.
-__device__ __forceinline__ bool xcd_block(int nblk, int npairs, int& pair, int& blk) {
+__device__ __forceinline__ bool xcd_block(int nblk, int npairs, int b_pair_base, int& pair, int& blk) {
   const int id = blockIdx.x;
   const int j = id >> 3;
-  pair = (j / nblk) * 8 + (id & 7);
+  const int local = (j / nblk) * 8 + (id & 7);
+  pair = b_pair_base + local;
   blk = j % nblk;
-  return pair < npairs;
+  return local < npairs;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -80,7 +81,7 @@ __device__ __forceinline__ bool xcd_block(int nblk, int npairs, int& pair, int& 
 // ------------------------------------------------------------------------------------------
 // Partial sums (f64) and bbox (f32, exact) of the raw target; grid = (kTgtReduceBlocks, pairs).
 __global__ __launch_bounds__(256) void tgt_reduce(IcpDev b) {
-  const int pair = blockIdx.y;
+  const int pair = b.pair_base + blockIdx.y;
   const int nt = b.in[pair].nt;
   const float4* tp = b.tgt_p + (size_t)pair * b.nt_cap;
   double sx = 0, sy = 0, sz = 0;
@@ -126,8 +127,8 @@ __device__ __forceinline__ void mat4_mul_rm(const double* a, const double* c, do
 
 // One thread per pair: mean, grid geometry, G = T(-mu) * guess, loop state reset.
 __global__ void grid_setup(IcpDev b, int npairs) {
-  const int pair = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pair >= npairs) return;
+  const int pair = b.pair_base + blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= b.pair_base + npairs) return;
   PairState* st = &b.state[pair];
   const double* part = b.tpart + (size_t)pair * kTgtReduceBlocks * 16;
   double s[3] = {0, 0, 0};
@@ -182,7 +183,7 @@ __device__ __forceinline__ float3 centre_point(const float4 p, const double* mu)
 }
 
 __global__ __launch_bounds__(256) void grid_mark(IcpDev b) {
-  const int pair = blockIdx.y;
+  const int pair = b.pair_base + blockIdx.y;
   const PairState* st = &b.state[pair];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= st->nt) return;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void grid_mark(IcpDev b) {
 // One 1024-thread block per pair: words[w] = {bits, exclusive popcount rank}; nocc.
 // Tiles of 4096 words, 16-byte coalesced loads, running carry between tiles.
 __global__ __launch_bounds__(1024) void grid_rank(IcpDev b) {
-  const int pair = blockIdx.x;
+  const int pair = b.pair_base + blockIdx.x;
   PairState* st = &b.state[pair];
   const int nw = st->nw;
   const uint32_t* bits = b.bits + (size_t)pair * kMaxGridWords;
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(1024) void grid_rank(IcpDev b) {
 }
 
 __global__ __launch_bounds__(256) void grid_count(IcpDev b) {
-  const int pair = blockIdx.y;
+  const int pair = b.pair_base + blockIdx.y;
   const PairState* st = &b.state[pair];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= st->nt) return;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void grid_count(IcpDev b) {
 }
 
 __global__ __launch_bounds__(1024) void grid_cscan(IcpDev b) {
-  const int pair = blockIdx.x;
+  const int pair = b.pair_base + blockIdx.x;
   const PairState* st = &b.state[pair];
   const int n = st->nocc;
   const uint32_t* cnt = b.ccount + (size_t)pair * (b.nt_cap + 1);
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(1024) void grid_cscan(IcpDev b) {
 }
 
 __global__ __launch_bounds__(256) void grid_scatter(IcpDev b) {
-  const int pair = blockIdx.y;
+  const int pair = b.pair_base + blockIdx.y;
   const PairState* st = &b.state[pair];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= st->nt) return;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256) void grid_scatter(IcpDev b) {
 // One thread per occupied cell: order the cell's points by original index so that sorted
 // positions (and with them the NN tie rule) do not depend on the atomic order of grid_count.
 __global__ __launch_bounds__(256) void grid_sort_cells(IcpDev b) {
-  const int pair = blockIdx.y;
+  const int pair = b.pair_base + blockIdx.y;
   const PairState* st = &b.state[pair];
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= st->nocc) return;
@@ -395,7 +396,7 @@ __device__ __forceinline__ void search_row(const uint2* __restrict__ words, cons
 template <bool DEFERRED>
 __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
   int pair, blk;
-  if (!xcd_block(nblk, b.npairs, pair, blk)) return;
+  if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
   PairState* st = &b.state[pair];
   if (st->done) return;
   const int count = DEFERRED ? (int)st->deferred_count : st->ns;
@@ -536,7 +537,7 @@ __device__ __forceinline__ void sweep_run(const float4* __restrict__ tq, uint32_
 
 __global__ __launch_bounds__(kNnThreads) void nn_ball_lds(IcpDev b, int nblk) {
   int pair, blk;
-  if (!xcd_block(nblk, b.npairs, pair, blk)) return;
+  if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
   PairState* st = &b.state[pair];
   if (st->done) return;
   const int ns = st->ns;
@@ -766,7 +767,7 @@ __device__ __forceinline__ void search_row(const uint2* __restrict__ words, cons
 // uncertified afterwards goes to the brute-force fallback list.
 template <bool HARD>
 __global__ __launch_bounds__(kNnThreads) void nn_ring(IcpDev b) {
-  const int pair = blockIdx.y;
+  const int pair = b.pair_base + blockIdx.y;
   PairState* st = &b.state[pair];
   if (st->done) return;
   if (HARD && !st->refine) return;
@@ -841,7 +842,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring(IcpDev b) {
 
 // LDS-tiled exact brute force over every source point (SMHIP_NN_BRUTE, BASELINE config #2).
 __global__ __launch_bounds__(kNnThreads) void nn_brute(IcpDev b) {
-  const int pair = blockIdx.y;
+  const int pair = b.pair_base + blockIdx.y;
   PairState* st = &b.state[pair];
   if (st->done) return;
   const int count = st->ns;
@@ -892,7 +893,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_brute(IcpDev b) {
 // slice of the target in LDS and sweeps ALL unresolved queries of the pair over it; the per-query
 // winner is merged with a 64-bit atomicMin on (d2 bits << 32 | sorted position).
 __global__ __launch_bounds__(kNnThreads) void nn_fallback_scan(IcpDev b) {
-  const int pair = blockIdx.y;
+  const int pair = b.pair_base + blockIdx.y;
   PairState* st = &b.state[pair];
   if (st->done) return;
   const int U = (int)st->unresolved_count;
@@ -923,7 +924,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_fallback_scan(IcpDev b) {
 }
 
 __global__ __launch_bounds__(kNnThreads) void nn_fallback_resolve(IcpDev b) {
-  const int pair = blockIdx.y;
+  const int pair = b.pair_base + blockIdx.y;
   PairState* st = &b.state[pair];
   if (st->done) return;
   const int U = (int)st->unresolved_count;
@@ -981,7 +982,7 @@ __device__ __forceinline__ void find_quantile_bin(const uint32_t* __restrict__ g
 // every lower bound nn_ball recorded?  If not (or if every match must be exact) switch the ring
 // search + fallback on for this iteration.
 __global__ __launch_bounds__(256) void nn_validate(IcpDev b) {
-  const int pair = blockIdx.x;
+  const int pair = b.pair_base + blockIdx.x;
   PairState* st = &b.state[pair];
   if (st->done) return;
   __shared__ uint32_t s_w[17];
@@ -1044,7 +1045,7 @@ __device__ __forceinline__ void block_reduce29(double* acc, double (*s_red)[29])
 
 __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
   int pair, blk;
-  if (!xcd_block(nblk, b.npairs, pair, blk)) return;
+  if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
   PairState* st = &b.state[pair];
   if (st->done) return;
   const int ns = st->ns;
@@ -1176,7 +1177,7 @@ __device__ double quat_angular_distance(const double* a, const double* c) {
 }
 
 __global__ __launch_bounds__(256) void finalize(IcpDev b) {
-  const int pair = blockIdx.x;
+  const int pair = b.pair_base + blockIdx.x;
   PairState* st = &b.state[pair];
   if (st->done) return;
   __shared__ uint32_t s_w[17];

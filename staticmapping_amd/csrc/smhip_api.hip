@@ -28,6 +28,8 @@ struct smhip_context {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t stream2 = nullptr;          // second half of a batch runs here so its latency-bound kernels
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // (finalize, validate, grid build) hide behind the other half's NN
   IcpDev dev{};
   smhip_icp_options opts{};
   std::vector<int> ns, nt, has_normals;
@@ -119,31 +121,67 @@ smhip_status check_slot(smhip_context* h, int slot) {
   return SMHIP_OK;
 }
 
-// target centring + search-structure build for pairs [0, np)
-smhip_status enqueue_prepare(smhip_context* h, int np, int nt_max) {
+// One half of a batch: a by-value copy of the device view restricted to pairs [pair_base, pair_base + np)
+// and the stream its launches go to.
+struct Half {
+  IcpDev d;
+  hipStream_t stream;
+  int np;
+};
+
+// per-call resets for pairs [0, np) (main stream, before the halves fork)
+smhip_status enqueue_resets(smhip_context* h, int np) {
   IcpDev& d = h->dev;
-  d.npairs = np;
-  Bracket br(h, 0);
   HIPCHK(h, hipMemcpyAsync(const_cast<PairInput*>(d.in), h->in_pinned, sizeof(PairInput) * np, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemsetAsync(d.bits, 0, sizeof(uint32_t) * (size_t)kMaxGridWords * np, h->stream));
   HIPCHK(h, hipMemsetAsync(d.ccount, 0, sizeof(uint32_t) * (size_t)(d.nt_cap + 1) * np, h->stream));
   HIPCHK(h, hipMemsetAsync(d.hist, 0, sizeof(uint32_t) * (size_t)kHistBins * np, h->stream));
   HIPCHK(h, hipMemsetAsync(d.done_count, 0, sizeof(uint32_t), h->stream));
+  return SMHIP_OK;
+}
+
+// target centring + search-structure build for one half
+smhip_status enqueue_grid_build(smhip_context* h, const Half& f, int nt_max) {
+  const IcpDev& d = f.d;
+  const int np = f.np;
+  Bracket br(h, 0);
   const dim3 gpts(ceil_div(nt_max, 256), np);
-  hipLaunchKernelGGL(tgt_reduce, dim3(kTgtReduceBlocks, np), dim3(256), 0, h->stream, d);
-  hipLaunchKernelGGL(grid_setup, dim3(ceil_div(np, 64)), dim3(64), 0, h->stream, d, np);
-  hipLaunchKernelGGL(grid_mark, gpts, dim3(256), 0, h->stream, d);
-  hipLaunchKernelGGL(grid_rank, dim3(np), dim3(1024), 0, h->stream, d);
-  hipLaunchKernelGGL(grid_count, gpts, dim3(256), 0, h->stream, d);
-  hipLaunchKernelGGL(grid_cscan, dim3(np), dim3(1024), 0, h->stream, d);
-  hipLaunchKernelGGL(grid_scatter, gpts, dim3(256), 0, h->stream, d);
-  if (d.sort_cells) hipLaunchKernelGGL(grid_sort_cells, gpts, dim3(256), 0, h->stream, d);
+  hipLaunchKernelGGL(tgt_reduce, dim3(kTgtReduceBlocks, np), dim3(256), 0, f.stream, d);
+  hipLaunchKernelGGL(grid_setup, dim3(ceil_div(np, 64)), dim3(64), 0, f.stream, d, np);
+  hipLaunchKernelGGL(grid_mark, gpts, dim3(256), 0, f.stream, d);
+  hipLaunchKernelGGL(grid_rank, dim3(np), dim3(1024), 0, f.stream, d);
+  hipLaunchKernelGGL(grid_count, gpts, dim3(256), 0, f.stream, d);
+  hipLaunchKernelGGL(grid_cscan, dim3(np), dim3(1024), 0, f.stream, d);
+  hipLaunchKernelGGL(grid_scatter, gpts, dim3(256), 0, f.stream, d);
+  if (d.sort_cells) hipLaunchKernelGGL(grid_sort_cells, gpts, dim3(256), 0, f.stream, d);
   HIPCHK(h, hipGetLastError());
   return SMHIP_OK;
 }
 
+Half whole_batch(smhip_context* h, int np) {
+  Half f;
+  f.d = h->dev; f.d.npairs = np; f.d.pair_base = 0;
+  f.stream = h->stream; f.np = np;
+  return f;
+}
+
+// single-stream convenience used by find_closests / the NDT fitness pass
+smhip_status enqueue_prepare(smhip_context* h, int np, int nt_max) {
+  smhip_status s = enqueue_resets(h, np);
+  if (s) return s;
+  return enqueue_grid_build(h, whole_batch(h, np), nt_max);
+}
+
+smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_max);
+
 smhip_status enqueue_find_closests(smhip_context* h, int np, int ns_max) {
-  IcpDev& d = h->dev;
+  return enqueue_find_closests_half(h, whole_batch(h, np), ns_max);
+}
+
+smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_max) {
+  const IcpDev& d = f.d;
+  const int np = f.np;
+  hipStream_t st = f.stream;
   const dim3 g(ceil_div(ns_max, kNnThreads), np);
   if (h->opts.nn_mode == SMHIP_NN_GRID) {
     if (d.use_ball) {
@@ -151,23 +189,23 @@ smhip_status enqueue_find_closests(smhip_context* h, int np, int ns_max) {
       const dim3 gx(nblk * 8 * ceil_div(np, 8));
       if (d.lds_table && !d.two_pass) {
         Bracket br(h, 4);
-        hipLaunchKernelGGL(nn_ball_lds, gx, dim3(kNnThreads), 0, h->stream, d, nblk);
+        hipLaunchKernelGGL(nn_ball_lds, gx, dim3(kNnThreads), 0, st, d, nblk);
       } else {
         Bracket br(h, 4);
-        hipLaunchKernelGGL(nn_ball<false>, gx, dim3(kNnThreads), 0, h->stream, d, nblk);
+        hipLaunchKernelGGL(nn_ball<false>, gx, dim3(kNnThreads), 0, st, d, nblk);
       }
-      if (d.two_pass) { Bracket br(h, 4); hipLaunchKernelGGL(nn_ball<true>, gx, dim3(kNnThreads), 0, h->stream, d, nblk); }
-      { Bracket br(h, 1); hipLaunchKernelGGL(nn_validate, dim3(np), dim3(256), 0, h->stream, d); }
-      { Bracket br(h, 1); hipLaunchKernelGGL(nn_ring<true>, dim3(32, np), dim3(kNnThreads), 0, h->stream, d); }
+      if (d.two_pass) { Bracket br(h, 4); hipLaunchKernelGGL(nn_ball<true>, gx, dim3(kNnThreads), 0, st, d, nblk); }
+      { Bracket br(h, 1); hipLaunchKernelGGL(nn_validate, dim3(np), dim3(256), 0, st, d); }
+      { Bracket br(h, 1); hipLaunchKernelGGL(nn_ring<true>, dim3(32, np), dim3(kNnThreads), 0, st, d); }
     } else {
       Bracket br(h, 4);
-      hipLaunchKernelGGL(nn_ring<false>, g, dim3(kNnThreads), 0, h->stream, d);
+      hipLaunchKernelGGL(nn_ring<false>, g, dim3(kNnThreads), 0, st, d);
     }
-    { Bracket br(h, 1); hipLaunchKernelGGL(nn_fallback_scan, dim3(kFallbackSlices, np), dim3(kNnThreads), 0, h->stream, d); }
-    { Bracket br(h, 1); hipLaunchKernelGGL(nn_fallback_resolve, dim3(32, np), dim3(kNnThreads), 0, h->stream, d); }
+    { Bracket br(h, 1); hipLaunchKernelGGL(nn_fallback_scan, dim3(kFallbackSlices, np), dim3(kNnThreads), 0, st, d); }
+    { Bracket br(h, 1); hipLaunchKernelGGL(nn_fallback_resolve, dim3(32, np), dim3(kNnThreads), 0, st, d); }
   } else {
     Bracket br(h, 4);
-    hipLaunchKernelGGL(nn_brute, g, dim3(kNnThreads), 0, h->stream, d);
+    hipLaunchKernelGGL(nn_brute, g, dim3(kNnThreads), 0, st, d);
   }
   return SMHIP_OK;
 }
@@ -339,6 +377,11 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return SMHIP_ERR_HIP; }
     h->own_stream = true;
   }
+  if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+    h->stream2 = nullptr;       // no overlap, still correct
+  }
   smhip_icp_default_options(&h->opts);
   IcpDev& d = h->dev;
   d.slots = pair_slots; d.ns_cap = max_source_points; d.nt_cap = max_target_points;
@@ -407,6 +450,9 @@ smhip_status smhip_destroy(smhip_handle h) {
   if (h->ids_pinned) (void)hipHostFree(h->ids_pinned);
   if (h->d2_pinned) (void)hipHostFree(h->d2_pinned);
   for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return SMHIP_OK;
@@ -545,25 +591,58 @@ smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* g
   HIPCHK(h, hipStreamSynchronize(h->stream));
   smhip_status s = fill_inputs(h, npairs, guesses, &ns_max, &nt_max);
   if (s) return s;
-  s = enqueue_prepare(h, npairs, nt_max);
+  s = enqueue_resets(h, npairs);
   if (s) return s;
-  IcpDev& d = h->dev;
-  const int max_it = d.max_iteration;
-  for (int it = 0; it < max_it; ++it) {
-    s = enqueue_find_closests(h, npairs, ns_max);
-    if (s) return s;
-    {
-      const int nblk = ceil_div(ns_max, kAccChunk);
-      Bracket br(h, 2);
-      hipLaunchKernelGGL(accumulate, dim3(nblk * 8 * ceil_div(npairs, 8)), dim3(kAccThreads), 0, h->stream, d, nblk);
+  // Split the batch over two streams: the latency-bound launches of one half (finalize, validate, grid
+  // build, near-empty refinement kernels) overlap the throughput-bound NN / accumulate of the other.
+  const bool split = h->opts.no_overlap == 0 && !h->profile && npairs >= 16 && h->stream2 != nullptr;
+  Half halves[2];
+  int nh = 1;
+  halves[0] = whole_batch(h, npairs);
+  if (split) {
+    nh = 2;
+    const int n0 = ((npairs / 2 + 7) / 8) * 8;          // keep both halves multiples of 8 for the XCD mapping
+    halves[0].np = n0; halves[0].d.npairs = n0;
+    halves[1] = whole_batch(h, npairs - n0);
+    halves[1].d.pair_base = n0; halves[1].stream = h->stream2;
+    HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+  }
+  auto join = [&]() -> smhip_status {
+    if (nh == 2) {
+      HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
+      HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
     }
-    { Bracket br(h, 3); hipLaunchKernelGGL(finalize, dim3(npairs), dim3(256), 0, h->stream, d); }
-    if (d.early_exit && (it + 1) % h->opts.check_every == 0 && it + 1 < max_it) {
-      HIPCHK(h, hipMemcpyAsync(h->done_pinned, d.done_count, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    return SMHIP_OK;
+  };
+  for (int k = 0; k < nh; ++k) { s = enqueue_grid_build(h, halves[k], nt_max); if (s) return s; }
+  const int max_it = h->dev.max_iteration;
+  for (int it = 0; it < max_it; ++it) {
+    for (int k = 0; k < nh; ++k) {
+      const Half& f = halves[k];
+      s = enqueue_find_closests_half(h, f, ns_max);
+      if (s) return s;
+      {
+        const int nblk = ceil_div(ns_max, kAccChunk);
+        Bracket br(h, 2);
+        hipLaunchKernelGGL(accumulate, dim3(nblk * 8 * ceil_div(f.np, 8)), dim3(kAccThreads), 0, f.stream, f.d, nblk);
+      }
+      { Bracket br(h, 3); hipLaunchKernelGGL(finalize, dim3(f.np), dim3(256), 0, f.stream, f.d); }
+    }
+    if (h->dev.early_exit && (it + 1) % h->opts.check_every == 0 && it + 1 < max_it) {
+      s = join();
+      if (s) return s;
+      HIPCHK(h, hipMemcpyAsync(h->done_pinned, h->dev.done_count, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));
       if (*h->done_pinned >= (uint32_t)npairs) break;
+      if (nh == 2) {   // re-fork for the next chunk of iterations
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+      }
     }
   }
+  s = join();
+  if (s) return s;
   HIPCHK(h, hipGetLastError());
   h->last_npairs = npairs;
   return SMHIP_OK;

@@ -78,7 +78,8 @@ struct PairInput {
 // Pointers + capacities handed to every kernel by value.
 struct IcpDev {
   int32_t slots, ns_cap, nt_cap;
-  int32_t npairs;            // pairs of the current call (XCD-aware kernels pad the grid to a multiple of 8)
+  int32_t npairs;            // pairs this launch covers (XCD-aware kernels pad the grid to a multiple of 8)
+  int32_t pair_base;         // first pair slot of this launch (the batch is split over two streams)
   int32_t acc_blocks;        // ceil(ns_cap / kAccChunk)
   PairState* state;
   const PairInput* in;

@@ -313,6 +313,19 @@ __device__ __forceinline__ void test_ascending(const float4 t, int j, float qx, 
   const float d = dist2(t, qx, qy, qz);
   if (d < best.d2) { best.d2 = d; best.j = j; }
 }
+// two candidates per step with packed fp32 (v_pk_add/mul/fma_f32): 6 instead of 9 VALU per candidate
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void test_ascending2(const float4 a, int ja, const float4 c, int jc,
+                                                float qx, float qy, float qz, Best& best) {
+  const f32x2 dx = (f32x2){qx, qx} - (f32x2){a.x, c.x};
+  const f32x2 dy = (f32x2){qy, qy} - (f32x2){a.y, c.y};
+  const f32x2 dz = (f32x2){qz, qz} - (f32x2){a.z, c.z};
+  f32x2 d = dx * dx;
+  d = __builtin_elementwise_fma(dy, dy, d);
+  d = __builtin_elementwise_fma(dz, dz, d);
+  if (d.x < best.d2) { best.d2 = d.x; best.j = ja; }
+  if (d.y < best.d2) { best.d2 = d.y; best.j = jc; }
+}
 // arbitrary visiting order: explicit tie rule
 __device__ __forceinline__ void test_any_order(const float4 t, int j, float qx, float qy, float qz, Best& best) {
   const float d = dist2(t, qx, qy, qz);
@@ -700,10 +713,12 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball_lds(IcpDev b, int nblk) {
                 const int rb = r * nxl - X0;
                 const uint32_t g0 = s_tab[rb + X0];
                 const uint32_t k0 = s_roff[r] + (s_tab[rb + x0] - g0), k1 = s_roff[r] + (s_tab[rb + x1 + 1] - g0);
-                for (uint32_t k = k0; k < k1; ++k) {
-                  const float4 t = s_pts[k];
-                  test_ascending(t, __float_as_int(t.w), qx, qy, qz, best);
+                uint32_t k = k0;
+                for (; k + 2 <= k1; k += 2) {
+                  const float4 ta = s_pts[k], tc = s_pts[k + 1];
+                  test_ascending2(ta, __float_as_int(ta.w), tc, __float_as_int(tc.w), qx, qy, qz, best);
                 }
+                if (k < k1) { const float4 t = s_pts[k]; test_ascending(t, __float_as_int(t.w), qx, qy, qz, best); }
               } else if (use_lds) {
                 const int rb = ((z - Z0) * nyl + (y - Y0)) * nxl - X0;
                 sweep_run(tq, s_tab[rb + x0], s_tab[rb + x1 + 1], qx, qy, qz, best);
@@ -870,8 +885,10 @@ __global__ __launch_bounds__(kNnThreads) void nn_brute(IcpDev b) {
     for (int k = threadIdx.x; k < m; k += kNnThreads) s_t[k] = tq[base + k];
     __syncthreads();
     if (valid) {
-#pragma unroll 8
-      for (int k = 0; k < m; ++k) test_ascending(s_t[k], base + k, qx, qy, qz, best);
+      int k = 0;
+#pragma unroll 4
+      for (; k + 2 <= m; k += 2) test_ascending2(s_t[k], base + k, s_t[k + 1], base + k + 1, qx, qy, qz, best);
+      if (k < m) test_ascending(s_t[k], base + k, qx, qy, qz, best);
     }
   }
   if (active) {

@@ -72,7 +72,8 @@ typedef struct smhip_icp_options {
                                    the transform / score are identical either way, only rejected matches differ) */
   float ball_radius;            /* largest search radius of the ball search in metres (default 0.5) */
   float ball_cap_factor;        /* next iteration's search-radius cap = factor x this iteration's quantile distance (default 1.5) */
-  int32_t two_pass;             /* 1: compact the cap-radius queries into a second launch (default 0: measured slower) */
+  int32_t two_pass;             /* repurposed as "no_certify": 1 = search every query in every iteration instead of running the
+                                   nearest-neighbour certificate pass first (default 0 = certificates on) */
   int32_t no_lds_table;         /* 1: voxel lookups from global memory (nn_ball) instead of LDS row tables (nn_ball_lds) */
   int32_t no_overlap;           /* 1: keep a batch on one stream (default 0: batches of >= 16 pairs are split over two
                                    streams so one half's latency-bound launches hide behind the other half's NN) */
@@ -88,6 +89,8 @@ typedef struct smhip_icp_stats {
   int32_t status;               /* per-pair smhip_status */
   int32_t hard_queries;         /* matches recorded as lower bounds by the ball search, summed over iterations */
   int32_t refined_iterations;   /* iterations in which those bounds had to be refined to exact matches */
+  int32_t searched_queries;     /* queries that needed a search (certificate failed / first iteration), summed over iterations */
+  int32_t reserved;
 } smhip_icp_stats;
 
 /* Kernel-time breakdown collected when profiling is enabled (HIP events on the

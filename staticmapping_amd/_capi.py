@@ -23,7 +23,7 @@ class IcpOptions(ctypes.Structure):
 class IcpStats(ctypes.Structure):
     _fields_ = [("iterations", ctypes.c_int32), ("kept", ctypes.c_int32), ("limit_d2", ctypes.c_double),
                 ("fallback_queries", ctypes.c_int32), ("status", ctypes.c_int32), ("hard_queries", ctypes.c_int32),
-                ("refined_iterations", ctypes.c_int32)]
+                ("refined_iterations", ctypes.c_int32), ("searched_queries", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class IcpProfile(ctypes.Structure):

@@ -167,13 +167,13 @@ __global__ void grid_setup(IcpDev b, int npairs) {
   double Tmi[16] = {1, 0, 0, -mu[0], 0, 1, 0, -mu[1], 0, 0, 1, -mu[2], 0, 0, 0, 1};
   mat4_mul_rm(Tmi, st->guess, st->G);
   for (int i = 0; i < 16; ++i) st->T_iter[i] = (i % 5 == 0) ? 1.0 : 0.0;
-  for (int i = 0; i < 12; ++i) st->M[i] = st->G[i];
+  for (int i = 0; i < 12; ++i) { st->M[i] = st->G[i]; st->M_prev[i] = st->G[i]; }
   st->quat[0][0] = 1; st->quat[0][1] = st->quat[0][2] = st->quat[0][3] = 0;      // :478-479
   st->trans[0][0] = st->trans[0][1] = st->trans[0][2] = 0;
   st->n_hist = 1;
   st->iter = 0; st->done = 0; st->status = 0;
   st->unresolved_count = 0; st->blist_count = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
-  st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0;
+  st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0; st->searched_total = 0;
   st->rcap2 = b.ball_radius * b.ball_radius;
   st->kept = 0; st->limit_key = 0; st->score = 0; st->nocc = 0;
 }
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void grid_sort_cells(IcpDev b) {
 // Tie rule everywhere: among equidistant targets the smallest SORTED position j wins.  Positions
 // are deterministic (cells in linear order, points inside a cell ordered by original index, see
 // grid_sort_cells), so brute force, tile search, ring search and fallback agree bit for bit.
-struct Best { float d2; int j; };
+struct Best { float d2; int j; float s2; };   // nearest (squared distance, position) and runner-up squared distance
 
 __device__ __forceinline__ float dist2(const float4 t, float qx, float qy, float qz) {
   const float dx = qx - t.x, dy = qy - t.y, dz = qz - t.z;
@@ -311,6 +311,12 @@ __device__ __forceinline__ float dist2(const float4 t, float qx, float qy, float
 // candidates visited in ascending j: strict "<" keeps the smallest j among ties
 __device__ __forceinline__ void test_ascending(const float4 t, int j, float qx, float qy, float qz, Best& best) {
   const float d = dist2(t, qx, qy, qz);
+  if (d < best.d2) { best.d2 = d; best.j = j; }
+}
+// same, also tracking the runner-up distance (what the next iteration's certificate needs)
+__device__ __forceinline__ void test_ascending_ru(const float4 t, int j, float qx, float qy, float qz, Best& best) {
+  const float d = dist2(t, qx, qy, qz);
+  best.s2 = fminf(best.s2, fmaxf(d, best.d2));     // d < best: old best becomes runner-up; else d competes for runner-up
   if (d < best.d2) { best.d2 = d; best.j = j; }
 }
 // two candidates per step with packed fp32 (v_pk_add/mul/fma_f32): 6 instead of 9 VALU per candidate
@@ -399,20 +405,31 @@ __device__ __forceinline__ void search_row(const uint2* __restrict__ words, cons
 // So each lane visits only the cells meeting the ball (q, min(|q - t_prev|, R_cap)): typically
 // 1-2 cells per axis once ICP has settled.
 //
-// Optional two-launch split (two_pass, off by default: measured slower, 9.0 vs 6.8 ms per
-// 64-pair batch -- the kernel is bound by divergent vector-memory issue, not by VALU divergence):
-// DEFERRED = false sweeps every query but only
-// searches those whose previous match already lies inside the cap (small balls, 1-2 cells per
-// axis); the others (no previous match, or previous distance beyond the cap: the future rejects)
-// are compacted into the deferred list, which the DEFERRED = true launch searches with the full
-// cap radius -- full wavefronts of equally expensive queries instead of one slow lane per wave.
-template <bool DEFERRED>
+//
+//  (3) certificates: every search also records L = a lower bound on the distance from the query to every
+//      target point OTHER than its match (runner-up distance, capped by the searched radius).  In the next
+//      iteration the query has moved by delta = |M_new s - M_prev s|, so all other points are still at least
+//      L - delta away: if the old match is closer than that it is provably still the unique nearest
+//      neighbour and no search happens at all (nn_certify).  Lower-bounded ("hard") queries keep their
+//      bound the same way.  Only the queries whose certificate fails are compacted into dlist and searched
+//      (LISTED = true); iteration 0 searches everything.
+// The search radius is min(R_cap, d_prev + margin) rather than d_prev so the runner-up information
+// reaches beyond the match; margin = 3 x the query's motion in this iteration (1 cm .. 10 cm).
+__device__ __forceinline__ float search_radius2(float r2cap, float dub2, float margin) {
+  const float r = sqrtf(dub2) + margin;
+  return fminf(r2cap, r * r);
+}
+// how far beyond the previous match the search looks: enough that next iteration's certificate
+// (runner-up bound minus the query's motion) can still clear the match; motion shrinks every iteration
+__device__ __forceinline__ float search_margin(float delta) { return fminf(fmaxf(3.0f * delta, 0.01f), 0.10f); }
+
+template <bool LISTED>
 __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
   int pair, blk;
   if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
   PairState* st = &b.state[pair];
   if (st->done) return;
-  const int count = DEFERRED ? (int)st->deferred_count : st->ns;
+  const int count = LISTED ? (int)st->deferred_count : st->ns;
   const int base = blk * (kNnThreads * kBallItems);
   if (base >= count) return;
   __shared__ uint32_t s_hist[kHistBins];
@@ -432,77 +449,68 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
 
   for (int it = 0; it < kBallItems; ++it) {
     const int e = base + it * kNnThreads + threadIdx.x;
-    bool hard = false, defer = false;
+    bool hard = false;
     int i = -1;
     if (e < count) {
-      i = DEFERRED ? b.dlist[so + e] : e;
+      i = LISTED ? b.dlist[so + e] : e;
       double px, py, pz;
       transform_point(st->M, b.src[so + i], px, py, pz);
       const float qx = (float)px, qy = (float)py, qz = (float)pz;
-      Best best = {INFINITY, -1};
-      float d2out = INFINITY;
+      Best best = {INFINITY, -1, INFINITY};
+      float d2out = INFINITY, lbout = 0.f;
+      int jout = -1;
       if (isfinite(qx) && isfinite(qy) && isfinite(qz)) {
         float R2 = r2cap;
+        int jp = -1;
         if (have_prev) {
-          const int jp = b.idx[so + i];
+          jp = b.idx[so + i];
           if (jp >= 0) {
-            if (b.ablate >= 3) { best.d2 = 0.01f * r2cap; best.j = jp; }
-            else { best.d2 = dist2(tq[jp], qx, qy, qz); best.j = jp; }
-            R2 = fminf(R2, best.d2);
+            double ux, uy, uz;
+            transform_point(st->M_prev, b.src[so + i], ux, uy, uz);
+            const float ex = qx - (float)ux, ey = qy - (float)uy, ez = qz - (float)uz;
+            R2 = search_radius2(r2cap, dist2(tq[jp], qx, qy, qz), search_margin(sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)))));
           }
         }
-        defer = !DEFERRED && b.two_pass && !(best.d2 <= r2cap);
-        if (!defer) {
-          // every target point within sqrt(R2) of q lies in a cell meeting [q - Rs, q + Rs]^3
-          const float Rs = sqrtf(R2) * 1.0001f + 1.0e-3f * h;
-          const int x0 = max(cell_coord(qx - Rs, ox, inv_h), 0), x1 = min(cell_coord(qx + Rs, ox, inv_h), nx - 1);
-          const int y0 = max(cell_coord(qy - Rs, oy, inv_h), 0), y1 = min(cell_coord(qy + Rs, oy, inv_h), ny - 1);
-          const int z0 = max(cell_coord(qz - Rs, oz, inv_h), 0), z1 = min(cell_coord(qz + Rs, oz, inv_h), nz - 1);
-          if (x0 <= x1) {
-            const float slack = 2.0e-3f * h;
-            for (int z = z0; z <= z1; ++z) {
-              const float zl = oz + (float)z * h;
-              const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + h)) - slack, 0.f);
-              for (int y = y0; y <= y1; ++y) {
-                const float yl = oy + (float)y * h;
-                const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + h)) - slack, 0.f);
-                if (fmaf(dy, dy, dz * dz) > fminf(best.d2, R2)) continue;     // the row cannot hold anything useful
-                if (b.ablate >= 2) continue;
-                if (b.ablate == 1) {   // lookups only
-                  uint32_t sb, se;
-                  row_slots(words, (z * ny + y) * wx, x0, x1, sb, se);
-                  if (se > sb) { const uint32_t j0 = cstart[sb], j1 = cstart[se]; if (j1 - j0 > 100000u) best.j = (int)j0; }
-                  continue;
-                }
-                search_row(words, cstart, tq, (z * ny + y) * wx, x0, x1, qx, qy, qz, best);
+        // every target point within sqrt(R2) of q lies in a cell meeting [q - Rs, q + Rs]^3
+        const float Rs = sqrtf(R2) * 1.0001f + 1.0e-3f * h;
+        const int x0 = max(cell_coord(qx - Rs, ox, inv_h), 0), x1 = min(cell_coord(qx + Rs, ox, inv_h), nx - 1);
+        const int y0 = max(cell_coord(qy - Rs, oy, inv_h), 0), y1 = min(cell_coord(qy + Rs, oy, inv_h), ny - 1);
+        const int z0 = max(cell_coord(qz - Rs, oz, inv_h), 0), z1 = min(cell_coord(qz + Rs, oz, inv_h), nz - 1);
+        if (x0 <= x1) {
+          const float slack = 2.0e-3f * h;
+          for (int z = z0; z <= z1; ++z) {
+            const float zl = oz + (float)z * h;
+            const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + h)) - slack, 0.f);
+            for (int y = y0; y <= y1; ++y) {
+              const float yl = oy + (float)y * h;
+              const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + h)) - slack, 0.f);
+              if (fmaf(dy, dy, dz * dz) > R2) continue;            // the row lies outside the ball
+              uint32_t sb, se;
+              row_slots(words, (z * ny + y) * wx, x0, x1, sb, se);
+              if (se > sb) {
+                const uint32_t j0 = cstart[sb], j1 = cstart[se];
+                for (uint32_t j = j0; j < j1; ++j) test_ascending_ru(tq[j], (int)j, qx, qy, qz, best);
               }
             }
           }
-          if (best.d2 <= R2) {
-            d2out = best.d2;                      // exact: everything within sqrt(R2) was seen
-          } else {
-            d2out = R2;                           // certified lower bound: nothing lies within sqrt(R2)
-            hard = true;
-            min_lb = min(min_lb, __float_as_uint(R2));
-          }
+        }
+        if (best.d2 <= R2) {                  // exact: everything within sqrt(R2) was seen
+          d2out = best.d2;
+          jout = best.j;
+          lbout = sqrtf(fminf(best.s2, R2));  // every other point is at least this far
+        } else {                              // certified lower bound: nothing lies within sqrt(R2)
+          d2out = R2;
+          jout = best.j >= 0 ? best.j : jp;   // an upper-bound seed for later iterations
+          lbout = -sqrtf(R2);
+          hard = true;
+          min_lb = min(min_lb, __float_as_uint(R2));
         }
       }
-      if (!defer) {
-        b.d2[so + i] = d2out;
-        b.idx[so + i] = best.j;
-        const uint32_t key = __float_as_uint(d2out);
-        if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
-      }
-    }
-    // wave-aggregated, order-preserving appends
-    if (!DEFERRED) {
-      const unsigned long long dm = __ballot(defer);
-      if (dm) {
-        uint32_t basepos = 0;
-        if (lane == 0) basepos = atomicAdd(&st->deferred_count, (uint32_t)__popcll(dm));
-        basepos = __shfl(basepos, 0, 64);
-        if (defer) b.dlist[so + basepos + __popcll(dm & ((1ull << lane) - 1ull))] = i;
-      }
+      b.d2[so + i] = d2out;
+      b.idx[so + i] = jout;
+      b.lb[so + i] = lbout;
+      const uint32_t key = __float_as_uint(d2out);
+      if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
     }
     const unsigned long long hm = __ballot(hard);
     if (hm) {
@@ -513,6 +521,85 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
     }
   }
   if (min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
+  __syncthreads();
+  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
+    const uint32_t v = s_hist[k];
+    if (v) atomicAdd(&gh[k], v);
+  }
+}
+
+// Certificate pass (iterations >= 1): no search, five memory operations per query.
+__global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
+  int pair, blk;
+  if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  const int ns = st->ns;
+  const int base = blk * (kNnThreads * kBallItems);
+  if (base >= ns) return;
+  __shared__ uint32_t s_hist[kHistBins];
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const size_t so = (size_t)pair * b.ns_cap;
+  const float4* __restrict__ tq = b.tq + (size_t)pair * b.nt_cap;
+  const float r_need = 0.9f * sqrtf(st->rcap2);     // a hard query's bound must stay well above the quantile
+  uint32_t min_lb = 0xffffffffu;
+  for (int it = 0; it < kBallItems; ++it) {
+    const int i = base + it * kNnThreads + threadIdx.x;
+    bool hard = false, fail = false;
+    if (i < ns) {
+      const float4 s = b.src[so + i];
+      const float l = b.lb[so + i];
+      const int j = b.idx[so + i];
+      double px, py, pz, ox_, oy_, oz_;
+      transform_point(st->M, s, px, py, pz);
+      transform_point(st->M_prev, s, ox_, oy_, oz_);
+      const float qx = (float)px, qy = (float)py, qz = (float)pz;
+      const float ex = qx - (float)ox_, ey = qy - (float)oy_, ez = qz - (float)oz_;
+      const float delta = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+      // all points other than the match (or all points, for a lower-bounded query) are still at least Lp away
+      const float Lp = fabsf(l) - delta - 1.0e-5f * (1.0f + fabsf(l));
+      fail = true;
+      if (isfinite(qx) && isfinite(qy) && isfinite(qz) && Lp > 0.f) {
+        if (l > 0.f && j >= 0) {
+          const float d1 = dist2(tq[j], qx, qy, qz);
+          if (d1 < Lp * Lp) {                       // still the unique nearest neighbour: exact, no search
+            b.d2[so + i] = d1;
+            b.lb[so + i] = Lp;
+            atomicAdd(&s_hist[__float_as_uint(d1) >> kHistShift], 1u);
+            fail = false;
+          }
+        } else if (l < 0.f && Lp >= r_need) {       // still provably farther than the trimming radius
+          const float lb2 = Lp * Lp;
+          b.d2[so + i] = lb2;
+          b.lb[so + i] = -Lp;
+          atomicAdd(&s_hist[__float_as_uint(lb2) >> kHistShift], 1u);
+          min_lb = min(min_lb, __float_as_uint(lb2));
+          hard = true;
+          fail = false;
+        }
+      }
+    }
+    const unsigned long long dm = __ballot(fail);
+    if (dm) {
+      uint32_t basepos = 0;
+      if (lane == 0) basepos = atomicAdd(&st->deferred_count, (uint32_t)__popcll(dm));
+      basepos = __shfl(basepos, 0, 64);
+      if (fail) b.dlist[so + basepos + __popcll(dm & ((1ull << lane) - 1ull))] = i;
+    }
+    const unsigned long long hm = __ballot(hard);
+    if (hm) {
+      uint32_t basepos = 0;
+      if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
+      basepos = __shfl(basepos, 0, 64);
+      if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) min_lb = min(min_lb, (uint32_t)__shfl_xor((int)min_lb, off, 64));
+  if (lane == 0 && min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
   __syncthreads();
   uint32_t* gh = b.hist + (size_t)pair * kHistBins;
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
@@ -540,12 +627,12 @@ __device__ __forceinline__ void sweep_run(const float4* __restrict__ tq, uint32_
   uint32_t j = j0;
   for (; j + 4 <= j1; j += 4) {     // four independent loads in flight per lane
     const float4 t0 = tq[j], t1 = tq[j + 1], t2 = tq[j + 2], t3 = tq[j + 3];
-    test_ascending(t0, (int)j, qx, qy, qz, best);
-    test_ascending(t1, (int)j + 1, qx, qy, qz, best);
-    test_ascending(t2, (int)j + 2, qx, qy, qz, best);
-    test_ascending(t3, (int)j + 3, qx, qy, qz, best);
+    test_ascending_ru(t0, (int)j, qx, qy, qz, best);
+    test_ascending_ru(t1, (int)j + 1, qx, qy, qz, best);
+    test_ascending_ru(t2, (int)j + 2, qx, qy, qz, best);
+    test_ascending_ru(t3, (int)j + 3, qx, qy, qz, best);
   }
-  for (; j < j1; ++j) test_ascending(tq[j], (int)j, qx, qy, qz, best);
+  for (; j < j1; ++j) test_ascending_ru(tq[j], (int)j, qx, qy, qz, best);
 }
 
 __global__ __launch_bounds__(kNnThreads) void nn_ball_lds(IcpDev b, int nblk) {
@@ -560,10 +647,15 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball_lds(IcpDev b, int nblk) {
   __shared__ uint32_t s_tab[kLdsTableCap];
   __shared__ float4 s_pts[kLdsPointCap];
   __shared__ uint32_t s_roff[kLdsRowCap + 1];
+  __shared__ float4 s_q[kNnThreads];          // queries of the round that need a search: x, y, z, previous match
+  __shared__ float s_r2[kNnThreads];          // their squared search radius
+  __shared__ uint16_t s_lid[kNnThreads];      // their lane in the round
+  __shared__ uint32_t s_nsearch[2];
   __shared__ uint32_t s_w[17];
   __shared__ int s_box[2][6];
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
   if (threadIdx.x < 6) { s_box[0][threadIdx.x] = threadIdx.x < 3 ? 0x3fffffff : -0x3fffffff; s_box[1][threadIdx.x] = s_box[0][threadIdx.x]; }
+  if (threadIdx.x < 2) s_nsearch[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const size_t so = (size_t)pair * b.ns_cap;
@@ -574,27 +666,37 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball_lds(IcpDev b, int nblk) {
   const float h = st->h, inv_h = st->inv_h;
   const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx, nw = st->nw;
   const float r2cap = st->rcap2;
-  const float Rcap_s = sqrtf(r2cap) * 1.0001f + 1.0e-3f * h;
+  const float r_need = 0.9f * sqrtf(r2cap);
   const bool have_prev = st->iter > 0;
+  const bool certify = have_prev && b.certify;
   uint32_t min_lb = 0xffffffffu;
 
   // level 1 of round 0
   int i = base0 + threadIdx.x;
   float4 s_cur = make_float4(0, 0, 0, 0);
   int jp_cur = -1;
-  if (i < ns) { s_cur = b.src[so + i]; if (have_prev) jp_cur = b.idx[so + i]; }
+  float l_cur = 0.f;
+  if (i < ns) {
+    s_cur = b.src[so + i];
+    if (have_prev) { jp_cur = b.idx[so + i]; if (certify) l_cur = b.lb[so + i]; }
+  }
 
   for (int it = 0; it < kBallItems; ++it) {
     const int base = base0 + it * kNnThreads;
     if (base >= ns) break;                               // block-uniform
     i = base + threadIdx.x;
     int* box = s_box[it & 1];
+    uint32_t* nsearch = &s_nsearch[it & 1];
     // prefetch level 1 of the next round
     const int i_next = i + kNnThreads;
     float4 s_next = make_float4(0, 0, 0, 0);
     int jp_next = -1;
-    if (it + 1 < kBallItems && i_next < ns) { s_next = b.src[so + i_next]; if (have_prev) jp_next = b.idx[so + i_next]; }
-    // query
+    float l_next = 0.f;
+    if (it + 1 < kBallItems && i_next < ns) {
+      s_next = b.src[so + i_next];
+      if (have_prev) { jp_next = b.idx[so + i_next]; if (certify) l_next = b.lb[so + i_next]; }
+    }
+    // ---- phase C (every lane): query, previous match, certificate
     float qx = 0.f, qy = 0.f, qz = 0.f;
     bool valid = false;
     if (i < ns) {
@@ -603,36 +705,102 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball_lds(IcpDev b, int nblk) {
       qx = (float)px; qy = (float)py; qz = (float)pz;
       valid = isfinite(qx) && isfinite(qy) && isfinite(qz);
     }
-    // level 2a: previous match in flight
-    float4 tprev = make_float4(0, 0, 0, 0);
     const bool has_jp = valid && jp_cur >= 0;
-    if (has_jp) tprev = tq[jp_cur];
-    // box of the round from q +- R_cap (does not need the previous match)
-    int bx0 = 1, bx1 = 0, by0 = 1, by1 = 0, bz0 = 1, bz1 = 0;
-    if (valid) {
-      bx0 = max(cell_coord(qx - Rcap_s, ox, inv_h), 0); bx1 = min(cell_coord(qx + Rcap_s, ox, inv_h), nx - 1);
-      by0 = max(cell_coord(qy - Rcap_s, oy, inv_h), 0); by1 = min(cell_coord(qy + Rcap_s, oy, inv_h), ny - 1);
-      bz0 = max(cell_coord(qz - Rcap_s, oz, inv_h), 0); bz1 = min(cell_coord(qz + Rcap_s, oz, inv_h), nz - 1);
+    float dub2 = INFINITY;
+    if (has_jp) dub2 = dist2(tq[jp_cur], qx, qy, qz);
+    bool need_search = valid, hard = false;
+    if (i < ns && !valid) {                                // NaN / inf input: no match
+      b.d2[so + i] = INFINITY; b.idx[so + i] = -1; b.lb[so + i] = 0.f;
     }
-    const bool inbox = valid && bx0 <= bx1 && by0 <= by1 && bz0 <= bz1;
+    float delta = 0.03f;                                   // first iteration: no motion history yet
+    if (have_prev && valid) {
+      double ox_, oy_, oz_;
+      transform_point(st->M_prev, s_cur, ox_, oy_, oz_);
+      const float ex = qx - (float)ox_, ey = qy - (float)oy_, ez = qz - (float)oz_;
+      delta = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+    }
+    if (certify && valid) {
+      // every point other than the match (every point, for a lower-bounded query) is still >= Lp away
+      const float Lp = fabsf(l_cur) - delta - 1.0e-5f * (1.0f + fabsf(l_cur));
+      if (Lp > 0.f) {
+        if (l_cur > 0.f && has_jp && dub2 < Lp * Lp) {     // still the unique nearest neighbour: exact, no search
+          b.d2[so + i] = dub2;
+          b.lb[so + i] = Lp;
+          atomicAdd(&s_hist[__float_as_uint(dub2) >> kHistShift], 1u);
+          need_search = false;
+        } else if (l_cur < 0.f && Lp >= r_need) {          // still provably beyond the trimming radius
+          const float lb2 = Lp * Lp;
+          b.d2[so + i] = lb2;
+          b.lb[so + i] = -Lp;
+          atomicAdd(&s_hist[__float_as_uint(lb2) >> kHistShift], 1u);
+          min_lb = min(min_lb, __float_as_uint(lb2));
+          hard = true;
+          need_search = false;
+        }
+      }
+    }
+    // compact the lanes that need a search into s_q (wave-aggregated, order-preserving inside a wave)
     {
+      const unsigned long long sm = __ballot(need_search);
+      if (sm) {
+        uint32_t basepos = 0;
+        if (lane == 0) basepos = atomicAdd(nsearch, (uint32_t)__popcll(sm));
+        basepos = __shfl(basepos, 0, 64);
+        if (need_search) {
+          const uint32_t pos = basepos + __popcll(sm & ((1ull << lane) - 1ull));
+          s_q[pos] = make_float4(qx, qy, qz, __int_as_float(jp_cur));
+          s_r2[pos] = has_jp ? search_radius2(r2cap, dub2, search_margin(delta)) : r2cap;
+          s_lid[pos] = (uint16_t)threadIdx.x;
+        }
+      }
+    }
+    {   // lower-bounded lanes of phase C go to the hard list right away
+      const unsigned long long hm = __ballot(hard);
+      if (hm) {
+        uint32_t basepos = 0;
+        if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
+        basepos = __shfl(basepos, 0, 64);
+        if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
+      }
+    }
+    __syncthreads();                                      // (A) search list complete
+    const int nq = (int)*nsearch;
+    if (threadIdx.x == 0 && nq) atomicAdd(&st->deferred_count, (uint32_t)nq);     // statistics only
+    // ---- phase S: the first nq threads own one searching query each
+    const bool mine = (int)threadIdx.x < nq;
+    float R2 = 0.f;
+    int jseed = -1, gi = -1;
+    if (mine) {
+      const float4 q4 = s_q[threadIdx.x];
+      qx = q4.x; qy = q4.y; qz = q4.z; jseed = __float_as_int(q4.w);
+      R2 = s_r2[threadIdx.x];
+      gi = base + (int)s_lid[threadIdx.x];
+    }
+    int x0 = 1, x1 = 0, y0 = 1, y1 = 0, z0 = 1, z1 = 0;
+    if (mine) {
+      const float Rs = sqrtf(R2) * 1.0001f + 1.0e-3f * h;
+      x0 = max(cell_coord(qx - Rs, ox, inv_h), 0); x1 = min(cell_coord(qx + Rs, ox, inv_h), nx - 1);
+      y0 = max(cell_coord(qy - Rs, oy, inv_h), 0); y1 = min(cell_coord(qy + Rs, oy, inv_h), ny - 1);
+      z0 = max(cell_coord(qz - Rs, oz, inv_h), 0); z1 = min(cell_coord(qz + Rs, oz, inv_h), nz - 1);
+    }
+    const bool inbox = mine && x0 <= x1 && y0 <= y1 && z0 <= z1;
+    if ((int)(threadIdx.x & ~63) < nq) {                  // waves that hold searching queries
       const int big = 0x3fffffff;
-      const int mx0 = wave_min_i(inbox ? bx0 : big), mx1 = wave_max_i(inbox ? bx1 : -big);
-      const int my0 = wave_min_i(inbox ? by0 : big), my1 = wave_max_i(inbox ? by1 : -big);
-      const int mz0 = wave_min_i(inbox ? bz0 : big), mz1 = wave_max_i(inbox ? bz1 : -big);
+      const int mx0 = wave_min_i(inbox ? x0 : big), mx1 = wave_max_i(inbox ? x1 : -big);
+      const int my0 = wave_min_i(inbox ? y0 : big), my1 = wave_max_i(inbox ? y1 : -big);
+      const int mz0 = wave_min_i(inbox ? z0 : big), mz1 = wave_max_i(inbox ? z1 : -big);
       if (lane == 0 && mx0 <= mx1) {
         atomicMin(&box[0], mx0); atomicMin(&box[1], my0); atomicMin(&box[2], mz0);
         atomicMax(&box[3], mx1); atomicMax(&box[4], my1); atomicMax(&box[5], mz1);
       }
     }
-    __syncthreads();                                      // (A) box complete; previous round's table reads done
+    __syncthreads();                                      // (B) box complete
     const int X0 = box[0], Y0 = box[1], Z0 = box[2];
     const int nxl = box[3] - X0 + 2, nyl = box[4] - Y0 + 1, nzl = box[5] - Z0 + 1;     // one extra x column
     const bool any = box[3] >= X0;
     const long long entries = any ? (long long)nxl * nyl * nzl : 0;
     const bool use_lds = any && entries <= kLdsTableCap;
-    // level 2b/3: stage the row tables
-    if (use_lds) {
+    if (use_lds) {                                        // stage the row tables (all threads help)
       const float inv_nxl = 1.0f / (float)nxl, inv_nyl = 1.0f / (float)nyl;    // entries <= 2048: exact via float
       for (int e = threadIdx.x; e < (int)entries; e += kNnThreads) {
         const int r = (int)(((float)e + 0.5f) * inv_nxl);
@@ -648,12 +816,13 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball_lds(IcpDev b, int nblk) {
         s_tab[e] = val;
       }
     }
-    // reset the other round's box while nobody reads it
+    // reset the other round's scratch while nobody reads it
     if (threadIdx.x < 6) s_box[(it + 1) & 1][threadIdx.x] = threadIdx.x < 3 ? 0x3fffffff : -0x3fffffff;
+    if (threadIdx.x == 6) s_nsearch[(it + 1) & 1] = 0;
     // stage the box's target points: every grid row of the box is ONE contiguous run of tq
     const int rows = use_lds ? nyl * nzl : 0;
     bool pts_lds = use_lds && rows <= kLdsRowCap;
-    if (use_lds) __syncthreads();                         // (A2) table visible
+    if (use_lds) __syncthreads();                         // (B2) table visible
     if (pts_lds) {
       uint32_t len = 0;
       if ((int)threadIdx.x < rows) len = s_tab[threadIdx.x * nxl + nxl - 1] - s_tab[threadIdx.x * nxl];
@@ -674,84 +843,71 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball_lds(IcpDev b, int nblk) {
         }
       }
     }
-    // consume the previous match
-    Best best = {INFINITY, -1};
-    float R2 = r2cap;
-    if (has_jp) {
-      const float dub = dist2(tprev, qx, qy, qz);
-      R2 = fminf(R2, dub);
-      // Candidates are swept in ascending position with a strict "<" (first minimum = smallest position).
-      // The seed is bumped by one ulp so that the seed point itself, which lies inside the ball whenever
-      // dub <= R2 and is therefore swept again, replaces it under the same rule.
-      best.d2 = __uint_as_float(__float_as_uint(dub) + 1u);
-      best.j = jp_cur;
-    }
-    int x0 = 1, x1 = 0, y0 = 1, y1 = 0, z0 = 1, z1 = 0;
-    if (valid) {
-      const float Rs = sqrtf(R2) * 1.0001f + 1.0e-3f * h;
-      x0 = max(cell_coord(qx - Rs, ox, inv_h), 0); x1 = min(cell_coord(qx + Rs, ox, inv_h), nx - 1);
-      y0 = max(cell_coord(qy - Rs, oy, inv_h), 0); y1 = min(cell_coord(qy + Rs, oy, inv_h), ny - 1);
-      z0 = max(cell_coord(qz - Rs, oz, inv_h), 0); z1 = min(cell_coord(qz + Rs, oz, inv_h), nz - 1);
-    }
-    __syncthreads();                                      // (B) table staged
-    // level 3/4: search
-    bool hard = false;
-    if (i < ns) {
-      float d2out = INFINITY;
-      if (valid) {
-        if (x0 <= x1) {
-          const float slack = 2.0e-3f * h;
-          for (int z = z0; z <= z1; ++z) {
-            const float zl = oz + (float)z * h;
-            const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + h)) - slack, 0.f);
-            for (int y = y0; y <= y1; ++y) {
-              const float yl = oy + (float)y * h;
-              const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + h)) - slack, 0.f);
-              if (fmaf(dy, dy, dz * dz) > fminf(best.d2, R2)) continue;
-              if (pts_lds) {
-                const int r = (z - Z0) * nyl + (y - Y0);
-                const int rb = r * nxl - X0;
-                const uint32_t g0 = s_tab[rb + X0];
-                const uint32_t k0 = s_roff[r] + (s_tab[rb + x0] - g0), k1 = s_roff[r] + (s_tab[rb + x1 + 1] - g0);
-                uint32_t k = k0;
-                for (; k + 2 <= k1; k += 2) {
-                  const float4 ta = s_pts[k], tc = s_pts[k + 1];
-                  test_ascending2(ta, __float_as_int(ta.w), tc, __float_as_int(tc.w), qx, qy, qz, best);
-                }
-                if (k < k1) { const float4 t = s_pts[k]; test_ascending(t, __float_as_int(t.w), qx, qy, qz, best); }
-              } else if (use_lds) {
-                const int rb = ((z - Z0) * nyl + (y - Y0)) * nxl - X0;
-                sweep_run(tq, s_tab[rb + x0], s_tab[rb + x1 + 1], qx, qy, qz, best);
-              } else {
-                uint32_t sb, se;
-                row_slots(words, (z * ny + y) * wx, x0, x1, sb, se);
-                if (se > sb) sweep_run(tq, cstart[sb], cstart[se], qx, qy, qz, best);
+    __syncthreads();                                      // (C) table / points staged
+    // search (threads < nq)
+    bool hard2 = false;
+    if (mine) {
+      Best best = {INFINITY, -1, INFINITY};
+      if (x0 <= x1 && y0 <= y1 && z0 <= z1) {
+        const float slack = 2.0e-3f * h;
+        for (int z = z0; z <= z1; ++z) {
+          const float zl = oz + (float)z * h;
+          const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + h)) - slack, 0.f);
+          for (int y = y0; y <= y1; ++y) {
+            const float yl = oy + (float)y * h;
+            const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + h)) - slack, 0.f);
+            if (fmaf(dy, dy, dz * dz) > R2) continue;              // the row lies outside the ball
+            if (pts_lds) {
+              const int r = (z - Z0) * nyl + (y - Y0);
+              const int rb = r * nxl - X0;
+              const uint32_t g0 = s_tab[rb + X0];
+              const uint32_t k0 = s_roff[r] + (s_tab[rb + x0] - g0), k1 = s_roff[r] + (s_tab[rb + x1 + 1] - g0);
+              for (uint32_t k = k0; k < k1; ++k) {
+                const float4 t = s_pts[k];
+                test_ascending_ru(t, __float_as_int(t.w), qx, qy, qz, best);
               }
+            } else if (use_lds) {
+              const int rb = ((z - Z0) * nyl + (y - Y0)) * nxl - X0;
+              sweep_run(tq, s_tab[rb + x0], s_tab[rb + x1 + 1], qx, qy, qz, best);
+            } else {
+              uint32_t sb, se;
+              row_slots(words, (z * ny + y) * wx, x0, x1, sb, se);
+              if (se > sb) sweep_run(tq, cstart[sb], cstart[se], qx, qy, qz, best);
             }
           }
         }
-        if (best.d2 <= R2) {
-          d2out = best.d2;
-        } else {
-          d2out = R2;
-          hard = true;
-          min_lb = min(min_lb, __float_as_uint(R2));
-        }
       }
-      b.d2[so + i] = d2out;
-      b.idx[so + i] = best.j;
+      float d2out, lbout;
+      int jout;
+      if (best.d2 <= R2) {                  // exact: everything within sqrt(R2) was seen
+        d2out = best.d2;
+        jout = best.j;
+        lbout = sqrtf(fminf(best.s2, R2));  // every other point is at least this far
+      } else {                              // certified lower bound
+        d2out = R2;
+        jout = best.j >= 0 ? best.j : jseed;
+        lbout = -sqrtf(R2);
+        hard2 = true;
+        min_lb = min(min_lb, __float_as_uint(R2));
+      }
+      b.d2[so + gi] = d2out;
+      b.idx[so + gi] = jout;
+      b.lb[so + gi] = lbout;
       const uint32_t key = __float_as_uint(d2out);
       if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
     }
-    const unsigned long long hm = __ballot(hard);
-    if (hm) {
-      uint32_t basepos = 0;
-      if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
-      basepos = __shfl(basepos, 0, 64);
-      if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
+    {
+      const unsigned long long hm = __ballot(hard2);
+      if (hm) {
+        uint32_t basepos = 0;
+        if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
+        basepos = __shfl(basepos, 0, 64);
+        if (hard2) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = gi;
+      }
     }
-    s_cur = s_next; jp_cur = jp_next;
+    s_cur = s_next; jp_cur = jp_next; l_cur = l_next;
   }
+  // statistics: queries searched by this block are counted through deferred_count
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) min_lb = min(min_lb, (uint32_t)__shfl_xor((int)min_lb, off, 64));
   if (lane == 0 && min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
@@ -802,7 +958,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring(IcpDev b) {
     double px, py, pz;
     transform_point(st->M, b.src[so + i], px, py, pz);
     const float qx = (float)px, qy = (float)py, qz = (float)pz;
-    Best best = {INFINITY, -1};
+    Best best = {INFINITY, -1, INFINITY};
     bool resolved = true;
     if (isfinite(qx) && isfinite(qy) && isfinite(qz)) {
       const uint2* words = b.words + (size_t)pair * kMaxGridWords;
@@ -839,6 +995,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring(IcpDev b) {
     }
     b.d2[so + i] = best.d2;
     b.idx[so + i] = best.j;
+    b.lb[so + i] = 0.f;                 // exact match, but no runner-up information: searched again next time
     if (resolved) {
       const uint32_t key = __float_as_uint(best.d2);
       if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
@@ -869,7 +1026,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_brute(IcpDev b) {
   const int i = blockIdx.x * kNnThreads + threadIdx.x;
   const bool active = i < count;
   float qx = 0, qy = 0, qz = 0;
-  Best best = {INFINITY, -1};
+  Best best = {INFINITY, -1, INFINITY};
   bool valid = false;
   if (active) {
     double px, py, pz;
@@ -931,7 +1088,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_fallback_scan(IcpDev b) {
       double px, py, pz;
       transform_point(st->M, b.src[so + b.ulist[so + e]], px, py, pz);
       const float qx = (float)px, qy = (float)py, qz = (float)pz;
-      Best best = {INFINITY, -1};
+      Best best = {INFINITY, -1, INFINITY};
 #pragma unroll 8
       for (int k = 0; k < m; ++k) test_ascending(s_t[k], base + k, qx, qy, qz, best);
       const unsigned long long key = ((unsigned long long)__float_as_uint(best.d2) << 32) | (uint32_t)best.j;
@@ -952,6 +1109,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_fallback_resolve(IcpDev b) {
     const uint32_t dbits = (uint32_t)(key >> 32);
     b.d2[so + i] = __uint_as_float(dbits);
     b.idx[so + i] = (int)(uint32_t)(key & 0xffffffffu);
+    b.lb[so + i] = 0.f;
     if (dbits < 0x7f800000u) atomicAdd(&b.hist[(size_t)pair * kHistBins + (dbits >> kHistShift)], 1u);
   }
 }
@@ -1281,6 +1439,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   st->unresolved_count = 0;
   st->hard_total += st->hard_count;
   st->hard_count = 0;
+  st->searched_total += st->deferred_count ? st->deferred_count : (uint32_t)ns;
   st->deferred_count = 0;
   st->min_lb_key = 0xffffffffu;
   st->refine = 0;
@@ -1331,7 +1490,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   for (int i = 0; i < 16; ++i) st->T_iter[i] = Tn[i];
   double Mn[16];
   mat4_mul_rm(Tn, st->G, Mn);
-  for (int i = 0; i < 12; ++i) st->M[i] = Mn[i];
+  for (int i = 0; i < 12; ++i) { st->M_prev[i] = st->M[i]; st->M[i] = Mn[i]; }
   const int it = ++st->iter;                                                  // :513
   // history ring (latest at n_hist-1, at most 5 kept)
   int nh = st->n_hist;

@@ -172,13 +172,13 @@ smhip_status enqueue_prepare(smhip_context* h, int np, int nt_max) {
   return enqueue_grid_build(h, whole_batch(h, np), nt_max);
 }
 
-smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_max);
+smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_max, int iteration);
 
 smhip_status enqueue_find_closests(smhip_context* h, int np, int ns_max) {
-  return enqueue_find_closests_half(h, whole_batch(h, np), ns_max);
+  return enqueue_find_closests_half(h, whole_batch(h, np), ns_max, 0);
 }
 
-smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_max) {
+smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_max, int iteration) {
   const IcpDev& d = f.d;
   const int np = f.np;
   hipStream_t st = f.stream;
@@ -187,14 +187,18 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
     if (d.use_ball) {
       const int nblk = ceil_div(ns_max, kNnThreads * kBallItems);
       const dim3 gx(nblk * 8 * ceil_div(np, 8));
-      if (d.lds_table && !d.two_pass) {
+      if (d.lds_table) {
+        // certificate, in-workgroup compaction of the failing queries and LDS-staged search in one launch
         Bracket br(h, 4);
         hipLaunchKernelGGL(nn_ball_lds, gx, dim3(kNnThreads), 0, st, d, nblk);
+      } else if (d.certify && iteration > 0) {
+        // global-memory variant: certificate pass, then a search over the compacted failing queries
+        { Bracket br(h, 4); hipLaunchKernelGGL(nn_certify, gx, dim3(kNnThreads), 0, st, d, nblk); }
+        { Bracket br(h, 4); hipLaunchKernelGGL(nn_ball<true>, gx, dim3(kNnThreads), 0, st, d, nblk); }
       } else {
         Bracket br(h, 4);
         hipLaunchKernelGGL(nn_ball<false>, gx, dim3(kNnThreads), 0, st, d, nblk);
       }
-      if (d.two_pass) { Bracket br(h, 4); hipLaunchKernelGGL(nn_ball<true>, gx, dim3(kNnThreads), 0, st, d, nblk); }
       { Bracket br(h, 1); hipLaunchKernelGGL(nn_validate, dim3(np), dim3(256), 0, st, d); }
       { Bracket br(h, 1); hipLaunchKernelGGL(nn_ring<true>, dim3(32, np), dim3(kNnThreads), 0, st, d); }
     } else {
@@ -282,7 +286,7 @@ void sync_options(smhip_context* h) {
   h->dev.grid_cell = h->opts.grid_cell > 0 ? h->opts.grid_cell : 0.5f;
   h->dev.use_ball = h->opts.use_ball;
   h->dev.sort_cells = 1;
-  h->dev.two_pass = h->opts.two_pass;
+  h->dev.certify = h->opts.two_pass ? 0 : 1;
   h->dev.lds_table = h->opts.no_lds_table ? 0 : 1;
   { const char* a = std::getenv("SMHIP_ABLATE"); h->dev.ablate = a ? std::atoi(a) : 0; }
   h->dev.cap_factor = h->opts.ball_cap_factor > 1.0f ? h->opts.ball_cap_factor : 1.5f;
@@ -404,6 +408,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, &d.ccount, B * (NT + 1)));
   A(dev_alloc(h, &d.cstart, B * (NT + 1)));
   A(dev_alloc(h, &d.d2, B * NS));
+  A(dev_alloc(h, &d.lb, B * NS));
   A(dev_alloc(h, &d.idx, B * NS));
   A(dev_alloc(h, &d.hist, B * kHistBins));
   A(dev_alloc(h, &d.dlist, B * NS));
@@ -620,7 +625,7 @@ smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* g
   for (int it = 0; it < max_it; ++it) {
     for (int k = 0; k < nh; ++k) {
       const Half& f = halves[k];
-      s = enqueue_find_closests_half(h, f, ns_max);
+      s = enqueue_find_closests_half(h, f, ns_max, it);
       if (s) return s;
       {
         const int nblk = ceil_div(ns_max, kAccChunk);
@@ -668,6 +673,8 @@ smhip_status smhip_icp_fetch_batch(smhip_handle h, int npairs, double* results, 
       stats[p].status = st.status;
       stats[p].hard_queries = (int32_t)st.hard_total;
       stats[p].refined_iterations = (int32_t)st.refine_total;
+      stats[p].searched_queries = (int32_t)st.searched_total;
+      stats[p].reserved = 0;
     }
     if (st.status != SMHIP_OK && worst == SMHIP_OK) { worst = st.status; h->err = "pair failed: no finite correspondence"; }
     if (!st.done && worst == SMHIP_OK) { worst = SMHIP_ERR_HIP; h->err = "pair did not finish (internal)"; }

@@ -27,6 +27,7 @@ constexpr int kBallItems = 4;            // queries per thread in nn_ball (1024 
 struct PairState {
   // transforms, row-major
   double M[12];          // T_iter * G : applied to the raw source every iteration
+  double M_prev[12];     // the same of the previous iteration (how far each query moved: nn_certify)
   double T_iter[16];
   double G[16];          // T(-mu) * guess
   double mu[3];          // target mean (icp_fast.cc:457-458)
@@ -52,6 +53,7 @@ struct PairState {
   uint32_t unresolved_count;
   uint32_t blist_count;
   uint32_t fallback_total;
+  uint32_t searched_total;   // queries that went through a search, summed over iterations
   uint32_t deferred_count;   // queries nn_ball<false> left to the cap-radius launch
   uint32_t hard_count;       // queries nn_ball recorded with a lower bound this iteration
   uint32_t hard_total;
@@ -95,6 +97,8 @@ struct IcpDev {
   uint2* words;              // [slots][kMaxGridWords] {occupancy bits, exclusive rank}
   uint32_t* ccount;          // [slots][nt_cap + 1]
   uint32_t* cstart;          // [slots][nt_cap + 1]
+  float* lb;                 // [slots][ns_cap] > 0: every target point other than the match is at least this far;
+                             //                 < 0: no exact match, EVERY target point is at least -lb away; 0: unknown
   float* d2;                 // [slots][ns_cap]
   int32_t* idx;              // [slots][ns_cap] index into tq/tn (sorted order)
   uint32_t* hist;            // [slots][kHistBins]
@@ -113,8 +117,8 @@ struct IcpDev {
   int32_t sort_cells;        // 1 = order points inside a cell by caller index (deterministic tie rule)
   int32_t use_ball;          // 1 = ball-bounded search with certified trimming; 0 = ring search over every query
   int32_t lds_table;         // 1 = nn_ball_lds (row tables staged in LDS), 0 = nn_ball (global lookups)
-  int32_t ablate;            // development only (env SMHIP_ABLATE): skip parts of nn_ball to time the rest
-  int32_t two_pass;          // 1 = nn_ball defers cap-radius queries to a second, compacted launch
+  int32_t certify;           // 1 = iterations >= 1 run nn_certify and search only the queries whose certificate fails
+  int32_t ablate;            // development only (env SMHIP_ABLATE)
   int32_t exact_all;         // 1 = every match exact (no lower bounds survive), e.g. find_closests
   float ball_radius;         // largest search radius of nn_ball (first iteration / clamp)
   float cap_factor;          // next cap = cap_factor x quantile distance

@@ -145,7 +145,8 @@ class IcpFastHip:
                                              scores.ctypes.data_as(_capi.c_double_p), stats)
         self.last_stats = [dict(iterations=s.iterations, kept=s.kept, limit_d2=s.limit_d2,
                                 fallback_queries=s.fallback_queries, status=s.status,
-                                hard_queries=s.hard_queries, refined_iterations=s.refined_iterations) for s in stats]
+                                hard_queries=s.hard_queries, refined_iterations=s.refined_iterations,
+                                searched_queries=s.searched_queries) for s in stats]
         self._check(st)
         return res.reshape(npairs, 4, 4).transpose(0, 2, 1).copy(), scores, self.last_stats
 
@@ -161,7 +162,8 @@ class IcpFastHip:
                                              scores.ctypes.data_as(_capi.c_double_p), stats)
         self.last_stats = [dict(iterations=s.iterations, kept=s.kept, limit_d2=s.limit_d2,
                                 fallback_queries=s.fallback_queries, status=s.status,
-                                hard_queries=s.hard_queries, refined_iterations=s.refined_iterations) for s in stats]
+                                hard_queries=s.hard_queries, refined_iterations=s.refined_iterations,
+                                searched_queries=s.searched_queries) for s in stats]
         self._check(st)
         return res.reshape(npairs, 4, 4).transpose(0, 2, 1).copy(), scores, self.last_stats
 

@@ -89,7 +89,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "WARN"          # keep RCCL's version banner off stdout: rank 0 prints ONE JSON line
+    under_torchrun = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if world > 1 or under_torchrun:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -129,7 +132,7 @@ def main():
         return gathered
 
     def sync_all():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -202,7 +205,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(work[0], args.cpu_seconds)
     m.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

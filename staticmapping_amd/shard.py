@@ -33,7 +33,7 @@ def gather_poses(local: torch.Tensor, n_pairs: int, group=None) -> torch.Tensor:
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     per = padded_local_count(n_pairs, world)
     assert local.shape == (per, POSE_DOUBLES) and local.dtype == torch.float64, local.shape
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return local[:n_pairs].clone()
     out = torch.empty((world * per, POSE_DOUBLES), dtype=torch.float64, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous(), group=group)

@@ -169,6 +169,14 @@ smhip_status smhip_icp_export_results_device(smhip_handle h, int npairs, void* d
 smhip_status smhip_calculate_normals_f64(const double* xyz_colmajor_3xN, int n, double* out_xyz,
                                          double* out_normals, int* n_out);
 
+/* Device-side target preparation: upload a raw scan (float32 rows, stride in
+ * floats) and run CalculateNormals on the GPU; the surviving points + normals become `slot`'s target.
+ * *n_out = number of target points.  smhip_prepare_target_from_source does the same from the source
+ * cloud already resident in slot `from` (scan-to-scan sequences: scan i is the source of pair i-1 and the
+ * target of pair i, uploaded once). */
+smhip_status smhip_prepare_target_f32(smhip_handle h, int slot, const float* xyz, int stride_floats, int n, int* n_out);
+smhip_status smhip_prepare_target_from_source(smhip_handle h, int from_slot, int to_slot, int* n_out);
+
 /* ---- introspection for parity tests ------------------------------------
  * Matches of the LAST executed iteration of `slot` (FindClosests output, icp_fast.cc:169-180):
  * ids index the target cloud in the caller's order, d2 are squared distances (float32).  Every match
@@ -215,6 +223,8 @@ smhip_status smhip_ndt_align(smhip_handle h, const double guess[16], double resu
 smhip_status smhip_ndt_build_voxels(smhip_handle h, int* n_voxels);
 smhip_status smhip_ndt_get_voxels(smhip_handle h, int capacity, int32_t* keys, int32_t* counts, double* means,
                                   float* icovs, float* centroids);
+/* copy slot's current target (as uploaded / prepared) back to the host: xyz and normals, 3 floats each */
+smhip_status smhip_get_target_f32(smhip_handle h, int slot, float* xyz, float* normals, int n);
 smhip_status smhip_ndt_compute_derivatives(smhip_handle h, const double pose6[6], int compute_hessian,
                                            double* score, double grad[6], double hess[36]);
 

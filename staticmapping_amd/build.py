@@ -12,8 +12,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsmhip.so")
 
-HIP_SOURCES = ["smhip_api.hip", "host_cloud.cc"]            # translation units (each may #include kernel files)
-HIP_DEPS = ["icp_kernels.hip", "smhip_device.h", "host_cloud.cc", "ndt_kernels.hip", "smhip_ndt_api.hip",
+HIP_SOURCES = ["smhip_api.hip", "prep_normals.hip", "host_cloud.cc"]            # translation units (each may #include kernel files)
+HIP_DEPS = ["icp_kernels.hip", "smhip_device.h", "host_cloud.cc", "prep_normals.h", "ndt_kernels.hip", "smhip_ndt_api.hip",
             os.path.join("..", "..", "include", "smhip.h")]
 
 

@@ -1,0 +1,13 @@
+// prep_normals.h -- internal interface of the device-side CalculateNormals (prep_normals.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace smhip {
+struct PrepWorkspace;
+PrepWorkspace* prep_create(int max_points);
+void prep_destroy(PrepWorkspace* w);
+// raw: n device points (xyz in .x .y .z).  out_p / out_n: device arrays with room for n / 4 + 8 entries.
+// Blocks until *m_host (number of surviving points) is known.
+hipError_t prep_calculate_normals(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float4* out_p,
+                                  float4* out_n, int* m_host);
+}  // namespace smhip

@@ -1,0 +1,339 @@
+// prep_normals.hip -- EigenPointCloud::CalculateNormals on the device.
+//
+// Reference: /root/reference/builder/data/cloud_types.cc:347-368 (driver), :105-144 (BuildNormals: kd-box
+// split on the widest tracked-bbox axis by std::nth_element until <= 7 points), :73-103 (leaf: mean point,
+// unconstrained least-squares normal, rank test).  The caller of the registrator runs it on every new
+// key-frame right before SetInputTarget (builder/map_builder.cc:286,389), so it is the step immediately
+// before the hot path; on the host it costs ~30 ms per 120 k-point scan, 200x the GPU alignment itself.
+//
+// Level-synchronous formulation: all nodes of one tree level are split together.  Points of a node occupy a
+// contiguous segment of `order`; one stable radix sort (rocPRIM building block) of the composite key
+// (segment start << 32 | order-preserving float bits of the node's cut coordinate) sorts every active
+// segment along its own axis; the split index count - count / 2 and the cut value are then read off.
+// Exact medians, so the partition equals nth_element's up to ties in the cut coordinate (which
+// std::nth_element leaves unspecified as well).
+#include <cstring>
+#include <string.h>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <cmath>
+#include <cstdint>
+
+#include "prep_normals.h"
+
+namespace smhip {
+
+namespace {
+
+constexpr int kLeafMax = 7;              // kNormalEstimationKnn, cloud_types.cc:38
+
+struct KdNode {
+  int32_t start, count;
+  float lo[3], hi[3];                    // tracked bounding box (exact: every value is a point coordinate)
+  int32_t dim;
+  int32_t left;                          // points going to the left child
+};
+
+__device__ __forceinline__ uint32_t ordered_bits(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+struct KdLeaf { int32_t start, count; };   // a node that will not be split further
+
+__global__ void kd_init(const float4* raw, int n, int32_t* order, int32_t* seg, int32_t* node_at, KdNode* nodes, int32_t* counts,
+                        float* bbox_part, KdLeaf* leaves) {
+  // order = identity, one root segment; bbox from the partials computed by kd_bbox
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { order[i] = i; seg[i] = 0; node_at[i] = -1; }
+  if (i == 0) {
+    KdNode r;
+    r.start = 0; r.count = n; r.dim = 0; r.left = 0;
+    for (int c = 0; c < 3; ++c) { r.lo[c] = bbox_part[c]; r.hi[c] = bbox_part[3 + c]; }
+    nodes[0] = r;
+    node_at[0] = (n > kLeafMax) ? 0 : -1;
+    counts[0] = (n > kLeafMax) ? 1 : 0;     // active nodes at this level
+    counts[1] = 0;                          // active nodes at the next level
+    counts[2] = 0;                          // leaves
+    if (n <= kLeafMax) { leaves[0].start = 0; leaves[0].count = n; counts[2] = 1; }
+  }
+}
+
+__global__ __launch_bounds__(1024) void kd_bbox(const float4* raw, int n, float* out) {   // one block
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float4 p = raw[i];
+    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+  }
+  __shared__ float s[16][6];
+  for (int c = 0; c < 3; ++c)
+    for (int off = 32; off > 0; off >>= 1) { mn[c] = fminf(mn[c], __shfl_down(mn[c], off, 64)); mx[c] = fmaxf(mx[c], __shfl_down(mx[c], off, 64)); }
+  if ((threadIdx.x & 63) == 0) for (int c = 0; c < 3; ++c) { s[threadIdx.x >> 6][c] = mn[c]; s[threadIdx.x >> 6][3 + c] = mx[c]; }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    float v = s[0][threadIdx.x];
+    for (int w = 1; w < 16; ++w) v = threadIdx.x < 3 ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
+    out[threadIdx.x] = v;
+  }
+}
+
+__global__ void kd_choose_dim(KdNode* nodes, const int32_t* counts) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= counts[0]) return;
+  KdNode& nd = nodes[k];
+  // ArgMax of cloud_types.cc:41-56: starts from (index 0, value 0.0), strict ">"
+  double best = 0.0; int dim = 0;
+  for (int c = 0; c < 3; ++c) { const double e = (double)nd.hi[c] - (double)nd.lo[c]; if (e > best) { best = e; dim = c; } }
+  nd.dim = dim;
+  const int right = nd.count / 2;                        // :118
+  nd.left = nd.count - right;
+}
+
+__global__ void kd_keys(const float4* raw, int n, const int32_t* order, const int32_t* seg, const int32_t* node_at,
+                        const KdNode* nodes, unsigned long long* keys) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= n) return;
+  const int st = seg[pos];
+  const int k = node_at[st];
+  uint32_t lowbits;
+  if (k >= 0) {
+    const float4 p = raw[order[pos]];
+    const int dim = nodes[k].dim;
+    lowbits = ordered_bits(dim == 0 ? p.x : (dim == 1 ? p.y : p.z));
+  } else {
+    lowbits = (uint32_t)(pos - st);                       // finished segment: keep its order
+  }
+  keys[pos] = ((unsigned long long)(uint32_t)st << 32) | lowbits;
+}
+
+// children of every active node; leaves are appended to the leaf list
+__global__ void kd_split(const float4* raw, const int32_t* order, const KdNode* nodes, KdNode* next, int32_t* counts,
+                         int32_t* node_at_next, KdLeaf* leaves) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= counts[0]) return;
+  const KdNode nd = nodes[k];
+  const float4 pc = raw[order[nd.start + nd.left]];        // the nth element, :128
+  const float cut = nd.dim == 0 ? pc.x : (nd.dim == 1 ? pc.y : pc.z);
+  KdNode ch[2];
+  ch[0].start = nd.start; ch[0].count = nd.left;
+  ch[1].start = nd.start + nd.left; ch[1].count = nd.count - nd.left;
+  for (int c = 0; c < 3; ++c) { ch[0].lo[c] = nd.lo[c]; ch[0].hi[c] = nd.hi[c]; ch[1].lo[c] = nd.lo[c]; ch[1].hi[c] = nd.hi[c]; }
+  ch[0].hi[nd.dim] = cut;                                  // :132-133
+  ch[1].lo[nd.dim] = cut;                                  // :135-136
+  for (int s = 0; s < 2; ++s) {
+    ch[s].dim = 0; ch[s].left = 0;
+    if (ch[s].count > kLeafMax) {
+      const int slot = atomicAdd(&counts[1], 1);
+      next[slot] = ch[s];
+      node_at_next[ch[s].start] = slot;
+    } else {
+      const int slot = atomicAdd(&counts[2], 1);
+      leaves[slot].start = ch[s].start; leaves[slot].count = ch[s].count;
+      node_at_next[ch[s].start] = -1;
+    }
+  }
+}
+
+__global__ void kd_update_seg(int n, const int32_t* seg, const int32_t* node_at, const KdNode* nodes, int32_t* seg_next) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= n) return;
+  const int st = seg[pos];
+  const int k = node_at[st];
+  int out = st;
+  if (k >= 0 && pos - st >= nodes[k].left) out = st + nodes[k].left;
+  seg_next[pos] = out;
+}
+
+__global__ void kd_advance(int32_t* counts) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { counts[0] = counts[1]; counts[1] = 0; }
+}
+
+__device__ int rank3_sym(const double* C) {
+  double A[9];
+  for (int i = 0; i < 9; ++i) A[i] = C[i];
+  for (int sweep = 0; sweep < 50; ++sweep) {
+    const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 3; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        const double apq = A[3 * p + q];
+        if (fabs(apq) < 1e-300) continue;
+        const double theta = (A[3 * q + q] - A[3 * p + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) { const double akp = A[3 * k + p], akq = A[3 * k + q]; A[3 * k + p] = c * akp - s * akq; A[3 * k + q] = s * akp + c * akq; }
+        for (int k = 0; k < 3; ++k) { const double apk = A[3 * p + k], aqk = A[3 * q + k]; A[3 * p + k] = c * apk - s * aqk; A[3 * q + k] = s * apk + c * aqk; }
+      }
+  }
+  const double w[3] = {fabs(A[0]), fabs(A[4]), fabs(A[8])};
+  const double wmax = fmax(w[0], fmax(w[1], w[2]));
+  int r = 0;
+  for (int i = 0; i < 3; ++i) if (w[i] > 2.220446049250313e-16 * 3 * wmax) ++r;
+  return r;
+}
+
+// one thread per leaf: cloud_types.cc:73-103
+__global__ void kd_leaf_normals(const float4* raw, const int32_t* order, const KdLeaf* leaves, const int32_t* counts,
+                                float4* leaf_p, float4* leaf_n, unsigned long long* leaf_key, int32_t* leaf_id) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= counts[2]) return;
+  const KdLeaf lf = leaves[l];
+  double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+  int kmin = 0x7fffffff;
+  for (int i = 0; i < lf.count; ++i) {
+    const int idx = order[lf.start + i];
+    kmin = min(kmin, idx);
+    const float4 pf = raw[idx];
+    const double p[3] = {pf.x, pf.y, pf.z};
+    for (int a = 0; a < 3; ++a) { b[a] += p[a]; for (int c = 0; c < 3; ++c) M[3 * a + c] += p[a] * p[c]; }
+  }
+  const int n = lf.count;
+  const double mean[3] = {b[0] / n, b[1] / n, b[2] / n};
+  double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < lf.count; ++i) {
+    const float4 pf = raw[order[lf.start + i]];
+    const double e[3] = {pf.x - mean[0], pf.y - mean[1], pf.z - mean[2]};
+    for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) C[3 * a + c] += e[a] * e[c];
+  }
+  leaf_id[l] = l;
+  bool ok = n > 0 && rank3_sym(C) + 1 >= 3;               // :90-92
+  double nv[3] = {0, 0, 0}, nn = 0;
+  if (ok) {
+    const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+    const double invdet = 1.0 / (M[0] * c00 + M[1] * c01 + M[2] * c02);
+    const double inv[9] = {c00 * invdet, (M[2] * M[7] - M[1] * M[8]) * invdet, (M[1] * M[5] - M[2] * M[4]) * invdet,
+                           c01 * invdet, (M[0] * M[8] - M[2] * M[6]) * invdet, (M[2] * M[3] - M[0] * M[5]) * invdet,
+                           c02 * invdet, (M[1] * M[6] - M[0] * M[7]) * invdet, (M[0] * M[4] - M[1] * M[3]) * invdet};
+    for (int a = 0; a < 3; ++a) { nv[a] = inv[3 * a] * b[0] + inv[3 * a + 1] * b[1] + inv[3 * a + 2] * b[2]; nn += nv[a] * nv[a]; }   // :94
+    nn = sqrt(nn);
+    ok = nn > 0.0 && isfinite(nn);                         // singular M: dropped (the reference keeps a NaN normal)
+  }
+  if (ok) {
+    leaf_p[l] = make_float4((float)mean[0], (float)mean[1], (float)mean[2], 0.f);
+    leaf_n[l] = make_float4((float)(nv[0] / nn), (float)(nv[1] / nn), (float)(nv[2] / nn), 0.f);
+    leaf_key[l] = (unsigned long long)(uint32_t)kmin;
+  } else {
+    leaf_key[l] = 0xffffffffffffffffull;
+  }
+}
+
+__global__ void kd_emit(const float4* leaf_p, const float4* leaf_n, const unsigned long long* keys_sorted, const int32_t* ids_sorted,
+                        const int32_t* counts, float4* out_p, float4* out_n, int32_t* m_out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nl = counts[2];
+  if (r >= nl) return;
+  const bool valid = keys_sorted[r] != 0xffffffffffffffffull;
+  if (valid) {
+    const int l = ids_sorted[r];
+    out_p[r] = leaf_p[l];
+    out_n[r] = leaf_n[l];
+    // the number of valid leaves = index of the first invalid key (sorted ascending)
+    if (r + 1 == nl || keys_sorted[r + 1] == 0xffffffffffffffffull) *m_out = r + 1;
+  } else if (r == 0) {
+    *m_out = 0;
+  }
+}
+
+}  // namespace
+
+struct PrepWorkspace {
+  int cap = 0;
+  int32_t *order[2] = {nullptr, nullptr}, *seg[2] = {nullptr, nullptr}, *node_at[2] = {nullptr, nullptr};
+  unsigned long long *keys[2] = {nullptr, nullptr};
+  KdNode* nodes[2] = {nullptr, nullptr};
+  KdLeaf* leaves = nullptr;
+  int32_t* counts = nullptr;
+  float* bbox = nullptr;
+  float4 *leaf_p = nullptr, *leaf_n = nullptr;
+  int32_t *leaf_id[2] = {nullptr, nullptr};
+  void* sort_tmp = nullptr;
+  size_t sort_bytes = 0;
+  int32_t* m_dev = nullptr;
+  int32_t* host_pinned = nullptr;        // [0] = m, [1..3] = counts
+};
+
+PrepWorkspace* prep_create(int max_points) {
+  PrepWorkspace* w = new PrepWorkspace();
+  w->cap = max_points;
+  const size_t N = (size_t)max_points;
+  bool ok = true;
+  auto A = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
+  for (int k = 0; k < 2; ++k) {
+    A((void**)&w->order[k], N * 4); A((void**)&w->seg[k], N * 4); A((void**)&w->node_at[k], N * 4);
+    A((void**)&w->keys[k], N * 8); A((void**)&w->nodes[k], (N / 4 + 16) * sizeof(KdNode)); A((void**)&w->leaf_id[k], (N / 2 + 16) * 4);
+  }
+  A((void**)&w->leaves, (N / 2 + 16) * sizeof(KdLeaf));
+  A((void**)&w->counts, 16 * 4); A((void**)&w->bbox, 8 * 4); A((void**)&w->m_dev, 4);
+  A((void**)&w->leaf_p, (N / 2 + 16) * sizeof(float4)); A((void**)&w->leaf_n, (N / 2 + 16) * sizeof(float4));
+  if (ok) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                    (const int32_t*)nullptr, (int32_t*)nullptr, (unsigned)max_points, 0, 64, (hipStream_t)0);
+    w->sort_bytes = bytes + 256;
+    A(&w->sort_tmp, w->sort_bytes);
+  }
+  if (ok && hipHostMalloc((void**)&w->host_pinned, 64) != hipSuccess) ok = false;
+  if (!ok) { prep_destroy(w); return nullptr; }
+  return w;
+}
+
+void prep_destroy(PrepWorkspace* w) {
+  if (!w) return;
+  for (int k = 0; k < 2; ++k) {
+    (void)hipFree(w->order[k]); (void)hipFree(w->seg[k]); (void)hipFree(w->node_at[k]); (void)hipFree(w->keys[k]);
+    (void)hipFree(w->nodes[k]); (void)hipFree(w->leaf_id[k]);
+  }
+  (void)hipFree(w->leaves); (void)hipFree(w->counts); (void)hipFree(w->bbox); (void)hipFree(w->m_dev);
+  (void)hipFree(w->leaf_p); (void)hipFree(w->leaf_n); (void)hipFree(w->sort_tmp);
+  if (w->host_pinned) (void)hipHostFree(w->host_pinned);
+  delete w;
+}
+
+#define PCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t prep_calculate_normals(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float4* out_p, float4* out_n, int* m_host) {
+  if (!w || n <= 0 || n > w->cap) return hipErrorInvalidValue;
+  const int gp = (n + 255) / 256;
+  hipLaunchKernelGGL(kd_bbox, dim3(1), dim3(1024), 0, st, raw, n, w->bbox);
+  hipLaunchKernelGGL(kd_init, dim3(gp), dim3(256), 0, st, raw, n, w->order[0], w->seg[0], w->node_at[0], w->nodes[0], w->counts, w->bbox, w->leaves);
+  int cur = 0;
+  // depth <= ceil(log2(n / 4)) + 1; the loop runs a fixed number of levels (extra levels are no-ops: zero active nodes)
+  int levels = 1;
+  while (((long long)kLeafMax << levels) < (long long)n * 2) ++levels;
+  levels += 1;
+  for (int lv = 0; lv < levels; ++lv) {
+    const int nxt = cur ^ 1;
+    const int max_nodes = std::min(n / (kLeafMax + 1) + 2, 1 << std::min(lv, 30));
+    const int gn = (max_nodes + 63) / 64;
+    hipLaunchKernelGGL(kd_choose_dim, dim3(gn), dim3(64), 0, st, w->nodes[cur], w->counts);
+    hipLaunchKernelGGL(kd_keys, dim3(gp), dim3(256), 0, st, raw, n, w->order[cur], w->seg[cur], w->node_at[cur], w->nodes[cur], w->keys[0]);
+    size_t bytes = w->sort_bytes;
+    PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[cur], w->order[nxt], (unsigned)n, 0, 64, st));
+    PCHK(hipMemsetAsync(w->node_at[nxt], 0xff, (size_t)n * 4, st));
+    hipLaunchKernelGGL(kd_split, dim3(gn), dim3(64), 0, st, raw, w->order[nxt], w->nodes[cur], w->nodes[nxt], w->counts, w->node_at[nxt], w->leaves);
+    hipLaunchKernelGGL(kd_update_seg, dim3(gp), dim3(256), 0, st, n, w->seg[cur], w->node_at[cur], w->nodes[cur], w->seg[nxt]);
+    hipLaunchKernelGGL(kd_advance, dim3(1), dim3(1), 0, st, w->counts);
+    cur = nxt;
+  }
+  // leaves -> (mean, normal), ordered by the smallest original index of the leaf (cloud_types.cc:358)
+  const int max_leaves = n / 2 + 16;
+  const int gl = (max_leaves + 255) / 256;
+  hipLaunchKernelGGL(kd_leaf_normals, dim3(gl), dim3(256), 0, st, raw, w->order[cur], w->leaves, w->counts, w->leaf_p, w->leaf_n, w->keys[0], w->leaf_id[0]);
+  PCHK(hipMemcpyAsync(w->host_pinned + 1, w->counts, 12, hipMemcpyDeviceToHost, st));
+  PCHK(hipStreamSynchronize(st));
+  const int nl = w->host_pinned[3];
+  if (nl <= 0 || nl > max_leaves) { *m_host = 0; return hipSuccess; }
+  size_t bytes = w->sort_bytes;
+  PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->leaf_id[0], w->leaf_id[1], (unsigned)nl, 0, 64, st));
+  hipLaunchKernelGGL(kd_emit, dim3((nl + 255) / 256), dim3(256), 0, st, w->leaf_p, w->leaf_n, w->keys[1], w->leaf_id[1], w->counts, out_p, out_n, w->m_dev);
+  PCHK(hipMemcpyAsync(w->host_pinned, w->m_dev, 4, hipMemcpyDeviceToHost, st));
+  PCHK(hipStreamSynchronize(st));
+  PCHK(hipGetLastError());
+  *m_host = w->host_pinned[0];
+  return hipSuccess;
+}
+
+}  // namespace smhip

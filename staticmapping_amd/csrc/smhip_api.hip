@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/smhip.h"
+#include "prep_normals.h"
 
 using namespace smhip;
 
@@ -25,6 +26,8 @@ struct smhip_ndt_state;
 
 struct smhip_context {
   smhip_ndt_state* ndt = nullptr;
+  PrepWorkspace* prep = nullptr;          // device CalculateNormals workspace (allocated on first use)
+  float4* prep_raw = nullptr;             // raw scan staging on the device
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -447,6 +450,7 @@ smhip_status smhip_destroy(smhip_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   smhip_internal_free_ndt(h);
+  if (h->prep) prep_destroy(h->prep);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->stage) (void)hipHostFree(h->stage);
   if (h->in_pinned) (void)hipHostFree(h->in_pinned);
@@ -566,6 +570,74 @@ smhip_status smhip_set_target_f32(smhip_handle h, int slot, const float* xyz, in
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->nt[slot] = n;
   h->has_normals[slot] = nrm != nullptr;
+  return SMHIP_OK;
+}
+
+static smhip_status prep_ensure(smhip_handle h) {
+  if (h->prep) return SMHIP_OK;
+  const int cap = std::max(h->dev.ns_cap, h->dev.nt_cap);
+  h->prep = prep_create(cap);
+  if (!h->prep) { h->err = "device CalculateNormals workspace allocation failed"; return SMHIP_ERR_HIP; }
+  return dev_alloc(h, &h->prep_raw, (size_t)cap);
+}
+
+static smhip_status prep_run(smhip_handle h, const float4* raw_dev, int n, int slot, int* n_out) {
+  // the leaf count is only known afterwards: run into the scratch halves of the staging-sized device buffer
+  // when the slot's arrays could overflow, i.e. require nt_cap >= n / 4 + 8 (every leaf holds >= 4 points)
+  if (h->dev.nt_cap < n / 4 + 8) { h->err = "max_target_points too small for the prepared target (need n / 4 + 8)"; return SMHIP_ERR_CAPACITY; }
+  int m = 0;
+  const hipError_t e = prep_calculate_normals(h->prep, h->stream, raw_dev, n,
+                                              const_cast<float4*>(h->dev.tgt_p) + (size_t)slot * h->dev.nt_cap,
+                                              const_cast<float4*>(h->dev.tgt_n) + (size_t)slot * h->dev.nt_cap, &m);
+  if (e != hipSuccess) { h->err = std::string("prep_calculate_normals: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
+  if (m <= 0) { h->err = "CalculateNormals produced no target points"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  h->nt[slot] = m;
+  h->has_normals[slot] = 1;
+  if (n_out) *n_out = m;
+  return SMHIP_OK;
+}
+
+smhip_status smhip_prepare_target_f32(smhip_handle h, int slot, const float* xyz, int stride, int n, int* n_out) {
+  smhip_status s = check_slot(h, slot);
+  if (s) return s;
+  if (!xyz || n <= 0 || stride < 3) { h->err = "empty cloud / bad stride"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  if (n > std::max(h->dev.ns_cap, h->dev.nt_cap)) { h->err = "scan larger than the handle's capacity"; return SMHIP_ERR_CAPACITY; }
+  HIPCHK(h, hipSetDevice(h->device));
+  s = prep_ensure(h);
+  if (s) return s;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < n; ++i) h->stage[i] = make_float4(xyz[(size_t)stride * i], xyz[(size_t)stride * i + 1], xyz[(size_t)stride * i + 2], 0.f);
+  HIPCHK(h, hipMemcpyAsync(h->prep_raw, h->stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  return prep_run(h, h->prep_raw, n, slot, n_out);
+}
+
+smhip_status smhip_prepare_target_from_source(smhip_handle h, int from, int to, int* n_out) {
+  smhip_status s = check_slot(h, from);
+  if (s) return s;
+  s = check_slot(h, to);
+  if (s) return s;
+  if (h->ns[from] <= 0) { h->err = "source slot is empty"; return SMHIP_ERR_NOT_READY; }
+  HIPCHK(h, hipSetDevice(h->device));
+  s = prep_ensure(h);
+  if (s) return s;
+  return prep_run(h, h->dev.src + (size_t)from * h->dev.ns_cap, h->ns[from], to, n_out);
+}
+
+smhip_status smhip_get_target_f32(smhip_handle h, int slot, float* xyz, float* normals, int n) {
+  smhip_status s = check_slot(h, slot);
+  if (s) return s;
+  if (n != h->nt[slot] || n <= 0) { h->err = "n must equal the slot's target size"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  float4* sp = h->stage;
+  float4* sn = h->stage + std::max(h->dev.ns_cap, h->dev.nt_cap);
+  HIPCHK(h, hipMemcpyAsync(sp, h->dev.tgt_p + (size_t)slot * h->dev.nt_cap, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(sn, h->dev.tgt_n + (size_t)slot * h->dev.nt_cap, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < n; ++i) {
+    if (xyz) { xyz[3 * i] = sp[i].x; xyz[3 * i + 1] = sp[i].y; xyz[3 * i + 2] = sp[i].z; }
+    if (normals) { normals[3 * i] = sn[i].x; normals[3 * i + 1] = sn[i].y; normals[3 * i + 2] = sn[i].z; }
+  }
   return SMHIP_OK;
 }
 

@@ -114,6 +114,23 @@ class IcpFastHip:
             self._h, slot, p.ctypes.data_as(_capi.c_double_p),
             n.ctypes.data_as(_capi.c_double_p) if n is not None else None, p.shape[0]))
 
+    def prepare_target(self, scan, slot: int = 0) -> int:
+        """Upload a raw float32 scan [N,3+] and run CalculateNormals on the GPU; returns the target size."""
+        a = np.ascontiguousarray(np.asarray(scan, dtype=np.float32))
+        m = ctypes.c_int32()
+        self._check(self._lib.smhip_prepare_target_f32(self._h, slot, a.ctypes.data_as(_capi.c_float_p), a.shape[1], a.shape[0], ctypes.byref(m)))
+        return m.value
+
+    def prepare_target_from_source(self, from_slot: int, to_slot: int) -> int:
+        m = ctypes.c_int32()
+        self._check(self._lib.smhip_prepare_target_from_source(self._h, from_slot, to_slot, ctypes.byref(m)))
+        return m.value
+
+    def get_target(self, n: int, slot: int = 0):
+        p = np.zeros((n, 3), np.float32); nr = np.zeros((n, 3), np.float32)
+        self._check(self._lib.smhip_get_target_f32(self._h, slot, p.ctypes.data_as(_capi.c_float_p), nr.ctypes.data_as(_capi.c_float_p), n))
+        return p, nr
+
     def copy_slot(self, src_slot: int, dst_slot: int):
         self._check(self._lib.smhip_copy_slot(self._h, src_slot, dst_slot))
 

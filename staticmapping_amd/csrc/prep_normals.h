@@ -10,4 +10,6 @@ void prep_destroy(PrepWorkspace* w);
 // Blocks until *m_host (number of surviving points) is known.
 hipError_t prep_calculate_normals(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float4* out_p,
                                   float4* out_n, int* m_host);
+// Morton-order `raw` into `out` (out[k].w = index of the point in `raw`); asynchronous on `st`.
+hipError_t prep_morton_sort(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float4* out);
 }  // namespace smhip

@@ -294,6 +294,72 @@ void prep_destroy(PrepWorkspace* w) {
 
 #define PCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
 
+namespace {
+__device__ __forceinline__ unsigned long long spread21(unsigned long long v) {
+  v &= 0x1fffffull;
+  v = (v | (v << 32)) & 0x1f00000000ffffull;
+  v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+  v = (v | (v << 8)) & 0x100f00f00f00f00full;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+__global__ void morton_keys(const float4* raw, int n, const float* bbox, unsigned long long* keys, int32_t* idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = raw[i];
+  const float inv = 1.0f / 0.0625f;                       // 6.25 cm quantum
+  unsigned long long q[3];
+  const float v[3] = {p.x, p.y, p.z};
+  for (int c = 0; c < 3; ++c) {
+    const float t = (v[c] - bbox[c]) * inv;
+    q[c] = (isfinite(t)) ? (unsigned long long)fminf(fmaxf(t, 0.f), 2097151.f) : 0ull;
+  }
+  keys[i] = spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2);
+  idx[i] = i;
+}
+__global__ void morton_gather(const float4* raw, const int32_t* idx, int n, float4* out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int i = idx[k];
+  float4 p = raw[i];
+  p.w = __int_as_float(i);                                // the caller's index rides along
+  out[k] = p;
+}
+// bbox over finite coordinates only (NaN points must not poison the quantisation origin)
+__global__ __launch_bounds__(1024) void finite_min(const float4* raw, int n, float* out) {
+  float mn[3] = {INFINITY, INFINITY, INFINITY};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float4 p = raw[i];
+    if (isfinite(p.x)) mn[0] = fminf(mn[0], p.x);
+    if (isfinite(p.y)) mn[1] = fminf(mn[1], p.y);
+    if (isfinite(p.z)) mn[2] = fminf(mn[2], p.z);
+  }
+  __shared__ float s[16][3];
+  for (int c = 0; c < 3; ++c)
+    for (int off = 32; off > 0; off >>= 1) mn[c] = fminf(mn[c], __shfl_down(mn[c], off, 64));
+  if ((threadIdx.x & 63) == 0) for (int c = 0; c < 3; ++c) s[threadIdx.x >> 6][c] = mn[c];
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float v = s[0][threadIdx.x];
+    for (int w = 1; w < 16; ++w) v = fminf(v, s[w][threadIdx.x]);
+    out[threadIdx.x] = isfinite(v) ? v : 0.f;
+  }
+}
+}  // namespace
+
+// Morton (Z-order) permutation of a cloud on the device: out[k] = raw[perm[k]], w = perm[k].
+hipError_t prep_morton_sort(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float4* out) {
+  if (!w || n <= 0 || n > w->cap) return hipErrorInvalidValue;
+  const int gp = (n + 255) / 256;
+  hipLaunchKernelGGL(finite_min, dim3(1), dim3(1024), 0, st, raw, n, w->bbox);
+  hipLaunchKernelGGL(morton_keys, dim3(gp), dim3(256), 0, st, raw, n, w->bbox, w->keys[0], w->order[0]);
+  size_t bytes = w->sort_bytes;
+  PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[0], w->order[1], (unsigned)n, 0, 63, st));
+  hipLaunchKernelGGL(morton_gather, dim3(gp), dim3(256), 0, st, raw, w->order[1], n, out);
+  return hipGetLastError();
+}
+
 hipError_t prep_calculate_normals(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float4* out_p, float4* out_n, int* m_host) {
   if (!w || n <= 0 || n > w->cap) return hipErrorInvalidValue;
   const int gp = (n + 255) / 256;

@@ -44,8 +44,6 @@ struct smhip_context {
   float* d2_pinned = nullptr;
   int32_t* ids_dev = nullptr;    // scratch for exported matches
   float* d2_dev = nullptr;
-  std::vector<uint64_t> mkeys, mkeys2;   // Morton sort scratch
-  std::vector<int32_t> morder, morder2;
   std::vector<void*> allocs;
   std::string err;
   int last_npairs = 0;
@@ -215,55 +213,6 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
     hipLaunchKernelGGL(nn_brute, g, dim3(kNnThreads), 0, st, d);
   }
   return SMHIP_OK;
-}
-
-// Morton (Z-order) permutation of a staged cloud: consecutive points end up spatially close, which
-// is what makes the 64 queries of a wavefront share their candidate set in nn_tile.
-inline uint64_t spread21(uint64_t v) {
-  v &= 0x1fffffull;
-  v = (v | (v << 32)) & 0x1f00000000ffffull;
-  v = (v | (v << 16)) & 0x1f0000ff0000ffull;
-  v = (v | (v << 8)) & 0x100f00f00f00f00full;
-  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
-  v = (v | (v << 2)) & 0x1249249249249249ull;
-  return v;
-}
-
-void morton_permute(smhip_context* h, float4* pts, int n) {
-  float mn[3] = {INFINITY, INFINITY, INFINITY};
-  for (int i = 0; i < n; ++i) {
-    if (std::isfinite(pts[i].x)) mn[0] = std::min(mn[0], pts[i].x);
-    if (std::isfinite(pts[i].y)) mn[1] = std::min(mn[1], pts[i].y);
-    if (std::isfinite(pts[i].z)) mn[2] = std::min(mn[2], pts[i].z);
-  }
-  const float inv = 1.0f / 0.0625f;     // 6.25 cm quantum
-  auto quant = [&](float v, float lo) -> uint64_t {
-    if (!std::isfinite(v) || !std::isfinite(lo)) return 0;
-    const float q = (v - lo) * inv;
-    return (uint64_t)std::min(std::max(q, 0.0f), 2097151.0f);
-  };
-  h->mkeys.resize(n); h->mkeys2.resize(n); h->morder.resize(n); h->morder2.resize(n);
-  for (int i = 0; i < n; ++i) {
-    h->mkeys[i] = spread21(quant(pts[i].x, mn[0])) | (spread21(quant(pts[i].y, mn[1])) << 1) | (spread21(quant(pts[i].z, mn[2])) << 2);
-    h->morder[i] = i;
-  }
-  // LSD radix sort, 4 passes of 16 bits (63-bit keys)
-  std::vector<uint32_t> cnt(65536);
-  uint64_t* ka = h->mkeys.data(); uint64_t* kb = h->mkeys2.data();
-  int32_t* oa = h->morder.data(); int32_t* ob = h->morder2.data();
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 16 * pass;
-    std::fill(cnt.begin(), cnt.end(), 0u);
-    for (int i = 0; i < n; ++i) cnt[(ka[i] >> shift) & 0xffff]++;
-    uint32_t run = 0;
-    for (auto& c : cnt) { const uint32_t t = c; c = run; run += t; }
-    for (int i = 0; i < n; ++i) { const uint32_t p = cnt[(ka[i] >> shift) & 0xffff]++; kb[p] = ka[i]; ob[p] = oa[i]; }
-    std::swap(ka, kb); std::swap(oa, ob);
-  }
-  // apply (after 4 passes the result is back in mkeys/morder); w keeps the caller's index
-  float4* tmp = pts + n;                 // second half of the staging buffer
-  for (int i = 0; i < n; ++i) { tmp[i] = pts[oa[i]]; tmp[i].w = __builtin_bit_cast(float, (int32_t)oa[i]); }
-  std::memcpy(pts, tmp, sizeof(float4) * (size_t)n);
 }
 
 smhip_status fill_inputs(smhip_context* h, int np, const double* guesses, int* ns_max, int* nt_max) {
@@ -490,6 +439,20 @@ smhip_status smhip_synchronize(smhip_handle h) {
 }
 
 // ---- uploads ---------------------------------------------------------------------------
+static smhip_status prep_ensure(smhip_handle h);
+
+// staged source -> device, Morton-ordered there (spatially coherent wavefronts; w = caller index)
+static smhip_status upload_source(smhip_handle h, int slot, int n) {
+  smhip_status s = prep_ensure(h);
+  if (s) return s;
+  HIPCHK(h, hipMemcpyAsync(h->prep_raw, h->stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  const hipError_t e = prep_morton_sort(h->prep, h->stream, h->prep_raw, n, const_cast<float4*>(h->dev.src) + (size_t)slot * h->dev.ns_cap);
+  if (e != hipSuccess) { h->err = std::string("prep_morton_sort: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->ns[slot] = n;
+  return SMHIP_OK;
+}
+
 static smhip_status upload(smhip_handle h, const float4* dst_dev, const float4* staged, int n) {
   HIPCHK(h, hipMemcpyAsync(const_cast<float4*>(dst_dev), staged, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, h->stream));
   return SMHIP_OK;
@@ -503,12 +466,7 @@ smhip_status smhip_set_source_f64(smhip_handle h, int slot, const double* xyz, i
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));   // staging buffer reuse
   for (int i = 0; i < n; ++i) h->stage[i] = make_float4((float)xyz[3 * i], (float)xyz[3 * i + 1], (float)xyz[3 * i + 2], 0.f);
-  morton_permute(h, h->stage, n);
-  s = upload(h, h->dev.src + (size_t)slot * h->dev.ns_cap, h->stage, n);
-  if (s) return s;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->ns[slot] = n;
-  return SMHIP_OK;
+  return upload_source(h, slot, n);
 }
 
 smhip_status smhip_set_source_f32(smhip_handle h, int slot, const float* xyz, int stride, int n) {
@@ -518,13 +476,9 @@ smhip_status smhip_set_source_f32(smhip_handle h, int slot, const float* xyz, in
   if (n > h->dev.ns_cap) { h->err = "source larger than max_source_points"; return SMHIP_ERR_CAPACITY; }
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  for (int i = 0; i < n; ++i) h->stage[i] = make_float4(xyz[(size_t)stride * i], xyz[(size_t)stride * i + 1], xyz[(size_t)stride * i + 2], 0.f);
-  morton_permute(h, h->stage, n);
-  s = upload(h, h->dev.src + (size_t)slot * h->dev.ns_cap, h->stage, n);
-  if (s) return s;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->ns[slot] = n;
-  return SMHIP_OK;
+  if (stride == 4) std::memcpy(h->stage, xyz, sizeof(float4) * (size_t)n);      // KITTI rows are already float4 (w is overwritten on the device)
+  else for (int i = 0; i < n; ++i) h->stage[i] = make_float4(xyz[(size_t)stride * i], xyz[(size_t)stride * i + 1], xyz[(size_t)stride * i + 2], 0.f);
+  return upload_source(h, slot, n);
 }
 
 smhip_status smhip_set_target_f64(smhip_handle h, int slot, const double* xyz, const double* nrm, int n) {
@@ -606,7 +560,8 @@ smhip_status smhip_prepare_target_f32(smhip_handle h, int slot, const float* xyz
   s = prep_ensure(h);
   if (s) return s;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  for (int i = 0; i < n; ++i) h->stage[i] = make_float4(xyz[(size_t)stride * i], xyz[(size_t)stride * i + 1], xyz[(size_t)stride * i + 2], 0.f);
+  if (stride == 4) std::memcpy(h->stage, xyz, sizeof(float4) * (size_t)n);
+  else for (int i = 0; i < n; ++i) h->stage[i] = make_float4(xyz[(size_t)stride * i], xyz[(size_t)stride * i + 1], xyz[(size_t)stride * i + 2], 0.f);
   HIPCHK(h, hipMemcpyAsync(h->prep_raw, h->stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, h->stream));
   return prep_run(h, h->prep_raw, n, slot, n_out);
 }

@@ -146,12 +146,14 @@ def angle_derivatives(p):
     return j, h
 
 
-def compute_derivatives(grid: VoxelGrid, src_f32, trans_f32, p, d1, d2, compute_hessian=True):
-    """ndt_omp_impl.hpp:180-284 + 397-438 + 483-535.  Returns (score, gradient[6], hessian[6,6], n_pairs)."""
+def compute_derivatives(grid: VoxelGrid, src_f32, trans_f32, p, d1, d2, compute_hessian=True, pairs=None):
+    """ndt_omp_impl.hpp:180-284 + 397-438 + 483-535.  Returns (score, gradient[6], hessian[6,6], n_pairs).
+    `pairs` = (point idx, voxel idx) freezes the neighbourhoods (tests only: the score itself jumps
+    whenever a point crosses a radius-search boundary, so finite differences need a fixed set)."""
     x = np.asarray(src_f32, dtype=F)[:, :3]
     xt = np.asarray(trans_f32, dtype=F)[:, :3]
     j_ang, h_ang = angle_derivatives(p)
-    pi, vi = grid.radius_pairs(xt)
+    pi, vi = grid.radius_pairs(xt) if pairs is None else pairs
     g = np.zeros(6)
     H = np.zeros((6, 6))
     if len(pi) == 0:

@@ -370,6 +370,8 @@ hipError_t prep_calculate_normals(PrepWorkspace* w, hipStream_t st, const float4
   int levels = 1;
   while (((long long)kLeafMax << levels) < (long long)n * 2) ++levels;
   levels += 1;
+  int seg_bits = 1;
+  while ((1ll << seg_bits) < (long long)n) ++seg_bits;
   for (int lv = 0; lv < levels; ++lv) {
     const int nxt = cur ^ 1;
     const int max_nodes = std::min(n / (kLeafMax + 1) + 2, 1 << std::min(lv, 30));
@@ -377,7 +379,8 @@ hipError_t prep_calculate_normals(PrepWorkspace* w, hipStream_t st, const float4
     hipLaunchKernelGGL(kd_choose_dim, dim3(gn), dim3(64), 0, st, w->nodes[cur], w->counts);
     hipLaunchKernelGGL(kd_keys, dim3(gp), dim3(256), 0, st, raw, n, w->order[cur], w->seg[cur], w->node_at[cur], w->nodes[cur], w->keys[0]);
     size_t bytes = w->sort_bytes;
-    PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[cur], w->order[nxt], (unsigned)n, 0, 64, st));
+    // key = segment start (needs `seg_bits` bits) << 32 | coordinate bits
+    PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[cur], w->order[nxt], (unsigned)n, 0, 32 + seg_bits, st));
     PCHK(hipMemsetAsync(w->node_at[nxt], 0xff, (size_t)n * 4, st));
     hipLaunchKernelGGL(kd_split, dim3(gn), dim3(64), 0, st, raw, w->order[nxt], w->nodes[cur], w->nodes[nxt], w->counts, w->node_at[nxt], w->leaves);
     hipLaunchKernelGGL(kd_update_seg, dim3(gp), dim3(256), 0, st, n, w->seg[cur], w->node_at[cur], w->nodes[cur], w->seg[nxt]);

@@ -62,10 +62,11 @@ def scan_to_scan_sequence(scans, matcher, batch: int, guesses=None, rank: int = 
 
     scans: list of float32 [N,4] arrays (or callables returning one, for lazy loading);
     matcher: an IcpFastHip with at least `batch` pair slots;  guesses: optional [n_pairs,4,4].
+    Target preparation (CalculateNormals, builder/map_builder.cc:286,389) runs on the GPU; when the
+    previous pair of the chunk already uploaded scan i as its source, that resident copy is re-used.
+    `prepare_target`: optional host callable scan -> (points, normals) to override that.
     Returns (pair_indices, transforms [k,4,4], scores [k], iterations [k]) for this rank's pairs.
     """
-    from .matcher import calculate_normals
-    prepare_target = prepare_target or (lambda s: calculate_normals(s[:, :3].astype(np.float64)))
     n_pairs = len(scans) - 1
     mine = shard.pairs_of_rank(n_pairs, rank, world)
     get = lambda i: scans[i]() if callable(scans[i]) else scans[i]
@@ -74,8 +75,13 @@ def scan_to_scan_sequence(scans, matcher, batch: int, guesses=None, rank: int = 
         chunk = mine[b0:b0 + batch]
         g = []
         for s, pair in enumerate(chunk):
-            q, n = prepare_target(get(pair))
-            matcher.set_input_target(q, n, slot=s)
+            if prepare_target is not None:
+                q, n = prepare_target(get(pair))
+                matcher.set_input_target(q, n, slot=s)
+            elif s > 0 and chunk[s - 1] == pair - 1:
+                matcher.prepare_target_from_source(s - 1, s)      # scan `pair` is the previous slot's source
+            else:
+                matcher.prepare_target(get(pair), slot=s)
             matcher.set_input_source(get(pair + 1), slot=s)
             g.append(np.eye(4) if guesses is None else guesses[pair])
         T, sc, st = matcher.align_batch(len(chunk), g)

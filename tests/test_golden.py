@@ -1,0 +1,84 @@
+"""Committed fixtures (tests/golden/*.json, made by tests/golden/make_golden.py from the numpy oracle):
+the C restatement, the numpy restatement and -- on the GPU box -- the HIP path must reproduce them."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _icp_inputs():
+    from staticmapping_amd import synth
+    from oracle import icp_fast as o
+    tgt, src, T = synth.three_planes_pair(2000, seed=11, sigma=0.01)
+    q, n, _ = o.calculate_normals(tgt[:, :3].astype(np.float64))
+    return src, q, n
+
+
+def _ndt_inputs():
+    from staticmapping_amd import synth
+    scene = synth.make_scene(0)
+    poses = [synth.make_pose(t=(0.8 * k, 0.0, 0.0)) for k in range(3)]
+    scans = [synth.velodyne_scan(scene, P, seed=20 + k, n_points=8000) for k, P in enumerate(poses)]
+    tgt = np.concatenate([s[:, :3].astype(np.float64) @ P[:3, :3].T + P[:3, 3] for s, P in zip(scans[:2], poses[:2])]).astype(np.float32)
+    G = poses[2].copy(); G[0, 3] -= 0.25
+    return scans[2], tgt, G
+
+
+def test_icp_golden_numpy_and_c():
+    from oracle import icp_fast as o, cref
+    g = json.load(open(os.path.join(HERE, "golden", "icp_three_planes_2000.json")))
+    src, q, n = _icp_inputs()
+    assert len(q) == g["target_points"]
+    trace = []
+    R, score, it = o.icp_fast_align(src[:, :3].astype(np.float64), q, n, trace=trace)
+    assert it == g["iterations"] and abs(score - g["score"]) < 1e-12
+    assert np.allclose(R, np.array(g["result"]), atol=1e-10)
+    assert trace[0]["limit"] == pytest.approx(g["first_limit_d2"], rel=1e-12)
+    assert int(trace[0]["keep"].sum()) == g["first_kept"]
+    r = cref.icp_fast_align(src[:, :3].astype(np.float64), q, n)
+    assert r["iterations"] == g["iterations"]
+    assert np.allclose(r["result"], np.array(g["result"]), atol=1e-9)
+
+
+def test_ndt_golden_numpy():
+    from oracle import ndt as ondt
+    g = json.load(open(os.path.join(HERE, "golden", "ndt_two_scans_8000.json")))
+    src, tgt, G = _ndt_inputs()
+    r = ondt.ndt_align(src, tgt, guess=G)
+    assert r["iterations"] == g["iterations"] and r["derivative_calls"] == g["derivative_calls"]
+    assert np.allclose(r["result"], np.array(g["result"]), atol=1e-6)
+    assert abs(r["score"] - g["score"]) <= 1e-6 * g["score"]
+
+
+@pytest.mark.gpu
+def test_icp_golden_gpu():
+    import staticmapping_amd as sm
+    g = json.load(open(os.path.join(HERE, "golden", "icp_three_planes_2000.json")))
+    src, q, n = _icp_inputs()
+    m = sm.IcpFastHip(max_source_points=4096, max_target_points=4096)
+    m.set_input_source(src); m.set_input_target(q, n)
+    ok, R = m.align()
+    da, dt = sm.se3_error(R, np.array(g["result"]))
+    assert da < 1e-4 and dt < 1e-3
+    assert m.last_stats[0]["iterations"] == g["iterations"]
+    assert abs(m.get_fitness_score() - g["score"]) < 1e-4
+    m.close()
+
+
+@pytest.mark.gpu
+def test_ndt_golden_gpu():
+    import staticmapping_amd as sm
+    g = json.load(open(os.path.join(HERE, "golden", "ndt_two_scans_8000.json")))
+    src, tgt, G = _ndt_inputs()
+    tgt4 = np.concatenate([tgt, np.zeros((len(tgt), 1), np.float32)], axis=1)
+    m = sm.NdtHip(max_source_points=len(src), max_target_points=len(tgt4))
+    m.set_input_source(src); m.set_input_target(tgt4)
+    ok, R = m.align(G)
+    da, dt = sm.se3_error(R, np.array(g["result"]))
+    assert da < 1e-4 and dt < 1e-3
+    assert m.last_ndt_stats["iterations"] == g["iterations"]
+    assert abs(m.get_fitness_score() - g["score"]) <= 1e-3 * g["score"]
+    m.close()

@@ -72,8 +72,8 @@ typedef struct smhip_icp_options {
                                    the transform / score are identical either way, only rejected matches differ) */
   float ball_radius;            /* largest search radius of the ball search in metres (default 0.5) */
   float ball_cap_factor;        /* next iteration's search-radius cap = factor x this iteration's quantile distance (default 1.5) */
-  int32_t two_pass;             /* repurposed as "no_certify": 1 = search every query in every iteration instead of running the
-                                   nearest-neighbour certificate pass first (default 0 = certificates on) */
+  int32_t no_certify;           /* 1 = search every query in every iteration instead of first trying the nearest-neighbour
+                                   certificate (runner-up bound minus the query's motion); default 0 = certificates on */
   int32_t no_lds_table;         /* 1: voxel lookups from global memory (nn_ball) instead of LDS row tables (nn_ball_lds) */
   int32_t no_overlap;           /* 1: keep a batch on one stream (default 0: batches of >= 16 pairs are split over two
                                    streams so one half's latency-bound launches hide behind the other half's NN) */

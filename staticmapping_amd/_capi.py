@@ -16,7 +16,7 @@ class IcpOptions(ctypes.Structure):
                 ("early_exit", ctypes.c_int32), ("nn_mode", ctypes.c_int32), ("grid_cell", ctypes.c_float),
                 ("grid_max_ring", ctypes.c_int32), ("check_every", ctypes.c_int32),
                 ("use_ball", ctypes.c_int32), ("exact_matches", ctypes.c_int32), ("ball_radius", ctypes.c_float),
-                ("ball_cap_factor", ctypes.c_float), ("two_pass", ctypes.c_int32), ("no_lds_table", ctypes.c_int32),
+                ("ball_cap_factor", ctypes.c_float), ("no_certify", ctypes.c_int32), ("no_lds_table", ctypes.c_int32),
                 ("no_overlap", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1)]
 
 

@@ -1235,7 +1235,7 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
 #pragma unroll
   for (int c = 0; c < 29; ++c) acc[c] = 0.0;
   const size_t so = (size_t)pair * b.ns_cap;
-#pragma unroll 1
+#pragma unroll 2
   for (int it = 0; it < kAccItems; ++it) {
     const int i = base + it * kAccThreads + threadIdx.x;
     if (i < ns) {

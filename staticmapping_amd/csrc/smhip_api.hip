@@ -238,9 +238,8 @@ void sync_options(smhip_context* h) {
   h->dev.grid_cell = h->opts.grid_cell > 0 ? h->opts.grid_cell : 0.5f;
   h->dev.use_ball = h->opts.use_ball;
   h->dev.sort_cells = 1;
-  h->dev.certify = h->opts.two_pass ? 0 : 1;
+  h->dev.certify = h->opts.no_certify ? 0 : 1;
   h->dev.lds_table = h->opts.no_lds_table ? 0 : 1;
-  { const char* a = std::getenv("SMHIP_ABLATE"); h->dev.ablate = a ? std::atoi(a) : 0; }
   h->dev.cap_factor = h->opts.ball_cap_factor > 1.0f ? h->opts.ball_cap_factor : 1.5f;
   h->dev.exact_all = h->opts.exact_matches;
   h->dev.ball_radius = h->opts.ball_radius > 0 ? h->opts.ball_radius : 0.5f;
@@ -313,7 +312,7 @@ void smhip_icp_default_options(smhip_icp_options* o) {
   o->exact_matches = 0;
   o->ball_radius = 0.5f;
   o->ball_cap_factor = 1.5f;
-  o->two_pass = 0;
+  o->no_certify = 0;
 }
 
 smhip_status smhip_create(int device, void* stream, int pair_slots, int max_source_points, int max_target_points,

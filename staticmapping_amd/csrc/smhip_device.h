@@ -118,7 +118,6 @@ struct IcpDev {
   int32_t use_ball;          // 1 = ball-bounded search with certified trimming; 0 = ring search over every query
   int32_t lds_table;         // 1 = nn_ball_lds (row tables staged in LDS), 0 = nn_ball (global lookups)
   int32_t certify;           // 1 = iterations >= 1 run nn_certify and search only the queries whose certificate fails
-  int32_t ablate;            // development only (env SMHIP_ABLATE)
   int32_t exact_all;         // 1 = every match exact (no lower bounds survive), e.g. find_closests
   float ball_radius;         // largest search radius of nn_ball (first iteration / clamp)
   float cap_factor;          // next cap = cap_factor x quantile distance

@@ -30,7 +30,7 @@ NN_VARIANTS = {
     "ball": dict(nn_mode=1, use_ball=1),                    # ball search + certified trimming (default)
     "ball_exact": dict(nn_mode=1, use_ball=1, exact_matches=1),
     "ball_global": dict(nn_mode=1, use_ball=1, no_lds_table=1),      # voxel lookups from global memory
-    "ball_nocert": dict(nn_mode=1, use_ball=1, two_pass=1),          # search every query in every iteration
+    "ball_nocert": dict(nn_mode=1, use_ball=1, no_certify=1),          # search every query in every iteration
     "ball_small": dict(nn_mode=1, use_ball=1, ball_radius=0.1, grid_cell=0.5),   # validation fails early on -> refinement path
     "ring": dict(nn_mode=1, use_ball=0),                    # per-query ring search only
     "ring_small": dict(nn_mode=1, use_ball=0, grid_max_ring=1),   # most queries through the brute fallback

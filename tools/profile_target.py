@@ -11,7 +11,7 @@ a, b, T = synth.scan_pair("cfg2", n_points=n_points)
 q, n = sm.calculate_normals(a[:, :3].astype(np.float64))
 guess = synth.make_pose(t=(0.6, 0, 0))
 m = sm.IcpFastHip(pair_slots=B, max_source_points=len(b), max_target_points=len(q), max_iteration=20, early_exit=0,
-                  nn_mode=mode, grid_cell=cell, grid_max_ring=ring, no_overlap=noov, two_pass=nocert)
+                  nn_mode=mode, grid_cell=cell, grid_max_ring=ring, no_overlap=noov, no_certify=nocert)
 m.set_input_source(b); m.set_input_target(q, n)
 for s in range(1, B): m.copy_slot(0, s)
 for _ in range(reps): R, sc, st = m.align_batch(B, [guess] * B)

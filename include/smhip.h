@@ -176,6 +176,9 @@ smhip_status smhip_calculate_normals_f64(const double* xyz_colmajor_3xN, int n, 
  * target of pair i, uploaded once). */
 smhip_status smhip_prepare_target_f32(smhip_handle h, int slot, const float* xyz, int stride_floats, int n, int* n_out);
 smhip_status smhip_prepare_target_from_source(smhip_handle h, int from_slot, int to_slot, int* n_out);
+/* Batched form: count targets in ONE pass (one kd forest, one sort per tree level for all scans);
+ * target of to_slots[k] = CalculateNormals(source cloud of from_slots[k]); n_out[k] = its size. */
+smhip_status smhip_prepare_targets_from_sources(smhip_handle h, int count, const int* from_slots, const int* to_slots, int* n_out);
 
 /* ---- introspection for parity tests ------------------------------------
  * Matches of the LAST executed iteration of `slot` (FindClosests output, icp_fast.cc:169-180):

@@ -74,6 +74,7 @@ SIGNATURES = {
     "smhip_calculate_normals_f64": (ctypes.c_int, [c_double_p, ctypes.c_int, c_double_p, c_double_p, c_int32_p]),
     "smhip_prepare_target_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int, c_int32_p]),
     "smhip_prepare_target_from_source": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_int32_p]),
+    "smhip_prepare_targets_from_sources": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int32_p, c_int32_p, c_int32_p]),
     "smhip_get_target_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_float_p, c_float_p, ctypes.c_int]),
     "smhip_icp_get_matches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int32_p, c_float_p, ctypes.c_int]),
     "smhip_icp_find_closests": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_int32_p, c_float_p,

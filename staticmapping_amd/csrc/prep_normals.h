@@ -10,6 +10,11 @@ void prep_destroy(PrepWorkspace* w);
 // Blocks until *m_host (number of surviving points) is known.
 hipError_t prep_calculate_normals(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float4* out_p,
                                   float4* out_n, int* m_host);
+// The same for S scans in one pass (one forest, one sort per tree level for all of them): scan s =
+// raw[offset[s] .. offset[s] + n[s]), written to out_p / out_n at out_offset[s]; m_host[s] survivors.
+// The workspace must hold sum(n) points.
+hipError_t prep_calculate_normals_batch(PrepWorkspace* w, hipStream_t st, const float4* raw, int S, const int* offset,
+                                        const int* n, const int* out_offset, float4* out_p, float4* out_n, int* m_host);
 // Morton-order `raw` into `out` (out[k].w = index of the point in `raw`); asynchronous on `st`.
 hipError_t prep_morton_sort(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float4* out);
 }  // namespace smhip

@@ -28,6 +28,7 @@ namespace smhip {
 namespace {
 
 constexpr int kLeafMax = 7;              // kNormalEstimationKnn, cloud_types.cc:38
+constexpr int kMaxScans = 512;           // scans one batched CalculateNormals call may hold
 
 struct KdNode {
   int32_t start, count;
@@ -43,28 +44,26 @@ __device__ __forceinline__ uint32_t ordered_bits(float f) {
 
 struct KdLeaf { int32_t start, count; };   // a node that will not be split further
 
-__global__ void kd_init(const float4* raw, int n, int32_t* order, int32_t* seg, int32_t* node_at, KdNode* nodes, int32_t* counts,
-                        float* bbox_part, KdLeaf* leaves) {
-  // order = identity, one root segment; bbox from the partials computed by kd_bbox
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { order[i] = i; seg[i] = 0; node_at[i] = -1; }
-  if (i == 0) {
-    KdNode r;
-    r.start = 0; r.count = n; r.dim = 0; r.left = 0;
-    for (int c = 0; c < 3; ++c) { r.lo[c] = bbox_part[c]; r.hi[c] = bbox_part[3 + c]; }
-    nodes[0] = r;
-    node_at[0] = (n > kLeafMax) ? 0 : -1;
-    counts[0] = (n > kLeafMax) ? 1 : 0;     // active nodes at this level
-    counts[1] = 0;                          // active nodes at the next level
-    counts[2] = 0;                          // leaves
-    if (n <= kLeafMax) { leaves[0].start = 0; leaves[0].count = n; counts[2] = 1; }
-  }
+// S scans are processed as ONE forest: scan s owns positions [prefix[s], prefix[s + 1]) and is one root.
+struct ScanSet {
+  int32_t S;
+  const int32_t* offset;     // [S] first element of scan s in `raw`
+  const int32_t* prefix;     // [S + 1] positions
+};
+
+__device__ __forceinline__ int scan_of_pos(const ScanSet& ss, int pos) {
+  int lo = 0, hi = ss.S - 1;                       // last s with prefix[s] <= pos
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ss.prefix[mid] <= pos) lo = mid; else hi = mid - 1; }
+  return lo;
 }
 
-__global__ __launch_bounds__(1024) void kd_bbox(const float4* raw, int n, float* out) {   // one block
+__global__ __launch_bounds__(1024) void kd_bbox(const float4* raw, ScanSet ss, float* out) {   // one block per scan
+  const int sc = blockIdx.x;
+  const float4* p0 = raw + ss.offset[sc];
+  const int n = ss.prefix[sc + 1] - ss.prefix[sc];
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const float4 p = raw[i];
+    const float4 p = p0[i];
     mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
     mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
   }
@@ -76,7 +75,37 @@ __global__ __launch_bounds__(1024) void kd_bbox(const float4* raw, int n, float*
   if (threadIdx.x < 6) {
     float v = s[0][threadIdx.x];
     for (int w = 1; w < 16; ++w) v = threadIdx.x < 3 ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
-    out[threadIdx.x] = v;
+    out[8 * sc + threadIdx.x] = v;
+  }
+}
+
+__global__ void kd_init(ScanSet ss, int total, int32_t* order, int32_t* seg, int32_t* node_at, KdNode* nodes, int32_t* counts,
+                        const float* bbox, KdLeaf* leaves) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos < total) {
+    const int sc = scan_of_pos(ss, pos);
+    order[pos] = ss.offset[sc] + (pos - ss.prefix[sc]);
+    seg[pos] = ss.prefix[sc];
+    node_at[pos] = -1;
+  }
+  if (pos == 0) { counts[0] = 0; counts[1] = 0; counts[2] = 0; }
+}
+
+__global__ void kd_roots(ScanSet ss, int32_t* node_at, KdNode* nodes, int32_t* counts, const float* bbox, KdLeaf* leaves) {
+  const int sc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sc >= ss.S) return;
+  const int n = ss.prefix[sc + 1] - ss.prefix[sc];
+  if (n <= 0) return;
+  if (n > kLeafMax) {
+    KdNode r;
+    r.start = ss.prefix[sc]; r.count = n; r.dim = 0; r.left = 0;
+    for (int c = 0; c < 3; ++c) { r.lo[c] = bbox[8 * sc + c]; r.hi[c] = bbox[8 * sc + 3 + c]; }
+    const int slot = atomicAdd(&counts[0], 1);
+    nodes[slot] = r;
+    node_at[r.start] = slot;
+  } else {
+    const int slot = atomicAdd(&counts[2], 1);
+    leaves[slot].start = ss.prefix[sc]; leaves[slot].count = n;
   }
 }
 
@@ -176,7 +205,7 @@ __device__ int rank3_sym(const double* C) {
 }
 
 // one thread per leaf: cloud_types.cc:73-103
-__global__ void kd_leaf_normals(const float4* raw, const int32_t* order, const KdLeaf* leaves, const int32_t* counts,
+__global__ void kd_leaf_normals(const float4* raw, ScanSet ss, const int32_t* order, const KdLeaf* leaves, const int32_t* counts,
                                 float4* leaf_p, float4* leaf_n, unsigned long long* leaf_key, int32_t* leaf_id) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= counts[2]) return;
@@ -199,6 +228,8 @@ __global__ void kd_leaf_normals(const float4* raw, const int32_t* order, const K
     for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) C[3 * a + c] += e[a] * e[c];
   }
   leaf_id[l] = l;
+  const int sc = scan_of_pos(ss, lf.start);
+  kmin -= ss.offset[sc];                                    // index inside its own scan
   bool ok = n > 0 && rank3_sym(C) + 1 >= 3;               // :90-92
   double nv[3] = {0, 0, 0}, nn = 0;
   if (ok) {
@@ -214,27 +245,39 @@ __global__ void kd_leaf_normals(const float4* raw, const int32_t* order, const K
   if (ok) {
     leaf_p[l] = make_float4((float)mean[0], (float)mean[1], (float)mean[2], 0.f);
     leaf_n[l] = make_float4((float)(nv[0] / nn), (float)(nv[1] / nn), (float)(nv[2] / nn), 0.f);
-    leaf_key[l] = (unsigned long long)(uint32_t)kmin;
+    leaf_key[l] = ((unsigned long long)(uint32_t)sc << 32) | (uint32_t)kmin;
   } else {
-    leaf_key[l] = 0xffffffffffffffffull;
+    leaf_key[l] = ((unsigned long long)(uint32_t)sc << 32) | 0xffffffffull;     // sorts behind the scan's valid leaves
   }
 }
 
-__global__ void kd_emit(const float4* leaf_p, const float4* leaf_n, const unsigned long long* keys_sorted, const int32_t* ids_sorted,
-                        const int32_t* counts, float4* out_p, float4* out_n, int32_t* m_out) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+// first sorted rank of every scan's leaves and the number of valid ones
+__global__ void kd_scan_ranges(const unsigned long long* keys_sorted, const int32_t* counts, int S, int32_t* lstart, int32_t* m_out) {
+  const int sc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sc >= S) return;
   const int nl = counts[2];
-  if (r >= nl) return;
-  const bool valid = keys_sorted[r] != 0xffffffffffffffffull;
-  if (valid) {
-    const int l = ids_sorted[r];
-    out_p[r] = leaf_p[l];
-    out_n[r] = leaf_n[l];
-    // the number of valid leaves = index of the first invalid key (sorted ascending)
-    if (r + 1 == nl || keys_sorted[r + 1] == 0xffffffffffffffffull) *m_out = r + 1;
-  } else if (r == 0) {
-    *m_out = 0;
-  }
+  auto lower = [&](unsigned long long key) {       // first r with keys_sorted[r] >= key
+    int lo = 0, hi = nl;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys_sorted[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  const int a = lower((unsigned long long)(uint32_t)sc << 32);
+  const int b = lower(((unsigned long long)(uint32_t)sc << 32) | 0xffffffffull);
+  lstart[sc] = a;
+  m_out[sc] = b - a;
+}
+
+__global__ void kd_emit(const float4* leaf_p, const float4* leaf_n, const unsigned long long* keys_sorted, const int32_t* ids_sorted,
+                        const int32_t* counts, const int32_t* lstart, const int32_t* out_offset, float4* out_p, float4* out_n) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= counts[2]) return;
+  const unsigned long long key = keys_sorted[r];
+  if ((key & 0xffffffffull) == 0xffffffffull) return;      // dropped leaf
+  const int sc = (int)(key >> 32);
+  const int l = ids_sorted[r];
+  const size_t o = (size_t)out_offset[sc] + (size_t)(r - lstart[sc]);
+  out_p[o] = leaf_p[l];
+  out_n[o] = leaf_n[l];
 }
 
 }  // namespace
@@ -251,9 +294,12 @@ struct PrepWorkspace {
   int32_t *leaf_id[2] = {nullptr, nullptr};
   void* sort_tmp = nullptr;
   size_t sort_bytes = 0;
-  int32_t* m_dev = nullptr;
-  int32_t* host_pinned = nullptr;        // [0] = m, [1..3] = counts
+  int32_t* m_dev = nullptr;              // [kMaxScans]
+  int32_t* lstart = nullptr;             // [kMaxScans]
+  int32_t* scan_meta = nullptr;          // device: offset[kMaxScans], prefix[kMaxScans + 1], out_offset[kMaxScans]
+  int32_t* host_pinned = nullptr;        // [0..3] counts, then m[kMaxScans], then the scan_meta staging
 };
+
 
 PrepWorkspace* prep_create(int max_points) {
   PrepWorkspace* w = new PrepWorkspace();
@@ -263,10 +309,11 @@ PrepWorkspace* prep_create(int max_points) {
   auto A = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
   for (int k = 0; k < 2; ++k) {
     A((void**)&w->order[k], N * 4); A((void**)&w->seg[k], N * 4); A((void**)&w->node_at[k], N * 4);
-    A((void**)&w->keys[k], N * 8); A((void**)&w->nodes[k], (N / 4 + 16) * sizeof(KdNode)); A((void**)&w->leaf_id[k], (N / 2 + 16) * 4);
+    A((void**)&w->keys[k], N * 8); A((void**)&w->nodes[k], (N / 4 + 16 + kMaxScans) * sizeof(KdNode)); A((void**)&w->leaf_id[k], (N / 2 + 16) * 4);
   }
   A((void**)&w->leaves, (N / 2 + 16) * sizeof(KdLeaf));
-  A((void**)&w->counts, 16 * 4); A((void**)&w->bbox, 8 * 4); A((void**)&w->m_dev, 4);
+  A((void**)&w->counts, 16 * 4); A((void**)&w->bbox, (size_t)8 * 4 * kMaxScans); A((void**)&w->m_dev, (size_t)4 * kMaxScans);
+  A((void**)&w->lstart, (size_t)4 * kMaxScans); A((void**)&w->scan_meta, (size_t)4 * (3 * kMaxScans + 8));
   A((void**)&w->leaf_p, (N / 2 + 16) * sizeof(float4)); A((void**)&w->leaf_n, (N / 2 + 16) * sizeof(float4));
   if (ok) {
     size_t bytes = 0;
@@ -275,7 +322,7 @@ PrepWorkspace* prep_create(int max_points) {
     w->sort_bytes = bytes + 256;
     A(&w->sort_tmp, w->sort_bytes);
   }
-  if (ok && hipHostMalloc((void**)&w->host_pinned, 64) != hipSuccess) ok = false;
+  if (ok && hipHostMalloc((void**)&w->host_pinned, (size_t)4 * (8 + 4 * kMaxScans + 8)) != hipSuccess) ok = false;
   if (!ok) { prep_destroy(w); return nullptr; }
   return w;
 }
@@ -287,6 +334,7 @@ void prep_destroy(PrepWorkspace* w) {
     (void)hipFree(w->nodes[k]); (void)hipFree(w->leaf_id[k]);
   }
   (void)hipFree(w->leaves); (void)hipFree(w->counts); (void)hipFree(w->bbox); (void)hipFree(w->m_dev);
+  (void)hipFree(w->lstart); (void)hipFree(w->scan_meta);
   (void)hipFree(w->leaf_p); (void)hipFree(w->leaf_n); (void)hipFree(w->sort_tmp);
   if (w->host_pinned) (void)hipHostFree(w->host_pinned);
   delete w;
@@ -360,49 +408,79 @@ hipError_t prep_morton_sort(PrepWorkspace* w, hipStream_t st, const float4* raw,
   return hipGetLastError();
 }
 
-hipError_t prep_calculate_normals(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float4* out_p, float4* out_n, int* m_host) {
-  if (!w || n <= 0 || n > w->cap) return hipErrorInvalidValue;
-  const int gp = (n + 255) / 256;
-  hipLaunchKernelGGL(kd_bbox, dim3(1), dim3(1024), 0, st, raw, n, w->bbox);
-  hipLaunchKernelGGL(kd_init, dim3(gp), dim3(256), 0, st, raw, n, w->order[0], w->seg[0], w->node_at[0], w->nodes[0], w->counts, w->bbox, w->leaves);
+// S scans at once: scan s = raw[offset[s] .. offset[s] + n[s]), results to out_p/out_n[out_offset[s] ..], m_host[s] survivors.
+hipError_t prep_calculate_normals_batch(PrepWorkspace* w, hipStream_t st, const float4* raw, int S, const int* offset, const int* n,
+                                        const int* out_offset, float4* out_p, float4* out_n, int* m_host) {
+  if (!w || S <= 0 || S > kMaxScans) return hipErrorInvalidValue;
+  int32_t* hp = w->host_pinned;
+  int32_t* h_meta = hp + 8 + kMaxScans;           // offset[S], prefix[S + 1], out_offset[S]
+  long long total = 0;
+  int nmax = 0;
+  for (int s2 = 0; s2 < S; ++s2) {
+    if (n[s2] <= 0) return hipErrorInvalidValue;
+    h_meta[s2] = offset[s2];
+    h_meta[kMaxScans + s2] = (int32_t)total;
+    h_meta[2 * kMaxScans + 1 + s2] = out_offset[s2];
+    total += n[s2];
+    nmax = std::max(nmax, n[s2]);
+  }
+  h_meta[kMaxScans + S] = (int32_t)total;
+  if (total > w->cap) return hipErrorInvalidValue;
+  PCHK(hipMemcpyAsync(w->scan_meta, h_meta, sizeof(int32_t) * (3 * kMaxScans + 2), hipMemcpyHostToDevice, st));
+  ScanSet ss;
+  ss.S = S; ss.offset = w->scan_meta; ss.prefix = w->scan_meta + kMaxScans;
+  const int32_t* d_out_offset = w->scan_meta + 2 * kMaxScans + 1;
+  const int N = (int)total;
+  const int gp = (N + 255) / 256;
+  hipLaunchKernelGGL(kd_bbox, dim3(S), dim3(1024), 0, st, raw, ss, w->bbox);
+  hipLaunchKernelGGL(kd_init, dim3(gp), dim3(256), 0, st, ss, N, w->order[0], w->seg[0], w->node_at[0], w->nodes[0], w->counts, w->bbox, w->leaves);
+  hipLaunchKernelGGL(kd_roots, dim3((S + 63) / 64), dim3(64), 0, st, ss, w->node_at[0], w->nodes[0], w->counts, w->bbox, w->leaves);
   int cur = 0;
-  // depth <= ceil(log2(n / 4)) + 1; the loop runs a fixed number of levels (extra levels are no-ops: zero active nodes)
+  // depth <= ceil(log2(n / 4)) + 1; a fixed number of levels runs (extra levels are no-ops: zero active nodes)
   int levels = 1;
-  while (((long long)kLeafMax << levels) < (long long)n * 2) ++levels;
+  while (((long long)kLeafMax << levels) < (long long)nmax * 2) ++levels;
   levels += 1;
   int seg_bits = 1;
-  while ((1ll << seg_bits) < (long long)n) ++seg_bits;
+  while ((1ll << seg_bits) < total) ++seg_bits;
   for (int lv = 0; lv < levels; ++lv) {
     const int nxt = cur ^ 1;
-    const int max_nodes = std::min(n / (kLeafMax + 1) + 2, 1 << std::min(lv, 30));
-    const int gn = (max_nodes + 63) / 64;
+    const long long cap_nodes = std::min<long long>(total / (kLeafMax + 1) + 2 + S, (long long)S << std::min(lv, 24));
+    const int gn = (int)((cap_nodes + 63) / 64);
     hipLaunchKernelGGL(kd_choose_dim, dim3(gn), dim3(64), 0, st, w->nodes[cur], w->counts);
-    hipLaunchKernelGGL(kd_keys, dim3(gp), dim3(256), 0, st, raw, n, w->order[cur], w->seg[cur], w->node_at[cur], w->nodes[cur], w->keys[0]);
+    hipLaunchKernelGGL(kd_keys, dim3(gp), dim3(256), 0, st, raw, N, w->order[cur], w->seg[cur], w->node_at[cur], w->nodes[cur], w->keys[0]);
     size_t bytes = w->sort_bytes;
     // key = segment start (needs `seg_bits` bits) << 32 | coordinate bits
-    PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[cur], w->order[nxt], (unsigned)n, 0, 32 + seg_bits, st));
-    PCHK(hipMemsetAsync(w->node_at[nxt], 0xff, (size_t)n * 4, st));
+    PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[cur], w->order[nxt], (unsigned)N, 0, 32 + seg_bits, st));
+    PCHK(hipMemsetAsync(w->node_at[nxt], 0xff, (size_t)N * 4, st));
     hipLaunchKernelGGL(kd_split, dim3(gn), dim3(64), 0, st, raw, w->order[nxt], w->nodes[cur], w->nodes[nxt], w->counts, w->node_at[nxt], w->leaves);
-    hipLaunchKernelGGL(kd_update_seg, dim3(gp), dim3(256), 0, st, n, w->seg[cur], w->node_at[cur], w->nodes[cur], w->seg[nxt]);
+    hipLaunchKernelGGL(kd_update_seg, dim3(gp), dim3(256), 0, st, N, w->seg[cur], w->node_at[cur], w->nodes[cur], w->seg[nxt]);
     hipLaunchKernelGGL(kd_advance, dim3(1), dim3(1), 0, st, w->counts);
     cur = nxt;
   }
-  // leaves -> (mean, normal), ordered by the smallest original index of the leaf (cloud_types.cc:358)
-  const int max_leaves = n / 2 + 16;
+  // leaves -> (mean, normal), ordered per scan by the smallest original index of the leaf (cloud_types.cc:358)
+  const int max_leaves = N / 2 + 16;
   const int gl = (max_leaves + 255) / 256;
-  hipLaunchKernelGGL(kd_leaf_normals, dim3(gl), dim3(256), 0, st, raw, w->order[cur], w->leaves, w->counts, w->leaf_p, w->leaf_n, w->keys[0], w->leaf_id[0]);
-  PCHK(hipMemcpyAsync(w->host_pinned + 1, w->counts, 12, hipMemcpyDeviceToHost, st));
+  hipLaunchKernelGGL(kd_leaf_normals, dim3(gl), dim3(256), 0, st, raw, ss, w->order[cur], w->leaves, w->counts, w->leaf_p, w->leaf_n, w->keys[0], w->leaf_id[0]);
+  PCHK(hipMemcpyAsync(hp, w->counts, 12, hipMemcpyDeviceToHost, st));
   PCHK(hipStreamSynchronize(st));
-  const int nl = w->host_pinned[3];
-  if (nl <= 0 || nl > max_leaves) { *m_host = 0; return hipSuccess; }
+  const int nl = hp[2];
+  for (int s2 = 0; s2 < S; ++s2) m_host[s2] = 0;
+  if (nl <= 0 || nl > max_leaves) return hipSuccess;
   size_t bytes = w->sort_bytes;
   PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->leaf_id[0], w->leaf_id[1], (unsigned)nl, 0, 64, st));
-  hipLaunchKernelGGL(kd_emit, dim3((nl + 255) / 256), dim3(256), 0, st, w->leaf_p, w->leaf_n, w->keys[1], w->leaf_id[1], w->counts, out_p, out_n, w->m_dev);
-  PCHK(hipMemcpyAsync(w->host_pinned, w->m_dev, 4, hipMemcpyDeviceToHost, st));
+  hipLaunchKernelGGL(kd_scan_ranges, dim3((S + 63) / 64), dim3(64), 0, st, w->keys[1], w->counts, S, w->lstart, w->m_dev);
+  hipLaunchKernelGGL(kd_emit, dim3((nl + 255) / 256), dim3(256), 0, st, w->leaf_p, w->leaf_n, w->keys[1], w->leaf_id[1], w->counts, w->lstart,
+                     d_out_offset, out_p, out_n);
+  PCHK(hipMemcpyAsync(hp + 8, w->m_dev, sizeof(int32_t) * S, hipMemcpyDeviceToHost, st));
   PCHK(hipStreamSynchronize(st));
   PCHK(hipGetLastError());
-  *m_host = w->host_pinned[0];
+  for (int s2 = 0; s2 < S; ++s2) m_host[s2] = hp[8 + s2];
   return hipSuccess;
+}
+
+hipError_t prep_calculate_normals(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float4* out_p, float4* out_n, int* m_host) {
+  const int zero = 0;
+  return prep_calculate_normals_batch(w, st, raw, 1, &zero, &n, &zero, out_p, out_n, m_host);
 }
 
 }  // namespace smhip

@@ -27,6 +27,7 @@ struct smhip_ndt_state;
 struct smhip_context {
   smhip_ndt_state* ndt = nullptr;
   PrepWorkspace* prep = nullptr;          // device CalculateNormals workspace (allocated on first use)
+  PrepWorkspace* prep_batch = nullptr;    // the same sized for every slot at once (batched target preparation)
   float4* prep_raw = nullptr;             // raw scan staging on the device
   int device = 0;
   hipStream_t stream = nullptr;
@@ -399,6 +400,7 @@ smhip_status smhip_destroy(smhip_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   smhip_internal_free_ndt(h);
   if (h->prep) prep_destroy(h->prep);
+  if (h->prep_batch) prep_destroy(h->prep_batch);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->stage) (void)hipHostFree(h->stage);
   if (h->in_pinned) (void)hipHostFree(h->in_pinned);
@@ -575,6 +577,37 @@ smhip_status smhip_prepare_target_from_source(smhip_handle h, int from, int to, 
   s = prep_ensure(h);
   if (s) return s;
   return prep_run(h, h->dev.src + (size_t)from * h->dev.ns_cap, h->ns[from], to, n_out);
+}
+
+smhip_status smhip_prepare_targets_from_sources(smhip_handle h, int count, const int* from_slots, const int* to_slots, int* n_out) {
+  if (!h || !from_slots || !to_slots || count < 1 || count > h->dev.slots) return SMHIP_ERR_INVALID_ARGUMENT;
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<int> off(count), n(count), out_off(count), m(count, 0);
+  for (int k = 0; k < count; ++k) {
+    smhip_status s = check_slot(h, from_slots[k]);
+    if (s) return s;
+    s = check_slot(h, to_slots[k]);
+    if (s) return s;
+    if (h->ns[from_slots[k]] <= 0) { h->err = "source slot is empty"; return SMHIP_ERR_NOT_READY; }
+    n[k] = h->ns[from_slots[k]];
+    if (h->dev.nt_cap < n[k] / 4 + 8) { h->err = "max_target_points too small for the prepared target (need n / 4 + 8)"; return SMHIP_ERR_CAPACITY; }
+    off[k] = from_slots[k] * h->dev.ns_cap;
+    out_off[k] = to_slots[k] * h->dev.nt_cap;
+  }
+  if (!h->prep_batch) {
+    h->prep_batch = prep_create(h->dev.slots * h->dev.ns_cap);
+    if (!h->prep_batch) { h->err = "batched CalculateNormals workspace allocation failed"; return SMHIP_ERR_HIP; }
+  }
+  const hipError_t e = prep_calculate_normals_batch(h->prep_batch, h->stream, h->dev.src, count, off.data(), n.data(), out_off.data(),
+                                                    const_cast<float4*>(h->dev.tgt_p), const_cast<float4*>(h->dev.tgt_n), m.data());
+  if (e != hipSuccess) { h->err = std::string("prep_calculate_normals_batch: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
+  for (int k = 0; k < count; ++k) {
+    if (m[k] <= 0) { h->err = "CalculateNormals produced no target points"; return SMHIP_ERR_INVALID_ARGUMENT; }
+    h->nt[to_slots[k]] = m[k];
+    h->has_normals[to_slots[k]] = 1;
+    if (n_out) n_out[k] = m[k];
+  }
+  return SMHIP_OK;
 }
 
 smhip_status smhip_get_target_f32(smhip_handle h, int slot, float* xyz, float* normals, int n) {

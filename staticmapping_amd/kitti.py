@@ -71,19 +71,31 @@ def scan_to_scan_sequence(scans, matcher, batch: int, guesses=None, rank: int = 
     mine = shard.pairs_of_rank(n_pairs, rank, world)
     get = lambda i: scans[i]() if callable(scans[i]) else scans[i]
     out_T, out_s, out_it = [], [], []
+    spare = matcher.pair_slots - 1                         # holds a target scan nobody uploaded as a source
     for b0 in range(0, len(mine), batch):
         chunk = mine[b0:b0 + batch]
         g = []
-        for s, pair in enumerate(chunk):
-            if prepare_target is not None:
-                q, n = prepare_target(get(pair))
-                matcher.set_input_target(q, n, slot=s)
-            elif s > 0 and chunk[s - 1] == pair - 1:
-                matcher.prepare_target_from_source(s - 1, s)      # scan `pair` is the previous slot's source
-            else:
-                matcher.prepare_target(get(pair), slot=s)
+        for s, pair in enumerate(chunk):                  # every source once
             matcher.set_input_source(get(pair + 1), slot=s)
             g.append(np.eye(4) if guesses is None else guesses[pair])
+        if prepare_target is not None:
+            for s, pair in enumerate(chunk):
+                q, n = prepare_target(get(pair))
+                matcher.set_input_target(q, n, slot=s)
+        else:
+            # targets: scan `pair` is the previous slot's source when the chunk is consecutive; all of those are
+            # prepared in ONE batched device pass, the others are uploaded and prepared one by one
+            fr, to = [], []
+            for s, pair in enumerate(chunk):
+                if s > 0 and chunk[s - 1] == pair - 1:
+                    fr.append(s - 1); to.append(s)
+                elif spare >= len(chunk) and not fr:      # first pair of a consecutive chunk: park its target scan
+                    matcher.set_input_source(get(pair), slot=spare)
+                    fr.append(spare); to.append(s)
+                else:
+                    matcher.prepare_target(get(pair), slot=s)
+            if fr:
+                matcher.prepare_targets_from_sources(fr, to)
         T, sc, st = matcher.align_batch(len(chunk), g)
         out_T.append(T); out_s.append(sc); out_it.append([x["iterations"] for x in st])
     if not out_T:

@@ -126,6 +126,14 @@ class IcpFastHip:
         self._check(self._lib.smhip_prepare_target_from_source(self._h, from_slot, to_slot, ctypes.byref(m)))
         return m.value
 
+    def prepare_targets_from_sources(self, from_slots, to_slots):
+        """Batched device CalculateNormals: target of to_slots[k] from the source cloud resident in from_slots[k]."""
+        f = np.ascontiguousarray(from_slots, dtype=np.int32); t = np.ascontiguousarray(to_slots, dtype=np.int32)
+        m = np.zeros(len(f), dtype=np.int32)
+        self._check(self._lib.smhip_prepare_targets_from_sources(self._h, len(f), f.ctypes.data_as(_capi.c_int32_p),
+                                                                 t.ctypes.data_as(_capi.c_int32_p), m.ctypes.data_as(_capi.c_int32_p)))
+        return m
+
     def get_target(self, n: int, slot: int = 0):
         p = np.zeros((n, 3), np.float32); nr = np.zeros((n, 3), np.float32)
         self._check(self._lib.smhip_get_target_f32(self._h, slot, p.ctypes.data_as(_capi.c_float_p), nr.ctypes.data_as(_capi.c_float_p), n))

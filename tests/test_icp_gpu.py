@@ -273,3 +273,37 @@ def test_rigid_motion_equivariance_full_size(smhip, cfg2):
     da, dt = smhip.se3_error(R1, W @ R0)
     assert da < ROT_TOL and dt < TRANS_TOL, (da, dt)
     m.close()
+
+
+def test_concurrent_matcher_instances(smhip, velo20k, cfg1):
+    """The back end runs up to 6 matcher instances concurrently (builder/map_builder.cc:655,706-708):
+    one handle per thread, no shared mutable state in the library."""
+    import threading
+    cases = [velo20k, cfg1, velo20k, cfg1]
+    guesses = [velo20k["guess"], np.eye(4), np.eye(4), np.eye(4)]
+    ref = []
+    for c, g in zip(cases, guesses):
+        m = smhip.IcpFastHip(max_source_points=len(c["src"]), max_target_points=len(c["q"]))
+        m.set_input_source(c["src"]); m.set_input_target(c["q"], c["n"])
+        ref.append(m.align(g)[1]); m.close()
+    out = [None] * len(cases)
+    err = []
+
+    def work(k):
+        try:
+            c = cases[k]
+            m = smhip.IcpFastHip(max_source_points=len(c["src"]), max_target_points=len(c["q"]))
+            for _ in range(3):
+                m.set_input_source(c["src"]); m.set_input_target(c["q"], c["n"])
+                out[k] = m.align(guesses[k])[1]
+            m.close()
+        except Exception as e:      # noqa: BLE001
+            err.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(cases))]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not err, err
+    for k in range(len(cases)):
+        da, dt = smhip.se3_error(out[k], ref[k])
+        assert da < 1e-6 and dt < 1e-5

@@ -55,3 +55,23 @@ def test_prepared_target_aligns_like_host_prepared(velo20k):
     da, dt = sm.se3_error(R_dev, c["T"])
     assert da < 2e-3 and dt < 2e-2
     m.close()
+
+
+def test_batched_preparation_equals_single_calls(velo20k, cfg2):
+    """One kd forest for several scans gives exactly what the scans give one at a time."""
+    import staticmapping_amd as sm
+    scans = [velo20k["tgt"], cfg2["tgt"][:60000], velo20k["src"]]
+    cap = max(len(s) for s in scans)
+    m = sm.IcpFastHip(pair_slots=6, max_source_points=cap, max_target_points=cap // 4 + 64)
+    single = []
+    for k, sc in enumerate(scans):
+        m.set_input_source(sc, slot=k)
+        M = m.prepare_target_from_source(k, k)
+        single.append(m.get_target(M, slot=k))
+    Ms = m.prepare_targets_from_sources([0, 1, 2], [3, 4, 5])
+    for k in range(3):
+        p1, n1 = single[k]
+        assert Ms[k] == len(p1)
+        p2, n2 = m.get_target(int(Ms[k]), slot=3 + k)
+        assert np.array_equal(p1, p2) and np.array_equal(n1, n2)
+    m.close()

@@ -15,8 +15,8 @@ rel_true = [np.linalg.inv(poses[k]) @ poses[k + 1] for k in range(K - 1)]
 guesses = []
 for T in rel_true:
     G = np.eye(4); G[:3, 3] = 0.75 * T[:3, 3]; guesses.append(G)
-for batch in (16,):
-    m = sm.IcpFastHip(pair_slots=batch, max_source_points=120000, max_target_points=120000 // 4 + 64, max_iteration=100, early_exit=1)
+for batch in (16, 64):
+    m = sm.IcpFastHip(pair_slots=batch + 1, max_source_points=120000, max_target_points=120000 // 4 + 64, max_iteration=100, early_exit=1)
     kitti.scan_to_scan_sequence(scans[:3], m, batch=batch, guesses=guesses)      # warm-up (workspace allocation)
     t = time.time()
     idx, T, sc, it = kitti.scan_to_scan_sequence(scans, m, batch=batch, guesses=guesses)

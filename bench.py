@@ -139,6 +139,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
+    m.enable_profile(2)          # HIP events around the dominant NN kernel only, on the stream each launch goes to
     t0 = time.perf_counter()
     for _ in range(args.steps):
         gathered = step()
@@ -149,6 +150,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     res, scores, stats = m.fetch_batch(B)
+    nn_prof = m.get_profile()    # the timed region's launches of the dominant kernel
+    m.enable_profile(False)
 
     # correctness of what was timed: every gathered pose is the known motion of its pair
     T_all, sc_all, it_all = shard.unpack_pose_rows(gathered)
@@ -161,21 +164,24 @@ def main():
     out = None
     if rank == 0:
         value = n_total * args.steps / elapsed
-        # ---- roofline of the dominant kernel: HIP events on the launch stream (untimed extra step)
+        # ---- per-kernel breakdown: HIP events around every launch (untimed extra step)
         m.enable_profile(True)
         m.enqueue_batch(B, guesses)
         m.fetch_batch(B)
         prof = m.get_profile()
         m.enable_profile(False)
-        nn_ms = prof["ms_nn_main"] / max(1, prof["launches_nn_main"])
-        nn_bytes = nn_bytes_per_launch(B, ns)
+        # ---- roofline of the dominant kernel from the events of the TIMED region
+        nn_ms = nn_prof["ms_nn_main"] / max(1, nn_prof["launches_nn_main"])
+        # with >= 16 pairs a step is two half-batches on two streams: one launch covers B / 2 pairs
+        pairs_per_launch = B * ICP_ITERS * args.steps // max(1, nn_prof["launches_nn_main"])
+        nn_bytes = nn_bytes_per_launch(pairs_per_launch, ns)
         achieved = nn_bytes / (nn_ms * 1e-3) / 1e9
         traffic = None
         tj = os.path.join(ROOT, "profiles", "traffic_nn_main.json")
         if os.path.exists(tj):
             try:
                 tdat = json.load(open(tj))
-                if tdat.get("pairs") == B and tdat.get("nn_mode") == args.nn_mode:
+                if tdat.get("pairs_per_launch") == pairs_per_launch and tdat.get("nn_mode") == args.nn_mode:
                     traffic = tdat.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -194,8 +200,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "nn_ball_lds" if args.nn_mode == "grid" else "nn_brute",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "bytes_per_launch": nn_bytes, "avg_launch_ms": round(nn_ms, 4),
-                         "launches_timed": prof["launches_nn_main"],
+                         "bytes_per_launch": nn_bytes, "pairs_per_launch": pairs_per_launch, "avg_launch_ms": round(nn_ms, 4),
+                         "launches_timed": nn_prof["launches_nn_main"],
                          "whole_alignment": {"algorithmic_bytes": alg_bytes,
                                              "achieved_GBs": round(alg_bytes * value / world / 1e9, 2),
                                              "frac": round(alg_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)}},

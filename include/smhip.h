@@ -93,8 +93,9 @@ typedef struct smhip_icp_stats {
   int32_t reserved;
 } smhip_icp_stats;
 
-/* Kernel-time breakdown collected when profiling is enabled (HIP events on the
- * handle's stream around every launch).  Names follow the reference's
+/* Kernel-time breakdown collected when profiling is enabled (HIP events around
+ * every launch, recorded on the stream the launch goes to: a batch of >= 16 pairs
+ * runs as two halves on two streams, so the sums can exceed the wall time).  Names follow the reference's
  * REGISTER_BLOCK labels where one exists (icp_fast.cc:103,171,261,484). */
 typedef struct smhip_icp_profile {
   double ms_prepare;            /* target centring + grid build (replaces kd-tree build, icp_fast.cc:464-467) */
@@ -232,6 +233,8 @@ smhip_status smhip_ndt_compute_derivatives(smhip_handle h, const double pose6[6]
                                            double* score, double grad[6], double hess[36]);
 
 /* ---- profiling ----------------------------------------------------------- */
+/* enable: 0 off, 1 events around every launch, 2 events around the dominant NN kernel only (cheap enough to
+ * leave on inside a timed region) */
 smhip_status smhip_icp_enable_profile(smhip_handle h, int enable);
 smhip_status smhip_icp_get_profile(smhip_handle h, smhip_icp_profile* out);
 

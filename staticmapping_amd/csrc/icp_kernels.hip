@@ -635,7 +635,7 @@ __device__ __forceinline__ void sweep_run(const float4* __restrict__ tq, uint32_
   for (; j < j1; ++j) test_ascending_ru(tq[j], (int)j, qx, qy, qz, best);
 }
 
-__global__ __launch_bounds__(kNnThreads) void nn_ball_lds(IcpDev b, int nblk) {
+__global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk) {
   int pair, blk;
   if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
   PairState* st = &b.state[pair];

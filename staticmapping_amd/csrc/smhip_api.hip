@@ -49,7 +49,7 @@ struct smhip_context {
   std::string err;
   int last_npairs = 0;
   // profiling
-  bool profile = false;
+  int profile = 0;               // 0 off, 1 every launch, 2 the dominant NN kernel only
   struct Ev { hipEvent_t a, b; int cat; };
   std::vector<Ev> ev_pool;
   size_t ev_used = 0;
@@ -84,8 +84,9 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 struct Bracket {
   smhip_context* h;
   smhip_context::Ev* ev = nullptr;
-  Bracket(smhip_context* h_, int cat) : h(h_) {
-    if (!h->profile) return;
+  hipStream_t st;
+  Bracket(smhip_context* h_, int cat, hipStream_t st_) : h(h_), st(st_) {
+    if (!h->profile || (h->profile == 2 && cat != 4)) return;
     if (h->ev_used == h->ev_pool.size()) {
       smhip_context::Ev e{};
       if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
@@ -93,10 +94,10 @@ struct Bracket {
     }
     ev = &h->ev_pool[h->ev_used++];
     ev->cat = cat;
-    (void)hipEventRecord(ev->a, h->stream);
+    (void)hipEventRecord(ev->a, st);
   }
   ~Bracket() {
-    if (ev) (void)hipEventRecord(ev->b, h->stream);
+    if (ev) (void)hipEventRecord(ev->b, st);
   }
 };
 
@@ -146,7 +147,7 @@ smhip_status enqueue_resets(smhip_context* h, int np) {
 smhip_status enqueue_grid_build(smhip_context* h, const Half& f, int nt_max) {
   const IcpDev& d = f.d;
   const int np = f.np;
-  Bracket br(h, 0);
+  Bracket br(h, 0, f.stream);
   const dim3 gpts(ceil_div(nt_max, 256), np);
   hipLaunchKernelGGL(tgt_reduce, dim3(kTgtReduceBlocks, np), dim3(256), 0, f.stream, d);
   hipLaunchKernelGGL(grid_setup, dim3(ceil_div(np, 64)), dim3(64), 0, f.stream, d, np);
@@ -191,26 +192,26 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
       const dim3 gx(nblk * 8 * ceil_div(np, 8));
       if (d.lds_table) {
         // certificate, in-workgroup compaction of the failing queries and LDS-staged search in one launch
-        Bracket br(h, 4);
+        Bracket br(h, 4, st);
         hipLaunchKernelGGL(nn_ball_lds, gx, dim3(kNnThreads), 0, st, d, nblk);
       } else if (d.certify && iteration > 0) {
         // global-memory variant: certificate pass, then a search over the compacted failing queries
-        { Bracket br(h, 4); hipLaunchKernelGGL(nn_certify, gx, dim3(kNnThreads), 0, st, d, nblk); }
-        { Bracket br(h, 4); hipLaunchKernelGGL(nn_ball<true>, gx, dim3(kNnThreads), 0, st, d, nblk); }
+        { Bracket br(h, 4, st); hipLaunchKernelGGL(nn_certify, gx, dim3(kNnThreads), 0, st, d, nblk); }
+        { Bracket br(h, 4, st); hipLaunchKernelGGL(nn_ball<true>, gx, dim3(kNnThreads), 0, st, d, nblk); }
       } else {
-        Bracket br(h, 4);
+        Bracket br(h, 4, st);
         hipLaunchKernelGGL(nn_ball<false>, gx, dim3(kNnThreads), 0, st, d, nblk);
       }
-      { Bracket br(h, 1); hipLaunchKernelGGL(nn_validate, dim3(np), dim3(256), 0, st, d); }
-      { Bracket br(h, 1); hipLaunchKernelGGL(nn_ring<true>, dim3(32, np), dim3(kNnThreads), 0, st, d); }
+      { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_validate, dim3(np), dim3(256), 0, st, d); }
+      { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_ring<true>, dim3(32, np), dim3(kNnThreads), 0, st, d); }
     } else {
-      Bracket br(h, 4);
+      Bracket br(h, 4, st);
       hipLaunchKernelGGL(nn_ring<false>, g, dim3(kNnThreads), 0, st, d);
     }
-    { Bracket br(h, 1); hipLaunchKernelGGL(nn_fallback_scan, dim3(kFallbackSlices, np), dim3(kNnThreads), 0, st, d); }
-    { Bracket br(h, 1); hipLaunchKernelGGL(nn_fallback_resolve, dim3(32, np), dim3(kNnThreads), 0, st, d); }
+    { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_fallback_scan, dim3(kFallbackSlices, np), dim3(kNnThreads), 0, st, d); }
+    { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_fallback_resolve, dim3(32, np), dim3(kNnThreads), 0, st, d); }
   } else {
-    Bracket br(h, 4);
+    Bracket br(h, 4, st);
     hipLaunchKernelGGL(nn_brute, g, dim3(kNnThreads), 0, st, d);
   }
   return SMHIP_OK;
@@ -659,7 +660,7 @@ smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* g
   if (s) return s;
   // Split the batch over two streams: the latency-bound launches of one half (finalize, validate, grid
   // build, near-empty refinement kernels) overlap the throughput-bound NN / accumulate of the other.
-  const bool split = h->opts.no_overlap == 0 && !h->profile && npairs >= 16 && h->stream2 != nullptr;
+  const bool split = h->opts.no_overlap == 0 && npairs >= 16 && h->stream2 != nullptr;
   Half halves[2];
   int nh = 1;
   halves[0] = whole_batch(h, npairs);
@@ -688,10 +689,10 @@ smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* g
       if (s) return s;
       {
         const int nblk = ceil_div(ns_max, kAccChunk);
-        Bracket br(h, 2);
+        Bracket br(h, 2, f.stream);
         hipLaunchKernelGGL(accumulate, dim3(nblk * 8 * ceil_div(f.np, 8)), dim3(kAccThreads), 0, f.stream, f.d, nblk);
       }
-      { Bracket br(h, 3); hipLaunchKernelGGL(finalize, dim3(f.np), dim3(256), 0, f.stream, f.d); }
+      { Bracket br(h, 3, f.stream); hipLaunchKernelGGL(finalize, dim3(f.np), dim3(256), 0, f.stream, f.d); }
     }
     if (h->dev.early_exit && (it + 1) % h->opts.check_every == 0 && it + 1 < max_it) {
       s = join();
@@ -808,7 +809,7 @@ smhip_status smhip_icp_find_closests(smhip_handle h, int slot, const double T[16
 
 smhip_status smhip_icp_enable_profile(smhip_handle h, int enable) {
   if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
-  h->profile = enable != 0;
+  h->profile = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
   h->prof = smhip_icp_profile{};
   h->ev_used = 0;
   return SMHIP_OK;

@@ -18,8 +18,8 @@ constexpr int kMaxGridWords = 1 << 18;   // 32-cell words per pair (8 Mi cells)
 constexpr int kTgtReduceBlocks = 32;     // partial blocks for the target mean / bbox
 constexpr int kBruteTile = 1024;
 constexpr int kFallbackSlices = 64;
-constexpr int kLdsTableCap = 2048;        // u32 entries of the per-workgroup row table in nn_ball_lds (8 KiB)
-constexpr int kLdsPointCap = 1024;        // target points staged per round (16 KiB)
+constexpr int kLdsTableCap = 1024;        // u32 entries of the per-workgroup row table in nn_ball_lds (4 KiB)
+constexpr int kLdsPointCap = 512;         // target points staged per round (8 KiB)
 constexpr int kLdsRowCap = 256;           // grid rows of the box whose runs are staged (<= workgroup size)
 constexpr int kBallItems = 4;            // queries per thread in nn_ball (1024 per block: fewer histogram flushes)      // target slices the fallback sweep is spread over         // target points staged in LDS per tile (16 KiB as float4)
 

@@ -216,7 +216,8 @@ class IcpFastHip:
         """Write npairs x 18 doubles (16 col-major transform, score, iterations) to device memory."""
         self._check(self._lib.smhip_icp_export_results_device(self._h, npairs, ctypes.c_void_p(dev_ptr)))
 
-    def enable_profile(self, on: bool = True):
+    def enable_profile(self, on=True):
+        """False/0 off, True/1 HIP events around every launch, 2 around the dominant NN kernel only."""
         self._check(self._lib.smhip_icp_enable_profile(self._h, int(on)))
 
     def get_profile(self) -> dict:

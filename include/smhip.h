@@ -232,6 +232,61 @@ smhip_status smhip_get_target_f32(smhip_handle h, int slot, float* xyz, float* n
 smhip_status smhip_ndt_compute_derivatives(smhip_handle h, const double pose6[6], int compute_hessian,
                                            double* score, double grad[6], double hess[36]);
 
+/* ---- registrators::NdtWithGicp (ndt_gicp.cc:28-112) ------------------------------------------
+ * ApproximateVoxelGrid (0.2 m) on both clouds -> stock pcl NDT -> stock pcl GICP; PCL is not vendored by the
+ * reference, the arithmetic follows PCL 1.8.1 (see oracle/ndt_gicp.py for the pinning).  The matcher keeps its
+ * raw clouds in private device buffers and uses pair slots 0 and 1 of the handle as working space, so the handle
+ * must be created with pair_slots >= 2, max_source_points / max_target_points >= the raw cloud sizes and
+ * max_target_points >= the down-sampled source size. */
+typedef struct smhip_ndt_gicp_options {
+  float voxel_resolution;              /* 0.2  ndt_gicp.h:73 */
+  int32_t using_voxel_filter;          /* 1    ndt_gicp.h:74 */
+  int32_t use_ndt;                     /* 1    ndt_gicp.h:75 */
+  float ndt_transformation_epsilon;    /* 0.01 ndt_gicp.cc:38 */
+  float ndt_step_size;                 /* 0.1  :39 */
+  float ndt_resolution;                /* 1.0  :40 */
+  int32_t ndt_max_iterations;          /* 35   :41 */
+  int32_t gicp_max_iterations;         /* 35   :44 */
+  double gicp_rotation_epsilon;        /* 1e-3 :43 */
+  double gicp_transformation_epsilon;  /* 5e-4 PCL default (pclomp/gicp_omp.h:117) */
+  double gicp_epsilon;                 /* 1e-3 (gicp_omp.h:109) */
+  double gicp_corr_dist_threshold;     /* 5 m  (gicp_omp.h:118) */
+  int32_t gicp_max_inner_iterations;   /* 20   (gicp_omp.h:112) */
+  int32_t gicp_k_correspondences;      /* 20   (gicp_omp.h:108) */
+  float gicp_search_cell;              /* grid cell (m) of the k-NN search behind the covariances; 0 = 4 x voxel_resolution.
+                                          Performance only: the search is exact for any cell. */
+  int32_t reserved[3];
+} smhip_ndt_gicp_options;
+
+typedef struct smhip_ndt_gicp_stats {
+  int32_t ok;                          /* Align's bool: 0 when the NDT fitness was > 1 (result = guess) */
+  int32_t n_source, n_target;          /* cloud sizes after the voxel filter */
+  int32_t ndt_iterations;
+  int32_t gicp_iterations;             /* outer iterations (nr_iterations_) */
+  int32_t gicp_function_evaluations;   /* functor evaluations of all BFGS runs */
+  int32_t gicp_correspondences;        /* kept correspondences of the last outer iteration */
+  int32_t reserved;
+  double ndt_score;                    /* ndt_.getFitnessScore() (0.9 when use_ndt = 0) */
+  double gicp_score;                   /* gicp_.getFitnessScore() (10 when skipped) */
+} smhip_ndt_gicp_stats;
+
+void smhip_ndt_gicp_default_options(smhip_ndt_gicp_options* o);
+smhip_status smhip_ndt_gicp_set_options(smhip_handle h, const smhip_ndt_gicp_options* o);
+/* SetInputSource / SetInputTarget of this matcher: raw clouds (stride 3, 4 or 5 floats), kept as handed over */
+smhip_status smhip_ndt_gicp_set_source_f32(smhip_handle h, const float* xyz, int stride_floats, int n);
+smhip_status smhip_ndt_gicp_set_target_f32(smhip_handle h, const float* xyz, int stride_floats, int n);
+/* NdtWithGicp::Align.  *score = exp(-GICP fitness) (exp(-10) when stats->ok == 0, ndt_gicp.cc:103,107). */
+smhip_status smhip_ndt_gicp_align(smhip_handle h, const double guess[16], double result[16], double* score,
+                                  smhip_ndt_gicp_stats* stats);
+/* pcl GICP alone on slot 0's clouds (smhip_set_source_f32 / smhip_set_target_f32); *fitness = getFitnessScore() */
+smhip_status smhip_gicp_align(smhip_handle h, const double guess[16], double result[16], double* fitness,
+                              smhip_ndt_gicp_stats* stats);
+/* parity-test hooks: the working clouds of the last smhip_ndt_gicp_align in the filter's output order (which = 0
+ * source, 1 target; xyz may be NULL to query the size) and the GICP covariances (n x 6 doubles: xx xy xz yy yz zz)
+ * in that same order (or the upload order for smhip_gicp_align) */
+smhip_status smhip_ndt_gicp_get_downsampled(smhip_handle h, int which, float* xyz, int capacity, int* n_out);
+smhip_status smhip_gicp_get_covariances(smhip_handle h, int which, double* cov, int n);
+
 /* ---- profiling ----------------------------------------------------------- */
 /* enable: 0 off, 1 events around every launch, 2 events around the dominant NN kernel only (cheap enough to
  * leave on inside a timed region) */

@@ -348,6 +348,64 @@ class NdtHip : public Interface {
   smhip_ndt_stats stats_{};
 };
 
+// GPU replacement of registrator::NdtWithGicp (ndt_gicp.h:39-77, ndt_gicp.cc:28-112): ApproximateVoxelGrid on both
+// clouds -> pcl NDT -> pcl GICP; score = exp(-GICP fitness), Align returns false (result = guess) when the NDT
+// fitness is > 1.  Option names are the reference's (ndt_gicp.cc:31-36).
+class NdtGicpHip : public Interface {
+ public:
+  explicit NdtGicpHip(int device = 0, int max_source = 1 << 18, int max_target = 1 << 21)
+      : device_(device), max_source_(max_source), max_target_(max_target) {
+    this->type_ = kNdtWithGicp;
+    smhip_ndt_gicp_default_options(&opt_);
+    SMHIP_REG_REGISTRATOR_INNER_OPTION("device_id", OptionItemDataType::kInt32, device_);
+    SMHIP_REG_REGISTRATOR_INNER_OPTION("use_ndt", OptionItemDataType::kBool, use_ndt_);
+    SMHIP_REG_REGISTRATOR_INNER_OPTION("using_voxel_filter", OptionItemDataType::kBool, using_voxel_filter_);
+    SMHIP_REG_REGISTRATOR_INNER_OPTION("voxel_resolution", OptionItemDataType::kFloat32, opt_.voxel_resolution);
+  }
+  ~NdtGicpHip() override { if (handle_) smhip_destroy(handle_); }
+  void InitWithOptions() override { EnsureHandle(); }
+
+  bool Align(const Matrix4d& guess, Matrix4d& result) override {      // ndt_gicp.cc:55-112
+    if (!this->source_cloud_ || !this->target_cloud_) return false;
+    EnsureHandle();
+    // ToPclPointCloud of both stored clouds on every Align (:59-76)
+    const auto& s = this->source_cloud_->GetInnerCloud();
+    const auto& t = this->target_cloud_->GetInnerCloud();
+    if (smhip_ndt_gicp_set_source_f32(handle_, &s[0].x, 5, static_cast<int>(s.size())) != SMHIP_OK ||
+        smhip_ndt_gicp_set_target_f32(handle_, &t[0].x, 5, static_cast<int>(t.size())) != SMHIP_OK) {
+      std::fprintf(stderr, "[ERROR] NdtGicpHip: %s\n", smhip_last_error(handle_));
+      return false;
+    }
+    double score = 0.0;
+    const smhip_status st = smhip_ndt_gicp_align(handle_, guess.data(), result.data(), &score, &stats_);
+    if (st != SMHIP_OK) {
+      std::fprintf(stderr, "[ERROR] NdtGicpHip::Align: %s (%s)\n", smhip_status_string(st), smhip_last_error(handle_));
+      result = guess;
+      return false;
+    }
+    this->final_score_ = score;                                       // :102 / :107
+    return stats_.ok != 0;
+  }
+  const smhip_ndt_gicp_stats& LastStats() const { return stats_; }
+
+ private:
+  void EnsureHandle() {
+    if (!handle_) {
+      const smhip_status s = smhip_create(device_, nullptr, 2, max_source_, max_target_ > max_source_ ? max_target_ : max_source_, &handle_);
+      SMHIP_CHECK(s == SMHIP_OK, "no usable MI355X (gfx950) device: there is no CPU fallback");
+    }
+    opt_.use_ndt = use_ndt_ ? 1 : 0;
+    opt_.using_voxel_filter = using_voxel_filter_ ? 1 : 0;
+    SMHIP_CHECK(smhip_ndt_gicp_set_options(handle_, &opt_) == SMHIP_OK, "smhip_ndt_gicp_set_options");
+  }
+  smhip_ndt_gicp_options opt_;
+  bool use_ndt_ = true, using_voxel_filter_ = true;
+  int32_t device_ = 0;
+  int max_source_, max_target_;
+  smhip_handle handle_ = nullptr;
+  smhip_ndt_gicp_stats stats_{};
+};
+
 // GPU replacement of registrator::IcpUsingPointMatcher (icp_pointmatcher.cc:104-247): the
 // libpointmatcher chain RandomSampling(0.9) -> SamplingSurfaceNormal(knn 7, method 1) -> KDTree(1-NN)
 // -> TrimmedDist(0.7) -> PointToPlane -> Counter(150) + Differential(1e-3, 1e-2, 4), followed by the
@@ -448,6 +506,9 @@ inline std::shared_ptr<Interface> CreateMatcher(const MatcherOptions& options, b
       break;
     case kIcpPM:
       matcher.reset(new IcpPointMatcherHip(options.device));
+      break;
+    case kNdtWithGicp:
+      matcher.reset(new NdtGicpHip(options.device));
       break;
     default:
       std::fprintf(stderr, "[ERROR] Wrong type\n");

@@ -113,8 +113,10 @@ def gauss_constants(resolution=1.0, outlier_ratio=0.55):
     return d1, d2, d3
 
 
-def angle_derivatives(p):
-    """ndt_omp_impl.hpp:288-393: j_ang (8x4 float) and h_ang (16x4 float, 15 rows used)."""
+def angle_derivatives(p, real=None):
+    """ndt_omp_impl.hpp:288-393: j_ang (8x4 float) and h_ang (16x4 float, 15 rows used); `real`=float64 for
+    stock PCL (double rows)."""
+    F = np.float32 if real is None else real
     def cs(a):
         return (1.0, 0.0) if abs(a) < 10e-5 else (np.cos(a), np.sin(a))
     cx, sx = cs(p[3]); cy, sy = cs(p[4]); cz, sz = cs(p[5])
@@ -146,13 +148,17 @@ def angle_derivatives(p):
     return j, h
 
 
-def compute_derivatives(grid: VoxelGrid, src_f32, trans_f32, p, d1, d2, compute_hessian=True, pairs=None):
+def compute_derivatives(grid: VoxelGrid, src_f32, trans_f32, p, d1, d2, compute_hessian=True, pairs=None, real=None):
     """ndt_omp_impl.hpp:180-284 + 397-438 + 483-535.  Returns (score, gradient[6], hessian[6,6], n_pairs).
     `pairs` = (point idx, voxel idx) freezes the neighbourhoods (tests only: the score itself jumps
-    whenever a point crosses a radius-search boundary, so finite differences need a fixed set)."""
-    x = np.asarray(src_f32, dtype=F)[:, :3]
-    xt = np.asarray(trans_f32, dtype=F)[:, :3]
-    j_ang, h_ang = angle_derivatives(p)
+    whenever a point crosses a radius-search boundary, so finite differences need a fixed set).
+    `real` = arithmetic type of the per-neighbour math: float32 restates pclomp (the default), float64
+    restates stock pcl::NormalDistributionsTransform (PCL 1.8.1 ndt.hpp, same formulas in double) which
+    registrators/ndt_gicp.cc uses."""
+    F = np.float32 if real is None else real
+    x = np.asarray(src_f32, dtype=np.float32)[:, :3].astype(F)
+    xt = np.asarray(trans_f32, dtype=np.float32)[:, :3].astype(F)
+    j_ang, h_ang = angle_derivatives(p, F)
     pi, vi = grid.radius_pairs(xt) if pairs is None else pairs
     g = np.zeros(6)
     H = np.zeros((6, 6))
@@ -297,7 +303,7 @@ def _trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, f_t, g_t):
 
 
 def ndt_align(source_f32, target_f32, guess=None, resolution=1.0, step_size=0.1, outlier_ratio=0.55,
-              trans_eps=0.1, max_iterations=35, grid: VoxelGrid | None = None, with_fitness=True, trace=None):
+              trans_eps=0.1, max_iterations=35, grid: VoxelGrid | None = None, with_fitness=True, trace=None, real=None):
     """registrators/ndt.cc:38-64 -> pclomp computeTransformation (ndt_omp_impl.hpp:81-171).
 
     Returns dict(result 4x4 float64 (source->target), score = getFitnessScore() (mean squared 1-NN
@@ -317,7 +323,7 @@ def ndt_align(source_f32, target_f32, guess=None, resolution=1.0, step_size=0.1,
     p[:3] = final[:3, 3].astype(np.float64)                                          # :107-111
     p[3:] = euler_xyz_from_matrix(final[:3, :3]).astype(F).astype(np.float64)        # Vector3f eulerAngles
     calls = 0
-    score, g, H, _ = compute_derivatives(grid, src, trans, p, d1, d2, True); calls += 1    # :119
+    score, g, H, _ = compute_derivatives(grid, src, trans, p, d1, d2, True, real=real); calls += 1    # :119
     it = 0
     converged = False
     while not converged:                                                             # :121
@@ -349,7 +355,7 @@ def ndt_align(source_f32, target_f32, guess=None, resolution=1.0, step_size=0.1,
             x_t = p + step_dir * a_t
             final = pose_to_matrix_f32(x_t)                                          # :803-806
             trans = transform_cloud_f32(src, final)                                  # :809
-            score, g, H, _ = compute_derivatives(grid, src, trans, x_t, d1, d2, True); calls += 1   # :813
+            score, g, H, _ = compute_derivatives(grid, src, trans, x_t, d1, d2, True, real=real); calls += 1   # :813
             phi_t = -score; d_phi_t = -(g @ step_dir)
             psi_t = _psi(a_t, phi_t, phi_0, d_phi_0, mu); d_psi_t = _dpsi(d_phi_t, d_phi_0, mu)
             step_iterations = 0
@@ -362,7 +368,7 @@ def ndt_align(source_f32, target_f32, guess=None, resolution=1.0, step_size=0.1,
                 x_t = p + step_dir * a_t
                 final = pose_to_matrix_f32(x_t)
                 trans = transform_cloud_f32(src, final)
-                score, g, _, _ = compute_derivatives(grid, src, trans, x_t, d1, d2, False); calls += 1
+                score, g, _, _ = compute_derivatives(grid, src, trans, x_t, d1, d2, False, real=real); calls += 1
                 phi_t = -score; d_phi_t = -(g @ step_dir)
                 psi_t = _psi(a_t, phi_t, phi_0, d_phi_0, mu); d_psi_t = _dpsi(d_phi_t, d_phi_0, mu)
                 if open_interval and (psi_t <= 0 and d_psi_t >= 0):
@@ -375,7 +381,7 @@ def ndt_align(source_f32, target_f32, guess=None, resolution=1.0, step_size=0.1,
                     a_l, f_l, g_l, a_u, f_u, g_u, interval_converged = _update_interval(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t)
                 step_iterations += 1
             if step_iterations:                                                      # :912-913
-                _, _, H, _ = compute_derivatives(grid, src, trans, x_t, d1, d2, True); calls += 1
+                _, _, H, _ = compute_derivatives(grid, src, trans, x_t, d1, d2, True, real=real); calls += 1
         dp_norm = a_t                                                                # :142
         dp = step_dir * dp_norm                                                      # :143
         p = p + dp                                                                   # :152

@@ -46,6 +46,24 @@ class NdtStats(ctypes.Structure):
                 ("status", ctypes.c_int32), ("trans_probability", ctypes.c_double), ("pairs_last", ctypes.c_double)]
 
 
+class NdtGicpOptions(ctypes.Structure):
+    _fields_ = [("voxel_resolution", ctypes.c_float), ("using_voxel_filter", ctypes.c_int32), ("use_ndt", ctypes.c_int32),
+                ("ndt_transformation_epsilon", ctypes.c_float), ("ndt_step_size", ctypes.c_float),
+                ("ndt_resolution", ctypes.c_float), ("ndt_max_iterations", ctypes.c_int32),
+                ("gicp_max_iterations", ctypes.c_int32), ("gicp_rotation_epsilon", ctypes.c_double),
+                ("gicp_transformation_epsilon", ctypes.c_double), ("gicp_epsilon", ctypes.c_double),
+                ("gicp_corr_dist_threshold", ctypes.c_double), ("gicp_max_inner_iterations", ctypes.c_int32),
+                ("gicp_k_correspondences", ctypes.c_int32), ("gicp_search_cell", ctypes.c_float),
+                ("reserved", ctypes.c_int32 * 3)]
+
+
+class NdtGicpStats(ctypes.Structure):
+    _fields_ = [("ok", ctypes.c_int32), ("n_source", ctypes.c_int32), ("n_target", ctypes.c_int32),
+                ("ndt_iterations", ctypes.c_int32), ("gicp_iterations", ctypes.c_int32),
+                ("gicp_function_evaluations", ctypes.c_int32), ("gicp_correspondences", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("ndt_score", ctypes.c_double), ("gicp_score", ctypes.c_double)]
+
+
 # name -> (restype, argtypes): every symbol include/smhip.h declares
 SIGNATURES = {
     "smhip_version": (ctypes.c_int, []),
@@ -85,6 +103,14 @@ SIGNATURES = {
     "smhip_ndt_build_voxels": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
     "smhip_ndt_get_voxels": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int32_p, c_int32_p, c_double_p, c_float_p, c_float_p]),
     "smhip_ndt_compute_derivatives": (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int, c_double_p, c_double_p, c_double_p]),
+    "smhip_ndt_gicp_default_options": (None, [ctypes.POINTER(NdtGicpOptions)]),
+    "smhip_ndt_gicp_set_options": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(NdtGicpOptions)]),
+    "smhip_ndt_gicp_set_source_f32": (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int]),
+    "smhip_ndt_gicp_set_target_f32": (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int]),
+    "smhip_ndt_gicp_align": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p, ctypes.POINTER(NdtGicpStats)]),
+    "smhip_gicp_align": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p, ctypes.POINTER(NdtGicpStats)]),
+    "smhip_ndt_gicp_get_downsampled": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    "smhip_gicp_get_covariances": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, ctypes.c_int]),
     "smhip_icp_enable_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "smhip_icp_get_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(IcpProfile)]),
 }

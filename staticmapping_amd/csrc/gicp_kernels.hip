@@ -1,0 +1,237 @@
+// gicp_kernels.hip -- device side of the GICP stage of registrators::NdtWithGicp.
+//
+// /root/reference/registrators/ndt_gicp.cc:94-103 runs stock pcl::GeneralizedIterativeClosestPoint (PCL 1.8.1,
+// not vendored).  The in-tree fork registrators/pclomp/gicp_omp_impl.hpp carries the same statements; lines below
+// are the fork's:
+//   gicp_knn_cov   computeCovariances                      :59-131
+//   gicp_corr      correspondence filter + Mahalanobis     :441-463
+//   gicp_fdf       OptimizationFunctorWithIndices f/df/fdf :250-377 (the sums; the 6-vector tail is host code)
+// The BFGS minimiser (pcl/registration/bfgs.h) and the outer loop run on the host in smhip_gicp_api.hip.
+#pragma once
+#include "smhip_device.h"
+
+namespace smhip {
+
+constexpr int kGicpKMax = 32;                // k_correspondences_ <= 32 (default 20)
+constexpr int kGicpKnnThreads = 128;
+constexpr int kGicpCols = 16;                // f, g_t[3], R[9], count, 2 spare
+constexpr int kGicpMaxBlocks = 1024;
+
+struct GicpDev {
+  double* cov_s;           // [ns_cap][6] source covariances, index = position in slot 0's src array
+  double* cov_t;           // [nt_cap][6] target covariances, index = position in slot 0's tgt_p array
+  double* maha;            // [ns_cap][6] mahalanobis_[i] (symmetric): xx xy xz yy yz zz
+  float4* qraw;            // [ns_cap] matched raw target point; w = 1 if the correspondence is kept
+  double* partials;        // [kGicpMaxBlocks][kGicpCols]
+  double* out;             // [kGicpCols]
+  uint32_t* count;         // kept correspondences
+};
+
+// symmetric 3x3 (xx xy xz yy yz zz) helpers
+__device__ __forceinline__ void sym_inverse(const double* a, double* o) {
+  const double c00 = a[3] * a[5] - a[4] * a[4], c01 = a[2] * a[4] - a[1] * a[5], c02 = a[1] * a[4] - a[2] * a[3];
+  const double det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+  const double id = 1.0 / det;
+  o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
+  o[3] = (a[0] * a[5] - a[2] * a[2]) * id; o[4] = (a[1] * a[2] - a[0] * a[4]) * id;
+  o[5] = (a[0] * a[3] - a[1] * a[1]) * id;
+}
+
+// k nearest neighbours of every target point of `pair` among that same target (the point itself included, as
+// nearestKSearch returns it), then the regularised covariance.  One query per thread; the sorted best-k list
+// lives in LDS (k x 128 threads x 8 B).  Search = shells of grid cells around the query's cell; inside a shell
+// the x-extent of a grid row is one contiguous run of the cell-sorted target (row_slots).  A shell ends the
+// search once the k-th distance is within the distance to the nearest unexplored face (block_guarantee).
+// cov is indexed by the point's position in the pair's raw target array (tq.w), so it survives grid rebuilds.
+__global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pair, int k, double gicp_epsilon, double* cov) {
+  __shared__ float s_d[kGicpKMax][kGicpKnnThreads];
+  __shared__ int s_j[kGicpKMax][kGicpKnnThreads];
+  const PairState* st = &b.state[pair];
+  const int nt = st->nt;
+  const int j0 = blockIdx.x * kGicpKnnThreads + threadIdx.x;
+  if (j0 >= nt) return;
+  const int t = threadIdx.x;
+  const float4* tq = b.tq + (size_t)pair * b.nt_cap;
+  const uint2* words = b.words + (size_t)pair * kMaxGridWords;
+  const uint32_t* cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
+  const float4 q = tq[j0];
+  for (int m = 0; m < k; ++m) { s_d[m][t] = INFINITY; s_j[m][t] = -1; }
+  float worst = INFINITY;                     // s_d[k - 1][t]
+  const int cx = min(max(cell_coord(q.x, st->origin[0], st->inv_h), 0), st->nx - 1);
+  const int cy = min(max(cell_coord(q.y, st->origin[1], st->inv_h), 0), st->ny - 1);
+  const int cz = min(max(cell_coord(q.z, st->origin[2], st->inv_h), 0), st->nz - 1);
+  auto scan = [&](int rowbase, int xa, int xb) {
+    uint32_t sa, sb;
+    row_slots(words, rowbase, xa, xb, sa, sb);
+    const uint32_t pa = cstart[sa], pb = cstart[sb];
+    for (uint32_t p = pa; p < pb; ++p) {
+      const float d = dist2(tq[p], q.x, q.y, q.z);
+      if (!(d < worst)) continue;
+      int m = k - 1;                           // insertion into the ascending list
+      while (m > 0 && s_d[m - 1][t] > d) { s_d[m][t] = s_d[m - 1][t]; s_j[m][t] = s_j[m - 1][t]; --m; }
+      s_d[m][t] = d; s_j[m][t] = (int)p;
+      worst = s_d[k - 1][t];
+    }
+  };
+  const int rmax = max(max(st->nx, st->ny), st->nz);
+  for (int r = 0; r <= rmax; ++r) {
+    const int X0 = max(cx - r, 0), X1 = min(cx + r, st->nx - 1);
+    for (int dz = -r; dz <= r; ++dz) {
+      const int z = cz + dz;
+      if (z < 0 || z >= st->nz) continue;
+      for (int dy = -r; dy <= r; ++dy) {
+        const int y = cy + dy;
+        if (y < 0 || y >= st->ny) continue;
+        const int rowbase = (z * st->ny + y) * st->wx;
+        if (max(abs(dz), abs(dy)) == r) {
+          scan(rowbase, X0, X1);               // a face row of the shell: its whole x extent
+        } else {                                // an inner row: only the two end cells belong to the shell
+          if (cx - r >= 0) scan(rowbase, cx - r, cx - r);
+          if (cx + r < st->nx) scan(rowbase, cx + r, cx + r);
+        }
+      }
+    }
+    const float g = block_guarantee(st, q.x, q.y, q.z, X0, X1, max(cy - r, 0), min(cy + r, st->ny - 1), max(cz - r, 0),
+                                    min(cz + r, st->nz - 1));
+    if (g == INFINITY) break;                   // the block covers the grid
+    if (g > 0.f && worst <= g * g) break;
+  }
+  // covariance of the k neighbours from the RAW coordinates; the products pt.x * pt.y are float products (:95-103)
+  const float4* raw = b.tgt_p + (size_t)pair * b.nt_cap;
+  double mean[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
+  for (int m = 0; m < k; ++m) {
+    const int jj = s_j[m][t];
+    const float4 p = raw[__float_as_int(tq[jj].w)];
+    mean[0] += p.x; mean[1] += p.y; mean[2] += p.z;
+    const float xx = p.x * p.x, yx = p.y * p.x, yy = p.y * p.y, zx = p.z * p.x, zy = p.z * p.y, zz = p.z * p.z;
+    c[0] += (double)xx; c[1] += (double)yx; c[2] += (double)zx; c[3] += (double)yy; c[4] += (double)zy; c[5] += (double)zz;
+  }
+  const double kk = (double)k;
+  for (int a = 0; a < 3; ++a) mean[a] /= kk;
+  double A[9], V[9], w[3];
+  A[0] = c[0] / kk - mean[0] * mean[0];
+  A[1] = A[3] = c[1] / kk - mean[1] * mean[0];
+  A[2] = A[6] = c[2] / kk - mean[2] * mean[0];
+  A[4] = c[3] / kk - mean[1] * mean[1];
+  A[5] = A[7] = c[4] / kk - mean[2] * mean[1];
+  A[8] = c[5] / kk - mean[2] * mean[2];
+  jacobi_eig3(A, V, w);                         // ascending eigenvalues, eigenvectors in the columns of V
+  // JacobiSVD orders by singular value = |eigenvalue|: the direction that gets gicp_epsilon is the smallest |w|
+  int col = 0;
+  if (fabs(w[1]) < fabs(w[col])) col = 1;
+  if (fabs(w[2]) < fabs(w[col])) col = 2;
+  const double u0 = V[col], u1 = V[3 + col], u2 = V[6 + col];
+  const double s = 1.0 - gicp_epsilon;          // U diag(1, 1, eps) U^T = I - (1 - eps) u3 u3^T  (:118-129)
+  double* o = cov + (size_t)__float_as_int(q.w) * 6;
+  o[0] = 1.0 - s * u0 * u0; o[1] = -s * u0 * u1; o[2] = -s * u0 * u2;
+  o[3] = 1.0 - s * u1 * u1; o[4] = -s * u1 * u2; o[5] = 1.0 - s * u2 * u2;
+}
+
+// per source point: keep the correspondence if d2 < threshold^2 and store (R C1 R^T + C2)^-1 and the raw target point
+__global__ __launch_bounds__(256) void gicp_corr(IcpDev b, GicpDev g, int ns, float thr2, const double* Rrm /*3x3 row-major, device*/) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool keep = false;
+  if (i < ns) {
+    const int j = b.idx[i];
+    const float d2 = b.d2[i];
+    if (j >= 0 && d2 < thr2) {                                                       // :449
+      keep = true;
+      const int orig = __float_as_int(b.tq[j].w);
+      const double* C1 = g.cov_s + (size_t)i * 6;
+      const double* C2 = g.cov_t + (size_t)orig * 6;
+      const double c1[9] = {C1[0], C1[1], C1[2], C1[1], C1[3], C1[4], C1[2], C1[4], C1[5]};
+      double M[9];                                                                   // M = R * C1
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) M[3 * r + c] = Rrm[3 * r] * c1[c] + Rrm[3 * r + 1] * c1[3 + c] + Rrm[3 * r + 2] * c1[6 + c];
+      double T[6];                                                                   // temp = M * R^T + C2 (symmetric)
+      int e = 0;
+      for (int r = 0; r < 3; ++r)
+        for (int c = r; c < 3; ++c) {
+          const double full[9] = {C2[0], C2[1], C2[2], C2[1], C2[3], C2[4], C2[2], C2[4], C2[5]};
+          T[e++] = M[3 * r] * Rrm[3 * c] + M[3 * r + 1] * Rrm[3 * c + 1] + M[3 * r + 2] * Rrm[3 * c + 2] + full[3 * r + c];
+        }
+      sym_inverse(T, g.maha + (size_t)i * 6);                                         // :459
+      float4 p = b.tgt_p[orig];
+      p.w = 1.f;
+      g.qraw[i] = p;
+    } else {
+      g.qraw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const unsigned long long m = __ballot(keep);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(g.count, (uint32_t)__popcll(m));
+}
+
+struct GicpPose {
+  float T[12];             // applyState(base_transformation_, x), rows 0..2
+  float B[12];             // base_transformation_ (the guess), rows 0..2
+};
+
+// sums of the functor over the kept correspondences: f (:272), g_t (:316-318), R (:320-321)
+__global__ __launch_bounds__(256) void gicp_fdf(IcpDev b, GicpDev g, int ns, GicpPose P) {
+  double acc[13];
+#pragma unroll
+  for (int k = 0; k < 13; ++k) acc[k] = 0.0;
+  double cnt = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+    const float4 q = g.qraw[i];
+    if (q.w == 0.f) continue;
+    const float4 s = b.src[i];
+    // Eigen Matrix4f * Vector4f: column by column accumulation in float
+    const float px = ((P.T[0] * s.x + P.T[1] * s.y) + P.T[2] * s.z) + P.T[3];
+    const float py = ((P.T[4] * s.x + P.T[5] * s.y) + P.T[6] * s.z) + P.T[7];
+    const float pz = ((P.T[8] * s.x + P.T[9] * s.y) + P.T[10] * s.z) + P.T[11];
+    const double r0 = (double)(px - q.x), r1 = (double)(py - q.y), r2 = (double)(pz - q.z);      // float differences (:268)
+    const double* M = g.maha + (size_t)i * 6;
+    const double t0 = M[0] * r0 + M[1] * r1 + M[2] * r2;
+    const double t1 = M[1] * r0 + M[3] * r1 + M[4] * r2;
+    const double t2 = M[2] * r0 + M[4] * r1 + M[5] * r2;
+    acc[0] += r0 * t0 + r1 * t1 + r2 * t2;
+    acc[1] += t0; acc[2] += t1; acc[3] += t2;
+    const double bx = (double)(((P.B[0] * s.x + P.B[1] * s.y) + P.B[2] * s.z) + P.B[3]);         // base_transformation_ * p_src
+    const double by = (double)(((P.B[4] * s.x + P.B[5] * s.y) + P.B[6] * s.z) + P.B[7]);
+    const double bz = (double)(((P.B[8] * s.x + P.B[9] * s.y) + P.B[10] * s.z) + P.B[11]);
+    acc[4] += bx * t0; acc[5] += bx * t1; acc[6] += bx * t2;                                      // R += p_src3 * temp^T
+    acc[7] += by * t0; acc[8] += by * t1; acc[9] += by * t2;
+    acc[10] += bz * t0; acc[11] += bz * t1; acc[12] += bz * t2;
+    cnt += 1.0;
+  }
+  __shared__ double s_red[4][kGicpCols];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 13; ++k) acc[k] = wave_sum(acc[k]);
+  cnt = wave_sum(cnt);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 13; ++k) s_red[wave][k] = acc[k];
+    s_red[wave][13] = cnt; s_red[wave][14] = 0; s_red[wave][15] = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x < kGicpCols)
+    g.partials[(size_t)blockIdx.x * kGicpCols + threadIdx.x] =
+        s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+}
+
+// fixed-order fold of the block partials (repeated evaluations at one x are bitwise identical)
+__global__ __launch_bounds__(16 * 64) void gicp_reduce(GicpDev g, int nblocks) {
+  __shared__ double s_g[16][kGicpCols];
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  if (c < kGicpCols) {
+    double t = 0;
+    for (int k = grp; k < nblocks; k += 16) t += g.partials[(size_t)k * kGicpCols + c];
+    s_g[grp][c] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < kGicpCols) {
+    double t = 0;
+    for (int k = 0; k < 16; ++k) t += s_g[k][threadIdx.x];
+    g.out[threadIdx.x] = t;
+  }
+}
+
+__global__ void gicp_copy_points(const float4* from, float4* to, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) to[i] = from[i];
+}
+
+}  // namespace smhip

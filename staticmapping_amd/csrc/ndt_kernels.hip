@@ -52,6 +52,7 @@ struct NdtDev {
   uint32_t* vstart;        // [nt + 1]
   float4* vpts;            // [nt] points sorted by voxel
   NdtVoxel* vox;           // [nt] one record per occupied voxel
+  double* icovd;           // [nt][6] Leaf::icov_ in double: xx xy xz yy yz zz (stock PCL path reads these)
   double* partials;        // [kNdtMaxDerivBlocks][kNdtDerivCols]
   double* out;             // [kNdtDerivCols]
 };
@@ -61,7 +62,9 @@ struct NdtPose {           // per derivative evaluation
   float j_ang[8][3];       // computeAngleDerivatives (float rows)
   float h_ang[15][3];
   float d1, d2;            // gauss_d1_, gauss_d2_ (d1 kept in double on the host too, see use)
-  double d1d;
+  double d1d, d2d;
+  double j_angd[8][3];     // the same rows in double (stock PCL path)
+  double h_angd[15][3];
   float res2;              // resolution^2 for the centroid radius test
   int32_t compute_hessian;
 };
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(256) void ndt_voxel_stats(NdtDev d) {
   for (int k = 0; k < 3; ++k) o.centroid[k] = cs[k] / (float)n;      // :289
   const double mean[3] = {s[0] / nn, s[1] / nn, s[2] / nn};          // :293
   for (int k = 0; k < 3; ++k) o.mean[k] = mean[k];
-  for (int k = 0; k < 6; ++k) o.icov[k] = 0.f;
+  for (int k = 0; k < 6; ++k) { o.icov[k] = 0.f; d.icovd[(size_t)v * 6 + k] = 0.0; }
   o.n = n;
   if (n < d.min_points) return;                                      // :297 (not searchable)
   // cov_ started as identity (Leaf ctor), :329-330
@@ -285,18 +288,25 @@ __global__ __launch_bounds__(256) void ndt_voxel_stats(NdtDev d) {
   if (bad) { o.n = -1; return; }                                     // :360-364
   o.icov[0] = (float)I[0]; o.icov[1] = (float)I[1]; o.icov[2] = (float)I[2];
   o.icov[3] = (float)I[4]; o.icov[4] = (float)I[5]; o.icov[5] = (float)I[8];
+  double* oi = d.icovd + (size_t)v * 6;
+  oi[0] = I[0]; oi[1] = I[1]; oi[2] = I[2]; oi[3] = I[4]; oi[4] = I[5]; oi[5] = I[8];
 }
 
 // ------------------------------------------------------------------------------------------
 // derivatives
 // ------------------------------------------------------------------------------------------
+// R = float restates pclomp (ndt_omp_impl.hpp: Matrix<float,4,6> math); R = double restates stock
+// pcl::NormalDistributionsTransform (PCL 1.8.1 ndt.hpp: the same formulas on Vector3d / Matrix3d), which
+// registrators/ndt_gicp.cc:38-41,84-89 uses.
+template <typename R>
 __global__ __launch_bounds__(kNdtDerivThreads) void ndt_derivatives(NdtDev d, NdtPose P) {
+  constexpr bool kDouble = sizeof(R) == 8;
   const NdtGridInfo* g = d.info;
   double acc[43];
 #pragma unroll
   for (int k = 0; k < 43; ++k) acc[k] = 0.0;
   double pairs = 0;
-  const float gd2 = P.d2;
+  const R gd2 = kDouble ? (R)P.d2d : (R)P.d2;
   for (int i = blockIdx.x * kNdtDerivThreads + threadIdx.x; i < d.ns; i += gridDim.x * kNdtDerivThreads) {
     const float4 s = d.src[i];
     if (!(isfinite(s.x) && isfinite(s.y) && isfinite(s.z))) continue;
@@ -309,13 +319,17 @@ __global__ __launch_bounds__(kNdtDerivThreads) void ndt_derivatives(NdtDev d, Nd
     const int c1 = (int)(floorf(ty * g->inv) - (float)g->min_b[1]);
     const int c2 = (int)(floorf(tz * g->inv) - (float)g->min_b[2]);
     // point gradient (4x6 float): identity + 8 angular entries, :397-412
-    float pg[8];
+    R pg[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) pg[r] = P.j_ang[r][0] * s.x + P.j_ang[r][1] * s.y + P.j_ang[r][2] * s.z;
-    float ph[15];
+    for (int r = 0; r < 8; ++r)
+      pg[r] = kDouble ? (R)(P.j_angd[r][0] * (double)s.x + P.j_angd[r][1] * (double)s.y + P.j_angd[r][2] * (double)s.z)
+                      : (R)(P.j_ang[r][0] * s.x + P.j_ang[r][1] * s.y + P.j_ang[r][2] * s.z);
+    R ph[15];
     if (P.compute_hessian) {
 #pragma unroll
-      for (int r = 0; r < 15; ++r) ph[r] = P.h_ang[r][0] * s.x + P.h_ang[r][1] * s.y + P.h_ang[r][2] * s.z;   // :416
+      for (int r = 0; r < 15; ++r)                                                                             // :416
+        ph[r] = kDouble ? (R)(P.h_angd[r][0] * (double)s.x + P.h_angd[r][1] * (double)s.y + P.h_angd[r][2] * (double)s.z)
+                        : (R)(P.h_ang[r][0] * s.x + P.h_ang[r][1] * s.y + P.h_ang[r][2] * s.z);
     }
     double score_pt = 0, g_pt[6] = {0, 0, 0, 0, 0, 0};
     double h_pt[36];
@@ -342,49 +356,55 @@ __global__ __launch_bounds__(kNdtDerivThreads) void ndt_derivatives(NdtDev d, Nd
           if (ex * ex + ey * ey + ez * ez > P.res2) continue;        // radiusSearch(x_trans, resolution_), :235
           pairs += 1.0;
           // x_trans - mean in double, then float (:253, :490)
-          const float u0 = (float)((double)tx - vx.mean[0]), u1 = (float)((double)ty - vx.mean[1]), u2 = (float)((double)tz - vx.mean[2]);
-          const float cxx = vx.icov[0], cxy = vx.icov[1], cxz = vx.icov[2], cyy = vx.icov[3], cyz = vx.icov[4], czz = vx.icov[5];
+          const R u0 = (R)((double)tx - vx.mean[0]), u1 = (R)((double)ty - vx.mean[1]), u2 = (R)((double)tz - vx.mean[2]);
+          R cxx, cxy, cxz, cyy, cyz, czz;
+          if (kDouble) {
+            const double* ic = d.icovd + (size_t)slot * 6;
+            cxx = (R)ic[0]; cxy = (R)ic[1]; cxz = (R)ic[2]; cyy = (R)ic[3]; cyz = (R)ic[4]; czz = (R)ic[5];
+          } else {
+            cxx = vx.icov[0]; cxy = vx.icov[1]; cxz = vx.icov[2]; cyy = vx.icov[3]; cyz = vx.icov[4]; czz = vx.icov[5];
+          }
           // x_trans4 * c_inv4
-          const float v0 = u0 * cxx + u1 * cxy + u2 * cxz;
-          const float v1 = u0 * cxy + u1 * cyy + u2 * cyz;
-          const float v2 = u0 * cxz + u1 * cyz + u2 * czz;
-          const float q = u0 * v0 + u1 * v1 + u2 * v2;
-          float e = expf(-gd2 * q * 0.5f);                           // :497
-          const float score_inc = (float)(-P.d1d * (double)e);       // :499
+          const R v0 = u0 * cxx + u1 * cxy + u2 * cxz;
+          const R v1 = u0 * cxy + u1 * cyy + u2 * cyz;
+          const R v2 = u0 * cxz + u1 * cyz + u2 * czz;
+          const R q = u0 * v0 + u1 * v1 + u2 * v2;
+          R e = kDouble ? (R)exp(-(double)gd2 * (double)q / 2) : (R)expf(-(float)gd2 * (float)q * 0.5f);   // :497
+          const R score_inc = (R)(-P.d1d * (double)e);               // :499
           e = gd2 * e;                                               // :501
-          if (e > 1.f || e < 0.f || e != e) continue;                // :504-505
-          e = (float)(P.d1d * (double)e);                            // :508
+          if (e > (R)1 || e < (R)0 || e != e) continue;              // :504-505
+          e = (R)(P.d1d * (double)e);                                // :508
           score_pt += (double)score_inc;
           // columns of c_inv4 * point_gradient4: col 0..2 = columns of C; col 3..5 from the angular entries
           // J col3 = (0, pg0, pg1), col4 = (pg2, pg3, pg4), col5 = (pg5, pg6, pg7)
-          float CJ[6][3];
+          R CJ[6][3];
           CJ[0][0] = cxx; CJ[0][1] = cxy; CJ[0][2] = cxz;
           CJ[1][0] = cxy; CJ[1][1] = cyy; CJ[1][2] = cyz;
           CJ[2][0] = cxz; CJ[2][1] = cyz; CJ[2][2] = czz;
           CJ[3][0] = cxy * pg[0] + cxz * pg[1]; CJ[3][1] = cyy * pg[0] + cyz * pg[1]; CJ[3][2] = cyz * pg[0] + czz * pg[1];
           CJ[4][0] = cxx * pg[2] + cxy * pg[3] + cxz * pg[4]; CJ[4][1] = cxy * pg[2] + cyy * pg[3] + cyz * pg[4]; CJ[4][2] = cxz * pg[2] + cyz * pg[3] + czz * pg[4];
           CJ[5][0] = cxx * pg[5] + cxy * pg[6] + cxz * pg[7]; CJ[5][1] = cxy * pg[5] + cyy * pg[6] + cyz * pg[7]; CJ[5][2] = cxz * pg[5] + cyz * pg[6] + czz * pg[7];
-          float xCJ[6];
+          R xCJ[6];
 #pragma unroll
           for (int c = 0; c < 6; ++c) xCJ[c] = u0 * CJ[c][0] + u1 * CJ[c][1] + u2 * CJ[c][2];     // :511
 #pragma unroll
           for (int c = 0; c < 6; ++c) g_pt[c] += (double)(e * xCJ[c]);                              // :513
           if (P.compute_hessian) {
             // J columns as 3-vectors
-            float Jc[6][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, pg[0], pg[1]}, {pg[2], pg[3], pg[4]}, {pg[5], pg[6], pg[7]}};
+            R Jc[6][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, pg[0], pg[1]}, {pg[2], pg[3], pg[4]}, {pg[5], pg[6], pg[7]}};
             // x_trans4_x_c_inv4 . point_hessian block (i, j): only i, j in 3..5 are non-zero, :418-437
             // a=(0,ph0,ph1) b=(0,ph2,ph3) c=(0,ph4,ph5) d=(ph6,ph7,ph8) e=(ph9,ph10,ph11) f=(ph12,ph13,ph14)
-            const float ha = v1 * ph[0] + v2 * ph[1], hb = v1 * ph[2] + v2 * ph[3], hc = v1 * ph[4] + v2 * ph[5];
-            const float hd = v0 * ph[6] + v1 * ph[7] + v2 * ph[8], he = v0 * ph[9] + v1 * ph[10] + v2 * ph[11];
-            const float hf = v0 * ph[12] + v1 * ph[13] + v2 * ph[14];
-            const float xH[3][3] = {{ha, hb, hc}, {hb, hd, he}, {hc, he, hf}};     // [i-3][j-3]
+            const R ha = v1 * ph[0] + v2 * ph[1], hb = v1 * ph[2] + v2 * ph[3], hc = v1 * ph[4] + v2 * ph[5];
+            const R hd = v0 * ph[6] + v1 * ph[7] + v2 * ph[8], he = v0 * ph[9] + v1 * ph[10] + v2 * ph[11];
+            const R hf = v0 * ph[12] + v1 * ph[13] + v2 * ph[14];
+            const R xH[3][3] = {{ha, hb, hc}, {hb, hd, he}, {hc, he, hf}};     // [i-3][j-3]
 #pragma unroll
             for (int a = 0; a < 6; ++a)
 #pragma unroll
               for (int c = 0; c < 6; ++c) {
                 // point_gradient4.col(j) . (c_inv4 * point_gradient4.col(i))  -> (j, i) entry, :517, :529
-                const float jcj = Jc[c][0] * CJ[a][0] + Jc[c][1] * CJ[a][1] + Jc[c][2] * CJ[a][2];
-                const float hh = (a >= 3 && c >= 3) ? xH[a - 3][c - 3] : 0.f;
+                const R jcj = Jc[c][0] * CJ[a][0] + Jc[c][1] * CJ[a][1] + Jc[c][2] * CJ[a][2];
+                const R hh = (a >= 3 && c >= 3) ? xH[a - 3][c - 3] : (R)0;
                 h_pt[6 * a + c] += (double)(e * (-gd2 * xCJ[a] * xCJ[c] + hh + jcj));               // :527-529
               }
           }

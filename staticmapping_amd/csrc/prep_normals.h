@@ -17,4 +17,7 @@ hipError_t prep_calculate_normals_batch(PrepWorkspace* w, hipStream_t st, const 
                                         const int* n, const int* out_offset, float4* out_p, float4* out_n, int* m_host);
 // Morton-order `raw` into `out` (out[k].w = index of the point in `raw`); asynchronous on `st`.
 hipError_t prep_morton_sort(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float4* out);
+// pcl::ApproximateVoxelGrid (leaf x leaf x leaf) of `raw` (n points, arrival order = array order) into `out`
+// (room for n entries; out[k].w = k).  Blocks until *m_host (number of centroids) is known.
+hipError_t prep_approx_voxel_grid(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float leaf, float4* out, int* m_host);
 }  // namespace smhip

@@ -298,6 +298,7 @@ struct PrepWorkspace {
   int32_t* lstart = nullptr;             // [kMaxScans]
   int32_t* scan_meta = nullptr;          // device: offset[kMaxScans], prefix[kMaxScans + 1], out_offset[kMaxScans]
   int32_t* host_pinned = nullptr;        // [0..3] counts, then m[kMaxScans], then the scan_meta staging
+  float4* avg_cent = nullptr;            // [cap] run centroids of prep_approx_voxel_grid (allocated on first use)
 };
 
 
@@ -335,7 +336,7 @@ void prep_destroy(PrepWorkspace* w) {
   }
   (void)hipFree(w->leaves); (void)hipFree(w->counts); (void)hipFree(w->bbox); (void)hipFree(w->m_dev);
   (void)hipFree(w->lstart); (void)hipFree(w->scan_meta);
-  (void)hipFree(w->leaf_p); (void)hipFree(w->leaf_n); (void)hipFree(w->sort_tmp);
+  (void)hipFree(w->leaf_p); (void)hipFree(w->leaf_n); (void)hipFree(w->sort_tmp); (void)hipFree(w->avg_cent);
   if (w->host_pinned) (void)hipHostFree(w->host_pinned);
   delete w;
 }
@@ -405,6 +406,98 @@ hipError_t prep_morton_sort(PrepWorkspace* w, hipStream_t st, const float4* raw,
   size_t bytes = w->sort_bytes;
   PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[0], w->order[1], (unsigned)n, 0, 63, st));
   hipLaunchKernelGGL(morton_gather, dim3(gp), dim3(256), 0, st, raw, w->order[1], n, out);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// pcl::ApproximateVoxelGrid<PointXYZ>::applyFilter (PCL 1.8.1, pcl/filters/impl/approximate_voxel_grid.hpp), the
+// down-sampling step of registrators/ndt_gicp.cc:60-71.  The reference loop is serial: a 512-entry hash history
+// indexed by (ix * 7171 + iy * 3079 + iz * 4231) & 511; a point that lands on an entry holding a DIFFERENT voxel
+// flushes that entry's float centroid to the output, and whatever is left is flushed at the end in entry order.
+// Each entry only ever sees its own subsequence of the points, so the filter decomposes exactly:
+//   sort by (entry, arrival index); maximal runs of equal voxel inside an entry are the flushed centroids (summed
+//   in arrival order, in float, like the reference); a run is emitted when the first point of the entry's next run
+//   arrives, the last run of every entry at time n + entry.  A second sort by that time gives the output order.
+// ------------------------------------------------------------------------------------------
+namespace {
+constexpr int kAvgHist = 512;
+__device__ __forceinline__ void avg_voxel(const float4 p, float inv, int& ix, int& iy, int& iz, uint32_t& hsh) {
+  ix = (int)floorf(p.x * inv); iy = (int)floorf(p.y * inv); iz = (int)floorf(p.z * inv);
+  hsh = (uint32_t)((ix * 7171 + iy * 3079 + iz * 4231) & (kAvgHist - 1));
+}
+__global__ void avg_keys(const float4* raw, int n, float inv, unsigned long long* keys, int32_t* idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int ix, iy, iz; uint32_t hsh;
+  avg_voxel(raw[i], inv, ix, iy, iz, hsh);
+  keys[i] = ((unsigned long long)hsh << 32) | (uint32_t)i;
+  idx[i] = i;
+}
+__global__ void avg_heads(const float4* raw, const int32_t* idx, int n, float inv, int32_t* head) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  int ax, ay, az, bx, by, bz; uint32_t ha, hb;
+  avg_voxel(raw[idx[s]], inv, ax, ay, az, ha);
+  int hd = 1;
+  if (s > 0) {
+    avg_voxel(raw[idx[s - 1]], inv, bx, by, bz, hb);
+    hd = (ha != hb || ax != bx || ay != by || az != bz) ? 1 : 0;
+  }
+  head[s] = hd;
+}
+__global__ void avg_run_starts(const int32_t* head, const int32_t* incl, int n, int32_t* run_start, int32_t* counts) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  if (head[s]) run_start[incl[s] - 1] = s;
+  if (s == n - 1) counts[0] = incl[s];
+}
+__global__ void avg_flush(const float4* raw, const int32_t* idx, const int32_t* run_start, const int32_t* counts, int n, float inv,
+                          float4* cent, unsigned long long* when, int32_t* rid) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int R = counts[0];
+  if (r >= R) return;
+  const int a = run_start[r], b = (r + 1 < R) ? run_start[r + 1] : n;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int s = a; s < b; ++s) { const float4 p = raw[idx[s]]; sx += p.x; sy += p.y; sz += p.z; }   // hhe->centroid += scratch
+  const float c = (float)(b - a);
+  cent[r] = make_float4(sx / c, sy / c, sz / c, 0.f);                                               // flush: centroid /= count
+  int ix, iy, iz; uint32_t h0, h1 = 0xffffffffu;
+  avg_voxel(raw[idx[a]], inv, ix, iy, iz, h0);
+  if (b < n) avg_voxel(raw[idx[b]], inv, ix, iy, iz, h1);
+  when[r] = (h1 == h0) ? (unsigned long long)(uint32_t)idx[b] : (unsigned long long)n + h0;
+  rid[r] = r;
+}
+__global__ void avg_emit(const float4* cent, const int32_t* rid_sorted, const int32_t* counts, float4* out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= counts[0]) return;
+  float4 c = cent[rid_sorted[k]];
+  c.w = __int_as_float(k);
+  out[k] = c;
+}
+}  // namespace
+
+hipError_t prep_approx_voxel_grid(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float leaf, float4* out, int* m_host) {
+  if (!w || n <= 0 || n > w->cap || !(leaf > 0.f)) return hipErrorInvalidValue;
+  if (!w->avg_cent && hipMalloc((void**)&w->avg_cent, sizeof(float4) * (size_t)w->cap) != hipSuccess) return hipErrorOutOfMemory;
+  const float inv = 1.0f / leaf;                             // inverse_leaf_size_ = Array3f::Ones() / leaf_size_
+  const int gp = (n + 255) / 256;
+  hipLaunchKernelGGL(avg_keys, dim3(gp), dim3(256), 0, st, raw, n, inv, w->keys[0], w->order[0]);
+  size_t bytes = w->sort_bytes;
+  PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[0], w->order[1], (unsigned)n, 0, 41, st));
+  hipLaunchKernelGGL(avg_heads, dim3(gp), dim3(256), 0, st, raw, w->order[1], n, inv, w->seg[0]);
+  size_t sbytes = w->sort_bytes;
+  PCHK(rocprim::inclusive_scan(w->sort_tmp, sbytes, w->seg[0], w->seg[1], (size_t)n, rocprim::plus<int32_t>(), st));
+  hipLaunchKernelGGL(avg_run_starts, dim3(gp), dim3(256), 0, st, w->seg[0], w->seg[1], n, w->node_at[0], w->counts);
+  hipLaunchKernelGGL(avg_flush, dim3(gp), dim3(256), 0, st, raw, w->order[1], w->node_at[0], w->counts, n, inv, w->avg_cent,
+                     w->keys[0], w->order[0]);
+  PCHK(hipMemcpyAsync(w->host_pinned, w->counts, 4, hipMemcpyDeviceToHost, st));
+  PCHK(hipStreamSynchronize(st));
+  const int R = w->host_pinned[0];
+  if (R <= 0 || R > n) return hipErrorUnknown;
+  bytes = w->sort_bytes;
+  PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[0], w->node_at[1], (unsigned)R, 0, 33, st));
+  hipLaunchKernelGGL(avg_emit, dim3((R + 255) / 256), dim3(256), 0, st, w->avg_cent, w->node_at[1], w->counts, out);
+  *m_host = R;
   return hipGetLastError();
 }
 

@@ -23,9 +23,11 @@
 using namespace smhip;
 
 struct smhip_ndt_state;
+struct smhip_gicp_state;
 
 struct smhip_context {
   smhip_ndt_state* ndt = nullptr;
+  smhip_gicp_state* gicp = nullptr;
   PrepWorkspace* prep = nullptr;          // device CalculateNormals workspace (allocated on first use)
   PrepWorkspace* prep_batch = nullptr;    // the same sized for every slot at once (batched target preparation)
   float4* prep_raw = nullptr;             // raw scan staging on the device
@@ -394,12 +396,14 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
 }
 
 extern "C" void smhip_internal_free_ndt(smhip_context* h);
+extern "C" void smhip_internal_free_gicp(smhip_context* h);
 
 smhip_status smhip_destroy(smhip_handle h) {
   if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   smhip_internal_free_ndt(h);
+  smhip_internal_free_gicp(h);
   if (h->prep) prep_destroy(h->prep);
   if (h->prep_batch) prep_destroy(h->prep_batch);
   for (void* p : h->allocs) (void)hipFree(p);
@@ -841,4 +845,25 @@ extern "C" void smhip_internal_free_ndt(smhip_context* h) {
   if (n.fit_pinned) (void)hipHostFree(n.fit_pinned);
   delete h->ndt;
   h->ndt = nullptr;
+}
+
+// ---- registrators::NdtWithGicp ------------------------------------------------------------------
+#include "smhip_gicp_api.hip"
+
+struct smhip_gicp_state { GicpHost g; };
+
+namespace {
+GicpHost& gicp_of(smhip_context* h) {
+  if (!h->gicp) { h->gicp = new smhip_gicp_state(); smhip_ndt_gicp_default_options(&h->gicp->g.opts); }
+  return h->gicp->g;
+}
+}  // namespace
+
+extern "C" void smhip_internal_free_gicp(smhip_context* h) {
+  if (!h || !h->gicp) return;
+  GicpHost& g = h->gicp->g;
+  if (g.out_pinned) (void)hipHostFree(g.out_pinned);
+  if (g.count_pinned) (void)hipHostFree(g.count_pinned);
+  delete h->gicp;
+  h->gicp = nullptr;
 }

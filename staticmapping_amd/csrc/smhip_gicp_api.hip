@@ -1,0 +1,605 @@
+// smhip_gicp_api.hip -- host side of registrators::NdtWithGicp on the C ABI (included by smhip_api.hip).
+//
+// NdtWithGicp::Align (/root/reference/registrators/ndt_gicp.cc:55-112) = pcl::ApproximateVoxelGrid on both clouds
+// -> stock pcl NDT -> (fitness <= 1) stock pcl GICP -> score exp(-fitness).  All three live in PCL (1.8.1 pinned,
+// see oracle/ndt_gicp.py); GICP statements are cited from the in-tree fork registrators/pclomp/gicp_omp_impl.hpp.
+// The matcher keeps its raw clouds in private device buffers (the reference converts its stored clouds in every
+// Align, ndt_gicp.cc:59-76) and uses pair slot 0 as the working pair for the down-sampled clouds and slot 1 as
+// scratch for the source's neighbour search, so the handle needs pair_slots >= 2.
+#include "gicp_kernels.hip"
+
+namespace {
+
+struct GicpHost {
+  GicpDev dev{};
+  bool allocated = false;
+  smhip_ndt_gicp_options opts{};
+  float4* raw_src = nullptr;          // [ns_cap] as handed over
+  float4* raw_tgt = nullptr;          // [nt_cap]
+  float4* ds_tmp = nullptr;           // [max(ns_cap, nt_cap)] filter output before the Morton ordering
+  int n_raw_src = 0, n_raw_tgt = 0;
+  double* out_pinned = nullptr;       // kGicpCols doubles
+  double* rot_dev = nullptr;          // 9 doubles
+  uint32_t* count_pinned = nullptr;
+  int evals = 0;
+};
+
+GicpHost& gicp_of(smhip_context* h);
+
+smhip_status gicp_ensure(smhip_context* h) {
+  GicpHost& g = gicp_of(h);
+  if (g.allocated) return SMHIP_OK;
+  if (h->dev.slots < 2) { h->err = "NdtWithGicp needs a handle created with pair_slots >= 2"; return SMHIP_ERR_CAPACITY; }
+  smhip_status s = ndt_ensure(h);
+  if (s) return s;
+  s = prep_ensure(h);
+  if (s) return s;
+  const size_t NS = h->dev.ns_cap, NT = h->dev.nt_cap;
+  auto A = [&](smhip_status r) { if (s == SMHIP_OK) s = r; };
+  A(dev_alloc(h, &g.dev.cov_s, NS * 6));
+  A(dev_alloc(h, &g.dev.cov_t, NT * 6));
+  A(dev_alloc(h, &g.dev.maha, NS * 6));
+  A(dev_alloc(h, &g.dev.qraw, NS));
+  A(dev_alloc(h, &g.dev.partials, (size_t)kGicpMaxBlocks * kGicpCols));
+  A(dev_alloc(h, &g.dev.out, (size_t)kGicpCols));
+  A(dev_alloc(h, &g.dev.count, 4));
+  A(dev_alloc(h, &g.raw_src, NS));
+  A(dev_alloc(h, &g.raw_tgt, NT));
+  A(dev_alloc(h, &g.ds_tmp, std::max(NS, NT)));
+  A(dev_alloc(h, &g.rot_dev, 9));
+  if (s) return s;
+  if (hipHostMalloc(reinterpret_cast<void**>(&g.out_pinned), sizeof(double) * kGicpCols) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&g.count_pinned), sizeof(uint32_t) * 4) != hipSuccess) {
+    h->err = "hipHostMalloc failed (GICP)";
+    return SMHIP_ERR_HIP;
+  }
+  g.allocated = true;
+  return SMHIP_OK;
+}
+
+// ---- 6-vector helpers -------------------------------------------------------------------------
+// applyState (:516-527) on a float 4x4 (row-major): t.topLeft = Rz(x5) Ry(x4) Rx(x3) * t.topLeft ; t.col(3) += x0..2
+void apply_state_f32(const float* Tin, const double* x, float* Tout) {
+  const float a = (float)x[3], b = (float)x[4], c = (float)x[5];
+  const float ca = std::cos(a), sa = std::sin(a), cb = std::cos(b), sb = std::sin(b), cc = std::cos(c), sc = std::sin(c);
+  const float Rx[9] = {1, 0, 0, 0, ca, -sa, 0, sa, ca};
+  const float Ry[9] = {cb, 0, sb, 0, 1, 0, -sb, 0, cb};
+  const float Rz[9] = {cc, -sc, 0, sc, cc, 0, 0, 0, 1};
+  float M[9], R[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { float s = 0; for (int k = 0; k < 3; ++k) s += Rz[3 * i + k] * Ry[3 * k + j]; M[3 * i + j] = s; }
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { float s = 0; for (int k = 0; k < 3; ++k) s += M[3 * i + k] * Rx[3 * k + j]; R[3 * i + j] = s; }
+  float out[16];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) { float s = 0; for (int k = 0; k < 3; ++k) s += R[3 * i + k] * Tin[4 * k + j]; out[4 * i + j] = s; }
+    out[4 * i + 3] = Tin[4 * i + 3] + (float)x[i];
+  }
+  out[12] = Tin[12]; out[13] = Tin[13]; out[14] = Tin[14]; out[15] = Tin[15];
+  for (int i = 0; i < 16; ++i) Tout[i] = out[i];
+}
+
+// computeRDerivative (:133-186): g[3..5] = <dR/dphi, R>, <dR/dtheta, R>, <dR/dpsi, R>, <A, B> = sum A(j,i) B(i,j)
+void r_derivative(const double* x, const double* R /*row-major 3x3*/, double* g) {
+  const double phi = x[3], theta = x[4], psi = x[5];
+  const double cphi = std::cos(phi), sphi = std::sin(phi), cth = std::cos(theta), sth = std::sin(theta);
+  const double cpsi = std::cos(psi), spsi = std::sin(psi);
+  const double dphi[9] = {0, sphi * spsi + cphi * cpsi * sth, cphi * spsi - cpsi * sphi * sth,
+                          0, -cpsi * sphi + cphi * spsi * sth, -cphi * cpsi - sphi * spsi * sth,
+                          0, cphi * cth, -cth * sphi};
+  const double dth[9] = {-cpsi * sth, cpsi * cth * sphi, cphi * cpsi * cth,
+                         -spsi * sth, cth * sphi * spsi, cphi * cth * spsi,
+                         -cth, -sphi * sth, -cphi * sth};
+  const double dpsi[9] = {-cth * spsi, -cphi * cpsi - sphi * spsi * sth, cpsi * sphi - cphi * spsi * sth,
+                          cpsi * cth, -cphi * spsi + cpsi * sphi * sth, sphi * spsi + cphi * cpsi * sth,
+                          0, 0, 0};
+  auto ip = [&](const double* A) { double r = 0; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r += A[3 * j + i] * R[3 * i + j]; return r; };
+  g[3] = ip(dphi); g[4] = ip(dth); g[5] = ip(dpsi);
+}
+
+// One evaluation of the functor (f and g together: one launch either way), :250-377
+struct GicpFunctor {
+  smhip_context* h;
+  float base[16];          // base_transformation_ = guess (row-major float)
+  int ns;
+  smhip_status status = SMHIP_OK;
+  void fdf(const double* x, double& f, double* g) {
+    GicpHost& G = gicp_of(h);
+    GicpPose P;
+    float T[16];
+    apply_state_f32(base, x, T);
+    for (int i = 0; i < 12; ++i) { P.T[i] = T[i]; P.B[i] = base[i]; }
+    const int blocks = std::min(kGicpMaxBlocks, std::max(1, ceil_div(ns, 256)));
+    hipLaunchKernelGGL(gicp_fdf, dim3(blocks), dim3(256), 0, h->stream, h->dev, G.dev, ns, P);
+    hipLaunchKernelGGL(gicp_reduce, dim3(1), dim3(16 * 64), 0, h->stream, G.dev, blocks);
+    if (hipMemcpyAsync(G.out_pinned, G.dev.out, sizeof(double) * kGicpCols, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) { status = SMHIP_ERR_HIP; f = 0; for (int i = 0; i < 6; ++i) g[i] = 0; return; }
+    const double* o = G.out_pinned;
+    const double m = o[13];
+    f = o[0] / m;
+    for (int i = 0; i < 3; ++i) g[i] = o[1 + i] * (2.0 / m);
+    double R[9];
+    for (int i = 0; i < 9; ++i) R[i] = o[4 + i] * (2.0 / m);
+    r_derivative(x, R, g);
+    G.evals++;
+  }
+};
+
+// ---- pcl/registration/bfgs.h: BFGS<Functor> (GSL vector_bfgs2, Fletcher's line search) -------------
+enum { kBfgsSuccess = 0, kBfgsNoProgress = 1, kBfgsRunning = -1 };
+
+int solve_quadratic(double a, double b, double c, double* x0, double* x1) {     // gsl_poly_solve_quadratic
+  if (a == 0) { if (b == 0) return 0; *x0 = -c / b; return 1; }
+  const double disc = b * b - 4 * a * c;
+  if (disc > 0) {
+    if (b == 0) { const double r = std::sqrt(-c / a); *x0 = -r; *x1 = r; }
+    else {
+      const double sgnb = b > 0 ? 1 : -1;
+      const double temp = -0.5 * (b + sgnb * std::sqrt(disc));
+      const double r1 = temp / a, r2 = c / temp;
+      if (r1 < r2) { *x0 = r1; *x1 = r2; } else { *x0 = r2; *x1 = r1; }
+    }
+    return 2;
+  }
+  if (disc == 0) { *x0 = -0.5 * b / a; *x1 = -0.5 * b / a; return 2; }
+  return 0;
+}
+double interp_quad(double f0, double fp0, double f1, double zl, double zh) {
+  const double fl = f0 + zl * (fp0 + zl * (f1 - f0 - fp0));
+  const double fh = f0 + zh * (fp0 + zh * (f1 - f0 - fp0));
+  const double c = 2 * (f1 - f0 - fp0);
+  double zmin = zl, fmin = fl;
+  if (fh < fmin) { zmin = zh; fmin = fh; }
+  if (c > 0) {
+    const double z = -fp0 / c;
+    if (z > zl && z < zh) { const double f = f0 + z * (fp0 + z * (f1 - f0 - fp0)); if (f < fmin) { zmin = z; fmin = f; } }
+  }
+  return zmin;
+}
+double interp_cubic(double f0, double fp0, double f1, double fp1, double zl, double zh) {
+  const double eta = 3 * (f1 - f0) - 2 * fp0 - fp1, xi = fp0 + fp1 - 2 * (f1 - f0);
+  const double c0 = f0, c1 = fp0, c2 = eta, c3 = xi;
+  auto cubic = [&](double z) { return c0 + z * (c1 + z * (c2 + z * c3)); };
+  double zmin = zl, fmin = cubic(zl);
+  auto check = [&](double z) { const double y = cubic(z); if (y < fmin) { zmin = z; fmin = y; } };
+  check(zh);
+  double z0 = 0, z1 = 0;
+  const int n = solve_quadratic(3 * c3, 2 * c2, c1, &z0, &z1);
+  if (n == 2) { if (z0 > zl && z0 < zh) check(z0); if (z1 > zl && z1 < zh) check(z1); }
+  else if (n == 1) { if (z0 > zl && z0 < zh) check(z0); }
+  return zmin;
+}
+double interpolate(double a, double fa, double fpa, double b, double fb, double fpb, double xmin, double xmax, int order) {
+  double zmin = (xmin - a) / (b - a), zmax = (xmax - a) / (b - a);
+  if (zmin > zmax) std::swap(zmin, zmax);
+  const double z = (order > 2 && std::isfinite(fpb)) ? interp_cubic(fa, fpa * (b - a), fb, fpb * (b - a), zmin, zmax)
+                                                      : interp_quad(fa, fpa * (b - a), fb, zmin, zmax);
+  return a + z * (b - a);
+}
+
+struct Bfgs {
+  GicpFunctor& fn;
+  double sigma = 0.01, rho = 0.01, tau1 = 9, tau2 = 0.05, tau3 = 0.5, step_size = 1;   // :218-223
+  int order = 3;
+  double x0[6], g0[6], p[6], gradient[6], f = 0, delta_f = 0, g0norm = 0, pnorm = 0, fp0 = 0;
+  // the line function's one-entry caches (bfgs.h moveTo / applyF / applyDF / applyFDF)
+  double x_alpha[6], g_alpha[6], f_alpha = 0, df_alpha = 0, x_key = 0, f_key = 0, g_key = 0, df_key = 0;
+  explicit Bfgs(GicpFunctor& f_) : fn(f_) {}
+  static double dot(const double* a, const double* b) { double s = 0; for (int i = 0; i < 6; ++i) s += a[i] * b[i]; return s; }
+  static double norm(const double* a) { return std::sqrt(dot(a, a)); }
+  void move(double alpha) { if (alpha != x_key) { for (int i = 0; i < 6; ++i) x_alpha[i] = x0[i] + alpha * p[i]; x_key = alpha; } }
+  // the functor's f-only and df-only entry points cost the same launch as fdf here, so every miss fills both caches
+  void eval(double alpha) {
+    move(alpha);
+    fn.fdf(x_alpha, f_alpha, g_alpha);
+    f_key = g_key = alpha;
+    df_alpha = dot(g_alpha, p); df_key = alpha;
+  }
+  double F(double alpha) { if (alpha != f_key) eval(alpha); return f_alpha; }
+  double DF(double alpha) {
+    if (alpha == df_key) return df_alpha;
+    if (alpha != g_key) eval(alpha);
+    else { df_alpha = dot(g_alpha, p); df_key = alpha; }
+    return df_alpha;
+  }
+  void init(const double* x) {
+    delta_f = 0;
+    fn.fdf(x, f, gradient);
+    for (int i = 0; i < 6; ++i) { x0[i] = x[i]; g0[i] = gradient[i]; }
+    g0norm = norm(g0);
+    for (int i = 0; i < 6; ++i) p[i] = -gradient[i] / g0norm;
+    pnorm = norm(p);
+    fp0 = -g0norm;
+    for (int i = 0; i < 6; ++i) { x_alpha[i] = x0[i]; g_alpha[i] = g0[i]; }
+    x_key = f_key = g_key = df_key = 0; f_alpha = f; df_alpha = dot(g_alpha, p);
+  }
+  int line_search(double alpha1, double* alpha_new) {
+    const double f0v = F(0.0), fp0v = DF(0.0);
+    double falpha, falpha_prev = f0v, fpalpha, fpalpha_prev = fp0v, alpha = alpha1, alpha_prev = 0;
+    double a = 0, b = alpha, fa = f0v, fb = 0, fpa = fp0v, fpb = 0;
+    int i = 0;
+    bool bracketed = false;
+    while (i++ < 100) {
+      falpha = F(alpha);
+      if (falpha > f0v + alpha * rho * fp0v || falpha >= falpha_prev) {
+        a = alpha_prev; fa = falpha_prev; fpa = fpalpha_prev; b = alpha; fb = falpha; fpb = NAN; bracketed = true; break;
+      }
+      fpalpha = DF(alpha);
+      if (std::fabs(fpalpha) <= -sigma * fp0v) { *alpha_new = alpha; return kBfgsSuccess; }
+      if (fpalpha >= 0) {
+        a = alpha; fa = falpha; fpa = fpalpha; b = alpha_prev; fb = falpha_prev; fpb = fpalpha_prev; bracketed = true; break;
+      }
+      const double delta = alpha - alpha_prev;
+      const double alpha_next = interpolate(alpha_prev, falpha_prev, fpalpha_prev, alpha, falpha, fpalpha, alpha + delta, alpha + tau1 * delta, order);
+      alpha_prev = alpha; falpha_prev = falpha; fpalpha_prev = fpalpha; alpha = alpha_next;
+    }
+    (void)bracketed;
+    while (i++ < 100) {
+      const double delta = b - a;
+      alpha = interpolate(a, fa, fpa, b, fb, fpb, a + tau2 * delta, b - tau3 * delta, order);
+      falpha = F(alpha);
+      if ((a - alpha) * fpa <= 2.220446049250313e-16) return kBfgsNoProgress;
+      if (falpha > f0v + rho * alpha * fp0v || falpha >= fa) { b = alpha; fb = falpha; fpb = NAN; }
+      else {
+        fpalpha = DF(alpha);
+        if (std::fabs(fpalpha) <= -sigma * fp0v) { *alpha_new = alpha; return kBfgsSuccess; }
+        if (((b - a) >= 0 && fpalpha >= 0) || ((b - a) <= 0 && fpalpha <= 0)) { b = a; fb = fa; fpb = fpa; }
+        a = alpha; fa = falpha; fpa = fpalpha;
+      }
+    }
+    *alpha_new = alpha;
+    return kBfgsSuccess;
+  }
+  int one_step(double* x) {
+    const double f0v = f;
+    if (pnorm == 0.0 || g0norm == 0.0 || fp0 == 0) return kBfgsNoProgress;
+    double alpha1;
+    if (delta_f < 0) { const double del = std::max(-delta_f, 10 * 2.220446049250313e-16 * std::fabs(f0v)); alpha1 = std::min(1.0, 2.0 * del / (-fp0)); }
+    else alpha1 = std::fabs(step_size);
+    double alpha = 0;
+    const int st = line_search(alpha1, &alpha);
+    if (st != kBfgsSuccess) return st;
+    f = F(alpha); (void)DF(alpha);                               // updatePosition
+    for (int i = 0; i < 6; ++i) { x[i] = x_alpha[i]; gradient[i] = g_alpha[i]; }
+    delta_f = f - f0v;
+    double dx0[6], dg0[6];
+    for (int i = 0; i < 6; ++i) { dx0[i] = x[i] - x0[i]; dg0[i] = gradient[i] - g0[i]; }
+    const double dxg = dot(dx0, gradient), dgg = dot(dg0, gradient), dxdg = dot(dx0, dg0), dgnorm = norm(dg0);
+    double A = 0, B = 0;
+    if (dxdg != 0) { B = dxg / dxdg; A = -(1.0 + dgnorm * dgnorm / dxdg) * B + dgg / dxdg; }
+    for (int i = 0; i < 6; ++i) p[i] = gradient[i] - A * dx0[i] - B * dg0[i];
+    for (int i = 0; i < 6; ++i) { g0[i] = gradient[i]; x0[i] = x[i]; }
+    g0norm = norm(g0);
+    pnorm = norm(p);
+    const double dir = dot(p, gradient) > 0 ? -1.0 : 1.0;
+    for (int i = 0; i < 6; ++i) p[i] *= dir / pnorm;
+    pnorm = norm(p);
+    fp0 = dot(p, g0);
+    for (int i = 0; i < 6; ++i) { x_alpha[i] = x0[i]; g_alpha[i] = g0[i]; }   // changeDirection
+    x_key = f_key = g_key = df_key = 0; df_alpha = dot(g_alpha, p);
+    return kBfgsSuccess;
+  }
+  int test_gradient(double eps) const { return g0norm < eps ? kBfgsSuccess : kBfgsRunning; }
+};
+
+// both working slots prepared as search structures: slot 0 = (source, target), slot 1 = (source as its own target)
+smhip_status gicp_prepare_slots(smhip_context* h, int np, const double* T_colmajor, int* ns_max, int* nt_max) {
+  double guesses[32];
+  for (int p = 0; p < np; ++p) for (int i = 0; i < 16; ++i) guesses[16 * p + i] = p == 0 ? T_colmajor[i] : ((i % 5 == 0) ? 1.0 : 0.0);
+  int had[2] = {h->has_normals[0], h->has_normals[1]};
+  for (int p = 0; p < np; ++p) h->has_normals[p] = 1;
+  smhip_status s = fill_inputs(h, np, guesses, ns_max, nt_max);
+  for (int p = 0; p < np; ++p) h->has_normals[p] = had[p];
+  if (s) return s;
+  const int sort_was = h->dev.sort_cells, ball_was = h->dev.use_ball;
+  h->dev.sort_cells = 0; h->dev.use_ball = 0;
+  s = enqueue_prepare(h, np, *nt_max);
+  h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was;
+  return s;
+}
+
+smhip_status gicp_find_closests(smhip_context* h, int ns_max) {
+  const int sort_was = h->dev.sort_cells, ball_was = h->dev.use_ball;
+  h->dev.sort_cells = 0; h->dev.use_ball = 0;
+  const smhip_status s = enqueue_find_closests(h, 1, ns_max);
+  h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was;
+  HIPCHK(h, hipMemsetAsync(h->dev.hist, 0, sizeof(uint32_t) * kHistBins, h->stream));
+  h->ev_used = 0;
+  return s;
+}
+
+// pcl GICP computeTransformation (:381-514) on slot 0's clouds; guess / result are float 4x4 row-major
+smhip_status gicp_align_slot0(smhip_context* h, const float* guess, float* final_out, smhip_ndt_gicp_stats* stats) {
+  GicpHost& G = gicp_of(h);
+  const smhip_ndt_gicp_options& o = G.opts;
+  const int ns = h->ns[0], nt = h->nt[0], k = o.gicp_k_correspondences;
+  if (k < 3 || k > kGicpKMax) { h->err = "gicp_k_correspondences must be in [3, 32]"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  if (ns < k || nt < k) { h->err = "GICP: a cloud has fewer points than k_correspondences (gicp_omp_impl.hpp:64-68)"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  if (ns > h->dev.nt_cap) { h->err = "GICP: max_target_points must be >= the down-sampled source size"; return SMHIP_ERR_CAPACITY; }
+  // ---- covariances (:391-402): target over slot 0's grid, source over slot 1's (the source as its own target)
+  hipLaunchKernelGGL(gicp_copy_points, dim3(ceil_div(ns, 256)), dim3(256), 0, h->stream, h->dev.src,
+                     const_cast<float4*>(h->dev.tgt_p) + h->dev.nt_cap, ns);
+  h->ns[1] = ns; h->nt[1] = ns;
+  double I16[16];
+  for (int i = 0; i < 16; ++i) I16[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  int ns_max = 0, nt_max = 0;
+  // the k-NN search wants cells of a few point spacings: one shell then holds the 20 neighbours almost everywhere
+  const float cell_was = h->dev.grid_cell;
+  h->dev.grid_cell = o.gicp_search_cell > 0 ? o.gicp_search_cell : 4.0f * (o.using_voxel_filter ? o.voxel_resolution : 0.2f);
+  smhip_status s = gicp_prepare_slots(h, 2, I16, &ns_max, &nt_max);
+  h->dev.grid_cell = cell_was;
+  if (s) return s;
+  hipLaunchKernelGGL(gicp_knn_cov, dim3(ceil_div(nt, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, h->dev, 0, k,
+                     o.gicp_epsilon, G.dev.cov_t);
+  hipLaunchKernelGGL(gicp_knn_cov, dim3(ceil_div(ns, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, h->dev, 1, k,
+                     o.gicp_epsilon, G.dev.cov_s);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));              // the pinned pair inputs are rewritten below
+  // ---- outer loop
+  float T[16], prev[16];                                   // transformation_, previous_transformation_
+  for (int i = 0; i < 16; ++i) T[i] = prev[i] = (i % 5 == 0) ? 1.f : 0.f;
+  GicpFunctor fn{h, {}, ns};
+  for (int i = 0; i < 16; ++i) fn.base[i] = guess[i];
+  const float thr2 = (float)(o.gicp_corr_dist_threshold * o.gicp_corr_dist_threshold);
+  int it = 0;
+  uint32_t ncorr = 0;
+  G.evals = 0;
+  for (;;) {
+    // transform_R = transformation_ * guess in double (:425-429); the search uses the same product
+    double TR[16];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { double a = 0; for (int q = 0; q < 4; ++q) a += (double)T[4 * i + q] * (double)guess[4 * q + j]; TR[4 * i + j] = a; }
+    double TRcm[16], R9[9];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) TRcm[4 * j + i] = TR[4 * i + j];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R9[3 * i + j] = TR[4 * i + j];
+    s = gicp_prepare_slots(h, 1, TRcm, &ns_max, &nt_max);
+    if (s) return s;
+    s = gicp_find_closests(h, ns_max);
+    if (s) return s;
+    HIPCHK(h, hipMemcpyAsync(G.rot_dev, R9, sizeof(R9), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(G.dev.count, 0, sizeof(uint32_t), h->stream));
+    hipLaunchKernelGGL(gicp_corr, dim3(ceil_div(ns, 256)), dim3(256), 0, h->stream, h->dev, G.dev, ns, thr2, G.rot_dev);
+    HIPCHK(h, hipMemcpyAsync(G.count_pinned, G.dev.count, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // also keeps R9 alive until it is on the device
+    ncorr = *G.count_pinned;
+    for (int i = 0; i < 16; ++i) prev[i] = T[i];                          // :467
+    if (ncorr < 4) break;                                                // NotEnoughPointsException -> break (:494-498)
+    // ---- estimateRigidTransformationBFGS (:189-247)
+    double x[6] = {T[3], T[7], T[11], std::atan2((double)T[9], (double)T[10]), std::asin(-(double)T[8]), std::atan2((double)T[4], (double)T[0])};
+    Bfgs bfgs(fn);
+    bfgs.init(x);
+    int inner = 0, result;
+    do {
+      inner++;
+      result = bfgs.one_step(x);
+      if (result) break;
+      result = bfgs.test_gradient(1e-2);
+    } while (result == kBfgsRunning && inner < o.gicp_max_inner_iterations);
+    if (fn.status) { h->err = "GICP functor evaluation failed"; return fn.status; }
+    const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    apply_state_f32(I4, x, T);                                           // :240-241
+    double delta = 0;                                                    // :475-491
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) {
+        const double ratio = (r < 3 && c < 3) ? 1.0 / o.gicp_rotation_epsilon : 1.0 / o.gicp_transformation_epsilon;
+        delta = std::max(delta, ratio * std::fabs((double)prev[4 * r + c] - (double)T[4 * r + c]));
+      }
+    it++;
+    if (it >= o.gicp_max_iterations || delta < 1) { for (int i = 0; i < 16; ++i) prev[i] = T[i]; break; }   // :500-505
+  }
+  // final_transformation_ (:511-514)
+  for (int i = 0; i < 16; ++i) final_out[i] = (i % 5 == 0) ? 1.f : 0.f;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) { float a = 0; for (int q = 0; q < 3; ++q) a += prev[4 * r + q] * guess[4 * q + c]; final_out[4 * r + c] = a; }
+    final_out[4 * r + 3] = prev[4 * r + 3] + guess[4 * r + 3];
+  }
+  if (stats) { stats->gicp_iterations = it; stats->gicp_function_evaluations = G.evals; stats->gicp_correspondences = (int32_t)ncorr; }
+  return SMHIP_OK;
+}
+
+smhip_status gicp_upload_raw(smhip_context* h, float4* dst, const float* xyz, int stride, int n, int cap, int* n_out) {
+  if (!xyz || n <= 0 || (stride != 3 && stride != 4 && stride != 5)) { h->err = "bad cloud / stride"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  if (n > cap) { h->err = "cloud larger than the handle's capacity"; return SMHIP_ERR_CAPACITY; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  // the pinned staging buffer holds 2 * max(ns_cap, nt_cap) points
+  for (int i = 0; i < n; ++i) h->stage[i] = make_float4(xyz[(size_t)stride * i], xyz[(size_t)stride * i + 1], xyz[(size_t)stride * i + 2], 0.f);
+  HIPCHK(h, hipMemcpyAsync(dst, h->stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  *n_out = n;
+  return SMHIP_OK;
+}
+
+void colmajor_to_rm_f32(const double* cm, float* rm) { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) rm[4 * r + c] = (float)cm[4 * c + r]; }
+void rm_f32_to_colmajor(const float* rm, double* cm) { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) cm[4 * c + r] = (double)rm[4 * r + c]; }
+
+}  // namespace
+
+extern "C" {
+
+void smhip_ndt_gicp_default_options(smhip_ndt_gicp_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->voxel_resolution = 0.2f;              // ndt_gicp.h:73
+  o->using_voxel_filter = 1;               // :74
+  o->use_ndt = 1;                          // :75
+  o->ndt_transformation_epsilon = 0.01f;   // ndt_gicp.cc:38
+  o->ndt_step_size = 0.1f;                 // :39
+  o->ndt_resolution = 1.0f;                // :40
+  o->ndt_max_iterations = 35;              // :41
+  o->gicp_rotation_epsilon = 1e-3;         // :43
+  o->gicp_max_iterations = 35;             // :44
+  o->gicp_transformation_epsilon = 5e-4;   // PCL defaults, gicp_omp.h:108-118
+  o->gicp_epsilon = 1e-3;
+  o->gicp_corr_dist_threshold = 5.0;
+  o->gicp_max_inner_iterations = 20;
+  o->gicp_k_correspondences = 20;
+}
+
+smhip_status smhip_ndt_gicp_set_options(smhip_handle h, const smhip_ndt_gicp_options* o) {
+  if (!h || !o) return SMHIP_ERR_INVALID_ARGUMENT;
+  if (!(o->voxel_resolution > 0) || !(o->ndt_resolution > 0) || !(o->ndt_step_size > 0) || o->gicp_max_iterations < 1 ||
+      o->gicp_k_correspondences < 3 || o->gicp_k_correspondences > kGicpKMax || !(o->gicp_rotation_epsilon > 0) ||
+      !(o->gicp_transformation_epsilon > 0)) {
+    h->err = "bad NdtWithGicp options";
+    return SMHIP_ERR_INVALID_ARGUMENT;
+  }
+  gicp_of(h).opts = *o;
+  return SMHIP_OK;
+}
+
+smhip_status smhip_ndt_gicp_set_source_f32(smhip_handle h, const float* xyz, int stride_floats, int n) {
+  if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
+  smhip_status s = gicp_ensure(h);
+  if (s) return s;
+  GicpHost& g = gicp_of(h);
+  return gicp_upload_raw(h, g.raw_src, xyz, stride_floats, n, h->dev.ns_cap, &g.n_raw_src);
+}
+
+smhip_status smhip_ndt_gicp_set_target_f32(smhip_handle h, const float* xyz, int stride_floats, int n) {
+  if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
+  smhip_status s = gicp_ensure(h);
+  if (s) return s;
+  GicpHost& g = gicp_of(h);
+  return gicp_upload_raw(h, g.raw_tgt, xyz, stride_floats, n, h->dev.nt_cap, &g.n_raw_tgt);
+}
+
+// ndt_gicp.cc:55-81: the (optionally down-sampled) clouds become slot 0's source and target
+static smhip_status ndt_gicp_stage_clouds(smhip_handle h) {
+  GicpHost& g = gicp_of(h);
+  if (g.n_raw_src <= 0 || g.n_raw_tgt <= 0) { h->err = "NdtWithGicp::Align before SetInputSource/SetInputTarget"; return SMHIP_ERR_NOT_READY; }
+  float4* src0 = const_cast<float4*>(h->dev.src);
+  float4* tgt0 = const_cast<float4*>(h->dev.tgt_p);
+  int ms = g.n_raw_src, mt = g.n_raw_tgt;
+  hipError_t e = hipSuccess;
+  if (g.opts.using_voxel_filter) {
+    e = prep_approx_voxel_grid(h->prep, h->stream, g.raw_src, g.n_raw_src, g.opts.voxel_resolution, g.ds_tmp, &ms);
+    if (e == hipSuccess) e = prep_morton_sort(h->prep, h->stream, g.ds_tmp, ms, src0);
+    if (e == hipSuccess) e = prep_approx_voxel_grid(h->prep, h->stream, g.raw_tgt, g.n_raw_tgt, g.opts.voxel_resolution, tgt0, &mt);
+  } else {
+    e = prep_morton_sort(h->prep, h->stream, g.raw_src, ms, src0);
+    if (e == hipSuccess) e = hipMemcpyAsync(tgt0, g.raw_tgt, sizeof(float4) * (size_t)mt, hipMemcpyDeviceToDevice, h->stream);
+  }
+  if (e != hipSuccess) { h->err = std::string("NdtWithGicp down-sampling: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
+  h->ns[0] = ms; h->nt[0] = mt; h->has_normals[0] = 0;
+  return SMHIP_OK;
+}
+
+smhip_status smhip_ndt_gicp_align(smhip_handle h, const double guess[16], double result[16], double* score, smhip_ndt_gicp_stats* stats) {
+  if (!h || !guess || !result) return SMHIP_ERR_INVALID_ARGUMENT;
+  HIPCHK(h, hipSetDevice(h->device));
+  smhip_status s = gicp_ensure(h);
+  if (s) return s;
+  GicpHost& g = gicp_of(h);
+  smhip_ndt_gicp_stats st{};
+  s = ndt_gicp_stage_clouds(h);
+  if (s) return s;
+  st.n_source = h->ns[0]; st.n_target = h->nt[0];
+  float ndt_guess[16];
+  colmajor_to_rm_f32(guess, ndt_guess);                      // guess.cast<float>(), :80
+  double ndt_score = 0.9;                                    // :81
+  if (g.opts.use_ndt) {                                      // :82-90
+    NdtHost& n = ndt_of(h);
+    const smhip_ndt_options saved = n.opts;
+    const bool dm = n.double_math;
+    smhip_ndt_options no;
+    smhip_ndt_default_options(&no);
+    no.resolution = g.opts.ndt_resolution; no.step_size = g.opts.ndt_step_size;
+    no.transformation_epsilon = g.opts.ndt_transformation_epsilon; no.max_iterations = g.opts.ndt_max_iterations;
+    n.opts = no; n.double_math = true; n.grid_valid = false;
+    double nres[16];
+    smhip_ndt_stats ns{};
+    s = smhip_ndt_align(h, guess, nres, &ndt_score, &ns);
+    n.opts = saved; n.double_math = dm; n.grid_valid = false;
+    if (s) return s;
+    colmajor_to_rm_f32(nres, ndt_guess);                     // ndt_.getFinalTransformation()
+    st.ndt_iterations = ns.iterations;
+  }
+  st.ndt_score = ndt_score;
+  double icp_score = 10.0;                                   // :92
+  if (ndt_score <= 1.0) {                                    // :94
+    float fin[16];
+    s = gicp_align_slot0(h, ndt_guess, fin, &st);
+    if (s) return s;
+    rm_f32_to_colmajor(fin, result);
+    s = fitness_score(h, result, &icp_score);                // gicp_.getFitnessScore(), :101
+    if (s) return s;
+    st.ok = 1;
+  } else {
+    for (int i = 0; i < 16; ++i) result[i] = guess[i];       // :106
+    st.ok = 0;
+  }
+  st.gicp_score = icp_score;
+  if (score) *score = std::exp(-icp_score);                  // :103 / :107
+  if (stats) *stats = st;
+  return SMHIP_OK;
+}
+
+// GICP alone on slot 0's clouds as set by smhip_set_source_f32 / smhip_set_target_f32 (parity hook; also what a
+// caller that wants plain pcl GICP semantics uses).  *fitness = getFitnessScore().
+smhip_status smhip_gicp_align(smhip_handle h, const double guess[16], double result[16], double* fitness, smhip_ndt_gicp_stats* stats) {
+  if (!h || !guess || !result) return SMHIP_ERR_INVALID_ARGUMENT;
+  HIPCHK(h, hipSetDevice(h->device));
+  smhip_status s = gicp_ensure(h);
+  if (s) return s;
+  if (h->ns[0] <= 0 || h->nt[0] <= 0) { h->err = "GICP before SetInputSource/SetInputTarget"; return SMHIP_ERR_NOT_READY; }
+  smhip_ndt_gicp_stats st{};
+  st.n_source = h->ns[0]; st.n_target = h->nt[0];
+  float g32[16], fin[16];
+  colmajor_to_rm_f32(guess, g32);
+  s = gicp_align_slot0(h, g32, fin, &st);
+  if (s) return s;
+  rm_f32_to_colmajor(fin, result);
+  double fit = 0;
+  s = fitness_score(h, result, &fit);
+  if (s) return s;
+  st.ok = 1; st.gicp_score = fit;
+  if (fitness) *fitness = fit;
+  if (stats) *stats = st;
+  return SMHIP_OK;
+}
+
+// parity hooks -----------------------------------------------------------------------------------
+// the working clouds of the last smhip_ndt_gicp_align (which = 0 source, 1 target) in filter output order
+smhip_status smhip_ndt_gicp_get_downsampled(smhip_handle h, int which, float* xyz, int capacity, int* n_out) {
+  if (!h || !n_out || (which != 0 && which != 1)) return SMHIP_ERR_INVALID_ARGUMENT;
+  const int n = which == 0 ? h->ns[0] : h->nt[0];
+  *n_out = n;
+  if (!xyz) return SMHIP_OK;
+  if (capacity < n) { h->err = "capacity too small"; return SMHIP_ERR_CAPACITY; }
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<float4> tmp((size_t)n);
+  HIPCHK(h, hipMemcpyAsync(tmp.data(), which == 0 ? h->dev.src : h->dev.tgt_p, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < n; ++i) {
+    // the source was Morton-ordered after the filter: w holds its position in the filter's output
+    const int k = which == 0 ? [&] { int v; std::memcpy(&v, &tmp[i].w, 4); return v; }() : i;
+    xyz[3 * k] = tmp[i].x; xyz[3 * k + 1] = tmp[i].y; xyz[3 * k + 2] = tmp[i].z;
+  }
+  return SMHIP_OK;
+}
+
+// covariances of the last GICP run in the order of smhip_ndt_gicp_get_downsampled / the uploaded clouds:
+// cov = n x 6 doubles (xx xy xz yy yz zz)
+smhip_status smhip_gicp_get_covariances(smhip_handle h, int which, double* cov, int n) {
+  if (!h || !cov || (which != 0 && which != 1)) return SMHIP_ERR_INVALID_ARGUMENT;
+  GicpHost& g = gicp_of(h);
+  if (!g.allocated) { h->err = "GICP has not run"; return SMHIP_ERR_NOT_READY; }
+  const int m = which == 0 ? h->ns[0] : h->nt[0];
+  if (n != m) { h->err = "n must equal the cloud size"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<double> c((size_t)m * 6);
+  HIPCHK(h, hipMemcpyAsync(c.data(), which == 0 ? g.dev.cov_s : g.dev.cov_t, sizeof(double) * 6 * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+  if (which == 1) {                                          // already indexed by the target's array position
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::memcpy(cov, c.data(), sizeof(double) * 6 * (size_t)m);
+    return SMHIP_OK;
+  }
+  std::vector<float4> pts((size_t)m);
+  HIPCHK(h, hipMemcpyAsync(pts.data(), h->dev.src, sizeof(float4) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < m; ++i) {
+    int k; std::memcpy(&k, &pts[i].w, 4);                    // caller / filter-output index of source entry i
+    for (int e = 0; e < 6; ++e) cov[(size_t)6 * k + e] = c[(size_t)6 * i + e];
+  }
+  return SMHIP_OK;
+}
+
+}  // extern "C"

@@ -20,6 +20,7 @@ struct NdtHost {
   int32_t* vkey = nullptr;            // [nt] linear voxel index of every occupied voxel (tests)
   int deriv_calls = 0;
   double last_pairs = 0;
+  bool double_math = false;           // stock pcl::NormalDistributionsTransform arithmetic (NdtWithGicp)
 };
 
 // ---- small dense helpers (host, double unless noted) ------------------------------------------
@@ -103,8 +104,8 @@ void angle_derivatives(const double* p, NdtPose& P) {   // :288-393
       {(-cy * cz), (cy * sz), (sy)}, {(-sx * sy * cz), (sx * sy * sz), (sx * cy)}, {(cx * sy * cz), (-cx * sy * sz), (-cx * cy)},
       {(sy * sz), (sy * cz), 0}, {(-sx * cy * sz), (-sx * cy * cz), 0}, {(cx * cy * sz), (cx * cy * cz), 0},
       {(-cy * cz), (cy * sz), 0}, {(-cx * sz - sx * sy * cz), (-cx * cz + sx * sy * sz), 0}, {(-sx * sz + cx * sy * cz), (-cx * sy * sz - sx * cz), 0}};
-  for (int r = 0; r < 8; ++r) for (int c = 0; c < 3; ++c) P.j_ang[r][c] = (float)j[r][c];
-  for (int r = 0; r < 15; ++r) for (int c = 0; c < 3; ++c) P.h_ang[r][c] = (float)hh[r][c];
+  for (int r = 0; r < 8; ++r) for (int c = 0; c < 3; ++c) { P.j_ang[r][c] = (float)j[r][c]; P.j_angd[r][c] = j[r][c]; }
+  for (int r = 0; r < 15; ++r) for (int c = 0; c < 3; ++c) { P.h_ang[r][c] = (float)hh[r][c]; P.h_angd[r][c] = hh[r][c]; }
 }
 
 }  // namespace
@@ -132,6 +133,7 @@ smhip_status ndt_ensure(smhip_context* h) {
   A(dev_alloc(h, &d.vstart, NT + 1));
   A(dev_alloc(h, &d.vpts, NT));
   A(dev_alloc(h, &d.vox, NT));
+  A(dev_alloc(h, &d.icovd, NT * 6));
   A(dev_alloc(h, &d.partials, (size_t)kNdtMaxDerivBlocks * kNdtDerivCols));
   A(dev_alloc(h, &d.out, (size_t)kNdtDerivCols));
   A(dev_alloc(h, &n.fit_dev, 128));
@@ -198,11 +200,12 @@ smhip_status ndt_derivs(smhip_context* h, const double* p, const float* T, bool 
   const double d3 = -std::log(c2);
   const double d1 = -std::log(c1 + c2) - d3;
   const double d2 = -2 * std::log((-std::log(c1 * std::exp(-0.5) + c2) - d3) / d1);
-  P.d1d = d1; P.d1 = (float)d1; P.d2 = (float)d2;
+  P.d1d = d1; P.d2d = d2; P.d1 = (float)d1; P.d2 = (float)d2;
   P.res2 = n.opts.resolution * n.opts.resolution;
   P.compute_hessian = hess ? 1 : 0;
   const int blocks = std::min(kNdtMaxDerivBlocks, std::max(1, ceil_div(n.dev.ns, kNdtDerivThreads)));
-  hipLaunchKernelGGL(ndt_derivatives, dim3(blocks), dim3(kNdtDerivThreads), 0, h->stream, n.dev, P);
+  if (n.double_math) hipLaunchKernelGGL(ndt_derivatives<double>, dim3(blocks), dim3(kNdtDerivThreads), 0, h->stream, n.dev, P);
+  else hipLaunchKernelGGL(ndt_derivatives<float>, dim3(blocks), dim3(kNdtDerivThreads), 0, h->stream, n.dev, P);
   hipLaunchKernelGGL(ndt_reduce, dim3(1), dim3(16 * 64), 0, h->stream, n.dev, blocks);
   HIPCHK(h, hipMemcpyAsync(n.out_pinned, n.dev.out, sizeof(double) * kNdtDerivCols, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -249,6 +252,35 @@ double trial_value_mt(double a_l, double f_l, double g_l, double a_u, double f_u
   const double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u;
   const double w = std::sqrt(z * z - g_t * g_u);
   return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+}
+
+// pcl::Registration::getFitnessScore(): mean squared 1-NN distance of slot 0's source, moved by `T`
+// (column-major 4x4), to slot 0's raw target (ndt.cc:60, ndt_gicp.cc:88,101).
+smhip_status fitness_score(smhip_context* h, const double* T, double* out) {
+  NdtHost& n = ndt_of(h);
+  int ns_max = 0, nt_max = 0;
+  const int had = h->has_normals[0];
+  h->has_normals[0] = 1;
+  smhip_status s = fill_inputs(h, 1, T, &ns_max, &nt_max);
+  h->has_normals[0] = had;
+  if (s) return s;
+  // distances only: no tie-order requirement (skip the per-cell sort) and no previous match to seed a
+  // ball search -> plain exact ring search (r = 1 certifies almost every query against a dense submap)
+  const int sort_was = h->dev.sort_cells, ball_was = h->dev.use_ball;
+  h->dev.sort_cells = 0; h->dev.use_ball = 0;
+  s = enqueue_prepare(h, 1, nt_max);
+  if (s == SMHIP_OK) s = enqueue_find_closests(h, 1, ns_max);
+  h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was;
+  if (s) return s;
+  hipLaunchKernelGGL(fitness_partial, dim3(64), dim3(256), 0, h->stream, h->dev.d2, h->ns[0], n.fit_dev);
+  HIPCHK(h, hipMemsetAsync(h->dev.hist, 0, sizeof(uint32_t) * kHistBins, h->stream));
+  HIPCHK(h, hipMemcpyAsync(n.fit_pinned, n.fit_dev, sizeof(double) * 128, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  double ssum = 0, cnt = 0;
+  for (int k = 0; k < 64; ++k) { ssum += n.fit_pinned[2 * k]; cnt += n.fit_pinned[2 * k + 1]; }
+  *out = cnt > 0 ? ssum / cnt : 1.7976931348623157e308;
+  h->ev_used = 0;
+  return SMHIP_OK;
 }
 
 }  // namespace
@@ -371,32 +403,9 @@ smhip_status smhip_ndt_align(smhip_handle h, const double guess[16], double resu
   }
   // getFinalTransformation().cast<double>(), column-major out (ndt.cc:61)
   for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) result[4 * c + r] = (double)Tf[4 * r + c];
-  // getFitnessScore(): mean squared 1-NN distance of the transformed source to the RAW target (ndt.cc:60)
   double fit = 0;
-  {
-    int ns_max = 0, nt_max = 0;
-    const int had = h->has_normals[0];
-    h->has_normals[0] = 1;
-    s = fill_inputs(h, 1, result, &ns_max, &nt_max);
-    h->has_normals[0] = had;
-    if (s) return s;
-    // distances only: no tie-order requirement (skip the per-cell sort) and no previous match to seed a
-    // ball search -> plain exact ring search (r = 1 certifies almost every query against a dense submap)
-    const int sort_was = h->dev.sort_cells, ball_was = h->dev.use_ball;
-    h->dev.sort_cells = 0; h->dev.use_ball = 0;
-    s = enqueue_prepare(h, 1, nt_max);
-    if (s == SMHIP_OK) s = enqueue_find_closests(h, 1, ns_max);
-    h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was;
-    if (s) return s;
-    hipLaunchKernelGGL(fitness_partial, dim3(64), dim3(256), 0, h->stream, h->dev.d2, h->ns[0], n.fit_dev);
-    HIPCHK(h, hipMemsetAsync(h->dev.hist, 0, sizeof(uint32_t) * kHistBins, h->stream));
-    HIPCHK(h, hipMemcpyAsync(n.fit_pinned, n.fit_dev, sizeof(double) * 128, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    double ssum = 0, cnt = 0;
-    for (int k = 0; k < 64; ++k) { ssum += n.fit_pinned[2 * k]; cnt += n.fit_pinned[2 * k + 1]; }
-    fit = cnt > 0 ? ssum / cnt : 1.7976931348623157e308;
-    h->ev_used = 0;
-  }
+  s = fitness_score(h, result, &fit);
+  if (s) return s;
   if (score) *score = fit;
   if (stats) {
     stats->iterations = it;

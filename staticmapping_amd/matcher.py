@@ -292,6 +292,78 @@ class NdtHip(IcpFastHip):
         return score.value, g, H.reshape(6, 6)
 
 
+class NdtGicpHip(IcpFastHip):
+    """registrators::NdtWithGicp on the GPU: mirrors NdtWithGicp::Align
+    (/root/reference/registrators/ndt_gicp.cc:55-112): ApproximateVoxelGrid(0.2 m) on both clouds -> pcl NDT ->
+    pcl GICP; get_fitness_score() = exp(-GICP fitness), HIGHER is better.  Clouds are float32 [N,3+] arrays.
+    Options carry the reference's names (`use_ndt`, `using_voxel_filter`, `voxel_resolution`, ndt_gicp.cc:31-36)
+    plus the PCL parameters the reference fixes in InitWithOptions (:45-53)."""
+
+    def __init__(self, device: int = 0, max_source_points: int = 131072, max_target_points: int = 524288,
+                 stream: int | None = None, **options):
+        super().__init__(device=device, pair_slots=2, max_source_points=max_source_points,
+                         max_target_points=max(max_target_points, max_source_points), stream=stream)
+        self._gopts = _capi.NdtGicpOptions()
+        self._lib.smhip_ndt_gicp_default_options(ctypes.byref(self._gopts))
+        if options:
+            self.set_gicp_options(**options)
+        self.last_gicp_stats = None
+
+    def set_gicp_options(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self._gopts, k):
+                raise KeyError(f"unknown option {k}")
+            setattr(self._gopts, k, v)
+        self._check(self._lib.smhip_ndt_gicp_set_options(self._h, ctypes.byref(self._gopts)))
+
+    def set_input_source(self, points, slot: int = 0):
+        a = np.ascontiguousarray(np.asarray(points, dtype=np.float32))
+        self._check(self._lib.smhip_ndt_gicp_set_source_f32(self._h, a.ctypes.data_as(_capi.c_float_p), a.shape[1], a.shape[0]))
+
+    def set_input_target(self, points, normals=None, slot: int = 0):
+        a = np.ascontiguousarray(np.asarray(points, dtype=np.float32))
+        self._check(self._lib.smhip_ndt_gicp_set_target_f32(self._h, a.ctypes.data_as(_capi.c_float_p), a.shape[1], a.shape[0]))
+
+    def _run(self, fn, guess):
+        G = np.eye(4) if guess is None else np.asarray(guess, dtype=np.float64)
+        g = np.ascontiguousarray(G.T).reshape(-1)
+        res = np.zeros(16)
+        score = ctypes.c_double()
+        st = _capi.NdtGicpStats()
+        self._check(fn(self._h, g.ctypes.data_as(_capi.c_double_p), res.ctypes.data_as(_capi.c_double_p),
+                       ctypes.byref(score), ctypes.byref(st)))
+        self.last_gicp_stats = {k: getattr(st, k) for k, _ in st._fields_ if k != "reserved"}
+        return score.value, res.reshape(4, 4).T.copy()
+
+    def align(self, guess=None):
+        self.final_score_, result = self._run(self._lib.smhip_ndt_gicp_align, guess)
+        return bool(self.last_gicp_stats["ok"]), result
+
+    # -- parity-test hooks ---------------------------------------------------------------------
+    def gicp_only(self, source, target, guess=None):
+        """pcl GICP alone (no filter, no NDT) on the given clouds; returns (fitness, result)."""
+        a = np.ascontiguousarray(np.asarray(source, dtype=np.float32))
+        b = np.ascontiguousarray(np.asarray(target, dtype=np.float32))
+        self._check(self._lib.smhip_set_source_f32(self._h, 0, a.ctypes.data_as(_capi.c_float_p), a.shape[1], a.shape[0]))
+        self._check(self._lib.smhip_set_target_f32(self._h, 0, b.ctypes.data_as(_capi.c_float_p), b.shape[1], None, 0, b.shape[0]))
+        return self._run(self._lib.smhip_gicp_align, guess)
+
+    def get_downsampled(self, which: int) -> np.ndarray:
+        n = ctypes.c_int()
+        self._check(self._lib.smhip_ndt_gicp_get_downsampled(self._h, which, None, 0, ctypes.byref(n)))
+        out = np.zeros((n.value, 3), np.float32)
+        self._check(self._lib.smhip_ndt_gicp_get_downsampled(self._h, which, out.ctypes.data_as(_capi.c_float_p), n.value, ctypes.byref(n)))
+        return out
+
+    def get_covariances(self, which: int, n: int) -> np.ndarray:
+        c = np.zeros((n, 6))
+        self._check(self._lib.smhip_gicp_get_covariances(self._h, which, c.ctypes.data_as(_capi.c_double_p), n))
+        C = np.zeros((n, 3, 3))
+        C[:, 0, 0] = c[:, 0]; C[:, 0, 1] = C[:, 1, 0] = c[:, 1]; C[:, 0, 2] = C[:, 2, 0] = c[:, 2]
+        C[:, 1, 1] = c[:, 3]; C[:, 1, 2] = C[:, 2, 1] = c[:, 4]; C[:, 2, 2] = c[:, 5]
+        return C
+
+
 class IcpPointMatcherHip:
     """registrators::IcpUsingPointMatcher (/root/reference/registrators/icp_pointmatcher.cc:104-247) on the
     same GPU engine: IcpFast is the author's restatement of exactly this libpointmatcher chain.

@@ -82,7 +82,25 @@ int main(int argc, char** argv) {
     pm_ok = pm->Align(guess, pres);
     pm_score = pm->GetFitnessScore();
   }
-  std::printf("{\"pm_ok\": %s, \"pm_score\": %.17g, \"pm_result\": [", pm_ok ? "true" : "false", pm_score);
+  // registrators::NdtWithGicp (type 3) with the reference's own option names
+  reg::MatcherOptions gopt; gopt.type = reg::kNdtWithGicp;
+  gopt.registrator_options_node = "<param name=\"use_ndt\"> true </param><param name=\"voxel_resolution\"> 0.2 </param>";
+  auto gm = reg::CreateMatcher(gopt);
+  reg::Matrix4d gres = reg::Matrix4d::Identity();
+  bool gicp_ok = false; double gicp_score = -1; int gicp_type = -1;
+  if (gm) {
+    InnerPointCloudData::Ptr target4(new InnerPointCloudData(ReadKittiBin(argv[1])));
+    gm->SetInputTarget(target4);
+    gm->SetInputSource(source);
+    gicp_ok = gm->Align(guess, gres);
+    gicp_score = gm->GetFitnessScore();
+    gicp_type = (int)gm->GetType();
+  }
+  std::printf("{\"gicp_ok\": %s, \"gicp_score\": %.17g, \"gicp_type\": %d, \"gicp_result\": [", gicp_ok ? "true" : "false", gicp_score, gicp_type);
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) std::printf("%.17g%s", gres(r, c), (r == 3 && c == 3) ? "" : ", ");
+  std::printf("], ");
+  std::printf("\"pm_ok\": %s, \"pm_score\": %.17g, \"pm_result\": [", pm_ok ? "true" : "false", pm_score);
   for (int r = 0; r < 4; ++r)
     for (int c = 0; c < 4; ++c) std::printf("%.17g%s", pres(r, c), (r == 3 && c == 3) ? "" : ", ");
   std::printf("], ");

@@ -67,3 +67,12 @@ def test_cpp_interface_matches_python_path_and_oracle(tmp_path, velo20k):
     da, dt = sm.se3_error(Rn, nref["result"])
     assert da < 1e-4 and dt < 1e-3, (da, dt)
     assert abs(res["ndt_score"] - nref["score"]) <= 1e-3 * nref["score"]
+    # registrators::NdtWithGicp through the same C++ surface vs its restatement
+    from oracle import ndt_gicp as ong
+    assert res["gicp_type"] == 3
+    gref = ong.ndt_gicp_align(c["src"][:, :3], c["tgt"][:, :3], c["guess"])
+    assert res["gicp_ok"] == gref["ok"]
+    Rg = np.array(res["gicp_result"]).reshape(4, 4)
+    da, dt = sm.se3_error(Rg, gref["result"])
+    assert da < 1e-4 and dt < 1e-3, (da, dt)
+    assert abs(res["gicp_score"] - gref["score"]) < 1e-3

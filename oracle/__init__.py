@@ -9,4 +9,6 @@ golden vector or known-answer fixture for any registrator
 and cannot be compiled in this image (Eigen / PCL / libnabo / libpointmatcher /
 glog are absent), so these restatements are anchored on the reference's source
 text (file:line cited per function) and on self-consistency KATs only.
+`ndt_gicp.py` (registrators::NdtWithGicp) additionally restates un-vendored PCL 1.8.1
+(ApproximateVoxelGrid, NDT, GICP, BFGS) from its published algorithm; its header says which parts.
 """

@@ -287,6 +287,36 @@ smhip_status smhip_gicp_align(smhip_handle h, const double guess[16], double res
 smhip_status smhip_ndt_gicp_get_downsampled(smhip_handle h, int which, float* xyz, int capacity, int* n_out);
 smhip_status smhip_gicp_get_covariances(smhip_handle h, int which, double* cov, int n);
 
+/* ---- pre_processers::filter (pre_processors/filter_*.cc): the front end's pre-filters -----------
+ * Range / AxisRange / BoundingBoxRemoval / RandomSampler / VoxelGrid applied in order to one cloud on the device,
+ * as filter::Factory::Filter does (filter_factory.cc:83-106).  p[] carries each filter's float parameters:
+ *   RANGE                 p[0] min_range, p[1] max_range
+ *   AXIS_RANGE            p[0] min, p[1] max, axis_index 0 / 1 / 2
+ *   RANDOM_SAMPLER        p[0] sampling_rate; seed selects the (counter-based) random stream
+ *   VOXEL_GRID            p[0] voxel_size
+ *   BOUNDING_BOX_REMOVAL  p[0..2] min_x min_y min_z, p[3..5] max_x max_y max_z */
+enum { SMHIP_FILTER_RANGE = 1, SMHIP_FILTER_AXIS_RANGE = 2, SMHIP_FILTER_RANDOM_SAMPLER = 3, SMHIP_FILTER_VOXEL_GRID = 4,
+       SMHIP_FILTER_BOUNDING_BOX_REMOVAL = 5 };
+typedef struct smhip_filter_desc {
+  int32_t type;
+  int32_t axis_index;
+  uint32_t seed;
+  int32_t reserved;
+  float p[6];
+} smhip_filter_desc;
+/* the filter's constructor defaults / its ConfigsValid() (1 = valid) */
+void smhip_filter_default(int type, smhip_filter_desc* f);
+int smhip_filter_config_valid(const smhip_filter_desc* f);
+/* points: n rows of stride 4 (x y z intensity: KITTI; factor = i / n as the collector sets it,
+ * builder/data/data_collector.h:202-204) or 5 floats (InnerPointType).  *n_out = size of the filtered cloud. */
+smhip_status smhip_filter_chain_f32(smhip_handle h, const float* points, int stride_floats, int n,
+                                    const smhip_filter_desc* chain, int n_filters, int* n_out);
+/* the filtered cloud as InnerPointType rows (n x 5 floats) and, per point, the row of the input it came from
+ * (inliers composed over the chain; -1 after a VoxelGrid).  Either pointer may be NULL. */
+smhip_status smhip_filter_get_output(smhip_handle h, float* points5, int32_t* source_index, int n);
+/* the filtered cloud becomes SetInputSource of `slot` without leaving the device */
+smhip_status smhip_filter_output_to_source(smhip_handle h, int slot);
+
 /* ---- profiling ----------------------------------------------------------- */
 /* enable: 0 off, 1 events around every launch, 2 events around the dominant NN kernel only (cheap enough to
  * leave on inside a timed region) */

@@ -64,6 +64,11 @@ class NdtGicpStats(ctypes.Structure):
                 ("reserved", ctypes.c_int32), ("ndt_score", ctypes.c_double), ("gicp_score", ctypes.c_double)]
 
 
+class FilterDesc(ctypes.Structure):
+    _fields_ = [("type", ctypes.c_int32), ("axis_index", ctypes.c_int32), ("seed", ctypes.c_uint32),
+                ("reserved", ctypes.c_int32), ("p", ctypes.c_float * 6)]
+
+
 # name -> (restype, argtypes): every symbol include/smhip.h declares
 SIGNATURES = {
     "smhip_version": (ctypes.c_int, []),
@@ -111,6 +116,12 @@ SIGNATURES = {
     "smhip_gicp_align": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p, ctypes.POINTER(NdtGicpStats)]),
     "smhip_ndt_gicp_get_downsampled": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "smhip_gicp_get_covariances": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, ctypes.c_int]),
+    "smhip_filter_default": (None, [ctypes.c_int, ctypes.POINTER(FilterDesc)]),
+    "smhip_filter_config_valid": (ctypes.c_int, [ctypes.POINTER(FilterDesc)]),
+    "smhip_filter_chain_f32": (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(FilterDesc),
+                                              ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    "smhip_filter_get_output": (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_int32_p, ctypes.c_int]),
+    "smhip_filter_output_to_source": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "smhip_icp_enable_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "smhip_icp_get_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(IcpProfile)]),
 }

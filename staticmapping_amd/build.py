@@ -12,8 +12,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsmhip.so")
 
-HIP_SOURCES = ["smhip_api.hip", "prep_normals.hip", "host_cloud.cc"]            # translation units (each may #include kernel files)
+HIP_SOURCES = ["smhip_api.hip", "prep_normals.hip", "cloud_filters.hip", "host_cloud.cc"]            # translation units (each may #include kernel files)
 HIP_DEPS = ["icp_kernels.hip", "smhip_device.h", "host_cloud.cc", "prep_normals.h", "ndt_kernels.hip", "smhip_ndt_api.hip",
+            "gicp_kernels.hip", "smhip_gicp_api.hip", "smhip_filter_api.hip", "cloud_filters.h",
             os.path.join("..", "..", "include", "smhip.h")]
 
 

@@ -19,6 +19,7 @@
 
 #include "../../include/smhip.h"
 #include "prep_normals.h"
+#include "cloud_filters.h"
 
 using namespace smhip;
 
@@ -30,6 +31,7 @@ struct smhip_context {
   smhip_gicp_state* gicp = nullptr;
   PrepWorkspace* prep = nullptr;          // device CalculateNormals workspace (allocated on first use)
   PrepWorkspace* prep_batch = nullptr;    // the same sized for every slot at once (batched target preparation)
+  FilterWorkspace* filt = nullptr;        // device pre-filters (allocated on first use)
   float4* prep_raw = nullptr;             // raw scan staging on the device
   int device = 0;
   hipStream_t stream = nullptr;
@@ -406,6 +408,7 @@ smhip_status smhip_destroy(smhip_handle h) {
   smhip_internal_free_gicp(h);
   if (h->prep) prep_destroy(h->prep);
   if (h->prep_batch) prep_destroy(h->prep_batch);
+  if (h->filt) filt_destroy(h->filt);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->stage) (void)hipHostFree(h->stage);
   if (h->in_pinned) (void)hipHostFree(h->in_pinned);
@@ -846,6 +849,9 @@ extern "C" void smhip_internal_free_ndt(smhip_context* h) {
   delete h->ndt;
   h->ndt = nullptr;
 }
+
+// ---- pre_processers::filter -----------------------------------------------------------------------
+#include "smhip_filter_api.hip"
 
 // ---- registrators::NdtWithGicp ------------------------------------------------------------------
 #include "smhip_gicp_api.hip"

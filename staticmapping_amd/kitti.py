@@ -57,7 +57,7 @@ def read_poses(path: str) -> np.ndarray:
 
 
 def scan_to_scan_sequence(scans, matcher, batch: int, guesses=None, rank: int = 0, world: int = 1,
-                          prepare_target=None):
+                          prepare_target=None, filter_chain=None):
     """Align every consecutive pair (scan i = target, scan i+1 = source) owned by this rank.
 
     scans: list of float32 [N,4] arrays (or callables returning one, for lazy loading);
@@ -65,6 +65,9 @@ def scan_to_scan_sequence(scans, matcher, batch: int, guesses=None, rank: int = 
     Target preparation (CalculateNormals, builder/map_builder.cc:286,389) runs on the GPU; when the
     previous pair of the chunk already uploaded scan i as its source, that resident copy is re-used.
     `prepare_target`: optional host callable scan -> (points, normals) to override that.
+    `filter_chain`: optional list of filters (staticmapping_amd.filters.make_filter / chain_from_xml): the front end's
+    <filters> chain (config/lidar_only_kitti.xml:18-41) applied on the device to every scan as it is loaded; the
+    filtered cloud goes to its slot without returning to the host.
     Returns (pair_indices, transforms [k,4,4], scores [k], iterations [k]) for this rank's pairs.
     """
     n_pairs = len(scans) - 1
@@ -72,11 +75,20 @@ def scan_to_scan_sequence(scans, matcher, batch: int, guesses=None, rank: int = 
     get = lambda i: scans[i]() if callable(scans[i]) else scans[i]
     out_T, out_s, out_it = [], [], []
     spare = matcher.pair_slots - 1                         # holds a target scan nobody uploaded as a source
+    if filter_chain is not None:
+        from . import filters as _filters
+
+    def load_source(index, slot):
+        if filter_chain is None:
+            matcher.set_input_source(get(index), slot=slot)
+        else:
+            _filters.run_chain_resident(matcher, get(index), filter_chain)
+            _filters.output_to_source(matcher, slot)
     for b0 in range(0, len(mine), batch):
         chunk = mine[b0:b0 + batch]
         g = []
         for s, pair in enumerate(chunk):                  # every source once
-            matcher.set_input_source(get(pair + 1), slot=s)
+            load_source(pair + 1, s)
             g.append(np.eye(4) if guesses is None else guesses[pair])
         if prepare_target is not None:
             for s, pair in enumerate(chunk):
@@ -90,10 +102,15 @@ def scan_to_scan_sequence(scans, matcher, batch: int, guesses=None, rank: int = 
                 if s > 0 and chunk[s - 1] == pair - 1:
                     fr.append(s - 1); to.append(s)
                 elif spare >= len(chunk) and not fr:      # first pair of a consecutive chunk: park its target scan
-                    matcher.set_input_source(get(pair), slot=spare)
+                    load_source(pair, spare)
                     fr.append(spare); to.append(s)
-                else:
+                elif filter_chain is None:
                     matcher.prepare_target(get(pair), slot=s)
+                else:                                     # filtered target with no resident copy: park it in the spare slot first
+                    if fr:
+                        matcher.prepare_targets_from_sources(fr, to); fr, to = [], []
+                    load_source(pair, spare)
+                    matcher.prepare_targets_from_sources([spare], [s])
             if fr:
                 matcher.prepare_targets_from_sources(fr, to)
         T, sc, st = matcher.align_batch(len(chunk), g)

@@ -24,8 +24,31 @@ def _build_exe():
     return EXE
 
 
+def _build_filters_exe():
+    from staticmapping_amd import build
+    lib = build.build()
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "test_filters")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    src = os.path.join(ROOT, "tests", "cpp", "test_filters.cc")
+    hdr = os.path.join(ROOT, "include", "smhip", "filters.h")
+    if (not os.path.exists(exe)) or max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(lib)) > os.path.getmtime(exe):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                               "-L", os.path.dirname(lib), "-lsmhip", "-Wl,-rpath," + os.path.dirname(lib),
+                               "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
 def test_cpp_mirror_compiles_and_links():
     assert os.path.exists(_build_exe())
+    assert os.path.exists(_build_filters_exe())
+
+
+@pytest.mark.gpu
+def test_cpp_filters_replay_the_reference_tests():
+    """tests/cpp/test_filters.cc = the reference's five filter tests + the Factory chain, against include/smhip/filters.h"""
+    out = subprocess.run([_build_filters_exe()], text=True, capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(out.stdout.strip().splitlines()[-1])["failed"] == 0
 
 
 @pytest.mark.gpu

@@ -34,3 +34,36 @@ def test_synthetic_drive_scan_to_scan(tmp_path):
     assert np.linalg.norm(traj[-1][:3, 3] - (np.linalg.inv(poses[0]) @ poses[-1])[:3, 3]) < 0.05
     kitti.write_poses(str(tmp_path / "kitti_pose.txt"), traj)
     assert len(open(tmp_path / "kitti_pose.txt").read().splitlines()) == 7
+
+
+def test_synthetic_drive_with_the_kitti_filter_chain(tmp_path):
+    """The same drive with config/lidar_only_kitti.xml's <filters> chain applied on the device to every scan:
+    filtered sources and filtered targets never return to the host between load and Align."""
+    import staticmapping_amd as sm
+    from staticmapping_amd import synth, kitti, filters as df
+    from oracle import filters as of, cref
+    scene = synth.make_scene(0)
+    poses = [synth.make_pose(t=(0.5 * k, 0.02 * k, 0.0), rpy_deg=(0, 0, 1.0 * k)) for k in range(5)]
+    scans = [synth.velodyne_scan(scene, P, seed=80 + k, n_points=30000) for k, P in enumerate(poses)]
+    rel_true = [np.linalg.inv(poses[k]) @ poses[k + 1] for k in range(4)]
+    guesses = []
+    for T in rel_true:
+        G = np.eye(4); G[:3, 3] = 0.75 * T[:3, 3]; guesses.append(G)
+    chain = [df.make_filter("Range", min_range=5.0), df.make_filter("AxisRange", min=-2.0),
+             df.make_filter("RandomSampler", sampling_rate=0.5, seed=11)]
+    m = sm.IcpFastHip(pair_slots=5, max_source_points=30000, max_target_points=30000, max_iteration=30, early_exit=1)
+    idx, T, sc, it = kitti.scan_to_scan_sequence(scans, m, batch=4, guesses=guesses, filter_chain=chain)
+    assert list(idx) == [0, 1, 2, 3]
+    # the oracle on the same filtered clouds: filters (pinned oracle) -> CalculateNormals -> IcpFast restatement
+    ochain = [dict(of.default(of.RANGE), min_range=5.0), dict(of.default(of.AXIS_RANGE), min=-2.0),
+              dict(of.default(of.RANDOM_SAMPLER), sampling_rate=0.5, seed=11)]
+    for i in range(4):
+        fs, _ = of.run_chain(of.with_factor(scans[i + 1][:, :4]), ochain)
+        ft, _ = of.run_chain(of.with_factor(scans[i][:, :4]), ochain)
+        q, n = sm.calculate_normals(ft[:, :3].astype(np.float64))
+        ref = cref.icp_fast_align(fs[:, :3].astype(np.float64), q, n, guess=guesses[i], max_iteration=30)
+        da, dt = sm.se3_error(T[i], ref["result"])
+        assert da < 1e-4 and dt < 1e-3, (i, da, dt)
+        da, dt = sm.se3_error(T[i], rel_true[i])
+        assert da < 3e-3 and dt < 3e-2, (i, da, dt)
+    m.close()

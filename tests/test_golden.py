@@ -82,3 +82,24 @@ def test_ndt_golden_gpu():
     assert m.last_ndt_stats["iterations"] == g["iterations"]
     assert abs(m.get_fitness_score() - g["score"]) <= 1e-3 * g["score"]
     m.close()
+
+
+@pytest.mark.gpu
+def test_reference_transform_known_answer_through_the_device():
+    """builder/data/test/test_cloud_types.cc:166-187 (TransformPointAndCloud): the point (10, 0, 30) under the identity
+    stays put and under Vector6ToTransform(0,0,0,0,0,pi) goes to (-10, -0, 30).  The device applies the caller's
+    transform inside FindClosests (ApplyTransform is fused), so the known answer is replayed through
+    it: the transformed point must land on a target point placed at the reference's expected coordinates."""
+    import staticmapping_amd as sm
+    src = np.array([[10.0, 0.0, 30.0], [1.0, 2.0, 3.0], [-4.0, 5.0, 6.0], [7.0, -8.0, 9.0]])
+    tgt = np.array([[-10.0, 0.0, 30.0], [10.0, 0.0, 30.0], [50.0, 50.0, 50.0], [-1.0, -2.0, 3.0], [4.0, -5.0, 6.0], [-7.0, 8.0, 9.0]])
+    nrm = np.tile([0.0, 0.0, 1.0], (len(tgt), 1))
+    m = sm.IcpFastHip(pair_slots=1, max_source_points=16, max_target_points=16)
+    m.set_input_source(src); m.set_input_target(tgt, nrm)
+    ids, d2 = m.find_closests(np.eye(4), len(src))
+    assert ids[0] == 1 and d2[0] == 0.0                                     # identity: (10, 0, 30)
+    Rz = np.eye(4); Rz[0, 0] = Rz[1, 1] = np.cos(np.pi); Rz[0, 1] = -np.sin(np.pi); Rz[1, 0] = np.sin(np.pi)
+    ids, d2 = m.find_closests(Rz, len(src))
+    assert list(ids) == [0, 3, 4, 5]                                        # (-x, -y, z) of every source point
+    assert np.all(d2 < 1e-10)                                               # BOOST_CHECK_DOUBLE_EQUAL tolerance squared
+    m.close()

@@ -1,0 +1,67 @@
+// The two back-end callers of the registrator boundary (include/smhip/back_end.h) on synthetic submaps.
+// argv: target.bin source.bin  tx ty tz yaw_deg (source pose; the target pose is the identity)  matcher_type
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <vector>
+
+#include "smhip/back_end.h"
+
+namespace reg = smhip::registrator;
+using smhip::data::InnerPointCloudData;
+using smhip::data::InnerPointType;
+
+static std::vector<InnerPointType> ReadKittiBin(const char* path) {      // ros_node/kitti_reader.cc:91-121
+  std::ifstream f(path, std::ios::binary);
+  std::vector<InnerPointType> pts;
+  float row[4];
+  while (f.read(reinterpret_cast<char*>(row), sizeof(row))) { InnerPointType p; p.x = row[0]; p.y = row[1]; p.z = row[2]; p.intensity = row[3]; pts.push_back(p); }
+  for (size_t i = 0; i < pts.size(); ++i) pts[i].factor = static_cast<float>(static_cast<double>(i) / pts.size());
+  return pts;
+}
+
+static void PrintMatrix(const char* key, const reg::Matrix4d& m, bool last = false) {
+  std::printf("\"%s\": [", key);
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) std::printf("%.17g%s", m(r, c), (r == 3 && c == 3) ? "" : ", ");
+  std::printf("]%s", last ? "" : ", ");
+}
+
+int main(int argc, char** argv) {
+  if (argc < 8) return 2;
+  InnerPointCloudData::Ptr target(new InnerPointCloudData(ReadKittiBin(argv[1])));
+  InnerPointCloudData::Ptr source(new InnerPointCloudData(ReadKittiBin(argv[2])));
+  reg::Matrix4d tpose = reg::Matrix4d::Identity(), spose = reg::Matrix4d::Identity();
+  const double yaw = std::atof(argv[6]) * M_PI / 180.0;
+  spose(0, 0) = std::cos(yaw); spose(0, 1) = -std::sin(yaw); spose(1, 0) = std::sin(yaw); spose(1, 1) = std::cos(yaw);
+  spose(0, 3) = std::atof(argv[3]); spose(1, 3) = std::atof(argv[4]); spose(2, 3) = std::atof(argv[5]);
+
+  smhip::back_end::LoopEdge edge;
+  smhip::back_end::LoopDetectorSettings settings;
+  settings.accept_scan_match_score = 0.8f;                                   // config/lidar_only_kitti.xml:124
+  settings.max_points = 1 << 18;
+  const bool closed = smhip::back_end::CloseLoop(tpose, target, spose, source, settings, &edge);
+  // a hopeless candidate: the same clouds with the source pose 30 m off must be rejected
+  reg::Matrix4d far = spose; far(0, 3) += 30.0; far(1, 3) -= 20.0;
+  smhip::back_end::LoopEdge bad_edge;
+  const bool closed_far = smhip::back_end::CloseLoop(tpose, target, far, source, settings, &bad_edge);
+
+  reg::MatcherOptions mopt;
+  mopt.type = static_cast<reg::Type>(std::atoi(argv[7]));
+  mopt.accepted_min_score = 0.7f;                                            // config/lidar_only_kitti.xml:95
+  mopt.registrator_options_node = mopt.type == reg::kFastIcp ? "<param name=\"max_iteration\"> 50 </param>" : "";
+  const auto sub = smhip::back_end::SubmapPairMatch(mopt, source, spose, target, tpose);
+  const auto sub_far = smhip::back_end::SubmapPairMatch(mopt, source, far, target, tpose);
+
+  std::printf("{\"closed\": %s, \"edge_score\": %.17g, \"closed_far\": %s, ", closed ? "true" : "false", edge.score, closed_far ? "true" : "false");
+  PrintMatrix("edge_guess", edge.init_guess);
+  PrintMatrix("edge_transform", edge.transform);
+  std::printf("\"sub_accepted\": %s, \"sub_score\": %.17g, \"sub_far_accepted\": %s, \"sub_far_score\": %.17g, ",
+              sub.accepted ? "true" : "false", sub.match_score, sub_far.accepted ? "true" : "false", sub_far.match_score);
+  PrintMatrix("sub_guess", sub.guess);
+  PrintMatrix("sub_far_transform", sub_far.transform_to_next);
+  PrintMatrix("sub_far_guess", sub_far.guess);
+  PrintMatrix("sub_transform", sub.transform_to_next, true);
+  std::printf("}\n");
+  return 0;
+}

@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=128, help="scan pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=512, help="scan pairs per GPU per step")
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic scan pairs (replicated over the slots)")
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--nn-mode", choices=["grid", "brute"], default="grid")
@@ -181,8 +181,9 @@ def main():
         if os.path.exists(tj):
             try:
                 tdat = json.load(open(tj))
-                if tdat.get("pairs_per_launch") == pairs_per_launch and tdat.get("nn_mode") == args.nn_mode:
-                    traffic = tdat.get("hbm_bytes_per_launch")
+                if tdat.get("nn_mode") == args.nn_mode and tdat.get("source_points") in (None, ns):
+                    # counters are per launch of `pairs_per_launch` pairs; traffic is per point, so it scales with the pairs
+                    traffic = int(tdat["hbm_bytes_per_launch"] * pairs_per_launch / tdat["pairs_per_launch"])
             except Exception:
                 traffic = None
         alg_bytes = algorithmic_bytes_per_alignment(ns, nt)

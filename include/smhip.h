@@ -75,9 +75,9 @@ typedef struct smhip_icp_options {
   int32_t no_certify;           /* 1 = search every query in every iteration instead of first trying the nearest-neighbour
                                    certificate (runner-up bound minus the query's motion); default 0 = certificates on */
   int32_t no_lds_table;         /* 1: voxel lookups from global memory (nn_ball) instead of LDS row tables (nn_ball_lds) */
-  int32_t no_overlap;           /* 1: keep a batch on one stream (default 0: batches of >= 16 pairs are split over two
-                                   streams so one half's latency-bound launches hide behind the other half's NN) */
-  int32_t reserved[1];
+  int32_t no_overlap;           /* 1: keep a batch on one stream (default 0: a batch is split into parts of >= 16 pairs on
+                                   separate streams so one part's latency-bound launches hide behind the others' NN) */
+  int32_t overlap_streams;      /* number of such parts, 1..4; 0 = default (2; more parts measured no faster) */
 } smhip_icp_options;
 
 /* Per-call statistics (all optional to read). */

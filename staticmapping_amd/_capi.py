@@ -17,7 +17,7 @@ class IcpOptions(ctypes.Structure):
                 ("grid_max_ring", ctypes.c_int32), ("check_every", ctypes.c_int32),
                 ("use_ball", ctypes.c_int32), ("exact_matches", ctypes.c_int32), ("ball_radius", ctypes.c_float),
                 ("ball_cap_factor", ctypes.c_float), ("no_certify", ctypes.c_int32), ("no_lds_table", ctypes.c_int32),
-                ("no_overlap", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1)]
+                ("no_overlap", ctypes.c_int32), ("overlap_streams", ctypes.c_int32)]
 
 
 class IcpStats(ctypes.Structure):

@@ -36,8 +36,12 @@ struct smhip_context {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  hipStream_t stream2 = nullptr;          // second half of a batch runs here so its latency-bound kernels
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // (finalize, validate, grid build) hide behind the other half's NN
+  // a batch is split into up to kMaxParts parts on separate streams so that the latency-bound kernels of one part
+  // (finalize, validate, grid build) hide behind the NN / accumulate kernels of the others
+  static constexpr int kMaxParts = 4;
+  hipStream_t side[kMaxParts - 1] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxParts - 1] = {nullptr, nullptr, nullptr};
+  int n_side = 0;
   IcpDev dev{};
   smhip_icp_options opts{};
   std::vector<int> ns, nt, has_normals;
@@ -338,10 +342,12 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return SMHIP_ERR_HIP; }
     h->own_stream = true;
   }
-  if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
-    h->stream2 = nullptr;       // no overlap, still correct
+  if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess) {
+    for (int k = 0; k < smhip_context::kMaxParts - 1; ++k) {      // fewer side streams = less overlap, still correct
+      if (hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking) != hipSuccess) { h->side[k] = nullptr; break; }
+      if (hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(h->side[k]); h->side[k] = nullptr; break; }
+      h->n_side = k + 1;
+    }
   }
   smhip_icp_default_options(&h->opts);
   IcpDev& d = h->dev;
@@ -417,9 +423,10 @@ smhip_status smhip_destroy(smhip_handle h) {
   if (h->ids_pinned) (void)hipHostFree(h->ids_pinned);
   if (h->d2_pinned) (void)hipHostFree(h->d2_pinned);
   for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+  for (int k = 0; k < h->n_side; ++k) {
+    (void)hipStreamSynchronize(h->side[k]); (void)hipStreamDestroy(h->side[k]); (void)hipEventDestroy(h->ev_join[k]);
+  }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return SMHIP_OK;
@@ -665,28 +672,41 @@ smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* g
   if (s) return s;
   s = enqueue_resets(h, npairs);
   if (s) return s;
-  // Split the batch over two streams: the latency-bound launches of one half (finalize, validate, grid
-  // build, near-empty refinement kernels) overlap the throughput-bound NN / accumulate of the other.
-  const bool split = h->opts.no_overlap == 0 && npairs >= 16 && h->stream2 != nullptr;
-  Half halves[2];
-  int nh = 1;
-  halves[0] = whole_batch(h, npairs);
-  if (split) {
-    nh = 2;
-    const int n0 = ((npairs / 2 + 7) / 8) * 8;          // keep both halves multiples of 8 for the XCD mapping
-    halves[0].np = n0; halves[0].d.npairs = n0;
-    halves[1] = whole_batch(h, npairs - n0);
-    halves[1].d.pair_base = n0; halves[1].stream = h->stream2;
-    HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-    HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+  // Split the batch over several streams: the latency-bound launches of one part (finalize, validate, grid
+  // build, near-empty refinement kernels) overlap the throughput-bound NN / accumulate of the others.
+  // Parts are multiples of 8 pairs (the XCD mapping) and at least 16 pairs each.
+  int want = h->opts.no_overlap ? 1 : (h->opts.overlap_streams > 0 ? h->opts.overlap_streams : 2);
+  want = std::min(want, std::min(1 + h->n_side, smhip_context::kMaxParts));
+  while (want > 1 && npairs < 16 * want) --want;
+  Half halves[smhip_context::kMaxParts];
+  int nh = want;
+  {
+    int done = 0;
+    for (int k = 0; k < nh; ++k) {
+      int np = (k == nh - 1) ? npairs - done : (((npairs - done) / (nh - k) + 7) / 8) * 8;
+      np = std::min(np, npairs - done);
+      halves[k] = whole_batch(h, np);
+      halves[k].d.pair_base = done;
+      halves[k].stream = k == 0 ? h->stream : h->side[k - 1];
+      done += np;
+    }
   }
-  auto join = [&]() -> smhip_status {
-    if (nh == 2) {
-      HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
-      HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  auto fork = [&]() -> smhip_status {
+    if (nh > 1) {
+      HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+      for (int k = 1; k < nh; ++k) HIPCHK(h, hipStreamWaitEvent(h->side[k - 1], h->ev_fork, 0));
     }
     return SMHIP_OK;
   };
+  auto join = [&]() -> smhip_status {
+    for (int k = 1; k < nh; ++k) {
+      HIPCHK(h, hipEventRecord(h->ev_join[k - 1], h->side[k - 1]));
+      HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[k - 1], 0));
+    }
+    return SMHIP_OK;
+  };
+  s = fork();
+  if (s) return s;
   for (int k = 0; k < nh; ++k) { s = enqueue_grid_build(h, halves[k], nt_max); if (s) return s; }
   const int max_it = h->dev.max_iteration;
   for (int it = 0; it < max_it; ++it) {
@@ -707,10 +727,8 @@ smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* g
       HIPCHK(h, hipMemcpyAsync(h->done_pinned, h->dev.done_count, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));
       if (*h->done_pinned >= (uint32_t)npairs) break;
-      if (nh == 2) {   // re-fork for the next chunk of iterations
-        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-        HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-      }
+      s = fork();      // re-fork for the next chunk of iterations
+      if (s) return s;
     }
   }
   s = join();

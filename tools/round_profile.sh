@@ -9,8 +9,8 @@ export TMPDIR=/tmp
 python bench.py > "$out/bench_line.json" 2> "$out/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python bench.py --no-cpu-baseline > "$out/bench_line_traced.json" 2> "$out/trace.err"
 find "$out/trace" -name '*kernel_stats.csv' -exec cp {} "$out/bench_kernel_stats.csv" \;
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python tools/profile_target.py B=128 reps=1 > "$out/pmc_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python tools/profile_target.py B=128 reps=1 > "$out/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python tools/profile_target.py B=512 reps=1 > "$out/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python tools/profile_target.py B=512 reps=1 > "$out/pmc_write.log" 2>&1
 python tools/pmc_summary.py "$out/pmc_fetch" nn_ball_lds accumulate > "$out/pmc_fetch_summary.txt"
 python tools/pmc_summary.py "$out/pmc_write" nn_ball_lds accumulate > "$out/pmc_write_summary.txt"
 rm -rf "$out/trace" "$out/pmc_fetch" "$out/pmc_write"

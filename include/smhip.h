@@ -285,6 +285,9 @@ smhip_status smhip_gicp_align(smhip_handle h, const double guess[16], double res
  * source, 1 target; xyz may be NULL to query the size) and the GICP covariances (n x 6 doubles: xx xy xz yy yz zz)
  * in that same order (or the upload order for smhip_gicp_align) */
 smhip_status smhip_ndt_gicp_get_downsampled(smhip_handle h, int which, float* xyz, int capacity, int* n_out);
+/* the GICP functor (value and 6-gradient, state x = tx ty tz roll pitch yaw) over the correspondences of the last outer
+ * iteration of the last GICP run, with base_transformation_ = guess */
+smhip_status smhip_gicp_evaluate(smhip_handle h, const double guess[16], const double x[6], double* f, double grad[6]);
 smhip_status smhip_gicp_get_covariances(smhip_handle h, int which, double* cov, int n);
 
 /* ---- pre_processers::filter (pre_processors/filter_*.cc): the front end's pre-filters -----------

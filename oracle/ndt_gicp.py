@@ -329,9 +329,14 @@ class Bfgs:
         alpha, alpha_prev = alpha1, 0.0
         a, b, fa, fb, fpa, fpb = 0.0, alpha, f0, 0.0, fp0, 0.0
         i = 0
+        dbg = getattr(self, "debug", False)
+        if dbg:
+            print("[oracle]     ls f0=%.15g fp0=%.9g alpha1=%.9g" % (f0, fp0, alpha1))
         while i < 100:                                           # bracketing
             i += 1
             falpha = self._F(alpha)
+            if dbg:
+                print("[oracle]     br alpha=%.12g f=%.15g" % (alpha, falpha))
             if falpha > f0 + alpha * rho * fp0 or falpha >= falpha_prev:
                 a, fa, fpa = alpha_prev, falpha_prev, fpalpha_prev
                 b, fb, fpb = alpha, falpha, np.nan
@@ -355,6 +360,8 @@ class Bfgs:
             delta = b - a
             alpha = _interpolate(a, fa, fpa, b, fb, fpb, a + tau2 * delta, b - tau3 * delta, order)
             falpha = self._F(alpha)
+            if dbg and i < 12:
+                print("[oracle]     sec a=%.9g b=%.9g alpha=%.12g f=%.15g fa=%.15g fpa=%.6g" % (a, b, alpha, falpha, fa, fpa))
             if (a - alpha) * fpa <= DBL_EPS:
                 return NO_PROGRESS, alpha
             if falpha > f0 + rho * alpha * fp0 or falpha >= fa:
@@ -413,7 +420,7 @@ class Bfgs:
         return SUCCESS if self.g0norm < eps else RUNNING
 
 
-def estimate_rigid_transformation_bfgs(functor, T_f32, max_inner_iterations=20, gradient_tol=1e-2):
+def estimate_rigid_transformation_bfgs(functor, T_f32, max_inner_iterations=20, gradient_tol=1e-2, debug=False):
     """:189-247.  x from the current transformation_, <= 20 BFGS steps, transformation_ = applyState(I, x)."""
     T = np.asarray(T_f32, dtype=F)
     x = np.zeros(6)
@@ -422,11 +429,16 @@ def estimate_rigid_transformation_bfgs(functor, T_f32, max_inner_iterations=20, 
     x[4] = np.arcsin(-np.float64(T[2, 0]))
     x[5] = np.arctan2(T[1, 0], T[0, 0])
     bfgs = Bfgs(functor)
+    bfgs.debug = debug
     bfgs.init(x)
     inner = 0
+    if debug:
+        print("[oracle] f0=%.12g g0=%s" % (bfgs.f, np.array2string(bfgs.g0, precision=6)))
     while True:
         inner += 1
         result, x = bfgs.one_step(x)
+        if debug:
+            print("[oracle]   inner %d status %d f=%.12g |g|=%.6g x=%s evals=%d" % (inner, result, bfgs.f, bfgs.g0norm, np.array2string(x, precision=8), functor.evals))
         if result:
             break
         result = bfgs.test_gradient(gradient_tol)
@@ -436,7 +448,7 @@ def estimate_rigid_transformation_bfgs(functor, T_f32, max_inner_iterations=20, 
 
 
 def gicp_align(src_f32, tgt_f32, guess_f32, max_iterations=35, rotation_epsilon=1e-3, transformation_epsilon=5e-4,
-               corr_dist_threshold=5.0, k=20, gicp_epsilon=1e-3, max_inner_iterations=20, trace=None):
+               corr_dist_threshold=5.0, k=20, gicp_epsilon=1e-3, max_inner_iterations=20, trace=None, debug=False):
     """computeTransformation (:381-514) + getFitnessScore.  Returns dict(result f32 4x4, score, iterations)."""
     src = np.asarray(src_f32, dtype=F)[:, :3]
     tgt = np.asarray(tgt_f32, dtype=F)[:, :3]
@@ -461,7 +473,7 @@ def gicp_align(src_f32, tgt_f32, guess_f32, max_iterations=35, rotation_epsilon=
         fn = GicpFunctor(guess, src[keep], tgt[j[keep]], Mh)
         if len(keep) < 4:                                         # NotEnoughPointsException -> break (:494-498)
             break
-        T, x, inner = estimate_rigid_transformation_bfgs(fn, T, max_inner_iterations)
+        T, x, inner = estimate_rigid_transformation_bfgs(fn, T, max_inner_iterations, debug=debug)
         ratio = np.full((4, 4), 1.0 / transformation_epsilon)
         ratio[:3, :3] = 1.0 / rotation_epsilon
         delta = float(np.max(ratio * np.abs(prev.astype(np.float64) - T.astype(np.float64))))   # :475-491

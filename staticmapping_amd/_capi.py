@@ -115,6 +115,7 @@ SIGNATURES = {
     "smhip_ndt_gicp_align": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p, ctypes.POINTER(NdtGicpStats)]),
     "smhip_gicp_align": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p, ctypes.POINTER(NdtGicpStats)]),
     "smhip_ndt_gicp_get_downsampled": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    "smhip_gicp_evaluate": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "smhip_gicp_get_covariances": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, ctypes.c_int]),
     "smhip_filter_default": (None, [ctypes.c_int, ctypes.POINTER(FilterDesc)]),
     "smhip_filter_config_valid": (ctypes.c_int, [ctypes.POINTER(FilterDesc)]),

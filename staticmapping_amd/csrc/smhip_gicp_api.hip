@@ -6,6 +6,8 @@
 // The matcher keeps its raw clouds in private device buffers (the reference converts its stored clouds in every
 // Align, ndt_gicp.cc:59-76) and uses pair slot 0 as the working pair for the down-sampled clouds and slot 1 as
 // scratch for the source's neighbour search, so the handle needs pair_slots >= 2.
+#include <cstdlib>
+#include <cstdio>
 #include "gicp_kernels.hip"
 
 namespace {
@@ -217,8 +219,11 @@ struct Bfgs {
     double a = 0, b = alpha, fa = f0v, fb = 0, fpa = fp0v, fpb = 0;
     int i = 0;
     bool bracketed = false;
+    const bool dbg = std::getenv("SMHIP_GICP_DEBUG") != nullptr;
+    if (dbg) std::fprintf(stderr, "[gicp]     ls f0=%.15g fp0=%.9g alpha1=%.9g\n", f0v, fp0v, alpha1);
     while (i++ < 100) {
       falpha = F(alpha);
+      if (dbg) std::fprintf(stderr, "[gicp]     br alpha=%.12g f=%.15g\n", alpha, falpha);
       if (falpha > f0v + alpha * rho * fp0v || falpha >= falpha_prev) {
         a = alpha_prev; fa = falpha_prev; fpa = fpalpha_prev; b = alpha; fb = falpha; fpb = NAN; bracketed = true; break;
       }
@@ -236,6 +241,7 @@ struct Bfgs {
       const double delta = b - a;
       alpha = interpolate(a, fa, fpa, b, fb, fpb, a + tau2 * delta, b - tau3 * delta, order);
       falpha = F(alpha);
+      if (dbg && i < 12) std::fprintf(stderr, "[gicp]     sec a=%.9g b=%.9g alpha=%.12g f=%.15g fa=%.15g fpa=%.6g\n", a, b, alpha, falpha, fa, fpa);
       if ((a - alpha) * fpa <= 2.220446049250313e-16) return kBfgsNoProgress;
       if (falpha > f0v + rho * alpha * fp0v || falpha >= fa) { b = alpha; fb = falpha; fpb = NAN; }
       else {
@@ -366,9 +372,12 @@ smhip_status gicp_align_slot0(smhip_context* h, const float* guess, float* final
     Bfgs bfgs(fn);
     bfgs.init(x);
     int inner = 0, result;
+    const bool dbg = std::getenv("SMHIP_GICP_DEBUG") != nullptr;
+    if (dbg) std::fprintf(stderr, "[gicp] outer %d m=%u f0=%.12g g0=(%.6g %.6g %.6g %.6g %.6g %.6g)\n", it, ncorr, bfgs.f, bfgs.g0[0], bfgs.g0[1], bfgs.g0[2], bfgs.g0[3], bfgs.g0[4], bfgs.g0[5]);
     do {
       inner++;
       result = bfgs.one_step(x);
+      if (dbg) std::fprintf(stderr, "[gicp]   inner %d status %d f=%.12g |g|=%.6g x=(%.8g %.8g %.8g %.8g %.8g %.8g) evals=%d\n", inner, result, bfgs.f, bfgs.g0norm, x[0], x[1], x[2], x[3], x[4], x[5], G.evals);
       if (result) break;
       result = bfgs.test_gradient(1e-2);
     } while (result == kBfgsRunning && inner < o.gicp_max_inner_iterations);
@@ -554,6 +563,19 @@ smhip_status smhip_gicp_align(smhip_handle h, const double guess[16], double res
   if (fitness) *fitness = fit;
   if (stats) *stats = st;
   return SMHIP_OK;
+}
+
+// parity hook: the GICP functor (f and its 6-gradient, gicp_omp_impl.hpp:250-377) at state x over the
+// correspondences of the LAST outer iteration of the last GICP run, with base_transformation_ = guess
+smhip_status smhip_gicp_evaluate(smhip_handle h, const double guess[16], const double x[6], double* f, double grad[6]) {
+  if (!h || !guess || !x || !f || !grad) return SMHIP_ERR_INVALID_ARGUMENT;
+  GicpHost& g = gicp_of(h);
+  if (!g.allocated || h->ns[0] <= 0) { h->err = "GICP has not run"; return SMHIP_ERR_NOT_READY; }
+  HIPCHK(h, hipSetDevice(h->device));
+  GicpFunctor fn{h, {}, h->ns[0]};
+  colmajor_to_rm_f32(guess, fn.base);
+  fn.fdf(x, *f, grad);
+  return fn.status;
 }
 
 // parity hooks -----------------------------------------------------------------------------------

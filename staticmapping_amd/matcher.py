@@ -348,6 +348,15 @@ class NdtGicpHip(IcpFastHip):
         self._check(self._lib.smhip_set_target_f32(self._h, 0, b.ctypes.data_as(_capi.c_float_p), b.shape[1], None, 0, b.shape[0]))
         return self._run(self._lib.smhip_gicp_align, guess)
 
+    def gicp_evaluate(self, guess, x):
+        """The GICP functor (f, gradient[6]) at state x over the last run's final correspondences."""
+        g = np.ascontiguousarray(np.asarray(guess, dtype=np.float64).T).reshape(-1)
+        xx = _f64(x)
+        f = ctypes.c_double(); grad = np.zeros(6)
+        self._check(self._lib.smhip_gicp_evaluate(self._h, g.ctypes.data_as(_capi.c_double_p), xx.ctypes.data_as(_capi.c_double_p),
+                                                  ctypes.byref(f), grad.ctypes.data_as(_capi.c_double_p)))
+        return f.value, grad
+
     def get_downsampled(self, which: int) -> np.ndarray:
         n = ctypes.c_int()
         self._check(self._lib.smhip_ndt_gicp_get_downsampled(self._h, which, None, 0, ctypes.byref(n)))

@@ -103,3 +103,65 @@ def test_reference_transform_known_answer_through_the_device():
     assert list(ids) == [0, 3, 4, 5]                                        # (-x, -y, z) of every source point
     assert np.all(d2 < 1e-10)                                               # BOOST_CHECK_DOUBLE_EQUAL tolerance squared
     m.close()
+
+
+def _load_make_golden():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_filters_and_ndt_gicp_golden_oracle():
+    import hashlib
+    from oracle import filters as of, ndt_gicp as ong
+    mg = _load_make_golden()
+    g = json.load(open(os.path.join(HERE, "golden", "filters_kitti_chain_12000.json")))
+    rows, chain = mg.filter_inputs()
+    out3, src3 = of.run_chain(of.with_factor(rows), chain[:3])
+    out4, _ = of.run_chain(of.with_factor(rows), chain)
+    assert len(out3) == g["n_after_sampler"] and hashlib.sha256(out3.tobytes()).hexdigest() == g["sampler_sha256"]
+    assert hashlib.sha256(src3.tobytes()).hexdigest() == g["index_sha256"]
+    assert len(out4) == g["n_after_voxel_grid"] and hashlib.sha256(out4.tobytes()).hexdigest() == g["voxel_sha256"]
+    g = json.load(open(os.path.join(HERE, "golden", "ndt_gicp_cfg2_12000.json")))
+    src, tgt, G, T = mg.ndt_gicp_inputs()
+    ds = ong.approximate_voxel_grid(src, 0.2)
+    assert hashlib.sha256(ds.tobytes()).hexdigest() == g["downsampled_source_sha256"]
+    r = ong.ndt_gicp_align(src, tgt, G)
+    assert (r["n_source"], r["n_target"], r["ok"]) == (g["n_source"], g["n_target"], g["ok"])
+    assert r["ndt"]["iterations"] == g["ndt_iterations"] and r["gicp"]["iterations"] == g["gicp_iterations"]
+    assert np.allclose(r["result"], np.array(g["result"]), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_filters_and_ndt_gicp_golden_gpu():
+    import hashlib
+    import staticmapping_amd as sm
+    from staticmapping_amd import filters as df
+    mg = _load_make_golden()
+    g = json.load(open(os.path.join(HERE, "golden", "filters_kitti_chain_12000.json")))
+    rows, ochain = mg.filter_inputs()
+    chain = [df.make_filter("Range", min_range=5.0), df.make_filter("AxisRange", min=-2.0),
+             df.make_filter("RandomSampler", sampling_rate=0.5, seed=21), df.make_filter("VoxelGrid", voxel_size=0.3)]
+    m = sm.NdtGicpHip(max_source_points=16384, max_target_points=16384)
+    out3, src3 = df.run_chain(m, rows, chain[:3])
+    out4, _ = df.run_chain(m, rows, chain)
+    assert hashlib.sha256(out3.tobytes()).hexdigest() == g["sampler_sha256"]
+    assert hashlib.sha256(src3.tobytes()).hexdigest() == g["index_sha256"]
+    assert hashlib.sha256(out4.tobytes()).hexdigest() == g["voxel_sha256"]
+    g = json.load(open(os.path.join(HERE, "golden", "ndt_gicp_cfg2_12000.json")))
+    src, tgt, G, T = mg.ndt_gicp_inputs()
+    m.set_input_source(src); m.set_input_target(tgt)
+    ok, R = m.align(G)
+    st = m.last_gicp_stats
+    assert ok == g["ok"] and (st["n_source"], st["n_target"]) == (g["n_source"], g["n_target"])
+    assert hashlib.sha256(m.get_downsampled(0).tobytes()).hexdigest() == g["downsampled_source_sha256"]
+    # the GICP outer loop stops on a threshold (max |delta| < 1 in units of 1e-3 rad / 0.5 mm): last-bit differences in
+    # the covariances can move the stop by one iteration; the pose tolerance below is what counts
+    assert st["ndt_iterations"] == g["ndt_iterations"] and abs(st["gicp_iterations"] - g["gicp_iterations"]) <= 2
+    da, dt = sm.se3_error(R, np.array(g["result"]))
+    assert da < 3e-3 and dt < 5e-2, (da, dt)            # GICP's own repeatability, see tests/test_ndt_gicp_gpu.py
+    assert abs(m.get_fitness_score() - g["score"]) < 2e-2
+    assert abs(st["ndt_score"] - g["ndt_score"]) < 1e-3 * g["ndt_score"]
+    m.close()

@@ -635,13 +635,16 @@ __device__ __forceinline__ void sweep_run(const float4* __restrict__ tq, uint32_
   for (; j < j1; ++j) test_ascending_ru(tq[j], (int)j, qx, qy, qz, best);
 }
 
+// ITEMS = rounds of 256 queries per workgroup: 4 for batches (fewer histogram flushes, prefetch across rounds), 1 when a
+// launch would otherwise have too few workgroups to fill the GPU (single pairs: 118 -> 469 workgroups for 120 k points).
+template <int ITEMS>
 __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk) {
   int pair, blk;
   if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
   PairState* st = &b.state[pair];
   if (st->done) return;
   const int ns = st->ns;
-  const int base0 = blk * (kNnThreads * kBallItems);
+  const int base0 = blk * (kNnThreads * ITEMS);
   if (base0 >= ns) return;
   __shared__ uint32_t s_hist[kHistBins];
   __shared__ uint32_t s_tab[kLdsTableCap];
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
     if (have_prev) { jp_cur = b.idx[so + i]; if (certify) l_cur = b.lb[so + i]; }
   }
 
-  for (int it = 0; it < kBallItems; ++it) {
+  for (int it = 0; it < ITEMS; ++it) {
     const int base = base0 + it * kNnThreads;
     if (base >= ns) break;                               // block-uniform
     i = base + threadIdx.x;
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
     float4 s_next = make_float4(0, 0, 0, 0);
     int jp_next = -1;
     float l_next = 0.f;
-    if (it + 1 < kBallItems && i_next < ns) {
+    if (it + 1 < ITEMS && i_next < ns) {
       s_next = b.src[so + i_next];
       if (have_prev) { jp_next = b.idx[so + i_next]; if (certify) l_next = b.lb[so + i_next]; }
     }
@@ -1114,6 +1117,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_fallback_resolve(IcpDev b) {
   }
 }
 
+
 // ------------------------------------------------------------------------------------------
 // K2/K3: quantile bin + point-to-plane accumulation
 // ------------------------------------------------------------------------------------------
@@ -1156,12 +1160,7 @@ __device__ __forceinline__ void find_quantile_bin(const uint32_t* __restrict__ g
 // One block per pair, between nn_ball and the refinement kernels: does the quantile stay below
 // every lower bound nn_ball recorded?  If not (or if every match must be exact) switch the ring
 // search + fallback on for this iteration.
-__global__ __launch_bounds__(256) void nn_validate(IcpDev b) {
-  const int pair = b.pair_base + blockIdx.x;
-  PairState* st = &b.state[pair];
-  if (st->done) return;
-  __shared__ uint32_t s_w[17];
-  __shared__ uint32_t s_q[4];
+__device__ __forceinline__ void validate_bounds(const IcpDev& b, PairState* st, int pair, uint32_t* s_w, uint32_t* s_q) {
   find_quantile_bin(b.hist + (size_t)pair * kHistBins, b.rho, s_w, s_q);
   if (threadIdx.x == 0) {
     const bool any = st->hard_count > 0;
@@ -1170,6 +1169,15 @@ __global__ __launch_bounds__(256) void nn_validate(IcpDev b) {
     st->refine = (any && (b.exact_all || below || s_q[2] == 0)) ? 1 : 0;
     if (st->refine) st->refine_total += 1;
   }
+}
+
+__global__ __launch_bounds__(256) void nn_validate(IcpDev b) {
+  const int pair = b.pair_base + blockIdx.x;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  __shared__ uint32_t s_w[17];
+  __shared__ uint32_t s_q[4];
+  validate_bounds(b, st, pair, s_w, s_q);
 }
 
 // J = [p x n ; n], r = (p - q) . n ; acc += upper(J J^T), J r, sqrt(d2), 1     (icp_fast.cc:182-202, 256-303)
@@ -1362,6 +1370,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   __shared__ double s_red[4][29];
   __shared__ double s_tot[29];
   __shared__ double s_part[8][32];
+  __shared__ uint32_t s_keys[kFinalizeKeyCap];
   uint32_t* gh = b.hist + (size_t)pair * kHistBins;
   find_quantile_bin(gh, b.rho, s_w, s_q);
   const uint32_t qbin = s_q[0], below = s_q[1], n_valid = s_q[2], krank = s_q[3];
@@ -1384,7 +1393,14 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
       s_h[threadIdx.x] = 0;
       __syncthreads();
       for (int e = threadIdx.x; e < nb; e += blockDim.x) {
-        const uint32_t key = __float_as_uint(b.d2[so + b.blist[so + e]]) & 0xfffffu;
+        // the boundary bin's keys are read from global memory once and kept in LDS for the other two passes
+        uint32_t key;
+        if (pass == 0 || e >= kFinalizeKeyCap) {
+          key = __float_as_uint(b.d2[so + b.blist[so + e]]) & 0xfffffu;
+          if (e < kFinalizeKeyCap) s_keys[e] = key;
+        } else {
+          key = s_keys[e];
+        }
         if ((key & mask) == prefix) atomicAdd(&s_h[(key >> shift) & (nd - 1u)], 1u);
       }
       __syncthreads();

@@ -138,6 +138,7 @@ struct Half {
   IcpDev d;
   hipStream_t stream;
   int np;
+  bool small = false;      // few workgroups per launch: use the single-round NN / short-chunk accumulate variants
 };
 
 // per-call resets for pairs [0, np) (main stream, before the halves fork)
@@ -201,7 +202,12 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
       if (d.lds_table) {
         // certificate, in-workgroup compaction of the failing queries and LDS-staged search in one launch
         Bracket br(h, 4, st);
-        hipLaunchKernelGGL(nn_ball_lds, gx, dim3(kNnThreads), 0, st, d, nblk);
+        if (f.small) {
+          const int nb1 = ceil_div(ns_max, kNnThreads);
+          hipLaunchKernelGGL(nn_ball_lds<1>, dim3(nb1 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nb1);
+        } else {
+          hipLaunchKernelGGL(nn_ball_lds<kBallItems>, gx, dim3(kNnThreads), 0, st, d, nblk);
+        }
       } else if (d.certify && iteration > 0) {
         // global-memory variant: certificate pass, then a search over the compacted failing queries
         { Bracket br(h, 4, st); hipLaunchKernelGGL(nn_certify, gx, dim3(kNnThreads), 0, st, d, nblk); }
@@ -707,6 +713,9 @@ smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* g
   };
   s = fork();
   if (s) return s;
+  for (int k = 0; k < nh; ++k) {   // launches of fewer than ~2 workgroups per CU take the small-launch kernel variants
+    halves[k].small = halves[k].np * ceil_div(ns_max, kNnThreads * kBallItems) < 512;
+  }
   for (int k = 0; k < nh; ++k) { s = enqueue_grid_build(h, halves[k], nt_max); if (s) return s; }
   const int max_it = h->dev.max_iteration;
   for (int it = 0; it < max_it; ++it) {
@@ -715,8 +724,8 @@ smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* g
       s = enqueue_find_closests_half(h, f, ns_max, it);
       if (s) return s;
       {
-        const int nblk = ceil_div(ns_max, kAccChunk);
         Bracket br(h, 2, f.stream);
+        const int nblk = ceil_div(ns_max, kAccChunk);
         hipLaunchKernelGGL(accumulate, dim3(nblk * 8 * ceil_div(f.np, 8)), dim3(kAccThreads), 0, f.stream, f.d, nblk);
       }
       { Bracket br(h, 3, f.stream); hipLaunchKernelGGL(finalize, dim3(f.np), dim3(256), 0, f.stream, f.d); }

@@ -13,6 +13,7 @@ constexpr int kNnThreads = 256;          // one query per thread, 4 waves per wo
 constexpr int kAccThreads = 256;
 constexpr int kAccItems = 8;             // source points per thread in the accumulate kernel
 constexpr int kAccChunk = kAccThreads * kAccItems;
+constexpr int kFinalizeKeyCap = 4096;     // boundary-bin keys finalize keeps in LDS between its radix-select passes
 constexpr int kAccCols = 32;             // 21 (A upper) + 6 (b) + 1 (sum sqrt d2) + 1 (count) padded to 32
 constexpr int kMaxGridWords = 1 << 18;   // 32-cell words per pair (8 Mi cells)
 constexpr int kTgtReduceBlocks = 32;     // partial blocks for the target mean / bbox

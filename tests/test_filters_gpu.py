@@ -127,3 +127,22 @@ def test_filtered_cloud_feeds_the_matcher_without_a_host_hop(matcher):
     assert np.array_equal(R1, R2)
     da, dt = sm.se3_error(R1, T)
     assert da < 2e-3 and dt < 0.05
+
+
+def test_filter_error_conventions(matcher):
+    import ctypes
+    from staticmapping_amd import _capi
+    raw = cloud(100)
+    with pytest.raises(sm.SmhipError):                          # rows must be x y z intensity [factor]
+        df.run_chain(matcher, raw[:, :3], [df.make_filter("Range")])
+    with pytest.raises(sm.SmhipError):                          # larger than the handle's capacity
+        df.run_chain(matcher, np.zeros((200000, 5), np.float32), [df.make_filter("Range")])
+    d = _capi.FilterDesc(); d.type = 99
+    assert not df.config_valid(d)
+    with pytest.raises(sm.SmhipError):
+        df.run_chain(matcher, raw, [d])
+    df.run_chain(matcher, raw, [df.make_filter("Range", min_range=1e9)])          # everything dropped ...
+    with pytest.raises(sm.SmhipError):                          # ... cannot become a matcher's source
+        df.output_to_source(matcher, 0)
+    got, src = df.run_chain(matcher, raw, [])                   # an empty chain is the identity (filter_factory.cc:90-93)
+    assert np.array_equal(got, raw) and np.array_equal(src, np.arange(100))

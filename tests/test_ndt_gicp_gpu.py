@@ -163,3 +163,34 @@ def test_ndt_rejects_bad_start(clouds, matcher):
     if not ok:
         assert np.allclose(res, far)
         assert abs(matcher.get_fitness_score() - np.exp(-10.0)) < 1e-12
+
+
+def test_error_conventions(clouds):
+    """Status codes instead of glog CHECK aborts / PCL exceptions; nothing throws across the C ABI."""
+    a, b, T = clouds
+    one = sm.NdtGicpHip.__new__(sm.NdtGicpHip)                 # a handle with a single pair slot cannot host the matcher
+    sm.IcpFastHip.__init__(one, pair_slots=1, max_source_points=4096, max_target_points=4096)
+    one._gopts = None
+    import ctypes
+    from staticmapping_amd import _capi
+    pts = np.ascontiguousarray(b[:100])
+    rc = one._lib.smhip_ndt_gicp_set_source_f32(one._h, pts.ctypes.data_as(_capi.c_float_p), 3, 100)
+    assert rc == 7 and b"pair_slots" in one._lib.smhip_last_error(one._h)          # SMHIP_ERR_CAPACITY
+    one.close()
+    m = sm.NdtGicpHip(max_source_points=4096, max_target_points=4096)
+    with pytest.raises(sm.SmhipError):                          # Align before SetInputSource / SetInputTarget
+        m.align()
+    with pytest.raises(sm.SmhipError):                          # bad options are rejected, the old ones stay
+        m.set_gicp_options(gicp_k_correspondences=64)
+    m.set_gicp_options(gicp_k_correspondences=20)
+    with pytest.raises(sm.SmhipError):                          # larger than the handle
+        m.set_input_source(np.zeros((5000, 3), np.float32))
+    with pytest.raises(sm.SmhipError):                          # unsupported row stride
+        m.set_input_source(np.zeros((100, 2), np.float32))
+    tiny = (np.random.default_rng(0).random((10, 3)) * 5).astype(np.float32)
+    m.set_input_source(tiny); m.set_input_target(tiny)
+    m.set_gicp_options(use_ndt=0)
+    with pytest.raises(sm.SmhipError) as e:                     # fewer points than k_correspondences (gicp_omp_impl.hpp:64-68)
+        m.align()
+    assert "k_correspondences" in str(e.value)
+    m.close()

@@ -170,6 +170,18 @@ def main():
         m.fetch_batch(B)
         prof = m.get_profile()
         m.enable_profile(False)
+        # ---- the same kernel with the GPU to itself (one stream, untimed extra step): how long a launch takes when it
+        # does not share the machine with the other half-batch's kernels
+        m.set_options(no_overlap=1)
+        m.enable_profile(2)
+        m.enqueue_batch(B, guesses)
+        m.fetch_batch(B)
+        alone = m.get_profile()
+        m.enable_profile(False)
+        m.set_options(no_overlap=0)
+        alone_ms = alone["ms_nn_main"] / max(1, alone["launches_nn_main"])
+        alone_pairs = B * ICP_ITERS // max(1, alone["launches_nn_main"])
+        alone_gbs = nn_bytes_per_launch(alone_pairs, ns) / (alone_ms * 1e-3) / 1e9
         # ---- roofline of the dominant kernel from the events of the TIMED region
         nn_ms = nn_prof["ms_nn_main"] / max(1, nn_prof["launches_nn_main"])
         # with >= 16 pairs a step is two half-batches on two streams: one launch covers B / 2 pairs
@@ -203,6 +215,9 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "bytes_per_launch": nn_bytes, "pairs_per_launch": pairs_per_launch, "avg_launch_ms": round(nn_ms, 4),
                          "launches_timed": nn_prof["launches_nn_main"],
+                         "alone": {"note": "same kernel on one stream, not sharing the GPU with the other half-batch",
+                                   "pairs_per_launch": alone_pairs, "avg_launch_ms": round(alone_ms, 4),
+                                   "achieved": round(alone_gbs, 2), "frac": round(alone_gbs / HBM_PEAK_GBS, 5)},
                          "whole_alignment": {"algorithmic_bytes": alg_bytes,
                                              "achieved_GBs": round(alg_bytes * value / world / 1e9, 2),
                                              "frac": round(alg_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)}},

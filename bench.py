@@ -180,12 +180,12 @@ def main():
         m.enable_profile(False)
         m.set_options(no_overlap=0)
         alone_ms = alone["ms_nn_main"] / max(1, alone["launches_nn_main"])
-        alone_pairs = B * ICP_ITERS // max(1, alone["launches_nn_main"])
+        alone_pairs = int(round(alone["pairs_nn_main"] / max(1, alone["launches_nn_main"])))
         alone_gbs = nn_bytes_per_launch(alone_pairs, ns) / (alone_ms * 1e-3) / 1e9
         # ---- roofline of the dominant kernel from the events of the TIMED region
         nn_ms = nn_prof["ms_nn_main"] / max(1, nn_prof["launches_nn_main"])
         # with >= 16 pairs a step is two half-batches on two streams: one launch covers B / 2 pairs
-        pairs_per_launch = B * ICP_ITERS * args.steps // max(1, nn_prof["launches_nn_main"])
+        pairs_per_launch = int(round(nn_prof["pairs_nn_main"] / max(1, nn_prof["launches_nn_main"])))
         nn_bytes = nn_bytes_per_launch(pairs_per_launch, ns)
         achieved = nn_bytes / (nn_ms * 1e-3) / 1e9
         traffic = None

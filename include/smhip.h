@@ -78,6 +78,9 @@ typedef struct smhip_icp_options {
   int32_t no_overlap;           /* 1: keep a batch on one stream (default 0: a batch is split into parts of >= 16 pairs on
                                    separate streams so one part's latency-bound launches hide behind the others' NN) */
   int32_t overlap_streams;      /* number of such parts, 1..4; 0 = default (2; more parts measured no faster) */
+  int32_t split_after;          /* iterations >= this run the certificate pass and the search of the failing queries as two
+                                   launches instead of the fused kernel (pays once few certificates fail); 0 = default 8,
+                                   negative = never.  Results are identical either way. */
 } smhip_icp_options;
 
 /* Per-call statistics (all optional to read). */
@@ -105,8 +108,10 @@ typedef struct smhip_icp_profile {
   int32_t launches_find_closests;
   int32_t launches_error_elements;
   int32_t launches_solve;
-  int32_t launches_nn_main;     /* launches of the dominant NN kernel alone */
+  int32_t launches_nn_main;     /* launches of the dominant NN kernel alone (nn_ball_lds; the certificate / listed-search
+                                   launches of the converged iterations count under find_closests only) */
   double ms_nn_main;            /* its summed duration (subset of ms_find_closests) */
+  double pairs_nn_main;         /* pairs those launches covered, summed (pairs per launch = this / launches_nn_main) */
 } smhip_icp_profile;
 
 /* ---- library / device ------------------------------------------------- */

@@ -17,7 +17,8 @@ class IcpOptions(ctypes.Structure):
                 ("grid_max_ring", ctypes.c_int32), ("check_every", ctypes.c_int32),
                 ("use_ball", ctypes.c_int32), ("exact_matches", ctypes.c_int32), ("ball_radius", ctypes.c_float),
                 ("ball_cap_factor", ctypes.c_float), ("no_certify", ctypes.c_int32), ("no_lds_table", ctypes.c_int32),
-                ("no_overlap", ctypes.c_int32), ("overlap_streams", ctypes.c_int32)]
+                ("no_overlap", ctypes.c_int32), ("overlap_streams", ctypes.c_int32),
+                ("split_after", ctypes.c_int32)]
 
 
 class IcpStats(ctypes.Structure):
@@ -31,7 +32,7 @@ class IcpProfile(ctypes.Structure):
                 ("ms_error_elements", ctypes.c_double), ("ms_solve", ctypes.c_double),
                 ("launches_find_closests", ctypes.c_int32), ("launches_error_elements", ctypes.c_int32),
                 ("launches_solve", ctypes.c_int32), ("launches_nn_main", ctypes.c_int32),
-                ("ms_nn_main", ctypes.c_double)]
+                ("ms_nn_main", ctypes.c_double), ("pairs_nn_main", ctypes.c_double)]
 
 
 class NdtOptions(ctypes.Structure):

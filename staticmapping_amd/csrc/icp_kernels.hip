@@ -430,8 +430,11 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
   PairState* st = &b.state[pair];
   if (st->done) return;
   const int count = LISTED ? (int)st->deferred_count : st->ns;
-  const int base = blk * (kNnThreads * kBallItems);
-  if (base >= count) return;
+  const int base0 = blk * (kNnThreads * kBallItems);
+  if (base0 >= count) return;
+  // LISTED: a small fixed grid strides over the list of failing queries (a handful once ICP has settled, all of them
+  // in the worst case); the unlisted form covers every query with one workgroup per 1024
+  const int stride = LISTED ? nblk * (kNnThreads * kBallItems) : count;
   __shared__ uint32_t s_hist[kHistBins];
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
   __syncthreads();
@@ -447,6 +450,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
   const bool have_prev = st->iter > 0;
   uint32_t min_lb = 0xffffffffu;
 
+  for (int base = base0; base < count; base += stride)
   for (int it = 0; it < kBallItems; ++it) {
     const int e = base + it * kNnThreads + threadIdx.x;
     bool hard = false;

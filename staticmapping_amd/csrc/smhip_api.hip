@@ -58,7 +58,7 @@ struct smhip_context {
   int last_npairs = 0;
   // profiling
   int profile = 0;               // 0 off, 1 every launch, 2 the dominant NN kernel only
-  struct Ev { hipEvent_t a, b; int cat; };
+  struct Ev { hipEvent_t a, b; int cat; int np; };
   std::vector<Ev> ev_pool;
   size_t ev_used = 0;
   smhip_icp_profile prof{};
@@ -93,7 +93,7 @@ struct Bracket {
   smhip_context* h;
   smhip_context::Ev* ev = nullptr;
   hipStream_t st;
-  Bracket(smhip_context* h_, int cat, hipStream_t st_) : h(h_), st(st_) {
+  Bracket(smhip_context* h_, int cat, hipStream_t st_, int np = 0) : h(h_), st(st_) {
     if (!h->profile || (h->profile == 2 && cat != 4)) return;
     if (h->ev_used == h->ev_pool.size()) {
       smhip_context::Ev e{};
@@ -102,6 +102,7 @@ struct Bracket {
     }
     ev = &h->ev_pool[h->ev_used++];
     ev->cat = cat;
+    ev->np = np;
     (void)hipEventRecord(ev->a, st);
   }
   ~Bracket() {
@@ -118,7 +119,7 @@ void collect_profile(smhip_context* h) {
       case 0: h->prof.ms_prepare += ms; break;
       case 1: h->prof.ms_find_closests += ms; h->prof.launches_find_closests++; break;
       case 4: h->prof.ms_find_closests += ms; h->prof.launches_find_closests++;
-              h->prof.ms_nn_main += ms; h->prof.launches_nn_main++; break;
+              h->prof.ms_nn_main += ms; h->prof.launches_nn_main++; h->prof.pairs_nn_main += h->ev_pool[k].np; break;
       case 2: h->prof.ms_error_elements += ms; h->prof.launches_error_elements++; break;
       case 3: h->prof.ms_solve += ms; h->prof.launches_solve++; break;
     }
@@ -199,9 +200,13 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
     if (d.use_ball) {
       const int nblk = ceil_div(ns_max, kNnThreads * kBallItems);
       const dim3 gx(nblk * 8 * ceil_div(np, 8));
-      if (d.lds_table) {
+      const dim3 glist(kListedBlocks * 8 * ceil_div(np, 8));
+      // the two-launch form pays from ~64 pairs per launch on (measured: -3 % at 32, +2 % at 64, +9 % at 256 pairs);
+      // an explicit split_after option is honoured for any size
+      const bool split_now = d.certify && iteration >= d.split_after && (h->opts.split_after > 0 || np >= 64);
+      if (d.lds_table && !split_now) {
         // certificate, in-workgroup compaction of the failing queries and LDS-staged search in one launch
-        Bracket br(h, 4, st);
+        Bracket br(h, 4, st, np);
         if (f.small) {
           const int nb1 = ceil_div(ns_max, kNnThreads);
           hipLaunchKernelGGL(nn_ball_lds<1>, dim3(nb1 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nb1);
@@ -210,22 +215,24 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
         }
       } else if (d.certify && iteration > 0) {
         // global-memory variant: certificate pass, then a search over the compacted failing queries
-        { Bracket br(h, 4, st); hipLaunchKernelGGL(nn_certify, gx, dim3(kNnThreads), 0, st, d, nblk); }
-        { Bracket br(h, 4, st); hipLaunchKernelGGL(nn_ball<true>, gx, dim3(kNnThreads), 0, st, d, nblk); }
+        // (also what the converged iterations of the LDS variant use: a streaming certificate pass at full occupancy and a
+        // near-empty listed search beat the fused kernel once only a handful of certificates fail)
+        { Bracket br(h, d.lds_table ? 1 : 4, st, np); hipLaunchKernelGGL(nn_certify, gx, dim3(kNnThreads), 0, st, d, nblk); }
+        { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_ball<true>, glist, dim3(kNnThreads), 0, st, d, kListedBlocks); }
       } else {
-        Bracket br(h, 4, st);
+        Bracket br(h, 4, st, np);
         hipLaunchKernelGGL(nn_ball<false>, gx, dim3(kNnThreads), 0, st, d, nblk);
       }
       { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_validate, dim3(np), dim3(256), 0, st, d); }
       { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_ring<true>, dim3(32, np), dim3(kNnThreads), 0, st, d); }
     } else {
-      Bracket br(h, 4, st);
+      Bracket br(h, 4, st, np);
       hipLaunchKernelGGL(nn_ring<false>, g, dim3(kNnThreads), 0, st, d);
     }
     { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_fallback_scan, dim3(kFallbackSlices, np), dim3(kNnThreads), 0, st, d); }
     { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_fallback_resolve, dim3(32, np), dim3(kNnThreads), 0, st, d); }
   } else {
-    Bracket br(h, 4, st);
+    Bracket br(h, 4, st, np);
     hipLaunchKernelGGL(nn_brute, g, dim3(kNnThreads), 0, st, d);
   }
   return SMHIP_OK;
@@ -255,6 +262,7 @@ void sync_options(smhip_context* h) {
   h->dev.use_ball = h->opts.use_ball;
   h->dev.sort_cells = 1;
   h->dev.certify = h->opts.no_certify ? 0 : 1;
+  h->dev.split_after = h->opts.split_after > 0 ? h->opts.split_after : (h->opts.split_after < 0 ? 1 << 30 : 8);
   h->dev.lds_table = h->opts.no_lds_table ? 0 : 1;
   h->dev.cap_factor = h->opts.ball_cap_factor > 1.0f ? h->opts.ball_cap_factor : 1.5f;
   h->dev.exact_all = h->opts.exact_matches;

@@ -22,6 +22,7 @@ constexpr int kFallbackSlices = 64;
 constexpr int kLdsTableCap = 1024;        // u32 entries of the per-workgroup row table in nn_ball_lds (4 KiB)
 constexpr int kLdsPointCap = 512;         // target points staged per round (8 KiB)
 constexpr int kLdsRowCap = 256;           // grid rows of the box whose runs are staged (<= workgroup size)
+constexpr int kListedBlocks = 32;          // workgroups per pair of the listed search (nn_ball<true>): it strides over the list
 constexpr int kBallItems = 4;            // queries per thread in nn_ball (1024 per block: fewer histogram flushes)      // target slices the fallback sweep is spread over         // target points staged in LDS per tile (16 KiB as float4)
 
 // Per-pair device state.  Everything an iteration needs and everything the host reads back.
@@ -119,6 +120,7 @@ struct IcpDev {
   int32_t use_ball;          // 1 = ball-bounded search with certified trimming; 0 = ring search over every query
   int32_t lds_table;         // 1 = nn_ball_lds (row tables staged in LDS), 0 = nn_ball (global lookups)
   int32_t certify;           // 1 = iterations >= 1 run nn_certify and search only the queries whose certificate fails
+  int32_t split_after;       // iterations >= this run the certificate pass and the listed search as two launches
   int32_t exact_all;         // 1 = every match exact (no lower bounds survive), e.g. find_closests
   float ball_radius;         // largest search radius of nn_ball (first iteration / clamp)
   float cap_factor;          // next cap = cap_factor x quantile distance

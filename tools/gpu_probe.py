@@ -16,7 +16,7 @@ mortons = [int(x) for x in kv.get("morton", "0").split(",")]
 modes = [int(x) for x in kv.get("mode", "1").split(",")]
 tiles = [int(x) for x in kv.get("ball", "1").split(",")]
 margins = [float(x) for x in kv.get("radius", "0.5").split(",")]
-capf = float(kv.get("capf", "1.5")); twop = int(kv.get("nocert", "0")); nolds = int(kv.get("nolds", "0")); noov = int(kv.get("noov", "0")); nstreams = int(kv.get("streams", "0"))
+capf = float(kv.get("capf", "1.5")); twop = int(kv.get("nocert", "0")); nolds = int(kv.get("nolds", "0")); noov = int(kv.get("noov", "0")); nstreams = int(kv.get("streams", "0")); split = int(kv.get("split", "0"))
 
 
 def morton_order(p, cell=0.25):
@@ -46,7 +46,7 @@ for mode in modes:
        for tile in tiles:
         for margin in margins:
          for B in batches:
-            m = sm.IcpFastHip(pair_slots=B, max_source_points=len(b), max_target_points=len(q), use_ball=tile, ball_radius=margin, ball_cap_factor=capf, no_certify=twop, no_lds_table=nolds, no_overlap=noov, overlap_streams=nstreams,
+            m = sm.IcpFastHip(pair_slots=B, max_source_points=len(b), max_target_points=len(q), use_ball=tile, ball_radius=margin, ball_cap_factor=capf, no_certify=twop, no_lds_table=nolds, no_overlap=noov, overlap_streams=nstreams, split_after=split,
                               max_iteration=20, early_exit=0, nn_mode=mode, grid_cell=cell, grid_max_ring=ring)
             m.set_input_source(b); m.set_input_target(q, n)
             for s in range(1, B): m.copy_slot(0, s)

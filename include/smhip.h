@@ -70,7 +70,8 @@ typedef struct smhip_icp_options {
                                    instead of an exact distance); 0: exact ring search for every query */
   int32_t exact_matches;        /* 1: refine every lower bound to the exact match in every iteration (default 0;
                                    the transform / score are identical either way, only rejected matches differ) */
-  float ball_radius;            /* largest search radius of the ball search in metres (default 0.5) */
+  float ball_radius;            /* largest search radius of the ball search in metres (default 0.3; queries with nothing that close
+                                   are lower-bounded and, if the trimming quantile reaches the bound, refined exactly) */
   float ball_cap_factor;        /* next iteration's search-radius cap = factor x this iteration's quantile distance (default 1.5) */
   int32_t no_certify;           /* 1 = search every query in every iteration instead of first trying the nearest-neighbour
                                    certificate (runner-up bound minus the query's motion); default 0 = certificates on */

@@ -266,7 +266,7 @@ void sync_options(smhip_context* h) {
   h->dev.lds_table = h->opts.no_lds_table ? 0 : 1;
   h->dev.cap_factor = h->opts.ball_cap_factor > 1.0f ? h->opts.ball_cap_factor : 1.5f;
   h->dev.exact_all = h->opts.exact_matches;
-  h->dev.ball_radius = h->opts.ball_radius > 0 ? h->opts.ball_radius : 0.5f;
+  h->dev.ball_radius = h->opts.ball_radius > 0 ? h->opts.ball_radius : 0.3f;
 }
 
 // FindClosests output in the caller's order: source i was uploaded from caller index src.w,
@@ -334,7 +334,7 @@ void smhip_icp_default_options(smhip_icp_options* o) {
   o->check_every = 8;
   o->use_ball = 1;
   o->exact_matches = 0;
-  o->ball_radius = 0.5f;
+  o->ball_radius = 0.3f;
   o->ball_cap_factor = 1.5f;
   o->no_certify = 0;
 }

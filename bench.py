@@ -61,6 +61,10 @@ def build_workload(n_distinct: int, n_points: int):
 
 
 def main():
+    # The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  With RCCL in the process
+    # (its own streams) the two streams a handle overlaps its half-batches on can end up sharing one queue, which
+    # serialises them (measured: 61.7 instead of 54.7 ms per step).  Must be set before the runtime starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -89,8 +93,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # rank 0 prints ONE JSON line on stdout: RCCL's version banner and its warnings (it logs to stdout by default,
+    # some of them at process exit) go to stderr instead
     if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-        os.environ["NCCL_DEBUG"] = "WARN"          # keep RCCL's version banner off stdout: rank 0 prints ONE JSON line
+        os.environ["NCCL_DEBUG"] = "WARN"
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
     under_torchrun = "RANK" in os.environ and "MASTER_PORT" in os.environ
     if world > 1 or under_torchrun:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -203,7 +210,7 @@ def main():
             "metric": "scan-pair alignments/sec (120k-pt KITTI-64, 20 ICP iters)",
             "value": round(value, 2), "unit": "alignments/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64",
             "data": "synthetic",
             "config": {"workload": "BASELINE config #2: IcpFast point-to-plane, 120k-pt synthetic Velodyne-64 scan pair "
                                    f"vs CalculateNormals target ({nt} pts), exactly 20 iterations, rho 0.7",

@@ -356,13 +356,9 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return SMHIP_ERR_HIP; }
     h->own_stream = true;
   }
-  if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess) {
-    for (int k = 0; k < smhip_context::kMaxParts - 1; ++k) {      // fewer side streams = less overlap, still correct
-      if (hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking) != hipSuccess) { h->side[k] = nullptr; break; }
-      if (hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(h->side[k]); h->side[k] = nullptr; break; }
-      h->n_side = k + 1;
-    }
-  }
+  if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) h->ev_fork = nullptr;
+  // side streams are created when a batch first asks for them (ensure_side_streams): the runtime maps streams onto a
+  // handful of hardware queues (GPU_MAX_HW_QUEUES, default 4), so idle streams are not free
   smhip_icp_default_options(&h->opts);
   IcpDev& d = h->dev;
   d.slots = pair_slots; d.ns_cap = max_source_points; d.nt_cap = max_target_points;
@@ -672,6 +668,16 @@ smhip_status smhip_copy_slot(smhip_handle h, int from, int to) {
   return SMHIP_OK;
 }
 
+// fewer side streams than asked for = less overlap, still correct
+static void ensure_side_streams(smhip_context* h, int n) {
+  if (!h->ev_fork) return;
+  for (int k = h->n_side; k < n && k < smhip_context::kMaxParts - 1; ++k) {
+    if (hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking) != hipSuccess) { h->side[k] = nullptr; return; }
+    if (hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(h->side[k]); h->side[k] = nullptr; return; }
+    h->n_side = k + 1;
+  }
+}
+
 // ---- Align -------------------------------------------------------------------------------
 smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* guesses) {
   if (!h || !guesses || npairs < 1 || npairs > h->dev.slots) {
@@ -690,7 +696,9 @@ smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* g
   // build, near-empty refinement kernels) overlap the throughput-bound NN / accumulate of the others.
   // Parts are multiples of 8 pairs (the XCD mapping) and at least 16 pairs each.
   int want = h->opts.no_overlap ? 1 : (h->opts.overlap_streams > 0 ? h->opts.overlap_streams : 2);
-  want = std::min(want, std::min(1 + h->n_side, smhip_context::kMaxParts));
+  want = std::min(want, smhip_context::kMaxParts);
+  if (want > 1 && npairs >= 32) ensure_side_streams(h, want - 1);
+  want = std::min(want, 1 + h->n_side);
   while (want > 1 && npairs < 16 * want) --want;
   Half halves[smhip_context::kMaxParts];
   int nh = want;

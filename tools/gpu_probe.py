@@ -15,7 +15,7 @@ rings = [int(x) for x in kv.get("ring", "8").split(",")]
 mortons = [int(x) for x in kv.get("morton", "0").split(",")]
 modes = [int(x) for x in kv.get("mode", "1").split(",")]
 tiles = [int(x) for x in kv.get("ball", "1").split(",")]
-margins = [float(x) for x in kv.get("radius", "0.5").split(",")]
+margins = [float(x) for x in kv.get("radius", "0.3").split(",")]
 capf = float(kv.get("capf", "1.5")); twop = int(kv.get("nocert", "0")); nolds = int(kv.get("nolds", "0")); noov = int(kv.get("noov", "0")); nstreams = int(kv.get("streams", "0")); split = int(kv.get("split", "0"))
 
 

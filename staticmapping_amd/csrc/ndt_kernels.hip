@@ -45,10 +45,6 @@ struct NdtDev {
   const double* tpart;     // [kTgtReduceBlocks][16] from tgt_reduce
   uint32_t* bits;          // [kNdtMaxWords]
   uint2* words;            // [kNdtMaxWords]
-  uint32_t* vidx;          // [nt] (word << 5) | bit
-  uint32_t* vslot;         // [nt]
-  uint32_t* vord;          // [nt]
-  uint32_t* vcount;        // [nt + 1]
   uint32_t* vstart;        // [nt + 1]
   float4* vpts;            // [nt] points sorted by voxel
   NdtVoxel* vox;           // [nt] one record per occupied voxel
@@ -105,26 +101,6 @@ __device__ __forceinline__ bool ndt_voxel_of(const NdtGridInfo* g, float x, floa
   return i0 >= 0 && i1 >= 0 && i2 >= 0 && i0 < g->div_b[0] && i1 < g->div_b[1] && i2 < g->div_b[2];
 }
 
-__global__ __launch_bounds__(256) void ndt_voxel_mark(NdtDev d) {
-  const NdtGridInfo* g = d.info;
-  if (g->status) return;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= d.nt) return;
-  const float4 p = d.tgt[j];
-  uint32_t code = 0xffffffffu;                                      // non-finite points are skipped (:209-213)
-  if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
-    int i0, i1, i2;
-    if (ndt_voxel_of(g, p.x, p.y, p.z, i0, i1, i2)) {
-      const uint32_t w = (uint32_t)((i2 * g->div_b[1] + i1) * g->wx + (i0 >> 5));
-      // hundreds of points share a voxel: look before the atomic so only the first few actually issue it
-      // (a plain, L1-cached load: a stale zero only costs a redundant atomic)
-      if (!(d.bits[w] & (1u << (i0 & 31)))) atomicOr(&d.bits[w], 1u << (i0 & 31));
-      code = (w << 5) | (uint32_t)(i0 & 31);
-    }
-  }
-  d.vidx[j] = code;
-}
-
 // one 1024-thread block: words = {bits, exclusive rank}; nocc
 __global__ __launch_bounds__(1024) void ndt_voxel_rank(NdtDev d) {
   NdtGridInfo* g = d.info;
@@ -147,58 +123,50 @@ __global__ __launch_bounds__(1024) void ndt_voxel_rank(NdtDev d) {
   if (threadIdx.x == 0) g->nocc = (int)carry;
 }
 
-__global__ __launch_bounds__(256) void ndt_voxel_count(NdtDev d) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  uint32_t slot = 0xffffffffu;
-  if (j < d.nt) {
-    const uint32_t code = d.vidx[j];
-    if (code != 0xffffffffu) {
-      const uint2 wd = d.words[code >> 5];
-      slot = wd.y + __popc(wd.x & ((1u << (code & 31)) - 1u));
-    }
-  }
-  // consecutive points of a scan fall into the same 1 m voxel in long runs: one atomic per
-  // (wave, voxel) instead of one per point
-  uint32_t ord = 0;
-  unsigned long long todo = __ballot(slot != 0xffffffffu);
-  for (int round = 0; round < 4 && todo; ++round) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const uint32_t s = __shfl(slot, leader, 64);
-    const unsigned long long same = __ballot(slot == s);
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&d.vcount[s], (uint32_t)__popcll(same));
-    base = __shfl(base, leader, 64);
-    if (slot == s) ord = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-    todo &= ~same;
-  }
-  if ((todo >> lane) & 1ull) ord = atomicAdd(&d.vcount[slot], 1u);   // incoherent input order: one atomic each
-  if (j < d.nt) { d.vslot[j] = slot; d.vord[j] = ord; }
-}
-
-__global__ __launch_bounds__(1024) void ndt_voxel_cscan(NdtDev d) {
-  const int n = d.info->nocc;
-  __shared__ uint32_t s_w[17];
-  uint32_t carry = 0;
-  for (int t0 = 0; t0 < n; t0 += 1024) {
-    const int k = t0 + (int)threadIdx.x;
-    const uint32_t c = k < n ? d.vcount[k] : 0u;
-    uint32_t total;
-    const uint32_t ex = carry + block_excl_scan(c, s_w, &total);
-    if (k < n) d.vstart[k] = ex;
-    carry += total;
-  }
-  if (threadIdx.x == 0) d.vstart[n] = carry;
-}
-
-__global__ __launch_bounds__(256) void ndt_voxel_scatter(NdtDev d) {
+// ---- sort-based build: (voxel code, point) pairs radix-sorted by the caller, then one pass marks the
+// first point of every voxel (one atomicOr per VOXEL instead of one per point: 500 k points fall into a few
+// thousand 1 m voxels) and one pass, after ndt_voxel_rank, records the voxel starts and gathers the points.
+__global__ __launch_bounds__(256) void ndt_voxel_keys64(NdtDev d, unsigned long long* keys, int32_t* vals) {
+  const NdtGridInfo* g = d.info;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= d.nt) return;
-  const uint32_t slot = d.vslot[j];
-  if (slot == 0xffffffffu) return;
-  float4 p = d.tgt[j];
-  p.w = __int_as_float(j);
-  d.vpts[d.vstart[slot] + d.vord[j]] = p;
+  unsigned long long code = 0xffffffffull;                          // non-finite / out-of-box points sort last (:209-213)
+  if (!g->status) {
+    const float4 p = d.tgt[j];
+    int i0, i1, i2;
+    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && ndt_voxel_of(g, p.x, p.y, p.z, i0, i1, i2))
+      code = ((unsigned long long)((i2 * g->div_b[1] + i1) * g->wx + (i0 >> 5)) << 5) | (unsigned long long)(i0 & 31);
+  }
+  keys[j] = code;
+  vals[j] = j;
+}
+
+__global__ __launch_bounds__(256) void ndt_voxel_heads(NdtDev d, const unsigned long long* keys) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.nt) return;
+  const unsigned long long c = keys[s];
+  if (c == 0xffffffffull) return;
+  if (s == 0 || keys[s - 1] != c) atomicOr(&d.bits[(uint32_t)(c >> 5)], 1u << (uint32_t)(c & 31));
+}
+
+__global__ __launch_bounds__(256) void ndt_voxel_starts(NdtDev d, const unsigned long long* keys, const int32_t* vals) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.nt) return;
+  const unsigned long long c = keys[s];
+  const bool valid = c != 0xffffffffull;
+  if (valid) {
+    const int j = vals[s];
+    float4 p = d.tgt[j];
+    p.w = __int_as_float(j);
+    d.vpts[s] = p;
+    if (s == 0 || keys[s - 1] != c) {
+      const uint2 wd = d.words[(uint32_t)(c >> 5)];
+      d.vstart[wd.y + __popc(wd.x & ((1u << (uint32_t)(c & 31)) - 1u))] = (uint32_t)s;
+    }
+  }
+  // one past the last valid point closes the last voxel
+  if (valid && (s == d.nt - 1 || keys[s + 1] == 0xffffffffull)) d.vstart[d.info->nocc] = (uint32_t)s + 1u;
+  if (s == 0 && !valid) d.vstart[0] = 0u;
 }
 
 __device__ void jacobi_eig3(double* A, double* V, double* w) {     // symmetric 3x3, cyclic Jacobi

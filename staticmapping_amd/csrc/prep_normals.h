@@ -1,6 +1,7 @@
 // prep_normals.h -- internal interface of the device-side CalculateNormals (prep_normals.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdint>
 
 namespace smhip {
 struct PrepWorkspace;
@@ -20,4 +21,9 @@ hipError_t prep_morton_sort(PrepWorkspace* w, hipStream_t st, const float4* raw,
 // pcl::ApproximateVoxelGrid (leaf x leaf x leaf) of `raw` (n points, arrival order = array order) into `out`
 // (room for n entries; out[k].w = k).  Blocks until *m_host (number of centroids) is known.
 hipError_t prep_approx_voxel_grid(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float leaf, float4* out, int* m_host);
+// Generic use of the workspace's radix sort by other builders (the NDT voxel grid): fill prep_keys(w, 0) / prep_values(w, 0)
+// with n (key, value) pairs, call prep_sort_pairs, read the sorted pairs from prep_keys(w, 1) / prep_values(w, 1).
+unsigned long long* prep_keys(PrepWorkspace* w, int which);
+int32_t* prep_values(PrepWorkspace* w, int which);
+hipError_t prep_sort_pairs(PrepWorkspace* w, hipStream_t st, int n, int end_bit);
 }  // namespace smhip

@@ -397,6 +397,14 @@ __global__ __launch_bounds__(1024) void finite_min(const float4* raw, int n, flo
 }
 }  // namespace
 
+unsigned long long* prep_keys(PrepWorkspace* w, int which) { return w->keys[which & 1]; }
+int32_t* prep_values(PrepWorkspace* w, int which) { return w->order[which & 1]; }
+hipError_t prep_sort_pairs(PrepWorkspace* w, hipStream_t st, int n, int end_bit) {
+  if (!w || n <= 0 || n > w->cap) return hipErrorInvalidValue;
+  size_t bytes = w->sort_bytes;
+  return rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[0], w->order[1], (unsigned)n, 0, (unsigned)end_bit, st);
+}
+
 // Morton (Z-order) permutation of a cloud on the device: out[k] = raw[perm[k]], w = perm[k].
 hipError_t prep_morton_sort(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float4* out) {
   if (!w || n <= 0 || n > w->cap) return hipErrorInvalidValue;

@@ -126,10 +126,6 @@ smhip_status ndt_ensure(smhip_context* h) {
   A(dev_alloc(h, &d.info, 1));
   A(dev_alloc(h, &d.bits, (size_t)kNdtMaxWords));
   A(dev_alloc(h, &d.words, (size_t)kNdtMaxWords));
-  A(dev_alloc(h, &d.vidx, NT));
-  A(dev_alloc(h, &d.vslot, NT));
-  A(dev_alloc(h, &d.vord, NT));
-  A(dev_alloc(h, &d.vcount, NT + 1));
   A(dev_alloc(h, &d.vstart, NT + 1));
   A(dev_alloc(h, &d.vpts, NT));
   A(dev_alloc(h, &d.vox, NT));
@@ -170,15 +166,21 @@ smhip_status ndt_build_grid(smhip_context* h) {
   h->in_pinned[0].nt = h->nt[0]; h->in_pinned[0].ns = h->ns[0];
   HIPCHK(h, hipMemcpyAsync(const_cast<PairInput*>(h->dev.in), h->in_pinned, sizeof(PairInput), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemsetAsync(d.bits, 0, sizeof(uint32_t) * (size_t)kNdtMaxWords, h->stream));
-  HIPCHK(h, hipMemsetAsync(d.vcount, 0, sizeof(uint32_t) * (size_t)(h->dev.nt_cap + 1), h->stream));
   const int gb = ceil_div(d.nt, 256);
   hipLaunchKernelGGL(tgt_reduce, dim3(kTgtReduceBlocks, 1), dim3(256), 0, h->stream, h->dev);
   hipLaunchKernelGGL(ndt_voxel_setup, dim3(1), dim3(64), 0, h->stream, d, n.opts.resolution);
-  hipLaunchKernelGGL(ndt_voxel_mark, dim3(gb), dim3(256), 0, h->stream, d);
-  hipLaunchKernelGGL(ndt_voxel_rank, dim3(1), dim3(1024), 0, h->stream, d);
-  hipLaunchKernelGGL(ndt_voxel_count, dim3(gb), dim3(256), 0, h->stream, d);
-  hipLaunchKernelGGL(ndt_voxel_cscan, dim3(1), dim3(1024), 0, h->stream, d);
-  hipLaunchKernelGGL(ndt_voxel_scatter, dim3(gb), dim3(256), 0, h->stream, d);
+  // (voxel code, point) pairs sorted with the rocPRIM radix sort of the preparation workspace; the voxel's slot is the
+  // rank of its bit, which is also its position among the sorted unique codes, so the sorted points ARE vpts
+  {
+    smhip_status ps = prep_ensure(h);
+    if (ps) return ps;
+    hipLaunchKernelGGL(ndt_voxel_keys64, dim3(gb), dim3(256), 0, h->stream, d, prep_keys(h->prep, 0), prep_values(h->prep, 0));
+    const hipError_t e = prep_sort_pairs(h->prep, h->stream, d.nt, 33);
+    if (e != hipSuccess) { h->err = std::string("NDT voxel sort: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
+    hipLaunchKernelGGL(ndt_voxel_heads, dim3(gb), dim3(256), 0, h->stream, d, prep_keys(h->prep, 1));
+    hipLaunchKernelGGL(ndt_voxel_rank, dim3(1), dim3(1024), 0, h->stream, d);
+    hipLaunchKernelGGL(ndt_voxel_starts, dim3(gb), dim3(256), 0, h->stream, d, prep_keys(h->prep, 1), prep_values(h->prep, 1));
+  }
   // one wave per occupied voxel; nocc <= nt
   hipLaunchKernelGGL(ndt_voxel_stats, dim3(ceil_div(d.nt, 4)), dim3(256), 0, h->stream, d);
   HIPCHK(h, hipMemcpyAsync(n.info_pinned, d.info, sizeof(NdtGridInfo), hipMemcpyDeviceToHost, h->stream));

@@ -1019,6 +1019,126 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring(IcpDev b) {
   }
 }
 
+// The same exact ring search with kCoopLanes adjacent lanes per query (rows of the cell block dealt round-robin, the
+// group's bests merged with the usual tie rule): a single cloud of ~100 k queries gives the one-query-per-lane form
+// fewer than two waves per SIMD, which cannot hide the latency of its dependent loads; this form has four times the
+// waves.  Used for launches with few queries (the NDT / GICP fitness and correspondence passes, single pairs).
+constexpr int kCoopLanes = 4;
+__global__ __launch_bounds__(kNnThreads) void nn_ring_coop(IcpDev b) {
+  const int pair = b.pair_base + blockIdx.y;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  const int count = st->ns;
+  constexpr int kQueriesPerBlock = kNnThreads / kCoopLanes;
+  if ((int)(blockIdx.x * kQueriesPerBlock) >= count) return;
+  __shared__ uint32_t s_hist[kHistBins];
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+  __syncthreads();
+  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
+  const int sub = threadIdx.x & (kCoopLanes - 1);
+  const size_t so = (size_t)pair * b.ns_cap;
+  const uint2* words = b.words + (size_t)pair * kMaxGridWords;
+  const uint32_t* cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
+  const float4* tq = b.tq + (size_t)pair * b.nt_cap;
+  const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
+  const float inv_h = st->inv_h;
+  const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
+  // the loop bound is rounded up so that all lanes of a group (and a wave) take the same number of trips
+  const int trips = (count + gridDim.x * kQueriesPerBlock - 1) / (gridDim.x * kQueriesPerBlock);
+  for (int trip = 0; trip < trips; ++trip) {
+    const int e = (trip * gridDim.x + blockIdx.x) * kQueriesPerBlock + (threadIdx.x / kCoopLanes);
+    const bool live = e < count;
+    const int i = live ? e : 0;
+    double px, py, pz;
+    transform_point(st->M, b.src[so + i], px, py, pz);
+    const float qx = (float)px, qy = (float)py, qz = (float)pz;
+    Best best = {INFINITY, -1, INFINITY};
+    bool resolved = true;
+    if (live && isfinite(qx) && isfinite(qy) && isfinite(qz)) {
+      const int cx = cell_coord(qx, ox, inv_h), cy = cell_coord(qy, oy, inv_h), cz = cell_coord(qz, oz, inv_h);
+      int rp = 0;
+      resolved = false;
+      for (int r = 1; r <= b.max_ring; r *= 2) {
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, nx - 1);
+        const int y0 = max(cy - r, 0), y1 = min(cy + r, ny - 1);
+        const int z0 = max(cz - r, 0), z1 = min(cz + r, nz - 1);
+        if (r == 1 && x0 <= x1 && y0 <= y1 && z0 <= z1) {
+          // first ring (where nearly every query ends): at most 9 rows, <= 3 per lane -- their word and cstart lookups are
+          // issued together so that a lane exposes three load latencies instead of three per row
+          uint32_t ja[3], jb[3];
+          uint2 wa[3], wc[3];
+          int nrow = 0;
+          {
+            int k = 0;
+            for (int z = z0; z <= z1; ++z)
+              for (int y = y0; y <= y1; ++y, ++k) {
+                if ((k & (kCoopLanes - 1)) != sub || nrow >= 3) continue;
+                const int rowbase = (z * ny + y) * wx;
+                wa[nrow] = words[rowbase + (x0 >> 5)];
+                wc[nrow] = words[rowbase + (x1 >> 5)];
+                ++nrow;
+              }
+          }
+#pragma unroll
+          for (int m = 0; m < 3; ++m)
+            if (m < nrow) {
+              const uint32_t sb = wa[m].y + __popc(wa[m].x & ((1u << (x0 & 31)) - 1u));
+              const uint32_t se = wc[m].y + __popc(wc[m].x & (0xffffffffu >> (31 - (x1 & 31))));
+              ja[m] = cstart[sb]; jb[m] = cstart[se];
+            }
+#pragma unroll
+          for (int m = 0; m < 3; ++m)
+            if (m < nrow)
+              for (uint32_t j = ja[m]; j < jb[m]; ++j) test_any_order(tq[j], (int)j, qx, qy, qz, best);
+        } else if (x0 <= x1 && y0 <= y1 && z0 <= z1) {
+          int k = 0;
+          for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y, ++k) {
+              if ((k & (kCoopLanes - 1)) != sub) continue;
+              const int rowbase = (z * ny + y) * wx;
+              const bool inner = rp > 0 && abs(y - cy) <= rp && abs(z - cz) <= rp;
+              if (!inner) {
+                search_row(words, cstart, tq, rowbase, x0, x1, qx, qy, qz, best);
+              } else {
+                const int xl1 = min(cx - rp - 1, nx - 1), xr0 = max(cx + rp + 1, 0);
+                if (x0 <= xl1) search_row(words, cstart, tq, rowbase, x0, xl1, qx, qy, qz, best);
+                if (xr0 <= x1) search_row(words, cstart, tq, rowbase, xr0, x1, qx, qy, qz, best);
+              }
+            }
+        }
+        // merge the group's bests: smaller distance, then smaller position
+#pragma unroll
+        for (int off = 1; off < kCoopLanes; off <<= 1) {
+          const float od = __shfl_xor(best.d2, off, 64);
+          const int oj = __shfl_xor(best.j, off, 64);
+          if (od < best.d2 || (od == best.d2 && oj >= 0 && (best.j < 0 || oj < best.j))) { best.d2 = od; best.j = oj; }
+        }
+        const float g = block_guarantee(st, qx, qy, qz, cx - r, cx + r, cy - r, cy + r, cz - r, cz + r);
+        if (g == INFINITY || (g > 0.f && best.d2 <= g * g)) { resolved = true; break; }
+        rp = r;
+      }
+    }
+    if (live && sub == 0) {
+      b.d2[so + i] = best.d2;
+      b.idx[so + i] = best.j;
+      b.lb[so + i] = 0.f;
+      if (resolved) {
+        const uint32_t key = __float_as_uint(best.d2);
+        if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
+      } else {
+        const uint32_t pos = atomicAdd(&st->unresolved_count, 1u);
+        b.ulist[so + pos] = i;
+        b.ukeys[so + pos] = ~0ull;
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
+    const uint32_t v = s_hist[k];
+    if (v) atomicAdd(&gh[k], v);
+  }
+}
+
 // LDS-tiled exact brute force over every source point (SMHIP_NN_BRUTE, BASELINE config #2).
 __global__ __launch_bounds__(kNnThreads) void nn_brute(IcpDev b) {
   const int pair = b.pair_base + blockIdx.y;

@@ -225,6 +225,10 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
       }
       { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_validate, dim3(np), dim3(256), 0, st, d); }
       { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_ring<true>, dim3(32, np), dim3(kNnThreads), 0, st, d); }
+    } else if ((long long)np * ns_max < (1ll << 21)) {
+      // few queries in the whole launch: several lanes per query keep the SIMDs busy
+      Bracket br(h, 4, st, np);
+      hipLaunchKernelGGL(nn_ring_coop, dim3(ceil_div(ns_max, kNnThreads / kCoopLanes), np), dim3(kNnThreads), 0, st, d);
     } else {
       Bracket br(h, 4, st, np);
       hipLaunchKernelGGL(nn_ring<false>, g, dim3(kNnThreads), 0, st, d);

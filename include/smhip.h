@@ -259,7 +259,7 @@ typedef struct smhip_ndt_gicp_options {
   double gicp_corr_dist_threshold;     /* 5 m  (gicp_omp.h:118) */
   int32_t gicp_max_inner_iterations;   /* 20   (gicp_omp.h:112) */
   int32_t gicp_k_correspondences;      /* 20   (gicp_omp.h:108) */
-  float gicp_search_cell;              /* grid cell (m) of the k-NN search behind the covariances; 0 = 4 x voxel_resolution.
+  float gicp_search_cell;              /* grid cell (m) of the k-NN search behind the covariances; 0 = 3 x voxel_resolution.
                                           Performance only: the search is exact for any cell. */
   int32_t reserved[3];
 } smhip_ndt_gicp_options;

@@ -73,28 +73,31 @@ __global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pa
       worst = s_d[k - 1][t];
     }
   };
+  // blocks of half-width 0, 1, 2, 4, ... cells around the query's cell; a larger block only visits what the previous one
+  // did not (whole rows outside it, the two x extensions of the rows inside it), so sparse regions cost O(log) steps
   const int rmax = max(max(st->nx, st->ny), st->nz);
-  for (int r = 0; r <= rmax; ++r) {
+  int rp = -1;                                   // half-width already covered
+  for (int r = 0; ; r = (r == 0 ? 1 : 2 * r)) {
     const int X0 = max(cx - r, 0), X1 = min(cx + r, st->nx - 1);
-    for (int dz = -r; dz <= r; ++dz) {
-      const int z = cz + dz;
-      if (z < 0 || z >= st->nz) continue;
-      for (int dy = -r; dy <= r; ++dy) {
-        const int y = cy + dy;
-        if (y < 0 || y >= st->ny) continue;
+    const int Y0 = max(cy - r, 0), Y1 = min(cy + r, st->ny - 1);
+    const int Z0 = max(cz - r, 0), Z1 = min(cz + r, st->nz - 1);
+    for (int z = Z0; z <= Z1; ++z)
+      for (int y = Y0; y <= Y1; ++y) {
         const int rowbase = (z * st->ny + y) * st->wx;
-        if (max(abs(dz), abs(dy)) == r) {
-          scan(rowbase, X0, X1);               // a face row of the shell: its whole x extent
-        } else {                                // an inner row: only the two end cells belong to the shell
-          if (cx - r >= 0) scan(rowbase, cx - r, cx - r);
-          if (cx + r < st->nx) scan(rowbase, cx + r, cx + r);
+        const bool inner = rp >= 0 && abs(y - cy) <= rp && abs(z - cz) <= rp;
+        if (!inner) {
+          scan(rowbase, X0, X1);
+        } else {
+          const int xl1 = min(cx - rp - 1, st->nx - 1), xr0 = max(cx + rp + 1, 0);
+          if (X0 <= xl1) scan(rowbase, X0, xl1);
+          if (xr0 <= X1) scan(rowbase, xr0, X1);
         }
       }
-    }
-    const float g = block_guarantee(st, q.x, q.y, q.z, X0, X1, max(cy - r, 0), min(cy + r, st->ny - 1), max(cz - r, 0),
-                                    min(cz + r, st->nz - 1));
+    const float g = block_guarantee(st, q.x, q.y, q.z, X0, X1, Y0, Y1, Z0, Z1);
     if (g == INFINITY) break;                   // the block covers the grid
     if (g > 0.f && worst <= g * g) break;
+    if (r > rmax) break;
+    rp = r;
   }
   // covariance of the k neighbours from the RAW coordinates; the products pt.x * pt.y are float products (:95-103)
   const float4* raw = b.tgt_p + (size_t)pair * b.nt_cap;

@@ -329,7 +329,7 @@ smhip_status gicp_align_slot0(smhip_context* h, const float* guess, float* final
   int ns_max = 0, nt_max = 0;
   // the k-NN search wants cells of a few point spacings: one shell then holds the 20 neighbours almost everywhere
   const float cell_was = h->dev.grid_cell;
-  h->dev.grid_cell = o.gicp_search_cell > 0 ? o.gicp_search_cell : 4.0f * (o.using_voxel_filter ? o.voxel_resolution : 0.2f);
+  h->dev.grid_cell = o.gicp_search_cell > 0 ? o.gicp_search_cell : 3.0f * (o.using_voxel_filter ? o.voxel_resolution : 0.2f);
   smhip_status s = gicp_prepare_slots(h, 2, I16, &ns_max, &nt_max);
   h->dev.grid_cell = cell_was;
   if (s) return s;

@@ -1,0 +1,103 @@
+"""Property tests (hypothesis) of the bit-exact device paths against their oracles on random inputs: filter chains,
+the ApproximateVoxelGrid restatement, and the exact-NN variants.  Few examples each: every example is a GPU round trip."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st, HealthCheck
+
+import staticmapping_amd as sm
+from staticmapping_amd import filters as df
+from oracle import filters as of, ndt_gicp as ong
+
+pytestmark = pytest.mark.gpu
+_SETTINGS = dict(max_examples=20, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+
+
+@pytest.fixture(scope="module")
+def handle():
+    m = sm.NdtGicpHip(max_source_points=32768, max_target_points=32768)
+    yield m
+    m.close()
+
+
+def _cloud(rng, n, scale, specials):
+    c = np.zeros((n, 5), np.float32)
+    c[:, :3] = rng.normal(0.0, scale, (n, 3))
+    c[:, 3] = rng.uniform(0, 255, n)
+    c[:, 4] = rng.uniform(0, 1, n)
+    if specials and n >= 8:
+        k = rng.integers(0, n, 4)
+        c[k[0], 0] = np.nan; c[k[1], 1] = np.inf; c[k[2], 2] = -np.inf; c[k[3], :3] = 0.0
+    return c
+
+
+_filter = st.one_of(
+    st.tuples(st.just("Range"), st.floats(0, 30), st.floats(31, 200)).map(lambda t: ("Range", dict(min_range=t[1], max_range=t[2]))),
+    st.tuples(st.integers(0, 2), st.floats(-50, 0), st.floats(1, 60)).map(lambda t: ("AxisRange", dict(axis_index=t[0], min=t[1], max=t[2]))),
+    st.tuples(st.floats(-40, 0), st.floats(1, 40)).map(lambda t: ("BoundingBoxRemoval", dict(min_x=t[0], max_x=t[1], min_y=t[0] / 2, max_y=t[1] / 2, min_z=-5.0, max_z=5.0))),
+    st.tuples(st.floats(0.05, 0.95), st.integers(0, 2**31 - 1)).map(lambda t: ("RandomSampler", dict(sampling_rate=t[0], seed=t[1]))),
+)
+
+
+def _oracle_filter(name, kw):
+    t = df.NAMES[name]
+    f = of.default(t)
+    f.update(kw)
+    return f
+
+
+@settings(**_SETTINGS)
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(0, 20000), scale=st.sampled_from([0.3, 5.0, 40.0]), specials=st.booleans(),
+       chain=st.lists(_filter, min_size=0, max_size=4), voxel=st.one_of(st.none(), st.sampled_from([0.1, 0.37, 2.5])))
+def test_filter_chains_are_bit_exact(handle, seed, n, scale, specials, chain, voxel):
+    rng = np.random.default_rng(seed)
+    raw = _cloud(rng, n, scale, specials and voxel is None)          # lround of a non-finite value is undefined in the reference
+    dchain = [df.make_filter(name, **kw) for name, kw in chain]
+    ochain = [_oracle_filter(name, kw) for name, kw in chain]
+    if voxel is not None:
+        dchain.append(df.make_filter("VoxelGrid", voxel_size=voxel)); ochain.append(dict(of.default(of.VOXEL_GRID), voxel_size=voxel))
+    got, gsrc = df.run_chain(handle, raw, dchain)
+    want, wsrc = of.run_chain(raw, ochain)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want, equal_nan=True)
+    assert np.array_equal(gsrc, wsrc)
+
+
+@settings(**_SETTINGS)
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(30, 20000), scale=st.sampled_from([0.15, 1.0, 25.0]), leaf=st.sampled_from([0.2, 0.5]))
+def test_approximate_voxel_grid_is_bit_exact(handle, seed, n, scale, leaf):
+    """pcl::ApproximateVoxelGrid restated in parallel: same centroids, same order, for clouds that revisit voxels
+    (small scale: few voxels, many evictions) and for sparse ones."""
+    rng = np.random.default_rng(seed)
+    pts = rng.normal(0.0, scale, (n, 3)).astype(np.float32)
+    handle.set_gicp_options(voxel_resolution=leaf, use_ndt=0, gicp_max_iterations=1)
+    handle.set_input_source(pts); handle.set_input_target(pts)
+    try:
+        handle.align()
+    except sm.SmhipError:
+        pass                                       # fewer than k points after the filter: GICP refuses, the filter ran
+    want = ong.approximate_voxel_grid(pts, leaf)
+    assert np.array_equal(handle.get_downsampled(1), want)
+    assert np.array_equal(handle.get_downsampled(0), want)
+    handle.set_gicp_options(voxel_resolution=0.2, use_ndt=1, gicp_max_iterations=35)
+
+
+@settings(max_examples=8, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 2**31 - 1), ns=st.integers(1, 6000), nt=st.integers(1, 6000), spread=st.sampled_from([0.5, 8.0, 60.0]),
+       offset=st.sampled_from([0.0, 0.3, 25.0]))
+def test_every_nn_variant_agrees_with_brute_force(seed, ns, nt, spread, offset):
+    """Exact 1-NN with the smallest-position tie rule: ball / LDS-table / ring / cooperative ring / fallback / brute force
+    return the same ids and bit-identical distances for random clouds, including sources far outside the target's box."""
+    rng = np.random.default_rng(seed)
+    tgt = rng.normal(0.0, spread, (nt, 3))
+    src = rng.normal(0.0, spread, (ns, 3)) + offset
+    nrm = np.tile([0.0, 0.0, 1.0], (nt, 1))
+    ref = None
+    for opts in (dict(nn_mode=0), dict(), dict(no_lds_table=1), dict(use_ball=0), dict(grid_cell=1.0), dict(grid_max_ring=1)):
+        m = sm.IcpFastHip(max_source_points=ns, max_target_points=nt, **opts)
+        m.set_input_source(src); m.set_input_target(tgt, nrm)
+        ids, d2 = m.find_closests(np.eye(4), ns)
+        m.close()
+        if ref is None:
+            ref = (ids, d2)
+        assert np.array_equal(ids, ref[0]), opts
+        assert np.array_equal(d2.view(np.uint32), ref[1].view(np.uint32)), opts

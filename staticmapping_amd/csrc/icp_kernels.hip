@@ -1370,18 +1370,23 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
 #pragma unroll 2
   for (int it = 0; it < kAccItems; ++it) {
     const int i = base + it * kAccThreads + threadIdx.x;
+    bool boundary = false;
     if (i < ns) {
       const float d = b.d2[so + i];
       const uint32_t key = __float_as_uint(d);
       if (key < 0x7f800000u) {
         const uint32_t bin = key >> kHistShift;
-        if (bin < qbin) {
-          accumulate_pair(b, st, pair, i, d, acc);
-        } else if (bin == qbin) {
-          const uint32_t pos = atomicAdd(&st->blist_count, 1u);
-          b.blist[so + pos] = i;
-        }
+        if (bin < qbin) accumulate_pair(b, st, pair, i, d, acc);
+        else boundary = bin == qbin;
       }
+    }
+    // the quantile bin's members are left for finalize, compacted per wave (= per group of 64 consecutive queries) in
+    // query order: no atomics, and an order that does not change from run to run
+    const unsigned long long bm = __ballot(boundary);
+    const int g0 = base + it * kAccThreads + (int)(threadIdx.x & ~63u);        // first query of this wave's group
+    if (g0 < ns) {
+      if (boundary) b.blist[so + g0 + __popcll(bm & ((1ull << (threadIdx.x & 63)) - 1ull))] = i;
+      if ((threadIdx.x & 63) == 0) b.gcount[(size_t)pair * ((b.ns_cap + 63) / 64) + (g0 >> 6)] = (uint32_t)__popcll(bm);
     }
   }
   block_reduce29(acc, s_red);
@@ -1499,12 +1504,33 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   find_quantile_bin(gh, b.rho, s_w, s_q);
   const uint32_t qbin = s_q[0], below = s_q[1], n_valid = s_q[2], krank = s_q[3];
   const size_t so = (size_t)pair * b.ns_cap;
-  const int nb = (int)st->blist_count;
   const int ns = st->ns;
+  const int ngroups = (ns + 63) >> 6;                      // groups of 64 queries; thread t owns groups t, t + 256, ...
+  const uint32_t* gcount = b.gcount + (size_t)pair * ((b.ns_cap + 63) / 64);
   double acc[29];
 #pragma unroll
   for (int c = 0; c < 29; ++c) acc[c] = 0.0;
   uint32_t limit_key = 0;
+  // The quantile bin's members, left by `accumulate` per group of 64 queries, are first gathered into one flat list in
+  // LDS (thread t's groups in order, then thread t + 1's: an order fixed by the data alone, so every sum below runs in
+  // the same order in every run).  Lists beyond the LDS capacity (very large clouds) are walked group by group instead.
+  __shared__ int s_idx[kFinalizeKeyCap];
+  int nb = 0;
+  bool flat = false;
+  if (n_valid > 0) {
+    uint32_t mine = 0;
+    for (int g = threadIdx.x; g < ngroups; g += blockDim.x) mine += gcount[g];
+    uint32_t total;
+    uint32_t o = block_excl_scan(mine, s_w, &total);
+    nb = (int)total;
+    flat = nb <= kFinalizeKeyCap;
+    if (flat)
+      for (int g = threadIdx.x; g < ngroups; g += blockDim.x) {
+        const int c = (int)gcount[g];
+        for (int m = 0; m < c; ++m) s_idx[o++] = b.blist[so + 64 * g + m];
+      }
+    __syncthreads();
+  }
   if (n_valid > 0) {
     // exact rank (krank - below) inside the boundary bin: radix select on the low 20 key bits
     uint32_t rank = krank - below;
@@ -1516,16 +1542,31 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
       const uint32_t nd = 1u << widths[pass];
       s_h[threadIdx.x] = 0;
       __syncthreads();
-      for (int e = threadIdx.x; e < nb; e += blockDim.x) {
-        // the boundary bin's keys are read from global memory once and kept in LDS for the other two passes
-        uint32_t key;
-        if (pass == 0 || e >= kFinalizeKeyCap) {
-          key = __float_as_uint(b.d2[so + b.blist[so + e]]) & 0xfffffu;
-          if (e < kFinalizeKeyCap) s_keys[e] = key;
-        } else {
-          key = s_keys[e];
+      if (flat) {
+        for (int e = threadIdx.x; e < nb; e += blockDim.x) {
+          // the keys are read from global memory once and kept in LDS for the other two passes
+          uint32_t key;
+          if (pass == 0) { key = __float_as_uint(b.d2[so + s_idx[e]]) & 0xfffffu; s_keys[e] = key; }
+          else key = s_keys[e];
+          if ((key & mask) == prefix) atomicAdd(&s_h[(key >> shift) & (nd - 1u)], 1u);
         }
-        if ((key & mask) == prefix) atomicAdd(&s_h[(key >> shift) & (nd - 1u)], 1u);
+      }
+      // (not flat) every thread walks its groups in the same order in every pass, so its k-th member is the same query
+      // each time: the first keys are kept in LDS (slot k * 256 + t)
+      int kth = 0;
+      for (int g = threadIdx.x; !flat && g < ngroups; g += blockDim.x) {
+        const int c = (int)gcount[g];
+        for (int m = 0; m < c; ++m, ++kth) {
+          const int slot = kth * 256 + (int)threadIdx.x;
+          uint32_t key;
+          if (pass == 0 || slot >= kFinalizeKeyCap) {
+            key = __float_as_uint(b.d2[so + b.blist[so + 64 * g + m]]) & 0xfffffu;
+            if (slot < kFinalizeKeyCap) s_keys[slot] = key;
+          } else {
+            key = s_keys[slot];
+          }
+          if ((key & mask) == prefix) atomicAdd(&s_h[(key >> shift) & (nd - 1u)], 1u);
+        }
       }
       __syncthreads();
       {   // the digit whose cumulative count crosses `rank`, found by all 256 threads at once
@@ -1544,10 +1585,21 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
     }
     limit_key = (qbin << kHistShift) | prefix;
     // weights = (d2 <= limit)  (icp_fast.cc:497-498) for the boundary-bin entries
-    for (int e = threadIdx.x; e < nb; e += blockDim.x) {
-      const int i = b.blist[so + e];
-      const float d = b.d2[so + i];
-      if (__float_as_uint(d) <= limit_key) accumulate_pair(b, st, pair, i, d, acc);
+    if (flat) {
+      for (int e = threadIdx.x; e < nb; e += blockDim.x) {
+        const int i = s_idx[e];
+        const float d = b.d2[so + i];
+        if (__float_as_uint(d) <= limit_key) accumulate_pair(b, st, pair, i, d, acc);
+      }
+    } else {
+      for (int g = threadIdx.x; g < ngroups; g += blockDim.x) {
+        const int c = (int)gcount[g];
+        for (int m = 0; m < c; ++m) {
+          const int i = b.blist[so + 64 * g + m];
+          const float d = b.d2[so + i];
+          if (__float_as_uint(d) <= limit_key) accumulate_pair(b, st, pair, i, d, acc);
+        }
+      }
     }
   }
   block_reduce29(acc, s_red);

@@ -393,6 +393,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, &d.ulist, B * NS));
   A(dev_alloc(h, &d.ukeys, B * NS));
   A(dev_alloc(h, &d.blist, B * NS));
+  A(dev_alloc(h, &d.gcount, B * ((NS + 63) / 64)));
   A(dev_alloc(h, &d.partials, B * d.acc_blocks * kAccCols));
   A(dev_alloc(h, &d.tpart, B * kTgtReduceBlocks * 16));
   A(dev_alloc(h, &d.done_count, 4));

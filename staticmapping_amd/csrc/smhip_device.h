@@ -108,7 +108,9 @@ struct IcpDev {
   int32_t* hlist;            // [slots][ns_cap] queries the tile phase could not certify (ring search)
   int32_t* ulist;            // [slots][ns_cap] unresolved queries (brute-force fallback)
   unsigned long long* ukeys; // [slots][ns_cap] fallback winners: (d2 bits << 32) | original target index
-  int32_t* blist;            // [slots][ns_cap] queries whose d2 falls in the quantile's histogram bin
+  int32_t* blist;            // [slots][ns_cap] queries whose d2 falls in the quantile's histogram bin: the members of the g-th
+                             //                 group of 64 consecutive queries sit at blist[64 g ...], in query order
+  uint32_t* gcount;          // [slots][ceil(ns_cap / 64)] how many members each group has
   double* partials;          // [slots][acc_blocks][kAccCols]
   double* tpart;             // [slots][kTgtReduceBlocks][16]
   uint32_t* done_count;      // number of finished pairs

@@ -307,3 +307,19 @@ def test_concurrent_matcher_instances(smhip, velo20k, cfg1):
     for k in range(len(cases)):
         da, dt = smhip.se3_error(out[k], ref[k])
         assert da < 1e-6 and dt < 1e-5
+
+
+def test_align_is_reproducible_bit_for_bit(smhip, cfg2):
+    """Every reduction runs in an order fixed by the data (per-block partials folded in block order, the quantile bin's
+    members gathered per 64-query group): the same inputs give the same 16 doubles in every run and in every slot."""
+    c = cfg2
+    m = smhip.IcpFastHip(pair_slots=3, max_source_points=len(c["src"]), max_target_points=len(c["q"]), max_iteration=20, early_exit=0)
+    for s in range(3):
+        m.set_input_source(c["src"], slot=s); m.set_input_target(c["q"], c["n"], slot=s)
+    runs = []
+    for _ in range(3):
+        R, sc, st = m.align_batch(3, [c["guess"]] * 3)
+        runs.append((R.tobytes(), sc.tobytes()))
+        assert R[0].tobytes() == R[1].tobytes() == R[2].tobytes()
+    assert runs[0] == runs[1] == runs[2]
+    m.close()

@@ -9,7 +9,9 @@ from staticmapping_amd import filters as df
 from oracle import filters as of, ndt_gicp as ong
 
 pytestmark = pytest.mark.gpu
-_SETTINGS = dict(max_examples=20, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+import os
+_N = int(os.environ.get("SMHIP_HYP_EXAMPLES", "20"))
+_SETTINGS = dict(max_examples=_N, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 
 
 @pytest.fixture(scope="module")
@@ -81,7 +83,7 @@ def test_approximate_voxel_grid_is_bit_exact(handle, seed, n, scale, leaf):
     handle.set_gicp_options(voxel_resolution=0.2, use_ndt=1, gicp_max_iterations=35)
 
 
-@settings(max_examples=8, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@settings(max_examples=max(8, _N // 3), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(seed=st.integers(0, 2**31 - 1), ns=st.integers(1, 6000), nt=st.integers(1, 6000), spread=st.sampled_from([0.5, 8.0, 60.0]),
        offset=st.sampled_from([0.0, 0.3, 25.0]))
 def test_every_nn_variant_agrees_with_brute_force(seed, ns, nt, spread, offset):
@@ -101,3 +103,28 @@ def test_every_nn_variant_agrees_with_brute_force(seed, ns, nt, spread, offset):
             ref = (ids, d2)
         assert np.array_equal(ids, ref[0]), opts
         assert np.array_equal(d2.view(np.uint32), ref[1].view(np.uint32)), opts
+
+
+@settings(max_examples=max(6, _N // 4), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(800, 6000), yaw=st.floats(-3.0, 3.0), tx=st.floats(-0.3, 0.3), rho=st.sampled_from([0.5, 0.7, 0.9]))
+def test_align_is_identical_across_search_variants(seed, n, yaw, tx, rho):
+    """Whatever way the matches are found (fused ball search, certificates off, global-memory variant, the two-launch
+    converged path from iteration 1, plain ring search, brute force), a whole Align returns the same bits: the matches that
+    survive the trimming are the same with the same distances, and every sum runs in a fixed order."""
+    from staticmapping_amd import synth
+    tgt, src, T = synth.three_planes_pair(n, seed=seed % 1000, sigma=0.01)
+    q, nr = sm.calculate_normals(tgt[:, :3].astype(np.float64))
+    guess = synth.make_pose(t=(tx, 0.05, 0.0), rpy_deg=(0, 0, yaw))
+    ref = None
+    for opts in (dict(), dict(no_certify=1), dict(no_lds_table=1), dict(split_after=1), dict(split_after=3, no_lds_table=1),
+                 dict(use_ball=0), dict(nn_mode=0), dict(ball_radius=0.05)):
+        m = sm.IcpFastHip(max_source_points=len(src), max_target_points=len(q), max_iteration=25, early_exit=1,
+                          dist_outlier_ratio=rho, **opts)
+        m.set_input_source(src); m.set_input_target(q, nr)
+        ok, R = m.align(guess)
+        st_ = m.last_stats[0]
+        m.close()
+        key = (R.tobytes(), st_["iterations"], st_["kept"], st_["limit_d2"])
+        if ref is None:
+            ref = key
+        assert key == ref, (opts, st_)

@@ -103,8 +103,16 @@ struct FrameResult {
 // MapBuilder::ScanMatchProcessing, one cloud per call
 class ScanMatcherFrontEnd {
  public:
-  ScanMatcherFrontEnd(std::shared_ptr<registrator::Interface> scan_matcher, const MotionFilter& filter, bool use_extrapolator = true)
-      : scan_matcher_(std::move(scan_matcher)), filter_(filter), use_extrapolator_(use_extrapolator) {}
+  // device_target_prep (IcpFastHip only): the key frame stays resident on the GPU.  Its normals are computed there
+  // (SetInputTargetRaw / PromoteSourceToTarget) instead of the host CalculateNormals of map_builder.cc:286,389, the
+  // target is not re-sent with every scan (the reference calls SetInputTarget per scan, :317), and a scan that becomes a
+  // key frame is handed over from the source slot without a second upload.  false = the reference's call sequence.
+  ScanMatcherFrontEnd(std::shared_ptr<registrator::Interface> scan_matcher, const MotionFilter& filter, bool use_extrapolator = true,
+                      bool device_target_prep = false)
+      : scan_matcher_(std::move(scan_matcher)), filter_(filter), use_extrapolator_(use_extrapolator) {
+    if (device_target_prep) device_icp_ = dynamic_cast<registrator::IcpFastHip*>(scan_matcher_.get());
+  }
+  bool DeviceTargetPrep() const { return device_icp_ != nullptr; }
 
   PoseExtrapolatorCTRV& Extrapolator() { return extrapolator_; }
 
@@ -113,13 +121,15 @@ class ScanMatcherFrontEnd {
     if (!got_first_point_cloud_) {                                          // :280-293
       got_first_point_cloud_ = true;
       target_cloud_ = source_cloud;
-      if (scan_matcher_->GetType() == registrator::kFastIcp) target_cloud_->CalculateNormals();
+      if (device_icp_) device_icp_->SetInputTargetRaw(target_cloud_);
+      else if (scan_matcher_->GetType() == registrator::kFastIcp) target_cloud_->CalculateNormals();
       if (use_extrapolator_) extrapolator_.AddPose(source_time, Matrix4d::Identity());
       out.new_key_frame = true;
       return out;
     }
     if (use_extrapolator_ && source_time < extrapolator_.GetLastPoseTime()) {  // :296-300
       target_cloud_ = source_cloud;
+      if (device_icp_) device_icp_->SetInputTargetRaw(target_cloud_);
       return out;
     }
     Matrix4d pose_source = pose_target_;
@@ -127,7 +137,7 @@ class ScanMatcherFrontEnd {
     Matrix4d guess = Multiply(RigidInverse(pose_target_), pose_source);        // :307
     NormalizeRotation(guess);                                                  // :308
     Matrix4d align_result = Matrix4d::Identity();
-    scan_matcher_->SetInputTarget(target_cloud_);                              // :317
+    if (!device_icp_) scan_matcher_->SetInputTarget(target_cloud_);            // :317 (resident otherwise)
     scan_matcher_->SetInputSource(source_cloud);                               // :329
     scan_matcher_->Align(guess, align_result);                                 // :333
     pose_source = Multiply(pose_target_, align_result);                        // :354
@@ -143,7 +153,8 @@ class ScanMatcherFrontEnd {
     if (accu_translation >= filter_.translation_range || (filter_.angle_range > 1e-3 && accu_angles >= filter_.angle_range)) {   // :379-383
       accumulative_transform_ = Matrix4d::Identity();
       target_cloud_ = source_cloud;
-      if (scan_matcher_->GetType() == registrator::kFastIcp) target_cloud_->CalculateNormals();   // :389
+      if (device_icp_) device_icp_->PromoteSourceToTarget();
+      else if (scan_matcher_->GetType() == registrator::kFastIcp) target_cloud_->CalculateNormals();   // :389
       pose_target_ = pose_source;
       out.new_key_frame = true;
     }
@@ -154,6 +165,7 @@ class ScanMatcherFrontEnd {
   std::shared_ptr<registrator::Interface> scan_matcher_;
   MotionFilter filter_;
   bool use_extrapolator_;
+  registrator::IcpFastHip* device_icp_ = nullptr;
   PoseExtrapolatorCTRV extrapolator_;
   bool got_first_point_cloud_ = false;
   InnerCloudPtr target_cloud_;

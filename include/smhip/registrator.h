@@ -257,6 +257,31 @@ class IcpFastHip : public Interface {
   }
   const smhip_icp_stats& LastStats() const { return stats_; }
 
+  // Device-resident target preparation (the backend's own additions; the reference has the caller run
+  // EigenPointCloud::CalculateNormals on the host, map_builder.cc:286,389, before SetInputTarget).
+  // The raw cloud is uploaded and its normals are computed on the GPU (csrc/prep_normals.hip); returns the number of
+  // target points that kept a normal.  The host cloud is left untouched (it gets no normals).
+  int SetInputTargetRaw(InnerCloudPtr cloud) {
+    SMHIP_CHECK(cloud != nullptr, "CHECK(cloud)");
+    SMHIP_CHECK(cloud->GetEigenCloud() != nullptr, "CHECK(cloud->GetEigenCloud())");
+    EnsureHandle();
+    const auto& e = *cloud->GetEigenCloud();
+    std::vector<float> rows(static_cast<size_t>(e.size()) * 3);
+    const double* p = e.points.data();
+    for (size_t i = 0; i < rows.size(); ++i) rows[i] = static_cast<float>(p[i]);   // 3xN column-major == N rows of xyz
+    int n_out = 0;
+    Check(smhip_prepare_target_f32(handle_, 0, rows.data(), 3, e.size(), &n_out), "smhip_prepare_target_f32");
+    return n_out;
+  }
+  // The source already resident from the last SetInputSource becomes the target (the key-frame hand-over of
+  // map_builder.cc:379-392) without a second upload.
+  int PromoteSourceToTarget() {
+    EnsureHandle();
+    int n_out = 0;
+    Check(smhip_prepare_target_from_source(handle_, 0, 0, &n_out), "smhip_prepare_target_from_source");
+    return n_out;
+  }
+
  private:
   void Check(smhip_status s, const char* what) {
     if (s != SMHIP_OK) {

@@ -50,3 +50,14 @@ def test_front_end_drive(tmp_path):
         da, dt = sm.se3_error(P, np.linalg.inv(poses[0]) @ poses[k])
         assert frames[k]["matched"] and frames[k]["score"] > 0.8
         assert da < 4e-3 and dt < 0.06, (k, da, dt)
+    # the GPU-resident key frame (device normals, no per-scan target upload) follows the same drive: the device and the host
+    # CalculateNormals keep the same points and agree on the normals to float rounding (tests/test_prepare_target_gpu.py)
+    out2 = subprocess.check_output([_build_exe(), str(n), str(tmp_path), "3.0", "0.1", "1"], text=True, timeout=600)
+    frames2 = json.loads(out2.strip().splitlines()[-1])["frames"]
+    assert [k for k, f in enumerate(frames2) if f["key"]] == keys
+    for k in range(1, n):
+        da, dt = sm.se3_error(np.array(frames2[k]["pose"]).reshape(4, 4), np.array(frames[k]["pose"]).reshape(4, 4))
+        assert da < 5e-4 and dt < 5e-3, (k, da, dt)
+    host_ms = np.median([f["ms"] for f in frames[2:]])
+    dev_ms = np.median([f["ms"] for f in frames2[2:]])
+    print("front end, median ms per scan (30 k points): host target prep %.2f, device-resident %.2f" % (host_ms, dev_ms))

@@ -1305,13 +1305,9 @@ __global__ __launch_bounds__(256) void nn_validate(IcpDev b) {
 }
 
 // J = [p x n ; n], r = (p - q) . n ; acc += upper(J J^T), J r, sqrt(d2), 1     (icp_fast.cc:182-202, 256-303)
-__device__ __forceinline__ void accumulate_pair(const IcpDev& b, const PairState* st, int pair, int i, float d2v, double* acc) {
-  const size_t so = (size_t)pair * b.ns_cap, to = (size_t)pair * b.nt_cap;
+__device__ __forceinline__ void accumulate_terms(const double* M, const float4 s4, const float4 q4, const float4 n4, float d2v, double* acc) {
   double px, py, pz;
-  transform_point(st->M, b.src[so + i], px, py, pz);
-  const int j = b.idx[so + i];
-  const float4 q4 = b.tq[to + j];
-  const float4 n4 = b.tn[to + j];
+  transform_point(M, s4, px, py, pz);
   const double nx = n4.x, ny = n4.y, nz = n4.z;
   double J[6];
   J[0] = py * nz - pz * ny;
@@ -1328,6 +1324,11 @@ __device__ __forceinline__ void accumulate_pair(const IcpDev& b, const PairState
   for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;     // b = -sum(J r): sign applied at solve time
   acc[27] += sqrt((double)d2v);
   acc[28] += 1.0;
+}
+__device__ __forceinline__ void accumulate_pair(const IcpDev& b, const PairState* st, int pair, int i, float d2v, double* acc) {
+  const size_t so = (size_t)pair * b.ns_cap, to = (size_t)pair * b.nt_cap;
+  const int j = b.idx[so + i];
+  accumulate_terms(st->M, b.src[so + i], b.tq[to + j], b.tn[to + j], d2v, acc);
 }
 
 // Block reduction of kAccCols-3 = 29 doubles; thread 0 ends up with the totals in acc[].
@@ -1350,13 +1351,14 @@ __device__ __forceinline__ void block_reduce29(double* acc, double (*s_red)[29])
   }
 }
 
+template <int ITEMS>
 __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
   int pair, blk;
   if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
   PairState* st = &b.state[pair];
   if (st->done) return;
   const int ns = st->ns;
-  const int base = blk * kAccChunk;
+  const int base = blk * (kAccThreads * ITEMS);
   if (base >= ns) return;
   __shared__ uint32_t s_w[17];
   __shared__ uint32_t s_q[4];
@@ -1367,16 +1369,31 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
 #pragma unroll
   for (int c = 0; c < 29; ++c) acc[c] = 0.0;
   const size_t so = (size_t)pair * b.ns_cap;
+  // the three streamed values of a query (d2, source point, match) are loaded one round ahead of their use, without
+  // looking at d2 first, so that their latency is not in series with the gathers of the matched target point and normal
+  const size_t to = (size_t)pair * b.nt_cap;
+  int ic = min(base + (int)threadIdx.x, ns - 1);
+  float d_n = b.d2[so + ic];
+  float4 s_n = b.src[so + ic];
+  int j_n = b.idx[so + ic];
 #pragma unroll 2
-  for (int it = 0; it < kAccItems; ++it) {
+  for (int it = 0; it < ITEMS; ++it) {
     const int i = base + it * kAccThreads + threadIdx.x;
+    const float d = d_n;
+    const float4 s4 = s_n;
+    const int j = j_n;
+    if (it + 1 < ITEMS) {
+      ic = min(i + kAccThreads, ns - 1);
+      d_n = b.d2[so + ic];
+      s_n = b.src[so + ic];
+      j_n = b.idx[so + ic];
+    }
     bool boundary = false;
     if (i < ns) {
-      const float d = b.d2[so + i];
       const uint32_t key = __float_as_uint(d);
       if (key < 0x7f800000u) {
         const uint32_t bin = key >> kHistShift;
-        if (bin < qbin) accumulate_pair(b, st, pair, i, d, acc);
+        if (bin < qbin) accumulate_terms(st->M, s4, b.tq[to + j], b.tn[to + j], d, acc);
         else boundary = bin == qbin;
       }
     }
@@ -1608,7 +1625,8 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   __syncthreads();
   // add the per-block partial sums of the accumulate kernel: 8 thread groups take every 8th block,
   // then one thread per column folds the 8 group sums -- a fixed order, so the result is reproducible
-  const int nblk = (ns + kAccChunk - 1) / kAccChunk;
+  const int chunk = kAccThreads * b.acc_items;
+  const int nblk = (ns + chunk - 1) / chunk;
   {
     const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
     double s = 0;

@@ -366,7 +366,8 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   smhip_icp_default_options(&h->opts);
   IcpDev& d = h->dev;
   d.slots = pair_slots; d.ns_cap = max_source_points; d.nt_cap = max_target_points;
-  d.acc_blocks = ceil_div(max_source_points, kAccChunk);
+  d.acc_blocks = ceil_div(max_source_points, kAccThreads * kAccItemsSmall);
+  d.acc_items = kAccItemsSmall;
   const size_t B = pair_slots, NS = max_source_points, NT = max_target_points;
   smhip_status s = SMHIP_OK;
   auto A = [&](smhip_status r) { if (s == SMHIP_OK) s = r; };
@@ -736,6 +737,8 @@ smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* g
   if (s) return s;
   for (int k = 0; k < nh; ++k) {   // launches of fewer than ~2 workgroups per CU take the small-launch kernel variants
     halves[k].small = halves[k].np * ceil_div(ns_max, kNnThreads * kBallItems) < 512;
+    // long accumulate chunks once they still leave >= 3 workgroups per CU
+    halves[k].d.acc_items = halves[k].np * ceil_div(ns_max, kAccThreads * kAccItemsBatch) >= 768 ? kAccItemsBatch : kAccItemsSmall;
   }
   for (int k = 0; k < nh; ++k) { s = enqueue_grid_build(h, halves[k], nt_max); if (s) return s; }
   const int max_it = h->dev.max_iteration;
@@ -746,8 +749,9 @@ smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* g
       if (s) return s;
       {
         Bracket br(h, 2, f.stream);
-        const int nblk = ceil_div(ns_max, kAccChunk);
-        hipLaunchKernelGGL(accumulate, dim3(nblk * 8 * ceil_div(f.np, 8)), dim3(kAccThreads), 0, f.stream, f.d, nblk);
+        const int nblk = ceil_div(ns_max, kAccThreads * f.d.acc_items);
+        if (f.d.acc_items == kAccItemsBatch) hipLaunchKernelGGL(accumulate<kAccItemsBatch>, dim3(nblk * 8 * ceil_div(f.np, 8)), dim3(kAccThreads), 0, f.stream, f.d, nblk);
+        else hipLaunchKernelGGL(accumulate<kAccItemsSmall>, dim3(nblk * 8 * ceil_div(f.np, 8)), dim3(kAccThreads), 0, f.stream, f.d, nblk);
       }
       { Bracket br(h, 3, f.stream); hipLaunchKernelGGL(finalize, dim3(f.np), dim3(256), 0, f.stream, f.d); }
     }

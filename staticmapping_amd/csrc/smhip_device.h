@@ -11,8 +11,11 @@ constexpr int kHistBins = 2048;          // level-1 histogram of d2 keys: float 
 constexpr int kHistShift = 20;
 constexpr int kNnThreads = 256;          // one query per thread, 4 waves per workgroup
 constexpr int kAccThreads = 256;
-constexpr int kAccItems = 8;             // source points per thread in the accumulate kernel
-constexpr int kAccChunk = kAccThreads * kAccItems;
+// source points per thread in the accumulate kernel.  Every workgroup ends with a 29-column f64 reduction that costs about
+// as many vector instructions as 8 points, so batches use long chunks (32 points per thread: 105 -> 62 us per 64 pairs);
+// a single pair keeps short ones, or it would have 15 workgroups for 256 CUs.
+constexpr int kAccItemsSmall = 8;
+constexpr int kAccItemsBatch = 32;
 constexpr int kFinalizeKeyCap = 4096;     // boundary-bin keys finalize keeps in LDS between its radix-select passes
 constexpr int kAccCols = 32;             // 21 (A upper) + 6 (b) + 1 (sum sqrt d2) + 1 (count) padded to 32
 constexpr int kMaxGridWords = 1 << 18;   // 32-cell words per pair (8 Mi cells)
@@ -84,7 +87,8 @@ struct IcpDev {
   int32_t slots, ns_cap, nt_cap;
   int32_t npairs;            // pairs this launch covers (XCD-aware kernels pad the grid to a multiple of 8)
   int32_t pair_base;         // first pair slot of this launch (the batch is split over two streams)
-  int32_t acc_blocks;        // ceil(ns_cap / kAccChunk)
+  int32_t acc_blocks;        // ceil(ns_cap / (kAccThreads * kAccItemsSmall))
+  int32_t acc_items;         // points per thread of the accumulate launches of this batch part (finalize folds accordingly)
   PairState* state;
   const PairInput* in;
   const float4* src;         // [slots][ns_cap] raw source xyz (w unused)

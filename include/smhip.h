@@ -123,7 +123,7 @@ int smhip_device_count(void);
 
 /* ---- handle ------------------------------------------------------------ */
 /* stream: a hipStream_t to borrow (e.g. torch's current stream) or NULL to own one.
- * pair_slots >= 1; max_source_points / max_target_points size the device arena once
+ * pair_slots >= 1; max_source_points / max_target_points size the device arena once (max_source_points <= 4194304).
  * (no hipMalloc happens inside Align). */
 smhip_status smhip_create(int device, void* stream, int pair_slots, int max_source_points,
                           int max_target_points, smhip_handle* out);

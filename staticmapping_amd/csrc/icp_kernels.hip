@@ -1332,23 +1332,37 @@ __device__ __forceinline__ void accumulate_pair(const IcpDev& b, const PairState
 }
 
 // Block reduction of kAccCols-3 = 29 doubles; thread 0 ends up with the totals in acc[].
-__device__ __forceinline__ void block_reduce29(double* acc, double (*s_red)[29]) {
+// v of the lanes a DPP control reads from, 0.0 where the control has no source lane or the row is masked off
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_or_zero(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// Sum over the wave, left in lane 63: an inclusive scan inside every row of 16 lanes (row_shr 1, 2, 4, 8), then the row
+// totals carried across (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3).  Register-to-register DPP moves:
+// the ds_bpermute form of __shfl_down took 3.5 us for the 29 columns.
+__device__ __forceinline__ double wave_sum_to_last(double v) {
+  v += dpp_or_zero<0x111, 0xf>(v);
+  v += dpp_or_zero<0x112, 0xf>(v);
+  v += dpp_or_zero<0x114, 0xf>(v);
+  v += dpp_or_zero<0x118, 0xf>(v);
+  v += dpp_or_zero<0x142, 0xa>(v);
+  v += dpp_or_zero<0x143, 0xc>(v);
+  return v;
+}
+
+// Block reduction of kAccCols-3 = 29 doubles over 4 waves: s_out[c] = the totals (valid after the call for every thread).
+__device__ __forceinline__ void block_reduce29(double* acc, double (*s_red)[29], double* s_out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int c = 0; c < 29; ++c) acc[c] = wave_sum(acc[c]);
-  if (lane == 0)
+  for (int c = 0; c < 29; ++c) acc[c] = wave_sum_to_last(acc[c]);
+  if (lane == 63)
 #pragma unroll
     for (int c = 0; c < 29; ++c) s_red[wave][c] = acc[c];
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const int nwave = blockDim.x >> 6;
-#pragma unroll
-    for (int c = 0; c < 29; ++c) {
-      double s = 0;
-      for (int w = 0; w < nwave; ++w) s += s_red[w][c];
-      acc[c] = s;
-    }
-  }
+  if (threadIdx.x < 29) s_out[threadIdx.x] = ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
+  __syncthreads();
 }
 
 template <int ITEMS>
@@ -1363,6 +1377,7 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
   __shared__ uint32_t s_w[17];
   __shared__ uint32_t s_q[4];
   __shared__ double s_red[4][29];
+  __shared__ double s_out[29];
   find_quantile_bin(b.hist + (size_t)pair * kHistBins, b.rho, s_w, s_q);
   const uint32_t qbin = s_q[0];
   double acc[29];
@@ -1372,6 +1387,9 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
   // the three streamed values of a query (d2, source point, match) are loaded one round ahead of their use, without
   // looking at d2 first, so that their latency is not in series with the gathers of the matched target point and normal
   const size_t to = (size_t)pair * b.nt_cap;
+  const int seg = blk * (kAccThreads / 64) + (int)(threadIdx.x >> 6);            // this wave's segment: 64 * ITEMS slots
+  const size_t segbase = (size_t)pair * b.bl_stride + (size_t)seg * (64 * ITEMS);
+  int wcount = 0;
   int ic = min(base + (int)threadIdx.x, ns - 1);
   float d_n = b.d2[so + ic];
   float4 s_n = b.src[so + ic];
@@ -1397,27 +1415,21 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
         else boundary = bin == qbin;
       }
     }
-    // the quantile bin's members are left for finalize, compacted per wave (= per group of 64 consecutive queries) in
-    // query order: no atomics, and an order that does not change from run to run
+    // the quantile bin's members are left for finalize, compacted per wave into the wave's own segment of blist, in the
+    // order the wave meets them: no atomics, and an order that does not change from run to run
     const unsigned long long bm = __ballot(boundary);
-    const int g0 = base + it * kAccThreads + (int)(threadIdx.x & ~63u);        // first query of this wave's group
-    if (g0 < ns) {
-      if (boundary) b.blist[so + g0 + __popcll(bm & ((1ull << (threadIdx.x & 63)) - 1ull))] = i;
-      if ((threadIdx.x & 63) == 0) b.gcount[(size_t)pair * ((b.ns_cap + 63) / 64) + (g0 >> 6)] = (uint32_t)__popcll(bm);
-    }
+    if (boundary) b.blist[segbase + wcount + __popcll(bm & ((1ull << (threadIdx.x & 63)) - 1ull))] = i;
+    wcount += (int)__popcll(bm);
   }
-  block_reduce29(acc, s_red);
-  if (threadIdx.x == 0) {
-    double* out = b.partials + ((size_t)pair * b.acc_blocks + blk) * kAccCols;
-#pragma unroll
-    for (int c = 0; c < 29; ++c) out[c] = acc[c];
-  }
+  if ((threadIdx.x & 63) == 0) b.gcount[(size_t)pair * b.seg_stride + seg] = (uint32_t)wcount;
+  block_reduce29(acc, s_red, s_out);
+  if (threadIdx.x < 29) b.partials[((size_t)pair * b.acc_blocks + blk) * kAccCols + threadIdx.x] = s_out[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------
 // K4: exact quantile, solve, update, convergence
 // ------------------------------------------------------------------------------------------
-__device__ void jacobi_eig6(double* A, double* V, double* w) {
+__device__ __noinline__ void jacobi_eig6(double* A, double* V, double* w) {
   for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) V[6 * i + j] = (i == j) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 60; ++sweep) {
     double off = 0;
@@ -1440,18 +1452,23 @@ __device__ void jacobi_eig6(double* A, double* V, double* w) {
 
 // SolvePossiblyUnderdeterminedLinearSystem (icp_fast.cc:204-254): Cholesky when A is numerically
 // invertible, otherwise the minimum-norm solution of the rank-reduced system (pseudo-inverse).
-__device__ void solve6(const double* A, const double* rhs, double* x) {
+__device__ __forceinline__ void solve6(const double* A, const double* rhs, double* x) {
+  // fully unrolled so that L lives in registers: with run-time indices it sits in scratch memory and every access is a
+  // memory round trip (the serial tail of finalize took 9-19 us that way)
   double L[36];
-  for (int i = 0; i < 36; ++i) L[i] = 0;
   double dmax = 0;
+#pragma unroll
   for (int i = 0; i < 6; ++i) dmax = fmax(dmax, fabs(A[6 * i + i]));
   bool ok = dmax > 0 && isfinite(dmax);
-  for (int i = 0; i < 6 && ok; ++i)
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
     for (int j = 0; j <= i; ++j) {
       double s = A[6 * i + j];
+#pragma unroll
       for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
       if (i == j) {
-        if (!(s > 1e-13 * dmax)) { ok = false; break; }
+        ok = ok && (s > 1e-13 * dmax);
         L[6 * i + i] = sqrt(s);
       } else {
         L[6 * i + j] = s / L[6 * j + j];
@@ -1459,11 +1476,24 @@ __device__ void solve6(const double* A, const double* rhs, double* x) {
     }
   if (ok) {
     double y[6];
-    for (int i = 0; i < 6; ++i) { double s = rhs[i]; for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k]; y[i] = s / L[6 * i + i]; }
-    for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k]; x[i] = s / L[6 * i + i]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      double s = rhs[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k];
+      y[i] = s / L[6 * i + i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+      double s = y[i];
+#pragma unroll
+      for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k];
+      x[i] = s / L[6 * i + i];
+    }
     return;
   }
   double E[36], V[36], w[6];
+#pragma unroll
   for (int i = 0; i < 36; ++i) E[i] = A[i];
   jacobi_eig6(E, V, w);
   double wmax = 0;
@@ -1522,30 +1552,86 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   const uint32_t qbin = s_q[0], below = s_q[1], n_valid = s_q[2], krank = s_q[3];
   const size_t so = (size_t)pair * b.ns_cap;
   const int ns = st->ns;
-  const int ngroups = (ns + 63) >> 6;                      // groups of 64 queries; thread t owns groups t, t + 256, ...
-  const uint32_t* gcount = b.gcount + (size_t)pair * ((b.ns_cap + 63) / 64);
+  // the quantile bin's members were left by `accumulate` in one segment per wave (64 * acc_items slots each, gcount = how
+  // many are used).  Member e of the pair = the (e - s_off[seg])-th entry of the segment with s_off[seg] <= e < s_off[seg+1]:
+  // an order fixed by the data alone, so every sum below runs in the same order in every run, and any thread can fetch
+  // any member with independent loads.
+  const int chunk = kAccThreads * b.acc_items;
+  const int nblk = (ns + chunk - 1) / chunk;
+  const int nseg = nblk * (kAccThreads / 64);
+  const int seg_len = 64 * b.acc_items;
+  const uint32_t* gcount = b.gcount + (size_t)pair * b.seg_stride;
+  const int32_t* bl = b.blist + (size_t)pair * b.bl_stride;
+  __shared__ uint32_t s_off[2 * kFinalizeMaxSeg];
+  __shared__ int s_idx[kFinalizeKeyCap];
+  auto segment_of = [&](int e) -> int {                   // the last segment with s_off[seg] <= e
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (s_off[mid] <= (uint32_t)e) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+  };
+  auto member = [&](int e) -> int {
+    const int seg = segment_of(e);
+    return bl[(size_t)seg * seg_len + (e - (int)s_off[seg])];
+  };
   double acc[29];
 #pragma unroll
   for (int c = 0; c < 29; ++c) acc[c] = 0.0;
   uint32_t limit_key = 0;
-  // The quantile bin's members, left by `accumulate` per group of 64 queries, are first gathered into one flat list in
-  // LDS (thread t's groups in order, then thread t + 1's: an order fixed by the data alone, so every sum below runs in
-  // the same order in every run).  Lists beyond the LDS capacity (very large clouds) are walked group by group instead.
-  __shared__ int s_idx[kFinalizeKeyCap];
   int nb = 0;
   bool flat = false;
   if (n_valid > 0) {
+    const int per = (nseg + 255) >> 8;                     // <= kFinalizeMaxSeg / 256
+    const int s0 = (int)threadIdx.x * per;
+    uint32_t c[kFinalizeMaxSeg / 256];
     uint32_t mine = 0;
-    for (int g = threadIdx.x; g < ngroups; g += blockDim.x) mine += gcount[g];
+#pragma unroll
+    for (int k = 0; k < kFinalizeMaxSeg / 256; ++k) {
+      c[k] = (k < per && s0 + k < nseg) ? gcount[s0 + k] : 0u;
+      mine += c[k];
+    }
     uint32_t total;
     uint32_t o = block_excl_scan(mine, s_w, &total);
+#pragma unroll
+    for (int k = 0; k < kFinalizeMaxSeg / 256; ++k)
+      if (k < per && s0 + k < nseg) { s_off[s0 + k] = o; o += c[k]; }
+    int top = 1;                                           // the first step of the segment search below
+    while (2 * top < nseg) top *= 2;
+    for (int x = nseg + (int)threadIdx.x; x < 2 * top; x += 256) s_off[x] = 0xffffffffu;
     nb = (int)total;
     flat = nb <= kFinalizeKeyCap;
-    if (flat)
-      for (int g = threadIdx.x; g < ngroups; g += blockDim.x) {
-        const int c = (int)gcount[g];
-        for (int m = 0; m < c; ++m) s_idx[o++] = b.blist[so + 64 * g + m];
+    __syncthreads();
+    // lists that fit are cached in LDS with their keys (the low 20 bits of d2: the high bits are the bin); longer lists
+    // (very large clouds, or many equal distances) are fetched again in every pass
+    if (flat && nb > 0) {
+      constexpr int kPer = kFinalizeKeyCap / 256;          // every member of a flat list in one round: two memory levels
+      int ii[kPer], sg[kPer];
+      float dd[kPer];
+      // the kPer segment searches advance together, one LDS level per step (a search per entry, one after the other,
+      // was most of this phase)
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) sg[k] = 0;
+      for (int step = top; step > 0; step >>= 1) {
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+          // s_off is padded with 0xffffffff up to the next power of two: one unconditional read and a select per entry, so
+          // the kPer reads of a step overlap (guarded by `cand < nseg` the compiler puts every read in its own branch)
+          const int cand = sg[k] + step;
+          sg[k] = s_off[cand] <= (uint32_t)min((int)threadIdx.x + 256 * k, nb - 1) ? cand : sg[k];
+        }
       }
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) ii[k] = bl[(size_t)sg[k] * seg_len + (min((int)threadIdx.x + 256 * k, nb - 1) - (int)s_off[sg[k]])];
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) dd[k] = b.d2[so + ii[k]];
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const int e = (int)threadIdx.x + 256 * k;
+        if (e < nb) { s_idx[e] = ii[k]; s_keys[e] = __float_as_uint(dd[k]) & 0xfffffu; }
+      }
+    }
     __syncthreads();
   }
   if (n_valid > 0) {
@@ -1559,31 +1645,9 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
       const uint32_t nd = 1u << widths[pass];
       s_h[threadIdx.x] = 0;
       __syncthreads();
-      if (flat) {
-        for (int e = threadIdx.x; e < nb; e += blockDim.x) {
-          // the keys are read from global memory once and kept in LDS for the other two passes
-          uint32_t key;
-          if (pass == 0) { key = __float_as_uint(b.d2[so + s_idx[e]]) & 0xfffffu; s_keys[e] = key; }
-          else key = s_keys[e];
-          if ((key & mask) == prefix) atomicAdd(&s_h[(key >> shift) & (nd - 1u)], 1u);
-        }
-      }
-      // (not flat) every thread walks its groups in the same order in every pass, so its k-th member is the same query
-      // each time: the first keys are kept in LDS (slot k * 256 + t)
-      int kth = 0;
-      for (int g = threadIdx.x; !flat && g < ngroups; g += blockDim.x) {
-        const int c = (int)gcount[g];
-        for (int m = 0; m < c; ++m, ++kth) {
-          const int slot = kth * 256 + (int)threadIdx.x;
-          uint32_t key;
-          if (pass == 0 || slot >= kFinalizeKeyCap) {
-            key = __float_as_uint(b.d2[so + b.blist[so + 64 * g + m]]) & 0xfffffu;
-            if (slot < kFinalizeKeyCap) s_keys[slot] = key;
-          } else {
-            key = s_keys[slot];
-          }
-          if ((key & mask) == prefix) atomicAdd(&s_h[(key >> shift) & (nd - 1u)], 1u);
-        }
+      for (int e = threadIdx.x; e < nb; e += blockDim.x) {
+        const uint32_t key = flat ? s_keys[e] : (__float_as_uint(b.d2[so + member(e)]) & 0xfffffu);
+        if ((key & mask) == prefix) atomicAdd(&s_h[(key >> shift) & (nd - 1u)], 1u);
       }
       __syncthreads();
       {   // the digit whose cumulative count crosses `rank`, found by all 256 threads at once
@@ -1603,30 +1667,39 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
     limit_key = (qbin << kHistShift) | prefix;
     // weights = (d2 <= limit)  (icp_fast.cc:497-498) for the boundary-bin entries
     if (flat) {
+      const size_t to = (size_t)pair * b.nt_cap;
+      // eight entries per thread and round, their loads issued level by level (source point + match, then the matched
+      // target point + normal) instead of one entry after the other
+      constexpr int kW = 8;
+      for (int e0 = threadIdx.x; e0 < nb; e0 += kW * 256) {
+        bool use[kW];
+        int ii[kW], jj[kW];
+        float4 s4[kW], q4[kW], n4[kW];
+#pragma unroll
+        for (int k = 0; k < kW; ++k) {
+          const int e = min(e0 + 256 * k, nb - 1);
+          use[k] = e0 + 256 * k < nb && s_keys[e] <= prefix;
+          ii[k] = s_idx[e];
+        }
+#pragma unroll
+        for (int k = 0; k < kW; ++k) { s4[k] = b.src[so + ii[k]]; jj[k] = max(b.idx[so + ii[k]], 0); }
+#pragma unroll
+        for (int k = 0; k < kW; ++k) { q4[k] = b.tq[to + jj[k]]; n4[k] = b.tn[to + jj[k]]; }
+#pragma unroll
+        for (int k = 0; k < kW; ++k)
+          if (use[k]) accumulate_terms(st->M, s4[k], q4[k], n4[k], __uint_as_float((qbin << kHistShift) | s_keys[e0 + 256 * k]), acc);
+      }
+    } else {
       for (int e = threadIdx.x; e < nb; e += blockDim.x) {
-        const int i = s_idx[e];
+        const int i = member(e);
         const float d = b.d2[so + i];
         if (__float_as_uint(d) <= limit_key) accumulate_pair(b, st, pair, i, d, acc);
       }
-    } else {
-      for (int g = threadIdx.x; g < ngroups; g += blockDim.x) {
-        const int c = (int)gcount[g];
-        for (int m = 0; m < c; ++m) {
-          const int i = b.blist[so + 64 * g + m];
-          const float d = b.d2[so + i];
-          if (__float_as_uint(d) <= limit_key) accumulate_pair(b, st, pair, i, d, acc);
-        }
-      }
     }
   }
-  block_reduce29(acc, s_red);
-  if (threadIdx.x == 0)
-    for (int c = 0; c < 29; ++c) s_tot[c] = acc[c];
-  __syncthreads();
+  block_reduce29(acc, s_red, s_tot);
   // add the per-block partial sums of the accumulate kernel: 8 thread groups take every 8th block,
   // then one thread per column folds the 8 group sums -- a fixed order, so the result is reproducible
-  const int chunk = kAccThreads * b.acc_items;
-  const int nblk = (ns + chunk - 1) / chunk;
   {
     const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
     double s = 0;
@@ -1644,7 +1717,6 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   for (int k = threadIdx.x; k < kHistBins; k += blockDim.x) gh[k] = 0;
   __syncthreads();
   if (threadIdx.x != 0) return;
-
   st->fallback_total += st->unresolved_count;
   st->unresolved_count = 0;
   st->hard_total += st->hard_count;
@@ -1674,8 +1746,11 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   double A[36], rhs[6], x[6];
   {
     int c = 0;
+#pragma unroll
     for (int a = 0; a < 6; ++a)
+#pragma unroll
       for (int e = a; e < 6; ++e) { A[6 * a + e] = s_tot[c]; A[6 * e + a] = s_tot[c]; ++c; }
+#pragma unroll
     for (int a = 0; a < 6; ++a) rhs[a] = -s_tot[21 + a];                       // b = -(wF * dot), :302
   }
   solve6(A, rhs, x);                                                          // :304

@@ -347,6 +347,8 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
                           smhip_handle* out) {
   if (!out || pair_slots < 1 || max_source_points < 1 || max_target_points < 1) return SMHIP_ERR_INVALID_ARGUMENT;
   *out = nullptr;
+  // finalize indexes at most kFinalizeMaxSeg accumulate waves per pair: 4 Mi source points per cloud
+  if (max_source_points > kFinalizeMaxSeg * 64 * kAccItemsBatch) return SMHIP_ERR_INVALID_ARGUMENT;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SMHIP_ERR_NO_DEVICE;
   hipDeviceProp_t prop;
@@ -368,6 +370,8 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   d.slots = pair_slots; d.ns_cap = max_source_points; d.nt_cap = max_target_points;
   d.acc_blocks = ceil_div(max_source_points, kAccThreads * kAccItemsSmall);
   d.acc_items = kAccItemsSmall;
+  d.bl_stride = ceil_div(max_source_points, kAccThreads * kAccItemsBatch) * (kAccThreads * kAccItemsBatch);
+  d.seg_stride = d.acc_blocks * (kAccThreads / 64);     // one segment per accumulate wave, short chunks = most waves
   const size_t B = pair_slots, NS = max_source_points, NT = max_target_points;
   smhip_status s = SMHIP_OK;
   auto A = [&](smhip_status r) { if (s == SMHIP_OK) s = r; };
@@ -393,8 +397,8 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, &d.hlist, B * NS));
   A(dev_alloc(h, &d.ulist, B * NS));
   A(dev_alloc(h, &d.ukeys, B * NS));
-  A(dev_alloc(h, &d.blist, B * NS));
-  A(dev_alloc(h, &d.gcount, B * ((NS + 63) / 64)));
+  A(dev_alloc(h, &d.blist, B * (size_t)d.bl_stride));
+  A(dev_alloc(h, &d.gcount, B * (size_t)d.seg_stride));
   A(dev_alloc(h, &d.partials, B * d.acc_blocks * kAccCols));
   A(dev_alloc(h, &d.tpart, B * kTgtReduceBlocks * 16));
   A(dev_alloc(h, &d.done_count, 4));
@@ -738,7 +742,9 @@ smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* g
   for (int k = 0; k < nh; ++k) {   // launches of fewer than ~2 workgroups per CU take the small-launch kernel variants
     halves[k].small = halves[k].np * ceil_div(ns_max, kNnThreads * kBallItems) < 512;
     // long accumulate chunks once they still leave >= 3 workgroups per CU
-    halves[k].d.acc_items = halves[k].np * ceil_div(ns_max, kAccThreads * kAccItemsBatch) >= 768 ? kAccItemsBatch : kAccItemsSmall;
+    // (or when short chunks would make more segments than finalize indexes)
+    halves[k].d.acc_items = (halves[k].np * ceil_div(ns_max, kAccThreads * kAccItemsBatch) >= 768 ||
+                             ceil_div(ns_max, kAccThreads * kAccItemsSmall) * (kAccThreads / 64) > kFinalizeMaxSeg) ? kAccItemsBatch : kAccItemsSmall;
   }
   for (int k = 0; k < nh; ++k) { s = enqueue_grid_build(h, halves[k], nt_max); if (s) return s; }
   const int max_it = h->dev.max_iteration;

@@ -17,6 +17,7 @@ constexpr int kAccThreads = 256;
 constexpr int kAccItemsSmall = 8;
 constexpr int kAccItemsBatch = 32;
 constexpr int kFinalizeKeyCap = 4096;     // boundary-bin keys finalize keeps in LDS between its radix-select passes
+constexpr int kFinalizeMaxSeg = 2048;     // accumulate waves (= blist segments) per pair finalize can index: 4 Mi source points at 32 per thread
 constexpr int kAccCols = 32;             // 21 (A upper) + 6 (b) + 1 (sum sqrt d2) + 1 (count) padded to 32
 constexpr int kMaxGridWords = 1 << 18;   // 32-cell words per pair (8 Mi cells)
 constexpr int kTgtReduceBlocks = 32;     // partial blocks for the target mean / bbox
@@ -88,6 +89,8 @@ struct IcpDev {
   int32_t npairs;            // pairs this launch covers (XCD-aware kernels pad the grid to a multiple of 8)
   int32_t pair_base;         // first pair slot of this launch (the batch is split over two streams)
   int32_t acc_blocks;        // ceil(ns_cap / (kAccThreads * kAccItemsSmall))
+  int32_t bl_stride;         // blist entries per pair: ns_cap rounded up to a whole batched accumulate chunk
+  int32_t seg_stride;        // gcount entries per pair
   int32_t acc_items;         // points per thread of the accumulate launches of this batch part (finalize folds accordingly)
   PairState* state;
   const PairInput* in;

@@ -171,6 +171,27 @@ def test_identical_clouds_give_identity(smhip, cfg1):
     m.close()
 
 
+def test_long_boundary_list_path(smhip, cfg2):
+    """More members in the quantile's histogram bin than finalize keeps in LDS (here: 21 k equal distances of a cloud
+    matched against itself) take the uncached list path; kept count, identity and score must come out the same way."""
+    q, n = cfg2["q"], cfg2["n"]
+    assert len(q) > 3 * 4096
+    m = smhip.IcpFastHip(max_source_points=len(q), max_target_points=len(q), max_iteration=6, early_exit=0)
+    m.set_input_source(q)
+    m.set_input_target(q, n)
+    ok, R = m.align()
+    st = m.last_stats[0]
+    assert ok and np.allclose(R, np.eye(4), atol=1e-5)
+    ids, d2 = m.get_matches(len(q))
+    k = int(len(d2) * float(np.float32(0.7)))
+    limit = np.partition(d2, k)[k]
+    assert ((d2.view(np.uint32) >> 20) == (np.float32(limit).view(np.uint32) >> 20)).sum() > 4096    # the long-list path
+    assert np.float32(st["limit_d2"]) == limit
+    assert st["kept"] == int((d2 <= limit).sum())
+    assert m.get_fitness_score() > 0.999
+    m.close()
+
+
 def test_far_source_uses_fallback_and_stays_exact(smhip, velo20k):
     """Queries far outside the target's grid go through the brute-force fallback; ids stay exact."""
     c = velo20k

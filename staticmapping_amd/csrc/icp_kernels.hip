@@ -412,7 +412,7 @@ __device__ __forceinline__ void search_row(const uint2* __restrict__ words, cons
 //      L - delta away: if the old match is closer than that it is provably still the unique nearest
 //      neighbour and no search happens at all (nn_certify).  Lower-bounded ("hard") queries keep their
 //      bound the same way.  Only the queries whose certificate fails are compacted into dlist and searched
-//      (LISTED = true); iteration 0 searches everything.
+//      (nn_ball_listed); iteration 0 searches everything.
 // The search radius is min(R_cap, d_prev + margin) rather than d_prev so the runner-up information
 // reaches beyond the match; margin = 3 x the query's motion in this iteration (1 cm .. 10 cm).
 __device__ __forceinline__ float search_radius2(float r2cap, float dub2, float margin) {
@@ -423,18 +423,14 @@ __device__ __forceinline__ float search_radius2(float r2cap, float dub2, float m
 // (runner-up bound minus the query's motion) can still clear the match; motion shrinks every iteration
 __device__ __forceinline__ float search_margin(float delta) { return fminf(fmaxf(3.0f * delta, 0.01f), 0.10f); }
 
-template <bool LISTED>
 __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
   int pair, blk;
   if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
   PairState* st = &b.state[pair];
   if (st->done) return;
-  const int count = LISTED ? (int)st->deferred_count : st->ns;
+  const int count = st->ns;
   const int base0 = blk * (kNnThreads * kBallItems);
   if (base0 >= count) return;
-  // LISTED: a small fixed grid strides over the list of failing queries (a handful once ICP has settled, all of them
-  // in the worst case); the unlisted form covers every query with one workgroup per 1024
-  const int stride = LISTED ? nblk * (kNnThreads * kBallItems) : count;
   __shared__ uint32_t s_hist[kHistBins];
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
   __syncthreads();
@@ -450,13 +446,12 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
   const bool have_prev = st->iter > 0;
   uint32_t min_lb = 0xffffffffu;
 
-  for (int base = base0; base < count; base += stride)
   for (int it = 0; it < kBallItems; ++it) {
-    const int e = base + it * kNnThreads + threadIdx.x;
+    const int e = base0 + it * kNnThreads + threadIdx.x;
     bool hard = false;
     int i = -1;
     if (e < count) {
-      i = LISTED ? b.dlist[so + e] : e;
+      i = e;
       double px, py, pz;
       transform_point(st->M, b.src[so + i], px, py, pz);
       const float qx = (float)px, qy = (float)py, qz = (float)pz;
@@ -515,6 +510,132 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
       b.lb[so + i] = lbout;
       const uint32_t key = __float_as_uint(d2out);
       if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
+    }
+    const unsigned long long hm = __ballot(hard);
+    if (hm) {
+      uint32_t basepos = 0;
+      if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
+      basepos = __shfl(basepos, 0, 64);
+      if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
+    }
+  }
+  if (min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
+  __syncthreads();
+  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
+    const uint32_t v = s_hist[k];
+    if (v) atomicAdd(&gh[k], v);
+  }
+}
+
+// The search of the queries nn_certify could not certify (dlist), on a small fixed grid per pair.  Once ICP has settled
+// a pair has a few hundred to a few thousand of them and a query's search is a chain of dependent lookups per grid row
+// (row words -> run bounds -> points), so the launch is pure latency: the grid's threads are therefore dealt out L at a
+// time to one query (L = the largest power of two <= 16 the list leaves room for), the L lanes take the rows of the
+// query's ball in turn and their results are merged with the tie rule of the sequential sweep (smallest distance, then
+// smallest sorted position; runner-up = the smallest of the rest).  Same ids, distances and bounds as a one-lane sweep.
+__global__ __launch_bounds__(kNnThreads) void nn_ball_listed(IcpDev b, int nblk) {
+  int pair, blk;
+  if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  const int count = (int)st->deferred_count;
+  if (count == 0) return;
+  int L = 1, logL = 0;
+  while (L < 16 && 2 * L * count <= nblk * kNnThreads) { L *= 2; ++logL; }
+  const int qpb = kNnThreads >> logL;                      // queries per workgroup and pass
+  if (blk * qpb >= count) return;
+  __shared__ uint32_t s_hist[kHistBins];
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int sub = (int)threadIdx.x & (L - 1), ql = (int)threadIdx.x >> logL;
+  const size_t so = (size_t)pair * b.ns_cap;
+  const uint2* __restrict__ words = b.words + (size_t)pair * kMaxGridWords;
+  const uint32_t* __restrict__ cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
+  const float4* __restrict__ tq = b.tq + (size_t)pair * b.nt_cap;
+  const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
+  const float h = st->h, inv_h = st->inv_h;
+  const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
+  const float r2cap = st->rcap2;
+  const bool have_prev = st->iter > 0;
+  uint32_t min_lb = 0xffffffffu;
+  for (int base = blk * qpb; base < count; base += nblk * qpb) {        // workgroup-uniform
+    const int e = base + ql;
+    bool hard = false;
+    int i = -1;
+    if (e < count) {
+      i = b.dlist[so + e];
+      const float4 s4 = b.src[so + i];
+      double px, py, pz;
+      transform_point(st->M, s4, px, py, pz);
+      const float qx = (float)px, qy = (float)py, qz = (float)pz;
+      Best best = {INFINITY, -1, INFINITY};
+      const bool finite = isfinite(qx) && isfinite(qy) && isfinite(qz);
+      float R2 = r2cap;
+      int jp = -1;
+      if (finite) {
+        if (have_prev) {
+          jp = b.idx[so + i];
+          if (jp >= 0) {
+            double ux, uy, uz;
+            transform_point(st->M_prev, s4, ux, uy, uz);
+            const float ex = qx - (float)ux, ey = qy - (float)uy, ez = qz - (float)uz;
+            R2 = search_radius2(r2cap, dist2(tq[jp], qx, qy, qz), search_margin(sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)))));
+          }
+        }
+        // every target point within sqrt(R2) of q lies in a cell meeting [q - Rs, q + Rs]^3
+        const float Rs = sqrtf(R2) * 1.0001f + 1.0e-3f * h;
+        const int x0 = max(cell_coord(qx - Rs, ox, inv_h), 0), x1 = min(cell_coord(qx + Rs, ox, inv_h), nx - 1);
+        const int y0 = max(cell_coord(qy - Rs, oy, inv_h), 0), y1 = min(cell_coord(qy + Rs, oy, inv_h), ny - 1);
+        const int z0 = max(cell_coord(qz - Rs, oz, inv_h), 0), z1 = min(cell_coord(qz + Rs, oz, inv_h), nz - 1);
+        const int nyr = y1 - y0 + 1;
+        const int nrows = (x0 <= x1 && y0 <= y1 && z0 <= z1) ? nyr * (z1 - z0 + 1) : 0;
+        const float slack = 2.0e-3f * h;
+        for (int r = sub; r < nrows; r += L) {              // this lane's rows of the ball
+          const int zr = r / nyr;
+          const int z = z0 + zr, y = y0 + (r - zr * nyr);
+          const float zl = oz + (float)z * h, yl = oy + (float)y * h;
+          const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + h)) - slack, 0.f);
+          const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + h)) - slack, 0.f);
+          if (fmaf(dy, dy, dz * dz) > R2) continue;          // the row lies outside the ball
+          uint32_t sb, se;
+          row_slots(words, (z * ny + y) * wx, x0, x1, sb, se);
+          if (se > sb) {
+            const uint32_t j0 = cstart[sb], j1 = cstart[se];
+            for (uint32_t j = j0; j < j1; ++j) test_ascending_ru(tq[j], (int)j, qx, qy, qz, best);
+          }
+        }
+      }
+      // merge the L lanes of the query (butterfly inside aligned groups of L lanes; every lane ends with the result)
+      for (int off = 1; off < L; off <<= 1) {
+        const float od = __shfl_xor(best.d2, off, 64), os = __shfl_xor(best.s2, off, 64);
+        const int oj = __shfl_xor(best.j, off, 64);
+        best.s2 = fminf(fminf(best.s2, os), fmaxf(best.d2, od));
+        if (od < best.d2 || (od == best.d2 && (unsigned)oj < (unsigned)best.j)) { best.d2 = od; best.j = oj; }
+      }
+      if (sub == 0) {
+        float d2out = INFINITY, lbout = 0.f;
+        int jout = -1;
+        if (finite) {
+          if (best.d2 <= R2) {                  // exact: everything within sqrt(R2) was seen
+            d2out = best.d2;
+            jout = best.j;
+            lbout = sqrtf(fminf(best.s2, R2));  // every other point is at least this far
+          } else {                              // certified lower bound: nothing lies within sqrt(R2)
+            d2out = R2;
+            jout = best.j >= 0 ? best.j : jp;   // an upper-bound seed for later iterations
+            lbout = -sqrtf(R2);
+            hard = true;
+            min_lb = min(min_lb, __float_as_uint(R2));
+          }
+        }
+        b.d2[so + i] = d2out;
+        b.idx[so + i] = jout;
+        b.lb[so + i] = lbout;
+        const uint32_t key = __float_as_uint(d2out);
+        if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
+      }
     }
     const unsigned long long hm = __ballot(hard);
     if (hm) {

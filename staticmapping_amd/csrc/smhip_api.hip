@@ -218,10 +218,10 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
         // (also what the converged iterations of the LDS variant use: a streaming certificate pass at full occupancy and a
         // near-empty listed search beat the fused kernel once only a handful of certificates fail)
         { Bracket br(h, d.lds_table ? 1 : 4, st, np); hipLaunchKernelGGL(nn_certify, gx, dim3(kNnThreads), 0, st, d, nblk); }
-        { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_ball<true>, glist, dim3(kNnThreads), 0, st, d, kListedBlocks); }
+        { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_ball_listed, glist, dim3(kNnThreads), 0, st, d, kListedBlocks); }
       } else {
         Bracket br(h, 4, st, np);
-        hipLaunchKernelGGL(nn_ball<false>, gx, dim3(kNnThreads), 0, st, d, nblk);
+        hipLaunchKernelGGL(nn_ball, gx, dim3(kNnThreads), 0, st, d, nblk);
       }
       { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_validate, dim3(np), dim3(256), 0, st, d); }
       { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_ring<true>, dim3(32, np), dim3(kNnThreads), 0, st, d); }

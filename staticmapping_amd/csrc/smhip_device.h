@@ -26,7 +26,7 @@ constexpr int kFallbackSlices = 64;
 constexpr int kLdsTableCap = 1024;        // u32 entries of the per-workgroup row table in nn_ball_lds (4 KiB)
 constexpr int kLdsPointCap = 512;         // target points staged per round (8 KiB)
 constexpr int kLdsRowCap = 256;           // grid rows of the box whose runs are staged (<= workgroup size)
-constexpr int kListedBlocks = 32;          // workgroups per pair of the listed search (nn_ball<true>): it strides over the list
+constexpr int kListedBlocks = 32;           // workgroups per pair of the listed search (nn_ball_listed): it strides over the list
 constexpr int kBallItems = 4;            // queries per thread in nn_ball (1024 per block: fewer histogram flushes)      // target slices the fallback sweep is spread over         // target points staged in LDS per tile (16 KiB as float4)
 
 // Per-pair device state.  Everything an iteration needs and everything the host reads back.
@@ -60,7 +60,7 @@ struct PairState {
   uint32_t blist_count;
   uint32_t fallback_total;
   uint32_t searched_total;   // queries that went through a search, summed over iterations
-  uint32_t deferred_count;   // queries nn_ball<false> left to the cap-radius launch
+  uint32_t deferred_count;   // queries whose certificate failed (nn_certify), searched by nn_ball_listed
   uint32_t hard_count;       // queries nn_ball recorded with a lower bound this iteration
   uint32_t hard_total;
   uint32_t min_lb_key;       // smallest such bound (float bits)
@@ -111,7 +111,7 @@ struct IcpDev {
   float* d2;                 // [slots][ns_cap]
   int32_t* idx;              // [slots][ns_cap] index into tq/tn (sorted order)
   uint32_t* hist;            // [slots][kHistBins]
-  int32_t* dlist;            // [slots][ns_cap] deferred queries (searched with the cap radius by nn_ball<true>)
+  int32_t* dlist;            // [slots][ns_cap] deferred queries (searched by nn_ball_listed)
   int32_t* hlist;            // [slots][ns_cap] queries the tile phase could not certify (ring search)
   int32_t* ulist;            // [slots][ns_cap] unresolved queries (brute-force fallback)
   unsigned long long* ukeys; // [slots][ns_cap] fallback winners: (d2 bits << 32) | original target index

@@ -655,13 +655,15 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball_listed(IcpDev b, int nblk)
 }
 
 // Certificate pass (iterations >= 1): no search, five memory operations per query.
+// ITEMS = rounds of 256 queries per workgroup: kBallItems in batches, 1 where that would leave too few workgroups (one pair)
+template <int ITEMS>
 __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
   int pair, blk;
   if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
   PairState* st = &b.state[pair];
   if (st->done) return;
   const int ns = st->ns;
-  const int base = blk * (kNnThreads * kBallItems);
+  const int base = blk * (kNnThreads * ITEMS);
   if (base >= ns) return;
   __shared__ uint32_t s_hist[kHistBins];
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
@@ -671,7 +673,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
   const float4* __restrict__ tq = b.tq + (size_t)pair * b.nt_cap;
   const float r_need = 0.9f * sqrtf(st->rcap2);     // a hard query's bound must stay well above the quantile
   uint32_t min_lb = 0xffffffffu;
-  for (int it = 0; it < kBallItems; ++it) {
+  for (int it = 0; it < ITEMS; ++it) {
     const int i = base + it * kNnThreads + threadIdx.x;
     bool hard = false, fail = false;
     if (i < ns) {

@@ -201,9 +201,10 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
       const int nblk = ceil_div(ns_max, kNnThreads * kBallItems);
       const dim3 gx(nblk * 8 * ceil_div(np, 8));
       const dim3 glist(kListedBlocks * 8 * ceil_div(np, 8));
-      // the two-launch form pays from ~64 pairs per launch on (measured: -3 % at 32, +2 % at 64, +9 % at 256 pairs);
-      // an explicit split_after option is honoured for any size
-      const bool split_now = d.certify && iteration >= d.split_after && (h->opts.split_after > 0 || np >= 64);
+      // the two-launch form pays from ~16 pairs per launch on (measured with the many-lanes-per-query listed search: equal for
+      // one pair, +4 % at 16, +1 % at 32, +6 % at 2 x 32, +9 % at 256 pairs); an explicit split_after option is honoured
+      // for any size
+      const bool split_now = d.certify && iteration >= d.split_after && (h->opts.split_after > 0 || np >= 16);
       if (d.lds_table && !split_now) {
         // certificate, in-workgroup compaction of the failing queries and LDS-staged search in one launch
         Bracket br(h, 4, st, np);
@@ -217,7 +218,15 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
         // global-memory variant: certificate pass, then a search over the compacted failing queries
         // (also what the converged iterations of the LDS variant use: a streaming certificate pass at full occupancy and a
         // near-empty listed search beat the fused kernel once only a handful of certificates fail)
-        { Bracket br(h, d.lds_table ? 1 : 4, st, np); hipLaunchKernelGGL(nn_certify, gx, dim3(kNnThreads), 0, st, d, nblk); }
+        {
+          Bracket br(h, d.lds_table ? 1 : 4, st, np);
+          if (f.small) {
+            const int nb1 = ceil_div(ns_max, kNnThreads);
+            hipLaunchKernelGGL(nn_certify<1>, dim3(nb1 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nb1);
+          } else {
+            hipLaunchKernelGGL(nn_certify<kBallItems>, gx, dim3(kNnThreads), 0, st, d, nblk);
+          }
+        }
         { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_ball_listed, glist, dim3(kNnThreads), 0, st, d, kListedBlocks); }
       } else {
         Bracket br(h, 4, st, np);

@@ -1049,6 +1049,21 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
   }
 }
 
+// a run of the sorted target tested with the explicit tie rule, four independent loads in flight per lane (one load per
+// trip left every candidate a full memory latency: 400 us for the first ring of 120 k queries against a dense submap)
+__device__ __forceinline__ void sweep_run_any(const float4* __restrict__ tq, uint32_t j0, uint32_t j1,
+                                              float qx, float qy, float qz, Best& best) {
+  uint32_t j = j0;
+  for (; j + 4 <= j1; j += 4) {
+    const float4 t0 = tq[j], t1 = tq[j + 1], t2 = tq[j + 2], t3 = tq[j + 3];
+    test_any_order(t0, (int)j, qx, qy, qz, best);
+    test_any_order(t1, (int)j + 1, qx, qy, qz, best);
+    test_any_order(t2, (int)j + 2, qx, qy, qz, best);
+    test_any_order(t3, (int)j + 3, qx, qy, qz, best);
+  }
+  for (; j < j1; ++j) test_any_order(tq[j], (int)j, qx, qy, qz, best);
+}
+
 // candidates of the cells x in [xa, xb] of row (y, z): one contiguous run of the sorted target
 __device__ __forceinline__ void search_row(const uint2* __restrict__ words, const uint32_t* __restrict__ cstart,
                                            const float4* __restrict__ tq, int rowbase, int xa, int xb,
@@ -1056,8 +1071,7 @@ __device__ __forceinline__ void search_row(const uint2* __restrict__ words, cons
   uint32_t sb, se;
   row_slots(words, rowbase, xa, xb, sb, se);
   if (se > sb) {
-    const uint32_t j0 = cstart[sb], j1 = cstart[se];
-    for (uint32_t j = j0; j < j1; ++j) test_any_order(tq[j], (int)j, qx, qy, qz, best);
+    sweep_run_any(tq, cstart[sb], cstart[se], qx, qy, qz, best);
   }
 }
 
@@ -1178,73 +1192,138 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring_coop(IcpDev b) {
     Best best = {INFINITY, -1, INFINITY};
     bool resolved = true;
     if (live && isfinite(qx) && isfinite(qy) && isfinite(qz)) {
+      // first ring only (where nearly every query ends; the few that need a wider block go to nn_ring_wide, a wave each:
+      // left here they took 20-70 rows per lane and every workgroup waited for its slowest query)
       const int cx = cell_coord(qx, ox, inv_h), cy = cell_coord(qy, oy, inv_h), cz = cell_coord(qz, oz, inv_h);
-      int rp = 0;
-      resolved = false;
-      for (int r = 1; r <= b.max_ring; r *= 2) {
-        const int x0 = max(cx - r, 0), x1 = min(cx + r, nx - 1);
-        const int y0 = max(cy - r, 0), y1 = min(cy + r, ny - 1);
-        const int z0 = max(cz - r, 0), z1 = min(cz + r, nz - 1);
-        if (r == 1 && x0 <= x1 && y0 <= y1 && z0 <= z1) {
-          // first ring (where nearly every query ends): at most 9 rows, <= 3 per lane -- their word and cstart lookups are
-          // issued together so that a lane exposes three load latencies instead of three per row
-          uint32_t ja[3], jb[3];
-          uint2 wa[3], wc[3];
-          int nrow = 0;
-          {
-            int k = 0;
-            for (int z = z0; z <= z1; ++z)
-              for (int y = y0; y <= y1; ++y, ++k) {
-                if ((k & (kCoopLanes - 1)) != sub || nrow >= 3) continue;
-                const int rowbase = (z * ny + y) * wx;
-                wa[nrow] = words[rowbase + (x0 >> 5)];
-                wc[nrow] = words[rowbase + (x1 >> 5)];
-                ++nrow;
-              }
-          }
-#pragma unroll
-          for (int m = 0; m < 3; ++m)
-            if (m < nrow) {
-              const uint32_t sb = wa[m].y + __popc(wa[m].x & ((1u << (x0 & 31)) - 1u));
-              const uint32_t se = wc[m].y + __popc(wc[m].x & (0xffffffffu >> (31 - (x1 & 31))));
-              ja[m] = cstart[sb]; jb[m] = cstart[se];
-            }
-#pragma unroll
-          for (int m = 0; m < 3; ++m)
-            if (m < nrow)
-              for (uint32_t j = ja[m]; j < jb[m]; ++j) test_any_order(tq[j], (int)j, qx, qy, qz, best);
-        } else if (x0 <= x1 && y0 <= y1 && z0 <= z1) {
+      const int x0 = max(cx - 1, 0), x1 = min(cx + 1, nx - 1);
+      const int y0 = max(cy - 1, 0), y1 = min(cy + 1, ny - 1);
+      const int z0 = max(cz - 1, 0), z1 = min(cz + 1, nz - 1);
+      if (x0 <= x1 && y0 <= y1 && z0 <= z1) {
+        // at most 9 rows, <= 3 per lane -- their word and cstart lookups are issued together so that a lane exposes three
+        // load latencies instead of three per row
+        uint32_t ja[3], jb[3];
+        uint2 wa[3], wc[3];
+        int nrow = 0;
+        {
           int k = 0;
           for (int z = z0; z <= z1; ++z)
             for (int y = y0; y <= y1; ++y, ++k) {
-              if ((k & (kCoopLanes - 1)) != sub) continue;
+              if ((k & (kCoopLanes - 1)) != sub || nrow >= 3) continue;
               const int rowbase = (z * ny + y) * wx;
-              const bool inner = rp > 0 && abs(y - cy) <= rp && abs(z - cz) <= rp;
-              if (!inner) {
-                search_row(words, cstart, tq, rowbase, x0, x1, qx, qy, qz, best);
-              } else {
-                const int xl1 = min(cx - rp - 1, nx - 1), xr0 = max(cx + rp + 1, 0);
-                if (x0 <= xl1) search_row(words, cstart, tq, rowbase, x0, xl1, qx, qy, qz, best);
-                if (xr0 <= x1) search_row(words, cstart, tq, rowbase, xr0, x1, qx, qy, qz, best);
-              }
+              wa[nrow] = words[rowbase + (x0 >> 5)];
+              wc[nrow] = words[rowbase + (x1 >> 5)];
+              ++nrow;
             }
         }
-        // merge the group's bests: smaller distance, then smaller position
 #pragma unroll
-        for (int off = 1; off < kCoopLanes; off <<= 1) {
-          const float od = __shfl_xor(best.d2, off, 64);
-          const int oj = __shfl_xor(best.j, off, 64);
-          if (od < best.d2 || (od == best.d2 && oj >= 0 && (best.j < 0 || oj < best.j))) { best.d2 = od; best.j = oj; }
-        }
-        const float g = block_guarantee(st, qx, qy, qz, cx - r, cx + r, cy - r, cy + r, cz - r, cz + r);
-        if (g == INFINITY || (g > 0.f && best.d2 <= g * g)) { resolved = true; break; }
-        rp = r;
+        for (int m = 0; m < 3; ++m)
+          if (m < nrow) {
+            const uint32_t sb = wa[m].y + __popc(wa[m].x & ((1u << (x0 & 31)) - 1u));
+            const uint32_t se = wc[m].y + __popc(wc[m].x & (0xffffffffu >> (31 - (x1 & 31))));
+            ja[m] = cstart[sb]; jb[m] = cstart[se];
+          }
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+          if (m < nrow)
+            sweep_run_any(tq, ja[m], jb[m], qx, qy, qz, best);
       }
+      // merge the group's bests: smaller distance, then smaller position
+#pragma unroll
+      for (int off = 1; off < kCoopLanes; off <<= 1) {
+        const float od = __shfl_xor(best.d2, off, 64);
+        const int oj = __shfl_xor(best.j, off, 64);
+        if (od < best.d2 || (od == best.d2 && oj >= 0 && (best.j < 0 || oj < best.j))) { best.d2 = od; best.j = oj; }
+      }
+      const float g = block_guarantee(st, qx, qy, qz, cx - 1, cx + 1, cy - 1, cy + 1, cz - 1, cz + 1);
+      resolved = g == INFINITY || (g > 0.f && best.d2 <= g * g);
     }
     if (live && sub == 0) {
       b.d2[so + i] = best.d2;
       b.idx[so + i] = best.j;
       b.lb[so + i] = 0.f;
+      if (resolved) {
+        const uint32_t key = __float_as_uint(best.d2);
+        if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
+      } else if (b.max_ring >= 2) {                       // wider rings: nn_ring_wide
+        b.dlist[so + atomicAdd(&st->deferred_count, 1u)] = i;
+      } else {
+        const uint32_t pos = atomicAdd(&st->unresolved_count, 1u);
+        b.ulist[so + pos] = i;
+        b.ukeys[so + pos] = ~0ull;
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
+    const uint32_t v = s_hist[k];
+    if (v) atomicAdd(&gh[k], v);
+  }
+}
+
+// Rings 2, 4, ... max_ring for the queries the first ring did not certify (dlist), one WAVE per query: the rows of the
+// cell block go round the 64 lanes (cells of the previous block are skipped as in nn_ring), the lanes' results are merged
+// with the explicit tie rule, and the certification test is the same.  What is still uncertified goes to the brute-force
+// fallback list.  Fixed grid; the waves stride over the list.
+__global__ __launch_bounds__(kNnThreads) void nn_ring_wide(IcpDev b) {
+  const int pair = b.pair_base + blockIdx.y;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  const int count = (int)st->deferred_count;
+  constexpr int kWaves = kNnThreads / 64;
+  if ((int)blockIdx.x * kWaves >= count) return;
+  __shared__ uint32_t s_hist[kHistBins];
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const size_t so = (size_t)pair * b.ns_cap;
+  const uint2* words = b.words + (size_t)pair * kMaxGridWords;
+  const uint32_t* cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
+  const float4* tq = b.tq + (size_t)pair * b.nt_cap;
+  const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
+  const float inv_h = st->inv_h;
+  const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
+  for (int e = (int)blockIdx.x * kWaves + (int)(threadIdx.x >> 6); e < count; e += (int)gridDim.x * kWaves) {   // wave-uniform
+    const int i = b.dlist[so + e];
+    double px, py, pz;
+    transform_point(st->M, b.src[so + i], px, py, pz);
+    const float qx = (float)px, qy = (float)py, qz = (float)pz;
+    const int cx = cell_coord(qx, ox, inv_h), cy = cell_coord(qy, oy, inv_h), cz = cell_coord(qz, oz, inv_h);
+    Best best = {b.d2[so + i], b.idx[so + i], INFINITY};            // what the first ring found (uncertified)
+    bool resolved = false;
+    int rp = 1;
+    for (int r = 2; r <= b.max_ring; r *= 2) {
+      const int x0 = max(cx - r, 0), x1 = min(cx + r, nx - 1);
+      const int y0 = max(cy - r, 0), y1 = min(cy + r, ny - 1);
+      const int z0 = max(cz - r, 0), z1 = min(cz + r, nz - 1);
+      if (x0 <= x1 && y0 <= y1 && z0 <= z1) {
+        const int nyr = y1 - y0 + 1, nrows = nyr * (z1 - z0 + 1);
+        for (int k = lane; k < nrows; k += 64) {
+          const int zr = k / nyr;
+          const int z = z0 + zr, y = y0 + (k - zr * nyr);
+          const int rowbase = (z * ny + y) * wx;
+          const bool inner = abs(y - cy) <= rp && abs(z - cz) <= rp;
+          if (!inner) {
+            search_row(words, cstart, tq, rowbase, x0, x1, qx, qy, qz, best);
+          } else {
+            const int xl1 = min(cx - rp - 1, nx - 1), xr0 = max(cx + rp + 1, 0);
+            if (x0 <= xl1) search_row(words, cstart, tq, rowbase, x0, xl1, qx, qy, qz, best);
+            if (xr0 <= x1) search_row(words, cstart, tq, rowbase, xr0, x1, qx, qy, qz, best);
+          }
+        }
+      }
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const float od = __shfl_xor(best.d2, off, 64);
+        const int oj = __shfl_xor(best.j, off, 64);
+        if (od < best.d2 || (od == best.d2 && oj >= 0 && (best.j < 0 || oj < best.j))) { best.d2 = od; best.j = oj; }
+      }
+      const float g = block_guarantee(st, qx, qy, qz, cx - r, cx + r, cy - r, cy + r, cz - r, cz + r);
+      if (g == INFINITY || (g > 0.f && best.d2 <= g * g)) { resolved = true; break; }
+      rp = r;
+    }
+    if (lane == 0) {
+      b.d2[so + i] = best.d2;
+      b.idx[so + i] = best.j;
       if (resolved) {
         const uint32_t key = __float_as_uint(best.d2);
         if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
@@ -1256,6 +1335,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring_coop(IcpDev b) {
     }
   }
   __syncthreads();
+  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
     const uint32_t v = s_hist[k];
     if (v) atomicAdd(&gh[k], v);

@@ -266,8 +266,11 @@ __global__ __launch_bounds__(256) void ndt_voxel_stats(NdtDev d) {
 // R = float restates pclomp (ndt_omp_impl.hpp: Matrix<float,4,6> math); R = double restates stock
 // pcl::NormalDistributionsTransform (PCL 1.8.1 ndt.hpp: the same formulas on Vector3d / Matrix3d), which
 // registrators/ndt_gicp.cc:38-41,84-89 uses.
-template <typename R>
-__global__ __launch_bounds__(kNdtDerivThreads) void ndt_derivatives(NdtDev d, NdtPose P) {
+// ONE = the grid has a thread for every source point (always, up to 524 288 points): the per-point sums of the reference
+// (score_pt, g_pt, h_pt: summed per point first, then added to the totals) are then the thread's totals themselves and
+// need no registers of their own -- 43 doubles fewer per lane.
+template <typename R, bool ONE>
+__global__ __launch_bounds__(kNdtDerivThreads, ONE ? 2 : 1) void ndt_derivatives(NdtDev d, NdtPose P) {
   constexpr bool kDouble = sizeof(R) == 8;
   const NdtGridInfo* g = d.info;
   double acc[43];
@@ -299,11 +302,11 @@ __global__ __launch_bounds__(kNdtDerivThreads) void ndt_derivatives(NdtDev d, Nd
         ph[r] = kDouble ? (R)(P.h_angd[r][0] * (double)s.x + P.h_angd[r][1] * (double)s.y + P.h_angd[r][2] * (double)s.z)
                         : (R)(P.h_ang[r][0] * s.x + P.h_ang[r][1] * s.y + P.h_ang[r][2] * s.z);
     }
-    double score_pt = 0, g_pt[6] = {0, 0, 0, 0, 0, 0};
-    double h_pt[36];
-    if (P.compute_hessian) {
+    double pt_sums[ONE ? 1 : 43];
+    double* const pt = ONE ? acc : pt_sums;                 // [0] score, [1..6] gradient, [7..42] hessian of this point
+    if (!ONE) {
 #pragma unroll
-      for (int k = 0; k < 36; ++k) h_pt[k] = 0.0;
+      for (int k = 0; k < 43; ++k) pt_sums[ONE ? 0 : k] = 0.0;
     }
     for (int dz = -1; dz <= 1; ++dz) {
       const int z = c2 + dz;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(kNdtDerivThreads) void ndt_derivatives(NdtDev d, Nd
           e = gd2 * e;                                               // :501
           if (e > (R)1 || e < (R)0 || e != e) continue;              // :504-505
           e = (R)(P.d1d * (double)e);                                // :508
-          score_pt += (double)score_inc;
+          pt[0] += (double)score_inc;
           // columns of c_inv4 * point_gradient4: col 0..2 = columns of C; col 3..5 from the angular entries
           // J col3 = (0, pg0, pg1), col4 = (pg2, pg3, pg4), col5 = (pg5, pg6, pg7)
           R CJ[6][3];
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(kNdtDerivThreads) void ndt_derivatives(NdtDev d, Nd
 #pragma unroll
           for (int c = 0; c < 6; ++c) xCJ[c] = u0 * CJ[c][0] + u1 * CJ[c][1] + u2 * CJ[c][2];     // :511
 #pragma unroll
-          for (int c = 0; c < 6; ++c) g_pt[c] += (double)(e * xCJ[c]);                              // :513
+          for (int c = 0; c < 6; ++c) pt[1 + c] += (double)(e * xCJ[c]);                              // :513
           if (P.compute_hessian) {
             // J columns as 3-vectors
             R Jc[6][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, pg[0], pg[1]}, {pg[2], pg[3], pg[4]}, {pg[5], pg[6], pg[7]}};
@@ -373,27 +376,29 @@ __global__ __launch_bounds__(kNdtDerivThreads) void ndt_derivatives(NdtDev d, Nd
                 // point_gradient4.col(j) . (c_inv4 * point_gradient4.col(i))  -> (j, i) entry, :517, :529
                 const R jcj = Jc[c][0] * CJ[a][0] + Jc[c][1] * CJ[a][1] + Jc[c][2] * CJ[a][2];
                 const R hh = (a >= 3 && c >= 3) ? xH[a - 3][c - 3] : (R)0;
-                h_pt[6 * a + c] += (double)(e * (-gd2 * xCJ[a] * xCJ[c] + hh + jcj));               // :527-529
+                pt[7 + 6 * a + c] += (double)(e * (-gd2 * xCJ[a] * xCJ[c] + hh + jcj));               // :527-529
               }
           }
         }
       }
     }
-    acc[0] += score_pt;
+    if (!ONE) {
+      acc[0] += pt[0];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) acc[1 + c] += g_pt[c];
-    if (P.compute_hessian) {
+      for (int c = 0; c < 6; ++c) acc[1 + c] += pt[1 + c];
+      if (P.compute_hessian) {
 #pragma unroll
-      for (int k = 0; k < 36; ++k) acc[7 + k] += h_pt[k];
+        for (int k = 0; k < 36; ++k) acc[7 + k] += pt[7 + k];
+      }
     }
   }
   // block reduction -> partials
   __shared__ double s_red[kNdtDerivThreads / 64][kNdtDerivCols];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < 43; ++k) acc[k] = wave_sum(acc[k]);
-  pairs = wave_sum(pairs);
-  if (lane == 0) {
+  for (int k = 0; k < 43; ++k) acc[k] = wave_sum_to_last(acc[k]);      // DPP row operations, total in lane 63
+  pairs = wave_sum_to_last(pairs);
+  if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < 43; ++k) s_red[wave][k] = acc[k];
     s_red[wave][43] = pairs;

@@ -238,6 +238,7 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
       // few queries in the whole launch: several lanes per query keep the SIMDs busy
       Bracket br(h, 4, st, np);
       hipLaunchKernelGGL(nn_ring_coop, dim3(ceil_div(ns_max, kNnThreads / kCoopLanes), np), dim3(kNnThreads), 0, st, d);
+      hipLaunchKernelGGL(nn_ring_wide, dim3(kWideBlocks, np), dim3(kNnThreads), 0, st, d);
     } else {
       Bracket br(h, 4, st, np);
       hipLaunchKernelGGL(nn_ring<false>, g, dim3(kNnThreads), 0, st, d);

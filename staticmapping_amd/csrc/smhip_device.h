@@ -26,6 +26,7 @@ constexpr int kFallbackSlices = 64;
 constexpr int kLdsTableCap = 1024;        // u32 entries of the per-workgroup row table in nn_ball_lds (4 KiB)
 constexpr int kLdsPointCap = 512;         // target points staged per round (8 KiB)
 constexpr int kLdsRowCap = 256;           // grid rows of the box whose runs are staged (<= workgroup size)
+constexpr int kWideBlocks = 512;            // workgroups (4 waves = 4 queries at a time) per pair of nn_ring_wide
 constexpr int kListedBlocks = 32;           // workgroups per pair of the listed search (nn_ball_listed): it strides over the list
 constexpr int kBallItems = 4;            // queries per thread in nn_ball (1024 per block: fewer histogram flushes)      // target slices the fallback sweep is spread over         // target points staged in LDS per tile (16 KiB as float4)
 

@@ -206,8 +206,14 @@ smhip_status ndt_derivs(smhip_context* h, const double* p, const float* T, bool 
   P.res2 = n.opts.resolution * n.opts.resolution;
   P.compute_hessian = hess ? 1 : 0;
   const int blocks = std::min(kNdtMaxDerivBlocks, std::max(1, ceil_div(n.dev.ns, kNdtDerivThreads)));
-  if (n.double_math) hipLaunchKernelGGL(ndt_derivatives<double>, dim3(blocks), dim3(kNdtDerivThreads), 0, h->stream, n.dev, P);
-  else hipLaunchKernelGGL(ndt_derivatives<float>, dim3(blocks), dim3(kNdtDerivThreads), 0, h->stream, n.dev, P);
+  const bool one = (long long)blocks * kNdtDerivThreads >= n.dev.ns;     // a thread per source point
+  if (n.double_math) {
+    if (one) hipLaunchKernelGGL((ndt_derivatives<double, true>), dim3(blocks), dim3(kNdtDerivThreads), 0, h->stream, n.dev, P);
+    else hipLaunchKernelGGL((ndt_derivatives<double, false>), dim3(blocks), dim3(kNdtDerivThreads), 0, h->stream, n.dev, P);
+  } else {
+    if (one) hipLaunchKernelGGL((ndt_derivatives<float, true>), dim3(blocks), dim3(kNdtDerivThreads), 0, h->stream, n.dev, P);
+    else hipLaunchKernelGGL((ndt_derivatives<float, false>), dim3(blocks), dim3(kNdtDerivThreads), 0, h->stream, n.dev, P);
+  }
   hipLaunchKernelGGL(ndt_reduce, dim3(1), dim3(16 * 64), 0, h->stream, n.dev, blocks);
   HIPCHK(h, hipMemcpyAsync(n.out_pinned, n.dev.out, sizeof(double) * kNdtDerivCols, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -64,14 +64,20 @@ __global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pa
     uint32_t sa, sb;
     row_slots(words, rowbase, xa, xb, sa, sb);
     const uint32_t pa = cstart[sa], pb = cstart[sb];
-    for (uint32_t p = pa; p < pb; ++p) {
-      const float d = dist2(tq[p], q.x, q.y, q.z);
-      if (!(d < worst)) continue;
+    auto consider = [&](const float4 c, uint32_t p) {
+      const float d = dist2(c, q.x, q.y, q.z);
+      if (!(d < worst)) return;
       int m = k - 1;                           // insertion into the ascending list
       while (m > 0 && s_d[m - 1][t] > d) { s_d[m][t] = s_d[m - 1][t]; s_j[m][t] = s_j[m - 1][t]; --m; }
       s_d[m][t] = d; s_j[m][t] = (int)p;
       worst = s_d[k - 1][t];
+    };
+    uint32_t p = pa;
+    for (; p + 4 <= pb; p += 4) {              // four candidate loads in flight (in order: ties keep the earlier position)
+      const float4 c0 = tq[p], c1 = tq[p + 1], c2 = tq[p + 2], c3 = tq[p + 3];
+      consider(c0, p); consider(c1, p + 1); consider(c2, p + 2); consider(c3, p + 3);
     }
+    for (; p < pb; ++p) consider(tq[p], p);
   };
   // blocks of half-width 0, 1, 2, 4, ... cells around the query's cell; a larger block only visits what the previous one
   // did not (whole rows outside it, the two x extensions of the rows inside it), so sparse regions cost O(log) steps

@@ -1075,6 +1075,13 @@ __device__ __forceinline__ void search_row(const uint2* __restrict__ words, cons
   }
 }
 
+// The caller only uses matches closer than sqrt(nn_cutoff2) (GICP's correspondence distance): once the searched block
+// guarantees that everything outside it is farther than that and nothing inside it is closer either, the query is done
+// -- whatever its true nearest neighbour is, it is beyond the cutoff (the reported d2 is >= the cutoff too).
+__device__ __forceinline__ bool ring_irrelevant(const IcpDev& b, float g, float best_d2) {
+  return b.nn_cutoff2 > 0.f && g * g >= b.nn_cutoff2 && best_d2 >= b.nn_cutoff2;
+}
+
 // Phase B -- exact per-query ring search.  HARD = true: refinement of the lower-bounded queries of
 // nn_ball, run only when nn_validate found that the quantile may reach one of the bounds (or when
 // every match must be exact); HARD = false: over every source point (nn_ball skipped).
@@ -1133,7 +1140,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring(IcpDev b) {
             }
         }
         const float g = block_guarantee(st, qx, qy, qz, cx - r, cx + r, cy - r, cy + r, cz - r, cz + r);
-        if (g == INFINITY || (g > 0.f && best.d2 <= g * g)) { resolved = true; break; }
+        if (g == INFINITY || (g > 0.f && (best.d2 <= g * g || ring_irrelevant(b, g, best.d2)))) { resolved = true; break; }
         rp = r;
       }
     }
@@ -1318,7 +1325,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring_wide(IcpDev b) {
         if (od < best.d2 || (od == best.d2 && oj >= 0 && (best.j < 0 || oj < best.j))) { best.d2 = od; best.j = oj; }
       }
       const float g = block_guarantee(st, qx, qy, qz, cx - r, cx + r, cy - r, cy + r, cz - r, cz + r);
-      if (g == INFINITY || (g > 0.f && best.d2 <= g * g)) { resolved = true; break; }
+      if (g == INFINITY || (g > 0.f && (best.d2 <= g * g || ring_irrelevant(b, g, best.d2)))) { resolved = true; break; }
       rp = r;
     }
     if (lane == 0) {

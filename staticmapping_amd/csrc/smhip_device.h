@@ -126,6 +126,7 @@ struct IcpDev {
   int32_t max_iteration;
   int32_t early_exit;
   int32_t max_ring;
+  float nn_cutoff2;          // > 0: the ring searches may stop once every unseen point is provably farther than this (squared)
   int32_t sort_cells;        // 1 = order points inside a cell by caller index (deterministic tie rule)
   int32_t use_ball;          // 1 = ball-bounded search with certified trimming; 0 = ring search over every query
   int32_t lds_table;         // 1 = nn_ball_lds (row tables staged in LDS), 0 = nn_ball (global lookups)

@@ -302,10 +302,12 @@ smhip_status gicp_prepare_slots(smhip_context* h, int np, const double* T_colmaj
   return s;
 }
 
-smhip_status gicp_find_closests(smhip_context* h, int ns_max) {
+smhip_status gicp_find_closests(smhip_context* h, int ns_max, float cutoff2) {
   const int sort_was = h->dev.sort_cells, ball_was = h->dev.use_ball;
   h->dev.sort_cells = 0; h->dev.use_ball = 0;
+  h->dev.nn_cutoff2 = cutoff2;          // correspondences beyond the distance threshold are dropped anyway (gicp_corr)
   const smhip_status s = enqueue_find_closests(h, 1, ns_max);
+  h->dev.nn_cutoff2 = 0.f;
   h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was;
   HIPCHK(h, hipMemsetAsync(h->dev.hist, 0, sizeof(uint32_t) * kHistBins, h->stream));
   h->ev_used = 0;
@@ -357,7 +359,7 @@ smhip_status gicp_align_slot0(smhip_context* h, const float* guess, float* final
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R9[3 * i + j] = TR[4 * i + j];
     s = gicp_prepare_slots(h, 1, TRcm, &ns_max, &nt_max);
     if (s) return s;
-    s = gicp_find_closests(h, ns_max);
+    s = gicp_find_closests(h, ns_max, thr2);
     if (s) return s;
     HIPCHK(h, hipMemcpyAsync(G.rot_dev, R9, sizeof(R9), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(G.dev.count, 0, sizeof(uint32_t), h->stream));

@@ -172,7 +172,7 @@ __global__ void grid_setup(IcpDev b, int npairs) {
   st->trans[0][0] = st->trans[0][1] = st->trans[0][2] = 0;
   st->n_hist = 1;
   st->iter = 0; st->done = 0; st->status = 0;
-  st->unresolved_count = 0; st->blist_count = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
+  st->unresolved_count = 0; st->fallback_ticket = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
   st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0; st->searched_total = 0;
   st->rcap2 = b.ball_radius * b.ball_radius;
   st->kept = 0; st->limit_key = 0; st->score = 0; st->nocc = 0;
@@ -1403,13 +1403,14 @@ __global__ __launch_bounds__(kNnThreads) void nn_brute(IcpDev b) {
 // The work (U queries x nt targets) is spread over the whole chip: block (slice, pair) stages one
 // slice of the target in LDS and sweeps ALL unresolved queries of the pair over it; the per-query
 // winner is merged with a 64-bit atomicMin on (d2 bits << 32 | sorted position).
-__global__ __launch_bounds__(kNnThreads) void nn_fallback_scan(IcpDev b) {
+__global__ __launch_bounds__(kNnThreads) void nn_fallback(IcpDev b) {
   const int pair = b.pair_base + blockIdx.y;
   PairState* st = &b.state[pair];
   if (st->done) return;
   const int U = (int)st->unresolved_count;
-  if (U == 0) return;
+  if (U == 0) return;                                     // the usual case: nothing reaches the fallback
   __shared__ float4 s_t[kBruteTile];
+  __shared__ uint32_t s_last;
   const int nt = st->nt;
   const int per = (nt + gridDim.x - 1) / gridDim.x;
   const int lo = blockIdx.x * per, hi = min(nt, lo + per);
@@ -1432,23 +1433,27 @@ __global__ __launch_bounds__(kNnThreads) void nn_fallback_scan(IcpDev b) {
       atomicMin(&b.ukeys[so + e], key);
     }
   }
-}
-
-__global__ __launch_bounds__(kNnThreads) void nn_fallback_resolve(IcpDev b) {
-  const int pair = b.pair_base + blockIdx.y;
-  PairState* st = &b.state[pair];
-  if (st->done) return;
-  const int U = (int)st->unresolved_count;
-  const size_t so = (size_t)pair * b.ns_cap;
-  for (int e = blockIdx.x * kNnThreads + threadIdx.x; e < U; e += gridDim.x * kNnThreads) {
+  // The slice that finishes last writes the results back (this used to be a second launch that was empty in nearly every
+  // iteration).  Only this rare path pays for the agent-scope fences; the ticket orders the slices' atomicMin's before it.
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t active = (uint32_t)((nt + per - 1) / per);
+    s_last = atomicAdd(&st->fallback_ticket, 1u) == active - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  for (int e = threadIdx.x; e < U; e += kNnThreads) {
     const int i = b.ulist[so + e];
-    const unsigned long long key = b.ukeys[so + e];
+    const unsigned long long key = __hip_atomic_load(&b.ukeys[so + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t dbits = (uint32_t)(key >> 32);
     b.d2[so + i] = __uint_as_float(dbits);
     b.idx[so + i] = (int)(uint32_t)(key & 0xffffffffu);
     b.lb[so + i] = 0.f;
     if (dbits < 0x7f800000u) atomicAdd(&b.hist[(size_t)pair * kHistBins + (dbits >> kHistShift)], 1u);
   }
+  if (threadIdx.x == 0) st->fallback_ticket = 0;
 }
 
 
@@ -1941,7 +1946,6 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
     if (!(n_valid > 0)) rc = b.ball_radius;
     st->rcap2 = rc * rc;
   }
-  st->blist_count = 0;
   st->limit_key = limit_key;
   const double kept = s_tot[28];
   st->kept = (int)kept;

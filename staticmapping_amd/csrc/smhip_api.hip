@@ -243,8 +243,7 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
       Bracket br(h, 4, st, np);
       hipLaunchKernelGGL(nn_ring<false>, g, dim3(kNnThreads), 0, st, d);
     }
-    { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_fallback_scan, dim3(kFallbackSlices, np), dim3(kNnThreads), 0, st, d); }
-    { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_fallback_resolve, dim3(32, np), dim3(kNnThreads), 0, st, d); }
+    { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_fallback, dim3(kFallbackSlices, np), dim3(kNnThreads), 0, st, d); }
   } else {
     Bracket br(h, 4, st, np);
     hipLaunchKernelGGL(nn_brute, g, dim3(kNnThreads), 0, st, d);

@@ -58,7 +58,7 @@ struct PairState {
   int32_t nocc;
   // selection / lists
   uint32_t unresolved_count;
-  uint32_t blist_count;
+  uint32_t fallback_ticket;  // slices of nn_fallback that have finished (the last one writes the results back)
   uint32_t fallback_total;
   uint32_t searched_total;   // queries that went through a search, summed over iterations
   uint32_t deferred_count;   // queries whose certificate failed (nn_certify), searched by nn_ball_listed

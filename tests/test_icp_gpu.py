@@ -192,6 +192,29 @@ def test_long_boundary_list_path(smhip, cfg2):
     m.close()
 
 
+@pytest.mark.parametrize("copies", [5, 11])
+def test_large_source_clouds(smhip, cfg2, copies):
+    """Source clouds beyond one accumulate-segment per finalize thread (600 k points: 1 176 segments, several per thread) and
+    beyond 2 048 short segments (1.3 M points: the single pair switches to the long accumulate chunks) against the oracle."""
+    from oracle import cref
+    rng = np.random.default_rng(7)
+    base = cfg2["src"][:, :3].astype(np.float64)
+    src = np.concatenate([base + rng.normal(0, 0.01, base.shape) for _ in range(copies)]).astype(np.float32)
+    m = smhip.IcpFastHip(max_source_points=len(src), max_target_points=len(cfg2["q"]), max_iteration=3, early_exit=0)
+    m.set_input_source(src)
+    m.set_input_target(cfg2["q"], cfg2["n"])
+    ok, R = m.align(cfg2["guess"])
+    st = m.last_stats[0]
+    ids, d2 = m.get_matches(len(src))
+    m.close()
+    ref = cref.icp_fast_align(src.astype(np.float64), cfg2["q"], cfg2["n"], guess=cfg2["guess"], max_iteration=3, early_exit=False)
+    da, dt = smhip.se3_error(R, ref["result"])
+    assert ok and da < ROT_TOL and dt < TRANS_TOL, (da, dt)
+    k = int(len(d2) * float(np.float32(0.7)))
+    limit = np.partition(d2, k)[k]
+    assert np.float32(st["limit_d2"]) == limit and st["kept"] == int((d2 <= limit).sum())
+
+
 def test_far_source_uses_fallback_and_stays_exact(smhip, velo20k):
     """Queries far outside the target's grid go through the brute-force fallback; ids stay exact."""
     c = velo20k
@@ -255,6 +278,9 @@ def test_error_conventions(smhip, cfg1):
     with pytest.raises(smhip.SmhipError):
         m.set_options(dist_outlier_ratio=1.5)
     m.close()
+    with pytest.raises(smhip.SmhipError) as e:      # beyond the 4 Mi source points a handle can index (include/smhip.h)
+        smhip.IcpFastHip(max_source_points=(1 << 22) + 1, max_target_points=1000)
+    assert e.value.status == 1
 
 
 def test_batch_slots_equal_single_runs(smhip, velo20k, cfg1):

@@ -21,6 +21,6 @@ rm -rf "$out/trace" "$out/pmc_fetch" "$out/pmc_write"
 cat "$out/bench_line.json"; cat "$out/timed_region_trace_average.txt"; cat "$out/pmc_fetch_summary.txt" "$out/pmc_write_summary.txt"; head -8 "$out/bench_kernel_stats.csv"
 # per-iteration durations of one 64-pair batch on ONE stream (no overlap) for reading the iteration profile
 rocprofv3 --kernel-trace --output-format csv -d "$out/seq" -- python tools/profile_target.py B=64 reps=1 noov=1 > "$out/seq.log" 2>&1
-python tools/trace_iterations.py "$out/seq" nn_ball_lds nn_certify nn_ball_listed accumulate finalize nn_validate "nn_ring" nn_fallback_scan > "$out/iteration_profile.txt"
+python tools/trace_iterations.py "$out/seq" nn_ball_lds nn_certify nn_ball_listed accumulate finalize nn_validate "nn_ring" nn_fallback > "$out/iteration_profile.txt"
 rm -rf "$out/seq"
 cat "$out/iteration_profile.txt"

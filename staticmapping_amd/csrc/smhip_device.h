@@ -21,14 +21,14 @@ constexpr int kFinalizeMaxSeg = 2048;     // accumulate waves (= blist segments)
 constexpr int kAccCols = 32;             // 21 (A upper) + 6 (b) + 1 (sum sqrt d2) + 1 (count) padded to 32
 constexpr int kMaxGridWords = 1 << 18;   // 32-cell words per pair (8 Mi cells)
 constexpr int kTgtReduceBlocks = 32;     // partial blocks for the target mean / bbox
-constexpr int kBruteTile = 1024;
-constexpr int kFallbackSlices = 64;
+constexpr int kBruteTile = 1024;         // target points staged in LDS per tile of the brute-force kernels (16 KiB as float4)
+constexpr int kFallbackSlices = 64;      // target slices the fallback sweep is spread over
 constexpr int kLdsTableCap = 1024;        // u32 entries of the per-workgroup row table in nn_ball_lds (4 KiB)
 constexpr int kLdsPointCap = 512;         // target points staged per round (8 KiB)
 constexpr int kLdsRowCap = 256;           // grid rows of the box whose runs are staged (<= workgroup size)
-constexpr int kWideBlocks = 512;            // workgroups (4 waves = 4 queries at a time) per pair of nn_ring_wide
-constexpr int kListedBlocks = 32;           // workgroups per pair of the listed search (nn_ball_listed): it strides over the list
-constexpr int kBallItems = 4;            // queries per thread in nn_ball (1024 per block: fewer histogram flushes)      // target slices the fallback sweep is spread over         // target points staged in LDS per tile (16 KiB as float4)
+constexpr int kWideBlocks = 512;         // workgroups (4 waves = 4 queries at a time) per pair of nn_ring_wide
+constexpr int kListedBlocks = 32;        // workgroups per pair of the listed search (nn_ball_listed): it strides over the list
+constexpr int kBallItems = 4;            // rounds of 256 queries per workgroup in the NN kernels (fewer histogram flushes, prefetch across rounds)
 
 // Per-pair device state.  Everything an iteration needs and everything the host reads back.
 struct PairState {

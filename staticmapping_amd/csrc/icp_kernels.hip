@@ -33,12 +33,21 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
   return v;
 }
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    uint32_t t = __shfl_up(v, off, 64);
-    if (lane >= off) v += t;
-  }
+// `fill` where the DPP control has no source lane (or the row is masked off), else v of the source lane
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or(int fill, int v) {
+  return __builtin_amdgcn_update_dpp(fill, v, CTRL, ROW_MASK, 0xf, false);
+}
+// Inclusive scan over the wave with DPP row operations (register to register): a scan inside every row of 16 lanes
+// (row_shr 1, 2, 4, 8), then the row totals carried across (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and
+// 3).  The __shfl_up form went through ds_bpermute: 6 LDS round trips per scan.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int /*lane*/) {
+  v += (uint32_t)dpp_or<0x111, 0xf>(0, (int)v);
+  v += (uint32_t)dpp_or<0x112, 0xf>(0, (int)v);
+  v += (uint32_t)dpp_or<0x114, 0xf>(0, (int)v);
+  v += (uint32_t)dpp_or<0x118, 0xf>(0, (int)v);
+  v += (uint32_t)dpp_or<0x142, 0xa>(0, (int)v);
+  v += (uint32_t)dpp_or<0x143, 0xc>(0, (int)v);
   return v;
 }
 
@@ -308,16 +317,23 @@ __device__ __forceinline__ float dist2(const float4 t, float qx, float qy, float
   const float dx = qx - t.x, dy = qy - t.y, dz = qz - t.z;
   return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
 }
+// Squared distances are sums of squares of finite numbers: never negative, never NaN (at worst +inf), so they order like
+// their bit patterns.  The integer forms below give the same results as fminf / fmaxf / "<" without the IEEE
+// canonicalisation (v_max_f32 x, x) the compiler puts before every float min/max: 2-3 of ~16 vector instructions per
+// candidate in the inner loops of a search that is bound by vector issue.
+__device__ __forceinline__ bool lt_d2(float a, float b) { return __float_as_uint(a) < __float_as_uint(b); }
+__device__ __forceinline__ float min_d2(float a, float b) { return __uint_as_float(min(__float_as_uint(a), __float_as_uint(b))); }
+__device__ __forceinline__ float max_d2(float a, float b) { return __uint_as_float(max(__float_as_uint(a), __float_as_uint(b))); }
 // candidates visited in ascending j: strict "<" keeps the smallest j among ties
 __device__ __forceinline__ void test_ascending(const float4 t, int j, float qx, float qy, float qz, Best& best) {
   const float d = dist2(t, qx, qy, qz);
-  if (d < best.d2) { best.d2 = d; best.j = j; }
+  if (lt_d2(d, best.d2)) { best.d2 = d; best.j = j; }
 }
 // same, also tracking the runner-up distance (what the next iteration's certificate needs)
 __device__ __forceinline__ void test_ascending_ru(const float4 t, int j, float qx, float qy, float qz, Best& best) {
   const float d = dist2(t, qx, qy, qz);
-  best.s2 = fminf(best.s2, fmaxf(d, best.d2));     // d < best: old best becomes runner-up; else d competes for runner-up
-  if (d < best.d2) { best.d2 = d; best.j = j; }
+  best.s2 = min_d2(best.s2, max_d2(d, best.d2));   // d < best: old best becomes runner-up; else d competes for runner-up
+  if (lt_d2(d, best.d2)) { best.d2 = d; best.j = j; }
 }
 // two candidates per step with packed fp32 (v_pk_add/mul/fma_f32): 6 instead of 9 VALU per candidate
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -345,15 +361,27 @@ __device__ __forceinline__ void transform_point(const double* M, const float4 s,
   pz = fma(M[8], x, fma(M[9], y, fma(M[10], z, M[11])));
 }
 
+// wave-wide min / max of an int, uniform result: the same DPP pattern as wave_incl_scan with min / max in place of +, the
+// total read from lane 63
 __device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-  return v;
+  constexpr int kId = 0x7fffffff;
+  v = min(v, dpp_or<0x111, 0xf>(kId, v));
+  v = min(v, dpp_or<0x112, 0xf>(kId, v));
+  v = min(v, dpp_or<0x114, 0xf>(kId, v));
+  v = min(v, dpp_or<0x118, 0xf>(kId, v));
+  v = min(v, dpp_or<0x142, 0xa>(kId, v));
+  v = min(v, dpp_or<0x143, 0xc>(kId, v));
+  return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-  return v;
+  constexpr int kId = -0x7fffffff - 1;
+  v = max(v, dpp_or<0x111, 0xf>(kId, v));
+  v = max(v, dpp_or<0x112, 0xf>(kId, v));
+  v = max(v, dpp_or<0x114, 0xf>(kId, v));
+  v = max(v, dpp_or<0x118, 0xf>(kId, v));
+  v = max(v, dpp_or<0x142, 0xa>(kId, v));
+  v = max(v, dpp_or<0x143, 0xc>(kId, v));
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 // occupied-cell slots [s_begin, s_end) of the cells x in [xa, xb] of one grid row
@@ -992,7 +1020,13 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
               const int rb = r * nxl - X0;
               const uint32_t g0 = s_tab[rb + X0];
               const uint32_t k0 = s_roff[r] + (s_tab[rb + x0] - g0), k1 = s_roff[r] + (s_tab[rb + x1 + 1] - g0);
-              for (uint32_t k = k0; k < k1; ++k) {
+              uint32_t k = k0;
+              for (; k + 2 <= k1; k += 2) {                         // two LDS reads in flight, half the loop overhead
+                const float4 t0 = s_pts[k], t1 = s_pts[k + 1];
+                test_ascending_ru(t0, __float_as_int(t0.w), qx, qy, qz, best);
+                test_ascending_ru(t1, __float_as_int(t1.w), qx, qy, qz, best);
+              }
+              if (k < k1) {
                 const float4 t = s_pts[k];
                 test_ascending_ru(t, __float_as_int(t.w), qx, qy, qz, best);
               }

@@ -317,23 +317,18 @@ __device__ __forceinline__ float dist2(const float4 t, float qx, float qy, float
   const float dx = qx - t.x, dy = qy - t.y, dz = qz - t.z;
   return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
 }
-// Squared distances are sums of squares of finite numbers: never negative, never NaN (at worst +inf), so they order like
-// their bit patterns.  The integer forms below give the same results as fminf / fmaxf / "<" without the IEEE
-// canonicalisation (v_max_f32 x, x) the compiler puts before every float min/max: 2-3 of ~16 vector instructions per
-// candidate in the inner loops of a search that is bound by vector issue.
-__device__ __forceinline__ bool lt_d2(float a, float b) { return __float_as_uint(a) < __float_as_uint(b); }
-__device__ __forceinline__ float min_d2(float a, float b) { return __uint_as_float(min(__float_as_uint(a), __float_as_uint(b))); }
-__device__ __forceinline__ float max_d2(float a, float b) { return __uint_as_float(max(__float_as_uint(a), __float_as_uint(b))); }
 // candidates visited in ascending j: strict "<" keeps the smallest j among ties
 __device__ __forceinline__ void test_ascending(const float4 t, int j, float qx, float qy, float qz, Best& best) {
   const float d = dist2(t, qx, qy, qz);
-  if (lt_d2(d, best.d2)) { best.d2 = d; best.j = j; }
+  if (d < best.d2) { best.d2 = d; best.j = j; }
 }
-// same, also tracking the runner-up distance (what the next iteration's certificate needs)
+// same, also tracking the runner-up distance (what the next iteration's certificate needs).  (Ordering the distances as
+// unsigned integers -- they are never negative or NaN -- drops the v_max_f32 x, x canonicalisation the compiler puts before
+// every float min / max, but cost nn_ball_lds 36 more bytes of scratch per lane at its 80-VGPR budget and 6 % of its speed.)
 __device__ __forceinline__ void test_ascending_ru(const float4 t, int j, float qx, float qy, float qz, Best& best) {
   const float d = dist2(t, qx, qy, qz);
-  best.s2 = min_d2(best.s2, max_d2(d, best.d2));   // d < best: old best becomes runner-up; else d competes for runner-up
-  if (lt_d2(d, best.d2)) { best.d2 = d; best.j = j; }
+  best.s2 = fminf(best.s2, fmaxf(d, best.d2));     // d < best: old best becomes runner-up; else d competes for runner-up
+  if (d < best.d2) { best.d2 = d; best.j = j; }
 }
 // two candidates per step with packed fp32 (v_pk_add/mul/fma_f32): 6 instead of 9 VALU per candidate
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -1020,13 +1015,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
               const int rb = r * nxl - X0;
               const uint32_t g0 = s_tab[rb + X0];
               const uint32_t k0 = s_roff[r] + (s_tab[rb + x0] - g0), k1 = s_roff[r] + (s_tab[rb + x1 + 1] - g0);
-              uint32_t k = k0;
-              for (; k + 2 <= k1; k += 2) {                         // two LDS reads in flight, half the loop overhead
-                const float4 t0 = s_pts[k], t1 = s_pts[k + 1];
-                test_ascending_ru(t0, __float_as_int(t0.w), qx, qy, qz, best);
-                test_ascending_ru(t1, __float_as_int(t1.w), qx, qy, qz, best);
-              }
-              if (k < k1) {
+              for (uint32_t k = k0; k < k1; ++k) {
                 const float4 t = s_pts[k];
                 test_ascending_ru(t, __float_as_int(t.w), qx, qy, qz, best);
               }

@@ -538,7 +538,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
     if (hm) {
       uint32_t basepos = 0;
       if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
-      basepos = __shfl(basepos, 0, 64);
+      basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);   // lane 0 did the atomic
       if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
     }
   }
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball_listed(IcpDev b, int nblk)
     if (hm) {
       uint32_t basepos = 0;
       if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
-      basepos = __shfl(basepos, 0, 64);
+      basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);   // lane 0 did the atomic
       if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
     }
   }
@@ -736,14 +736,14 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
     if (dm) {
       uint32_t basepos = 0;
       if (lane == 0) basepos = atomicAdd(&st->deferred_count, (uint32_t)__popcll(dm));
-      basepos = __shfl(basepos, 0, 64);
+      basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);   // lane 0 did the atomic
       if (fail) b.dlist[so + basepos + __popcll(dm & ((1ull << lane) - 1ull))] = i;
     }
     const unsigned long long hm = __ballot(hard);
     if (hm) {
       uint32_t basepos = 0;
       if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
-      basepos = __shfl(basepos, 0, 64);
+      basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);   // lane 0 did the atomic
       if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
     }
   }
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
       if (sm) {
         uint32_t basepos = 0;
         if (lane == 0) basepos = atomicAdd(nsearch, (uint32_t)__popcll(sm));
-        basepos = __shfl(basepos, 0, 64);
+        basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);   // lane 0 did the atomic
         if (need_search) {
           const uint32_t pos = basepos + __popcll(sm & ((1ull << lane) - 1ull));
           s_q[pos] = make_float4(qx, qy, qz, __int_as_float(jp_cur));
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
       if (hm) {
         uint32_t basepos = 0;
         if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
-        basepos = __shfl(basepos, 0, 64);
+        basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);   // lane 0 did the atomic
         if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
       }
     }
@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
       if (hm) {
         uint32_t basepos = 0;
         if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
-        basepos = __shfl(basepos, 0, 64);
+        basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);   // lane 0 did the atomic
         if (hard2) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = gi;
       }
     }

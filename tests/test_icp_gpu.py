@@ -304,6 +304,34 @@ def test_batch_slots_equal_single_runs(smhip, velo20k, cfg1):
         m1.close()
 
 
+def test_large_batch_matches_single(smhip, cfg2):
+    """128 full-size pairs in one call (two 64-pair halves on two streams, long accumulate chunks, the two-launch converged
+    path with the many-lanes listed search) against the same pairs aligned one at a time (short chunks, fused kernel)."""
+    c = cfg2
+    from staticmapping_amd import synth
+    guesses = [c["guess"], c["guess"] @ synth.make_pose(t=(0.05, -0.03, 0.0), rpy_deg=(0, 0, 0.3))]
+    single = []
+    m1 = smhip.IcpFastHip(max_source_points=len(c["src"]), max_target_points=len(c["q"]), max_iteration=20, early_exit=0)
+    m1.set_input_source(c["src"]); m1.set_input_target(c["q"], c["n"])
+    for g in guesses:
+        ok, R = m1.align(g)
+        single.append((R, m1.last_stats[0]))
+    m1.close()
+    B = 128
+    m = smhip.IcpFastHip(pair_slots=B, max_source_points=len(c["src"]), max_target_points=len(c["q"]), max_iteration=20, early_exit=0)
+    m.set_input_source(c["src"]); m.set_input_target(c["q"], c["n"])
+    for s in range(1, B):
+        m.copy_slot(0, s)
+    R, sc, st = m.align_batch(B, [guesses[s % 2] for s in range(B)])
+    m.close()
+    for s in range(B):
+        Rs, ss = single[s % 2]
+        da, dt = smhip.se3_error(R[s], Rs)
+        assert da < 1e-9 and dt < 1e-8, (s, da, dt)
+        assert st[s]["kept"] == ss["kept"] and st[s]["limit_d2"] == ss["limit_d2"] and st[s]["iterations"] == 20
+    assert R[0].tobytes() == R[2].tobytes() == R[126].tobytes() and R[1].tobytes() == R[127].tobytes()
+
+
 def test_rigid_motion_equivariance_full_size(smhip, cfg2):
     """Size-independent property at full size: moving the target frame by W moves the result by W
     (Align(W q, W n; W guess) = W Align(q, n; guess))."""

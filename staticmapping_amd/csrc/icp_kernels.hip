@@ -207,17 +207,32 @@ __global__ __launch_bounds__(256) void grid_mark(IcpDev b) {
   b.tcell[(size_t)pair * b.nt_cap + j] = (w << 5) | bit;
 }
 
-// One 1024-thread block per pair: words[w] = {bits, exclusive popcount rank}; nocc.
-// Tiles of 4096 words, 16-byte coalesced loads, running carry between tiles.
+// words[w] = {bits, exclusive popcount rank}; nocc.  Tiles of 4096 words, 16-byte coalesced loads, running carry between
+// tiles.  grid = (segments, pairs): a batch gives every pair one 1024-thread workgroup; a launch with few pairs (one scan
+// pair, the 500 k-point NDT / GICP targets) cuts the pair's words into segments, and a segment's workgroup first
+// popcounts the words before its own (reads only, no scan) to get its starting rank -- 66 -> 14 us for one pair.
 __global__ __launch_bounds__(1024) void grid_rank(IcpDev b) {
-  const int pair = b.pair_base + blockIdx.x;
+  const int pair = b.pair_base + blockIdx.y;
   PairState* st = &b.state[pair];
   const int nw = st->nw;
   const uint32_t* bits = b.bits + (size_t)pair * kMaxGridWords;
   uint2* words = b.words + (size_t)pair * kMaxGridWords;
   __shared__ uint32_t s_w[17];
+  const int tiles = (nw + 4095) / 4096;
+  const int tiles_per_seg = (tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int lo = (int)blockIdx.x * tiles_per_seg * 4096;
+  const int hi = min(nw, lo + tiles_per_seg * 4096);
+  if (lo >= nw) return;
   uint32_t carry = 0;
-  for (int t0 = 0; t0 < nw; t0 += 4096) {
+  if (lo > 0) {                                            // rank at the start of this segment (lo is a multiple of 4096)
+    uint32_t mine = 0;
+    for (int w = (int)threadIdx.x * 4; w < lo; w += 4096) {
+      const uint4 v = *reinterpret_cast<const uint4*>(bits + w);
+      mine += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+    (void)block_excl_scan(mine, s_w, &carry);
+  }
+  for (int t0 = lo; t0 < hi; t0 += 4096) {
     const int w = t0 + (int)threadIdx.x * 4;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (w + 3 < nw) v = *reinterpret_cast<const uint4*>(bits + w);      // kMaxGridWords keeps this 16-B aligned
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(1024) void grid_rank(IcpDev b) {
     if (w + 3 < nw) words[w + 3] = make_uint2(v.w, run);
     carry += total;
   }
-  if (threadIdx.x == 0) st->nocc = (int)carry;
+  if (hi >= nw && threadIdx.x == 0) st->nocc = (int)carry;   // the segment that holds the last word
 }
 
 __global__ __launch_bounds__(256) void grid_count(IcpDev b) {

@@ -162,7 +162,7 @@ smhip_status enqueue_grid_build(smhip_context* h, const Half& f, int nt_max) {
   hipLaunchKernelGGL(tgt_reduce, dim3(kTgtReduceBlocks, np), dim3(256), 0, f.stream, d);
   hipLaunchKernelGGL(grid_setup, dim3(ceil_div(np, 64)), dim3(64), 0, f.stream, d, np);
   hipLaunchKernelGGL(grid_mark, gpts, dim3(256), 0, f.stream, d);
-  hipLaunchKernelGGL(grid_rank, dim3(np), dim3(1024), 0, f.stream, d);
+  hipLaunchKernelGGL(grid_rank, dim3(std::max(1, std::min(16, 64 / np)), np), dim3(1024), 0, f.stream, d);   // segments per pair when pairs are few
   hipLaunchKernelGGL(grid_count, gpts, dim3(256), 0, f.stream, d);
   hipLaunchKernelGGL(grid_cscan, dim3(np), dim3(1024), 0, f.stream, d);
   hipLaunchKernelGGL(grid_scatter, gpts, dim3(256), 0, f.stream, d);

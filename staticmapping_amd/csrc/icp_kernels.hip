@@ -135,6 +135,16 @@ __device__ __forceinline__ void mat4_mul_rm(const double* a, const double* c, do
 }
 
 // One thread per pair: mean, grid geometry, G = T(-mu) * guess, loop state reset.
+// Per-Align scratch of the first npairs slots zeroed in one launch (four memsets cost a single pair ~30 us of launch gaps).
+__global__ __launch_bounds__(256) void reset_scratch(IcpDev b, int npairs) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  uint4* bits4 = reinterpret_cast<uint4*>(b.bits);                       // hipMalloc alignment; kMaxGridWords % 4 == 0
+  for (size_t k = tid; k < (size_t)kMaxGridWords / 4 * npairs; k += nth) bits4[k] = make_uint4(0, 0, 0, 0);
+  for (size_t k = tid; k < (size_t)(b.nt_cap + 1) * npairs; k += nth) b.ccount[k] = 0;
+  for (size_t k = tid; k < (size_t)kHistBins * npairs; k += nth) b.hist[k] = 0;
+  if (tid == 0) *b.done_count = 0;
+}
+
 __global__ void grid_setup(IcpDev b, int npairs) {
   const int pair = b.pair_base + blockIdx.x * blockDim.x + threadIdx.x;
   if (pair >= b.pair_base + npairs) return;

@@ -146,10 +146,7 @@ struct Half {
 smhip_status enqueue_resets(smhip_context* h, int np) {
   IcpDev& d = h->dev;
   HIPCHK(h, hipMemcpyAsync(const_cast<PairInput*>(d.in), h->in_pinned, sizeof(PairInput) * np, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemsetAsync(d.bits, 0, sizeof(uint32_t) * (size_t)kMaxGridWords * np, h->stream));
-  HIPCHK(h, hipMemsetAsync(d.ccount, 0, sizeof(uint32_t) * (size_t)(d.nt_cap + 1) * np, h->stream));
-  HIPCHK(h, hipMemsetAsync(d.hist, 0, sizeof(uint32_t) * (size_t)kHistBins * np, h->stream));
-  HIPCHK(h, hipMemsetAsync(d.done_count, 0, sizeof(uint32_t), h->stream));
+  hipLaunchKernelGGL(reset_scratch, dim3(std::min(4096, 256 * np)), dim3(256), 0, h->stream, d, np);
   return SMHIP_OK;
 }
 

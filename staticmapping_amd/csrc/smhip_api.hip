@@ -221,7 +221,8 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
             const int nb1 = ceil_div(ns_max, kNnThreads);
             hipLaunchKernelGGL(nn_certify<1>, dim3(nb1 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nb1);
           } else {
-            hipLaunchKernelGGL(nn_certify<kBallItems>, gx, dim3(kNnThreads), 0, st, d, nblk);
+            const int nbc = ceil_div(ns_max, kNnThreads * kCertifyItems);
+            hipLaunchKernelGGL(nn_certify<kCertifyItems>, dim3(nbc * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nbc);
           }
         }
         { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_ball_listed, glist, dim3(kNnThreads), 0, st, d, kListedBlocks); }

@@ -28,7 +28,7 @@ constexpr int kLdsPointCap = 512;         // target points staged per round (8 K
 constexpr int kLdsRowCap = 256;           // grid rows of the box whose runs are staged (<= workgroup size)
 constexpr int kWideBlocks = 512;         // workgroups (4 waves = 4 queries at a time) per pair of nn_ring_wide
 constexpr int kListedBlocks = 32;        // workgroups per pair of the listed search (nn_ball_listed): it strides over the list
-constexpr int kBallItems = 4;            // rounds of 256 queries per workgroup in the NN kernels (fewer histogram flushes, prefetch across rounds)
+constexpr int kBallItems = 2;            // rounds of 256 queries per workgroup in nn_ball_lds / nn_ball (prefetch across rounds; 2 measured best: 4 = +8 %, 1 = +5 %)
 constexpr int kCertifyItems = 8;         // rounds per workgroup of the certificate pass (8: 85 -> 79 us per 64 pairs, 16: slower again)
 
 // Per-pair device state.  Everything an iteration needs and everything the host reads back.

@@ -6,7 +6,14 @@
  * Restates (paths relative to /root/reference):
  *   registrators/icp_fast.cc:65-90    Matches::GetDistsQuantile
  *   registrators/icp_fast.cc:100-166  ErrorElements (compaction + gather)
- *   registrators/icp_fast.cc:169-180  FindClosests (1-NN; EXACT here, eps=0)
+ *   registrators/icp_fast.cc:169-180  FindClosests: exact 1-NN (own kd-tree, smallest-id tie rule) or, with
+ *                                     nn_eps >= 0, libnabo's own search: the KDTREE_LINEAR_HEAP tree of
+ *                                     libnabo tags/1.0.7 (setup/install_libnabo.sh:16-18; not vendored by the
+ *                                     reference) restated from its published source nabo/kdtree_cpu.cpp --
+ *                                     buildNodes (bucketSize 8, argMax of the INHERITED box, nth_element at
+ *                                     count - count/2, cutVal = that element) and recurseKnn (incremental
+ *                                     off[]/rd bound, far side pruned unless rd * (1+eps)^2 < best).  With
+ *                                     nn_eps = 3.16 this is the reference's call at icp_fast.cc:174-178.
  *   registrators/icp_fast.cc:204-324  point-to-plane normal equations + solve
  *   registrators/icp_fast.cc:377-405  CheckConvergence
  *   registrators/icp_fast.cc:455-529  IcpFast::Align
@@ -22,7 +29,9 @@
 #include <omp.h>
 #endif
 
-static double now_s(void) {
+#include "smref_internal.h"
+
+double now_s(void) {
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return ts.tv_sec + 1e-9 * ts.tv_nsec;
@@ -32,20 +41,8 @@ static double now_s(void) {
 /* exact kd-tree (replaces libnabo KDTREE_LINEAR_HEAP, icp_fast.cc:466) */
 /* ------------------------------------------------------------------ */
 #define KD_LEAF 8
-typedef struct {
-  int n;
-  const double* pts; /* [n][3] */
-  int* perm;         /* point order */
-  int* node_lo;      /* per node: first */
-  int* node_hi;      /* per node: last (exclusive) */
-  int* node_dim;     /* -1 = leaf */
-  double* node_cut;
-  int* node_left;
-  int* node_right;
-  int n_nodes, cap_nodes;
-} KdTree;
 
-static void kd_select(const double* pts, int* idx, int lo, int hi, int k, int dim) {
+void kd_select(const double* pts, int* idx, int lo, int hi, int k, int dim) {
   /* quickselect so that idx[k] holds the k-th smallest by coordinate dim */
   while (hi - lo > 1) {
     double pivot = pts[3 * idx[lo + (hi - lo) / 2] + dim];
@@ -85,7 +82,7 @@ static int kd_build_rec(KdTree* t, int lo, int hi) {
   return id;
 }
 
-static KdTree* kd_build(const double* pts, int n) {
+KdTree* kd_build(const double* pts, int n) {
   KdTree* t = (KdTree*)calloc(1, sizeof(KdTree));
   t->n = n; t->pts = pts;
   t->cap_nodes = 2 * (n / (KD_LEAF / 2) + 2) + 8;
@@ -101,12 +98,12 @@ static KdTree* kd_build(const double* pts, int n) {
   return t;
 }
 
-static void kd_free(KdTree* t) {
+void kd_free(KdTree* t) {
   free(t->perm); free(t->node_lo); free(t->node_hi); free(t->node_dim);
   free(t->node_left); free(t->node_right); free(t->node_cut); free(t);
 }
 
-static void kd_nn(const KdTree* t, const double q[3], int* best_id, double* best_d2) {
+void kd_nn(const KdTree* t, const double q[3], int* best_id, double* best_d2) {
   int stack_node[64]; double stack_d[64]; int sp = 0;
   double bd = INFINITY; int bi = -1;
   if (t->n == 0) { *best_id = -1; *best_d2 = INFINITY; return; }
@@ -132,6 +129,102 @@ static void kd_nn(const KdTree* t, const double q[3], int* best_id, double* best
   *best_id = bi; *best_d2 = bd;
 }
 
+
+/* ------------------------------------------------------------------ */
+/* libnabo 1.0.7 KDTreeUnbalancedPtInLeavesImplicitBoundsStackOpt       */
+/* (what NNS::create(..., NNS::KDTREE_LINEAR_HEAP) builds, icp_fast.cc:466, and what knn(..., epsilon, ...) */
+/*  walks, icp_fast.cc:177-178).  Restated from the library's published source; the library is absent here. */
+/* ------------------------------------------------------------------ */
+#define NABO_BUCKET 8            /* additionalParameters "bucketSize" default */
+typedef struct {
+  const double* pts;             /* [n][3] */
+  int* perm;                     /* build points, permuted by nth_element */
+  int* dim;                      /* per node: cut dimension, 3 = leaf */
+  double* cut;                   /* per node: cutVal */
+  int* child;                    /* internal: right child (left child = node + 1); leaf: first bucket entry */
+  int* count;                    /* leaf: bucket size */
+  int n_nodes, cap;
+} NaboTree;
+
+static int nabo_build_nodes(NaboTree* t, int first, int last, const double mn[3], const double mx[3]) {
+  const int cnt = last - first;
+  const int pos = t->n_nodes++;
+  if (cnt <= NABO_BUCKET) {                                   /* bucket: entries in build order */
+    t->dim[pos] = 3; t->child[pos] = first; t->count[pos] = cnt; t->cut[pos] = 0;
+    return pos;
+  }
+  int cd = 0; double mv = 0.0;                                /* argMax: starts from (0, 0.) */
+  for (int i = 0; i < 3; ++i) if (mx[i] - mn[i] > mv) { mv = mx[i] - mn[i]; cd = i; }
+  const int right = cnt / 2, left = cnt - right;
+  kd_select(t->pts, t->perm, first, last, first + left, cd);  /* std::nth_element(first, first + leftCount, last) */
+  const double cv = t->pts[3 * t->perm[first + left] + cd];
+  double lmx[3] = {mx[0], mx[1], mx[2]}, rmn[3] = {mn[0], mn[1], mn[2]};
+  lmx[cd] = cv; rmn[cd] = cv;
+  t->dim[pos] = cd; t->cut[pos] = cv;
+  nabo_build_nodes(t, first, first + left, mn, lmx);          /* left child == pos + 1 */
+  t->child[pos] = nabo_build_nodes(t, first + left, last, rmn, mx);
+  return pos;
+}
+
+static NaboTree* nabo_build(const double* pts, int n) {
+  NaboTree* t = (NaboTree*)calloc(1, sizeof(NaboTree));
+  t->pts = pts;
+  t->cap = 2 * (n / (NABO_BUCKET / 2) + 2) + 8;
+  t->perm = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  t->dim = (int*)malloc(sizeof(int) * t->cap); t->child = (int*)malloc(sizeof(int) * t->cap);
+  t->count = (int*)malloc(sizeof(int) * t->cap); t->cut = (double*)malloc(sizeof(double) * t->cap);
+  double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = 0; i < n; ++i) {
+    t->perm[i] = i;
+    for (int d = 0; d < 3; ++d) { if (pts[3 * i + d] < mn[d]) mn[d] = pts[3 * i + d]; if (pts[3 * i + d] > mx[d]) mx[d] = pts[3 * i + d]; }
+  }
+  if (n > 0) nabo_build_nodes(t, 0, n, mn, mx);
+  return t;
+}
+static void nabo_free(NaboTree* t) { free(t->perm); free(t->dim); free(t->child); free(t->count); free(t->cut); free(t); }
+
+/* recurseKnn for k = 1, maxRadius = inf, ALLOW_SELF_MATCH: head of the heap = (best_id, best_d2) */
+static void nabo_recurse(const NaboTree* t, const double* q, int n, double rd, double off[3], double max_error2,
+                         int* best_id, double* best_d2, long* leaves) {
+  const int cd = t->dim[n];
+  if (cd == 3) {
+    const int* e = t->perm + t->child[n];
+    for (int i = 0; i < t->count[n]; ++i) {
+      const double* p = t->pts + 3 * e[i];
+      double dist = 0;
+      for (int d = 0; d < 3; ++d) { const double diff = q[d] - p[d]; dist += diff * diff; }
+      if (dist < *best_d2) { *best_d2 = dist; *best_id = e[i]; }
+    }
+    if (leaves) ++*leaves;
+    return;
+  }
+  const int right = t->child[n];
+  const double old_off = off[cd], new_off = q[cd] - t->cut[n];
+  if (new_off > 0) {
+    nabo_recurse(t, q, right, rd, off, max_error2, best_id, best_d2, leaves);
+    rd += -old_off * old_off + new_off * new_off;
+    if (rd * max_error2 < *best_d2) {
+      off[cd] = new_off;
+      nabo_recurse(t, q, n + 1, rd, off, max_error2, best_id, best_d2, leaves);
+      off[cd] = old_off;
+    }
+  } else {
+    nabo_recurse(t, q, n + 1, rd, off, max_error2, best_id, best_d2, leaves);
+    rd += -old_off * old_off + new_off * new_off;
+    if (rd * max_error2 < *best_d2) {
+      off[cd] = new_off;
+      nabo_recurse(t, q, right, rd, off, max_error2, best_id, best_d2, leaves);
+      off[cd] = old_off;
+    }
+  }
+}
+static void nabo_nn(const NaboTree* t, const double q[3], double eps, int* best_id, double* best_d2, long* leaves) {
+  double off[3] = {0, 0, 0};
+  *best_id = -1; *best_d2 = INFINITY;
+  if (t->n_nodes == 0) return;
+  nabo_recurse(t, q, 0, 0.0, off, (1 + eps) * (1 + eps), best_id, best_d2, leaves);
+}
+
 /* ------------------------------------------------------------------ */
 /* small dense helpers                                                  */
 /* ------------------------------------------------------------------ */
@@ -148,7 +241,7 @@ static void mat4_mul(const double* a, const double* b, double* c) { /* row-major
 static void mat4_eye(double* a) { memset(a, 0, 16 * sizeof(double)); a[0] = a[5] = a[10] = a[15] = 1.0; }
 
 /* cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 6) */
-static void jacobi_eig(int n, double* A /*n*n, destroyed*/, double* V, double* w) {
+void jacobi_eig(int n, double* A /*n*n, destroyed*/, double* V, double* w) {
   for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[n * i + j] = (i == j);
   for (int sweep = 0; sweep < 60; ++sweep) {
     double off = 0;
@@ -278,21 +371,29 @@ static double select_kth(double* v, int n, int k) {
 /* ------------------------------------------------------------------ */
 /* IcpFast::Align                                                       */
 /* ------------------------------------------------------------------ */
-/* block_times[4]: FindClosests, GetDistsQuantile+ErrorElements, ComputePointToPlane, BuildKdTree
- * (names follow the reference's REGISTER_BLOCK labels, icp_fast.cc:103,171,261,464). */
-int smref_icp_align(const double* src, int ns, const double* tgt, const double* nrm, int nt,
-                    const double* guess, int max_iteration, float dist_outlier_ratio,
-                    int early_exit, int nthreads, double* result, double* score, int* iterations,
-                    double* block_times, int* last_ids, double* last_d2) {
+/* block_times[6]: FindClosests, GetDistsQuantile+ErrorElements, ComputePointToPlane, BuildKdTree, ApplyTransform,
+ * whole Align (names follow the reference's REGISTER_BLOCK labels, icp_fast.cc:103,171,261,464,484).
+ * nn_eps < 0: exact 1-NN with the smallest-id tie rule (own kd-tree; what the GPU path implements);
+ * nn_eps >= 0: libnabo's tree and eps-approximate search (3.16 = the reference's call, icp_fast.cc:174).
+ * nthreads: FindClosests runs under OpenMP like libnabo's knn (schedule(guided, 32)); ApplyTransform and the normal
+ * equations are parallel too (the reference is built with -fopenmp, CMakeLists.txt:17-28, so Eigen's products are);
+ * the sums are folded in thread order, so results depend on nthreads only at the 1e-16 level. */
+int smref_icp_align_ex(const double* src, int ns, const double* tgt, const double* nrm, int nt,
+                       const double* guess, int max_iteration, float dist_outlier_ratio,
+                       int early_exit, int nthreads, double nn_eps, double* result, double* score, int* iterations,
+                       double* block_times, int* last_ids, double* last_d2, long* leaves_visited) {
   if (ns <= 0 || nt <= 0) return -1;
-  double t_nn = 0, t_err = 0, t_p2p = 0, t_kd = 0, t0;
+  if (nthreads < 1) nthreads = 1;
+  const double t_begin = now_s();
+  double t_nn = 0, t_err = 0, t_p2p = 0, t_kd = 0, t_tf = 0, t0;
   double mu[3] = {0, 0, 0};
   for (int j = 0; j < nt; ++j) for (int d = 0; d < 3; ++d) mu[d] += tgt[3 * j + d];   /* :457-458 */
   for (int d = 0; d < 3; ++d) mu[d] /= nt;
   double* Q = (double*)malloc(sizeof(double) * 3 * (size_t)nt);
   for (int j = 0; j < nt; ++j) for (int d = 0; d < 3; ++d) Q[3 * j + d] = tgt[3 * j + d] - mu[d];  /* :462 */
   t0 = now_s();
-  KdTree* tree = kd_build(Q, nt);                                                     /* :464-467 */
+  KdTree* tree = NULL; NaboTree* nabo = NULL;
+  if (nn_eps < 0) tree = kd_build(Q, nt); else nabo = nabo_build(Q, nt);                /* :464-467 */
   t_kd = now_s() - t0;
   double Tm[16], Tmi[16], G[16], Titer[16];
   mat4_eye(Tm); Tm[3] = mu[0]; Tm[7] = mu[1]; Tm[11] = mu[2];
@@ -303,46 +404,85 @@ int smref_icp_align(const double* src, int ns, const double* tgt, const double* 
   int* ids = (int*)malloc(sizeof(int) * (size_t)ns);
   double* d2 = (double*)malloc(sizeof(double) * (size_t)ns);
   double* scratch = (double*)malloc(sizeof(double) * (size_t)ns);
+  double* part = (double*)calloc((size_t)nthreads * 48, sizeof(double));                /* per-thread A(36) b(6) sum kept */
   for (int i = 0; i < ns; ++i)                                                        /* :470 */
     for (int r = 0; r < 3; ++r)
       P0[3 * i + r] = G[4 * r] * src[3 * i] + G[4 * r + 1] * src[3 * i + 1] + G[4 * r + 2] * src[3 * i + 2] + G[4 * r + 3];
   mat4_eye(Titer);                                                                    /* :473 */
-  enum { HIST = 128 };
   double (*rots)[4] = (double(*)[4])malloc(sizeof(double) * 4 * (size_t)(max_iteration + 2));
   double (*trs)[3] = (double(*)[3])malloc(sizeof(double) * 3 * (size_t)(max_iteration + 2));
   rots[0][0] = 1; rots[0][1] = rots[0][2] = rots[0][3] = 0;                           /* :478-479 */
   trs[0][0] = trs[0][1] = trs[0][2] = 0;
   int nh = 1, it = 0;
+  long leaves = 0;
   const double rho = (double)dist_outlier_ratio;                                      /* float option widened */
-  (void)nthreads;
   for (;;) {
+    t0 = now_s();
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
     for (int i = 0; i < ns; ++i)                                                      /* :486-491 */
       for (int r = 0; r < 3; ++r)
         P[3 * i + r] = Titer[4 * r] * P0[3 * i] + Titer[4 * r + 1] * P0[3 * i + 1] + Titer[4 * r + 2] * P0[3 * i + 2] + Titer[4 * r + 3];
+    t_tf += now_s() - t0;
     t0 = now_s();
+    if (tree) {
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 1024) num_threads(nthreads > 0 ? nthreads : 1)
+#pragma omp parallel for schedule(guided, 32) num_threads(nthreads)
 #endif
-    for (int i = 0; i < ns; ++i) kd_nn(tree, &P[3 * i], &ids[i], &d2[i]);             /* :493 */
+      for (int i = 0; i < ns; ++i) kd_nn(tree, &P[3 * i], &ids[i], &d2[i]);           /* :493 */
+    } else {
+      long lv = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(guided, 32) num_threads(nthreads) reduction(+ : lv)
+#endif
+      for (int i = 0; i < ns; ++i) nabo_nn(nabo, &P[3 * i], nn_eps, &ids[i], &d2[i], &lv);
+      leaves += lv;
+    }
     t_nn += now_s() - t0;
     t0 = now_s();
     int nv = 0;
     for (int i = 0; i < ns; ++i) if (d2[i] != INFINITY) scratch[nv++] = d2[i];        /* :71-77 */
-    if (nv == 0) { free(Q); free(P0); free(P); free(ids); free(d2); free(scratch); free(rots); free(trs); kd_free(tree); return -2; }
+    if (nv == 0) {
+      free(Q); free(P0); free(P); free(ids); free(d2); free(scratch); free(part); free(rots); free(trs);
+      if (tree) kd_free(tree);
+      if (nabo) nabo_free(nabo);
+      return -2;
+    }
     double limit;
     if (rho == 1.0) { limit = scratch[0]; for (int i = 1; i < nv; ++i) if (scratch[i] > limit) limit = scratch[i]; }
     else { int k = (int)(nv * rho); limit = select_kth(scratch, nv, k); }               /* :86-89 */
     t_err += now_s() - t0;
     t0 = now_s();
+    memset(part, 0, sizeof(double) * (size_t)nthreads * 48);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+#ifdef _OPENMP
+      const int tid = omp_get_thread_num(), nth = omp_get_num_threads();
+#else
+      const int tid = 0, nth = 1;
+#endif
+      double* A = part + 48 * (size_t)tid;
+      double* b = A + 36;
+      const int lo = (int)((long)ns * tid / nth), hi = (int)((long)ns * (tid + 1) / nth);
+      for (int i = lo; i < hi; ++i) {
+        if (!(d2[i] <= limit) || d2[i] == INFINITY) continue;                          /* :497-498, :124-128 */
+        const double* p = &P[3 * i]; const double* q = &Q[3 * ids[i]]; const double* n = &nrm[3 * ids[i]];
+        double J[6] = {p[1] * n[2] - p[2] * n[1], p[2] * n[0] - p[0] * n[2], p[0] * n[1] - p[1] * n[0], n[0], n[1], n[2]};
+        double r = (p[0] - q[0]) * n[0] + (p[1] - q[1]) * n[1] + (p[2] - q[2]) * n[2];  /* :293-299 */
+        for (int a = 0; a < 6; ++a) { for (int c = 0; c < 6; ++c) A[6 * a + c] += J[a] * J[c]; b[a] -= J[a] * r; }
+        A[42] += sqrt(d2[i]); A[43] += 1.0;
+      }
+    }
     double A[36], b[6], sum_sqrt = 0; int kept = 0;
     memset(A, 0, sizeof(A)); memset(b, 0, sizeof(b));
-    for (int i = 0; i < ns; ++i) {
-      if (!(d2[i] <= limit) || d2[i] == INFINITY) continue;                            /* :497-498, :124-128 */
-      const double* p = &P[3 * i]; const double* q = &Q[3 * ids[i]]; const double* n = &nrm[3 * ids[i]];
-      double J[6] = {p[1] * n[2] - p[2] * n[1], p[2] * n[0] - p[0] * n[2], p[0] * n[1] - p[1] * n[0], n[0], n[1], n[2]};
-      double r = (p[0] - q[0]) * n[0] + (p[1] - q[1]) * n[1] + (p[2] - q[2]) * n[2];    /* :293-299 */
-      for (int a = 0; a < 6; ++a) { for (int c = 0; c < 6; ++c) A[6 * a + c] += J[a] * J[c]; b[a] -= J[a] * r; }
-      sum_sqrt += sqrt(d2[i]); ++kept;
+    for (int t = 0; t < nthreads; ++t) {
+      const double* pa = part + 48 * (size_t)t;
+      for (int k = 0; k < 36; ++k) A[k] += pa[k];
+      for (int k = 0; k < 6; ++k) b[k] += pa[36 + k];
+      sum_sqrt += pa[42]; kept += (int)pa[43];
     }
     double x[6], dT[16];
     solve_possibly_underdetermined6(A, b, x);                                          /* :304 */
@@ -369,10 +509,24 @@ int smref_icp_align(const double* src, int ns, const double* tgt, const double* 
   double tmp[16];
   mat4_mul(Titer, G, tmp); mat4_mul(Tm, tmp, result);                                  /* :527 */
   *iterations = it;
-  if (block_times) { block_times[0] = t_nn; block_times[1] = t_err; block_times[2] = t_p2p; block_times[3] = t_kd; }
+  if (block_times) { block_times[0] = t_nn; block_times[1] = t_err; block_times[2] = t_p2p; block_times[3] = t_kd;
+                     block_times[4] = t_tf; block_times[5] = now_s() - t_begin; }
   if (last_ids) memcpy(last_ids, ids, sizeof(int) * (size_t)ns);
   if (last_d2) memcpy(last_d2, d2, sizeof(double) * (size_t)ns);
-  free(Q); free(P0); free(P); free(ids); free(d2); free(scratch); free(rots); free(trs); kd_free(tree);
+  if (leaves_visited) *leaves_visited = leaves;
+  free(Q); free(P0); free(P); free(ids); free(d2); free(scratch); free(part); free(rots); free(trs);
+  if (tree) kd_free(tree);
+  if (nabo) nabo_free(nabo);
+  return 0;
+}
+
+/* eps-approximate 1-NN through the libnabo restatement (eps >= 0), for tests of the search alone */
+int smref_nn_nabo(const double* tgt, int nt, const double* qry, int nq, double eps, int* ids, double* d2, long* leaves) {
+  NaboTree* t = nabo_build(tgt, nt);
+  long lv = 0;
+  for (int i = 0; i < nq; ++i) nabo_nn(t, &qry[3 * i], eps, &ids[i], &d2[i], &lv);
+  if (leaves) *leaves = lv;
+  nabo_free(t);
   return 0;
 }
 

@@ -12,8 +12,9 @@ from scipy.spatial import cKDTree
 from . import icp_fast as o
 
 
-def align(reading_f32, reference_f32, guess, keep_mask, normals_fn=None):
-    """Returns (accepted, result 4x4, score, iterations)."""
+def align(reading_f32, reference_f32, guess, keep_mask, normals_fn=None, use_c=False):
+    """Returns (accepted, result 4x4, score, iterations).  use_c: run the ICP loop through the C restatement
+    (oracle/csrc/smref_icp.c, same algorithm, seconds instead of minutes on submap-sized clouds)."""
     rd = np.asarray(reading_f32, dtype=np.float32)
     rf = np.asarray(reference_f32, dtype=np.float32)
     rd = rd[~np.isnan(rd[:, :3]).any(axis=1)][:, :3].astype(np.float64)      # :57-66
@@ -23,7 +24,12 @@ def align(reading_f32, reference_f32, guess, keep_mask, normals_fn=None):
     ok = np.isfinite(n).all(axis=1)
     q, n = q[ok], n[ok]
     # compute(): Counter(150) + Differential checkers, TrimmedDist 0.7, PointToPlane               :187-224
-    result, _, it = o.icp_fast_align(rd[keep_mask], q, n, guess=guess, max_iteration=150, dist_outlier_ratio=0.7)
+    if use_c:
+        from . import cref
+        r = cref.icp_fast_align(rd[keep_mask], q, n, guess=guess, max_iteration=150, dist_outlier_ratio=0.7, nthreads=cref.usable_cores())
+        result, it = r["result"], r["iterations"]
+    else:
+        result, _, it = o.icp_fast_align(rd[keep_mask], q, n, guess=guess, max_iteration=150, dist_outlier_ratio=0.7)
     # final score: transformed FULL reading vs RAW reference, trimmed 0.7, mean distance           :112-143
     P = o.apply_transform(rd, result)
     d, _ = cKDTree(rf).query(P)

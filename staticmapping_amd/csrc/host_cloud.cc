@@ -2,8 +2,8 @@
 //
 // EigenPointCloud::CalculateNormals (/root/reference/builder/data/cloud_types.cc:347-368,
 // BuildNormals :105-144, leaf :73-103) is run by the CALLER of the registrator
-// (builder/map_builder.cc:286,389; builder/submap.cc:161), not by Align, so it stays host code
-// here as well (SURVEY.md §8(f) row N1 lists the device version as the next step).  Plain C++17,
+// (builder/map_builder.cc:286,389; builder/submap.cc:161), not by Align, so this entry point is host
+// code like the reference's; the device version is csrc/prep_normals.hip.  Plain C++17,
 // no Eigen: kd-box split on the widest bbox axis with std::nth_element until <= 7 points, one
 // surviving point (the leaf mean) + unconstrained-least-squares normal per leaf.
 #include <algorithm>

@@ -113,6 +113,117 @@ def _raycast(scene: Scene, origin: np.ndarray, dirs: np.ndarray) -> np.ndarray:
     return best
 
 
+def _raycast_torch(scene: Scene, origin: np.ndarray, dirs: np.ndarray, device) -> np.ndarray:
+    """_raycast with the rays-by-primitives arithmetic in float64 torch ops on `device` (the numpy form takes ~3 s per
+    120k-ray scan; benches that need dozens of scans generate them on the GPU).  Same formulas, same result up to
+    floating-point association."""
+    import torch
+    f64 = torch.float64
+    d = torch.as_tensor(dirs, dtype=f64, device=device)
+    o = torch.as_tensor(origin, dtype=f64, device=device)
+    inf = torch.tensor(float("inf"), dtype=f64, device=device)
+    dz = d[:, 2]
+    tg = (scene.ground_z - o[2]) / dz
+    best = torch.where((dz < 0) & (tg > 0), tg, inf)
+    if len(scene.box_min):
+        bmin = torch.as_tensor(scene.box_min, dtype=f64, device=device)
+        bmax = torch.as_tensor(scene.box_max, dtype=f64, device=device)
+        inv = 1.0 / d
+        t0 = (bmin[None, :, :] - o[None, None, :]) * inv[:, None, :]
+        t1 = (bmax[None, :, :] - o[None, None, :]) * inv[:, None, :]
+        lo = torch.nan_to_num(torch.minimum(t0, t1), nan=-float("inf"))
+        hi = torch.nan_to_num(torch.maximum(t0, t1), nan=float("inf"))
+        tn = lo.max(dim=2).values
+        tf = hi.min(dim=2).values
+        hit = (tf >= tn) & (tf > 0) & (tn > 0)
+        best = torch.minimum(best, torch.where(hit, tn, inf).min(dim=1).values)
+    if len(scene.cyl_r):
+        cxy = torch.as_tensor(scene.cyl_xy, dtype=f64, device=device)
+        cr = torch.as_tensor(scene.cyl_r, dtype=f64, device=device)
+        ct = torch.as_tensor(scene.cyl_top, dtype=f64, device=device)
+        ox = o[0] - cxy[:, 0]
+        oy = o[1] - cxy[:, 1]
+        dx, dy = d[:, 0:1], d[:, 1:2]
+        a = dx * dx + dy * dy
+        b = 2.0 * (dx * ox[None, :] + dy * oy[None, :])
+        c = (ox * ox + oy * oy - cr ** 2)[None, :]
+        disc = b * b - 4.0 * a * c
+        tc = (-b - torch.sqrt(torch.clamp(disc, min=0.0))) / (2.0 * a)
+        zc = o[2] + tc * d[:, 2:3]
+        ok = (disc >= 0) & (tc > 0) & (zc >= scene.ground_z) & (zc <= ct[None, :])
+        best = torch.minimum(best, torch.where(ok, tc, inf).min(dim=1).values)
+    best = torch.where(best > MAX_RANGE, inf, best)
+    return best.cpu().numpy()
+
+
+def scene_near(scene: Scene, origin: np.ndarray, radius: float = MAX_RANGE + 12.0) -> Scene:
+    """The primitives a sensor at `origin` can reach (a drive scene holds thousands; one scan sees a few dozen)."""
+    c = 0.5 * (scene.box_min[:, :2] + scene.box_max[:, :2]) if len(scene.box_min) else np.zeros((0, 2))
+    kb = np.linalg.norm(c - origin[:2], axis=1) < radius if len(c) else np.zeros(0, bool)
+    kc = np.linalg.norm(scene.cyl_xy - origin[:2], axis=1) < radius if len(scene.cyl_xy) else np.zeros(0, bool)
+    return Scene(scene.box_min[kb], scene.box_max[kb], scene.cyl_xy[kc], scene.cyl_r[kc], scene.cyl_top[kc], scene.ground_z)
+
+
+def drive_poses(n_poses: int, seed: int = 5, speed: float = 8.0, hz: float = 10.0, yaw_rate_max: float = 0.2,
+                segment_s: float = 1.0, speed_spread: float = 0.0) -> list:
+    """SURVEY.md §8(d) cfg 4: a drive at `speed` m/s sampled at `hz`, yaw rate ~ U[-yaw_rate_max, yaw_rate_max] rad/s
+    drawn every `segment_s` seconds and interpolated linearly in between (a vehicle does not jump its yaw rate); with
+    `speed_spread` > 0 the speed is drawn the same way from U[speed - spread, speed + spread].  Planar, starting at
+    the origin heading +x.  Deterministic in its arguments."""
+    rng = np.random.default_rng(seed)
+    dt = 1.0 / hz
+    per_seg = max(1, int(round(segment_s * hz)))
+    n_knots = n_poses // per_seg + 2
+    rate_k = rng.uniform(-yaw_rate_max, yaw_rate_max, size=n_knots)
+    speed_k = speed + rng.uniform(-speed_spread, speed_spread, size=n_knots)
+    x = y = yaw = 0.0
+    poses = []
+    for k in range(n_poses):
+        seg, f = divmod(k, per_seg)
+        w = f / per_seg
+        rate = (1 - w) * rate_k[seg] + w * rate_k[seg + 1]
+        v = (1 - w) * speed_k[seg] + w * speed_k[seg + 1]
+        T = np.eye(4)
+        T[:3, :3] = rpy_to_matrix(0.0, 0.0, yaw)
+        T[:3, 3] = (x, y, 0.0)
+        poses.append(T)
+        x += v * dt * np.cos(yaw)
+        y += v * dt * np.sin(yaw)
+        yaw += rate * dt
+    return poses
+
+
+def make_drive_scene(poses, seed: int = 5, keep_clear: float = 4.0, margin: float = 90.0) -> Scene:
+    """make_scene's primitives at the same density (40 boxes + 30 cylinders per 120 m x 120 m) over the bounding box of a
+    drive +- `margin`, minus everything within `keep_clear` metres of the path."""
+    rng = np.random.default_rng(seed)
+    path = np.array([P[:2, 3] for P in poses])
+    lo, hi = path.min(axis=0) - margin, path.max(axis=0) + margin
+    area = float(np.prod(hi - lo))
+    n_boxes = max(8, int(round(area * 40 / 14400.0)))
+    n_cyl = max(6, int(round(area * 30 / 14400.0)))
+    sub = path[:: max(1, len(path) // 4000)]
+
+    def clear(lo2, hi2):
+        """min distance from the path to each axis-aligned rectangle [lo2, hi2] (rows) > keep_clear"""
+        out = np.ones(len(lo2), dtype=bool)
+        for s0 in range(0, len(lo2), 512):
+            a, b = lo2[s0:s0 + 512], hi2[s0:s0 + 512]
+            d = np.maximum(np.maximum(a[:, None, :] - sub[None, :, :], sub[None, :, :] - b[:, None, :]), 0.0)
+            out[s0:s0 + 512] = np.sqrt((d * d).sum(axis=2)).min(axis=1) > keep_clear
+        return out
+    c = rng.uniform(lo, hi, size=(n_boxes, 2))
+    sz = rng.uniform(1.0, 15.0, size=(n_boxes, 3))
+    bmin = np.column_stack([c - sz[:, :2] / 2, np.full(n_boxes, GROUND_Z)])
+    bmax = np.column_stack([c + sz[:, :2] / 2, GROUND_Z + sz[:, 2]])
+    kb = clear(bmin[:, :2], bmax[:, :2])
+    cxy = rng.uniform(lo, hi, size=(n_cyl, 2))
+    cr = rng.uniform(0.1, 0.4, size=n_cyl)
+    ct = GROUND_Z + rng.uniform(2.0, 8.0, size=n_cyl)
+    kc = clear(cxy - cr[:, None], cxy + cr[:, None])
+    return Scene(bmin[kb], bmax[kb], cxy[kc], cr[kc], ct[kc])
+
+
 def rpy_to_matrix(roll: float, pitch: float, yaw: float) -> np.ndarray:
     cr, sr = np.cos(roll), np.sin(roll)
     cp, sp = np.cos(pitch), np.sin(pitch)
@@ -132,19 +243,24 @@ def make_pose(t=(0.0, 0.0, 0.0), rpy_deg=(0.0, 0.0, 0.0)) -> np.ndarray:
 
 def velodyne_scan(scene: Scene, pose: np.ndarray, seed: int, n_points: int = 120_000,
                   sigma_range: float = 0.02, n_rings: int = N_RINGS,
-                  n_az: int | None = None) -> np.ndarray:
+                  n_az: int | None = None, device=None) -> np.ndarray:
     """One scan taken at world pose `pose` (4x4), returned in the SENSOR frame.
 
     Returns float32 [n_points, 4] (x, y, z, intensity).  Deterministic in
-    (scene, pose, seed, n_points).
+    (scene, pose, seed, n_points).  `device`: a torch device to ray-cast on (same scan up to floating-point
+    association); None = numpy.
     """
     rng = np.random.default_rng(seed)
+    if device is not None:
+        _np_raycast = lambda sc, o, d: _raycast_torch(sc, o, d, device)
+    else:
+        _np_raycast = _raycast
     if n_az is None:
         n_az = max(8, int(round(n_points / n_rings)))
     R = pose[:3, :3]
     origin = pose[:3, 3]
     d_local = ring_directions(n_rings, n_az)
-    rng_hit = _raycast(scene, origin, d_local @ R.T)
+    rng_hit = _np_raycast(scene, origin, d_local @ R.T)
     keep = np.isfinite(rng_hit)
     d_keep = d_local[keep]
     r_keep = rng_hit[keep]
@@ -156,7 +272,7 @@ def velodyne_scan(scene: Scene, pose: np.ndarray, seed: int, n_points: int = 120
         e = elev[rng.integers(0, n_rings, size=m)]
         a = rng.uniform(0.0, 2.0 * np.pi, size=m)
         dl = np.stack([np.cos(e) * np.cos(a), np.cos(e) * np.sin(a), np.sin(e)], axis=-1)
-        rr = _raycast(scene, origin, dl @ R.T)
+        rr = _np_raycast(scene, origin, dl @ R.T)
         ok = np.isfinite(rr)
         d_keep = np.concatenate([d_keep, dl[ok][:need]], axis=0)
         r_keep = np.concatenate([r_keep, rr[ok][:need]], axis=0)

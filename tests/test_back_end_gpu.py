@@ -48,6 +48,17 @@ def _submaps():
     return tgt, src, T
 
 
+def _cpp_sampling_mask(n, prob=0.9, seed=0):
+    """The reading filter of the C++ IcpPointMatcherHip (include/smhip/registrator.h): one LCG draw per point."""
+    state = (seed * 2654435761 + 12345) & 0xffffffff
+    keep = np.zeros(n, dtype=bool)
+    p32 = np.float32(prob)
+    for i in range(n):
+        state = (state * 1664525 + 1013904223) & 0xffffffff
+        keep[i] = np.float32(state >> 8) * np.float32(1.0 / 16777216.0) < p32
+    return keep
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("matcher_type", [6, 1])                  # kFastIcp, kIcpPM as submap matcher
 def test_close_loop_and_submap_pair_match(tmp_path, matcher_type):
@@ -76,6 +87,27 @@ def test_close_loop_and_submap_pair_match(tmp_path, matcher_type):
     da, dt = sm.se3_error(Rp, M("edge_transform"))
     assert da < 1e-3 and dt < 1e-2, (da, dt)
     pm.close()
+    # ---- against the ORACLE (not only HIP against HIP): the same candidate through oracle/icp_pointmatcher.py with the
+    # sampling mask the C++ mirror drew
+    from oracle import icp_pointmatcher as opm
+    from oracle import cref
+    mask = _cpp_sampling_mask(len(src))
+    ok_o, R_o, score_o, it_o = opm.align(src, tgt, M("edge_guess"), mask, normals_fn=lambda p: cref.calculate_normals(p), use_c=True)
+    da, dt = sm.se3_error(M("edge_transform"), R_o)
+    assert da < 1e-4 and dt < 1e-3, ("CloseLoop vs oracle", da, dt)
+    assert abs(np.exp(-res["edge_score"]) - score_o) < 1e-4 and score_o > 0.8
+    # SubmapPairMatch vs the oracle: kFastIcp = IcpFast (max_iteration 50 from the XML) on the EigenCloud of the source and
+    # the CalculateNormals target; kIcpPM = the chain above from the submap guess
+    if matcher_type == 6:
+        q, n, _ = cref.calculate_normals(tgt[:, :3].astype(np.float64))
+        fin = np.isfinite(n).all(axis=1)
+        ref = cref.icp_fast_align(src[:, :3].astype(np.float64), q[fin], n[fin], guess=M("sub_guess"), max_iteration=50, nthreads=cref.usable_cores())
+        S_o, sub_score_o = ref["result"], ref["score"]
+    else:
+        _, S_o, sub_score_o, _ = opm.align(src, tgt, M("sub_guess"), mask, normals_fn=lambda p: cref.calculate_normals(p), use_c=True)
+    da, dt = sm.se3_error(M("sub_transform"), S_o)
+    assert da < 1e-4 and dt < 1e-3, ("SubmapPairMatch vs oracle", da, dt)
+    assert abs(res["sub_score"] - sub_score_o) < 1e-4
     # SubmapPairMatch: accepted result is a normalised rotation close to the truth; rejected keeps the guess
     assert res["sub_accepted"] and res["sub_score"] >= 0.7
     S = M("sub_transform")

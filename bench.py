@@ -9,9 +9,12 @@ value = pairs aligned by all ranks per second of the slowest rank.
 Workload: `--distinct` (64) DIFFERENT consecutive scan pairs of a synthetic drive (SURVEY.md §8(d) cfg 4: 10 Hz, speed and
 yaw rate varying, seed 5), each uploaded to its own slots -- no device-side replication of one pair.  The line carries three
 figures for the same clouds:
-  value / figures.identity_guess     guess = identity, exactly 20 iterations (SURVEY cfg 2 / cfg 4 literal)   <- headline
-  figures.extrapolated_guess         guess = the previous pair's motion (what the front end's extrapolator supplies,
-                                     builder/map_builder.cc:302-308), exactly 20 iterations
+  value / figures.extrapolated_guess guess = the previous pair's motion (what the front end's extrapolator supplies,
+                                     builder/map_builder.cc:302-308), exactly 20 iterations              <- headline
+  figures.identity_guess             guess = identity, exactly 20 iterations (SURVEY cfg 2 / cfg 4 literal).  With 0.6-1.0 m
+                                     between the scans, point-to-plane ICP on a road scene does not recover the along-track
+                                     motion from identity -- neither here nor in the CPU oracle (both end ~0.86 m from the
+                                     truth, and agree with each other): the reference's front end never calls Align that way
   figures.early_exit                 extrapolated guess, CheckConvergence on, max 100 iterations (the reference default)
 and the other matchers of the path, measured on one GPU (rank 0, N = 1 only), under `other_workloads`:
   ndt        BASELINE config #3: registrators::Ndt, 120k scan vs 500k-pt submap, 1.0 m voxels
@@ -93,7 +96,7 @@ def main():
     ap.add_argument("--nn-mode", choices=["grid", "brute"], default="grid")
     ap.add_argument("--cell", type=float, default=0.25)
     ap.add_argument("--ring", type=int, default=8)
-    ap.add_argument("--headline", choices=["identity", "extrapolated"], default="identity")
+    ap.add_argument("--headline", choices=["identity", "extrapolated"], default="extrapolated")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="oracle / cpu_baseline sample: distinct pairs run on the host (0 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (no parity-vs-oracle either)")
     ap.add_argument("--no-figures", action="store_true", help="skip the extra figures")

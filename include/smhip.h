@@ -63,7 +63,7 @@ typedef struct smhip_icp_options {
                                    0 = run exactly max_iteration iterations (throughput runs) */
   int32_t nn_mode;              /* SMHIP_NN_GRID (default) or SMHIP_NN_BRUTE */
   float grid_cell;              /* voxel edge in metres for SMHIP_NN_GRID (default 0.25) */
-  int32_t grid_max_ring;        /* largest ring searched in the grid before the brute-force fallback (default 4) */
+  int32_t grid_max_ring;        /* largest ring searched in the grid before the brute-force fallback (default 8: rings 1, 2, 4, 8) */
   int32_t check_every;          /* host polls the device "all done" word every this many iterations (default 8) */
   int32_t use_ball;             /* 1 (default): ball-bounded search seeded by the previous iteration's match, with
                                    certified trimming (matches beyond the quantile carry a proven lower bound
@@ -157,6 +157,15 @@ smhip_status smhip_icp_align(smhip_handle h, const double guess[16], double resu
                              smhip_icp_stats* stats);
 smhip_status smhip_icp_align_batch(smhip_handle h, int npairs, const double* guesses, double* results,
                                    double* scores, smhip_icp_stats* stats);
+/* The same for the pair slots [first_slot, first_slot + npairs): lets one handle keep several independent jobs resident
+ * (the back end's concurrent SubmapPairMatch tasks, builder/map_builder.cc:655; an ICP pair beside its score pair). */
+smhip_status smhip_icp_align_range(smhip_handle h, int first_slot, int npairs, const double* guesses, double* results,
+                                   double* scores, smhip_icp_stats* stats);
+/* IcpUsingPointMatcher::Align's post-hoc score (icp_pointmatcher.cc:112-143): one FindClosests + TrimmedDist(ratio) pass of
+ * the slot's source moved by T (column-major) against the slot's target; *score = exp(-mean distance of the kept matches),
+ * *kept (may be NULL) = their number.  The target needs no normals. */
+smhip_status smhip_icp_trimmed_score(smhip_handle h, int slot, const double T[16], float dist_outlier_ratio, double* score,
+                                     int32_t* kept);
 /* Asynchronous halves of the batch call: enqueue leaves everything on the stream (needs
  * early_exit = 0 or accepts running all max_iteration launches), fetch blocks and copies out. */
 smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* guesses);
@@ -186,6 +195,18 @@ smhip_status smhip_prepare_target_from_source(smhip_handle h, int from_slot, int
 /* Batched form: count targets in ONE pass (one kd forest, one sort per tree level for all scans);
  * target of to_slots[k] = CalculateNormals(source cloud of from_slots[k]); n_out[k] = its size. */
 smhip_status smhip_prepare_targets_from_sources(smhip_handle h, int count, const int* from_slots, const int* to_slots, int* n_out);
+
+/* CalculateNormals of the RAW target resident in from_slot becomes the (points + normals) target of to_slot -- the
+ * reference filter of the IcpUsingPointMatcher chain (SamplingSurfaceNormal, icp_pointmatcher.cc:176-184) without a
+ * second upload of the reference cloud.  from_slot != to_slot. */
+smhip_status smhip_prepare_target_from_target(smhip_handle h, int from_slot, int to_slot, int* n_out);
+/* RandomSamplingDataPointsFilter (icp_pointmatcher.cc:170-174) on the device: the source of to_slot = the points of
+ * from_slot's source whose uniform draw is < prob (prob >= 1 keeps everything).  The draw is a pure function of
+ * (seed, the point's index in the cloud as uploaded): splitmix64(seed << 32 | index) >> 11, times 2^-53. */
+smhip_status smhip_sample_source(smhip_handle h, int from_slot, int to_slot, float prob, uint32_t seed, int* n_out);
+/* what the handle was created with / what a slot currently holds (any pointer may be NULL) */
+smhip_status smhip_get_capacity(smhip_handle h, int* pair_slots, int* max_source_points, int* max_target_points);
+smhip_status smhip_get_cloud_sizes(smhip_handle h, int slot, int* n_source, int* n_target, int* has_normals);
 
 /* ---- introspection for parity tests ------------------------------------
  * Matches of the LAST executed iteration of `slot` (FindClosests output, icp_fast.cc:169-180):

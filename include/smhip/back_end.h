@@ -13,7 +13,9 @@
 #define SMHIP_BACK_END_H_
 
 #include <cmath>
+#include <memory>
 #include <utility>
+#include <vector>
 
 #include "smhip/registrator.h"
 
@@ -67,26 +69,33 @@ struct LoopEdge {
 struct LoopDetectorSettings {                   // back_end/loop_detector_options.h:39
   float accept_scan_match_score = 0.75f;
   int device = 0;
-  int max_points = 1 << 21;
+  int max_points = 1 << 18;          // initial arena size; the matcher grows it to fit the clouds
 };
 
-// LoopDetector::CloseLoop for one candidate pair of frames
+// LoopDetector::CloseLoop for one candidate pair of frames.  `scan_matcher` plays the stack matcher of :304; handing in
+// one that outlives the call (the loop detector checks many candidates in a row) keeps its device arena between
+// candidates -- it re-sizes itself when a cloud does not fit -- instead of allocating one per candidate.
 inline bool CloseLoop(const Matrix4d& target_global_pose, const InnerCloudPtr& target_cloud, const Matrix4d& source_global_pose,
-                      const InnerCloudPtr& source_cloud, const LoopDetectorSettings& settings, LoopEdge* edge) {
+                      const InnerCloudPtr& source_cloud, const LoopDetectorSettings& settings, LoopEdge* edge,
+                      registrator::IcpPointMatcherHip* scan_matcher) {
   Matrix4d init_guess = Multiply(RigidInverse(target_global_pose), source_global_pose);     // :287-288
   init_guess(2, 3) = 0.;                                                                     // :290 ("it is a trick")
   edge->init_guess = init_guess;
-  registrator::IcpPointMatcherHip scan_matcher(settings.device, settings.max_points);       // :304
-  scan_matcher.InitWithOptions();
-  scan_matcher.SetInputSource(source_cloud);
-  scan_matcher.SetInputTarget(target_cloud);
-  scan_matcher.Align(init_guess, edge->transform);
-  const double match_score = scan_matcher.GetFitnessScore();
+  scan_matcher->SetInputSource(source_cloud);
+  scan_matcher->SetInputTarget(target_cloud);
+  scan_matcher->Align(init_guess, edge->transform);
+  const double match_score = scan_matcher->GetFitnessScore();
   if (match_score > settings.accept_scan_match_score) {                                     // :309
     edge->score = -std::log(match_score);                                                   // :312
     return true;
   }
   return false;
+}
+inline bool CloseLoop(const Matrix4d& target_global_pose, const InnerCloudPtr& target_cloud, const Matrix4d& source_global_pose,
+                      const InnerCloudPtr& source_cloud, const LoopDetectorSettings& settings, LoopEdge* edge) {
+  registrator::IcpPointMatcherHip scan_matcher(settings.device, settings.max_points);       // :304
+  scan_matcher.InitWithOptions();
+  return CloseLoop(target_global_pose, target_cloud, source_global_pose, source_cloud, settings, edge, &scan_matcher);
 }
 
 struct SubmapPairMatchResult {
@@ -115,6 +124,54 @@ inline SubmapPairMatchResult SubmapPairMatch(const registrator::MatcherOptions& 
   out.match_score = matcher->GetFitnessScore();
   if (out.match_score >= options.accepted_min_score) { out.transform_to_next = result; out.accepted = true; }   // :437-439
   else { out.transform_to_next = out.guess; out.accepted = false; }                           // :440-444
+  return out;
+}
+
+// The back end runs up to six SubmapPairMatch tasks at once on its thread pool (map_builder.cc:655, 706-708), each with
+// its own matcher.  On the device the same six pairs are ONE batch: `matcher` (from CreateMatcher with the configured
+// submap_matcher_options; kept by the caller between batches, so no arena is allocated per pair) aligns all of them in
+// one launch sequence through its pair slots.  Matcher types without a batched form fall back to one Align per pair on
+// that same matcher.  Results are those of SubmapPairMatch pair by pair.
+struct SubmapPairJob {
+  InnerCloudPtr source_submap_cloud, target_submap_cloud;
+  Matrix4d source_first_frame_pose = Matrix4d::Identity(), target_first_frame_pose = Matrix4d::Identity();
+};
+
+inline std::vector<SubmapPairMatchResult> SubmapPairMatchBatch(const registrator::MatcherOptions& options,
+                                                               const std::shared_ptr<registrator::Interface>& matcher,
+                                                               const std::vector<SubmapPairJob>& jobs) {
+  SMHIP_CHECK(matcher != nullptr, "CreateMatcher returned null");
+  const size_t K = jobs.size();
+  std::vector<SubmapPairMatchResult> out(K);
+  if (K == 0) return out;
+  std::vector<InnerCloudPtr> src(K), tgt(K);
+  std::vector<Matrix4d> guess(K), result;
+  std::vector<double> score;
+  for (size_t k = 0; k < K; ++k) {
+    src[k] = jobs[k].source_submap_cloud; tgt[k] = jobs[k].target_submap_cloud;
+    if (matcher->GetType() == registrator::kFastIcp && !tgt[k]->GetEigenCloud()->HasNormals()) tgt[k]->CalculateNormals();   // submap.cc:161
+    guess[k] = Multiply(RigidInverse(jobs[k].target_first_frame_pose), jobs[k].source_first_frame_pose);                     // :427-429
+    out[k].guess = guess[k];
+  }
+  bool batched = false;
+  if (auto* fast = dynamic_cast<registrator::IcpFastHip*>(matcher.get())) batched = fast->AlignBatch(src, tgt, guess, &result, &score);
+  else if (auto* pm = dynamic_cast<registrator::IcpPointMatcherHip*>(matcher.get())) batched = pm->AlignBatch(src, tgt, guess, &result, &score);
+  if (!batched) {
+    result.assign(guess.begin(), guess.end());
+    score.assign(K, 0.0);
+    for (size_t k = 0; k < K; ++k) {
+      matcher->SetInputSource(src[k]);
+      matcher->SetInputTarget(tgt[k]);
+      matcher->Align(guess[k], result[k]);
+      score[k] = matcher->GetFitnessScore();
+    }
+  }
+  for (size_t k = 0; k < K; ++k) {
+    NormalizeRotation(result[k]);                                                              // :434
+    out[k].match_score = score[k];
+    if (score[k] >= options.accepted_min_score) { out[k].transform_to_next = result[k]; out[k].accepted = true; }   // :437-439
+    else { out[k].transform_to_next = out[k].guess; out[k].accepted = false; }                 // :440-444
+  }
   return out;
 }
 

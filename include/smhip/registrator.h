@@ -11,6 +11,7 @@
 #ifndef SMHIP_REGISTRATOR_H_
 #define SMHIP_REGISTRATOR_H_
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -139,16 +140,28 @@ class Interface {
 
   // interface.cc:62-90.  Accepts the children of a <registrator_options> element:
   //   <param name="max_iteration"> 100 </param>
-  void InitWithXml(const std::string& node) {
+  void InitWithXml(const std::string& node_in) {
+    // comments are not parameters (pugixml skips them): blank them out, keeping offsets
+    std::string node = node_in;
+    for (size_t c = node.find("<!--"); c != std::string::npos; c = node.find("<!--", c)) {
+      const size_t e = node.find("-->", c + 4);
+      const size_t stop = e == std::string::npos ? node.size() : e + 3;
+      for (size_t k = c; k < stop; ++k) node[k] = ' ';
+      c = stop;
+    }
     size_t pos = 0;
     while ((pos = node.find("<param", pos)) != std::string::npos) {
+      // every search is bounded by this element's own start tag
+      const size_t gt = node.find('>', pos);
+      SMHIP_CHECK(gt != std::string::npos, "malformed <param> element");
       const size_t name_at = node.find("name", pos);
+      SMHIP_CHECK(name_at != std::string::npos && name_at < gt, "malformed <param> element: no name attribute");
       const size_t q0 = node.find_first_of("\"'", name_at);
+      SMHIP_CHECK(q0 != std::string::npos && q0 < gt, "malformed <param> element: unquoted name");
       const size_t q1 = node.find(node[q0], q0 + 1);
-      const size_t gt = node.find('>', q1);
+      SMHIP_CHECK(q1 != std::string::npos && q1 < gt, "malformed <param> element: unterminated name");
       const size_t close = node.find("</param>", gt);
-      SMHIP_CHECK(name_at != std::string::npos && q0 != std::string::npos && q1 != std::string::npos &&
-                      gt != std::string::npos && close != std::string::npos, "malformed <param> element");
+      SMHIP_CHECK(close != std::string::npos, "malformed <param> element: no </param>");
       const std::string param_name = node.substr(q0 + 1, q1 - q0 - 1);
       const std::string text = node.substr(gt + 1, close - gt - 1);
       SMHIP_CHECK(inner_options_.count(param_name) > 0, "Init an unknown option of this matcher!");   // :66-67
@@ -209,6 +222,52 @@ class Interface {
   this->inner_options_[NAME].data_type = TYPE;                   \
   this->inner_options_[NAME].data_ptr = &VARIABLE;
 
+// The handle's device arena is sized at creation (no hipMalloc inside Align).  The reference has no size limit, so
+// the adapters below size the handle from the clouds they are handed: when a cloud does not fit, the handle is
+// destroyed and re-created with room to spare (x1.5, so a growing submap does not re-create it on every call) and
+// the adapter re-uploads what the old handle held.  "max_points" (inner option) is only the INITIAL capacity.
+struct DeviceArena {
+  smhip_handle handle = nullptr;
+  int device = 0, slots = 1, cap_source = 0, cap_target = 0;
+  static constexpr int kHardMaxSource = 4194304;     // smhip_create's limit on max_source_points
+  ~DeviceArena() { if (handle) smhip_destroy(handle); }
+  DeviceArena() = default;
+  DeviceArena(const DeviceArena&) = delete;
+  DeviceArena& operator=(const DeviceArena&) = delete;
+  static int Grow(int need, int have) {
+    if (need <= have) return have;
+    long long g = static_cast<long long>(need) + need / 2;
+    g = (g + 65535) / 65536 * 65536;
+    return static_cast<int>(g > 0x7fff0000LL ? 0x7fff0000LL : g);
+  }
+  // Makes sure a handle with room for ns source and nt target points exists on `dev`.
+  // *recreated = true when a new handle replaced an old one (its device-side clouds are gone).
+  // Returns false (and prints why) when the device refuses: no gfx950 device, out of memory, ns beyond the hard limit.
+  bool Reserve(int dev, int nslots, int ns, int nt, bool* recreated = nullptr) {
+    if (recreated) *recreated = false;
+    if (handle && dev == device && nslots <= slots && ns <= cap_source && nt <= cap_target) return true;
+    int want_s = Grow(ns, handle ? cap_source : 0), want_t = Grow(nt, handle ? cap_target : 0);
+    if (want_s > kHardMaxSource) want_s = kHardMaxSource;
+    if (ns > kHardMaxSource) {
+      std::fprintf(stderr, "[ERROR] source cloud of %d points exceeds the backend's limit of %d\n", ns, kHardMaxSource);
+      return false;
+    }
+    if (want_s < 1) want_s = 1;
+    if (want_t < 1) want_t = 1;
+    const bool had = handle != nullptr;
+    if (handle) { smhip_destroy(handle); handle = nullptr; }
+    const smhip_status s = smhip_create(dev, nullptr, nslots, want_s, want_t, &handle);
+    if (s != SMHIP_OK) {
+      std::fprintf(stderr, "[ERROR] smhip_create(device %d, %d slot(s), %d / %d points): %s\n", dev, nslots, want_s, want_t, smhip_status_string(s));
+      handle = nullptr; cap_source = cap_target = 0;
+      return false;
+    }
+    device = dev; slots = nslots; cap_source = want_s; cap_target = want_t;
+    if (recreated) *recreated = had;
+    return true;
+  }
+};
+
 // GPU replacement of registrator::IcpFast (icp_fast.h:38-64, icp_fast.cc:407-529).
 class IcpFastHip : public Interface {
  public:
@@ -219,36 +278,38 @@ class IcpFastHip : public Interface {
     SMHIP_REG_REGISTRATOR_INNER_OPTION("max_iteration", OptionItemDataType::kInt32, options_.max_iteration);
     SMHIP_REG_REGISTRATOR_INNER_OPTION("dist_outlier_ratio", OptionItemDataType::kFloat32, options_.dist_outlier_ratio);
     SMHIP_REG_REGISTRATOR_INNER_OPTION("device_id", OptionItemDataType::kInt32, device_);
+    SMHIP_REG_REGISTRATOR_INNER_OPTION("max_points", OptionItemDataType::kInt32, max_points_);
     SMHIP_REG_REGISTRATOR_INNER_OPTION("nn_mode", OptionItemDataType::kInt32, options_.nn_mode);
     SMHIP_REG_REGISTRATOR_INNER_OPTION("grid_cell", OptionItemDataType::kFloat32, options_.grid_cell);
     SMHIP_REG_REGISTRATOR_INNER_OPTION("exact_matches", OptionItemDataType::kBool, options_.exact_matches);
   }
-  ~IcpFastHip() override { if (handle_) smhip_destroy(handle_); }
 
-  void InitWithOptions() override { EnsureHandle(); }
+  void InitWithOptions() override { EnsureHandle(0, 0, true, true); }
 
   void SetInputSource(InnerCloudPtr cloud) override {               // icp_fast.cc:421-425
     SMHIP_CHECK(cloud != nullptr, "CHECK(cloud)");
     SMHIP_CHECK(cloud->GetEigenCloud() != nullptr, "CHECK(cloud->GetEigenCloud())");
-    EnsureHandle();
-    const auto& e = *cloud->GetEigenCloud();
-    Check(smhip_set_source_f64(handle_, 0, e.points.data(), e.size()), "smhip_set_source_f64");
+    source_keep_ = cloud;
+    input_ok_ = EnsureHandle(cloud->GetEigenCloud()->size(), 0, false, true) && UploadSource();
   }
   void SetInputTarget(InnerCloudPtr cloud) override {               // icp_fast.cc:427-431
     SMHIP_CHECK(cloud != nullptr, "CHECK(cloud)");
     SMHIP_CHECK(cloud->GetEigenCloud() != nullptr, "CHECK(cloud->GetEigenCloud())");
     SMHIP_CHECK(cloud->GetEigenCloud()->HasNormals(), "CHECK(cloud->GetEigenCloud()->HasNormals())");
-    EnsureHandle();
-    const auto& e = *cloud->GetEigenCloud();
-    Check(smhip_set_target_f64(handle_, 0, e.points.data(), e.normals.data(), e.size()), "smhip_set_target_f64");
+    target_keep_ = cloud; target_kind_ = kTargetWithNormals;
+    input_ok_ = EnsureHandle(0, cloud->GetEigenCloud()->size(), true, false) && UploadTarget();
   }
   bool Align(const Matrix4d& guess, Matrix4d& result) override {    // icp_fast.cc:455-529
-    EnsureHandle();
+    if (!input_ok_ || !EnsureHandle(0, 0, true, true)) {            // a cloud the device could not take: not an abort
+      std::fprintf(stderr, "[ERROR] IcpFastHip::Align: the input clouds are not on the device\n");
+      result = guess;
+      return false;
+    }
     double score = 0.0;
-    const smhip_status s = smhip_icp_align(handle_, guess.data(), result.data(), &score, &stats_);
+    const smhip_status s = smhip_icp_align(arena_.handle, guess.data(), result.data(), &score, &stats_);
     if (s != SMHIP_OK) {
       // the reference would CHECK-abort on these (icp_fast.cc:81,113); here: PRINT_ERROR + false
-      std::fprintf(stderr, "[ERROR] IcpFastHip::Align: %s (%s)\n", smhip_status_string(s), smhip_last_error(handle_));
+      std::fprintf(stderr, "[ERROR] IcpFastHip::Align: %s (%s)\n", smhip_status_string(s), smhip_last_error(arena_.handle));
       result = guess;
       return false;
     }
@@ -260,41 +321,92 @@ class IcpFastHip : public Interface {
   // Device-resident target preparation (the backend's own additions; the reference has the caller run
   // EigenPointCloud::CalculateNormals on the host, map_builder.cc:286,389, before SetInputTarget).
   // The raw cloud is uploaded and its normals are computed on the GPU (csrc/prep_normals.hip); returns the number of
-  // target points that kept a normal.  The host cloud is left untouched (it gets no normals).
+  // target points that kept a normal (0 when the device could not take the cloud).  The host cloud is left untouched.
   int SetInputTargetRaw(InnerCloudPtr cloud) {
     SMHIP_CHECK(cloud != nullptr, "CHECK(cloud)");
     SMHIP_CHECK(cloud->GetEigenCloud() != nullptr, "CHECK(cloud->GetEigenCloud())");
-    EnsureHandle();
-    const auto& e = *cloud->GetEigenCloud();
-    std::vector<float> rows(static_cast<size_t>(e.size()) * 3);
-    const double* p = e.points.data();
-    for (size_t i = 0; i < rows.size(); ++i) rows[i] = static_cast<float>(p[i]);   // 3xN column-major == N rows of xyz
-    int n_out = 0;
-    Check(smhip_prepare_target_f32(handle_, 0, rows.data(), 3, e.size(), &n_out), "smhip_prepare_target_f32");
-    return n_out;
+    target_keep_ = cloud; target_kind_ = kTargetRaw;
+    const int n = cloud->GetEigenCloud()->size();
+    input_ok_ = EnsureHandle(0, n, true, false) && UploadTarget();
+    return input_ok_ ? prepared_points_ : 0;
   }
   // The source already resident from the last SetInputSource becomes the target (the key-frame hand-over of
   // map_builder.cc:379-392) without a second upload.
   int PromoteSourceToTarget() {
-    EnsureHandle();
+    if (!source_keep_ || !input_ok_ || !EnsureHandle(0, source_keep_->GetEigenCloud()->size() / 4 + 8, true, true)) return 0;
     int n_out = 0;
-    Check(smhip_prepare_target_from_source(handle_, 0, 0, &n_out), "smhip_prepare_target_from_source");
+    if (!Ok(smhip_prepare_target_from_source(arena_.handle, 0, 0, &n_out), "smhip_prepare_target_from_source")) { input_ok_ = false; return 0; }
+    target_keep_ = source_keep_; target_kind_ = kTargetRaw; prepared_points_ = n_out;
     return n_out;
+  }
+  int CapacitySource() const { return arena_.cap_source; }
+  int CapacityTarget() const { return arena_.cap_target; }
+
+  // K independent (source, target) pairs in ONE launch sequence through K pair slots of a second handle that this
+  // matcher keeps between calls -- the six concurrent SubmapPairMatch tasks of the back end (map_builder.cc:655,
+  // 706-708) as one batch instead of six matchers with an arena each.  Targets must carry normals.
+  // results / scores are resized to K; returns false (results = guesses) when the device refused a cloud or a pair failed.
+  bool AlignBatch(const std::vector<InnerCloudPtr>& sources, const std::vector<InnerCloudPtr>& targets,
+                  const std::vector<Matrix4d>& guesses, std::vector<Matrix4d>* results, std::vector<double>* scores,
+                  std::vector<smhip_icp_stats>* stats = nullptr) {
+    const int K = static_cast<int>(sources.size());
+    SMHIP_CHECK(K > 0 && targets.size() == sources.size() && guesses.size() == sources.size() && results && scores, "AlignBatch: sizes");
+    results->assign(guesses.begin(), guesses.end());
+    scores->assign(K, 0.0);
+    int ns = 1, nt = 1;
+    for (int k = 0; k < K; ++k) {
+      SMHIP_CHECK(sources[k] && targets[k] && sources[k]->GetEigenCloud() && targets[k]->GetEigenCloud(), "CHECK(cloud)");
+      SMHIP_CHECK(targets[k]->GetEigenCloud()->HasNormals(), "CHECK(cloud->GetEigenCloud()->HasNormals())");
+      ns = std::max(ns, sources[k]->GetEigenCloud()->size());
+      nt = std::max(nt, targets[k]->GetEigenCloud()->size());
+    }
+    if (!batch_arena_.Reserve(device_, std::max(K, batch_arena_.slots), ns, nt)) return false;
+    smhip_handle h = batch_arena_.handle;
+    if (!ApplyOptions(h)) return false;
+    for (int k = 0; k < K; ++k) {
+      const auto& es = *sources[k]->GetEigenCloud();
+      const auto& et = *targets[k]->GetEigenCloud();
+      if (smhip_set_source_f64(h, k, es.points.data(), es.size()) != SMHIP_OK ||
+          smhip_set_target_f64(h, k, et.points.data(), et.normals.data(), et.size()) != SMHIP_OK) {
+        std::fprintf(stderr, "[ERROR] IcpFastHip::AlignBatch: %s\n", smhip_last_error(h));
+        return false;
+      }
+    }
+    std::vector<double> g(16 * static_cast<size_t>(K)), r(16 * static_cast<size_t>(K));
+    std::vector<smhip_icp_stats> st(K);
+    for (int k = 0; k < K; ++k) std::memcpy(&g[16 * static_cast<size_t>(k)], guesses[k].data(), sizeof(double) * 16);
+    const smhip_status s = smhip_icp_align_batch(h, K, g.data(), r.data(), scores->data(), st.data());
+    if (s != SMHIP_OK) {
+      std::fprintf(stderr, "[ERROR] IcpFastHip::AlignBatch: %s (%s)\n", smhip_status_string(s), smhip_last_error(h));
+      scores->assign(K, 0.0);
+      return false;
+    }
+    for (int k = 0; k < K; ++k) std::memcpy((*results)[k].data(), &r[16 * static_cast<size_t>(k)], sizeof(double) * 16);
+    if (stats) *stats = st;
+    return true;
   }
 
  private:
-  void Check(smhip_status s, const char* what) {
-    if (s != SMHIP_OK) {
-      std::fprintf(stderr, "[ERROR] %s: %s (%s)\n", what, smhip_status_string(s), handle_ ? smhip_last_error(handle_) : "");
-      SMHIP_CHECK(false, what);
-    }
+  enum TargetKind { kNoTarget, kTargetWithNormals, kTargetRaw };
+  bool Ok(smhip_status s, const char* what) {
+    if (s == SMHIP_OK) return true;
+    std::fprintf(stderr, "[ERROR] %s: %s (%s)\n", what, smhip_status_string(s), arena_.handle ? smhip_last_error(arena_.handle) : "");
+    return false;
   }
-  void EnsureHandle() {
-    if (!handle_) {
-      const smhip_status s = smhip_create(device_, nullptr, 1, max_points_, max_points_, &handle_);
-      if (s != SMHIP_OK) { std::fprintf(stderr, "[ERROR] smhip_create: %s\n", smhip_status_string(s)); }
-      SMHIP_CHECK(s == SMHIP_OK, "no usable MI355X (gfx950) device: there is no CPU fallback");
-    }
+  bool UploadSource() {
+    const auto& e = *source_keep_->GetEigenCloud();
+    return Ok(smhip_set_source_f64(arena_.handle, 0, e.points.data(), e.size()), "smhip_set_source_f64");
+  }
+  bool UploadTarget() {
+    const auto& e = *target_keep_->GetEigenCloud();
+    if (target_kind_ == kTargetWithNormals)
+      return Ok(smhip_set_target_f64(arena_.handle, 0, e.points.data(), e.normals.data(), e.size()), "smhip_set_target_f64");
+    std::vector<float> rows(static_cast<size_t>(e.size()) * 3);
+    const double* p = e.points.data();
+    for (size_t i = 0; i < rows.size(); ++i) rows[i] = static_cast<float>(p[i]);   // 3xN column-major == N rows of xyz
+    return Ok(smhip_prepare_target_f32(arena_.handle, 0, rows.data(), 3, e.size(), &prepared_points_), "smhip_prepare_target_f32");
+  }
+  bool ApplyOptions(smhip_handle h) {
     smhip_icp_options o;
     smhip_icp_default_options(&o);
     o.max_iteration = options_.max_iteration;
@@ -302,7 +414,24 @@ class IcpFastHip : public Interface {
     o.nn_mode = options_.nn_mode;
     o.grid_cell = options_.grid_cell;
     o.exact_matches = options_.exact_matches ? 1 : 0;
-    Check(smhip_icp_set_options(handle_, &o), "smhip_icp_set_options");
+    return Ok(smhip_icp_set_options(h, &o), "smhip_icp_set_options");
+  }
+  // Handle with room for ns / nt points (0 = whatever it has).  After a re-creation the clouds the old handle held
+  // are uploaded again from the shared_ptrs kept for that purpose, except the one the caller is about to upload itself.
+  bool EnsureHandle(int ns, int nt, bool restore_source, bool restore_target) {
+    const bool first = arena_.handle == nullptr;
+    const int init = max_points_ > 0 ? max_points_ : 1;
+    bool recreated = false;
+    if (!arena_.Reserve(device_, 1, std::max(ns, first ? init : 0), std::max(nt, first ? init : 0), &recreated)) {
+      SMHIP_CHECK(!first || smhip_device_count() > 0, "no usable MI355X (gfx950) device: there is no CPU fallback");
+      return false;
+    }
+    if (!ApplyOptions(arena_.handle)) return false;
+    if (recreated) {
+      if (restore_source && source_keep_ && !UploadSource()) return false;
+      if (restore_target && target_keep_ && target_kind_ != kNoTarget && !UploadTarget()) return false;
+    }
+    return true;
   }
 
   struct {
@@ -314,8 +443,13 @@ class IcpFastHip : public Interface {
     bool exact_matches = false;
   } options_;
   int32_t device_ = 0;
-  int max_points_;
-  smhip_handle handle_ = nullptr;
+  int32_t max_points_;
+  DeviceArena arena_;
+  DeviceArena batch_arena_;                    // AlignBatch's K-slot handle
+  InnerCloudPtr source_keep_, target_keep_;   // what the device holds (icp_fast.cc:424,431 deep-copies; here: to re-upload after a re-size)
+  TargetKind target_kind_ = kNoTarget;
+  int prepared_points_ = 0;
+  bool input_ok_ = true;
   smhip_icp_stats stats_{};
 };
 
@@ -332,15 +466,15 @@ class NdtHip : public Interface {
     SMHIP_REG_REGISTRATOR_INNER_OPTION("step_size", OptionItemDataType::kFloat32, opt_.step_size);
     SMHIP_REG_REGISTRATOR_INNER_OPTION("max_iterations", OptionItemDataType::kInt32, opt_.max_iterations);
   }
-  ~NdtHip() override { if (handle_) smhip_destroy(handle_); }
-  void InitWithOptions() override { EnsureHandle(); }
+  void InitWithOptions() override { EnsureHandle(0, 0); }
 
   bool Align(const Matrix4d& guess, Matrix4d& result) override {      // ndt.cc:38-64
     if (!this->source_cloud_ || !this->target_cloud_) return false;   // :40-42
-    EnsureHandle();
     // ToPclPointCloud of both clouds on every Align (:44-51): the 20-byte InnerPointType AoS goes up as is
     const auto& s = this->source_cloud_->GetInnerCloud();
     const auto& t = this->target_cloud_->GetInnerCloud();
+    if (!EnsureHandle(static_cast<int>(s.size()), static_cast<int>(t.size()))) { result = guess; return false; }
+    smhip_handle handle_ = arena_.handle;
     if (smhip_set_source_f32(handle_, 0, &s[0].x, 5, static_cast<int>(s.size())) != SMHIP_OK ||
         smhip_set_target_f32(handle_, 0, &t[0].x, 5, nullptr, 0, static_cast<int>(t.size())) != SMHIP_OK) {
       std::fprintf(stderr, "[ERROR] NdtHip: %s\n", smhip_last_error(handle_));
@@ -359,17 +493,19 @@ class NdtHip : public Interface {
   const smhip_ndt_stats& LastStats() const { return stats_; }
 
  private:
-  void EnsureHandle() {
-    if (!handle_) {
-      const smhip_status s = smhip_create(device_, nullptr, 1, max_source_, max_target_, &handle_);
-      SMHIP_CHECK(s == SMHIP_OK, "no usable MI355X (gfx950) device: there is no CPU fallback");
+  bool EnsureHandle(int ns, int nt) {
+    const bool first = arena_.handle == nullptr;
+    if (!arena_.Reserve(device_, 1, std::max(ns, first ? max_source_ : 0), std::max(nt, first ? max_target_ : 0))) {
+      SMHIP_CHECK(!first || smhip_device_count() > 0, "no usable MI355X (gfx950) device: there is no CPU fallback");
+      return false;
     }
-    SMHIP_CHECK(smhip_ndt_set_options(handle_, &opt_) == SMHIP_OK, "smhip_ndt_set_options");
+    SMHIP_CHECK(smhip_ndt_set_options(arena_.handle, &opt_) == SMHIP_OK, "smhip_ndt_set_options");
+    return true;
   }
   smhip_ndt_options opt_;
   int32_t device_ = 0;
   int max_source_, max_target_;
-  smhip_handle handle_ = nullptr;
+  DeviceArena arena_;
   smhip_ndt_stats stats_{};
 };
 
@@ -387,15 +523,15 @@ class NdtGicpHip : public Interface {
     SMHIP_REG_REGISTRATOR_INNER_OPTION("using_voxel_filter", OptionItemDataType::kBool, using_voxel_filter_);
     SMHIP_REG_REGISTRATOR_INNER_OPTION("voxel_resolution", OptionItemDataType::kFloat32, opt_.voxel_resolution);
   }
-  ~NdtGicpHip() override { if (handle_) smhip_destroy(handle_); }
-  void InitWithOptions() override { EnsureHandle(); }
+  void InitWithOptions() override { EnsureHandle(0, 0); }
 
   bool Align(const Matrix4d& guess, Matrix4d& result) override {      // ndt_gicp.cc:55-112
     if (!this->source_cloud_ || !this->target_cloud_) return false;
-    EnsureHandle();
     // ToPclPointCloud of both stored clouds on every Align (:59-76)
     const auto& s = this->source_cloud_->GetInnerCloud();
     const auto& t = this->target_cloud_->GetInnerCloud();
+    if (!EnsureHandle(static_cast<int>(s.size()), static_cast<int>(t.size()))) { result = guess; return false; }
+    smhip_handle handle_ = arena_.handle;
     if (smhip_ndt_gicp_set_source_f32(handle_, &s[0].x, 5, static_cast<int>(s.size())) != SMHIP_OK ||
         smhip_ndt_gicp_set_target_f32(handle_, &t[0].x, 5, static_cast<int>(t.size())) != SMHIP_OK) {
       std::fprintf(stderr, "[ERROR] NdtGicpHip: %s\n", smhip_last_error(handle_));
@@ -414,20 +550,25 @@ class NdtGicpHip : public Interface {
   const smhip_ndt_gicp_stats& LastStats() const { return stats_; }
 
  private:
-  void EnsureHandle() {
-    if (!handle_) {
-      const smhip_status s = smhip_create(device_, nullptr, 2, max_source_, max_target_ > max_source_ ? max_target_ : max_source_, &handle_);
-      SMHIP_CHECK(s == SMHIP_OK, "no usable MI355X (gfx950) device: there is no CPU fallback");
+  // two pair slots (working space of the matcher); the target side also has to hold the down-sampled source
+  bool EnsureHandle(int ns, int nt) {
+    const bool first = arena_.handle == nullptr;
+    const int want_s = std::max(ns, first ? max_source_ : 0);
+    const int want_t = std::max(std::max(nt, ns), first ? std::max(max_target_, max_source_) : 0);
+    if (!arena_.Reserve(device_, 2, want_s, want_t)) {
+      SMHIP_CHECK(!first || smhip_device_count() > 0, "no usable MI355X (gfx950) device: there is no CPU fallback");
+      return false;
     }
     opt_.use_ndt = use_ndt_ ? 1 : 0;
     opt_.using_voxel_filter = using_voxel_filter_ ? 1 : 0;
-    SMHIP_CHECK(smhip_ndt_gicp_set_options(handle_, &opt_) == SMHIP_OK, "smhip_ndt_gicp_set_options");
+    SMHIP_CHECK(smhip_ndt_gicp_set_options(arena_.handle, &opt_) == SMHIP_OK, "smhip_ndt_gicp_set_options");
+    return true;
   }
   smhip_ndt_gicp_options opt_;
   bool use_ndt_ = true, using_voxel_filter_ = true;
   int32_t device_ = 0;
   int max_source_, max_target_;
-  smhip_handle handle_ = nullptr;
+  DeviceArena arena_;
   smhip_ndt_gicp_stats stats_{};
 };
 
@@ -440,54 +581,101 @@ class IcpPointMatcherHip : public Interface {
   explicit IcpPointMatcherHip(int device = 0, int max_points = 1 << 18) : device_(device), max_points_(max_points) {
     this->type_ = kIcpPM;
     SMHIP_REG_REGISTRATOR_INNER_OPTION("device_id", OptionItemDataType::kInt32, device_);
+    SMHIP_REG_REGISTRATOR_INNER_OPTION("max_points", OptionItemDataType::kInt32, max_points_);
     SMHIP_REG_REGISTRATOR_INNER_OPTION("random_sampling_prob", OptionItemDataType::kFloat32, prob_);
     SMHIP_REG_REGISTRATOR_INNER_OPTION("random_seed", OptionItemDataType::kInt32, seed_);
   }
-  ~IcpPointMatcherHip() override { if (handle_) smhip_destroy(handle_); }
-  void InitWithOptions() override { EnsureHandle(); }
+  void InitWithOptions() override { EnsureHandle(0, 0); }
 
   void SetInputSource(InnerCloudPtr cloud) override {               // icp_pointmatcher.cc:84-92
     if (!cloud || cloud->Empty()) { std::fprintf(stderr, "[ERROR] Empty cloud.\n"); return; }
     reading_ = DropNan(cloud->GetInnerCloud());
+    reading_on_device_ = false;
   }
   void SetInputTarget(InnerCloudPtr cloud) override {               // :94-102
     if (!cloud || cloud->Empty()) { std::fprintf(stderr, "[ERROR] Empty cloud.\n"); return; }
     reference_ = DropNan(cloud->GetInnerCloud());
+    reference_on_device_ = false;
   }
+  // Slot 0 is the ICP pair (sampled reading vs CalculateNormals(reference)), slot 1 the score pair (full reading vs
+  // raw reference).  Each cloud is uploaded once; sampling, normals, the 150-iteration loop and the score pass all
+  // run on the device.
   bool Align(const Matrix4d& guess, Matrix4d& result) override {    // :104-149
     if (reading_.empty() || reference_.empty()) return false;
-    EnsureHandle();
-    // reading filter: RandomSampling (seeded here; the reference uses std::rand())
-    std::vector<float> sampled;
-    sampled.reserve(reading_.size());
-    uint32_t state = static_cast<uint32_t>(seed_) * 2654435761u + 12345u;
-    for (size_t i = 0; i + 2 < reading_.size(); i += 3) {
-      state = state * 1664525u + 1013904223u;
-      const float r = static_cast<float>(state >> 8) * (1.0f / 16777216.0f);
-      if (prob_ >= 1.0f || r < prob_) { sampled.push_back(reading_[i]); sampled.push_back(reading_[i + 1]); sampled.push_back(reading_[i + 2]); }
+    const int nr = static_cast<int>(reading_.size() / 3), nf = static_cast<int>(reference_.size() / 3);
+    bool recreated = false;
+    if (!EnsureHandle(nr, nf, &recreated)) { result = guess; return false; }
+    if (recreated) reading_on_device_ = reference_on_device_ = false;
+    smhip_handle h = arena_.handle;
+    if (!reading_on_device_) {
+      if (smhip_set_source_f32(h, 1, reading_.data(), 3, nr) != SMHIP_OK) return Fail(guess, result);
+      reading_on_device_ = true;
     }
-    // reference filter: SamplingSurfaceNormal == CalculateNormals
-    data::EigenPointCloud ref;
-    ref.points.assign(reference_.begin(), reference_.end());
-    ref.CalculateNormals();
+    if (!reference_on_device_) {
+      if (smhip_set_target_f32(h, 1, reference_.data(), 3, nullptr, 0, nf) != SMHIP_OK) return Fail(guess, result);
+      reference_on_device_ = true;
+    }
+    int n_sampled = 0, n_target = 0;
+    // reading filter: RandomSampling(prob) (:170-174); reference filter: SamplingSurfaceNormal == CalculateNormals (:176-184)
+    if (smhip_sample_source(h, 1, 0, prob_, static_cast<uint32_t>(seed_), &n_sampled) != SMHIP_OK ||
+        smhip_prepare_target_from_target(h, 1, 0, &n_target) != SMHIP_OK) return Fail(guess, result);
     smhip_icp_options o; smhip_icp_default_options(&o);
-    o.max_iteration = 150; o.dist_outlier_ratio = 0.7f; o.early_exit = 1;
-    if (smhip_icp_set_options(handle_, &o) != SMHIP_OK ||
-        smhip_set_source_f32(handle_, 0, sampled.data(), 3, static_cast<int>(sampled.size() / 3)) != SMHIP_OK ||
-        smhip_set_target_f64(handle_, 0, ref.points.data(), ref.normals.data(), ref.size()) != SMHIP_OK) return Fail(guess, result);
+    o.max_iteration = 150; o.dist_outlier_ratio = 0.7f; o.early_exit = 1;           // :196-224
+    if (smhip_icp_set_options(h, &o) != SMHIP_OK) return Fail(guess, result);
     double score = 0.0;
-    if (smhip_icp_align(handle_, guess.data(), result.data(), &score, &stats_) != SMHIP_OK) return Fail(guess, result);
+    if (smhip_icp_align(h, guess.data(), result.data(), &score, &stats_) != SMHIP_OK) return Fail(guess, result);
     // final score: the FULL reading transformed by `result` against the RAW reference, one trimmed pass (:112-143)
-    std::vector<double> raw(reference_.begin(), reference_.end()), up(raw.size(), 0.0);
-    for (size_t i = 2; i < up.size(); i += 3) up[i] = 1.0;
-    o.max_iteration = 1; o.early_exit = 0;
-    Matrix4d ignored;
-    if (smhip_icp_set_options(handle_, &o) != SMHIP_OK ||
-        smhip_set_source_f32(handle_, 0, reading_.data(), 3, static_cast<int>(reading_.size() / 3)) != SMHIP_OK ||
-        smhip_set_target_f64(handle_, 0, raw.data(), up.data(), static_cast<int>(raw.size() / 3)) != SMHIP_OK ||
-        smhip_icp_align(handle_, result.data(), ignored.data(), &score, nullptr) != SMHIP_OK) return Fail(guess, result);
+    if (smhip_icp_trimmed_score(h, 1, result.data(), 0.7f, &score, nullptr) != SMHIP_OK) return Fail(guess, result);
     this->final_score_ = score;                                      // :143
     return this->final_score_ >= 0.6;                                // :145-148
+  }
+  const smhip_icp_stats& LastStats() const { return stats_; }
+
+  // K independent (reading, reference) pairs through 2 K pair slots of a handle kept between calls: slots [0, K) hold the
+  // ICP pairs, slots [K, 2 K) the score pairs; ONE launch sequence runs the K 150-iteration loops together.
+  // accepted[k] = score >= 0.6 (Align's bool); results = guesses for pairs the device could not take.
+  bool AlignBatch(const std::vector<InnerCloudPtr>& sources, const std::vector<InnerCloudPtr>& targets,
+                  const std::vector<Matrix4d>& guesses, std::vector<Matrix4d>* results, std::vector<double>* scores,
+                  std::vector<bool>* accepted = nullptr) {
+    const int K = static_cast<int>(sources.size());
+    SMHIP_CHECK(K > 0 && targets.size() == sources.size() && guesses.size() == sources.size() && results && scores, "AlignBatch: sizes");
+    results->assign(guesses.begin(), guesses.end());
+    scores->assign(K, 0.0);
+    if (accepted) accepted->assign(K, false);
+    std::vector<std::vector<float>> rd(K), rf(K);
+    int ns = 1, nt = 1;
+    for (int k = 0; k < K; ++k) {
+      if (!sources[k] || sources[k]->Empty() || !targets[k] || targets[k]->Empty()) { std::fprintf(stderr, "[ERROR] Empty cloud.\n"); return false; }
+      rd[k] = DropNan(sources[k]->GetInnerCloud());
+      rf[k] = DropNan(targets[k]->GetInnerCloud());
+      if (rd[k].empty() || rf[k].empty()) return false;
+      ns = std::max(ns, static_cast<int>(rd[k].size() / 3));
+      nt = std::max(nt, static_cast<int>(rf[k].size() / 3));
+    }
+    if (!batch_arena_.Reserve(device_, std::max(2 * K, batch_arena_.slots), ns, nt)) return false;
+    smhip_handle h = batch_arena_.handle;
+    auto bad = [&]() { std::fprintf(stderr, "[ERROR] IcpPointMatcherHip::AlignBatch: %s\n", smhip_last_error(h)); return false; };
+    for (int k = 0; k < K; ++k) {
+      int m = 0;
+      if (smhip_set_source_f32(h, K + k, rd[k].data(), 3, static_cast<int>(rd[k].size() / 3)) != SMHIP_OK ||
+          smhip_set_target_f32(h, K + k, rf[k].data(), 3, nullptr, 0, static_cast<int>(rf[k].size() / 3)) != SMHIP_OK ||
+          smhip_sample_source(h, K + k, k, prob_, static_cast<uint32_t>(seed_), &m) != SMHIP_OK ||
+          smhip_prepare_target_from_target(h, K + k, k, &m) != SMHIP_OK) return bad();
+    }
+    smhip_icp_options o; smhip_icp_default_options(&o);
+    o.max_iteration = 150; o.dist_outlier_ratio = 0.7f; o.early_exit = 1;
+    if (smhip_icp_set_options(h, &o) != SMHIP_OK) return bad();
+    std::vector<double> g(16 * static_cast<size_t>(K)), r(16 * static_cast<size_t>(K)), sc(K);
+    for (int k = 0; k < K; ++k) std::memcpy(&g[16 * static_cast<size_t>(k)], guesses[k].data(), sizeof(double) * 16);
+    if (smhip_icp_align_range(h, 0, K, g.data(), r.data(), sc.data(), nullptr) != SMHIP_OK) return bad();
+    for (int k = 0; k < K; ++k) {
+      double score = 0.0;
+      if (smhip_icp_trimmed_score(h, K + k, &r[16 * static_cast<size_t>(k)], 0.7f, &score, nullptr) != SMHIP_OK) return bad();
+      std::memcpy((*results)[k].data(), &r[16 * static_cast<size_t>(k)], sizeof(double) * 16);
+      (*scores)[k] = score;
+      if (accepted) (*accepted)[k] = score >= 0.6;
+    }
+    return true;
   }
 
  private:
@@ -499,22 +687,28 @@ class IcpPointMatcherHip : public Interface {
     return out;
   }
   bool Fail(const Matrix4d& guess, Matrix4d& result) {
-    std::fprintf(stderr, "[ERROR] IcpPointMatcherHip::Align: %s\n", smhip_last_error(handle_));
+    std::fprintf(stderr, "[ERROR] IcpPointMatcherHip::Align: %s\n", arena_.handle ? smhip_last_error(arena_.handle) : "no handle");
     result = guess;
     return false;
   }
-  void EnsureHandle() {
-    if (!handle_) {
-      const smhip_status s = smhip_create(device_, nullptr, 1, max_points_, max_points_, &handle_);
-      SMHIP_CHECK(s == SMHIP_OK, "no usable MI355X (gfx950) device: there is no CPU fallback");
+  bool EnsureHandle(int ns, int nt, bool* recreated = nullptr) {
+    const bool first = arena_.handle == nullptr;
+    const int init = max_points_ > 0 ? max_points_ : 1;
+    // the raw reference is also the input of the device CalculateNormals, whose scratch is sized by max(ns, nt) capacity
+    if (!arena_.Reserve(device_, 2, std::max(ns, first ? init : 0), std::max(nt, first ? init : 0), recreated)) {
+      SMHIP_CHECK(!first || smhip_device_count() > 0, "no usable MI355X (gfx950) device: there is no CPU fallback");
+      return false;
     }
+    return true;
   }
   std::vector<float> reading_, reference_;     // xyz of the non-NaN points
+  bool reading_on_device_ = false, reference_on_device_ = false;
   float prob_ = 0.9f;                           // icp_pointmatcher.cc:172
   int32_t seed_ = 0;
   int32_t device_ = 0;
-  int max_points_;
-  smhip_handle handle_ = nullptr;
+  int32_t max_points_;
+  DeviceArena arena_;
+  DeviceArena batch_arena_;                    // AlignBatch's 2 K-slot handle
   smhip_icp_stats stats_{};
 };
 

@@ -77,7 +77,7 @@ def keep_mask(f: dict, pts: np.ndarray) -> np.ndarray:
         p = pts[:, :3].astype(np.float64)
         return ~np.all((p >= lo) & (p <= hi), axis=1)
     if t == RANDOM_SAMPLER:
-        if F(f["sampling_rate"]) > F(0.999):
+        if float(F(f["sampling_rate"])) > 0.999:      # filter_random_sample.cc:44: the float rate against the double literal
             return np.ones(len(pts), dtype=bool)
         return sampler_uniform(f.get("seed", 0), len(pts)) <= np.float64(F(f["sampling_rate"]))
     raise ValueError(t)

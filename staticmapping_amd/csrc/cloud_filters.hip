@@ -237,7 +237,7 @@ hipError_t filt_run_chain(FilterWorkspace* w, hipStream_t st, const smhip_filter
       FCHK(compact(w, st));
     } else if (f.type == SMHIP_FILTER_RANDOM_SAMPLER) {
       ++k;
-      if (f.p[0] > 0.999f) continue;                                       // filter_random_sample.cc:46-53
+      if ((double)f.p[0] > 0.999) continue;                                // filter_random_sample.cc:46-53: the float rate against the DOUBLE literal 0.999 (0.999f passes through)
       hipLaunchKernelGGL(filt_sample_flags, dim3(gp), dim3(256), 0, st, n, f.seed, f.p[0], w->flag);
       FCHK(compact(w, st));
     } else if (f.type == SMHIP_FILTER_VOXEL_GRID) {

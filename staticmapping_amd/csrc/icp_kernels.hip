@@ -136,12 +136,14 @@ __device__ __forceinline__ void mat4_mul_rm(const double* a, const double* c, do
 
 // One thread per pair: mean, grid geometry, G = T(-mu) * guess, loop state reset.
 // Per-Align scratch of the first npairs slots zeroed in one launch (four memsets cost a single pair ~30 us of launch gaps).
-__global__ __launch_bounds__(256) void reset_scratch(IcpDev b, int npairs) {
+__global__ __launch_bounds__(256) void reset_scratch(IcpDev b, int first, int npairs) {
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
-  uint4* bits4 = reinterpret_cast<uint4*>(b.bits);                       // hipMalloc alignment; kMaxGridWords % 4 == 0
+  uint4* bits4 = reinterpret_cast<uint4*>(b.bits) + (size_t)kMaxGridWords / 4 * first;   // hipMalloc alignment; kMaxGridWords % 4 == 0
+  uint32_t* cc = b.ccount + (size_t)(b.nt_cap + 1) * first;
+  uint32_t* hh = b.hist + (size_t)kHistBins * first;
   for (size_t k = tid; k < (size_t)kMaxGridWords / 4 * npairs; k += nth) bits4[k] = make_uint4(0, 0, 0, 0);
-  for (size_t k = tid; k < (size_t)(b.nt_cap + 1) * npairs; k += nth) b.ccount[k] = 0;
-  for (size_t k = tid; k < (size_t)kHistBins * npairs; k += nth) b.hist[k] = 0;
+  for (size_t k = tid; k < (size_t)(b.nt_cap + 1) * npairs; k += nth) cc[k] = 0;
+  for (size_t k = tid; k < (size_t)kHistBins * npairs; k += nth) hh[k] = 0;
   if (tid == 0) *b.done_count = 0;
 }
 
@@ -167,6 +169,25 @@ __global__ void grid_setup(IcpDev b, int npairs) {
   // centred bbox, the same rounding the mark/scatter kernels apply to every point
   float cmin[3], cmax[3];
   for (int d = 0; d < 3; ++d) { cmin[d] = (float)((double)mn[d] - mu[d]); cmax[d] = (float)((double)mx[d] - mu[d]); }
+  // A NaN / Inf target coordinate would make the cell counts below overflow (and grid_mark write outside `bits`): such a
+  // pair fails cleanly instead -- one cell, nothing searched, status = invalid argument, counted as finished.
+  bool finite_box = true;
+  for (int d = 0; d < 3; ++d) finite_box = finite_box && isfinite(cmin[d]) && isfinite(cmax[d]) && isfinite(mu[d]) && cmax[d] >= cmin[d];
+  if (!finite_box) {
+    st->h = 1.0f; st->inv_h = 1.0f;
+    for (int d = 0; d < 3; ++d) st->origin[d] = 0.f;
+    st->nx = st->ny = st->nz = 1; st->wx = 1; st->nw = 1; st->nocc = 0;
+    for (int i = 0; i < 16; ++i) { st->T_iter[i] = (i % 5 == 0) ? 1.0 : 0.0; st->G[i] = st->guess[i]; st->result[(i % 4) * 4 + i / 4] = st->guess[i]; }
+    for (int i = 0; i < 12; ++i) { st->M[i] = st->guess[i]; st->M_prev[i] = st->guess[i]; }
+    st->n_hist = 1; st->iter = 0; st->score = 0; st->kept = 0; st->limit_key = 0;
+    st->unresolved_count = 0; st->fallback_ticket = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
+    st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0; st->searched_total = 0;
+    st->rcap2 = 0.f;
+    st->status = 1;                        // SMHIP_ERR_INVALID_ARGUMENT
+    st->done = 1;
+    atomicAdd(b.done_count, 1u);
+    return;
+  }
   float h = b.grid_cell;
   int nx, ny, nz, wx;
   for (;;) {

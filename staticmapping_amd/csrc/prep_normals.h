@@ -18,6 +18,10 @@ hipError_t prep_calculate_normals_batch(PrepWorkspace* w, hipStream_t st, const 
                                         const int* n, const int* out_offset, float4* out_p, float4* out_n, int* m_host);
 // Morton-order `raw` into `out` (out[k].w = index of the point in `raw`); asynchronous on `st`.
 hipError_t prep_morton_sort(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float4* out);
+// Random sub-sampling of a Morton-ordered cloud (in[k].w = caller index): keeps the points whose counter-based uniform of
+// (seed, caller index) is < prob, in the input's order, with out[k].w = index in the sampled cloud in caller order.
+// Blocks until *m_host (points kept) is known.  in != out.
+hipError_t prep_sample_morton(PrepWorkspace* w, hipStream_t st, const float4* in, int n, float prob, uint32_t seed, float4* out, int* m_host);
 // pcl::ApproximateVoxelGrid (leaf x leaf x leaf) of `raw` (n points, arrival order = array order) into `out`
 // (room for n entries; out[k].w = k).  Blocks until *m_host (number of centroids) is known.
 hipError_t prep_approx_voxel_grid(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float leaf, float4* out, int* m_host);

@@ -418,6 +418,58 @@ hipError_t prep_morton_sort(PrepWorkspace* w, hipStream_t st, const float4* raw,
 }
 
 // ------------------------------------------------------------------------------------------
+// libpointmatcher's RandomSamplingDataPointsFilter (reading filter of the IcpUsingPointMatcher chain,
+// /root/reference/registrators/icp_pointmatcher.cc:170-174) on a Morton-ordered device cloud whose .w holds the caller
+// index.  The reference draws rand() per point; here a point is kept when its counter-based uniform -- a pure function
+// of (seed, CALLER index), the generator of the front-end RandomSampler in cloud_filters.hip -- is < prob, so the kept
+// set is reproducible on the host (staticmapping_amd.matcher.sampling_mask).  Output: the kept points in the input's
+// (Morton) order with .w = the point's index in the sampled cloud in CALLER order.  Two exclusive scans.
+// ------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ double sample_uniform(uint32_t seed, uint32_t i) {
+  unsigned long long z = ((unsigned long long)seed << 32 | i) + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+__global__ void sample_flags(const float4* in, int n, uint32_t seed, float prob, int32_t* by_caller, int32_t* by_pos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  by_caller[i] = (prob >= 1.0f || sample_uniform(seed, (uint32_t)i) < (double)prob) ? 1 : 0;
+  const uint32_t c = (uint32_t)__float_as_int(in[i].w);
+  by_pos[i] = (prob >= 1.0f || sample_uniform(seed, c) < (double)prob) ? 1 : 0;
+}
+__global__ void sample_scatter(const float4* in, int n, const int32_t* by_pos, const int32_t* pos_rank, const int32_t* caller_rank,
+                               float4* out, int32_t* count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (by_pos[i]) {
+    float4 p = in[i];
+    p.w = __int_as_float(caller_rank[__float_as_int(p.w)]);
+    out[pos_rank[i]] = p;
+  }
+  if (i == n - 1) count[0] = pos_rank[i] + by_pos[i];
+}
+}  // namespace
+
+hipError_t prep_sample_morton(PrepWorkspace* w, hipStream_t st, const float4* in, int n, float prob, uint32_t seed, float4* out, int* m_host) {
+  if (!w || n <= 0 || n > w->cap || in == out) return hipErrorInvalidValue;
+  const int gp = (n + 255) / 256;
+  int32_t *fc = w->order[0], *fp = w->order[1], *rc = w->seg[0], *rp = w->seg[1];
+  hipLaunchKernelGGL(sample_flags, dim3(gp), dim3(256), 0, st, in, n, seed, prob, fc, fp);
+  size_t bytes = w->sort_bytes;
+  PCHK(rocprim::exclusive_scan(w->sort_tmp, bytes, fc, rc, 0, (size_t)n, rocprim::plus<int32_t>(), st));
+  bytes = w->sort_bytes;
+  PCHK(rocprim::exclusive_scan(w->sort_tmp, bytes, fp, rp, 0, (size_t)n, rocprim::plus<int32_t>(), st));
+  hipLaunchKernelGGL(sample_scatter, dim3(gp), dim3(256), 0, st, in, n, fp, rp, rc, out, w->counts);
+  PCHK(hipMemcpyAsync(w->host_pinned, w->counts, 4, hipMemcpyDeviceToHost, st));
+  PCHK(hipStreamSynchronize(st));
+  *m_host = w->host_pinned[0];
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // pcl::ApproximateVoxelGrid<PointXYZ>::applyFilter (PCL 1.8.1, pcl/filters/impl/approximate_voxel_grid.hpp), the
 // down-sampling step of registrators/ndt_gicp.cc:60-71.  The reference loop is serial: a 512-entry hash history
 // indexed by (ix * 7171 + iy * 3079 + iz * 4231) & 511; a point that lands on an entry holding a DIFFERENT voxel

@@ -143,10 +143,10 @@ struct Half {
 };
 
 // per-call resets for pairs [0, np) (main stream, before the halves fork)
-smhip_status enqueue_resets(smhip_context* h, int np) {
+smhip_status enqueue_resets(smhip_context* h, int np, int first = 0) {
   IcpDev& d = h->dev;
-  HIPCHK(h, hipMemcpyAsync(const_cast<PairInput*>(d.in), h->in_pinned, sizeof(PairInput) * np, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(reset_scratch, dim3(std::min(4096, 256 * np)), dim3(256), 0, h->stream, d, np);
+  HIPCHK(h, hipMemcpyAsync(const_cast<PairInput*>(d.in) + first, h->in_pinned + first, sizeof(PairInput) * np, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(reset_scratch, dim3(std::min(4096, 256 * np)), dim3(256), 0, h->stream, d, first, np);
   return SMHIP_OK;
 }
 
@@ -168,9 +168,9 @@ smhip_status enqueue_grid_build(smhip_context* h, const Half& f, int nt_max) {
   return SMHIP_OK;
 }
 
-Half whole_batch(smhip_context* h, int np) {
+Half whole_batch(smhip_context* h, int np, int first = 0) {
   Half f;
-  f.d = h->dev; f.d.npairs = np; f.d.pair_base = 0;
+  f.d = h->dev; f.d.npairs = np; f.d.pair_base = first;
   f.stream = h->stream; f.np = np;
   return f;
 }
@@ -249,13 +249,13 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
   return SMHIP_OK;
 }
 
-smhip_status fill_inputs(smhip_context* h, int np, const double* guesses, int* ns_max, int* nt_max) {
+smhip_status fill_inputs(smhip_context* h, int np, const double* guesses, int* ns_max, int* nt_max, int first = 0) {
   *ns_max = 0; *nt_max = 0;
-  for (int p = 0; p < np; ++p) {
+  for (int p = first; p < first + np; ++p) {
     if (h->ns[p] <= 0 || h->nt[p] <= 0) { h->err = "Align before SetInputSource/SetInputTarget"; return SMHIP_ERR_NOT_READY; }
     if (!h->has_normals[p]) { h->err = "IcpFast target has no normals (icp_fast.cc:430)"; return SMHIP_ERR_NO_NORMALS; }
     PairInput& in = h->in_pinned[p];
-    const double* g = guesses + 16 * p;
+    const double* g = guesses + 16 * (p - first);
     for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) in.guess[4 * r + c] = g[4 * c + r];   // column-major in
     in.ns = h->ns[p]; in.nt = h->nt[p]; in.has_normals = 1; in.pad = 0;
     *ns_max = std::max(*ns_max, h->ns[p]);
@@ -533,10 +533,13 @@ smhip_status smhip_set_target_f64(smhip_handle h, int slot, const double* xyz, c
   HIPCHK(h, hipStreamSynchronize(h->stream));
   float4* sp = h->stage;
   float4* sn = h->stage + std::max(h->dev.ns_cap, h->dev.nt_cap);
+  bool finite = true;
   for (int i = 0; i < n; ++i) {
     sp[i] = make_float4((float)xyz[3 * i], (float)xyz[3 * i + 1], (float)xyz[3 * i + 2], 0.f);
     sn[i] = nrm ? make_float4((float)nrm[3 * i], (float)nrm[3 * i + 1], (float)nrm[3 * i + 2], 0.f) : make_float4(0, 0, 0, 0);
+    finite = finite && std::isfinite(sp[i].x) && std::isfinite(sp[i].y) && std::isfinite(sp[i].z);
   }
+  if (!finite) { h->err = "target cloud has NaN / Inf coordinates"; return SMHIP_ERR_INVALID_ARGUMENT; }
   s = upload(h, h->dev.tgt_p + (size_t)slot * h->dev.nt_cap, sp, n);
   if (s) return s;
   s = upload(h, h->dev.tgt_n + (size_t)slot * h->dev.nt_cap, sn, n);
@@ -556,10 +559,13 @@ smhip_status smhip_set_target_f32(smhip_handle h, int slot, const float* xyz, in
   HIPCHK(h, hipStreamSynchronize(h->stream));
   float4* sp = h->stage;
   float4* sn = h->stage + std::max(h->dev.ns_cap, h->dev.nt_cap);
+  bool finite = true;
   for (int i = 0; i < n; ++i) {
     sp[i] = make_float4(xyz[(size_t)stride * i], xyz[(size_t)stride * i + 1], xyz[(size_t)stride * i + 2], 0.f);
     sn[i] = nrm ? make_float4(nrm[(size_t)nstride * i], nrm[(size_t)nstride * i + 1], nrm[(size_t)nstride * i + 2], 0.f) : make_float4(0, 0, 0, 0);
+    finite = finite && std::isfinite(sp[i].x) && std::isfinite(sp[i].y) && std::isfinite(sp[i].z);
   }
+  if (!finite) { h->err = "target cloud has NaN / Inf coordinates"; return SMHIP_ERR_INVALID_ARGUMENT; }
   s = upload(h, h->dev.tgt_p + (size_t)slot * h->dev.nt_cap, sp, n);
   if (s) return s;
   s = upload(h, h->dev.tgt_n + (size_t)slot * h->dev.nt_cap, sn, n);
@@ -652,6 +658,40 @@ smhip_status smhip_prepare_targets_from_sources(smhip_handle h, int count, const
   return SMHIP_OK;
 }
 
+smhip_status smhip_prepare_target_from_target(smhip_handle h, int from, int to, int* n_out) {
+  smhip_status s = check_slot(h, from);
+  if (s) return s;
+  s = check_slot(h, to);
+  if (s) return s;
+  if (from == to) { h->err = "from_slot == to_slot: the raw target would be overwritten while it is read"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  if (h->nt[from] <= 0) { h->err = "target slot is empty"; return SMHIP_ERR_NOT_READY; }
+  HIPCHK(h, hipSetDevice(h->device));
+  s = prep_ensure(h);
+  if (s) return s;
+  return prep_run(h, h->dev.tgt_p + (size_t)from * h->dev.nt_cap, h->nt[from], to, n_out);
+}
+
+smhip_status smhip_sample_source(smhip_handle h, int from, int to, float prob, uint32_t seed, int* n_out) {
+  smhip_status s = check_slot(h, from);
+  if (s) return s;
+  s = check_slot(h, to);
+  if (s) return s;
+  if (from == to) { h->err = "from_slot == to_slot"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  if (h->ns[from] <= 0) { h->err = "source slot is empty"; return SMHIP_ERR_NOT_READY; }
+  if (!(prob > 0.f)) { h->err = "sampling probability must be > 0"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  HIPCHK(h, hipSetDevice(h->device));
+  s = prep_ensure(h);
+  if (s) return s;
+  int m = 0;
+  const hipError_t e = prep_sample_morton(h->prep, h->stream, h->dev.src + (size_t)from * h->dev.ns_cap, h->ns[from], prob, seed,
+                                          const_cast<float4*>(h->dev.src) + (size_t)to * h->dev.ns_cap, &m);
+  if (e != hipSuccess) { h->err = std::string("prep_sample_morton: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
+  if (m <= 0) { h->err = "sampling kept no point"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  h->ns[to] = m;
+  if (n_out) *n_out = m;
+  return SMHIP_OK;
+}
+
 smhip_status smhip_get_target_f32(smhip_handle h, int slot, float* xyz, float* normals, int n) {
   smhip_status s = check_slot(h, slot);
   if (s) return s;
@@ -696,18 +736,18 @@ static void ensure_side_streams(smhip_context* h, int n) {
 }
 
 // ---- Align -------------------------------------------------------------------------------
-smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* guesses) {
-  if (!h || !guesses || npairs < 1 || npairs > h->dev.slots) {
-    if (h) h->err = "bad npairs / guesses";
+static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const double* guesses) {
+  if (!h || !guesses || npairs < 1 || first < 0 || first + npairs > h->dev.slots) {
+    if (h) h->err = "bad slot range / guesses";
     return SMHIP_ERR_INVALID_ARGUMENT;
   }
   HIPCHK(h, hipSetDevice(h->device));
   int ns_max = 0, nt_max = 0;
   // in_pinned may still be in flight from a previous enqueue on this stream
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  smhip_status s = fill_inputs(h, npairs, guesses, &ns_max, &nt_max);
+  smhip_status s = fill_inputs(h, npairs, guesses, &ns_max, &nt_max, first);
   if (s) return s;
-  s = enqueue_resets(h, npairs);
+  s = enqueue_resets(h, npairs, first);
   if (s) return s;
   // Split the batch over several streams: the latency-bound launches of one part (finalize, validate, grid
   // build, near-empty refinement kernels) overlap the throughput-bound NN / accumulate of the others.
@@ -724,8 +764,7 @@ smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* g
     for (int k = 0; k < nh; ++k) {
       int np = (k == nh - 1) ? npairs - done : (((npairs - done) / (nh - k) + 7) / 8) * 8;
       np = std::min(np, npairs - done);
-      halves[k] = whole_batch(h, np);
-      halves[k].d.pair_base = done;
+      halves[k] = whole_batch(h, np, first + done);
       halves[k].stream = k == 0 ? h->stream : h->side[k - 1];
       done += np;
     }
@@ -785,10 +824,12 @@ smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* g
   return SMHIP_OK;
 }
 
-smhip_status smhip_icp_fetch_batch(smhip_handle h, int npairs, double* results, double* scores, smhip_icp_stats* stats) {
-  if (!h || npairs < 1 || npairs > h->dev.slots) return SMHIP_ERR_INVALID_ARGUMENT;
+smhip_status smhip_icp_enqueue_batch(smhip_handle h, int npairs, const double* guesses) { return enqueue_range(h, 0, npairs, guesses); }
+
+static smhip_status fetch_range(smhip_handle h, int first, int npairs, double* results, double* scores, smhip_icp_stats* stats) {
+  if (!h || npairs < 1 || first < 0 || first + npairs > h->dev.slots) return SMHIP_ERR_INVALID_ARGUMENT;
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipMemcpyAsync(h->state_pinned, h->dev.state, sizeof(PairState) * npairs, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->state_pinned, h->dev.state + first, sizeof(PairState) * npairs, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   collect_profile(h);
   smhip_status worst = SMHIP_OK;
@@ -808,10 +849,79 @@ smhip_status smhip_icp_fetch_batch(smhip_handle h, int npairs, double* results, 
       stats[p].searched_queries = (int32_t)st.searched_total;
       stats[p].reserved = 0;
     }
-    if (st.status != SMHIP_OK && worst == SMHIP_OK) { worst = st.status; h->err = "pair failed: no finite correspondence"; }
+    if (st.status != SMHIP_OK && worst == SMHIP_OK) {
+      worst = st.status;
+      h->err = st.status == SMHIP_ERR_INVALID_ARGUMENT ? "pair failed: target cloud has NaN / Inf coordinates" : "pair failed: no finite correspondence";
+    }
     if (!st.done && worst == SMHIP_OK) { worst = SMHIP_ERR_HIP; h->err = "pair did not finish (internal)"; }
   }
   return worst;
+}
+
+smhip_status smhip_icp_fetch_batch(smhip_handle h, int npairs, double* results, double* scores, smhip_icp_stats* stats) {
+  return fetch_range(h, 0, npairs, results, scores, stats);
+}
+
+smhip_status smhip_icp_align_range(smhip_handle h, int first_slot, int npairs, const double* guesses, double* results,
+                                   double* scores, smhip_icp_stats* stats) {
+  smhip_status s = enqueue_range(h, first_slot, npairs, guesses);
+  if (s) return s;
+  return fetch_range(h, first_slot, npairs, results, scores, stats);
+}
+
+__global__ void fill_unit_z_normals(float4* n, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) n[i] = make_float4(0.f, 0.f, 1.f, 0.f);
+}
+
+// The post-hoc score of IcpUsingPointMatcher::Align (icp_pointmatcher.cc:112-143): ONE FindClosests + TrimmedDist pass of
+// the slot's source moved by T against the slot's target; score = exp(-mean distance over the kept matches).  That is
+// exactly what a one-iteration IcpFast pass reports (its score comes from the matches made before the pose update), so
+// the pass runs through the same kernels; normals play no part in it (a target without normals gets unit-z placeholders).
+smhip_status smhip_icp_trimmed_score(smhip_handle h, int slot, const double T[16], float dist_outlier_ratio, double* score, int32_t* kept) {
+  smhip_status s = check_slot(h, slot);
+  if (s) return s;
+  if (!T || !score) return SMHIP_ERR_INVALID_ARGUMENT;
+  if (!(dist_outlier_ratio >= 0.f && dist_outlier_ratio <= 1.f)) { h->err = "dist_outlier_ratio must be in [0, 1]"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  if (h->ns[slot] <= 0 || h->nt[slot] <= 0) { h->err = "trimmed score before SetInputSource/SetInputTarget"; return SMHIP_ERR_NOT_READY; }
+  HIPCHK(h, hipSetDevice(h->device));
+  const int had = h->has_normals[slot];
+  if (!had) {
+    hipLaunchKernelGGL(fill_unit_z_normals, dim3(ceil_div(h->nt[slot], 256)), dim3(256), 0, h->stream,
+                       const_cast<float4*>(h->dev.tgt_n) + (size_t)slot * h->dev.nt_cap, h->nt[slot]);
+    h->has_normals[slot] = 1;
+  }
+  const smhip_icp_options saved = h->opts;
+  smhip_icp_options o = saved;
+  o.max_iteration = 1; o.early_exit = 0; o.dist_outlier_ratio = dist_outlier_ratio;
+  h->opts = o;
+  sync_options(h);
+  double result[16];
+  smhip_icp_stats st{};
+  s = enqueue_range(h, slot, 1, T);
+  if (s == SMHIP_OK) s = fetch_range(h, slot, 1, result, score, &st);
+  h->opts = saved;
+  sync_options(h);
+  h->has_normals[slot] = had;
+  if (kept) *kept = st.kept;
+  return s;
+}
+
+smhip_status smhip_get_capacity(smhip_handle h, int* pair_slots, int* max_source_points, int* max_target_points) {
+  if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
+  if (pair_slots) *pair_slots = h->dev.slots;
+  if (max_source_points) *max_source_points = h->dev.ns_cap;
+  if (max_target_points) *max_target_points = h->dev.nt_cap;
+  return SMHIP_OK;
+}
+
+smhip_status smhip_get_cloud_sizes(smhip_handle h, int slot, int* n_source, int* n_target, int* has_normals) {
+  smhip_status s = check_slot(h, slot);
+  if (s) return s;
+  if (n_source) *n_source = h->ns[slot];
+  if (n_target) *n_target = h->nt[slot];
+  if (has_normals) *has_normals = h->has_normals[slot];
+  return SMHIP_OK;
 }
 
 smhip_status smhip_icp_align_batch(smhip_handle h, int npairs, const double* guesses, double* results, double* scores,

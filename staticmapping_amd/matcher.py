@@ -387,10 +387,14 @@ class IcpPointMatcherHip:
     reference with the same trimmed filter (:112-143) and Align returns score >= 0.6 (:145-148).
     """
 
-    def __init__(self, device: int = 0, max_points: int = 262144, prob: float = 0.9, seed: int | None = 0, **options):
-        self._m = IcpFastHip(device=device, pair_slots=1, max_source_points=max_points, max_target_points=max_points, **options)
+    def __init__(self, device: int = 0, max_points: int = 262144, prob: float = 0.9, seed: int | None = 0,
+                 device_chain: bool = True, **options):
+        # slot 0: the ICP pair (sampled reading vs CalculateNormals(reference)); slot 1: the score pair (full reading vs
+        # raw reference).  Each cloud goes up once; sampling, normals and the score pass stay on the device.
+        self._m = IcpFastHip(device=device, pair_slots=2, max_source_points=max_points, max_target_points=max_points, **options)
         self.prob = prob
         self.seed = seed
+        self.device_chain = device_chain
         self.final_score_ = float("nan")
         self._reading = None
         self._reference = None
@@ -408,24 +412,53 @@ class IcpPointMatcherHip:
         self._reference = a[~np.isnan(a[:, :3]).any(axis=1)]
 
     def sampling_mask(self, n: int) -> np.ndarray:
+        """The kept set of the device sampler (smhip_sample_source): uniform = splitmix64(seed << 32 | i) >> 11 * 2^-53,
+        kept when < prob.  A pure function of (seed, row), so the oracle can be handed the same mask."""
         if self.prob >= 1.0:
             return np.ones(n, dtype=bool)
-        return np.random.default_rng(self.seed).random(n) < self.prob
+        seed = np.uint64((0 if self.seed is None else int(self.seed)) & 0xffffffff)
+        with np.errstate(over="ignore"):
+            z = (seed << np.uint64(32) | np.arange(n, dtype=np.uint64)) + np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+        u = (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        return u < np.float64(np.float32(self.prob))
 
     def align(self, guess=None):
         if self._reading is None or self._reference is None:
             raise SmhipError(4, "Align before SetInputSource/SetInputTarget")
         m = self._m
+        lib, h = m._lib, m._h
         G = np.eye(4) if guess is None else np.asarray(guess, dtype=np.float64)
-        # ---- pm_icp_.compute(reading, reference, guess)                                :107-110
         self.last_mask = self.sampling_mask(len(self._reading))
-        q, n = calculate_normals(self._reference[:, :3].astype(np.float64))
         m.set_options(max_iteration=150, dist_outlier_ratio=0.7, early_exit=1)
+        if self.device_chain:
+            m.set_input_source(np.ascontiguousarray(self._reading), slot=1)
+            m.set_input_target(np.ascontiguousarray(self._reference[:, :3]), None, slot=1)
+            n_out = ctypes.c_int32()
+            seed = (0 if self.seed is None else int(self.seed)) & 0xffffffff
+            m._check(lib.smhip_sample_source(h, 1, 0, float(self.prob), seed, ctypes.byref(n_out)))      # reading filter :170-174
+            assert n_out.value == int(self.last_mask.sum()), (n_out.value, int(self.last_mask.sum()))
+            m._check(lib.smhip_prepare_target_from_target(h, 1, 0, ctypes.byref(n_out)))                  # reference filter :176-184
+            self.target_points = n_out.value
+            # ---- pm_icp_.compute(reading, reference, guess)                            :107-110
+            _, result = m.align(G)
+            self.iterations = m.last_stats[0]["iterations"]
+            # ---- final score: full reading, raw reference, one trimmed matching pass    :112-143
+            Tc = np.asfortranarray(result, dtype=np.float64)
+            score = ctypes.c_double()
+            kept = ctypes.c_int32()
+            m._check(lib.smhip_icp_trimmed_score(h, 1, Tc.ctypes.data_as(_capi.c_double_p), 0.7, ctypes.byref(score), ctypes.byref(kept)))
+            self.final_score_ = score.value
+            self.score_kept = kept.value
+            return self.final_score_ >= 0.6, result                                    # :145-148
+        # host-side chain (kept for A/B tests of the device chain): host CalculateNormals, four uploads, a second Align
+        q, n = calculate_normals(self._reference[:, :3].astype(np.float64))
         m.set_input_source(np.ascontiguousarray(self._reading[self.last_mask]))
         m.set_input_target(q, n)
         _, result = m.align(G)
         self.iterations = m.last_stats[0]["iterations"]
-        # ---- final score: full reading, raw reference, one trimmed matching pass        :112-143
         m.set_options(max_iteration=1, early_exit=0)
         m.set_input_source(np.ascontiguousarray(self._reading))
         ref = self._reference[:, :3].astype(np.float64)

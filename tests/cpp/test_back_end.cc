@@ -53,6 +53,20 @@ int main(int argc, char** argv) {
   const auto sub = smhip::back_end::SubmapPairMatch(mopt, source, spose, target, tpose);
   const auto sub_far = smhip::back_end::SubmapPairMatch(mopt, source, far, target, tpose);
 
+  // the same two pairs as ONE batch through a matcher that outlives it (SubmapPairMatchBatch), twice (arena reuse)
+  auto pool_matcher = reg::CreateMatcher(mopt, false);
+  std::vector<smhip::back_end::SubmapPairJob> jobs(2);
+  jobs[0].source_submap_cloud = source; jobs[0].target_submap_cloud = target; jobs[0].source_first_frame_pose = spose; jobs[0].target_first_frame_pose = tpose;
+  jobs[1] = jobs[0]; jobs[1].source_first_frame_pose = far;
+  auto batch = smhip::back_end::SubmapPairMatchBatch(mopt, pool_matcher, jobs);
+  batch = smhip::back_end::SubmapPairMatchBatch(mopt, pool_matcher, jobs);
+  // a loop-closure matcher that outlives its candidates
+  reg::IcpPointMatcherHip keep_matcher(settings.device, 1 << 12);            // deliberately too small: must re-size itself
+  keep_matcher.InitWithOptions();
+  smhip::back_end::LoopEdge edge2, bad_edge2;
+  const bool closed2 = smhip::back_end::CloseLoop(tpose, target, spose, source, settings, &edge2, &keep_matcher);
+  const bool closed_far2 = smhip::back_end::CloseLoop(tpose, target, far, source, settings, &bad_edge2, &keep_matcher);
+
   std::printf("{\"closed\": %s, \"edge_score\": %.17g, \"closed_far\": %s, ", closed ? "true" : "false", edge.score, closed_far ? "true" : "false");
   PrintMatrix("edge_guess", edge.init_guess);
   PrintMatrix("edge_transform", edge.transform);
@@ -61,6 +75,12 @@ int main(int argc, char** argv) {
   PrintMatrix("sub_guess", sub.guess);
   PrintMatrix("sub_far_transform", sub_far.transform_to_next);
   PrintMatrix("sub_far_guess", sub_far.guess);
+  std::printf("\"batch_accepted\": [%s, %s], \"batch_score\": [%.17g, %.17g], \"closed2\": %s, \"closed_far2\": %s, \"edge2_score\": %.17g, ",
+              batch[0].accepted ? "true" : "false", batch[1].accepted ? "true" : "false", batch[0].match_score, batch[1].match_score,
+              closed2 ? "true" : "false", closed_far2 ? "true" : "false", edge2.score);
+  PrintMatrix("batch0_transform", batch[0].transform_to_next);
+  PrintMatrix("batch1_transform", batch[1].transform_to_next);
+  PrintMatrix("edge2_transform", edge2.transform);
   PrintMatrix("sub_transform", sub.transform_to_next, true);
   std::printf("}\n");
   return 0;

@@ -49,14 +49,12 @@ def _submaps():
 
 
 def _cpp_sampling_mask(n, prob=0.9, seed=0):
-    """The reading filter of the C++ IcpPointMatcherHip (include/smhip/registrator.h): one LCG draw per point."""
-    state = (seed * 2654435761 + 12345) & 0xffffffff
-    keep = np.zeros(n, dtype=bool)
-    p32 = np.float32(prob)
-    for i in range(n):
-        state = (state * 1664525 + 1013904223) & 0xffffffff
-        keep[i] = np.float32(state >> 8) * np.float32(1.0 / 16777216.0) < p32
-    return keep
+    """The reading filter of the C++ IcpPointMatcherHip = smhip_sample_source: a pure function of (seed, row), the same
+    generator the Python mirror exposes."""
+    import staticmapping_amd as sm
+    m = sm.IcpPointMatcherHip.__new__(sm.IcpPointMatcherHip)
+    m.prob, m.seed = prob, seed
+    return m.sampling_mask(n)
 
 
 @pytest.mark.gpu
@@ -78,8 +76,7 @@ def test_close_loop_and_submap_pair_match(tmp_path, matcher_type):
     assert abs(res["edge_score"]) < -np.log(0.8)                  # edge score = -log(match score), score > 0.8
     da, dt = sm.se3_error(M("edge_transform"), T)
     assert da < 3e-3 and dt < 5e-2, (da, dt)
-    # the same candidate through the Python mirror of IcpUsingPointMatcher (its RandomSampling draws differ from the
-    # C++ mirror's, as they do between two runs of the reference: agreement to the matcher's own repeatability)
+    # the same candidate through the Python mirror of IcpUsingPointMatcher (same device chain, same seed -> same draws)
     pm = sm.IcpPointMatcherHip(max_points=1 << 18)
     pm.set_input_source(src); pm.set_input_target(tgt)
     ok, Rp = pm.align(M("edge_guess"))
@@ -116,3 +113,13 @@ def test_close_loop_and_submap_pair_match(tmp_path, matcher_type):
     assert da < 3e-3 and dt < 5e-2, (da, dt)
     assert not res["sub_far_accepted"] and res["sub_far_score"] < 0.7
     assert np.array_equal(M("sub_far_transform"), M("sub_far_guess"))
+    # the two pairs as one batch through a pooled matcher (SubmapPairMatchBatch) = the two single calls
+    assert res["batch_accepted"] == [True, False]
+    da, dt = sm.se3_error(M("batch0_transform"), M("sub_transform"))
+    assert da < 1e-7 and dt < 1e-6, ("batch vs single", da, dt)
+    assert abs(res["batch_score"][0] - res["sub_score"]) < 1e-7 and abs(res["batch_score"][1] - res["sub_far_score"]) < 1e-7
+    assert np.array_equal(M("batch1_transform"), M("sub_far_guess"))
+    # CloseLoop through a matcher that outlives its candidates and started with a 4096-point arena
+    assert res["closed2"] and not res["closed_far2"]
+    da, dt = sm.se3_error(M("edge2_transform"), M("edge_transform"))
+    assert da < 1e-9 and dt < 1e-9 and abs(res["edge2_score"] - res["edge_score"]) < 1e-12

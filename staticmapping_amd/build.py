@@ -11,6 +11,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsmhip.so")
+SHARD_EXE = os.path.join(LIB_DIR, "smhip_shard")          # C++ sharded sequence driver (RCCL gather), csrc/shard_driver.cc
 
 HIP_SOURCES = ["smhip_api.hip", "prep_normals.hip", "cloud_filters.hip", "host_cloud.cc"]            # translation units (each may #include kernel files)
 HIP_DEPS = ["icp_kernels.hip", "smhip_device.h", "host_cloud.cc", "prep_normals.h", "ndt_kernels.hip", "smhip_ndt_api.hip",
@@ -36,9 +37,24 @@ def needs_build() -> bool:
     return False
 
 
+def build_shard_driver(force: bool = False, verbose: bool = False) -> str:
+    """The C++ host program of BASELINE config #4: links libsmhip.so + librccl.so (no device code of its own)."""
+    src = os.path.join(CSRC, "shard_driver.cc")
+    deps = [src, os.path.join(ROOT, "include", "smhip.h"), LIB_PATH]
+    if not force and os.path.exists(SHARD_EXE) and all(os.path.getmtime(d) <= os.path.getmtime(SHARD_EXE) for d in deps):
+        return SHARD_EXE
+    cmd = [_hipcc(), "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", SHARD_EXE,
+           "-L", LIB_DIR, "-lsmhip", "-L", "/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return SHARD_EXE
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP translation unit for gfx950 into staticmapping_amd/lib/libsmhip.so."""
+    """Compile every HIP translation unit for gfx950 into staticmapping_amd/lib/libsmhip.so (+ the smhip_shard driver)."""
     if not force and not needs_build():
+        build_shard_driver(False, verbose)
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
@@ -47,6 +63,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    build_shard_driver(True, verbose)
     return LIB_PATH
 
 

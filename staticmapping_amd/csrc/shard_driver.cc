@@ -1,0 +1,275 @@
+// shard_driver.cc -- BASELINE config #4 as a C++ program: scan-to-scan ICP over a KITTI-format sequence, consecutive pairs
+// dealt round-robin over the GPUs of one node, ONE RCCL all-gather of the resulting SE(3) poses.
+//
+// Reference pieces either side of the registration path that this driver stands in for:
+//   ros_node/kitti_reader.cc:91-149   `.bin` scans: float32 rows x y z reflectance, at most 1 000 000 floats per file,
+//                                      files in sorted directory order
+//   builder/map_builder.cc:354        pose_source = pose_target * align_result
+//   builder/map_builder.cc:626-641    kitti_pose.txt: 12 floats per line (row-major top 3x4), setprecision(8)
+// The reference itself has no multi-GPU path (its front end is one sequential thread); pairs are independent here because
+// every pair's guess is fixed up front (identity or a constant forward step), as SURVEY.md §8(e) lays out.
+//
+// One process per GPU.  `smhip_shard --gpus G ...` re-executes itself G times (rank r on device r); the ranks can also be
+// started by any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK (torchrun's variables).  The ncclUniqueId travels from
+// rank 0 to the others through a small file (--id-file, default under /tmp): no MPI, no sockets of our own.
+// All arithmetic happens behind the C ABI of include/smhip.h; the gather is ncclAllGather on the doubles
+// smhip_icp_export_results_device leaves in device memory -- the poses never visit the host before the collective.
+#include <dirent.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/smhip.h"
+
+namespace {
+
+constexpr int kPoseDoubles = 18;                 // 16 column-major transform + score + iterations
+constexpr size_t kMaxFloatsPerFile = 1000000;    // kitti_reader.cc:93
+
+struct Args {
+  std::string scans_dir, out_path = "kitti_pose.txt", id_file;
+  int gpus = 1, rank = -1, world = -1, local_rank = -1;
+  int batch = 64, iterations = 20, early_exit = 0, max_pairs = -1;
+  double guess_tx = 0.0;
+  bool quiet = false;
+};
+
+[[noreturn]] void Die(const std::string& m) { std::fprintf(stderr, "smhip_shard: %s\n", m.c_str()); std::exit(2); }
+
+#define HIPOK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) Die(std::string(#e) + ": " + hipGetErrorString(e_)); } while (0)
+#define NCCLOK(e) do { ncclResult_t r_ = (e); if (r_ != ncclSuccess) Die(std::string(#e) + ": " + ncclGetErrorString(r_)); } while (0)
+
+std::vector<std::string> ListScans(const std::string& dir) {            // kitti_reader.cc:124-131: sorted listing
+  std::vector<std::string> files;
+  DIR* d = opendir(dir.c_str());
+  if (!d) Die("cannot open " + dir);
+  while (dirent* e = readdir(d)) {
+    const std::string n = e->d_name;
+    if (n.size() > 4 && n.compare(n.size() - 4, 4, ".bin") == 0) files.push_back(dir + "/" + n);
+  }
+  closedir(d);
+  std::sort(files.begin(), files.end());
+  return files;
+}
+
+int ReadBin(const std::string& path, std::vector<float>* rows) {        // kitti_reader.cc:91-121
+  std::ifstream f(path, std::ios::binary);
+  if (!f) Die("cannot read " + path);
+  rows->resize(kMaxFloatsPerFile);
+  f.read(reinterpret_cast<char*>(rows->data()), sizeof(float) * kMaxFloatsPerFile);
+  const size_t got = static_cast<size_t>(f.gcount()) / sizeof(float);
+  const int n = static_cast<int>(got / 4);
+  rows->resize(static_cast<size_t>(n) * 4);
+  return n;
+}
+
+void Mul4(const double* a, const double* b, double* out) {              // row-major 4x4
+  double r[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) { double s = 0; for (int k = 0; k < 4; ++k) s += a[4 * i + k] * b[4 * k + j]; r[4 * i + j] = s; }
+  std::memcpy(out, r, sizeof(r));
+}
+
+Args Parse(int argc, char** argv) {
+  Args a;
+  for (int i = 1; i < argc; ++i) {
+    const std::string k = argv[i];
+    auto val = [&]() -> std::string { if (i + 1 >= argc) Die("missing value for " + k); return argv[++i]; };
+    if (k == "--scans") a.scans_dir = val();
+    else if (k == "--out") a.out_path = val();
+    else if (k == "--gpus") a.gpus = std::atoi(val().c_str());
+    else if (k == "--rank") a.rank = std::atoi(val().c_str());
+    else if (k == "--world") a.world = std::atoi(val().c_str());
+    else if (k == "--local-rank") a.local_rank = std::atoi(val().c_str());
+    else if (k == "--id-file") a.id_file = val();
+    else if (k == "--batch") a.batch = std::atoi(val().c_str());
+    else if (k == "--iterations") a.iterations = std::atoi(val().c_str());
+    else if (k == "--early-exit") a.early_exit = std::atoi(val().c_str());
+    else if (k == "--max-pairs") a.max_pairs = std::atoi(val().c_str());
+    else if (k == "--guess-tx") a.guess_tx = std::atof(val().c_str());
+    else if (k == "--quiet") a.quiet = true;
+    else Die("unknown argument " + k + "\nusage: smhip_shard --scans DIR [--gpus G] [--out kitti_pose.txt] [--batch 64] "
+             "[--iterations 20] [--early-exit 0|1] [--guess-tx metres] [--max-pairs N]");
+  }
+  if (a.scans_dir.empty()) Die("--scans DIR is required");
+  if (a.rank < 0 && std::getenv("RANK")) a.rank = std::atoi(std::getenv("RANK"));
+  if (a.world < 0 && std::getenv("WORLD_SIZE")) a.world = std::atoi(std::getenv("WORLD_SIZE"));
+  if (a.local_rank < 0 && std::getenv("LOCAL_RANK")) a.local_rank = std::atoi(std::getenv("LOCAL_RANK"));
+  return a;
+}
+
+// rank 0 creates the communicator id and publishes it; the others wait for the file
+ncclUniqueId ExchangeId(const Args& a, int rank) {
+  ncclUniqueId id;
+  if (rank == 0) {
+    NCCLOK(ncclGetUniqueId(&id));
+    const std::string tmp = a.id_file + ".tmp";
+    std::ofstream f(tmp, std::ios::binary);
+    f.write(reinterpret_cast<const char*>(&id), sizeof(id));
+    f.close();
+    if (std::rename(tmp.c_str(), a.id_file.c_str()) != 0) Die("cannot publish " + a.id_file);
+    return id;
+  }
+  for (int tries = 0; tries < 6000; ++tries) {                           // <= 60 s
+    std::ifstream f(a.id_file, std::ios::binary);
+    if (f && f.read(reinterpret_cast<char*>(&id), sizeof(id)) && f.gcount() == static_cast<std::streamsize>(sizeof(id))) return id;
+    usleep(10000);
+  }
+  Die("timed out waiting for " + a.id_file);
+}
+
+int RunRank(const Args& a, int rank, int world, int device) {
+  const auto files = ListScans(a.scans_dir);
+  if (files.size() < 2) Die("need at least two scans in " + a.scans_dir);
+  int n_pairs = static_cast<int>(files.size()) - 1;
+  if (a.max_pairs > 0) n_pairs = std::min(n_pairs, a.max_pairs);
+  const int per = (n_pairs + world - 1) / world;                         // padded pairs per rank
+
+  HIPOK(hipSetDevice(device));
+  ncclComm_t comm;
+  const ncclUniqueId id = ExchangeId(a, rank);
+  NCCLOK(ncclCommInitRank(&comm, world, id, rank));
+
+  hipStream_t stream;
+  HIPOK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  const int B = std::max(1, std::min(a.batch, per));
+  smhip_handle h = nullptr;
+  // capacity: a KITTI scan holds at most 250 000 points (1 000 000 floats per file)
+  const int cap = static_cast<int>(kMaxFloatsPerFile / 4);
+  smhip_status s = smhip_create(device, stream, B, cap, cap, &h);
+  if (s != SMHIP_OK) Die(std::string("smhip_create: ") + smhip_status_string(s) + " (is this a gfx950 GPU? there is no CPU fallback)");
+  smhip_icp_options o;
+  smhip_icp_default_options(&o);
+  o.max_iteration = a.iterations;
+  o.early_exit = a.early_exit;
+  if (smhip_icp_set_options(h, &o) != SMHIP_OK) Die(smhip_last_error(h));
+
+  double* local_dev = nullptr;
+  double* all_dev = nullptr;
+  HIPOK(hipMalloc(reinterpret_cast<void**>(&local_dev), sizeof(double) * kPoseDoubles * per));
+  HIPOK(hipMalloc(reinterpret_cast<void**>(&all_dev), sizeof(double) * kPoseDoubles * per * world));
+  HIPOK(hipMemsetAsync(local_dev, 0, sizeof(double) * kPoseDoubles * per, stream));
+
+  // guess: column-major 4x4; identity or a constant forward step (SURVEY.md §8(d) cfg 4; the reference front end always
+  // hands its matcher an extrapolated pose, map_builder.cc:302-308)
+  std::vector<double> guesses(16 * static_cast<size_t>(B), 0.0);
+  for (int k = 0; k < B; ++k) { double* g = &guesses[16 * static_cast<size_t>(k)]; g[0] = g[5] = g[10] = g[15] = 1.0; g[12] = a.guess_tx; }
+
+  std::vector<float> rows;
+  const auto t0 = std::chrono::steady_clock::now();
+  double upload_s = 0.0;
+  int done = 0, my_pairs = 0;
+  for (int base = 0; base < per; base += B) {
+    int nb = 0;
+    for (int k = 0; k < B && base + k < per; ++k) {
+      const int pair = (base + k) * world + rank;                        // round-robin: pair i -> rank i mod G
+      if (pair >= n_pairs) break;
+      const auto u0 = std::chrono::steady_clock::now();
+      int nt = 0;
+      int n = ReadBin(files[pair], &rows);                               // scan i = target (device CalculateNormals)
+      if (smhip_prepare_target_f32(h, k, rows.data(), 4, n, &nt) != SMHIP_OK) Die(std::string("target ") + files[pair] + ": " + smhip_last_error(h));
+      n = ReadBin(files[pair + 1], &rows);                               // scan i + 1 = source
+      if (smhip_set_source_f32(h, k, rows.data(), 4, n) != SMHIP_OK) Die(std::string("source ") + files[pair + 1] + ": " + smhip_last_error(h));
+      upload_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - u0).count();
+      ++nb;
+    }
+    if (nb == 0) break;
+    if (smhip_icp_enqueue_batch(h, nb, guesses.data()) != SMHIP_OK) Die(std::string("enqueue: ") + smhip_last_error(h));
+    if (smhip_icp_export_results_device(h, nb, local_dev + static_cast<size_t>(kPoseDoubles) * base) != SMHIP_OK) Die(smhip_last_error(h));
+    done = base + nb;
+    my_pairs += nb;
+  }
+  (void)done;
+  // the ONE collective of the path: every rank's padded block of poses, device to device over xGMI
+  NCCLOK(ncclAllGather(local_dev, all_dev, static_cast<size_t>(kPoseDoubles) * per, ncclDouble, comm, stream));
+  HIPOK(hipStreamSynchronize(stream));
+  const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+  int rc = 0;
+  if (rank == 0) {
+    std::vector<double> all(static_cast<size_t>(kPoseDoubles) * per * world);
+    HIPOK(hipMemcpy(all.data(), all_dev, sizeof(double) * all.size(), hipMemcpyDeviceToHost));
+    // rank r, local slot s -> pair s * world + r;  chain pose_{i+1} = pose_i * T_i
+    std::ofstream out(a.out_path);
+    if (!out) Die("cannot write " + a.out_path);
+    out.precision(8);
+    double pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    auto write_pose = [&]() {
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) out << pose[4 * r + c] << ((r == 2 && c == 3) ? "\n" : " ");
+    };
+    write_pose();
+    double score_sum = 0.0, iter_sum = 0.0;
+    int bad = 0;
+    for (int pair = 0; pair < n_pairs; ++pair) {
+      const double* row = &all[static_cast<size_t>(kPoseDoubles) * (static_cast<size_t>(pair % world) * per + pair / world)];
+      double T[16];
+      for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) T[4 * r + c] = row[4 * c + r];   // column-major -> row-major
+      if (!(row[17] >= 1.0)) ++bad;                                      // a pair that never ran left zeros
+      Mul4(pose, T, pose);
+      write_pose();
+      score_sum += row[16]; iter_sum += row[17];
+    }
+    out.close();
+    if (!a.quiet || bad) {
+      std::printf("{\"driver\": \"smhip_shard (C++, RCCL all-gather)\", \"n_gpus\": %d, \"pairs\": %d, \"pairs_rank0\": %d, \"seconds\": %.4f, "
+                  "\"pairs_per_s\": %.2f, \"read_upload_prepare_s_rank0\": %.4f, \"mean_score\": %.6f, \"mean_iterations\": %.2f, "
+                  "\"unfinished_pairs\": %d, \"poses_file\": \"%s\"}\n",
+                  world, n_pairs, my_pairs, elapsed, n_pairs / elapsed, upload_s, score_sum / n_pairs, iter_sum / n_pairs, bad, a.out_path.c_str());
+    }
+    if (bad) rc = 3;
+    if (world > 1) std::remove(a.id_file.c_str());
+  }
+  (void)hipFree(local_dev); (void)hipFree(all_dev);
+  smhip_destroy(h);
+  NCCLOK(ncclCommDestroy(comm));
+  (void)hipStreamDestroy(stream);
+  return rc;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  Args a = Parse(argc, argv);
+  if (a.id_file.empty()) a.id_file = "/tmp/smhip_shard_id_" + std::to_string(a.rank >= 0 ? static_cast<long>(getppid()) : static_cast<long>(getpid()));
+  if (a.rank >= 0) {                                                     // one rank of a launched group
+    const int world = a.world > 0 ? a.world : 1;
+    return RunRank(a, a.rank, world, a.local_rank >= 0 ? a.local_rank : a.rank);
+  }
+  if (a.gpus <= 1) { std::remove(a.id_file.c_str()); return RunRank(a, 0, 1, 0); }
+  // launcher: one child process per GPU (fresh processes -- no HIP state is inherited across the fork)
+  std::remove(a.id_file.c_str());
+  std::vector<pid_t> kids;
+  for (int r = 0; r < a.gpus; ++r) {
+    const pid_t pid = fork();
+    if (pid < 0) Die("fork failed");
+    if (pid == 0) {
+      std::vector<std::string> args(argv, argv + argc);
+      args.push_back("--rank"); args.push_back(std::to_string(r));
+      args.push_back("--world"); args.push_back(std::to_string(a.gpus));
+      args.push_back("--local-rank"); args.push_back(std::to_string(r));
+      args.push_back("--id-file"); args.push_back(a.id_file);
+      std::vector<char*> cargs;
+      for (auto& s : args) cargs.push_back(const_cast<char*>(s.c_str()));
+      cargs.push_back(nullptr);
+      execv("/proc/self/exe", cargs.data());
+      std::perror("execv");
+      _exit(127);
+    }
+    kids.push_back(pid);
+  }
+  int rc = 0;
+  for (pid_t k : kids) { int st = 0; waitpid(k, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = rc ? rc : (WIFEXITED(st) ? WEXITSTATUS(st) : 1); }
+  return rc;
+}

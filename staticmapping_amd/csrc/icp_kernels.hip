@@ -373,7 +373,10 @@ __device__ __forceinline__ void test_ascending(const float4 t, int j, float qx, 
 // every float min / max, but cost nn_ball_lds 36 more bytes of scratch per lane at its 80-VGPR budget and 6 % of its speed.)
 __device__ __forceinline__ void test_ascending_ru(const float4 t, int j, float qx, float qy, float qz, Best& best) {
   const float d = dist2(t, qx, qy, qz);
-  best.s2 = fminf(best.s2, fmaxf(d, best.d2));     // d < best: old best becomes runner-up; else d competes for runner-up
+  // (best, runner-up) = the two smallest of {best, runner-up, d}; best <= runner-up always holds, so the new runner-up is
+  // the median of the three: ONE v_med3_f32 instead of max + min with a canonicalising v_max_f32 x, x in front of each
+  // (3 of the 15 vector instructions per candidate).  Distances are never NaN here (finite queries, finite targets).
+  best.s2 = __builtin_amdgcn_fmed3f(d, best.d2, best.s2);
   if (d < best.d2) { best.d2 = d; best.j = j; }
 }
 // two candidates per step with packed fp32 (v_pk_add/mul/fma_f32): 6 instead of 9 VALU per candidate
@@ -734,6 +737,9 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
   const int ns = st->ns;
   const int base = blk * (kNnThreads * ITEMS);
   if (base >= ns) return;
+  double Mc[12], Mp[12];                 // read before the first store: scalar loads, held in SGPRs (see nn_ball_lds)
+#pragma unroll
+  for (int k = 0; k < 12; ++k) { Mc[k] = st->M[k]; Mp[k] = st->M_prev[k]; }
   __shared__ uint32_t s_hist[kHistBins];
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
   __syncthreads();
@@ -750,8 +756,8 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
       const float l = b.lb[so + i];
       const int j = b.idx[so + i];
       double px, py, pz, ox_, oy_, oz_;
-      transform_point(st->M, s, px, py, pz);
-      transform_point(st->M_prev, s, ox_, oy_, oz_);
+      transform_point(Mc, s, px, py, pz);
+      transform_point(Mp, s, ox_, oy_, oz_);
       const float qx = (float)px, qy = (float)py, qz = (float)pz;
       const float ex = qx - (float)ox_, ey = qy - (float)oy_, ez = qz - (float)oz_;
       const float delta = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
@@ -842,6 +848,13 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
   const int ns = st->ns;
   const int base0 = blk * (kNnThreads * ITEMS);
   if (base0 >= ns) return;
+  // The two transforms are read HERE, before the kernel's first store: the compiler then knows nothing has clobbered them,
+  // loads them through the scalar cache into SGPRs once, and the rounds below transform from registers.  Read inside the
+  // loop (behind the rounds' global stores) each lane fetched the same 2 x 96 bytes with six 16-byte vector loads per
+  // transform and round.
+  double Mc[12], Mp[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) { Mc[k] = st->M[k]; Mp[k] = st->M_prev[k]; }
   __shared__ uint32_t s_hist[kHistBins];
   __shared__ uint32_t s_tab[kLdsTableCap];
   __shared__ float4 s_pts[kLdsPointCap];
@@ -900,7 +913,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
     bool valid = false;
     if (i < ns) {
       double px, py, pz;
-      transform_point(st->M, s_cur, px, py, pz);
+      transform_point(Mc, s_cur, px, py, pz);
       qx = (float)px; qy = (float)py; qz = (float)pz;
       valid = isfinite(qx) && isfinite(qy) && isfinite(qz);
     }
@@ -914,7 +927,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
     float delta = 0.03f;                                   // first iteration: no motion history yet
     if (have_prev && valid) {
       double ox_, oy_, oz_;
-      transform_point(st->M_prev, s_cur, ox_, oy_, oz_);
+      transform_point(Mp, s_cur, ox_, oy_, oz_);
       const float ex = qx - (float)ox_, ey = qy - (float)oy_, ez = qz - (float)oz_;
       delta = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
     }
@@ -1061,8 +1074,8 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
               const int rb = r * nxl - X0;
               const uint32_t g0 = s_tab[rb + X0];
               const uint32_t k0 = s_roff[r] + (s_tab[rb + x0] - g0), k1 = s_roff[r] + (s_tab[rb + x1 + 1] - g0);
-              for (uint32_t k = k0; k < k1; ++k) {
-                const float4 t = s_pts[k];
+              for (const float4 *tp = s_pts + k0, *te = s_pts + k1; tp < te; ++tp) {     // one induction variable: the LDS address
+                const float4 t = *tp;
                 test_ascending_ru(t, __float_as_int(t.w), qx, qy, qz, best);
               }
             } else if (use_lds) {
@@ -1658,6 +1671,9 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
   const int ns = st->ns;
   const int base = blk * (kAccThreads * ITEMS);
   if (base >= ns) return;
+  double Mc[12];                         // read before the first store: scalar loads, held in SGPRs (see nn_ball_lds)
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Mc[k] = st->M[k];
   __shared__ uint32_t s_w[17];
   __shared__ uint32_t s_q[4];
   __shared__ double s_red[4][29];
@@ -1695,7 +1711,7 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
       const uint32_t key = __float_as_uint(d);
       if (key < 0x7f800000u) {
         const uint32_t bin = key >> kHistShift;
-        if (bin < qbin) accumulate_terms(st->M, s4, b.tq[to + j], b.tn[to + j], d, acc);
+        if (bin < qbin) accumulate_terms(Mc, s4, b.tq[to + j], b.tn[to + j], d, acc);
         else boundary = bin == qbin;
       }
     }

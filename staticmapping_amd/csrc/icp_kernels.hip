@@ -839,6 +839,19 @@ __device__ __forceinline__ void sweep_run(const float4* __restrict__ tq, uint32_
 
 // ITEMS = rounds of 256 queries per workgroup: 4 for batches (fewer histogram flushes, prefetch across rounds), 1 when a
 // launch would otherwise have too few workgroups to fill the GPU (single pairs: 118 -> 469 workgroups for 120 k points).
+// Diagnostic, compiled out by default (hipcc -DSMHIP_PHASE_TIMING=1, then run with SMHIP_DEBUG_FLAGS=16): per-wave s_memtime
+// deltas per phase of a round, summed into 8 u64 counters that live in the (idle during the iterations) tpart scratch of
+// slot 0; finalize prints their shares and clears them.  What it showed (64 pairs, iterations 1-4, nearly every query
+// searching): prologue + prefetch 13 %, phase C + compaction 13 %, wait at barrier A 9 %, search-lane setup + box 12 %,
+// staging between barriers B and C 22 %, the search itself 20 %, stores 5 %, histogram flush 6 % -- no phase dominates.
+#ifndef SMHIP_PHASE_TIMING
+#define SMHIP_PHASE_TIMING 0
+#endif
+#if SMHIP_PHASE_TIMING
+#define SMHIP_PHASE(k) do { if (timing) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[k] += now_ - tprev; tprev = now_; } } while (0)
+#else
+#define SMHIP_PHASE(k) do { } while (0)
+#endif
 template <int ITEMS>
 __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk) {
   int pair, blk;
@@ -855,6 +868,11 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
   double Mc[12], Mp[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) { Mc[k] = st->M[k]; Mp[k] = st->M_prev[k]; }
+#if SMHIP_PHASE_TIMING
+  const bool timing = (b.debug_flags & 16) != 0;
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = timing ? __builtin_readcyclecounter() : 0ull;
+#endif
   __shared__ uint32_t s_hist[kHistBins];
   __shared__ uint32_t s_tab[kLdsTableCap];
   __shared__ float4 s_pts[kLdsPointCap];
@@ -908,6 +926,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
       s_next = b.src[so + i_next];
       if (have_prev) { jp_next = b.idx[so + i_next]; if (certify) l_next = b.lb[so + i_next]; }
     }
+    SMHIP_PHASE(0);      // prologue / prefetch issue
     // ---- phase C (every lane): query, previous match, certificate
     float qx = 0.f, qy = 0.f, qz = 0.f;
     bool valid = false;
@@ -975,7 +994,9 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
         if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
       }
     }
+    SMHIP_PHASE(1);      // phase C + compaction
     __syncthreads();                                      // (A) search list complete
+    SMHIP_PHASE(2);      // wait at barrier A
     const int nq = (int)*nsearch;
     if (threadIdx.x == 0 && nq) atomicAdd(&st->deferred_count, (uint32_t)nq);     // statistics only
     // ---- phase S: the first nq threads own one searching query each
@@ -1006,6 +1027,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
         atomicMax(&box[3], mx1); atomicMax(&box[4], my1); atomicMax(&box[5], mz1);
       }
     }
+    SMHIP_PHASE(3);      // search-lane setup + box
     __syncthreads();                                      // (B) box complete
     const int X0 = box[0], Y0 = box[1], Z0 = box[2];
     const int nxl = box[3] - X0 + 2, nyl = box[4] - Y0 + 1, nzl = box[5] - Z0 + 1;     // one extra x column
@@ -1056,6 +1078,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
       }
     }
     __syncthreads();                                      // (C) table / points staged
+    SMHIP_PHASE(4);      // barrier B + staging + barrier C
     // search (threads < nq)
     bool hard2 = false;
     if (mine) {
@@ -1102,6 +1125,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
         hard2 = true;
         min_lb = min(min_lb, __float_as_uint(R2));
       }
+      SMHIP_PHASE(5);    // search
       b.d2[so + gi] = d2out;
       b.idx[so + gi] = jout;
       b.lb[so + gi] = lbout;
@@ -1118,6 +1142,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
       }
     }
     s_cur = s_next; jp_cur = jp_next; l_cur = l_next;
+    SMHIP_PHASE(6);      // stores + hard list
   }
   // statistics: queries searched by this block are counted through deferred_count
 #pragma unroll
@@ -1129,6 +1154,13 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
     const uint32_t v = s_hist[k];
     if (v) atomicAdd(&gh[k], v);
   }
+  SMHIP_PHASE(7);        // epilogue: histogram flush
+#if SMHIP_PHASE_TIMING
+  if (timing && lane == 0) {
+    unsigned long long* tc = reinterpret_cast<unsigned long long*>(b.tpart);
+    for (int k = 0; k < 8; ++k) atomicAdd(&tc[k], tacc[k]);
+  }
+#endif
 }
 
 // a run of the sorted target tested with the explicit tie rule, four independent loads in flight per lane (one load per
@@ -1839,6 +1871,16 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   const int pair = b.pair_base + blockIdx.x;
   PairState* st = &b.state[pair];
   if (st->done) return;
+#if SMHIP_PHASE_TIMING
+  if ((b.debug_flags & 16) && pair == 0 && threadIdx.x == 0) {            // phase timing report (diagnostic build only)
+    unsigned long long* tc = reinterpret_cast<unsigned long long*>(b.tpart);
+    unsigned long long tot = 0;
+    for (int k = 0; k < 8; ++k) tot += tc[k];
+    printf("[phase] iter %d total %llu :", st->iter, tot);
+    for (int k = 0; k < 8; ++k) { printf(" %.1f%%", tot ? 100.0 * (double)tc[k] / (double)tot : 0.0); tc[k] = 0; }
+    printf("\n");
+  }
+#endif
   __shared__ uint32_t s_w[17];
   __shared__ uint32_t s_q[4];
   __shared__ uint32_t s_h[256];

@@ -138,6 +138,7 @@ struct IcpDev {
   float cap_factor;          // next cap = cap_factor x quantile distance
   float rho;                 // dist_outlier_ratio as float (widened to double exactly like the reference)
   float grid_cell;
+  int32_t debug_flags;       // diagnostic builds only (SMHIP_DEBUG_FLAGS with -DSMHIP_PHASE_TIMING=1): bit 4 = per-phase timing of nn_ball_lds
 };
 
 }  // namespace smhip

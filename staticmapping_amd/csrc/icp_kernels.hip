@@ -147,6 +147,37 @@ __global__ __launch_bounds__(256) void reset_scratch(IcpDev b, int first, int np
   if (tid == 0) *b.done_count = 0;
 }
 
+// The per-Align part of grid_setup alone (pose chain, loop state), for a pair whose target -- and with it the mean, the
+// grid geometry and the sorted target -- is unchanged since the last build: the front end aligns many scans against one
+// key frame (map_builder.cc:379-392), the back end many candidates against one submap.
+__global__ void pose_setup(IcpDev b, int npairs) {
+  const int pair = b.pair_base + blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= b.pair_base + npairs) return;
+  PairState* st = &b.state[pair];
+  const PairInput* in = &b.in[pair];
+  st->ns = in->ns; st->has_normals = in->has_normals;
+  for (int i = 0; i < 16; ++i) st->guess[i] = in->guess[i];
+  const double Tmi[16] = {1, 0, 0, -st->mu[0], 0, 1, 0, -st->mu[1], 0, 0, 1, -st->mu[2], 0, 0, 0, 1};
+  mat4_mul_rm(Tmi, st->guess, st->G);
+  for (int i = 0; i < 16; ++i) st->T_iter[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  for (int i = 0; i < 12; ++i) { st->M[i] = st->G[i]; st->M_prev[i] = st->G[i]; }
+  st->quat[0][0] = 1; st->quat[0][1] = st->quat[0][2] = st->quat[0][3] = 0;
+  st->trans[0][0] = st->trans[0][1] = st->trans[0][2] = 0;
+  st->n_hist = 1;
+  st->iter = 0; st->done = 0; st->status = 0;
+  st->unresolved_count = 0; st->fallback_ticket = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
+  st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0; st->searched_total = 0;
+  st->rcap2 = b.ball_radius * b.ball_radius;
+  st->kept = 0; st->limit_key = 0; st->score = 0;
+}
+// per-Align scratch that is not part of the search structure: histogram + finished-pairs counter
+__global__ __launch_bounds__(256) void reset_scratch_light(IcpDev b, int first, int npairs) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  uint32_t* hh = b.hist + (size_t)kHistBins * first;
+  for (size_t k = tid; k < (size_t)kHistBins * npairs; k += nth) hh[k] = 0;
+  if (tid == 0) *b.done_count = 0;
+}
+
 __global__ void grid_setup(IcpDev b, int npairs) {
   const int pair = b.pair_base + blockIdx.x * blockDim.x + threadIdx.x;
   if (pair >= b.pair_base + npairs) return;

@@ -46,6 +46,15 @@ struct smhip_context {
   IcpDev dev{};
   smhip_icp_options opts{};
   std::vector<int> ns, nt, has_normals;
+  // Target-side structures are kept across calls while a slot's target is unchanged (single-pair calls only: the front end
+  // aligns scan after scan against one key frame, map_builder.cc:379-392).  tgt_gen[slot] changes whenever the slot's target
+  // does; grid_gen / grid_cell / grid_sorted describe the search structure currently resident in the slot.
+  std::vector<unsigned long long> tgt_gen, grid_gen;
+  std::vector<float> grid_cell_built;
+  std::vector<int> grid_sorted;
+  unsigned long long gen_counter = 0;
+  int target_cache = 1;             // smhip_set_target_cache
+  unsigned long long cache_hits = 0;
   PairInput* in_pinned = nullptr;
   PairState* state_pinned = nullptr;
   float4* stage = nullptr;       // pinned staging for uploads, 2 * max(ns_cap, nt_cap)
@@ -128,6 +137,11 @@ void collect_profile(smhip_context* h) {
   h->ev_used = 0;
 }
 
+inline void touch_target(smhip_context* h, int slot) { h->tgt_gen[slot] = ++h->gen_counter; }
+inline void touch_grid(smhip_context* h, int first, int np) {        // the slots' search structures are (re)built / overwritten
+  for (int p = first; p < first + np; ++p) { h->grid_gen[p] = 0; h->grid_cell_built[p] = 0.f; h->grid_sorted[p] = 0; }
+}
+
 smhip_status check_slot(smhip_context* h, int slot) {
   if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
   if (slot < 0 || slot >= h->dev.slots) { h->err = "slot out of range"; return SMHIP_ERR_INVALID_ARGUMENT; }
@@ -146,6 +160,7 @@ struct Half {
 // per-call resets for pairs [0, np) (main stream, before the halves fork)
 smhip_status enqueue_resets(smhip_context* h, int np, int first = 0) {
   IcpDev& d = h->dev;
+  touch_grid(h, first, np);               // bits / ccount are zeroed below: whatever structure was resident is gone
   HIPCHK(h, hipMemcpyAsync(const_cast<PairInput*>(d.in) + first, h->in_pinned + first, sizeof(PairInput) * np, hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(reset_scratch, dim3(std::min(4096, 256 * np)), dim3(256), 0, h->stream, d, first, np);
   return SMHIP_OK;
@@ -166,10 +181,37 @@ smhip_status enqueue_grid_build(smhip_context* h, const Half& f, int nt_max) {
   hipLaunchKernelGGL(grid_scatter, gpts, dim3(256), 0, f.stream, d);
   if (d.sort_cells) hipLaunchKernelGGL(grid_sort_cells, gpts, dim3(256), 0, f.stream, d);
   HIPCHK(h, hipGetLastError());
+  for (int p = d.pair_base; p < d.pair_base + np; ++p) {
+    h->grid_gen[p] = h->tgt_gen[p]; h->grid_cell_built[p] = d.grid_cell; h->grid_sorted[p] = d.sort_cells;
+  }
   return SMHIP_OK;
 }
 
-Half whole_batch(smhip_context* h, int np, int first = 0) {
+Half whole_batch(smhip_context* h, int np, int first);
+
+// is the search structure resident in `slot` the one a build with the current settings would produce?
+bool grid_cached(smhip_context* h, int slot) {
+  return h->target_cache && h->grid_gen[slot] != 0 && h->grid_gen[slot] == h->tgt_gen[slot] &&
+         h->grid_cell_built[slot] == h->dev.grid_cell && h->grid_sorted[slot] >= h->dev.sort_cells;
+}
+
+// single-pair form of enqueue_resets + enqueue_grid_build that skips the build when the slot's target is unchanged
+smhip_status enqueue_prepare_one(smhip_context* h, int slot, int nt_max) {
+  if (!grid_cached(h, slot)) {
+    smhip_status s = enqueue_resets(h, 1, slot);
+    if (s) return s;
+    return enqueue_grid_build(h, whole_batch(h, 1, slot), nt_max);
+  }
+  IcpDev d = h->dev; d.npairs = 1; d.pair_base = slot;
+  HIPCHK(h, hipMemcpyAsync(const_cast<PairInput*>(d.in) + slot, h->in_pinned + slot, sizeof(PairInput), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(reset_scratch_light, dim3(8), dim3(256), 0, h->stream, d, slot, 1);
+  hipLaunchKernelGGL(pose_setup, dim3(1), dim3(64), 0, h->stream, d, 1);
+  HIPCHK(h, hipGetLastError());
+  h->cache_hits++;
+  return SMHIP_OK;
+}
+
+Half whole_batch(smhip_context* h, int np, int first) {
   Half f;
   f.d = h->dev; f.d.npairs = np; f.d.pair_base = first;
   f.stream = h->stream; f.np = np;
@@ -178,15 +220,16 @@ Half whole_batch(smhip_context* h, int np, int first = 0) {
 
 // single-stream convenience used by find_closests / the NDT fitness pass
 smhip_status enqueue_prepare(smhip_context* h, int np, int nt_max) {
+  if (np == 1) return enqueue_prepare_one(h, 0, nt_max);
   smhip_status s = enqueue_resets(h, np);
   if (s) return s;
-  return enqueue_grid_build(h, whole_batch(h, np), nt_max);
+  return enqueue_grid_build(h, whole_batch(h, np, 0), nt_max);
 }
 
 smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_max, int iteration);
 
 smhip_status enqueue_find_closests(smhip_context* h, int np, int ns_max) {
-  return enqueue_find_closests_half(h, whole_batch(h, np), ns_max, 0);
+  return enqueue_find_closests_half(h, whole_batch(h, np, 0), ns_max, 0);
 }
 
 smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_max, int iteration) {
@@ -427,6 +470,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   if (s == SMHIP_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
   if (s != SMHIP_OK) { smhip_destroy(h); return s; }
   h->ns.assign(B, 0); h->nt.assign(B, 0); h->has_normals.assign(B, 0);
+  h->tgt_gen.assign(B, 0); h->grid_gen.assign(B, 0); h->grid_cell_built.assign(B, 0.f); h->grid_sorted.assign(B, 0);
   sync_options(h);
   *out = h;
   return SMHIP_OK;
@@ -549,6 +593,7 @@ smhip_status smhip_set_target_f64(smhip_handle h, int slot, const double* xyz, c
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->nt[slot] = n;
   h->has_normals[slot] = nrm != nullptr;
+  touch_target(h, slot);
   return SMHIP_OK;
 }
 
@@ -575,6 +620,7 @@ smhip_status smhip_set_target_f32(smhip_handle h, int slot, const float* xyz, in
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->nt[slot] = n;
   h->has_normals[slot] = nrm != nullptr;
+  touch_target(h, slot);
   return SMHIP_OK;
 }
 
@@ -598,6 +644,7 @@ static smhip_status prep_run(smhip_handle h, const float4* raw_dev, int n, int s
   if (m <= 0) { h->err = "CalculateNormals produced no target points"; return SMHIP_ERR_INVALID_ARGUMENT; }
   h->nt[slot] = m;
   h->has_normals[slot] = 1;
+  touch_target(h, slot);
   if (n_out) *n_out = m;
   return SMHIP_OK;
 }
@@ -655,6 +702,7 @@ smhip_status smhip_prepare_targets_from_sources(smhip_handle h, int count, const
     if (m[k] <= 0) { h->err = "CalculateNormals produced no target points"; return SMHIP_ERR_INVALID_ARGUMENT; }
     h->nt[to_slots[k]] = m[k];
     h->has_normals[to_slots[k]] = 1;
+    touch_target(h, to_slots[k]);
     if (n_out) n_out[k] = m[k];
   }
   return SMHIP_OK;
@@ -724,6 +772,7 @@ smhip_status smhip_copy_slot(smhip_handle h, int from, int to) {
                      const_cast<float4*>(d.src), const_cast<float4*>(d.tgt_p), const_cast<float4*>(d.tgt_n), from, to);
   HIPCHK(h, hipGetLastError());
   h->ns[to] = h->ns[from]; h->nt[to] = h->nt[from]; h->has_normals[to] = h->has_normals[from];
+  touch_target(h, to);
   return SMHIP_OK;
 }
 
@@ -749,7 +798,9 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
   HIPCHK(h, hipStreamSynchronize(h->stream));
   smhip_status s = fill_inputs(h, npairs, guesses, &ns_max, &nt_max, first);
   if (s) return s;
-  s = enqueue_resets(h, npairs, first);
+  const bool cached_one = npairs == 1 && grid_cached(h, first);
+  if (cached_one) s = enqueue_prepare_one(h, first, nt_max);     // target unchanged: pose + scratch reset only
+  else s = enqueue_resets(h, npairs, first);
   if (s) return s;
   // Split the batch over several streams: the latency-bound launches of one part (finalize, validate, grid
   // build, near-empty refinement kernels) overlap the throughput-bound NN / accumulate of the others.
@@ -794,7 +845,7 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
     halves[k].d.acc_items = (halves[k].np * ceil_div(ns_max, kAccThreads * kAccItemsBatch) >= 768 ||
                              ceil_div(ns_max, kAccThreads * kAccItemsSmall) * (kAccThreads / 64) > kFinalizeMaxSeg) ? kAccItemsBatch : kAccItemsSmall;
   }
-  for (int k = 0; k < nh; ++k) { s = enqueue_grid_build(h, halves[k], nt_max); if (s) return s; }
+  if (!cached_one) for (int k = 0; k < nh; ++k) { s = enqueue_grid_build(h, halves[k], nt_max); if (s) return s; }
   const int max_it = h->dev.max_iteration;
   for (int it = 0; it < max_it; ++it) {
     for (int k = 0; k < nh; ++k) {
@@ -907,6 +958,12 @@ smhip_status smhip_icp_trimmed_score(smhip_handle h, int slot, const double T[16
   h->has_normals[slot] = had;
   if (kept) *kept = st.kept;
   return s;
+}
+
+smhip_status smhip_set_target_cache(smhip_handle h, int enable) {
+  if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
+  h->target_cache = enable ? 1 : 0;
+  return SMHIP_OK;
 }
 
 smhip_status smhip_get_capacity(smhip_handle h, int* pair_slots, int* max_source_points, int* max_target_points) {

@@ -326,6 +326,7 @@ smhip_status gicp_align_slot0(smhip_context* h, const float* guess, float* final
   hipLaunchKernelGGL(gicp_copy_points, dim3(ceil_div(ns, 256)), dim3(256), 0, h->stream, h->dev.src,
                      const_cast<float4*>(h->dev.tgt_p) + h->dev.nt_cap, ns);
   h->ns[1] = ns; h->nt[1] = ns;
+  touch_target(h, 1);
   double I16[16];
   for (int i = 0; i < 16; ++i) I16[i] = (i % 5 == 0) ? 1.0 : 0.0;
   int ns_max = 0, nt_max = 0;
@@ -490,6 +491,7 @@ static smhip_status ndt_gicp_stage_clouds(smhip_handle h) {
   }
   if (e != hipSuccess) { h->err = std::string("NdtWithGicp down-sampling: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
   h->ns[0] = ms; h->nt[0] = mt; h->has_normals[0] = 0;
+  touch_target(h, 0);
   return SMHIP_OK;
 }
 

@@ -12,6 +12,7 @@ struct NdtHost {
   NdtDev dev{};
   bool allocated = false;
   bool grid_valid = false;
+  unsigned long long grid_gen = 0;    // tgt_gen[0] the voxel grid was built from
   smhip_ndt_options opts{};
   double* out_pinned = nullptr;       // kNdtDerivCols doubles
   NdtGridInfo* info_pinned = nullptr;
@@ -188,6 +189,7 @@ smhip_status ndt_build_grid(smhip_context* h) {
   HIPCHK(h, hipGetLastError());
   if (n.info_pinned->status) { h->err = "NDT voxel box exceeds the bit grid (leaf size too small for the target extent)"; return SMHIP_ERR_CAPACITY; }
   n.grid_valid = true;
+  n.grid_gen = h->tgt_gen[0];
   return SMHIP_OK;
 }
 
@@ -327,8 +329,15 @@ smhip_status smhip_ndt_align(smhip_handle h, const double guess[16], double resu
   if (s) return s;
   NdtHost& n = ndt_of(h);
   n.deriv_calls = 0;
-  s = ndt_build_grid(h);                                   // setInputTarget -> init(), every Align (ndt.cc:54)
-  if (s) return s;
+  // setInputTarget -> init() on every Align (ndt.cc:54).  The voxel table is a pure function of the target and the
+  // options, so it is kept while the slot's target is unchanged (smhip_set_target_cache(h, 0) = rebuild every time)
+  if (h->target_cache && n.grid_valid && n.grid_gen == h->tgt_gen[0]) {
+    n.dev.ns = h->ns[0]; n.dev.src = h->dev.src;
+    h->cache_hits++;
+  } else {
+    s = ndt_build_grid(h);
+    if (s) return s;
+  }
   const smhip_ndt_options& o = n.opts;
   // guess.cast<float>() (ndt.cc:58); final_transformation_ = guess (:98)
   float Tf[16];

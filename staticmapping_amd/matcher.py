@@ -139,6 +139,11 @@ class IcpFastHip:
         self._check(self._lib.smhip_get_target_f32(self._h, slot, p.ctypes.data_as(_capi.c_float_p), nr.ctypes.data_as(_capi.c_float_p), n))
         return p, nr
 
+    def set_target_cache(self, enable: bool = True):
+        """Keep the target-side structures (ICP search grid, NDT voxel table) across single-pair calls while the target is
+        unchanged (default on); off = rebuild on every Align like the reference.  Results are identical either way."""
+        self._check(self._lib.smhip_set_target_cache(self._h, 1 if enable else 0))
+
     def copy_slot(self, src_slot: int, dst_slot: int):
         self._check(self._lib.smhip_copy_slot(self._h, src_slot, dst_slot))
 

@@ -1,0 +1,55 @@
+"""Target-side structures (the ICP search grid, the NDT voxel table) are kept across single-pair calls while the slot's
+target is unchanged -- the front end aligns scan after scan against one key frame (builder/map_builder.cc:379-392).  The
+reference rebuilds them in every Align (icp_fast.cc:464-467, ndt.cc:54); results must not depend on which happens."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_icp_align_is_bitwise_identical_with_and_without_the_cache(velo20k):
+    import staticmapping_amd as sm
+    from staticmapping_amd import synth
+    g1, g2 = velo20k["guess"], velo20k["guess"] @ synth.make_pose(t=(0.05, -0.02, 0.0), rpy_deg=(0, 0, 0.3))
+    out = {}
+    for cache in (True, False):
+        m = sm.IcpFastHip(max_source_points=20000, max_target_points=len(velo20k["q"]), max_iteration=30)
+        m.set_target_cache(cache)
+        m.set_input_source(velo20k["src"]); m.set_input_target(velo20k["q"], velo20k["n"])
+        res = [m.align(g1)[1], m.align(g2)[1], m.align(g1)[1]]           # 2nd and 3rd call: target unchanged
+        res.append(m.find_closests(g1, len(velo20k["src"]))[0])
+        m.set_input_target(velo20k["q"][::2], velo20k["n"][::2])          # a new target must be picked up
+        res.append(m.align(g1)[1])
+        m.set_input_target(velo20k["q"], velo20k["n"])
+        res.append(m.align(g1)[1])
+        out[cache] = res
+        m.close()
+    for a, b in zip(out[True], out[False]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(out[True][0], out[True][2]) and np.array_equal(out[True][0], out[True][5])
+    assert not np.array_equal(out[True][0], out[True][4])
+
+
+def test_ndt_align_is_identical_with_and_without_the_cache():
+    import staticmapping_amd as sm
+    from staticmapping_amd import synth
+    scene = synth.make_scene(0)
+    tgt = np.concatenate([synth.velodyne_scan(scene, synth.make_pose(t=(0.8 * k, 0, 0)), seed=40 + k, n_points=30000) for k in range(3)])
+    for k in range(3):
+        tgt[30000 * k:30000 * (k + 1), 0] += 0.8 * k
+    src = synth.velodyne_scan(scene, synth.make_pose(t=(0.8, 0.05, 0.0), rpy_deg=(0, 0, 1.0)), seed=50, n_points=30000)
+    guess = synth.make_pose(t=(0.6, 0.0, 0.0))
+    out = {}
+    for cache in (True, False):
+        m = sm.NdtHip(max_source_points=30000, max_target_points=len(tgt))
+        m.set_target_cache(cache)
+        m.set_input_source(src); m.set_input_target(tgt)
+        r = []
+        for G in (guess, guess @ synth.make_pose(t=(0.05, 0, 0)), guess):
+            ok, R = m.align(G)
+            r.append((R.copy(), m.get_fitness_score(), dict(m.last_ndt_stats) if hasattr(m, "last_ndt_stats") else None))
+        out[cache] = r
+        m.close()
+    for (Ra, fa, _), (Rb, fb, _) in zip(out[True], out[False]):
+        assert np.array_equal(Ra, Rb) and fa == fb
+    assert np.array_equal(out[True][0][0], out[True][2][0])

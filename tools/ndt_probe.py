@@ -16,8 +16,10 @@ src = scans[5]; T = poses[5]
 G = T.copy(); G[0, 3] -= 0.3; 
 m = sm.NdtHip(max_source_points=len(src), max_target_points=len(tgt))
 m.set_input_source(src); m.set_input_target(tgt)
-m.align(G)
-t = time.time(); reps = 5
-for _ in range(reps): ok, R = m.align(G)
-dt = (time.time() - t) / reps
-print(f"NDT {len(src)} vs {len(tgt)}: {dt*1e3:.2f} ms/align  {1/dt:.1f} align/s stats={m.last_ndt_stats} score={m.get_fitness_score():.5f} err={sm.se3_error(R, T)}")
+for cache in (False, True):           # False = the reference's behaviour: voxel table + fitness search structure rebuilt in every Align
+    m.set_target_cache(cache)
+    m.align(G)
+    t = time.time(); reps = 5
+    for _ in range(reps): ok, R = m.align(G)
+    dt = (time.time() - t) / reps
+    print(f"NDT {len(src)} vs {len(tgt)} target_cache={int(cache)}: {dt*1e3:.2f} ms/align  {1/dt:.1f} align/s stats={m.last_ndt_stats} score={m.get_fitness_score():.5f} err={sm.se3_error(R, T)}")

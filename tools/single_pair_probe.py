@@ -1,0 +1,24 @@
+"""Single-pair IcpFast::Align latency (what the reference's sequential front end calls, map_builder.cc:260-397):
+120 k-pt scan vs its CalculateNormals key frame, 20 fixed iterations, target structures rebuilt every call / kept."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import staticmapping_amd as sm
+from staticmapping_amd import synth
+a, b, T = synth.scan_pair("cfg2", n_points=120000)
+q, n = sm.calculate_normals(a[:, :3].astype(np.float64))
+guess = synth.make_pose(t=(0.6, 0, 0))
+m = sm.IcpFastHip(pair_slots=1, max_source_points=len(b), max_target_points=len(q), max_iteration=20, early_exit=0)
+m.set_input_source(b); m.set_input_target(q, n)
+for cache in (False, True):
+    m.set_target_cache(cache)
+    m.align(guess)
+    t = time.time(); reps = 20
+    for _ in range(reps): ok, R = m.align(guess)
+    dt = (time.time() - t) / reps
+    print(f"single pair, 20 iterations, target_cache={int(cache)}: {dt*1e3:.3f} ms per Align  err={sm.se3_error(R, T)}")
+m.set_options(max_iteration=100, early_exit=1)
+m.align(guess)
+t = time.time()
+for _ in range(20): ok, R = m.align(guess)
+print(f"single pair, early exit (reference behaviour), target kept: {(time.time() - t) / 20 * 1e3:.3f} ms per Align, iterations {m.last_stats[0]['iterations']}")

@@ -158,7 +158,13 @@ def r_derivative(x, R):
 class GicpFunctor:
     """OptimizationFunctorWithIndices (:250-377) over one fixed correspondence set."""
 
-    def __init__(self, base_T_f32, src_f32, tgt_f32, maha):
+    def __init__(self, base_T_f32, src_f32, tgt_f32, maha, transform_mode="blas"):
+        # transform_mode: how the float 4x4 * point product of :263-268 is rounded -- "blas" (numpy's sgemm), "nofma" (every
+        # multiply and add rounded to float, what -ffp-contract=off compiles to) or "fma" (one rounding per multiply-add, what
+        # -ffp-contract=fast / a GPU compiles to).  All three are legal compilations of the same PCL statement; they differ
+        # by one float ulp in some coordinates, which is what tests/test_oracle_ndt_gicp.py uses to measure GICP's own
+        # repeatability.
+        self.transform_mode = transform_mode
         self.base = np.asarray(base_T_f32, dtype=F)
         self.src4 = np.concatenate([src_f32, np.ones((len(src_f32), 1), dtype=F)], axis=1).astype(F)
         self.tgt = np.asarray(tgt_f32, dtype=F)
@@ -167,9 +173,24 @@ class GicpFunctor:
         self.pbase = (self.src4 @ self.base.T).astype(F)[:, :3].astype(np.float64)   # base_transformation_ * p_src
         self.evals = 0
 
+    def _transform(self, T):
+        if self.transform_mode == "blas":
+            return (self.src4 @ T.T).astype(F)[:, :3]
+        x, y, z = self.src4[:, 0], self.src4[:, 1], self.src4[:, 2]
+        out = np.empty((self.m, 3), dtype=F)
+        for r in range(3):
+            a, b, c, d = T[r, 0], T[r, 1], T[r, 2], T[r, 3]
+            if self.transform_mode == "nofma":
+                out[:, r] = F(F(F(a * x) + F(b * y)) + F(c * z)) + d                       # every operation rounded to float
+            else:                                                                         # fma(c, z, fma(b, y, fma(a, x, d)))
+                t = (a.astype(np.float64) * x.astype(np.float64) + np.float64(d)).astype(F)    # exact product, one rounding
+                t = (b.astype(np.float64) * y.astype(np.float64) + t.astype(np.float64)).astype(F)
+                out[:, r] = (c.astype(np.float64) * z.astype(np.float64) + t.astype(np.float64)).astype(F)
+        return out
+
     def _res_temp(self, x):
         T = apply_state_f32(self.base, x)
-        pp = (self.src4 @ T.T).astype(F)[:, :3]
+        pp = self._transform(T)
         res = (pp - self.tgt).astype(F).astype(np.float64)                           # float differences (:268)
         temp = np.einsum("kij,kj->ki", self.maha, res)
         return res, temp
@@ -448,7 +469,8 @@ def estimate_rigid_transformation_bfgs(functor, T_f32, max_inner_iterations=20, 
 
 
 def gicp_align(src_f32, tgt_f32, guess_f32, max_iterations=35, rotation_epsilon=1e-3, transformation_epsilon=5e-4,
-               corr_dist_threshold=5.0, k=20, gicp_epsilon=1e-3, max_inner_iterations=20, trace=None, debug=False):
+               corr_dist_threshold=5.0, k=20, gicp_epsilon=1e-3, max_inner_iterations=20, trace=None, debug=False,
+               transform_mode="blas"):
     """computeTransformation (:381-514) + getFitnessScore.  Returns dict(result f32 4x4, score, iterations)."""
     src = np.asarray(src_f32, dtype=F)[:, :3]
     tgt = np.asarray(tgt_f32, dtype=F)[:, :3]
@@ -470,7 +492,7 @@ def gicp_align(src_f32, tgt_f32, guess_f32, max_iterations=35, rotation_epsilon=
         keep = np.flatnonzero(d2 < F(corr_dist_threshold * corr_dist_threshold))      # :449
         Mh = np.linalg.inv(R[None] @ C_s[keep] @ R.T[None] + C_t[j[keep]])            # :451-459
         prev = T.copy()
-        fn = GicpFunctor(guess, src[keep], tgt[j[keep]], Mh)
+        fn = GicpFunctor(guess, src[keep], tgt[j[keep]], Mh, transform_mode=transform_mode)
         if len(keep) < 4:                                         # NotEnoughPointsException -> break (:494-498)
             break
         T, x, inner = estimate_rigid_transformation_bfgs(fn, T, max_inner_iterations, debug=debug)

@@ -38,14 +38,19 @@ __device__ __forceinline__ void sym_inverse(const double* a, double* o) {
 }
 
 // k nearest neighbours of every target point of `pair` among that same target (the point itself included, as
-// nearestKSearch returns it), then the regularised covariance.  One query per thread; the sorted best-k list
-// lives in LDS (k x 128 threads x 8 B).  Search = shells of grid cells around the query's cell; inside a shell
+// nearestKSearch returns it), then the regularised covariance.  One query per thread; its best-k set lives in LDS
+// (KMAX x 128 threads x 8 B) as an UNSORTED set plus, in registers, the largest distance in it and where that entry sits:
+// a closer candidate overwrites that entry and one pass of k independent LDS reads finds the new largest.  (The sorted
+// list this replaces shifted half the list through LDS on every accepted candidate -- dependent read-modify-write steps
+// that cost several times the distance tests themselves: gicp_knn_cov was 56 % of NdtWithGicp::Align.)  The covariance is
+// a sum over the set, so its order is irrelevant.  Search = shells of grid cells around the query's cell; inside a shell
 // the x-extent of a grid row is one contiguous run of the cell-sorted target (row_slots).  A shell ends the
 // search once the k-th distance is within the distance to the nearest unexplored face (block_guarantee).
 // cov is indexed by the point's position in the pair's raw target array (tq.w), so it survives grid rebuilds.
+template <int KMAX>
 __global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pair, int k, double gicp_epsilon, double* cov) {
-  __shared__ float s_d[kGicpKMax][kGicpKnnThreads];
-  __shared__ int s_j[kGicpKMax][kGicpKnnThreads];
+  __shared__ float s_d[KMAX][kGicpKnnThreads];
+  __shared__ int s_j[KMAX][kGicpKnnThreads];
   const PairState* st = &b.state[pair];
   const int nt = st->nt;
   const int j0 = blockIdx.x * kGicpKnnThreads + threadIdx.x;
@@ -56,7 +61,8 @@ __global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pa
   const uint32_t* cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
   const float4 q = tq[j0];
   for (int m = 0; m < k; ++m) { s_d[m][t] = INFINITY; s_j[m][t] = -1; }
-  float worst = INFINITY;                     // s_d[k - 1][t]
+  float worst = INFINITY;                     // the largest distance of the set ...
+  int wpos = 0;                               // ... and the entry that holds it
   const int cx = min(max(cell_coord(q.x, st->origin[0], st->inv_h), 0), st->nx - 1);
   const int cy = min(max(cell_coord(q.y, st->origin[1], st->inv_h), 0), st->ny - 1);
   const int cz = min(max(cell_coord(q.z, st->origin[2], st->inv_h), 0), st->nz - 1);
@@ -67,13 +73,17 @@ __global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pa
     auto consider = [&](const float4 c, uint32_t p) {
       const float d = dist2(c, q.x, q.y, q.z);
       if (!(d < worst)) return;
-      int m = k - 1;                           // insertion into the ascending list
-      while (m > 0 && s_d[m - 1][t] > d) { s_d[m][t] = s_d[m - 1][t]; s_j[m][t] = s_j[m - 1][t]; --m; }
-      s_d[m][t] = d; s_j[m][t] = (int)p;
-      worst = s_d[k - 1][t];
+      s_d[wpos][t] = d; s_j[wpos][t] = (int)p;          // evict the farthest member
+      float w = -1.f;                                    // new farthest: k independent reads (empty entries are +inf)
+      int wp = 0;
+      for (int m = 0; m < k; ++m) {
+        const float dm = s_d[m][t];
+        if (dm > w) { w = dm; wp = m; }
+      }
+      worst = w; wpos = wp;
     };
     uint32_t p = pa;
-    for (; p + 4 <= pb; p += 4) {              // four candidate loads in flight (in order: ties keep the earlier position)
+    for (; p + 4 <= pb; p += 4) {              // four candidate loads in flight
       const float4 c0 = tq[p], c1 = tq[p + 1], c2 = tq[p + 2], c3 = tq[p + 3];
       consider(c0, p); consider(c1, p + 1); consider(c2, p + 2); consider(c3, p + 3);
     }

@@ -146,9 +146,10 @@ int RunRank(const Args& a, int rank, int world, int device) {
   HIPOK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   const int B = std::max(1, std::min(a.batch, per));
   smhip_handle h = nullptr;
-  // capacity: a KITTI scan holds at most 250 000 points (1 000 000 floats per file)
+  // capacity: a KITTI scan holds at most 250 000 points (1 000 000 floats per file).  Slots [0, B) hold the pairs of a
+  // batch, slots [B, 2 B) park target scans that no pair of the batch holds as its source already.
   const int cap = static_cast<int>(kMaxFloatsPerFile / 4);
-  smhip_status s = smhip_create(device, stream, B, cap, cap, &h);
+  smhip_status s = smhip_create(device, stream, 2 * B, cap, cap, &h);
   if (s != SMHIP_OK) Die(std::string("smhip_create: ") + smhip_status_string(s) + " (is this a gfx950 GPU? there is no CPU fallback)");
   smhip_icp_options o;
   smhip_icp_default_options(&o);
@@ -173,19 +174,31 @@ int RunRank(const Args& a, int rank, int world, int device) {
   int done = 0, my_pairs = 0;
   for (int base = 0; base < per; base += B) {
     int nb = 0;
+    const auto u0 = std::chrono::steady_clock::now();
+    std::vector<int> from, to, nts;
+    int prev_pair = -2;
     for (int k = 0; k < B && base + k < per; ++k) {
       const int pair = (base + k) * world + rank;                        // round-robin: pair i -> rank i mod G
       if (pair >= n_pairs) break;
-      const auto u0 = std::chrono::steady_clock::now();
-      int nt = 0;
-      int n = ReadBin(files[pair], &rows);                               // scan i = target (device CalculateNormals)
-      if (smhip_prepare_target_f32(h, k, rows.data(), 4, n, &nt) != SMHIP_OK) Die(std::string("target ") + files[pair] + ": " + smhip_last_error(h));
-      n = ReadBin(files[pair + 1], &rows);                               // scan i + 1 = source
+      // scan i = target.  When the previous slot's pair is i - 1 its source IS scan i, already on the device (one GPU:
+      // every pair but the first of a batch); otherwise the scan is parked in slot B + k.  Either way the targets of the
+      // whole batch are prepared in ONE device pass (CalculateNormals as a kd forest: one sort per tree level for all).
+      if (pair == prev_pair + 1) from.push_back(k - 1);
+      else {
+        const int n = ReadBin(files[pair], &rows);
+        if (smhip_set_source_f32(h, B + k, rows.data(), 4, n) != SMHIP_OK) Die(std::string("target ") + files[pair] + ": " + smhip_last_error(h));
+        from.push_back(B + k);
+      }
+      to.push_back(k);
+      const int n = ReadBin(files[pair + 1], &rows);                     // scan i + 1 = source
       if (smhip_set_source_f32(h, k, rows.data(), 4, n) != SMHIP_OK) Die(std::string("source ") + files[pair + 1] + ": " + smhip_last_error(h));
-      upload_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - u0).count();
+      prev_pair = pair;
       ++nb;
     }
     if (nb == 0) break;
+    nts.resize(nb);
+    if (smhip_prepare_targets_from_sources(h, nb, from.data(), to.data(), nts.data()) != SMHIP_OK) Die(std::string("prepare targets: ") + smhip_last_error(h));
+    upload_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - u0).count();
     if (smhip_icp_enqueue_batch(h, nb, guesses.data()) != SMHIP_OK) Die(std::string("enqueue: ") + smhip_last_error(h));
     if (smhip_icp_export_results_device(h, nb, local_dev + static_cast<size_t>(kPoseDoubles) * base) != SMHIP_OK) Die(smhip_last_error(h));
     done = base + nb;

@@ -336,10 +336,14 @@ smhip_status gicp_align_slot0(smhip_context* h, const float* guess, float* final
   smhip_status s = gicp_prepare_slots(h, 2, I16, &ns_max, &nt_max);
   h->dev.grid_cell = cell_was;
   if (s) return s;
-  hipLaunchKernelGGL(gicp_knn_cov, dim3(ceil_div(nt, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, h->dev, 0, k,
-                     o.gicp_epsilon, G.dev.cov_t);
-  hipLaunchKernelGGL(gicp_knn_cov, dim3(ceil_div(ns, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, h->dev, 1, k,
-                     o.gicp_epsilon, G.dev.cov_s);
+  // the set's LDS footprint follows k (the default 20 fits 20 entries per thread: 20 KiB per workgroup instead of 32)
+  if (k <= 20) {
+    hipLaunchKernelGGL(gicp_knn_cov<20>, dim3(ceil_div(nt, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, h->dev, 0, k, o.gicp_epsilon, G.dev.cov_t);
+    hipLaunchKernelGGL(gicp_knn_cov<20>, dim3(ceil_div(ns, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, h->dev, 1, k, o.gicp_epsilon, G.dev.cov_s);
+  } else {
+    hipLaunchKernelGGL(gicp_knn_cov<kGicpKMax>, dim3(ceil_div(nt, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, h->dev, 0, k, o.gicp_epsilon, G.dev.cov_t);
+    hipLaunchKernelGGL(gicp_knn_cov<kGicpKMax>, dim3(ceil_div(ns, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, h->dev, 1, k, o.gicp_epsilon, G.dev.cov_s);
+  }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));              // the pinned pair inputs are rewritten below
   // ---- outer loop

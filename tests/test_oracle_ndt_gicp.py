@@ -74,3 +74,43 @@ def test_gicp_recovers_a_known_motion_on_clean_planes():
     ang = np.arccos(np.clip((np.trace(R @ T[:3, :3].T) - 1) / 2, -1, 1))
     assert ang < 2e-3 and np.linalg.norm(t - T[:3, 3]) < 2e-2
     assert out["score"] < 1e-3
+
+
+def test_gicp_own_repeatability_under_legal_float_roundings(capsys):
+    """How far apart do two LEGAL compilations of PCL's GICP land?  The functor transforms every point with a float 4x4
+    (gicp_omp_impl.hpp:263-268); whether the compiler contracts the multiply-adds (one rounding) or not (two) moves some
+    coordinates by one float ulp.  The Mahalanobis weights reach 1 / gicp_epsilon = 1000 and the line search's Wolfe tests
+    (sigma = 0.01) decide on differences of that size, so the two runs part ways after a few BFGS steps.  This is the band a
+    GPU implementation (which contracts) can be compared with a CPU build of the reference in -- the tolerance of
+    tests/test_ndt_gicp_gpu.py's whole-run check -- measured here on the oracle alone, no GPU involved."""
+    scene = synth.make_scene(0)
+    tgt_scan = synth.velodyne_scan(scene, synth.make_pose(), seed=71, n_points=30000)
+    src_scan = synth.velodyne_scan(scene, synth.make_pose(t=(0.6, 0.05, 0.0), rpy_deg=(0, 0, 1.0)), seed=72, n_points=30000)
+    ds = ong.approximate_voxel_grid_runs(src_scan[:, :3], 0.4)
+    dt = ong.approximate_voxel_grid_runs(tgt_scan[:, :3], 0.4)
+    guess = synth.make_pose(t=(0.45, 0.0, 0.0)).astype(np.float32)
+    runs = {mode: ong.gicp_align(ds, dt, guess, transform_mode=mode) for mode in ("nofma", "fma", "blas")}
+    truth = synth.make_pose(t=(0.6, 0.05, 0.0), rpy_deg=(0, 0, 1.0))
+
+    def err(A, B):
+        R = A[:3, :3].astype(np.float64) @ B[:3, :3].astype(np.float64).T
+        return (float(np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))), float(np.linalg.norm(A[:3, 3].astype(np.float64) - B[:3, 3])))
+    lines = []
+    worst = (0.0, 0.0)
+    for a, b in (("nofma", "fma"), ("nofma", "blas"), ("fma", "blas")):
+        da, dt_ = err(runs[a]["result"], runs[b]["result"])
+        worst = (max(worst[0], da), max(worst[1], dt_))
+        lines.append(f"  {a:5s} vs {b:5s}: {da:.2e} rad {dt_:.2e} m  (iterations {runs[a]['iterations']} / {runs[b]['iterations']})")
+    with capsys.disabled():
+        print("\n[GICP repeatability under legal float roundings of the functor's transform]")
+        print("\n".join(lines))
+        for m, r in runs.items():
+            print(f"  {m:5s} vs truth: {err(r['result'], truth)[0]:.2e} rad {err(r['result'], truth)[1]:.2e} m  fitness {r['score']:.6f}")
+    # every variant is a valid GICP result (close to the truth, similar fitness) ...
+    for r in runs.values():
+        da, dt_ = err(r["result"], truth)
+        assert da < 1e-2 and dt_ < 0.25 and r["score"] < 0.1
+    # ... and two of them do NOT agree with each other to the north star's 1e-3 m (measured: 3.7e-4 rad / 0.14 m between
+    # the contracted and the uncontracted build on this pair): whole-run GICP parity beyond its own repeatability is not a
+    # property the reference has, which is why tests/test_ndt_gicp_gpu.py pins the stages and bounds the whole run loosely
+    assert 1e-3 < worst[1] < 0.3 and worst[0] < 5e-3

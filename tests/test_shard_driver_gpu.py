@@ -49,21 +49,14 @@ def test_cpp_driver_matches_the_python_driver(tmp_path):
     assert line["pairs"] == 6 and line["unfinished_pairs"] == 0 and line["mean_iterations"] == 20
     got = kitti.read_poses(str(out))
     assert got.shape == (7, 4, 4) and np.array_equal(got[0], np.eye(4))
-    # the same steps through the Python view of the C ABI: upload + device CalculateNormals of scan i, scan i + 1 as the
-    # source, batches of 4, 20 fixed iterations, the same guess
+    # the Python driver on the same files takes the same steps: every scan uploaded once as a source, the first target of a
+    # batch parked in a spare slot, the targets of a batch prepared in one device pass, batches of 4, 20 fixed iterations
     files = kitti.list_scans(seq)
+    scans = [(lambda f=f: kitti.read_bin(f, scale_intensity=False)) for f in files]
     G = np.eye(4); G[0, 3] = 0.6
-    m = sm.IcpFastHip(pair_slots=4, max_source_points=32768, max_target_points=32768, max_iteration=20, early_exit=0)
-    T = []
-    for b0 in range(0, 6, 4):
-        chunk = list(range(b0, min(6, b0 + 4)))
-        for s, pair in enumerate(chunk):
-            m.prepare_target(kitti.read_bin(files[pair], scale_intensity=False), slot=s)
-            m.set_input_source(kitti.read_bin(files[pair + 1], scale_intensity=False), slot=s)
-        Tb, sc, st = m.align_batch(len(chunk), [G] * len(chunk))
-        T.extend(Tb)
+    m = sm.IcpFastHip(pair_slots=5, max_source_points=32768, max_target_points=32768, max_iteration=20, early_exit=0)
+    idx, T, sc, it = kitti.scan_to_scan_sequence(scans, m, batch=4, guesses=[G] * 6)
     m.close()
-    T = np.stack(T)
     traj = shard.chain_poses(T)
     for k in range(7):                                                    # the file carries 8 significant digits
         da, dt = sm.se3_error(got[k], traj[k])

@@ -59,8 +59,10 @@ __global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pa
   const float4* tq = b.tq + (size_t)pair * b.nt_cap;
   const uint2* words = b.words + (size_t)pair * kMaxGridWords;
   const uint32_t* cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
+  const uint32_t* rowbits = b.have_rowbits ? b.rowbits + (size_t)pair * kMaxRowWords : nullptr;
   const float4 q = tq[j0];
-  for (int m = 0; m < k; ++m) { s_d[m][t] = INFINITY; s_j[m][t] = -1; }
+#pragma unroll
+  for (int m = 0; m < KMAX; ++m) { s_d[m][t] = m < k ? INFINITY : -2.0f; s_j[m][t] = -1; }   // entries >= k never hold the maximum
   float worst = INFINITY;                     // the largest distance of the set ...
   int wpos = 0;                               // ... and the entry that holds it
   const int cx = min(max(cell_coord(q.x, st->origin[0], st->inv_h), 0), st->nx - 1);
@@ -69,17 +71,21 @@ __global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pa
   auto scan = [&](int rowbase, int xa, int xb) {
     uint32_t sa, sb;
     row_slots(words, rowbase, xa, xb, sa, sb);
+    if (sa == sb) return;                       // empty stretch of the row (most of a large shell): no run to fetch
     const uint32_t pa = cstart[sa], pb = cstart[sb];
     auto consider = [&](const float4 c, uint32_t p) {
       const float d = dist2(c, q.x, q.y, q.z);
       if (!(d < worst)) return;
       s_d[wpos][t] = d; s_j[wpos][t] = (int)p;          // evict the farthest member
-      float w = -1.f;                                    // new farthest: k independent reads (empty entries are +inf)
+      // new farthest member: KMAX independent LDS reads issued back to back (compile-time trip count: with a run-time
+      // bound every read waited for the one before it, and a wave pays this whenever ANY of its lanes accepts a candidate)
+      float dm[KMAX];
+#pragma unroll
+      for (int m = 0; m < KMAX; ++m) dm[m] = s_d[m][t];
+      float w = -1.f;
       int wp = 0;
-      for (int m = 0; m < k; ++m) {
-        const float dm = s_d[m][t];
-        if (dm > w) { w = dm; wp = m; }
-      }
+#pragma unroll
+      for (int m = 0; m < KMAX; ++m) { const bool g = dm[m] > w; w = g ? dm[m] : w; wp = g ? m : wp; }
       worst = w; wpos = wp;
     };
     uint32_t p = pa;
@@ -97,18 +103,23 @@ __global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pa
     const int X0 = max(cx - r, 0), X1 = min(cx + r, st->nx - 1);
     const int Y0 = max(cy - r, 0), Y1 = min(cy + r, st->ny - 1);
     const int Z0 = max(cz - r, 0), Z1 = min(cz + r, st->nz - 1);
-    for (int z = Z0; z <= Z1; ++z)
-      for (int y = Y0; y <= Y1; ++y) {
-        const int rowbase = (z * st->ny + y) * st->wx;
-        const bool inner = rp >= 0 && abs(y - cy) <= rp && abs(z - cz) <= rp;
-        if (!inner) {
-          scan(rowbase, X0, X1);
-        } else {
-          const int xl1 = min(cx - rp - 1, st->nx - 1), xr0 = max(cx + rp + 1, 0);
-          if (X0 <= xl1) scan(rowbase, X0, xl1);
-          if (xr0 <= X1) scan(rowbase, xr0, X1);
-        }
+    auto visit_row = [&](int z, int y) {
+      const int rowbase = (z * st->ny + y) * st->wx;
+      const bool inner = rp >= 0 && abs(y - cy) <= rp && abs(z - cz) <= rp;
+      if (!inner) {
+        scan(rowbase, X0, X1);
+      } else {
+        const int xl1 = min(cx - rp - 1, st->nx - 1), xr0 = max(cx + rp + 1, 0);
+        if (X0 <= xl1) scan(rowbase, X0, xl1);
+        if (xr0 <= X1) scan(rowbase, xr0, X1);
       }
+    };
+    for (int z = Z0; z <= Z1; ++z) {
+      // a shell of half-width r has (2 r + 1)^2 rows, nearly all empty around a far-range point: the row-occupancy bitmap
+      // hands over the occupied ones (two words per slab and 32 rows) instead of two dependent loads per row
+      if (rowbits) for_each_occupied_row(rowbits, st->ny, z, Y0, Y1, [&](int y) { visit_row(z, y); });
+      else for (int y = Y0; y <= Y1; ++y) visit_row(z, y);
+    }
     const float g = block_guarantee(st, q.x, q.y, q.z, X0, X1, Y0, Y1, Z0, Z1);
     if (g == INFINITY) break;                   // the block covers the grid
     if (g > 0.f && worst <= g * g) break;

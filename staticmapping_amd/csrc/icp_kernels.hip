@@ -318,6 +318,44 @@ __global__ __launch_bounds__(1024) void grid_rank(IcpDev b) {
   if (hi >= nw && threadIdx.x == 0) st->nocc = (int)carry;   // the segment that holds the last word
 }
 
+// Row-occupancy bitmap: bit (z * ny + y) of rowbits says whether grid row (y, z) holds any point.  The ring searches walk
+// cell blocks of up to (2 r + 1)^2 rows per query; against a sparse far range nearly all of them are empty, and proving a
+// row empty through `words` costs two dependent loads.  One thread per 32-row word, no atomics, nothing to zero.
+__global__ __launch_bounds__(256) void grid_rowbits(IcpDev b) {
+  const int pair = b.pair_base + blockIdx.y;
+  const PairState* st = &b.state[pair];
+  const int rows = st->ny * st->nz, wx = st->wx;
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= kMaxRowWords) return;
+  uint32_t out = 0;
+  if (w * 32 < rows) {
+    const uint32_t* bits = b.bits + (size_t)pair * kMaxGridWords;
+    for (int r = 0; r < 32; ++r) {
+      const int row = w * 32 + r;
+      if (row >= rows) break;
+      uint32_t any = 0;
+      for (int k = 0; k < wx; ++k) any |= bits[(size_t)row * wx + k];
+      if (any) out |= 1u << r;
+    }
+  }
+  b.rowbits[(size_t)pair * kMaxRowWords + w] = out;
+}
+// rows y in [y0, y1] of slab z that hold points, in ascending y: f(y)
+template <typename F>
+__device__ __forceinline__ void for_each_occupied_row(const uint32_t* __restrict__ rb, int ny, int z, int y0, int y1, F f) {
+  for (int yb = y0; yb <= y1; yb += 32) {
+    const int cnt = min(32, y1 - yb + 1);
+    const int ry = z * ny + yb, w = ry >> 5, sh = ry & 31;
+    const unsigned long long two = (unsigned long long)rb[w] | ((unsigned long long)rb[w + 1] << 32);
+    uint32_t m = (uint32_t)(two >> sh) & (cnt == 32 ? 0xffffffffu : ((1u << cnt) - 1u));
+    while (m) { const int o = __ffs((int)m) - 1; m &= m - 1u; f(yb + o); }
+  }
+}
+__device__ __forceinline__ bool row_occupied(const uint32_t* __restrict__ rb, int ny, int z, int y) {
+  const int ry = z * ny + y;
+  return (rb[ry >> 5] >> (ry & 31)) & 1u;
+}
+
 __global__ __launch_bounds__(256) void grid_count(IcpDev b) {
   const int pair = b.pair_base + blockIdx.y;
   const PairState* st = &b.state[pair];
@@ -1431,6 +1469,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring_wide(IcpDev b) {
   const uint2* words = b.words + (size_t)pair * kMaxGridWords;
   const uint32_t* cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
   const float4* tq = b.tq + (size_t)pair * b.nt_cap;
+  const uint32_t* rowbits = b.have_rowbits ? b.rowbits + (size_t)pair * kMaxRowWords : nullptr;
   const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
   const float inv_h = st->inv_h;
   const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
@@ -1452,6 +1491,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring_wide(IcpDev b) {
         for (int k = lane; k < nrows; k += 64) {
           const int zr = k / nyr;
           const int z = z0 + zr, y = y0 + (k - zr * nyr);
+          if (rowbits && !row_occupied(rowbits, ny, z, y)) continue;       // an empty row: one bit instead of two dependent loads
           const int rowbase = (z * ny + y) * wx;
           const bool inner = abs(y - cy) <= rp && abs(z - cz) <= rp;
           if (!inner) {

@@ -51,7 +51,7 @@ struct smhip_context {
   // does; grid_gen / grid_cell / grid_sorted describe the search structure currently resident in the slot.
   std::vector<unsigned long long> tgt_gen, grid_gen;
   std::vector<float> grid_cell_built;
-  std::vector<int> grid_sorted;
+  std::vector<int> grid_sorted, grid_rows;      // grid_rows: the row-occupancy bitmap was built with the structure
   unsigned long long gen_counter = 0;
   int target_cache = 1;             // smhip_set_target_cache
   unsigned long long cache_hits = 0;
@@ -139,7 +139,7 @@ void collect_profile(smhip_context* h) {
 
 inline void touch_target(smhip_context* h, int slot) { h->tgt_gen[slot] = ++h->gen_counter; }
 inline void touch_grid(smhip_context* h, int first, int np) {        // the slots' search structures are (re)built / overwritten
-  for (int p = first; p < first + np; ++p) { h->grid_gen[p] = 0; h->grid_cell_built[p] = 0.f; h->grid_sorted[p] = 0; }
+  for (int p = first; p < first + np; ++p) { h->grid_gen[p] = 0; h->grid_cell_built[p] = 0.f; h->grid_sorted[p] = 0; h->grid_rows[p] = 0; }
 }
 
 smhip_status check_slot(smhip_context* h, int slot) {
@@ -175,6 +175,9 @@ smhip_status enqueue_grid_build(smhip_context* h, const Half& f, int nt_max) {
   hipLaunchKernelGGL(tgt_reduce, dim3(kTgtReduceBlocks, np), dim3(256), 0, f.stream, d);
   hipLaunchKernelGGL(grid_setup, dim3(ceil_div(np, 64)), dim3(64), 0, f.stream, d, np);
   hipLaunchKernelGGL(grid_mark, gpts, dim3(256), 0, f.stream, d);
+  // the ring searches (NDT fitness, GICP neighbourhoods / correspondences) skip empty grid rows through a bitmap; the ball
+  // search of IcpFast visits a handful of rows per query and does not need it
+  if (d.have_rowbits) hipLaunchKernelGGL(grid_rowbits, dim3(ceil_div(kMaxRowWords, 256), np), dim3(256), 0, f.stream, d);
   hipLaunchKernelGGL(grid_rank, dim3(std::max(1, std::min(16, 64 / np)), np), dim3(1024), 0, f.stream, d);   // segments per pair when pairs are few
   hipLaunchKernelGGL(grid_count, gpts, dim3(256), 0, f.stream, d);
   hipLaunchKernelGGL(grid_cscan, dim3(np), dim3(1024), 0, f.stream, d);
@@ -182,7 +185,7 @@ smhip_status enqueue_grid_build(smhip_context* h, const Half& f, int nt_max) {
   if (d.sort_cells) hipLaunchKernelGGL(grid_sort_cells, gpts, dim3(256), 0, f.stream, d);
   HIPCHK(h, hipGetLastError());
   for (int p = d.pair_base; p < d.pair_base + np; ++p) {
-    h->grid_gen[p] = h->tgt_gen[p]; h->grid_cell_built[p] = d.grid_cell; h->grid_sorted[p] = d.sort_cells;
+    h->grid_gen[p] = h->tgt_gen[p]; h->grid_cell_built[p] = d.grid_cell; h->grid_sorted[p] = d.sort_cells; h->grid_rows[p] = d.have_rowbits;
   }
   return SMHIP_OK;
 }
@@ -192,7 +195,8 @@ Half whole_batch(smhip_context* h, int np, int first);
 // is the search structure resident in `slot` the one a build with the current settings would produce?
 bool grid_cached(smhip_context* h, int slot) {
   return h->target_cache && h->grid_gen[slot] != 0 && h->grid_gen[slot] == h->tgt_gen[slot] &&
-         h->grid_cell_built[slot] == h->dev.grid_cell && h->grid_sorted[slot] >= h->dev.sort_cells;
+         h->grid_cell_built[slot] == h->dev.grid_cell && h->grid_sorted[slot] >= h->dev.sort_cells &&
+         h->grid_rows[slot] >= (h->dev.use_ball ? 0 : 1);
 }
 
 // single-pair form of enqueue_resets + enqueue_grid_build that skips the build when the slot's target is unchanged
@@ -202,7 +206,7 @@ smhip_status enqueue_prepare_one(smhip_context* h, int slot, int nt_max) {
     if (s) return s;
     return enqueue_grid_build(h, whole_batch(h, 1, slot), nt_max);
   }
-  IcpDev d = h->dev; d.npairs = 1; d.pair_base = slot;
+  IcpDev d = h->dev; d.npairs = 1; d.pair_base = slot; d.have_rowbits = h->dev.use_ball ? 0 : 1;
   HIPCHK(h, hipMemcpyAsync(const_cast<PairInput*>(d.in) + slot, h->in_pinned + slot, sizeof(PairInput), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(reset_scratch_light, dim3(8), dim3(256), 0, h->stream, d, slot, 1);
   hipLaunchKernelGGL(pose_setup, dim3(1), dim3(64), 0, h->stream, d, 1);
@@ -214,6 +218,7 @@ smhip_status enqueue_prepare_one(smhip_context* h, int slot, int nt_max) {
 Half whole_batch(smhip_context* h, int np, int first) {
   Half f;
   f.d = h->dev; f.d.npairs = np; f.d.pair_base = first;
+  f.d.have_rowbits = h->dev.use_ball ? 0 : 1;     // ring-search contexts build and use the row-occupancy bitmap
   f.stream = h->stream; f.np = np;
   return f;
 }
@@ -439,6 +444,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, &d.tord, B * NT));
   A(dev_alloc(h, &d.bits, B * kMaxGridWords));
   A(dev_alloc(h, &d.words, B * kMaxGridWords));
+  A(dev_alloc(h, &d.rowbits, B * (size_t)kMaxRowWords));
   A(dev_alloc(h, &d.ccount, B * (NT + 1)));
   A(dev_alloc(h, &d.cstart, B * (NT + 1)));
   A(dev_alloc(h, &d.d2, B * NS));
@@ -470,7 +476,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   if (s == SMHIP_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
   if (s != SMHIP_OK) { smhip_destroy(h); return s; }
   h->ns.assign(B, 0); h->nt.assign(B, 0); h->has_normals.assign(B, 0);
-  h->tgt_gen.assign(B, 0); h->grid_gen.assign(B, 0); h->grid_cell_built.assign(B, 0.f); h->grid_sorted.assign(B, 0);
+  h->tgt_gen.assign(B, 0); h->grid_gen.assign(B, 0); h->grid_cell_built.assign(B, 0.f); h->grid_sorted.assign(B, 0); h->grid_rows.assign(B, 0);
   sync_options(h);
   *out = h;
   return SMHIP_OK;

@@ -20,6 +20,7 @@ constexpr int kFinalizeKeyCap = 4096;     // boundary-bin keys finalize keeps in
 constexpr int kFinalizeMaxSeg = 2048;     // accumulate waves (= blist segments) per pair finalize can index: 4 Mi source points at 32 per thread
 constexpr int kAccCols = 32;             // 21 (A upper) + 6 (b) + 1 (sum sqrt d2) + 1 (count) padded to 32
 constexpr int kMaxGridWords = 1 << 18;   // 32-cell words per pair (8 Mi cells)
+constexpr int kMaxRowWords = (kMaxGridWords >> 5) + 2;   // 32-row words of the row-occupancy bitmap (rows = ny * nz <= kMaxGridWords), + slack for two-word reads
 constexpr int kTgtReduceBlocks = 32;     // partial blocks for the target mean / bbox
 constexpr int kBruteTile = 1024;         // target points staged in LDS per tile of the brute-force kernels (16 KiB as float4)
 constexpr int kFallbackSlices = 64;      // target slices the fallback sweep is spread over
@@ -106,6 +107,8 @@ struct IcpDev {
   uint32_t* tord;            // [slots][nt_cap] ordinal inside the cell
   uint32_t* bits;            // [slots][kMaxGridWords]
   uint2* words;              // [slots][kMaxGridWords] {occupancy bits, exclusive rank}
+  uint32_t* rowbits;         // [slots][kMaxRowWords] bit (z * ny + y) = grid row (y, z) holds at least one point (built for the ring searches)
+  int32_t have_rowbits;      // 1 = rowbits describes the resident grid
   uint32_t* ccount;          // [slots][nt_cap + 1]
   uint32_t* cstart;          // [slots][nt_cap + 1]
   float* lb;                 // [slots][ns_cap] > 0: every target point other than the match is at least this far;

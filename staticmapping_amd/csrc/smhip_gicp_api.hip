@@ -306,7 +306,12 @@ smhip_status gicp_find_closests(smhip_context* h, int ns_max, float cutoff2) {
   const int sort_was = h->dev.sort_cells, ball_was = h->dev.use_ball;
   h->dev.sort_cells = 0; h->dev.use_ball = 0;
   h->dev.nn_cutoff2 = cutoff2;          // correspondences beyond the distance threshold are dropped anyway (gicp_corr)
+  // with the row-occupancy bitmap a wide ring is cheap: let the ring search reach the correspondence distance (5 m =
+  // 20 cells) instead of handing the far queries to the brute-force sweep over the whole 0.5 M-point target
+  const int ring_was = h->dev.max_ring;
+  h->dev.max_ring = std::max(ring_was, 32);
   const smhip_status s = enqueue_find_closests(h, 1, ns_max);
+  h->dev.max_ring = ring_was;
   h->dev.nn_cutoff2 = 0.f;
   h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was;
   HIPCHK(h, hipMemsetAsync(h->dev.hist, 0, sizeof(uint32_t) * kHistBins, h->stream));
@@ -337,12 +342,14 @@ smhip_status gicp_align_slot0(smhip_context* h, const float* guess, float* final
   h->dev.grid_cell = cell_was;
   if (s) return s;
   // the set's LDS footprint follows k (the default 20 fits 20 entries per thread: 20 KiB per workgroup instead of 32)
+  IcpDev dk = h->dev;
+  dk.have_rowbits = 1;                       // built by gicp_prepare_slots (a ring-search context)
   if (k <= 20) {
-    hipLaunchKernelGGL(gicp_knn_cov<20>, dim3(ceil_div(nt, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, h->dev, 0, k, o.gicp_epsilon, G.dev.cov_t);
-    hipLaunchKernelGGL(gicp_knn_cov<20>, dim3(ceil_div(ns, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, h->dev, 1, k, o.gicp_epsilon, G.dev.cov_s);
+    hipLaunchKernelGGL(gicp_knn_cov<20>, dim3(ceil_div(nt, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, dk, 0, k, o.gicp_epsilon, G.dev.cov_t);
+    hipLaunchKernelGGL(gicp_knn_cov<20>, dim3(ceil_div(ns, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, dk, 1, k, o.gicp_epsilon, G.dev.cov_s);
   } else {
-    hipLaunchKernelGGL(gicp_knn_cov<kGicpKMax>, dim3(ceil_div(nt, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, h->dev, 0, k, o.gicp_epsilon, G.dev.cov_t);
-    hipLaunchKernelGGL(gicp_knn_cov<kGicpKMax>, dim3(ceil_div(ns, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, h->dev, 1, k, o.gicp_epsilon, G.dev.cov_s);
+    hipLaunchKernelGGL(gicp_knn_cov<kGicpKMax>, dim3(ceil_div(nt, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, dk, 0, k, o.gicp_epsilon, G.dev.cov_t);
+    hipLaunchKernelGGL(gicp_knn_cov<kGicpKMax>, dim3(ceil_div(ns, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, dk, 1, k, o.gicp_epsilon, G.dev.cov_s);
   }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));              // the pinned pair inputs are rewritten below

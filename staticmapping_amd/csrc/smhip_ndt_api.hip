@@ -277,10 +277,12 @@ smhip_status fitness_score(smhip_context* h, const double* T, double* out) {
   // distances only: no tie-order requirement (skip the per-cell sort) and no previous match to seed a
   // ball search -> plain exact ring search (r = 1 certifies almost every query against a dense submap)
   const int sort_was = h->dev.sort_cells, ball_was = h->dev.use_ball;
+  const int ring_was = h->dev.max_ring;
   h->dev.sort_cells = 0; h->dev.use_ball = 0;
+  h->dev.max_ring = std::max(ring_was, 32);      // wide rings are cheap with the row-occupancy bitmap; fewer queries reach the brute-force sweep
   s = enqueue_prepare(h, 1, nt_max);
   if (s == SMHIP_OK) s = enqueue_find_closests(h, 1, ns_max);
-  h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was;
+  h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was; h->dev.max_ring = ring_was;
   if (s) return s;
   hipLaunchKernelGGL(fitness_partial, dim3(64), dim3(256), 0, h->stream, h->dev.d2, h->ns[0], n.fit_dev);
   HIPCHK(h, hipMemsetAsync(h->dev.hist, 0, sizeof(uint32_t) * kHistBins, h->stream));

@@ -516,7 +516,7 @@ def other_workloads(dev, with_cpu):
         if not (with_cpu and os.environ.get("SMHIP_BENCH_GICP_CPU", "1") == "1") and os.path.exists(recorded):
             # the numpy oracle needs ~30 s for this case on the GPU box: when it is switched off (SMHIP_BENCH_GICP_CPU=0 or
             # --no-cpu-baseline) the line carries the figure of the recorded run
-            # (tools/gpu_run8.sh wrote the file)
+            # (tools/evidence_bench.sh wrote the file)
             try:
                 out["ndt_gicp"]["cpu_baseline"] = dict(json.load(open(recorded)), measured="recorded run, profiles/r02_gicp_cpu_baseline.json")
             except Exception:

@@ -50,7 +50,11 @@ typedef struct smhip_context* smhip_handle;
 /* nn_mode values */
 enum {
   SMHIP_NN_BRUTE = 0,           /* LDS-tiled exact brute force (BASELINE config #2) */
-  SMHIP_NN_GRID = 1             /* bit-rank voxel grid, exact with brute-force fallback */
+  SMHIP_NN_GRID = 1,            /* bit-rank voxel grid, exact with brute-force fallback */
+  SMHIP_NN_NABO = 2             /* the reference's own search: libnabo 1.0.7's KDTREE_LINEAR_HEAP tree rebuilt per Align and
+                                   its epsilon-approximate knn (icp_fast.cc:169-180, 464-467), nn_epsilon = 3.16 there.
+                                   APPROXIMATE by design: the mode that reproduces what a libnabo build of the reference
+                                   returns; the exact modes differ from it by millimetres */
 };
 
 /* Options of the IcpFast-equivalent matcher.  max_iteration / dist_outlier_ratio
@@ -61,7 +65,7 @@ typedef struct smhip_icp_options {
   float dist_outlier_ratio;     /* default 0.7f */
   int32_t early_exit;           /* 1 = CheckConvergence enabled (reference behaviour, icp_fast.cc:377-405);
                                    0 = run exactly max_iteration iterations (throughput runs) */
-  int32_t nn_mode;              /* SMHIP_NN_GRID (default) or SMHIP_NN_BRUTE */
+  int32_t nn_mode;              /* SMHIP_NN_GRID (default), SMHIP_NN_BRUTE or SMHIP_NN_NABO */
   float grid_cell;              /* voxel edge in metres for SMHIP_NN_GRID (default 0.25) */
   int32_t grid_max_ring;        /* largest ring searched in the grid before the brute-force fallback (default 8: rings 1, 2, 4, 8) */
   int32_t check_every;          /* host polls the device "all done" word every this many iterations (default 8) */
@@ -82,6 +86,7 @@ typedef struct smhip_icp_options {
   int32_t split_after;          /* iterations >= this run the certificate pass and the search of the failing queries as two
                                    launches instead of the fused kernel (pays once few certificates fail); 0 = default 8,
                                    negative = never.  Results are identical either way. */
+  float nn_epsilon;             /* SMHIP_NN_NABO only: libnabo's epsilon (default 3.16, icp_fast.cc:174; 0 = exact through the tree) */
 } smhip_icp_options;
 
 /* Per-call statistics (all optional to read). */

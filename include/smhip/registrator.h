@@ -280,6 +280,7 @@ class IcpFastHip : public Interface {
     SMHIP_REG_REGISTRATOR_INNER_OPTION("device_id", OptionItemDataType::kInt32, device_);
     SMHIP_REG_REGISTRATOR_INNER_OPTION("max_points", OptionItemDataType::kInt32, max_points_);
     SMHIP_REG_REGISTRATOR_INNER_OPTION("nn_mode", OptionItemDataType::kInt32, options_.nn_mode);
+    SMHIP_REG_REGISTRATOR_INNER_OPTION("nn_epsilon", OptionItemDataType::kFloat32, options_.nn_epsilon);
     SMHIP_REG_REGISTRATOR_INNER_OPTION("grid_cell", OptionItemDataType::kFloat32, options_.grid_cell);
     SMHIP_REG_REGISTRATOR_INNER_OPTION("exact_matches", OptionItemDataType::kBool, options_.exact_matches);
   }
@@ -412,6 +413,7 @@ class IcpFastHip : public Interface {
     o.max_iteration = options_.max_iteration;
     o.dist_outlier_ratio = options_.dist_outlier_ratio;
     o.nn_mode = options_.nn_mode;
+    o.nn_epsilon = options_.nn_epsilon;
     o.grid_cell = options_.grid_cell;
     o.exact_matches = options_.exact_matches ? 1 : 0;
     return Ok(smhip_icp_set_options(h, &o), "smhip_icp_set_options");
@@ -438,7 +440,8 @@ class IcpFastHip : public Interface {
     int32_t knn_for_normal_estimate = 7;     // icp_fast.h:57 (unused there as well)
     int32_t max_iteration = 100;             // icp_fast.h:58
     float dist_outlier_ratio = 0.7f;         // icp_fast.h:59
-    int32_t nn_mode = SMHIP_NN_GRID;
+    int32_t nn_mode = SMHIP_NN_GRID;         // SMHIP_NN_NABO = libnabo's tree and epsilon search (what the reference runs)
+    float nn_epsilon = 3.16f;                // icp_fast.cc:174
     float grid_cell = 0.25f;
     bool exact_matches = false;
   } options_;

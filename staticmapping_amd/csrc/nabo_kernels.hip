@@ -1,0 +1,438 @@
+// nabo_kernels.hip -- the reference's OWN nearest-neighbour search on the device (nn_mode = SMHIP_NN_NABO).
+//
+// IcpFast asks libnabo for an APPROXIMATE neighbour: NNS::create(points, dim, KDTREE_LINEAR_HEAP) rebuilt in every Align
+// (/root/reference/registrators/icp_fast.cc:464-467) and knn(query, ids, dists, 1, epsilon = 3.16, ALLOW_SELF_MATCH)
+// in every iteration (:169-180).  With epsilon = 3.16 a subtree is skipped unless it could hold a point (1 + 3.16)^2 =
+// 17.3 times closer (squared) than the best so far, so what comes back is often NOT the nearest neighbour, and a whole
+// Align ends 3-4 mm away from one that uses the exact neighbour -- more than the 1e-3 m the
+// north star allows.  The exact grid search (icp_kernels.hip) therefore cannot land within tolerance of a libnabo build;
+// this file walks libnabo's tree with libnabo's rule instead.
+//
+// libnabo is a git dependency pinned to tags/1.0.7 (setup/install_libnabo.sh:16-18), not vendored; the algorithm is the
+// published one of nabo/kdtree_cpu.cpp (class KDTreeUnbalancedPtInLeavesImplicitBoundsStackOpt), as restated and
+// cross-checked in oracle/nabo.py and oracle/csrc/smref_icp.c (nabo_*):
+//   buildNodes  leaf when count <= bucketSize (8); cut dimension = argMax(maxValues - minValues) of the box INHERITED from
+//               the parent (root: the cloud's bounds; a child gets the parent's box cut at cutVal), argMax starting from
+//               (index 0, value 0); leftCount = count - count / 2; std::nth_element at first + leftCount; cutVal = that
+//               element's coordinate.
+//   recurseKnn  leaf: every bucket entry with dist < best replaces it; inner node: new_off = q[cd] - cutVal, the side of
+//               the query first, then rd += new_off^2 - old_off^2 and the other side only if rd (1 + eps)^2 < best.
+// The tree depends only on which points fall on which side of each median (tie-free data: uniquely), so it is built
+// level by level with an exact radix select per segment instead of a recursive nth_element; the search keeps libnabo's
+// visiting order (deepest pending sibling first) with an explicit stack of root paths.
+// Arithmetic: float32 on the centred target / transformed query, like every other search here (libnabo: float64): a
+// pruning test within one float ulp of its threshold can fall the other way -- tests/test_nabo_gpu.py counts how often.
+#pragma once
+#include "smhip_device.h"
+
+namespace smhip {
+
+constexpr int kKdThreads = 1024;          // one workgroup builds one pair's tree
+constexpr int kKdBucket = 8;              // libnabo's default bucketSize
+constexpr int kKdHistWords = 16384;       // 64 KiB of LDS histograms: segments per pass x 2^bits bins
+constexpr int kKdStack = 24;              // pending siblings per query: at most one per tree level
+constexpr int kKdTopNodes = 511;          // tree levels 0..8 staged in LDS by the search kernel
+
+struct KdSeg {                            // one node of the current level while the tree is being built
+  uint32_t first, count;                  // its points: positions [first, first + count) of the working order
+  float mn[3], mx[3];                     // the box it inherited
+  uint32_t node;                          // its index in the node array
+  uint32_t split;                         // 1 = more than a bucket: splits at this level
+  uint32_t dim, left;                     // cut dimension, leftCount
+  uint32_t prefix, k, nless, neq;         // radix select state: key bits fixed so far, rank among the still-matching keys,
+                                          // keys known to be smaller, keys equal to the selected one
+  uint32_t vidx;                          // ties at the median: caller indices below this one go left
+  uint32_t rank;                          // number of splitting segments before this one
+  uint32_t tie, trank;                    // several points ON the median value of which `trank` (running) must go left
+};
+
+struct KdDev {
+  uint2* nodes;        // [slots][kd_node_cap]  inner: {cut value bits, (left child << 2) | dim}; leaf: {first, (count << 2) | 3}
+  KdSeg* segs;         // [slots][2][kd_seg_cap]
+  float4* alt;         // [slots][nt_cap]       second working order (ping-pong with tq)
+  uint32_t* cnt;       // [slots][2 * seg_cap]  left / right fill counters of a level with more segments than LDS holds
+  int32_t node_cap, seg_cap;
+  float max_error2;    // (1 + epsilon)^2
+};
+// rd of a sibling: the squared distance to its half-space box, updated exactly as recurseKnn does (no contraction, so
+// that the pre-filter at push time and the test at pop time see the same number)
+__device__ __forceinline__ float kd_rd_step(float rd, float old_off, float new_off) {
+  return __fadd_rn(rd, __fadd_rn(-__fmul_rn(old_off, old_off), __fmul_rn(new_off, new_off)));
+}
+
+__device__ __forceinline__ uint32_t kd_key(float x) {          // order-preserving float -> uint
+  const uint32_t u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float kd_unkey(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__device__ __forceinline__ float kd_coord(const float4 p, uint32_t d) { return d == 0 ? p.x : (d == 1 ? p.y : p.z); }
+
+// Build: grid = (pairs), 1024 threads.  Needs tgt_reduce + grid_setup to have run (st->mu, st->nt).
+__global__ __launch_bounds__(kKdThreads) void kd_build(IcpDev b, KdDev kd) {
+  const int pair = b.pair_base + blockIdx.x;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  const int n = st->nt;
+  const int tid = threadIdx.x;
+  __shared__ uint32_t s_hist[kKdHistWords];
+  __shared__ uint32_t s_w[17];
+  __shared__ float s_box[6][16];
+  __shared__ uint32_t s_misc[4];
+  const size_t to = (size_t)pair * b.nt_cap;
+  float4* cur = b.tq + to;                                   // working order: centred point, w = caller index
+  float4* oth = kd.alt + to;
+  uint32_t* sid = b.tcell + to;                              // segment of every position (0xffffffff = already in a leaf)
+  uint32_t* sid_o = b.tslot + to;
+  KdSeg* seg = kd.segs + (size_t)pair * 2 * kd.seg_cap;
+  KdSeg* seg_o = seg + kd.seg_cap;
+  uint2* nodes = kd.nodes + (size_t)pair * kd.node_cap;
+  const double mu[3] = {st->mu[0], st->mu[1], st->mu[2]};
+
+  // ---- centred points in caller order + the cloud's bounds (the root's box)
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = tid; i < n; i += kKdThreads) {
+    const float3 c = centre_point(b.tgt_p[to + i], mu);
+    cur[i] = make_float4(c.x, c.y, c.z, __int_as_float(i));
+    sid[i] = 0;
+    mn[0] = fminf(mn[0], c.x); mn[1] = fminf(mn[1], c.y); mn[2] = fminf(mn[2], c.z);
+    mx[0] = fmaxf(mx[0], c.x); mx[1] = fmaxf(mx[1], c.y); mx[2] = fmaxf(mx[2], c.z);
+  }
+  for (int d = 0; d < 3; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+  if ((tid & 63) == 0) for (int d = 0; d < 3; ++d) { s_box[d][tid >> 6] = mn[d]; s_box[3 + d][tid >> 6] = mx[d]; }
+  __syncthreads();
+  if (tid == 0) {
+    KdSeg r{};
+    r.first = 0; r.count = (uint32_t)n; r.node = 0;
+    for (int d = 0; d < 3; ++d) {
+      float a = s_box[d][0], c = s_box[3 + d][0];
+      for (int w = 1; w < kKdThreads / 64; ++w) { a = fminf(a, s_box[d][w]); c = fmaxf(c, s_box[3 + d][w]); }
+      r.mn[d] = a; r.mx[d] = c;
+    }
+    seg[0] = r;
+    s_misc[0] = 1;                                           // node count
+  }
+  __syncthreads();
+
+  int S = 1;                                                 // segments of the current level
+  for (int level = 0; level < 40 && S > 0; ++level) {
+    // ---- per segment: leaf or split, cut dimension, leftCount
+    uint32_t my_splits = 0;
+    const int per = (S + kKdThreads - 1) / kKdThreads;
+    const int s_lo = min(S, tid * per), s_hi = min(S, s_lo + per);
+    for (int s = s_lo; s < s_hi; ++s) {
+      KdSeg& g = seg[s];
+      if (g.count <= (uint32_t)kKdBucket) {
+        g.split = 0;
+        nodes[g.node] = make_uint2(g.first, (g.count << 2) | 3u);
+      } else {
+        g.split = 1;
+        uint32_t cd = 0; float mv = 0.f;                     // argMax from (0, 0.)
+        for (uint32_t d = 0; d < 3; ++d) { const float e = g.mx[d] - g.mn[d]; if (e > mv) { mv = e; cd = d; } }
+        g.dim = cd;
+        g.left = g.count - g.count / 2;
+        g.prefix = 0; g.k = g.left; g.nless = 0; g.neq = 0; g.vidx = 0;
+        ++my_splits;
+      }
+    }
+    uint32_t nsplit;
+    const uint32_t my_rank = block_excl_scan(my_splits, s_w, &nsplit);
+    {
+      uint32_t r = my_rank;
+      for (int s = s_lo; s < s_hi; ++s) if (seg[s].split) seg[s].rank = r++;
+    }
+    __syncthreads();
+    if (nsplit == 0) break;
+    if (2 * nsplit > (uint32_t)kd.seg_cap || s_misc[0] + 2 * nsplit > (uint32_t)kd.node_cap) { if (tid == 0) st->status = 3; break; }   // cannot happen: caps follow nt_cap
+
+    // ---- exact radix select of the element of rank `left` on the cut coordinate, all segments of a group at once
+    const int bits = S <= 64 ? 8 : (S <= 1024 ? 4 : (S <= 4096 ? 2 : 1));
+    const int G = kKdHistWords >> bits;                      // segments per group
+    const uint32_t mask = (1u << bits) - 1u;
+    for (int g0 = 0; g0 < S; g0 += G) {
+      const int g1 = min(S, g0 + G);
+      const uint32_t p_lo = seg[g0].first, p_hi = seg[g1 - 1].first + seg[g1 - 1].count;
+      for (int pass = 0; pass < 2; ++pass) {                 // pass 0: the coordinate key; pass 1 (ties only): the caller index
+        if (pass == 1) {
+          // does any segment of the group have several points ON its median value of which some must go left?
+          if (tid == 0) s_misc[1] = 0;
+          __syncthreads();
+          for (int s = g0 + tid; s < g1; s += kKdThreads) {
+            KdSeg& g = seg[s];
+            g.tie = (g.split && g.neq > 1 && g.k > 0) ? 1u : 0u;
+            g.trank = g.k;
+            g.vidx = 0;                                      // doubles as the prefix of the index select
+            if (g.tie) s_misc[1] = 1;
+          }
+          __syncthreads();
+          if (!s_misc[1]) break;                             // block-uniform
+        }
+        for (int shift = 32 - bits; shift >= 0; shift -= bits) {
+          for (int k = tid; k < (g1 - g0) << bits; k += kKdThreads) s_hist[k] = 0;
+          __syncthreads();
+          for (uint32_t pos = p_lo + tid; pos < p_hi; pos += kKdThreads) {
+            const uint32_t s = sid[pos];
+            if (s == 0xffffffffu) continue;
+            const KdSeg& g = seg[s];
+            if (!g.split) continue;
+            const float4 p = cur[pos];
+            const uint32_t key = kd_key(kd_coord(p, g.dim));
+            if (pass == 0) {
+              if (shift + bits < 32 && (key >> (shift + bits)) != (g.prefix >> (shift + bits))) continue;
+              atomicAdd(&s_hist[((s - g0) << bits) + ((key >> shift) & mask)], 1u);
+            } else {
+              if (!g.tie || key != g.prefix) continue;
+              const uint32_t ik = (uint32_t)__float_as_int(p.w);
+              if (shift + bits < 32 && (ik >> (shift + bits)) != (g.vidx >> (shift + bits))) continue;
+              atomicAdd(&s_hist[((s - g0) << bits) + ((ik >> shift) & mask)], 1u);
+            }
+          }
+          __syncthreads();
+          for (int s = g0 + tid; s < g1; s += kKdThreads) {
+            KdSeg& g = seg[s];
+            if (!g.split || (pass == 1 && !g.tie)) continue;
+            const uint32_t* hh = &s_hist[(s - g0) << bits];
+            const uint32_t want = pass == 0 ? g.k : g.trank;  // rank among the still-matching keys
+            uint32_t cum = 0;
+            for (uint32_t d = 0; d <= mask; ++d) {
+              const uint32_t c = hh[d];
+              if (cum + c > want) {
+                if (pass == 0) { g.prefix |= d << shift; g.nless += cum; g.k -= cum; g.neq = c; }
+                else { g.vidx |= d << shift; g.trank -= cum; }
+                break;
+              }
+              cum += c;
+            }
+          }
+          __syncthreads();
+        }
+      }
+    }
+    // After pass 0: prefix = key of the median element, nless = keys below it, neq = keys equal to it, k = how many of the
+    // equal ones go LEFT (0 for tie-free data).  After pass 1 (ties): vidx = caller index of the first equal point that
+    // goes right.  Without ties vidx stays 0: no equal point goes left.
+
+    // ---- partition into the other buffer; children become the next level's segments
+    const uint32_t nc = s_misc[0];
+    const bool lds_counters = 2 * S <= kKdHistWords;
+    uint32_t* cnt = lds_counters ? s_hist : kd.cnt + (size_t)pair * 2 * kd.seg_cap;
+    for (int k = tid; k < 2 * S; k += kKdThreads) cnt[k] = 0;
+    __syncthreads();
+    for (uint32_t pos0 = 0; pos0 < (uint32_t)n; pos0 += kKdThreads) {     // whole waves take the trip together (ballots below)
+      const uint32_t pos = pos0 + tid;
+      const bool live = pos < (uint32_t)n;
+      uint32_t s = 0xffffffffu;
+      float4 p = make_float4(0, 0, 0, 0);
+      if (live) { s = sid[pos]; p = cur[pos]; }
+      bool moving = false, left = false;
+      uint32_t first = 0, nleft = 0, rank = 0;
+      if (s != 0xffffffffu) {
+        const KdSeg& g = seg[s];
+        if (g.split) {
+          moving = true;
+          const uint32_t key = kd_key(kd_coord(p, g.dim));
+          left = key < g.prefix || (key == g.prefix && (uint32_t)__float_as_int(p.w) < g.vidx);
+          first = g.first; nleft = g.left; rank = g.rank;
+        }
+      }
+      if (live && !moving) { oth[pos] = p; sid_o[pos] = 0xffffffffu; }   // in a leaf (now or earlier): stays where it is for good
+      // fill counters: one atomic per wave and side when the wave's moving lanes share a segment (always so on the upper
+      // levels, where the same two counters would otherwise take every point of the cloud), one per lane otherwise
+      const unsigned long long mm = __ballot(moving);
+      if (mm) {
+        const int lane = tid & 63;
+        const int lead = __ffsll((long long)mm) - 1;
+        const uint32_t s_lead = (uint32_t)__shfl((int)s, lead, 64);
+        const bool uniform = __ballot(moving && s != s_lead) == 0ull;
+        uint32_t np = 0;
+        if (uniform) {
+          const unsigned long long ml = __ballot(moving && left), mr = mm & ~ml;
+          uint32_t bl = 0, br = 0;
+          if (lane == lead) {
+            if (ml) bl = atomicAdd(&cnt[2 * s], (uint32_t)__popcll(ml));
+            if (mr) br = atomicAdd(&cnt[2 * s + 1], (uint32_t)__popcll(mr));
+          }
+          bl = (uint32_t)__shfl((int)bl, lead, 64); br = (uint32_t)__shfl((int)br, lead, 64);
+          const unsigned long long below = (1ull << lane) - 1ull;
+          if (moving) np = left ? first + bl + (uint32_t)__popcll(ml & below) : first + nleft + br + (uint32_t)__popcll(mr & below);
+        } else if (moving) {
+          np = left ? first + atomicAdd(&cnt[2 * s], 1u) : first + nleft + atomicAdd(&cnt[2 * s + 1], 1u);
+        }
+        if (moving) { oth[np] = p; sid_o[np] = 2 * rank + (left ? 0u : 1u); }
+      }
+    }
+    __syncthreads();
+    for (int s = s_lo; s < s_hi; ++s) {
+      const KdSeg& g = seg[s];
+      if (!g.split) continue;
+      const float cut = kd_unkey(g.prefix);
+      nodes[g.node] = make_uint2(__float_as_uint(cut), ((nc + 2 * g.rank) << 2) | g.dim);
+      KdSeg l{}, r{};
+      l.first = g.first; l.count = g.left; l.node = nc + 2 * g.rank;
+      r.first = g.first + g.left; r.count = g.count - g.left; r.node = nc + 2 * g.rank + 1;
+      for (int d = 0; d < 3; ++d) { l.mn[d] = g.mn[d]; l.mx[d] = g.mx[d]; r.mn[d] = g.mn[d]; r.mx[d] = g.mx[d]; }
+      l.mx[g.dim] = cut; r.mn[g.dim] = cut;
+      seg_o[2 * g.rank] = l; seg_o[2 * g.rank + 1] = r;
+    }
+    __syncthreads();
+    if (tid == 0) s_misc[0] = nc + 2 * nsplit;
+    { float4* t4 = cur; cur = oth; oth = t4; }
+    { uint32_t* t1 = sid; sid = sid_o; sid_o = t1; }
+    { KdSeg* ts = seg; seg = seg_o; seg_o = ts; }
+    S = 2 * (int)nsplit;
+    __syncthreads();
+  }
+  // ---- final order into tq (+ normals), bucket entries by caller index (a deterministic stand-in for nth_element's
+  // unspecified order inside a bucket; it only matters for exactly equidistant entries)
+  float4* tq = b.tq + to;
+  if (cur != tq) {
+    for (int i = tid; i < n; i += kKdThreads) tq[i] = cur[i];
+    __syncthreads();
+  }
+  const int nn = (int)s_misc[0];
+  for (int v = tid; v < nn; v += kKdThreads) {
+    const uint2 nd = nodes[v];
+    if ((nd.y & 3u) != 3u) continue;
+    const uint32_t f = nd.x, c = nd.y >> 2;
+    for (uint32_t a = f + 1; a < f + c; ++a) {
+      const float4 kq = tq[a];
+      const int key = __float_as_int(kq.w);
+      uint32_t p = a;
+      while (p > f && __float_as_int(tq[p - 1].w) > key) { tq[p] = tq[p - 1]; --p; }
+      tq[p] = kq;
+    }
+  }
+  __syncthreads();
+  float4* tn = b.tn + to;
+  for (int i = tid; i < n; i += kKdThreads) {
+    float4 nr = b.tgt_n[to + __float_as_int(tq[i].w)];
+    nr.w = 0.f;
+    tn[i] = nr;
+  }
+  if (tid == 0) st->nocc = nn;                               // node count (the grid's occupied-cell count is unused in this mode)
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// knn(k = 1, epsilon, ALLOW_SELF_MATCH): one query per lane, libnabo's visiting order.
+// ------------------------------------------------------------------------------------------------------------------
+struct KdNodeView { uint32_t dim, left; float cut; };   // leaf: dim == 3, left = count, cut bits = first
+
+template <int ITEMS>
+__global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nblk) {
+  int pair, blk;
+  if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  const int ns = st->ns;
+  const int base0 = blk * (kNnThreads * ITEMS);
+  if (base0 >= ns) return;
+  double Mc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Mc[k] = st->M[k];
+  __shared__ uint32_t s_hist[kHistBins];
+  __shared__ uint2 s_top[kKdTopNodes + 1];
+  __shared__ uint32_t s_stack[kKdStack][kNnThreads];
+  const uint2* __restrict__ nodes = kd.nodes + (size_t)pair * kd.node_cap;
+  const float4* __restrict__ tq = b.tq + (size_t)pair * b.nt_cap;
+  const int n_nodes = st->nocc;
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+  for (int k = threadIdx.x; k < min(n_nodes, kKdTopNodes); k += kNnThreads) s_top[k] = nodes[k];
+  __syncthreads();
+  const float E2 = kd.max_error2;
+  const size_t so = (size_t)pair * b.ns_cap;
+  const int t = threadIdx.x;
+  auto node_at = [&](uint32_t v) -> uint2 { return v < (uint32_t)kKdTopNodes ? s_top[v] : nodes[v]; };
+
+  for (int it = 0; it < ITEMS; ++it) {
+    const int i = base0 + it * kNnThreads + t;
+    if (i >= ns) continue;
+    double px, py, pz;
+    transform_point(Mc, b.src[so + i], px, py, pz);
+    const float q[3] = {(float)px, (float)py, (float)pz};
+    float best = INFINITY;
+    int bestj = -1;
+    if (isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]) && n_nodes > 0) {
+      auto scan_leaf = [&](uint2 nd) {
+        const uint32_t f = nd.x, c = nd.y >> 2;
+        for (uint32_t e = f; e < f + c; ++e) {
+          const float d = dist2(tq[e], q[0], q[1], q[2]);
+          if (d < best) { best = d; bestj = (int)e; }
+        }
+      };
+      // (1) plain descent to the query's own leaf
+      uint32_t v = 0;
+      uint2 nd = node_at(v);
+      while ((nd.y & 3u) != 3u) {
+        const float off = (nd.y & 3u) == 0 ? q[0] : ((nd.y & 3u) == 1 ? q[1] : q[2]);
+        v = (nd.y >> 2) + ((off - __uint_as_float(nd.x)) > 0.f ? 1u : 0u);        // children sit side by side: left, right
+        nd = node_at(v);
+      }
+      scan_leaf(nd);
+      // (2) the same path again, remembering the siblings the first leaf's distance cannot prune (on this path no
+      //     coordinate has an offset yet: the sibling's rd is new_off^2).  A stack entry is the sibling's ROOT PATH:
+      //     a leading 1, then one bit per level (1 = right child).
+      int sp = 0;
+      uint32_t path = 1u;
+      v = 0; nd = node_at(v);
+      while ((nd.y & 3u) != 3u) {
+        const uint32_t cd = nd.y & 3u;
+        const float no = (cd == 0 ? q[0] : (cd == 1 ? q[1] : q[2])) - __uint_as_float(nd.x);
+        const uint32_t right = no > 0.f ? 1u : 0u;
+        if (kd_rd_step(0.f, 0.f, no) * E2 < best && sp < kKdStack) s_stack[sp++][t] = (path << 1) | (right ^ 1u);
+        path = (path << 1) | right;
+        v = (nd.y >> 2) + right;
+        nd = node_at(v);
+      }
+      // (3) pending siblings, deepest first; the test is libnabo's, with the best AS OF NOW
+      while (sp > 0) {
+        const uint32_t P = s_stack[--sp][t];
+        // state at that sibling: offsets and rd follow from the path (only steps to the far side of the query add to rd)
+        float off[3] = {0.f, 0.f, 0.f};
+        float rd = 0.f;
+        v = 0; nd = node_at(v);
+        const int depth = 31 - __clz((int)P);
+        for (int l = depth - 1; l >= 0; --l) {
+          const uint32_t cd = nd.y & 3u;
+          const float no = (cd == 0 ? q[0] : (cd == 1 ? q[1] : q[2])) - __uint_as_float(nd.x);
+          const uint32_t near = no > 0.f ? 1u : 0u, bit = (P >> l) & 1u;
+          if (bit != near) {
+            const float oo = cd == 0 ? off[0] : (cd == 1 ? off[1] : off[2]);
+            rd = kd_rd_step(rd, oo, no);
+            if (cd == 0) off[0] = no; else if (cd == 1) off[1] = no; else off[2] = no;
+          }
+          v = (nd.y >> 2) + bit;
+          nd = node_at(v);
+        }
+        if (!(rd * E2 < best)) continue;
+        // explore that subtree: near children first, its own far siblings pushed (pre-filtered with the current best)
+        uint32_t pp = P;
+        while ((nd.y & 3u) != 3u) {
+          const uint32_t cd = nd.y & 3u;
+          const float no = (cd == 0 ? q[0] : (cd == 1 ? q[1] : q[2])) - __uint_as_float(nd.x);
+          const uint32_t right = no > 0.f ? 1u : 0u;
+          const float oo = cd == 0 ? off[0] : (cd == 1 ? off[1] : off[2]);
+          const float rdf = kd_rd_step(rd, oo, no);
+          if (rdf * E2 < best && sp < kKdStack) s_stack[sp++][t] = (pp << 1) | (right ^ 1u);
+          pp = (pp << 1) | right;
+          v = (nd.y >> 2) + right;
+          nd = node_at(v);
+        }
+        scan_leaf(nd);
+      }
+    }
+    b.d2[so + i] = best;
+    b.idx[so + i] = bestj;
+    b.lb[so + i] = 0.f;
+    const uint32_t key = __float_as_uint(best);
+    if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
+  }
+  __syncthreads();
+  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
+    const uint32_t v = s_hist[k];
+    if (v) atomicAdd(&gh[k], v);
+  }
+}
+
+}  // namespace smhip

@@ -7,6 +7,7 @@
 // the device; the host only enqueues launches and, when early exit is on, polls one word
 // every `check_every` iterations.
 #include "icp_kernels.hip"
+#include "nabo_kernels.hip"
 
 #include <hip/hip_runtime.h>
 
@@ -44,6 +45,8 @@ struct smhip_context {
   hipEvent_t ev_fork = nullptr, ev_join[kMaxParts - 1] = {nullptr, nullptr, nullptr};
   int n_side = 0;
   IcpDev dev{};
+  KdDev kd{};                    // SMHIP_NN_NABO: tree arrays, allocated on first use
+  bool kd_allocated = false;
   smhip_icp_options opts{};
   std::vector<int> ns, nt, has_normals;
   // Target-side structures are kept across calls while a slot's target is unchanged (single-pair calls only: the front end
@@ -51,7 +54,7 @@ struct smhip_context {
   // does; grid_gen / grid_cell / grid_sorted describe the search structure currently resident in the slot.
   std::vector<unsigned long long> tgt_gen, grid_gen;
   std::vector<float> grid_cell_built;
-  std::vector<int> grid_sorted, grid_rows;      // grid_rows: the row-occupancy bitmap was built with the structure
+  std::vector<int> grid_sorted, grid_rows, grid_mode;   // grid_rows: row-occupancy bitmap built too; grid_mode: nn_mode of the structure
   unsigned long long gen_counter = 0;
   int target_cache = 1;             // smhip_set_target_cache
   unsigned long long cache_hits = 0;
@@ -139,7 +142,7 @@ void collect_profile(smhip_context* h) {
 
 inline void touch_target(smhip_context* h, int slot) { h->tgt_gen[slot] = ++h->gen_counter; }
 inline void touch_grid(smhip_context* h, int first, int np) {        // the slots' search structures are (re)built / overwritten
-  for (int p = first; p < first + np; ++p) { h->grid_gen[p] = 0; h->grid_cell_built[p] = 0.f; h->grid_sorted[p] = 0; h->grid_rows[p] = 0; }
+  for (int p = first; p < first + np; ++p) { h->grid_gen[p] = 0; h->grid_cell_built[p] = 0.f; h->grid_sorted[p] = 0; h->grid_rows[p] = 0; h->grid_mode[p] = -1; }
 }
 
 smhip_status check_slot(smhip_context* h, int slot) {
@@ -167,6 +170,21 @@ smhip_status enqueue_resets(smhip_context* h, int np, int first = 0) {
 }
 
 // target centring + search-structure build for one half
+smhip_status kd_ensure(smhip_context* h) {
+  if (h->kd_allocated) return SMHIP_OK;
+  const size_t B = h->dev.slots, NT = h->dev.nt_cap;
+  h->kd.node_cap = (int32_t)(NT / 2 + 8);       // a bucket holds > 4 points once the cloud has > 8: <= nt / 4 leaves, 2 leaves - 1 nodes
+  h->kd.seg_cap = (int32_t)(NT / 4 + 8);
+  smhip_status s = SMHIP_OK;
+  auto A = [&](smhip_status r) { if (s == SMHIP_OK) s = r; };
+  A(dev_alloc(h, &h->kd.nodes, B * (size_t)h->kd.node_cap));
+  A(dev_alloc(h, &h->kd.segs, B * 2 * (size_t)h->kd.seg_cap));
+  A(dev_alloc(h, &h->kd.alt, B * NT));
+  A(dev_alloc(h, &h->kd.cnt, B * 2 * (size_t)h->kd.seg_cap));
+  if (s == SMHIP_OK) h->kd_allocated = true;
+  return s;
+}
+
 smhip_status enqueue_grid_build(smhip_context* h, const Half& f, int nt_max) {
   const IcpDev& d = f.d;
   const int np = f.np;
@@ -174,6 +192,17 @@ smhip_status enqueue_grid_build(smhip_context* h, const Half& f, int nt_max) {
   const dim3 gpts(ceil_div(nt_max, 256), np);
   hipLaunchKernelGGL(tgt_reduce, dim3(kTgtReduceBlocks, np), dim3(256), 0, f.stream, d);
   hipLaunchKernelGGL(grid_setup, dim3(ceil_div(np, 64)), dim3(64), 0, f.stream, d, np);
+  if (h->opts.nn_mode == SMHIP_NN_NABO) {
+    // the reference's own structure: libnabo's kd-tree over the centred target, rebuilt per Align (icp_fast.cc:464-467)
+    smhip_status ks = kd_ensure(h);
+    if (ks) return ks;
+    hipLaunchKernelGGL(kd_build, dim3(np), dim3(kKdThreads), 0, f.stream, d, h->kd);
+    HIPCHK(h, hipGetLastError());
+    for (int p = d.pair_base; p < d.pair_base + np; ++p) {
+      h->grid_gen[p] = h->tgt_gen[p]; h->grid_cell_built[p] = d.grid_cell; h->grid_sorted[p] = 1; h->grid_rows[p] = 0; h->grid_mode[p] = SMHIP_NN_NABO;
+    }
+    return SMHIP_OK;
+  }
   hipLaunchKernelGGL(grid_mark, gpts, dim3(256), 0, f.stream, d);
   // the ring searches (NDT fitness, GICP neighbourhoods / correspondences) skip empty grid rows through a bitmap; the ball
   // search of IcpFast visits a handful of rows per query and does not need it
@@ -186,6 +215,7 @@ smhip_status enqueue_grid_build(smhip_context* h, const Half& f, int nt_max) {
   HIPCHK(h, hipGetLastError());
   for (int p = d.pair_base; p < d.pair_base + np; ++p) {
     h->grid_gen[p] = h->tgt_gen[p]; h->grid_cell_built[p] = d.grid_cell; h->grid_sorted[p] = d.sort_cells; h->grid_rows[p] = d.have_rowbits;
+    h->grid_mode[p] = SMHIP_NN_GRID;
   }
   return SMHIP_OK;
 }
@@ -194,6 +224,9 @@ Half whole_batch(smhip_context* h, int np, int first);
 
 // is the search structure resident in `slot` the one a build with the current settings would produce?
 bool grid_cached(smhip_context* h, int slot) {
+  const int want_mode = h->opts.nn_mode == SMHIP_NN_NABO ? SMHIP_NN_NABO : SMHIP_NN_GRID;   // which structure: kd-tree or grid
+  if (h->grid_mode[slot] != want_mode) return false;
+  if (want_mode == SMHIP_NN_NABO) return h->target_cache && h->grid_gen[slot] != 0 && h->grid_gen[slot] == h->tgt_gen[slot];
   return h->target_cache && h->grid_gen[slot] != 0 && h->grid_gen[slot] == h->tgt_gen[slot] &&
          h->grid_cell_built[slot] == h->dev.grid_cell && h->grid_sorted[slot] >= h->dev.sort_cells &&
          h->grid_rows[slot] >= (h->dev.use_ball ? 0 : 1);
@@ -242,7 +275,20 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
   const int np = f.np;
   hipStream_t st = f.stream;
   const dim3 g(ceil_div(ns_max, kNnThreads), np);
-  if (h->opts.nn_mode == SMHIP_NN_GRID) {
+  if (h->opts.nn_mode == SMHIP_NN_NABO) {
+    // knn(k = 1, epsilon) through libnabo's tree: what it returns IS the match (no bounds, nothing to refine)
+    Bracket br(h, 4, st, np);
+    KdDev kd = h->kd;
+    const float e = h->opts.nn_epsilon >= 0.f ? h->opts.nn_epsilon : 3.16f;
+    kd.max_error2 = (1.0f + e) * (1.0f + e);
+    if (f.small) {
+      const int nb1 = ceil_div(ns_max, kNnThreads);
+      hipLaunchKernelGGL(nn_nabo<1>, dim3(nb1 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, kd, nb1);
+    } else {
+      const int nb4 = ceil_div(ns_max, kNnThreads * 4);
+      hipLaunchKernelGGL(nn_nabo<4>, dim3(nb4 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, kd, nb4);
+    }
+  } else if (h->opts.nn_mode == SMHIP_NN_GRID) {
     if (d.use_ball) {
       const int nblk = ceil_div(ns_max, kNnThreads * kBallItems);
       const dim3 gx(nblk * 8 * ceil_div(np, 8));
@@ -398,6 +444,7 @@ void smhip_icp_default_options(smhip_icp_options* o) {
   o->ball_radius = 0.3f;
   o->ball_cap_factor = 1.5f;
   o->no_certify = 0;
+  o->nn_epsilon = 3.16f;           // icp_fast.cc:174 (used by SMHIP_NN_NABO only)
 }
 
 smhip_status smhip_create(int device, void* stream, int pair_slots, int max_source_points, int max_target_points,
@@ -476,7 +523,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   if (s == SMHIP_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
   if (s != SMHIP_OK) { smhip_destroy(h); return s; }
   h->ns.assign(B, 0); h->nt.assign(B, 0); h->has_normals.assign(B, 0);
-  h->tgt_gen.assign(B, 0); h->grid_gen.assign(B, 0); h->grid_cell_built.assign(B, 0.f); h->grid_sorted.assign(B, 0); h->grid_rows.assign(B, 0);
+  h->tgt_gen.assign(B, 0); h->grid_gen.assign(B, 0); h->grid_cell_built.assign(B, 0.f); h->grid_sorted.assign(B, 0); h->grid_rows.assign(B, 0); h->grid_mode.assign(B, -1);
   sync_options(h);
   *out = h;
   return SMHIP_OK;
@@ -519,7 +566,8 @@ smhip_status smhip_icp_set_options(smhip_handle h, const smhip_icp_options* o) {
     h->err = "dist_outlier_ratio must be in [0, 1]";
     return SMHIP_ERR_INVALID_ARGUMENT;
   }
-  if (o->nn_mode != SMHIP_NN_BRUTE && o->nn_mode != SMHIP_NN_GRID) { h->err = "bad nn_mode"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  if (o->nn_mode != SMHIP_NN_BRUTE && o->nn_mode != SMHIP_NN_GRID && o->nn_mode != SMHIP_NN_NABO) { h->err = "bad nn_mode"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  if (o->nn_mode == SMHIP_NN_NABO && !(o->nn_epsilon >= 0.f)) { h->err = "nn_epsilon must be >= 0"; return SMHIP_ERR_INVALID_ARGUMENT; }
   h->opts = *o;
   if (h->opts.check_every < 1) h->opts.check_every = 8;
   sync_options(h);

@@ -11,6 +11,7 @@ from . import _capi
 
 NN_BRUTE = 0
 NN_GRID = 1
+NN_NABO = 2          # libnabo's tree and epsilon-approximate search (the reference's own semantics)
 
 
 class SmhipError(RuntimeError):

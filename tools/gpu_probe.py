@@ -56,7 +56,7 @@ for mode in modes:
             for _ in range(reps): R, sc, st = m.align_batch(B, g)
             dt = (time.time() - t) / reps
             m.enable_profile(True); m.align_batch(B, g); p = m.get_profile(); m.enable_profile(False)
-            print(f"mode={'grid' if mode else 'brute'} ball={tile} radius={margin} cell={cell} ring={ring} B={B} {dt*1e3:.2f} ms/batch "
+            print(f"mode={ {0: 'brute', 1: 'grid', 2: 'nabo'}[mode] } ball={tile} radius={margin} cell={cell} ring={ring} B={B} {dt*1e3:.2f} ms/batch "
                   f"{B/dt:.1f} align/s hard={st[0]['hard_queries']} refined={st[0]['refined_iterations']} searched={st[0]['searched_queries']} fallback={st[0]['fallback_queries']} err={sm.se3_error(R[0], T)}", flush=True)
             print("   ", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in p.items()}, flush=True)
             m.close()

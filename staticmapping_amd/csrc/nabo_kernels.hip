@@ -30,8 +30,8 @@ namespace smhip {
 constexpr int kKdThreads = 1024;          // one workgroup builds one pair's tree
 constexpr int kKdBucket = 8;              // libnabo's default bucketSize
 constexpr int kKdHistWords = 16384;       // 64 KiB of LDS histograms: segments per pass x 2^bits bins
-constexpr int kKdStack = 24;              // pending siblings per query: at most one per tree level
-constexpr int kKdTopNodes = 511;          // tree levels 0..8 staged in LDS by the search kernel
+constexpr int kKdStack = 18;              // pending siblings per query: at most one per tree level (18 levels: > 1 M target points; node < 2^23)
+constexpr int kKdTopNodes = 1023;         // tree levels 0..9 staged in LDS by the search kernel (8 KiB)
 
 struct KdSeg {                            // one node of the current level while the tree is being built
   uint32_t first, count;                  // its points: positions [first, first + count) of the working order
@@ -332,7 +332,10 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
   for (int k = 0; k < 12; ++k) Mc[k] = st->M[k];
   __shared__ uint32_t s_hist[kHistBins];
   __shared__ uint2 s_top[kKdTopNodes + 1];
+  // pending siblings: word A = (node << 2) | cut dimension of its parent, or 0x80000000 | root path for a sibling met
+  // while exploring another sibling's subtree; word B = the query's offset from the parent's cut plane (kind A only)
   __shared__ uint32_t s_stack[kKdStack][kNnThreads];
+  __shared__ float s_off[kKdStack][kNnThreads];
   const uint2* __restrict__ nodes = kd.nodes + (size_t)pair * kd.node_cap;
   const float4* __restrict__ tq = b.tq + (size_t)pair * b.nt_cap;
   const int n_nodes = st->nocc;
@@ -353,67 +356,88 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
     float best = INFINITY;
     int bestj = -1;
     if (isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]) && n_nodes > 0) {
+      // a bucket holds at most 8 consecutive points: all eight loads are issued together (one memory latency per bucket
+      // instead of one per entry), entries beyond the bucket's count are masked; entries are tested in bucket order with
+      // a strict "<", as libnabo's leaf loop does
       auto scan_leaf = [&](uint2 nd) {
         const uint32_t f = nd.x, c = nd.y >> 2;
-        for (uint32_t e = f; e < f + c; ++e) {
-          const float d = dist2(tq[e], q[0], q[1], q[2]);
-          if (d < best) { best = d; bestj = (int)e; }
+        float4 p[kKdBucket];
+#pragma unroll
+        for (int e = 0; e < kKdBucket; ++e) p[e] = tq[f + min((uint32_t)e, c - 1u)];
+#pragma unroll
+        for (int e = 0; e < kKdBucket; ++e) {
+          const float d = dist2(p[e], q[0], q[1], q[2]);
+          if ((uint32_t)e < c && d < best) { best = d; bestj = (int)(f + e); }
         }
       };
-      // (1) plain descent to the query's own leaf
-      uint32_t v = 0;
+      // (1) descent to the query's own leaf.  On this path no coordinate has an offset yet, so the sibling left behind at a
+      //     level has rd = new_off^2 and the offset vector e_cd * new_off: (its node, cd) and new_off are parked in the
+      //     lane's stack column, and once the leaf has been scanned the column is compacted in place to the siblings the
+      //     leaf's distance cannot prune.
+      uint32_t v = 0, path = 1u;
+      int depth = 0;
       uint2 nd = node_at(v);
-      while ((nd.y & 3u) != 3u) {
-        const float off = (nd.y & 3u) == 0 ? q[0] : ((nd.y & 3u) == 1 ? q[1] : q[2]);
-        v = (nd.y >> 2) + ((off - __uint_as_float(nd.x)) > 0.f ? 1u : 0u);        // children sit side by side: left, right
-        nd = node_at(v);
-      }
-      scan_leaf(nd);
-      // (2) the same path again, remembering the siblings the first leaf's distance cannot prune (on this path no
-      //     coordinate has an offset yet: the sibling's rd is new_off^2).  A stack entry is the sibling's ROOT PATH:
-      //     a leading 1, then one bit per level (1 = right child).
-      int sp = 0;
-      uint32_t path = 1u;
-      v = 0; nd = node_at(v);
       while ((nd.y & 3u) != 3u) {
         const uint32_t cd = nd.y & 3u;
         const float no = (cd == 0 ? q[0] : (cd == 1 ? q[1] : q[2])) - __uint_as_float(nd.x);
         const uint32_t right = no > 0.f ? 1u : 0u;
-        if (kd_rd_step(0.f, 0.f, no) * E2 < best && sp < kKdStack) s_stack[sp++][t] = (path << 1) | (right ^ 1u);
+        if (depth < kKdStack) { s_stack[depth][t] = ((uint32_t)depth << 25) | (((nd.y >> 2) + (right ^ 1u)) << 2) | cd; s_off[depth][t] = no; }   // level | node | cd
+        ++depth;
         path = (path << 1) | right;
-        v = (nd.y >> 2) + right;
+        v = (nd.y >> 2) + right;                              // children sit side by side: left, right
         nd = node_at(v);
       }
-      // (3) pending siblings, deepest first; the test is libnabo's, with the best AS OF NOW
+      scan_leaf(nd);
+      int sp = 0;
+      for (int l = 0; l < min(depth, kKdStack); ++l) {         // shallow to deep: the write position never passes the read position
+        const float no = s_off[l][t];
+        if (kd_rd_step(0.f, 0.f, no) * E2 < best) { s_stack[sp][t] = s_stack[l][t]; s_off[sp][t] = no; ++sp; }
+      }
+      // (2) pending siblings, deepest first; the test is libnabo's, with the best AS OF NOW
       while (sp > 0) {
-        const uint32_t P = s_stack[--sp][t];
-        // state at that sibling: offsets and rd follow from the path (only steps to the far side of the query add to rd)
+        --sp;
+        const uint32_t A = s_stack[sp][t];
         float off[3] = {0.f, 0.f, 0.f};
         float rd = 0.f;
-        v = 0; nd = node_at(v);
-        const int depth = 31 - __clz((int)P);
-        for (int l = depth - 1; l >= 0; --l) {
-          const uint32_t cd = nd.y & 3u;
-          const float no = (cd == 0 ? q[0] : (cd == 1 ? q[1] : q[2])) - __uint_as_float(nd.x);
-          const uint32_t near = no > 0.f ? 1u : 0u, bit = (P >> l) & 1u;
-          if (bit != near) {
-            const float oo = cd == 0 ? off[0] : (cd == 1 ? off[1] : off[2]);
-            rd = kd_rd_step(rd, oo, no);
-            if (cd == 0) off[0] = no; else if (cd == 1) off[1] = no; else off[2] = no;
-          }
-          v = (nd.y >> 2) + bit;
+        uint32_t pp;                                           // root path of the node being explored (for nested siblings)
+        if (!(A & 0x80000000u)) {                              // a sibling of the main path: its state is one offset
+          const float no = s_off[sp][t];
+          const uint32_t cd = A & 3u;
+          rd = kd_rd_step(0.f, 0.f, no);
+          if (!(rd * E2 < best)) continue;
+          if (cd == 0) off[0] = no; else if (cd == 1) off[1] = no; else off[2] = no;
+          v = (A >> 2) & 0x7fffffu;
           nd = node_at(v);
+          const int lv = (int)(A >> 25);                       // its root path: the main path down to its level, last step flipped
+          pp = (path >> (depth - lv - 1)) ^ 1u;
+        } else {                                               // met inside another sibling's subtree: re-derive its state from its root path
+          const uint32_t P = A & 0x7fffffffu;
+          v = 0; nd = node_at(v);
+          const int dp = 31 - __clz((int)P);
+          for (int l = dp - 1; l >= 0; --l) {
+            const uint32_t cd = nd.y & 3u;
+            const float no = (cd == 0 ? q[0] : (cd == 1 ? q[1] : q[2])) - __uint_as_float(nd.x);
+            const uint32_t near = no > 0.f ? 1u : 0u, bit = (P >> l) & 1u;
+            if (bit != near) {
+              const float oo = cd == 0 ? off[0] : (cd == 1 ? off[1] : off[2]);
+              rd = kd_rd_step(rd, oo, no);
+              if (cd == 0) off[0] = no; else if (cd == 1) off[1] = no; else off[2] = no;
+            }
+            v = (nd.y >> 2) + bit;
+            nd = node_at(v);
+          }
+          if (!(rd * E2 < best)) continue;
+          pp = P;
         }
-        if (!(rd * E2 < best)) continue;
-        // explore that subtree: near children first, its own far siblings pushed (pre-filtered with the current best)
-        uint32_t pp = P;
+        // explore that subtree: near children first; its own far siblings are pushed as root paths (pre-filtered with the
+        // current best)
         while ((nd.y & 3u) != 3u) {
           const uint32_t cd = nd.y & 3u;
           const float no = (cd == 0 ? q[0] : (cd == 1 ? q[1] : q[2])) - __uint_as_float(nd.x);
           const uint32_t right = no > 0.f ? 1u : 0u;
           const float oo = cd == 0 ? off[0] : (cd == 1 ? off[1] : off[2]);
           const float rdf = kd_rd_step(rd, oo, no);
-          if (rdf * E2 < best && sp < kKdStack) s_stack[sp++][t] = (pp << 1) | (right ^ 1u);
+          if (rdf * E2 < best && sp < kKdStack) { s_stack[sp][t] = 0x80000000u | (pp << 1) | (right ^ 1u); ++sp; }
           pp = (pp << 1) | right;
           v = (nd.y >> 2) + right;
           nd = node_at(v);

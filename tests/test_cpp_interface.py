@@ -99,3 +99,27 @@ def test_cpp_interface_matches_python_path_and_oracle(tmp_path, velo20k):
     da, dt = sm.se3_error(Rg, gref["result"])
     assert da < 3e-3 and dt < 5e-2, (da, dt)            # GICP's own repeatability, see tests/test_ndt_gicp_gpu.py
     assert abs(res["gicp_score"] - gref["score"]) < 2e-2
+
+
+@pytest.mark.gpu
+def test_cpp_interface_with_the_reference_search_semantics(tmp_path, velo20k):
+    """The XML a maintainer would write to get the reference's own neighbour search (libnabo's tree, epsilon = 3.16) from
+    the C++ matcher: `nn_mode` 2 / `nn_epsilon`, against the oracle run with the same search."""
+    import staticmapping_amd as sm
+    from oracle import cref
+    exe = _build_exe()
+    c = velo20k
+    tgt_bin, src_bin = tmp_path / "t.bin", tmp_path / "s.bin"
+    c["tgt"].astype(np.float32).tofile(tgt_bin)
+    c["src"].astype(np.float32).tofile(src_bin)
+    xml = '<param name="nn_mode"> 2 </param><param name="nn_epsilon"> 3.16 </param><!-- <param name="bogus"> 1 </param> -->'
+    out = subprocess.check_output([exe, str(tgt_bin), str(src_bin), "0.6", xml], text=True, timeout=300)
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res["ok"] and res["type"] == 6
+    R = np.array(res["result"]).reshape(4, 4)
+    q, n = sm.calculate_normals(c["tgt"][:, :3].astype(np.float64))
+    ref = cref.icp_fast_align(c["src"][:, :3].astype(np.float64), q, n, guess=c["guess"], nn_eps=3.16)
+    da, dt = sm.se3_error(R, ref["result"])
+    assert da < 1e-4 and dt < 1e-3, (da, dt)
+    exact = cref.icp_fast_align(c["src"][:, :3].astype(np.float64), q, n, guess=c["guess"])
+    assert sm.se3_error(R, exact["result"])[1] > 1e-3          # and it is NOT the exact-search result

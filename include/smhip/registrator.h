@@ -587,6 +587,8 @@ class IcpPointMatcherHip : public Interface {
     SMHIP_REG_REGISTRATOR_INNER_OPTION("max_points", OptionItemDataType::kInt32, max_points_);
     SMHIP_REG_REGISTRATOR_INNER_OPTION("random_sampling_prob", OptionItemDataType::kFloat32, prob_);
     SMHIP_REG_REGISTRATOR_INNER_OPTION("random_seed", OptionItemDataType::kInt32, seed_);
+    SMHIP_REG_REGISTRATOR_INNER_OPTION("nn_mode", OptionItemDataType::kInt32, nn_mode_);
+    SMHIP_REG_REGISTRATOR_INNER_OPTION("nn_epsilon", OptionItemDataType::kFloat32, nn_epsilon_);
   }
   void InitWithOptions() override { EnsureHandle(0, 0); }
 
@@ -624,6 +626,7 @@ class IcpPointMatcherHip : public Interface {
         smhip_prepare_target_from_target(h, 1, 0, &n_target) != SMHIP_OK) return Fail(guess, result);
     smhip_icp_options o; smhip_icp_default_options(&o);
     o.max_iteration = 150; o.dist_outlier_ratio = 0.7f; o.early_exit = 1;           // :196-224
+    o.nn_mode = nn_mode_; o.nn_epsilon = nn_epsilon_;                               // KDTreeMatcher knn 1, epsilon 3.16 (:186-191) when nn_mode = 2
     if (smhip_icp_set_options(h, &o) != SMHIP_OK) return Fail(guess, result);
     double score = 0.0;
     if (smhip_icp_align(h, guess.data(), result.data(), &score, &stats_) != SMHIP_OK) return Fail(guess, result);
@@ -667,6 +670,7 @@ class IcpPointMatcherHip : public Interface {
     }
     smhip_icp_options o; smhip_icp_default_options(&o);
     o.max_iteration = 150; o.dist_outlier_ratio = 0.7f; o.early_exit = 1;
+    o.nn_mode = nn_mode_; o.nn_epsilon = nn_epsilon_;
     if (smhip_icp_set_options(h, &o) != SMHIP_OK) return bad();
     std::vector<double> g(16 * static_cast<size_t>(K)), r(16 * static_cast<size_t>(K)), sc(K);
     for (int k = 0; k < K; ++k) std::memcpy(&g[16 * static_cast<size_t>(k)], guesses[k].data(), sizeof(double) * 16);
@@ -708,6 +712,8 @@ class IcpPointMatcherHip : public Interface {
   bool reading_on_device_ = false, reference_on_device_ = false;
   float prob_ = 0.9f;                           // icp_pointmatcher.cc:172
   int32_t seed_ = 0;
+  int32_t nn_mode_ = SMHIP_NN_GRID;             // SMHIP_NN_NABO = libpointmatcher's KDTreeMatcher as configured (:186-191): libnabo, epsilon 3.16
+  float nn_epsilon_ = 3.16f;
   int32_t device_ = 0;
   int32_t max_points_;
   DeviceArena arena_;

@@ -12,7 +12,7 @@ from scipy.spatial import cKDTree
 from . import icp_fast as o
 
 
-def align(reading_f32, reference_f32, guess, keep_mask, normals_fn=None, use_c=False):
+def align(reading_f32, reference_f32, guess, keep_mask, normals_fn=None, use_c=False, nn_eps=None):
     """Returns (accepted, result 4x4, score, iterations).  use_c: run the ICP loop through the C restatement
     (oracle/csrc/smref_icp.c, same algorithm, seconds instead of minutes on submap-sized clouds)."""
     rd = np.asarray(reading_f32, dtype=np.float32)
@@ -24,16 +24,22 @@ def align(reading_f32, reference_f32, guess, keep_mask, normals_fn=None, use_c=F
     ok = np.isfinite(n).all(axis=1)
     q, n = q[ok], n[ok]
     # compute(): Counter(150) + Differential checkers, TrimmedDist 0.7, PointToPlane               :187-224
-    if use_c:
+    if use_c or nn_eps is not None:
+        # nn_eps: the KDTreeMatcher as the reference configures it (knn 1, epsilon 3.16, :186-191) = libnabo's approximate search
         from . import cref
-        r = cref.icp_fast_align(rd[keep_mask], q, n, guess=guess, max_iteration=150, dist_outlier_ratio=0.7, nthreads=cref.usable_cores())
+        r = cref.icp_fast_align(rd[keep_mask], q, n, guess=guess, max_iteration=150, dist_outlier_ratio=0.7, nthreads=cref.usable_cores(),
+                                nn_eps=nn_eps)
         result, it = r["result"], r["iterations"]
     else:
         result, _, it = o.icp_fast_align(rd[keep_mask], q, n, guess=guess, max_iteration=150, dist_outlier_ratio=0.7)
     # final score: transformed FULL reading vs RAW reference, trimmed 0.7, mean distance           :112-143
     P = o.apply_transform(rd, result)
-    d, _ = cKDTree(rf).query(P)
-    d2 = d * d
+    if nn_eps is not None:
+        from . import cref
+        _, d2, _ = cref.nn_nabo(rf, P, nn_eps)                 # matcher->findClosests with the same epsilon (:115-118)
+    else:
+        d, _ = cKDTree(rf).query(P)
+        d2 = d * d
     limit = o.dists_quantile(d2, float(np.float32(0.7)))
     kept = d2 <= limit
     score = float(np.exp(-np.sqrt(d2[kept]).sum() / kept.sum()))

@@ -100,3 +100,20 @@ def test_sampled_source_keeps_caller_order_indices(velo20k):
     assert (ids == ids_ref).mean() > 0.9995
     assert np.allclose(d2, d2_ref, rtol=1e-4, atol=1e-8)
     m.close()
+
+
+def test_chain_with_the_reference_matcher_settings(velo20k):
+    """KDTreeMatcher as icp_pointmatcher.cc:186-191 configures it (knn 1, epsilon 3.16 = libnabo's approximate search) in
+    the loop AND in the post-hoc score pass: device (nn_mode NABO) vs the oracle run the same way."""
+    import staticmapping_amd as sm
+    from oracle import icp_pointmatcher as opm
+    m = sm.IcpPointMatcherHip(max_points=32768, prob=0.9, seed=4, nn_mode=sm.NN_NABO, nn_epsilon=3.16)
+    m.set_input_source(velo20k["src"]); m.set_input_target(velo20k["tgt"])
+    ok, R = m.align(velo20k["guess"])
+    ok_o, R_o, score_o, it_o = opm.align(velo20k["src"], velo20k["tgt"], velo20k["guess"], m.last_mask,
+                                          normals_fn=_device_target_fn(m), nn_eps=3.16)
+    da, dt = sm.se3_error(R, R_o)
+    assert da < 1e-4 and dt < 1e-3, (da, dt)
+    assert m.iterations == it_o and ok == ok_o
+    assert abs(m.get_fitness_score() - score_o) < 1e-4
+    m.close()

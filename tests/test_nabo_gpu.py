@@ -93,3 +93,42 @@ def test_tree_build_survives_ties_and_tiny_clouds():
         assert (ids >= 0).all() and (ids < len(tgt)).all()
         assert np.allclose(d2, d2_x, rtol=1e-4, atol=1e-8)           # eps = 0: the exact distance, whichever of the tied points
         assert np.allclose(np.linalg.norm(qry - tgt[ids], axis=1) ** 2, d2, rtol=1e-3, atol=1e-6)
+
+
+def test_large_target_tree(capsys):
+    """A 150 k-point target: levels with more than 8192 segments (1-bit radix passes, fill counters in global memory)."""
+    import staticmapping_amd as sm
+    from oracle import cref
+    rng = np.random.default_rng(11)
+    tgt = rng.normal(0, 1, (150_000, 3)) * [40, 30, 2.0]
+    nrm = np.tile([0.0, 0.0, 1.0], (len(tgt), 1))
+    qry = (rng.normal(0, 1, (30_000, 3)) * [42, 31, 2.2]).astype(np.float32)
+    m = sm.IcpFastHip(max_source_points=len(qry), max_target_points=len(tgt), nn_mode=sm.NN_NABO, nn_epsilon=3.16)
+    m.set_input_source(qry); m.set_input_target(tgt, nrm)
+    ids, d2 = m.find_closests(np.eye(4), len(qry))
+    m.close()
+    mean = tgt.mean(axis=0)
+    ids_o, d2_o, _ = cref.nn_nabo(tgt - mean, qry.astype(np.float64) - mean, 3.16)
+    same = ids == ids_o
+    assert same.mean() > 0.998, same.mean()
+    assert np.allclose(d2[same], d2_o[same], rtol=2e-4, atol=1e-9)
+    _, d2_x = cref.nn(tgt - mean, qry.astype(np.float64) - mean)
+    assert (np.sqrt(d2) <= 4.16 * np.sqrt(d2_x) * (1 + 1e-4) + 1e-6).all()
+
+
+def test_batch_equals_single_calls_in_the_reference_search_mode(velo20k):
+    import staticmapping_amd as sm
+    guesses = [velo20k["guess"], velo20k["guess"] @ sm.synth.make_pose(t=(0.05, 0.02, 0.0), rpy_deg=(0, 0, 0.4)), np.eye(4)]
+    single = []
+    for G in guesses:
+        m = sm.IcpFastHip(max_source_points=20000, max_target_points=len(velo20k["q"]), nn_mode=sm.NN_NABO, max_iteration=25)
+        m.set_input_source(velo20k["src"]); m.set_input_target(velo20k["q"], velo20k["n"])
+        single.append(m.align(G)[1]); m.close()
+    m = sm.IcpFastHip(pair_slots=3, max_source_points=20000, max_target_points=len(velo20k["q"]), nn_mode=sm.NN_NABO, max_iteration=25)
+    for s in range(3):
+        m.set_input_source(velo20k["src"], slot=s); m.set_input_target(velo20k["q"], velo20k["n"], slot=s)
+    R, sc, st = m.align_batch(3, guesses)
+    m.close()
+    for k in range(3):
+        da, dt = sm.se3_error(R[k], single[k])
+        assert da < 1e-9 and dt < 1e-8, (k, da, dt)

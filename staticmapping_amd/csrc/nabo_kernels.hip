@@ -171,38 +171,77 @@ __global__ __launch_bounds__(kKdThreads) void kd_build(IcpDev b, KdDev kd) {
         for (int shift = 32 - bits; shift >= 0; shift -= bits) {
           for (int k = tid; k < (g1 - g0) << bits; k += kKdThreads) s_hist[k] = 0;
           __syncthreads();
-          for (uint32_t pos = p_lo + tid; pos < p_hi; pos += kKdThreads) {
-            const uint32_t s = sid[pos];
-            if (s == 0xffffffffu) continue;
-            const KdSeg& g = seg[s];
-            if (!g.split) continue;
-            const float4 p = cur[pos];
-            const uint32_t key = kd_key(kd_coord(p, g.dim));
-            if (pass == 0) {
-              if (shift + bits < 32 && (key >> (shift + bits)) != (g.prefix >> (shift + bits))) continue;
-              atomicAdd(&s_hist[((s - g0) << bits) + ((key >> shift) & mask)], 1u);
-            } else {
-              if (!g.tie || key != g.prefix) continue;
-              const uint32_t ik = (uint32_t)__float_as_int(p.w);
-              if (shift + bits < 32 && (ik >> (shift + bits)) != (g.vidx >> (shift + bits))) continue;
-              atomicAdd(&s_hist[((s - g0) << bits) + ((ik >> shift) & mask)], 1u);
+          // four positions per thread and trip, their three levels of loads (segment id, point, segment state) issued
+          // together: one position at a time every visit was a chain of three dependent memory latencies
+          for (uint32_t pos0 = p_lo + tid; pos0 < p_hi; pos0 += 4 * kKdThreads) {
+            uint32_t sv[4];
+            float4 pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const uint32_t pos = pos0 + u * kKdThreads;
+              sv[u] = pos < p_hi ? sid[pos] : 0xffffffffu;
+              pv[u] = cur[min(pos, p_hi - 1u)];
+            }
+            uint32_t gdim[4], gpre[4], gsel[4], gvid[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const KdSeg& g = seg[sv[u] == 0xffffffffu ? (uint32_t)g0 : sv[u]];
+              gdim[u] = g.dim; gpre[u] = g.prefix; gvid[u] = g.vidx;
+              gsel[u] = sv[u] == 0xffffffffu ? 0u : (pass == 0 ? g.split : (g.split & g.tie));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (!gsel[u]) continue;
+              const uint32_t key = kd_key(kd_coord(pv[u], gdim[u]));
+              if (pass == 0) {
+                if (shift + bits < 32 && (key >> (shift + bits)) != (gpre[u] >> (shift + bits))) continue;
+                atomicAdd(&s_hist[((sv[u] - g0) << bits) + ((key >> shift) & mask)], 1u);
+              } else {
+                if (key != gpre[u]) continue;
+                const uint32_t ik = (uint32_t)__float_as_int(pv[u].w);
+                if (shift + bits < 32 && (ik >> (shift + bits)) != (gvid[u] >> (shift + bits))) continue;
+                atomicAdd(&s_hist[((sv[u] - g0) << bits) + ((ik >> shift) & mask)], 1u);
+              }
             }
           }
           __syncthreads();
-          for (int s = g0 + tid; s < g1; s += kKdThreads) {
-            KdSeg& g = seg[s];
-            if (!g.split || (pass == 1 && !g.tie)) continue;
-            const uint32_t* hh = &s_hist[(s - g0) << bits];
-            const uint32_t want = pass == 0 ? g.k : g.trank;  // rank among the still-matching keys
-            uint32_t cum = 0;
-            for (uint32_t d = 0; d <= mask; ++d) {
-              const uint32_t c = hh[d];
-              if (cum + c > want) {
+          if (bits == 8) {
+            // few segments, 256 bins each: a wave per segment, four bins per lane, one scan (a single thread walking 256
+            // bins took longer than the sweep over the points)
+            const int lane = tid & 63;
+            for (int s = g0 + (tid >> 6); s < g1; s += kKdThreads / 64) {        // wave-uniform
+              KdSeg& g = seg[s];
+              if (!g.split || (pass == 1 && !g.tie)) continue;
+              const uint32_t* hh = &s_hist[(s - g0) << 8];
+              const uint32_t c0 = hh[4 * lane], c1 = hh[4 * lane + 1], c2 = hh[4 * lane + 2], c3 = hh[4 * lane + 3];
+              const uint32_t want = pass == 0 ? g.k : g.trank;
+              const uint32_t incl = wave_incl_scan(c0 + c1 + c2 + c3, lane);
+              const uint32_t excl = incl - (c0 + c1 + c2 + c3);
+              if (excl <= want && want < incl) {                                  // exactly one lane
+                uint32_t cum = excl, d = 4u * lane, c = c0;
+                if (cum + c <= want) { cum += c; ++d; c = c1; }
+                if (cum + c <= want) { cum += c; ++d; c = c2; }
+                if (cum + c <= want) { cum += c; ++d; c = c3; }
                 if (pass == 0) { g.prefix |= d << shift; g.nless += cum; g.k -= cum; g.neq = c; }
                 else { g.vidx |= d << shift; g.trank -= cum; }
-                break;
               }
-              cum += c;
+            }
+          } else {
+            for (int s = g0 + tid; s < g1; s += kKdThreads) {
+              KdSeg& g = seg[s];
+              if (!g.split || (pass == 1 && !g.tie)) continue;
+              const uint32_t* hh = &s_hist[(s - g0) << bits];
+              const uint32_t want = pass == 0 ? g.k : g.trank;  // rank among the still-matching keys
+              uint32_t cum = 0;
+              for (uint32_t d = 0; d <= mask; ++d) {
+                const uint32_t c = hh[d];
+                if (cum + c > want) {
+                  if (pass == 0) { g.prefix |= d << shift; g.nless += cum; g.k -= cum; g.neq = c; }
+                  else { g.vidx |= d << shift; g.trank -= cum; }
+                  break;
+                }
+                cum += c;
+              }
             }
           }
           __syncthreads();

@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--nn-mode", choices=["grid", "brute"], default="grid")
     ap.add_argument("--cell", type=float, default=0.25)
     ap.add_argument("--ring", type=int, default=8)
+    ap.add_argument("--split-after", type=int, default=0, help="smhip_icp_options.split_after (0 = the library's default)")
     ap.add_argument("--headline", choices=["identity", "extrapolated"], default="extrapolated")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="oracle / cpu_baseline sample: distinct pairs run on the host (0 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (no parity-vs-oracle either)")
@@ -145,7 +146,8 @@ def main():
     stream = tstream.cuda_stream
     m = sm.IcpFastHip(device=local_rank, pair_slots=B, max_source_points=ns, max_target_points=nt, stream=stream,
                       max_iteration=ICP_ITERS, early_exit=0, dist_outlier_ratio=RHO,
-                      nn_mode=1 if args.nn_mode == "grid" else 0, grid_cell=args.cell, grid_max_ring=args.ring)
+                      nn_mode=1 if args.nn_mode == "grid" else 0, grid_cell=args.cell, grid_max_ring=args.ring,
+                      split_after=args.split_after)
     # round-robin shard: slot s of this rank is global pair s * world + rank; its clouds are distinct pair (g mod D),
     # uploaded into the slot (every slot has its own copy in HBM: 512 slots x (120k + 21.7k) points)
     mine = shard.pairs_of_rank(n_total, rank, world)
@@ -183,11 +185,14 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         res, scores, stats = m.fetch_batch(B)
-        prof = m.get_profile() if profile_nn else None
+        prof = m.get_profile()
+        split = prof["split_after_used"]     # where the batch switched from the fused search to certify + listed search
         if profile_nn:
             m.enable_profile(False)
+        else:
+            prof = None
         T_all, sc_all, it_all = shard.unpack_pose_rows(gathered)
-        return dict(elapsed=elapsed, value=n_total * steps / elapsed, T=T_all, it=it_all, stats=stats, prof=prof, guesses=guesses)
+        return dict(elapsed=elapsed, value=n_total * steps / elapsed, T=T_all, it=it_all, stats=stats, prof=prof, guesses=guesses, split=split)
 
     def truth_errors(T_all):
         worst_rot = worst_t = 0.0
@@ -222,10 +227,10 @@ def main():
             e_rot, e_t, e_med = truth_errors(ee["T"])
             name_h = "identity_guess" if args.headline == "identity" else "extrapolated_guess"
             name_o = "extrapolated_guess" if args.headline == "identity" else "identity_guess"
-            figures[name_h] = dict(value=round(head["value"], 2), iterations=ICP_ITERS, searched_queries_per_alignment=searched(head["stats"]),
+            figures[name_h] = dict(value=round(head["value"], 2), iterations=ICP_ITERS, searched_queries_per_alignment=searched(head["stats"]), split_after=head["split"],
                                    worst_trans_err_vs_truth_m=h_t, median_trans_err_vs_truth_m=h_med, T=head["T"], guess_key=head_key,
                                    max_iteration=ICP_ITERS, early_exit=False)
-            figures[name_o] = dict(value=round(oth["value"], 2), iterations=ICP_ITERS, searched_queries_per_alignment=searched(oth["stats"]),
+            figures[name_o] = dict(value=round(oth["value"], 2), iterations=ICP_ITERS, searched_queries_per_alignment=searched(oth["stats"]), split_after=oth["split"],
                                    worst_trans_err_vs_truth_m=o_t, median_trans_err_vs_truth_m=o_med, T=oth["T"], guess_key=other_key,
                                    max_iteration=ICP_ITERS, early_exit=False)
             # the reference's own search semantics: libnabo's tree + epsilon = 3.16 approximate knn on the device (nn_mode NABO)
@@ -237,7 +242,7 @@ def main():
                                                        worst_trans_err_vs_truth_m=n_t, median_trans_err_vs_truth_m=n_med, T=nb["T"], guess_key="guess_cv",
                                                        max_iteration=ICP_ITERS, early_exit=False, nn_eps=3.16)
             figures["early_exit"] = dict(value=round(ee["value"], 2), iterations=float(ee["it"].mean()), iterations_max=int(ee["it"].max()),
-                                         searched_queries_per_alignment=searched(ee["stats"]), worst_trans_err_vs_truth_m=e_t,
+                                         searched_queries_per_alignment=searched(ee["stats"]), split_after=ee["split"], worst_trans_err_vs_truth_m=e_t,
                                          median_trans_err_vs_truth_m=e_med, T=ee["T"], guess_key="guess_cv", max_iteration=100, early_exit=True)
     if rank == 0:
         guesses = head["guesses"]
@@ -256,17 +261,28 @@ def main():
         alone = m.get_profile()
         m.enable_profile(False)
         m.set_options(no_overlap=0)
-        alone_ms = alone["ms_nn_main"] / max(1, alone["launches_nn_main"])
-        alone_pairs = int(round(alone["pairs_nn_main"] / max(1, alone["launches_nn_main"])))
-        alone_gbs = nn_bytes_per_launch(alone_pairs, ns) / (alone_ms * 1e-3) / 1e9
-        # ---- roofline of the dominant kernel from the events of the TIMED region
-        nn_ms = nn_prof["ms_nn_main"] / max(1, nn_prof["launches_nn_main"])
-        # with >= 16 pairs a step is two half-batches on two streams: one launch covers B / 2 pairs
-        pairs_per_launch = int(round(nn_prof["pairs_nn_main"] / max(1, nn_prof["launches_nn_main"])))
-        nn_bytes = nn_bytes_per_launch(pairs_per_launch, ns)
-        achieved = nn_bytes / (nn_ms * 1e-3) / 1e9
+        # ---- roofline of the dominant kernel from the events of the TIMED region.  FindClosests runs as two kernels: the
+        # fused search nn_ball_lds in the first iterations and the certificate pass nn_certify (+ a short listed search) in
+        # the rest; both are timed (HIP events on the stream each launch goes to) and the one the timed region spent more
+        # time in is the line's kernel.  Either does one iteration's FindClosests for every pair of its launch: the same
+        # 20 algorithmic bytes per source point.
+        def kernel_figures(p, key):
+            launches = max(1, p[f"launches_{key}"])
+            ms = p[f"ms_{key}"] / launches
+            pairs = int(round(p[f"pairs_{key}"] / launches))
+            by = nn_bytes_per_launch(pairs, ns)
+            return dict(total_ms=p[f"ms_{key}"], launches=p[f"launches_{key}"], avg_launch_ms=ms, pairs_per_launch=pairs,
+                        bytes_per_launch=by, achieved=by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0)
+        kf = {"nn_ball_lds" if args.nn_mode == "grid" else "nn_brute": kernel_figures(nn_prof, "nn_main")}
+        if nn_prof["launches_nn_certify"] > 0:
+            kf["nn_certify"] = kernel_figures(nn_prof, "nn_certify")
+        dom = max(kf, key=lambda k: kf[k]["total_ms"])
+        dom_key = "nn_certify" if dom == "nn_certify" else "nn_main"
+        nn_ms, pairs_per_launch, nn_bytes, achieved = (kf[dom][k] for k in ("avg_launch_ms", "pairs_per_launch", "bytes_per_launch", "achieved"))
+        alone_f = kernel_figures(alone, dom_key)
+        alone_ms, alone_pairs, alone_gbs = alone_f["avg_launch_ms"], alone_f["pairs_per_launch"], alone_f["achieved"]
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "traffic_nn_main.json")
+        tj = os.path.join(ROOT, "profiles", "traffic_nn_main.json" if dom_key == "nn_main" else "traffic_nn_certify.json")
         if os.path.exists(tj):
             try:
                 tdat = json.load(open(tj))
@@ -288,13 +304,17 @@ def main():
                                    + ("identity (SURVEY cfg 2 / cfg 4)" if args.headline == "identity" else "previous pair's motion"),
                        "pairs_per_gpu": B, "global_pairs_per_step": n_total, "distinct_pairs": D, "source_points": ns,
                        "target_points_mean": int(nt_mean), "iterations": ICP_ITERS, "nn_mode": args.nn_mode,
-                       "grid_cell_m": args.cell, "guess": args.headline,
+                       "grid_cell_m": args.cell, "guess": args.headline, "split_after": head["split"],
                        "parallelism": f"pairs round-robin over {world} GPU(s), one RCCL gather of poses"},
-            "roofline": {"bound": "hbm", "kernel": "nn_ball_lds" if args.nn_mode == "grid" else "nn_brute",
+            "roofline": {"bound": "hbm", "kernel": dom,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "bytes_per_launch": nn_bytes, "pairs_per_launch": pairs_per_launch, "avg_launch_ms": round(nn_ms, 4),
-                         "launches_timed": nn_prof["launches_nn_main"],
+                         "launches_timed": kf[dom]["launches"],
+                         "timed_region_ms_by_kernel": {k: round(v["total_ms"], 3) for k, v in kf.items()},
+                         "other_kernels": {k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "pairs_per_launch": v["pairs_per_launch"],
+                                               "launches_timed": v["launches"], "achieved": round(v["achieved"], 2),
+                                               "frac": round(v["achieved"] / HBM_PEAK_GBS, 5)} for k, v in kf.items() if k != dom},
                          "alone": {"note": "same kernel on one stream, not sharing the GPU with the other half-batch",
                                    "pairs_per_launch": alone_pairs, "avg_launch_ms": round(alone_ms, 4),
                                    "achieved": round(alone_gbs, 2), "frac": round(alone_gbs / HBM_PEAK_GBS, 5)},

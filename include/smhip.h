@@ -83,8 +83,10 @@ typedef struct smhip_icp_options {
   int32_t no_overlap;           /* 1: keep a batch on one stream (default 0: a batch is split into parts of >= 16 pairs on
                                    separate streams so one part's latency-bound launches hide behind the others' NN) */
   int32_t overlap_streams;      /* number of such parts, 1..4; 0 = default (2; more parts measured no faster) */
-  int32_t split_after;          /* iterations >= this run the certificate pass and the search of the failing queries as two
-                                   launches instead of the fused kernel (pays once few certificates fail); 0 = default 8,
+  int32_t split_after;          /* batches: iterations >= this run the certificate pass and the search of the failing queries as two
+                                   launches instead of the fused kernel (pays once few certificates fail).  0 = automatic: 2 for a
+                                   handle's first batch, then the first iteration in which the median pair of the PREVIOUS batch
+                                   searched fewer than a fifth of its queries (smhip_icp_profile.split_after_used reports it);
                                    negative = never.  Results are identical either way. */
   float nn_epsilon;             /* SMHIP_NN_NABO only: libnabo's epsilon (default 3.16, icp_fast.cc:174; 0 = exact through the tree) */
 } smhip_icp_options;
@@ -118,6 +120,11 @@ typedef struct smhip_icp_profile {
                                    launches of the converged iterations count under find_closests only) */
   double ms_nn_main;            /* its summed duration (subset of ms_find_closests) */
   double pairs_nn_main;         /* pairs those launches covered, summed (pairs per launch = this / launches_nn_main) */
+  double ms_nn_certify;         /* the certificate pass (nn_certify) alone: summed duration (subset of ms_find_closests) */
+  double pairs_nn_certify;      /* pairs its launches covered, summed */
+  int32_t launches_nn_certify;
+  int32_t split_after_used;     /* iteration from which the last batched enqueue ran certificate pass + listed search (filled with or
+                                   without profiling; 0 = the last enqueue was not a batch of >= 16 pairs) */
 } smhip_icp_profile;
 
 /* ---- library / device ------------------------------------------------- */

@@ -32,7 +32,9 @@ class IcpProfile(ctypes.Structure):
                 ("ms_error_elements", ctypes.c_double), ("ms_solve", ctypes.c_double),
                 ("launches_find_closests", ctypes.c_int32), ("launches_error_elements", ctypes.c_int32),
                 ("launches_solve", ctypes.c_int32), ("launches_nn_main", ctypes.c_int32),
-                ("ms_nn_main", ctypes.c_double), ("pairs_nn_main", ctypes.c_double)]
+                ("ms_nn_main", ctypes.c_double), ("pairs_nn_main", ctypes.c_double),
+                ("ms_nn_certify", ctypes.c_double), ("pairs_nn_certify", ctypes.c_double),
+                ("launches_nn_certify", ctypes.c_int32), ("split_after_used", ctypes.c_int32)]
 
 
 class NdtOptions(ctypes.Structure):

@@ -59,7 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH] + srcs
+           "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH] + os.environ.get("SMHIP_EXTRA_HIPCC_FLAGS", "").split() + srcs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

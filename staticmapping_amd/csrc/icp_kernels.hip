@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void reset_scratch(IcpDev b, int first, int np
   for (size_t k = tid; k < (size_t)kMaxGridWords / 4 * npairs; k += nth) bits4[k] = make_uint4(0, 0, 0, 0);
   for (size_t k = tid; k < (size_t)(b.nt_cap + 1) * npairs; k += nth) cc[k] = 0;
   for (size_t k = tid; k < (size_t)kHistBins * npairs; k += nth) hh[k] = 0;
+  for (size_t k = tid; k < (size_t)kSearchHist * npairs; k += nth) b.search_hist[(size_t)kSearchHist * first + k] = 0;
   if (tid == 0) *b.done_count = 0;
 }
 
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(256) void reset_scratch_light(IcpDev b, int first, 
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
   uint32_t* hh = b.hist + (size_t)kHistBins * first;
   for (size_t k = tid; k < (size_t)kHistBins * npairs; k += nth) hh[k] = 0;
+  for (size_t k = tid; k < (size_t)kSearchHist * npairs; k += nth) b.search_hist[(size_t)kSearchHist * first + k] = 0;
   if (tid == 0) *b.done_count = 0;
 }
 
@@ -467,6 +469,29 @@ __device__ __forceinline__ void test_any_order(const float4 t, int j, float qx, 
   if (d < best.d2 || (d == best.d2 && j < best.j)) { best.d2 = d; best.j = j; }
 }
 
+// source point k of the packed copy (one 12-byte load), as the float4 the kernels were written for
+__device__ __forceinline__ float4 ld_src(const IcpDev& b, size_t k) {
+  const float3 v = *reinterpret_cast<const float3*>(b.src3 + 3 * k);
+  return make_float4(v.x, v.y, v.z, 0.f);
+}
+__device__ __forceinline__ float ld_lb(const IcpDev& b, size_t k) { return b.lb[k]; }
+__device__ __forceinline__ void st_lb(const IcpDev& b, size_t k, float v) { b.lb[k] = v; }
+
+// src (float4 rows as uploaded) -> src3 for pairs [first, first + npairs)
+__global__ __launch_bounds__(256) void pack_source(IcpDev b, int first, int npairs) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  const size_t total = (size_t)npairs * (size_t)b.ns_cap;
+  float* out = const_cast<float*>(b.src3);
+  for (size_t k = tid; k < total; k += nth) {
+    const int pair = first + (int)(k / (size_t)b.ns_cap);
+    const int i = (int)(k % (size_t)b.ns_cap);
+    if (i >= b.in[pair].ns) continue;
+    const size_t g = (size_t)pair * b.ns_cap + i;
+    const float4 v = b.src[g];
+    *reinterpret_cast<float3*>(out + 3 * g) = make_float3(v.x, v.y, v.z);
+  }
+}
+
 __device__ __forceinline__ void transform_point(const double* M, const float4 s, double& px, double& py, double& pz) {
   const double x = s.x, y = s.y, z = s.z;
   px = fma(M[0], x, fma(M[1], y, fma(M[2], z, M[3])));      // ApplyTransform, cloud_types.cc:288-302
@@ -594,7 +619,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
     if (e < count) {
       i = e;
       double px, py, pz;
-      transform_point(st->M, b.src[so + i], px, py, pz);
+      transform_point(st->M, ld_src(b, so + i), px, py, pz);
       const float qx = (float)px, qy = (float)py, qz = (float)pz;
       Best best = {INFINITY, -1, INFINITY};
       float d2out = INFINITY, lbout = 0.f;
@@ -606,7 +631,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
           jp = b.idx[so + i];
           if (jp >= 0) {
             double ux, uy, uz;
-            transform_point(st->M_prev, b.src[so + i], ux, uy, uz);
+            transform_point(st->M_prev, ld_src(b, so + i), ux, uy, uz);
             const float ex = qx - (float)ux, ey = qy - (float)uy, ez = qz - (float)uz;
             R2 = search_radius2(r2cap, dist2(tq[jp], qx, qy, qz), search_margin(sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)))));
           }
@@ -648,7 +673,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
       }
       b.d2[so + i] = d2out;
       b.idx[so + i] = jout;
-      b.lb[so + i] = lbout;
+      st_lb(b, so + i, lbout);
       const uint32_t key = __float_as_uint(d2out);
       if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
     }
@@ -707,7 +732,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball_listed(IcpDev b, int nblk)
     int i = -1;
     if (e < count) {
       i = b.dlist[so + e];
-      const float4 s4 = b.src[so + i];
+      const float4 s4 = ld_src(b, so + i);
       double px, py, pz;
       transform_point(st->M, s4, px, py, pz);
       const float qx = (float)px, qy = (float)py, qz = (float)pz;
@@ -773,7 +798,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball_listed(IcpDev b, int nblk)
         }
         b.d2[so + i] = d2out;
         b.idx[so + i] = jout;
-        b.lb[so + i] = lbout;
+        st_lb(b, so + i, lbout);
         const uint32_t key = __float_as_uint(d2out);
         if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
       }
@@ -817,13 +842,33 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
   const float4* __restrict__ tq = b.tq + (size_t)pair * b.nt_cap;
   const float r_need = 0.9f * sqrtf(st->rcap2);     // a hard query's bound must stay well above the quantile
   uint32_t min_lb = 0xffffffffu;
+  // two-deep software pipeline: a round's streamed values (point, bound, previous match id) are loaded two rounds ahead and
+  // the gather of the previous match one round ahead, so no round waits for a load it has just issued
+  int ic = min(base + (int)threadIdx.x, ns - 1);
+  float4 s_1 = ld_src(b, so + ic);
+  float l_1 = ld_lb(b, so + ic);
+  int j_1 = b.idx[so + ic];
+  ic = min(base + kNnThreads + (int)threadIdx.x, ns - 1);
+  float4 s_2 = ld_src(b, so + ic);
+  float l_2 = ld_lb(b, so + ic);
+  int j_2 = b.idx[so + ic];
+  float4 t_1 = tq[max(j_1, 0)];
   for (int it = 0; it < ITEMS; ++it) {
     const int i = base + it * kNnThreads + threadIdx.x;
     bool hard = false, fail = false;
+    const float4 s = s_1;
+    const float l = l_1;
+    const int j = j_1;
+    const float4 t = t_1;
+    s_1 = s_2; l_1 = l_2; j_1 = j_2;
+    if (it + 1 < ITEMS) t_1 = tq[max(j_1, 0)];
+    if (it + 2 < ITEMS) {
+      ic = min(i + 2 * kNnThreads, ns - 1);
+      s_2 = ld_src(b, so + ic);
+      l_2 = ld_lb(b, so + ic);
+      j_2 = b.idx[so + ic];
+    }
     if (i < ns) {
-      const float4 s = b.src[so + i];
-      const float l = b.lb[so + i];
-      const int j = b.idx[so + i];
       double px, py, pz, ox_, oy_, oz_;
       transform_point(Mc, s, px, py, pz);
       transform_point(Mp, s, ox_, oy_, oz_);
@@ -835,17 +880,17 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
       fail = true;
       if (isfinite(qx) && isfinite(qy) && isfinite(qz) && Lp > 0.f) {
         if (l > 0.f && j >= 0) {
-          const float d1 = dist2(tq[j], qx, qy, qz);
+          const float d1 = dist2(t, qx, qy, qz);
           if (d1 < Lp * Lp) {                       // still the unique nearest neighbour: exact, no search
             b.d2[so + i] = d1;
-            b.lb[so + i] = Lp;
+            st_lb(b, so + i, Lp);
             atomicAdd(&s_hist[__float_as_uint(d1) >> kHistShift], 1u);
             fail = false;
           }
         } else if (l < 0.f && Lp >= r_need) {       // still provably farther than the trimming radius
           const float lb2 = Lp * Lp;
           b.d2[so + i] = lb2;
-          b.lb[so + i] = -Lp;
+          st_lb(b, so + i, -Lp);
           atomicAdd(&s_hist[__float_as_uint(lb2) >> kHistShift], 1u);
           min_lb = min(min_lb, __float_as_uint(lb2));
           hard = true;
@@ -976,8 +1021,8 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
   int jp_cur = -1;
   float l_cur = 0.f;
   if (i < ns) {
-    s_cur = b.src[so + i];
-    if (have_prev) { jp_cur = b.idx[so + i]; if (certify) l_cur = b.lb[so + i]; }
+    s_cur = ld_src(b, so + i);
+    if (have_prev) { jp_cur = b.idx[so + i]; if (certify) l_cur = ld_lb(b, so + i); }
   }
 
   for (int it = 0; it < ITEMS; ++it) {
@@ -992,8 +1037,8 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
     int jp_next = -1;
     float l_next = 0.f;
     if (it + 1 < ITEMS && i_next < ns) {
-      s_next = b.src[so + i_next];
-      if (have_prev) { jp_next = b.idx[so + i_next]; if (certify) l_next = b.lb[so + i_next]; }
+      s_next = ld_src(b, so + i_next);
+      if (have_prev) { jp_next = b.idx[so + i_next]; if (certify) l_next = ld_lb(b, so + i_next); }
     }
     SMHIP_PHASE(0);      // prologue / prefetch issue
     // ---- phase C (every lane): query, previous match, certificate
@@ -1010,7 +1055,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
     if (has_jp) dub2 = dist2(tq[jp_cur], qx, qy, qz);
     bool need_search = valid, hard = false;
     if (i < ns && !valid) {                                // NaN / inf input: no match
-      b.d2[so + i] = INFINITY; b.idx[so + i] = -1; b.lb[so + i] = 0.f;
+      b.d2[so + i] = INFINITY; b.idx[so + i] = -1; st_lb(b, so + i, 0.f);
     }
     float delta = 0.03f;                                   // first iteration: no motion history yet
     if (have_prev && valid) {
@@ -1025,13 +1070,13 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
       if (Lp > 0.f) {
         if (l_cur > 0.f && has_jp && dub2 < Lp * Lp) {     // still the unique nearest neighbour: exact, no search
           b.d2[so + i] = dub2;
-          b.lb[so + i] = Lp;
+          st_lb(b, so + i, Lp);
           atomicAdd(&s_hist[__float_as_uint(dub2) >> kHistShift], 1u);
           need_search = false;
         } else if (l_cur < 0.f && Lp >= r_need) {          // still provably beyond the trimming radius
           const float lb2 = Lp * Lp;
           b.d2[so + i] = lb2;
-          b.lb[so + i] = -Lp;
+          st_lb(b, so + i, -Lp);
           atomicAdd(&s_hist[__float_as_uint(lb2) >> kHistShift], 1u);
           min_lb = min(min_lb, __float_as_uint(lb2));
           hard = true;
@@ -1197,7 +1242,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
       SMHIP_PHASE(5);    // search
       b.d2[so + gi] = d2out;
       b.idx[so + gi] = jout;
-      b.lb[so + gi] = lbout;
+      st_lb(b, so + gi, lbout);
       const uint32_t key = __float_as_uint(d2out);
       if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
     }
@@ -1290,7 +1335,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring(IcpDev b) {
       if (old < 0x7f800000u) atomicSub(&gh[old >> kHistShift], 1u);
     }
     double px, py, pz;
-    transform_point(st->M, b.src[so + i], px, py, pz);
+    transform_point(st->M, ld_src(b, so + i), px, py, pz);
     const float qx = (float)px, qy = (float)py, qz = (float)pz;
     Best best = {INFINITY, -1, INFINITY};
     bool resolved = true;
@@ -1329,7 +1374,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring(IcpDev b) {
     }
     b.d2[so + i] = best.d2;
     b.idx[so + i] = best.j;
-    b.lb[so + i] = 0.f;                 // exact match, but no runner-up information: searched again next time
+    st_lb(b, so + i, 0.f);                 // exact match, but no runner-up information: searched again next time
     if (resolved) {
       const uint32_t key = __float_as_uint(best.d2);
       if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
@@ -1377,7 +1422,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring_coop(IcpDev b) {
     const bool live = e < count;
     const int i = live ? e : 0;
     double px, py, pz;
-    transform_point(st->M, b.src[so + i], px, py, pz);
+    transform_point(st->M, ld_src(b, so + i), px, py, pz);
     const float qx = (float)px, qy = (float)py, qz = (float)pz;
     Best best = {INFINITY, -1, INFINITY};
     bool resolved = true;
@@ -1430,7 +1475,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring_coop(IcpDev b) {
     if (live && sub == 0) {
       b.d2[so + i] = best.d2;
       b.idx[so + i] = best.j;
-      b.lb[so + i] = 0.f;
+      st_lb(b, so + i, 0.f);
       if (resolved) {
         const uint32_t key = __float_as_uint(best.d2);
         if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
@@ -1476,7 +1521,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring_wide(IcpDev b) {
   for (int e = (int)blockIdx.x * kWaves + (int)(threadIdx.x >> 6); e < count; e += (int)gridDim.x * kWaves) {   // wave-uniform
     const int i = b.dlist[so + e];
     double px, py, pz;
-    transform_point(st->M, b.src[so + i], px, py, pz);
+    transform_point(st->M, ld_src(b, so + i), px, py, pz);
     const float qx = (float)px, qy = (float)py, qz = (float)pz;
     const int cx = cell_coord(qx, ox, inv_h), cy = cell_coord(qy, oy, inv_h), cz = cell_coord(qz, oz, inv_h);
     Best best = {b.d2[so + i], b.idx[so + i], INFINITY};            // what the first ring found (uncertified)
@@ -1552,7 +1597,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_brute(IcpDev b) {
   bool valid = false;
   if (active) {
     double px, py, pz;
-    transform_point(st->M, b.src[so + i], px, py, pz);
+    transform_point(st->M, ld_src(b, so + i), px, py, pz);
     qx = (float)px; qy = (float)py; qz = (float)pz;
     valid = isfinite(qx) && isfinite(qy) && isfinite(qz);
   }
@@ -1609,7 +1654,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_fallback(IcpDev b) {
     __syncthreads();
     for (int e = threadIdx.x; e < U; e += kNnThreads) {
       double px, py, pz;
-      transform_point(st->M, b.src[so + b.ulist[so + e]], px, py, pz);
+      transform_point(st->M, ld_src(b, so + b.ulist[so + e]), px, py, pz);
       const float qx = (float)px, qy = (float)py, qz = (float)pz;
       Best best = {INFINITY, -1, INFINITY};
 #pragma unroll 8
@@ -1635,7 +1680,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_fallback(IcpDev b) {
     const uint32_t dbits = (uint32_t)(key >> 32);
     b.d2[so + i] = __uint_as_float(dbits);
     b.idx[so + i] = (int)(uint32_t)(key & 0xffffffffu);
-    b.lb[so + i] = 0.f;
+    st_lb(b, so + i, 0.f);
     if (dbits < 0x7f800000u) atomicAdd(&b.hist[(size_t)pair * kHistBins + (dbits >> kHistShift)], 1u);
   }
   if (threadIdx.x == 0) st->fallback_ticket = 0;
@@ -1722,13 +1767,20 @@ __device__ __forceinline__ void accumulate_terms(const double* M, const float4 s
     for (int e = a; e < 6; ++e) acc[c++] += J[a] * J[e];
 #pragma unroll
   for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;     // b = -sum(J r): sign applied at solve time
-  acc[27] += sqrt((double)d2v);
+  {
+    // sqrt(d2) in double without the f64 sqrt sequence (a sixth of this kernel's vector instructions): the f32 root and one
+    // Newton step in f64, s + (d2 - s^2) / (2 s), good to ~1e-14 relative
+    const float sf = __builtin_amdgcn_sqrtf(d2v);
+    double sd = (double)sf;
+    if (sf > 0.f) sd = fma(fma(-sd, sd, (double)d2v), (double)__builtin_amdgcn_rcpf(sf + sf), sd);
+    acc[27] += sd;
+  }
   acc[28] += 1.0;
 }
 __device__ __forceinline__ void accumulate_pair(const IcpDev& b, const PairState* st, int pair, int i, float d2v, double* acc) {
   const size_t so = (size_t)pair * b.ns_cap, to = (size_t)pair * b.nt_cap;
   const int j = b.idx[so + i];
-  accumulate_terms(st->M, b.src[so + i], b.tq[to + j], b.tn[to + j], d2v, acc);
+  accumulate_terms(st->M, ld_src(b, so + i), b.tq[to + j], b.tn[to + j], d2v, acc);
 }
 
 // Block reduction of kAccCols-3 = 29 doubles; thread 0 ends up with the totals in acc[].
@@ -1793,28 +1845,37 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
   const int seg = blk * (kAccThreads / 64) + (int)(threadIdx.x >> 6);            // this wave's segment: 64 * ITEMS slots
   const size_t segbase = (size_t)pair * b.bl_stride + (size_t)seg * (64 * ITEMS);
   int wcount = 0;
+  // two-deep software pipeline (as nn_certify): stream loads two rounds ahead, the gathers of the matched target point and
+  // normal one round ahead (for every lane: a trimmed query's gather is a wasted L2 hit, but nothing waits on d2 first)
   int ic = min(base + (int)threadIdx.x, ns - 1);
-  float d_n = b.d2[so + ic];
-  float4 s_n = b.src[so + ic];
-  int j_n = b.idx[so + ic];
+  float d_1 = b.d2[so + ic];
+  float4 s_1 = ld_src(b, so + ic);
+  int j_1 = b.idx[so + ic];
+  ic = min(base + kAccThreads + (int)threadIdx.x, ns - 1);
+  float d_2 = b.d2[so + ic];
+  float4 s_2 = ld_src(b, so + ic);
+  int j_2 = b.idx[so + ic];
+  float4 q_1 = b.tq[to + max(j_1, 0)], n_1 = b.tn[to + max(j_1, 0)];
 #pragma unroll 2
   for (int it = 0; it < ITEMS; ++it) {
     const int i = base + it * kAccThreads + threadIdx.x;
-    const float d = d_n;
-    const float4 s4 = s_n;
-    const int j = j_n;
-    if (it + 1 < ITEMS) {
-      ic = min(i + kAccThreads, ns - 1);
-      d_n = b.d2[so + ic];
-      s_n = b.src[so + ic];
-      j_n = b.idx[so + ic];
+    const float d = d_1;
+    const float4 s4 = s_1;
+    const float4 q4 = q_1, n4 = n_1;
+    d_1 = d_2; s_1 = s_2; j_1 = j_2;
+    if (it + 1 < ITEMS) { q_1 = b.tq[to + max(j_1, 0)]; n_1 = b.tn[to + max(j_1, 0)]; }
+    if (it + 2 < ITEMS) {
+      ic = min(i + 2 * kAccThreads, ns - 1);
+      d_2 = b.d2[so + ic];
+      s_2 = ld_src(b, so + ic);
+      j_2 = b.idx[so + ic];
     }
     bool boundary = false;
     if (i < ns) {
       const uint32_t key = __float_as_uint(d);
       if (key < 0x7f800000u) {
         const uint32_t bin = key >> kHistShift;
-        if (bin < qbin) accumulate_terms(Mc, s4, b.tq[to + j], b.tn[to + j], d, acc);
+        if (bin < qbin) accumulate_terms(Mc, s4, q4, n4, d, acc);
         else boundary = bin == qbin;
       }
     }
@@ -2095,7 +2156,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
           ii[k] = s_idx[e];
         }
 #pragma unroll
-        for (int k = 0; k < kW; ++k) { s4[k] = b.src[so + ii[k]]; jj[k] = max(b.idx[so + ii[k]], 0); }
+        for (int k = 0; k < kW; ++k) { s4[k] = ld_src(b, so + ii[k]); jj[k] = max(b.idx[so + ii[k]], 0); }
 #pragma unroll
         for (int k = 0; k < kW; ++k) { q4[k] = b.tq[to + jj[k]]; n4[k] = b.tn[to + jj[k]]; }
 #pragma unroll
@@ -2135,6 +2196,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   st->hard_total += st->hard_count;
   st->hard_count = 0;
   st->searched_total += st->deferred_count ? st->deferred_count : (uint32_t)ns;
+  if (st->iter < kSearchHist) b.search_hist[(size_t)pair * kSearchHist + st->iter] = st->deferred_count ? st->deferred_count : (uint32_t)ns;
   st->deferred_count = 0;
   st->min_lb_key = 0xffffffffu;
   st->refine = 0;

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
     const int i = base0 + it * kNnThreads + t;
     if (i >= ns) continue;
     double px, py, pz;
-    transform_point(Mc, b.src[so + i], px, py, pz);
+    transform_point(Mc, ld_src(b, so + i), px, py, pz);
     const float q[3] = {(float)px, (float)py, (float)pz};
     float best = INFINITY;
     int bestj = -1;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
     }
     b.d2[so + i] = best;
     b.idx[so + i] = bestj;
-    b.lb[so + i] = 0.f;
+    st_lb(b, so + i, 0.f);
     const uint32_t key = __float_as_uint(best);
     if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
   }

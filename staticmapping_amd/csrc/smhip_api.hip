@@ -53,6 +53,7 @@ struct smhip_context {
   // aligns scan after scan against one key frame, map_builder.cc:379-392).  tgt_gen[slot] changes whenever the slot's target
   // does; grid_gen / grid_cell / grid_sorted describe the search structure currently resident in the slot.
   std::vector<unsigned long long> tgt_gen, grid_gen;
+  std::vector<unsigned long long> src_gen, src3_gen;   // same idea for the packed 12-byte copy of a slot's source (pack_source)
   std::vector<float> grid_cell_built;
   std::vector<int> grid_sorted, grid_rows, grid_mode;   // grid_rows: row-occupancy bitmap built too; grid_mode: nn_mode of the structure
   unsigned long long gen_counter = 0;
@@ -62,6 +63,14 @@ struct smhip_context {
   PairState* state_pinned = nullptr;
   float4* stage = nullptr;       // pinned staging for uploads, 2 * max(ns_cap, nt_cap)
   uint32_t* done_pinned = nullptr;
+  // split_after = 0: where the batched iterations switch from the fused search to certify + listed search follows the
+  // previous batch (the share of queries that needed a search per iteration, search_hist): a front end's guesses are
+  // alike from call to call.  Results do not depend on it, only the time.
+  uint32_t* hist_pinned = nullptr;
+  int hist_first = 0;
+  int hist_pairs = 0;                  // pairs whose rows the last enqueue copied to hist_pinned (0 = none)
+  int hist_iters = 0;                  // iterations that enqueue ran
+  int auto_split = 2;
   int32_t* ids_pinned = nullptr;
   float* d2_pinned = nullptr;
   int32_t* ids_dev = nullptr;    // scratch for exported matches
@@ -107,7 +116,7 @@ struct Bracket {
   smhip_context::Ev* ev = nullptr;
   hipStream_t st;
   Bracket(smhip_context* h_, int cat, hipStream_t st_, int np = 0) : h(h_), st(st_) {
-    if (!h->profile || (h->profile == 2 && cat != 4)) return;
+    if (!h->profile || (h->profile == 2 && cat != 4 && cat != 5)) return;
     if (h->ev_used == h->ev_pool.size()) {
       smhip_context::Ev e{};
       if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
@@ -133,6 +142,8 @@ void collect_profile(smhip_context* h) {
       case 1: h->prof.ms_find_closests += ms; h->prof.launches_find_closests++; break;
       case 4: h->prof.ms_find_closests += ms; h->prof.launches_find_closests++;
               h->prof.ms_nn_main += ms; h->prof.launches_nn_main++; h->prof.pairs_nn_main += h->ev_pool[k].np; break;
+      case 5: h->prof.ms_find_closests += ms; h->prof.launches_find_closests++;
+              h->prof.ms_nn_certify += ms; h->prof.launches_nn_certify++; h->prof.pairs_nn_certify += h->ev_pool[k].np; break;
       case 2: h->prof.ms_error_elements += ms; h->prof.launches_error_elements++; break;
       case 3: h->prof.ms_solve += ms; h->prof.launches_solve++; break;
     }
@@ -141,6 +152,7 @@ void collect_profile(smhip_context* h) {
 }
 
 inline void touch_target(smhip_context* h, int slot) { h->tgt_gen[slot] = ++h->gen_counter; }
+inline void touch_source(smhip_context* h, int slot) { h->src_gen[slot] = ++h->gen_counter; }
 inline void touch_grid(smhip_context* h, int first, int np) {        // the slots' search structures are (re)built / overwritten
   for (int p = first; p < first + np; ++p) { h->grid_gen[p] = 0; h->grid_cell_built[p] = 0.f; h->grid_sorted[p] = 0; h->grid_rows[p] = 0; h->grid_mode[p] = -1; }
 }
@@ -160,13 +172,25 @@ struct Half {
   bool small = false;      // few workgroups per launch: use the single-round NN / short-chunk accumulate variants
 };
 
+// the ICP iteration kernels stream the 12-byte copy of the sources: repacked here (main stream, the PairInput rows already
+// on their way) for launches that cover a slot whose source changed since it was last packed
+smhip_status ensure_packed(smhip_context* h, int first, int np) {
+  bool stale = false;
+  for (int p = first; p < first + np; ++p) stale = stale || h->src3_gen[p] != h->src_gen[p];
+  if (!stale) return SMHIP_OK;
+  hipLaunchKernelGGL(pack_source, dim3(std::min(8192, 128 * np)), dim3(256), 0, h->stream, h->dev, first, np);
+  HIPCHK(h, hipGetLastError());
+  for (int p = first; p < first + np; ++p) h->src3_gen[p] = h->src_gen[p];
+  return SMHIP_OK;
+}
+
 // per-call resets for pairs [0, np) (main stream, before the halves fork)
 smhip_status enqueue_resets(smhip_context* h, int np, int first = 0) {
   IcpDev& d = h->dev;
   touch_grid(h, first, np);               // bits / ccount are zeroed below: whatever structure was resident is gone
   HIPCHK(h, hipMemcpyAsync(const_cast<PairInput*>(d.in) + first, h->in_pinned + first, sizeof(PairInput) * np, hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(reset_scratch, dim3(std::min(4096, 256 * np)), dim3(256), 0, h->stream, d, first, np);
-  return SMHIP_OK;
+  return ensure_packed(h, first, np);
 }
 
 // target centring + search-structure build for one half
@@ -241,6 +265,7 @@ smhip_status enqueue_prepare_one(smhip_context* h, int slot, int nt_max) {
   }
   IcpDev d = h->dev; d.npairs = 1; d.pair_base = slot; d.have_rowbits = h->dev.use_ball ? 0 : 1;
   HIPCHK(h, hipMemcpyAsync(const_cast<PairInput*>(d.in) + slot, h->in_pinned + slot, sizeof(PairInput), hipMemcpyHostToDevice, h->stream));
+  { smhip_status ps = ensure_packed(h, slot, 1); if (ps) return ps; }
   hipLaunchKernelGGL(reset_scratch_light, dim3(8), dim3(256), 0, h->stream, d, slot, 1);
   hipLaunchKernelGGL(pose_setup, dim3(1), dim3(64), 0, h->stream, d, 1);
   HIPCHK(h, hipGetLastError());
@@ -311,7 +336,7 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
         // (also what the converged iterations of the LDS variant use: a streaming certificate pass at full occupancy and a
         // near-empty listed search beat the fused kernel once only a handful of certificates fail)
         {
-          Bracket br(h, d.lds_table ? 1 : 4, st, np);
+          Bracket br(h, d.lds_table ? 5 : 4, st, np);
           if (f.small) {
             const int nb1 = ceil_div(ns_max, kNnThreads);
             hipLaunchKernelGGL(nn_certify<1>, dim3(nb1 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nb1);
@@ -368,7 +393,7 @@ void sync_options(smhip_context* h) {
   h->dev.use_ball = h->opts.use_ball;
   h->dev.sort_cells = 1;
   h->dev.certify = h->opts.no_certify ? 0 : 1;
-  h->dev.split_after = h->opts.split_after > 0 ? h->opts.split_after : (h->opts.split_after < 0 ? 1 << 30 : 8);
+  h->dev.split_after = h->opts.split_after > 0 ? h->opts.split_after : (h->opts.split_after < 0 ? 1 << 30 : 2);
   h->dev.lds_table = h->opts.no_lds_table ? 0 : 1;
   h->dev.cap_factor = h->opts.ball_cap_factor > 1.0f ? h->opts.ball_cap_factor : 1.5f;
   h->dev.exact_all = h->opts.exact_matches;
@@ -482,6 +507,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, &d.state, B));
   A(dev_alloc(h, const_cast<PairInput**>(&d.in), B));
   A(dev_alloc(h, const_cast<float4**>(&d.src), B * NS));
+  A(dev_alloc(h, const_cast<float**>(&d.src3), B * NS * 3));
   A(dev_alloc(h, const_cast<float4**>(&d.tgt_p), B * NT));
   A(dev_alloc(h, const_cast<float4**>(&d.tgt_n), B * NT));
   A(dev_alloc(h, &d.tq, B * NT));
@@ -496,6 +522,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, &d.cstart, B * (NT + 1)));
   A(dev_alloc(h, &d.d2, B * NS));
   A(dev_alloc(h, &d.lb, B * NS));
+  A(dev_alloc(h, &d.search_hist, B * kSearchHist));
   A(dev_alloc(h, &d.idx, B * NS));
   A(dev_alloc(h, &d.hist, B * kHistBins));
   A(dev_alloc(h, &d.dlist, B * NS));
@@ -515,6 +542,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
         hipHostMalloc(reinterpret_cast<void**>(&h->in_pinned), B * sizeof(PairInput)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&h->state_pinned), B * sizeof(PairState)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&h->done_pinned), 64) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h->hist_pinned), B * kSearchHist * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&h->ids_pinned), NS * sizeof(int32_t)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&h->d2_pinned), NS * sizeof(float)) != hipSuccess)
       s = SMHIP_ERR_HIP;
@@ -523,7 +551,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   if (s == SMHIP_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
   if (s != SMHIP_OK) { smhip_destroy(h); return s; }
   h->ns.assign(B, 0); h->nt.assign(B, 0); h->has_normals.assign(B, 0);
-  h->tgt_gen.assign(B, 0); h->grid_gen.assign(B, 0); h->grid_cell_built.assign(B, 0.f); h->grid_sorted.assign(B, 0); h->grid_rows.assign(B, 0); h->grid_mode.assign(B, -1);
+  h->tgt_gen.assign(B, 0); h->grid_gen.assign(B, 0); h->src_gen.assign(B, 1); h->src3_gen.assign(B, 0); h->grid_cell_built.assign(B, 0.f); h->grid_sorted.assign(B, 0); h->grid_rows.assign(B, 0); h->grid_mode.assign(B, -1);
   sync_options(h);
   *out = h;
   return SMHIP_OK;
@@ -546,6 +574,7 @@ smhip_status smhip_destroy(smhip_handle h) {
   if (h->in_pinned) (void)hipHostFree(h->in_pinned);
   if (h->state_pinned) (void)hipHostFree(h->state_pinned);
   if (h->done_pinned) (void)hipHostFree(h->done_pinned);
+  if (h->hist_pinned) (void)hipHostFree(h->hist_pinned);
   if (h->ids_pinned) (void)hipHostFree(h->ids_pinned);
   if (h->d2_pinned) (void)hipHostFree(h->d2_pinned);
   for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -593,6 +622,7 @@ static smhip_status upload_source(smhip_handle h, int slot, int n) {
   if (e != hipSuccess) { h->err = std::string("prep_morton_sort: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->ns[slot] = n;
+  touch_source(h, slot);
   return SMHIP_OK;
 }
 
@@ -792,6 +822,7 @@ smhip_status smhip_sample_source(smhip_handle h, int from, int to, float prob, u
   if (e != hipSuccess) { h->err = std::string("prep_sample_morton: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
   if (m <= 0) { h->err = "sampling kept no point"; return SMHIP_ERR_INVALID_ARGUMENT; }
   h->ns[to] = m;
+  touch_source(h, to);
   if (n_out) *n_out = m;
   return SMHIP_OK;
 }
@@ -826,6 +857,7 @@ smhip_status smhip_copy_slot(smhip_handle h, int from, int to) {
                      const_cast<float4*>(d.src), const_cast<float4*>(d.tgt_p), const_cast<float4*>(d.tgt_n), from, to);
   HIPCHK(h, hipGetLastError());
   h->ns[to] = h->ns[from]; h->nt[to] = h->nt[from]; h->has_normals[to] = h->has_normals[from];
+  touch_source(h, to);
   touch_target(h, to);
   return SMHIP_OK;
 }
@@ -852,6 +884,22 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
   HIPCHK(h, hipStreamSynchronize(h->stream));
   smhip_status s = fill_inputs(h, npairs, guesses, &ns_max, &nt_max, first);
   if (s) return s;
+  if (h->hist_pairs > 0) {
+    // the previous batch is complete (stream synchronised above): the first iteration k >= 1 in which the median pair searched
+    // fewer than a fifth of its queries is where certify + listed search starts to beat the fused kernel (measured: the listed
+    // search costs ~1 ms per 64 pairs with every query listed, the fused kernel 0.25-0.35 ms whatever the share)
+    int k = 1;
+    std::vector<float> share((size_t)h->hist_pairs);
+    for (; k < std::min(h->hist_iters, kSearchHist); ++k) {
+      for (int p = 0; p < h->hist_pairs; ++p) share[p] = (float)h->hist_pinned[(size_t)p * kSearchHist + k] / (float)std::max(1, h->ns[h->hist_first + p]);
+      std::nth_element(share.begin(), share.begin() + share.size() / 2, share.end());
+      if (share[share.size() / 2] < 0.2f) break;
+    }
+    h->auto_split = std::max(1, std::min(k, kSearchHist));
+    h->hist_pairs = 0;
+  }
+  if (h->opts.split_after == 0) h->dev.split_after = h->auto_split;
+  h->prof.split_after_used = npairs >= 16 && h->dev.certify ? h->dev.split_after : 0;
   const bool cached_one = npairs == 1 && grid_cached(h, first);
   if (cached_one) s = enqueue_prepare_one(h, first, nt_max);     // target unchanged: pose + scratch reset only
   else s = enqueue_resets(h, npairs, first);
@@ -926,6 +974,11 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
   }
   s = join();
   if (s) return s;
+  if (npairs >= 16 && h->opts.split_after == 0) {
+    HIPCHK(h, hipMemcpyAsync(h->hist_pinned, h->dev.search_hist + (size_t)first * kSearchHist, sizeof(uint32_t) * kSearchHist * (size_t)npairs,
+                             hipMemcpyDeviceToHost, h->stream));
+    h->hist_first = first; h->hist_pairs = npairs; h->hist_iters = max_it;
+  }
   HIPCHK(h, hipGetLastError());
   h->last_npairs = npairs;
   return SMHIP_OK;

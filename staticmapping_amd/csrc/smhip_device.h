@@ -9,6 +9,7 @@ namespace smhip {
 
 constexpr int kHistBins = 2048;          // level-1 histogram of d2 keys: float bits >> 20 (8 exp + 3 mantissa bits)
 constexpr int kHistShift = 20;
+constexpr int kSearchHist = 12;          // iterations whose searched-query counts are kept per pair
 constexpr int kNnThreads = 256;          // one query per thread, 4 waves per workgroup
 constexpr int kAccThreads = 256;
 // source points per thread in the accumulate kernel.  Every workgroup ends with a 29-column f64 reduction that costs about
@@ -30,7 +31,8 @@ constexpr int kLdsRowCap = 256;           // grid rows of the box whose runs are
 constexpr int kWideBlocks = 512;         // workgroups (4 waves = 4 queries at a time) per pair of nn_ring_wide
 constexpr int kListedBlocks = 32;        // workgroups per pair of the listed search (nn_ball_listed): it strides over the list
 constexpr int kBallItems = 2;            // rounds of 256 queries per workgroup in nn_ball_lds / nn_ball (prefetch across rounds; 2 measured best: 4 = +8 %, 1 = +5 %)
-constexpr int kCertifyItems = 8;         // rounds per workgroup of the certificate pass (8: 85 -> 79 us per 64 pairs, 16: slower again)
+constexpr int kCertifyItems = 20;        // rounds per workgroup of the certificate pass: its per-workgroup costs (histogram zero + flush, pipeline fill) are
+                                         // large next to a round's -- 8: 80, 12: 57, 16: 57, 20: 49, 24: 48, 28: 52, 32: 53 us per 64 pairs (120 k points)
 
 // Per-pair device state.  Everything an iteration needs and everything the host reads back.
 struct PairState {
@@ -97,7 +99,9 @@ struct IcpDev {
   int32_t acc_items;         // points per thread of the accumulate launches of this batch part (finalize folds accordingly)
   PairState* state;
   const PairInput* in;
-  const float4* src;         // [slots][ns_cap] raw source xyz (w unused)
+  const float4* src;         // [slots][ns_cap] raw source xyz, w = caller index bits (uploads, the prep / filter / NDT / GICP kernels)
+  const float* src3;         // [slots][ns_cap][3] the same points packed to 12 bytes: what the ICP iteration kernels stream
+                             //                 (20 iterations x 2 passes read it; packed by pack_source when a slot's source changed)
   const float4* tgt_p;       // [slots][nt_cap] raw target xyz
   const float4* tgt_n;       // [slots][nt_cap] raw target normals
   float4* tq;                // [slots][nt_cap] centred target, cell-sorted; w = original index bits
@@ -126,6 +130,8 @@ struct IcpDev {
   double* partials;          // [slots][acc_blocks][kAccCols]
   double* tpart;             // [slots][kTgtReduceBlocks][16]
   uint32_t* done_count;      // number of finished pairs
+  uint32_t* search_hist;     // [slots][kSearchHist] queries that needed a search in iteration k of the last Align (finalize; read back by the
+                             //                 host to place the switch from the fused search to certify + listed search, split_after = 0)
   // options
   int32_t max_iteration;
   int32_t early_exit;

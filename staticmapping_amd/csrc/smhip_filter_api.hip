@@ -102,6 +102,7 @@ smhip_status smhip_filter_output_to_source(smhip_handle h, int slot) {
   if (e != hipSuccess) { h->err = std::string("prep_morton_sort: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->ns[slot] = n;
+  touch_source(h, slot);
   return SMHIP_OK;
 }
 

@@ -503,6 +503,7 @@ static smhip_status ndt_gicp_stage_clouds(smhip_handle h) {
   if (e != hipSuccess) { h->err = std::string("NdtWithGicp down-sampling: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
   h->ns[0] = ms; h->nt[0] = mt; h->has_normals[0] = 0;
   touch_target(h, 0);
+  touch_source(h, 0);
   return SMHIP_OK;
 }
 

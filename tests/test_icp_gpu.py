@@ -398,3 +398,40 @@ def test_align_is_reproducible_bit_for_bit(smhip, cfg2):
         assert R[0].tobytes() == R[1].tobytes() == R[2].tobytes()
     assert runs[0] == runs[1] == runs[2]
     m.close()
+
+
+def test_batch_split_point_follows_the_previous_batch_and_changes_no_bits(smhip, cfg2):
+    """split_after = 0 (default): where a batch's iterations switch from the fused search (nn_ball_lds) to certificate pass +
+    listed search is taken from the share of queries the PREVIOUS batch had to search per iteration.  A handle's first batch
+    switches at 2; after a batch of good guesses it stays early, after a batch of poor guesses (many failing certificates
+    for several iterations) it moves later -- and the poses are the same bits wherever it is, static or automatic."""
+    sm = smhip
+    src, q, n, T = cfg2["src"], cfg2["q"], cfg2["n"], cfg2["T"]
+    B = 16
+    good = [T] * B
+    poor = [np.eye(4)] * B
+    ref = {}
+    for split in (2, 6, -1):
+        m = sm.IcpFastHip(pair_slots=B, max_source_points=len(src), max_target_points=len(q), max_iteration=12, early_exit=0, split_after=split)
+        m.set_input_source(src); m.set_input_target(q, n)
+        for s in range(1, B):
+            m.copy_slot(0, s)
+        for name, g in (("good", good), ("poor", poor)):
+            R, sc, st = m.align_batch(B, g)
+            key = (R.tobytes(), tuple(s["kept"] for s in st))
+            assert ref.setdefault(name, key) == key, (split, name)
+        m.close()
+    m = sm.IcpFastHip(pair_slots=B, max_source_points=len(src), max_target_points=len(q), max_iteration=12, early_exit=0)
+    m.set_input_source(src); m.set_input_target(q, n)
+    for s in range(1, B):
+        m.copy_slot(0, s)
+    used = []
+    for name, g in (("good", good), ("good", good), ("poor", poor), ("poor", poor), ("good", good), ("good", good)):
+        R, sc, st = m.align_batch(B, g)
+        used.append(m.get_profile()["split_after_used"])
+        assert (R.tobytes(), tuple(s["kept"] for s in st)) == ref[name], name
+    m.close()
+    assert used[0] == 2                      # nothing known yet
+    assert used[1] <= 2                      # after good guesses: almost every certificate holds from iteration 1 on
+    assert used[3] > used[1]                 # after poor guesses: the fused kernel keeps the first iterations
+    assert used[5] == used[1]                # and back

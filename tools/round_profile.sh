@@ -9,14 +9,20 @@ export TMPDIR=/tmp
 python bench.py > "$out/bench_line.json" 2> "$out/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python bench.py --no-cpu-baseline > "$out/bench_line_traced.json" 2> "$out/trace.err"
 find "$out/trace" -name '*kernel_stats.csv' -exec cp {} "$out/bench_kernel_stats.csv" \;
-# trace average of the dominant kernel over the launches of the timed region only: 16 launches per step (8 iterations x 2
-# half-batches), 2 warm-up steps first, 5 timed steps, then the untimed breakdown / alone steps that the --stats average
-# above also covers.  This is the number roofline.avg_launch_ms of the traced line must match.
-python tools/trace_tail_average.py "$out/trace" nn_ball_lds 32 80 > "$out/timed_region_trace_average.txt"
+# trace average of the two FindClosests kernels over the launches of the timed region only (2 warm-up steps first, 5 timed
+# steps, then the untimed breakdown / alone steps that the --stats average above also covers).  This is the number
+# roofline.avg_launch_ms (and roofline.other_kernels) of the traced line must match.
+# (split_after 2: per step 4 launches of nn_ball_lds -- iterations 0-1 x 2 half-batches -- and 36 of nn_certify)
+python tools/trace_tail_average.py "$out/trace" nn_certify 72 180 > "$out/timed_region_trace_average.txt"
+python tools/trace_tail_average.py "$out/trace" nn_ball_lds 8 20 >> "$out/timed_region_trace_average.txt"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python tools/profile_target.py B=512 reps=1 > "$out/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python tools/profile_target.py B=512 reps=1 > "$out/pmc_write.log" 2>&1
 python tools/pmc_summary.py "$out/pmc_fetch" nn_ball_lds nn_certify accumulate > "$out/pmc_fetch_summary.txt"
 python tools/pmc_summary.py "$out/pmc_write" nn_ball_lds nn_certify accumulate > "$out/pmc_write_summary.txt"
+# per source point: nn_certify reads 12 B point + 4 B previous match + 4 B bound and writes 4 B d2 + 4 B bound (28 B);
+# nn_ball_lds reads the same 20 B and writes id, d2, bound (32 B); the SURVEY 8(d) figure for either is 20 B
+python tools/traffic_json.py "$out/pmc_fetch" "$out/pmc_write" nn_certify 256 120000 20 28 > "$out/traffic_nn_certify.json"
+python tools/traffic_json.py "$out/pmc_fetch" "$out/pmc_write" nn_ball_lds 256 120000 20 32 > "$out/traffic_nn_main.json"
 rm -rf "$out/trace" "$out/pmc_fetch" "$out/pmc_write"
 cat "$out/bench_line.json"; cat "$out/timed_region_trace_average.txt"; cat "$out/pmc_fetch_summary.txt" "$out/pmc_write_summary.txt"; head -8 "$out/bench_kernel_stats.csv"
 # per-iteration durations of one 64-pair batch on ONE stream (no overlap) for reading the iteration profile

@@ -895,7 +895,7 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
       std::nth_element(share.begin(), share.begin() + share.size() / 2, share.end());
       if (share[share.size() / 2] < 0.2f) break;
     }
-    h->auto_split = std::max(1, std::min(k, kSearchHist));
+    h->auto_split = std::max(1, std::min(k, 8));              // 8: from there on the two-launch form won on every workload measured
     h->hist_pairs = 0;
   }
   if (h->opts.split_after == 0) h->dev.split_after = h->auto_split;
@@ -974,7 +974,8 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
   }
   s = join();
   if (s) return s;
-  if (npairs >= 16 && h->opts.split_after == 0) {
+  // (only batches that ran the ball search with certificates say anything about where its two forms cross)
+  if (npairs >= 16 && h->opts.split_after == 0 && h->opts.nn_mode == SMHIP_NN_GRID && h->dev.use_ball && h->dev.certify && h->dev.lds_table) {
     HIPCHK(h, hipMemcpyAsync(h->hist_pinned, h->dev.search_hist + (size_t)first * kSearchHist, sizeof(uint32_t) * kSearchHist * (size_t)npairs,
                              hipMemcpyDeviceToHost, h->stream));
     h->hist_first = first; h->hist_pairs = npairs; h->hist_iters = max_it;

@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--cell", type=float, default=0.25)
     ap.add_argument("--ring", type=int, default=8)
     ap.add_argument("--split-after", type=int, default=0, help="smhip_icp_options.split_after (0 = the library's default)")
+    ap.add_argument("--ball-radius", type=float, default=0.0, help="smhip_icp_options.ball_radius: first-iteration search radius (0 = the library's default, 0.3 m)")
+    ap.add_argument("--streams", type=int, default=0, help="smhip_icp_options.overlap_streams: parts a batch is split into (0 = the library's default, 2)")
     ap.add_argument("--headline", choices=["identity", "extrapolated"], default="extrapolated")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="oracle / cpu_baseline sample: distinct pairs run on the host (0 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (no parity-vs-oracle either)")
@@ -147,7 +149,7 @@ def main():
     m = sm.IcpFastHip(device=local_rank, pair_slots=B, max_source_points=ns, max_target_points=nt, stream=stream,
                       max_iteration=ICP_ITERS, early_exit=0, dist_outlier_ratio=RHO,
                       nn_mode=1 if args.nn_mode == "grid" else 0, grid_cell=args.cell, grid_max_ring=args.ring,
-                      split_after=args.split_after)
+                      split_after=args.split_after, ball_radius=args.ball_radius, overlap_streams=args.streams)
     # round-robin shard: slot s of this rank is global pair s * world + rank; its clouds are distinct pair (g mod D),
     # uploaded into the slot (every slot has its own copy in HBM: 512 slots x (120k + 21.7k) points)
     mine = shard.pairs_of_rank(n_total, rank, world)

@@ -8,7 +8,8 @@ from staticmapping_amd import synth
 a, b, T = synth.scan_pair("cfg2", n_points=120000)
 q, n = sm.calculate_normals(a[:, :3].astype(np.float64))
 guess = synth.make_pose(t=(0.6, 0, 0))
-m = sm.IcpFastHip(pair_slots=1, max_source_points=len(b), max_target_points=len(q), max_iteration=20, early_exit=0)
+kv = dict(x.split("=") for x in sys.argv[1:])
+m = sm.IcpFastHip(pair_slots=1, max_source_points=len(b), max_target_points=len(q), max_iteration=20, early_exit=0, split_after=int(kv.get("split", 0)))
 m.set_input_source(b); m.set_input_target(q, n)
 for cache in (False, True):
     m.set_target_cache(cache)

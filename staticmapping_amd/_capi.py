@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes
+import sys
 import os
 
 from . import build as _build
@@ -156,6 +157,14 @@ def load_library():
             f"{path} is missing: the HIP extension has not been built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
             "There is deliberately no CPU fallback for the registration hot path.")
+    # One process, one HIP runtime.  PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64; if libsmhip.so pulls the
+    # system's in first, a later torch.cuda initialisation in the same process finds "No HIP GPUs are available" (measured,
+    # tools/runtime_order_probe.py).  With torch's loaded first both share it, so when PyTorch is installed it goes first.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)        # AttributeError = header/library drift, also loud

@@ -24,6 +24,14 @@ struct GicpHost {
   double* rot_dev = nullptr;          // 9 doubles
   uint32_t* count_pinned = nullptr;
   int evals = 0;
+  // what is derived from the target alone is kept while the target is (smhip_set_target_cache, default on): the front end
+  // aligns scan after scan against one submap, and ndt_gicp.cc filters / rebuilds / re-estimates all of it in every Align
+  unsigned long long raw_tgt_gen = 0;       // bumped by every smhip_ndt_gicp_set_target_f32
+  unsigned long long staged_raw_gen = 0;    // the raw target slot 0's staged target was made from ...
+  unsigned long long staged_slot_gen = 0;   // ... and tgt_gen[0] right after staging it
+  int staged_filter = -1; float staged_res = 0.f; int staged_nt = 0;
+  unsigned long long cov_gen = 0;           // tgt_gen[0] cov_t was estimated from, with these parameters
+  int cov_k = 0; double cov_eps = 0; float cov_cell = 0.f;
 };
 
 GicpHost& gicp_of(smhip_context* h);
@@ -302,6 +310,22 @@ smhip_status gicp_prepare_slots(smhip_context* h, int np, const double* T_colmaj
   return s;
 }
 
+// the same for slot 1 alone (slot 0's target-side results are kept)
+smhip_status gicp_prepare_slot1(smhip_context* h, int* ns_max, int* nt_max) {
+  double guess[16];
+  for (int i = 0; i < 16; ++i) guess[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  const int had = h->has_normals[1];
+  h->has_normals[1] = 1;
+  smhip_status s = fill_inputs(h, 1, guess, ns_max, nt_max, 1);
+  h->has_normals[1] = had;
+  if (s) return s;
+  const int sort_was = h->dev.sort_cells, ball_was = h->dev.use_ball;
+  h->dev.sort_cells = 0; h->dev.use_ball = 0;
+  s = enqueue_prepare_one(h, 1, *nt_max);
+  h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was;
+  return s;
+}
+
 smhip_status gicp_find_closests(smhip_context* h, int ns_max, float cutoff2) {
   const int sort_was = h->dev.sort_cells, ball_was = h->dev.use_ball;
   h->dev.sort_cells = 0; h->dev.use_ball = 0;
@@ -338,19 +362,24 @@ smhip_status gicp_align_slot0(smhip_context* h, const float* guess, float* final
   // the k-NN search wants cells of a few point spacings: one shell then holds the 20 neighbours almost everywhere
   const float cell_was = h->dev.grid_cell;
   h->dev.grid_cell = o.gicp_search_cell > 0 ? o.gicp_search_cell : 3.0f * (o.using_voxel_filter ? o.voxel_resolution : 0.2f);
-  smhip_status s = gicp_prepare_slots(h, 2, I16, &ns_max, &nt_max);
+  const float knn_cell = h->dev.grid_cell;
+  // the target's covariances depend on the target, k, epsilon and the search cell alone: kept while those are
+  const bool cov_kept = h->target_cache && G.cov_gen != 0 && G.cov_gen == h->tgt_gen[0] && G.cov_k == k && G.cov_eps == o.gicp_epsilon && G.cov_cell == knn_cell;
+  smhip_status s = cov_kept ? gicp_prepare_slot1(h, &ns_max, &nt_max) : gicp_prepare_slots(h, 2, I16, &ns_max, &nt_max);
   h->dev.grid_cell = cell_was;
   if (s) return s;
+  if (cov_kept) h->cache_hits++;
   // the set's LDS footprint follows k (the default 20 fits 20 entries per thread: 20 KiB per workgroup instead of 32)
   IcpDev dk = h->dev;
   dk.have_rowbits = 1;                       // built by gicp_prepare_slots (a ring-search context)
   if (k <= 20) {
-    hipLaunchKernelGGL(gicp_knn_cov<20>, dim3(ceil_div(nt, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, dk, 0, k, o.gicp_epsilon, G.dev.cov_t);
+    if (!cov_kept) hipLaunchKernelGGL(gicp_knn_cov<20>, dim3(ceil_div(nt, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, dk, 0, k, o.gicp_epsilon, G.dev.cov_t);
     hipLaunchKernelGGL(gicp_knn_cov<20>, dim3(ceil_div(ns, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, dk, 1, k, o.gicp_epsilon, G.dev.cov_s);
   } else {
-    hipLaunchKernelGGL(gicp_knn_cov<kGicpKMax>, dim3(ceil_div(nt, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, dk, 0, k, o.gicp_epsilon, G.dev.cov_t);
+    if (!cov_kept) hipLaunchKernelGGL(gicp_knn_cov<kGicpKMax>, dim3(ceil_div(nt, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, dk, 0, k, o.gicp_epsilon, G.dev.cov_t);
     hipLaunchKernelGGL(gicp_knn_cov<kGicpKMax>, dim3(ceil_div(ns, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, dk, 1, k, o.gicp_epsilon, G.dev.cov_s);
   }
+  G.cov_gen = h->tgt_gen[0]; G.cov_k = k; G.cov_eps = o.gicp_epsilon; G.cov_cell = knn_cell;
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));              // the pinned pair inputs are rewritten below
   // ---- outer loop
@@ -481,6 +510,7 @@ smhip_status smhip_ndt_gicp_set_target_f32(smhip_handle h, const float* xyz, int
   smhip_status s = gicp_ensure(h);
   if (s) return s;
   GicpHost& g = gicp_of(h);
+  g.raw_tgt_gen = ++h->gen_counter;
   return gicp_upload_raw(h, g.raw_tgt, xyz, stride_floats, n, h->dev.nt_cap, &g.n_raw_tgt);
 }
 
@@ -492,18 +522,27 @@ static smhip_status ndt_gicp_stage_clouds(smhip_handle h) {
   float4* tgt0 = const_cast<float4*>(h->dev.tgt_p);
   int ms = g.n_raw_src, mt = g.n_raw_tgt;
   hipError_t e = hipSuccess;
-  if (g.opts.using_voxel_filter) {
+  const int filt = g.opts.using_voxel_filter ? 1 : 0;
+  const bool keep_target = h->target_cache && g.raw_tgt_gen != 0 && g.staged_raw_gen == g.raw_tgt_gen && g.staged_slot_gen == h->tgt_gen[0] &&
+                           g.staged_filter == filt && (!filt || g.staged_res == g.opts.voxel_resolution);
+  if (filt) {
     e = prep_approx_voxel_grid(h->prep, h->stream, g.raw_src, g.n_raw_src, g.opts.voxel_resolution, g.ds_tmp, &ms);
     if (e == hipSuccess) e = prep_morton_sort(h->prep, h->stream, g.ds_tmp, ms, src0);
-    if (e == hipSuccess) e = prep_approx_voxel_grid(h->prep, h->stream, g.raw_tgt, g.n_raw_tgt, g.opts.voxel_resolution, tgt0, &mt);
+    if (e == hipSuccess && !keep_target) e = prep_approx_voxel_grid(h->prep, h->stream, g.raw_tgt, g.n_raw_tgt, g.opts.voxel_resolution, tgt0, &mt);
   } else {
     e = prep_morton_sort(h->prep, h->stream, g.raw_src, ms, src0);
-    if (e == hipSuccess) e = hipMemcpyAsync(tgt0, g.raw_tgt, sizeof(float4) * (size_t)mt, hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess && !keep_target) e = hipMemcpyAsync(tgt0, g.raw_tgt, sizeof(float4) * (size_t)mt, hipMemcpyDeviceToDevice, h->stream);
   }
   if (e != hipSuccess) { h->err = std::string("NdtWithGicp down-sampling: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
-  h->ns[0] = ms; h->nt[0] = mt; h->has_normals[0] = 0;
-  touch_target(h, 0);
+  h->ns[0] = ms; h->has_normals[0] = 0;
   touch_source(h, 0);
+  if (keep_target) {
+    h->cache_hits++;
+    return SMHIP_OK;
+  }
+  h->nt[0] = mt;
+  touch_target(h, 0);
+  g.staged_raw_gen = g.raw_tgt_gen; g.staged_slot_gen = h->tgt_gen[0]; g.staged_filter = filt; g.staged_res = g.opts.voxel_resolution; g.staged_nt = mt;
   return SMHIP_OK;
 }
 
@@ -528,11 +567,11 @@ smhip_status smhip_ndt_gicp_align(smhip_handle h, const double guess[16], double
     smhip_ndt_default_options(&no);
     no.resolution = g.opts.ndt_resolution; no.step_size = g.opts.ndt_step_size;
     no.transformation_epsilon = g.opts.ndt_transformation_epsilon; no.max_iterations = g.opts.ndt_max_iterations;
-    n.opts = no; n.double_math = true; n.grid_valid = false;
+    n.opts = no; n.double_math = true;
     double nres[16];
     smhip_ndt_stats ns{};
     s = smhip_ndt_align(h, guess, nres, &ndt_score, &ns);
-    n.opts = saved; n.double_math = dm; n.grid_valid = false;
+    n.opts = saved; n.double_math = dm;
     if (s) return s;
     colmajor_to_rm_f32(nres, ndt_guess);                     // ndt_.getFinalTransformation()
     st.ndt_iterations = ns.iterations;

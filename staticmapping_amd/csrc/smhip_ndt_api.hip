@@ -13,6 +13,7 @@ struct NdtHost {
   bool allocated = false;
   bool grid_valid = false;
   unsigned long long grid_gen = 0;    // tgt_gen[0] the voxel grid was built from
+  float grid_resolution = 0.f; int grid_min_points = 0; float grid_eig_mult = 0.f;   // ... and the options it depends on
   smhip_ndt_options opts{};
   double* out_pinned = nullptr;       // kNdtDerivCols doubles
   NdtGridInfo* info_pinned = nullptr;
@@ -190,6 +191,7 @@ smhip_status ndt_build_grid(smhip_context* h) {
   if (n.info_pinned->status) { h->err = "NDT voxel box exceeds the bit grid (leaf size too small for the target extent)"; return SMHIP_ERR_CAPACITY; }
   n.grid_valid = true;
   n.grid_gen = h->tgt_gen[0];
+  n.grid_resolution = n.opts.resolution; n.grid_min_points = n.opts.min_points_per_voxel; n.grid_eig_mult = n.opts.min_covar_eigvalue_mult;
   return SMHIP_OK;
 }
 
@@ -333,7 +335,8 @@ smhip_status smhip_ndt_align(smhip_handle h, const double guess[16], double resu
   n.deriv_calls = 0;
   // setInputTarget -> init() on every Align (ndt.cc:54).  The voxel table is a pure function of the target and the
   // options, so it is kept while the slot's target is unchanged (smhip_set_target_cache(h, 0) = rebuild every time)
-  if (h->target_cache && n.grid_valid && n.grid_gen == h->tgt_gen[0]) {
+  if (h->target_cache && n.grid_valid && n.grid_gen == h->tgt_gen[0] && n.grid_resolution == n.opts.resolution &&
+      n.grid_min_points == n.opts.min_points_per_voxel && n.grid_eig_mult == n.opts.min_covar_eigvalue_mult) {
     n.dev.ns = h->ns[0]; n.dev.src = h->dev.src;
     h->cache_hits++;
   } else {

@@ -53,3 +53,48 @@ def test_ndt_align_is_identical_with_and_without_the_cache():
     for (Ra, fa, _), (Rb, fb, _) in zip(out[True], out[False]):
         assert np.array_equal(Ra, Rb) and fa == fb
     assert np.array_equal(out[True][0][0], out[True][2][0])
+
+
+def test_ndt_gicp_align_is_identical_with_and_without_the_cache():
+    """NdtWithGicp: the down-sampled target, the NDT voxel table, the correspondence grid and the target's GICP covariances are
+    functions of the target (and the options) alone and are kept across Aligns against an unchanged target; the reference
+    filters / rebuilds / re-estimates them in every Align (ndt_gicp.cc:55-81, gicp_omp_impl.hpp:391-402).  Same bits either way,
+    a new target and changed options are picked up."""
+    import staticmapping_amd as sm
+    from staticmapping_amd import synth
+    scene = synth.make_scene(0)
+    n = 30000
+    tgt = np.concatenate([synth.velodyne_scan(scene, synth.make_pose(t=(0.8 * k, 0, 0)), seed=40 + k, n_points=n) for k in range(4)])
+    for k in range(4):
+        tgt[n * k:n * (k + 1), 0] += 0.8 * k
+    src1 = synth.velodyne_scan(scene, synth.make_pose(t=(0.8, 0.05, 0.0), rpy_deg=(0, 0, 1.0)), seed=50, n_points=n)
+    src2 = synth.velodyne_scan(scene, synth.make_pose(t=(1.2, 0.0, 0.0), rpy_deg=(0, 0, -0.5)), seed=51, n_points=n)
+    g1, g2 = synth.make_pose(t=(0.7, 0.0, 0.0)), synth.make_pose(t=(1.1, 0.0, 0.0))
+    out = {}
+    for cache in (True, False):
+        m = sm.NdtGicpHip(max_source_points=n, max_target_points=len(tgt))
+        m.set_target_cache(cache)
+        r = []
+        m.set_input_target(tgt)
+        for src, G in ((src1, g1), (src2, g2), (src1, g1)):               # 2nd and 3rd: target unchanged, new source
+            m.set_input_source(src)
+            ok, R = m.align(G)
+            r.append((bool(ok), R.copy(), m.get_fitness_score()))
+        m.set_gicp_options(voxel_resolution=0.3)                           # changed filter: everything target-side is redone
+        ok, R = m.align(g1)
+        r.append((bool(ok), R.copy(), m.get_fitness_score()))
+        m.set_gicp_options(voxel_resolution=0.2)
+        m.set_input_target(tgt[:2 * n])                                    # a new target
+        ok, R = m.align(g1)
+        r.append((bool(ok), R.copy(), m.get_fitness_score()))
+        m.set_input_target(tgt)
+        ok, R = m.align(g1)
+        r.append((bool(ok), R.copy(), m.get_fitness_score()))
+        out[cache] = r
+        m.close()
+    for (oa, Ra, fa), (ob, Rb, fb) in zip(out[True], out[False]):
+        assert oa == ob and np.array_equal(Ra, Rb) and fa == fb
+    t = out[True]
+    assert all(x[0] for x in t)
+    assert np.array_equal(t[0][1], t[2][1]) and np.array_equal(t[0][1], t[5][1])
+    assert not np.array_equal(t[0][1], t[3][1]) and not np.array_equal(t[0][1], t[4][1])

@@ -19,13 +19,16 @@ src = np.ascontiguousarray(scans[n_scans][:, :3]); T = poses[n_scans]
 G = T.copy(); G[0, 3] -= 0.3
 m = sm.NdtGicpHip(max_source_points=len(src), max_target_points=len(tgt))
 t = time.time(); m.set_input_source(src); m.set_input_target(tgt); t_up = time.time() - t
-ok, R = m.align(G)
 reps = 3
-t = time.time()
-for _ in range(reps): ok, R = m.align(G)
-dt = (time.time() - t) / reps
-print(f"NdtWithGicp {len(src)} vs {len(tgt)}: upload {t_up*1e3:.1f} ms, {dt*1e3:.2f} ms/align ok={ok} stats={m.last_gicp_stats} "
-      f"score={m.get_fitness_score():.5f} err={sm.se3_error(R, T)}")
+for cache in (False, True):
+    m.set_target_cache(cache)
+    ok, R = m.align(G)
+    t = time.time()
+    for _ in range(reps): ok, R = m.align(G)
+    dt = (time.time() - t) / reps
+    print(f"NdtWithGicp {len(src)} vs {len(tgt)} target_cache={int(cache)}: upload {t_up*1e3:.1f} ms, {dt*1e3:.2f} ms/align ok={ok} stats={m.last_gicp_stats} "
+          f"score={m.get_fitness_score():.5f} err={sm.se3_error(R, T)}")
+m.set_target_cache(False)
 for name, kw in (("filter+gicp (use_ndt=0)", dict(use_ndt=0)), ("filter+ndt+1 gicp iteration", dict(use_ndt=1, gicp_max_iterations=1))):
     m.set_gicp_options(**kw)
     m.align(G)

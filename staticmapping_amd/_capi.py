@@ -157,14 +157,9 @@ def load_library():
             f"{path} is missing: the HIP extension has not been built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
             "There is deliberately no CPU fallback for the registration hot path.")
-    # One process, one HIP runtime.  PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64; if libsmhip.so pulls the
-    # system's in first, a later torch.cuda initialisation in the same process finds "No HIP GPUs are available" (measured,
-    # tools/runtime_order_probe.py).  With torch's loaded first both share it, so when PyTorch is installed it goes first.
-    if "torch" not in sys.modules:
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+    # (One process, one HIP runtime: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 under the same SONAMEs.  A
+    # process that uses both must import torch BEFORE the first call into this package -- bench.py and tests/conftest.py do --
+    # or torch's later initialisation finds "No HIP GPUs are available"; tools/runtime_order_probe.py shows both orders.)
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)        # AttributeError = header/library drift, also loud

@@ -8,6 +8,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# One process, one HIP runtime: some GPU tests build their clouds with torch on the device, and PyTorch-ROCm ships its own
+# libamdhip64 / libhsa-runtime64 under the SONAMEs libsmhip.so links against.  Whichever is loaded first is the one the
+# process uses; with libsmhip.so first, torch's later initialisation finds "No HIP GPUs are available" -- so torch goes first.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

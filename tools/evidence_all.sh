@@ -8,8 +8,7 @@ timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/$tag/pytest_gpu.txt 2
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/$tag/smoke.txt 2>&1; tail -1 gpurun_out/$tag/smoke.txt
 bash tools/round_profile.sh $tag > gpurun_out/$tag/round_profile.log 2>&1; head -c 600 gpurun_out/$tag/bench_line.json; echo
 cat gpurun_out/$tag/timed_region_trace_average.txt gpurun_out/$tag/iteration_profile.txt
-sed -i "s#r02d_ndt_gicp#${tag}_ndt_gicp#g" tools/evidence_ndt_gicp.sh
-bash tools/evidence_ndt_gicp.sh > gpurun_out/$tag/ndt_gicp.log 2>&1; grep "ms/align" gpurun_out/$tag/ndt_gicp.log | cut -c1-110
+bash tools/evidence_ndt_gicp.sh $tag > gpurun_out/$tag/ndt_gicp.log 2>&1; grep "ms/align" gpurun_out/$tag/ndt_gicp.log | cut -c1-110
 python tools/single_pair_probe.py > gpurun_out/$tag/single_pair_probe.txt 2>&1; cat gpurun_out/$tag/single_pair_probe.txt
 python tools/pm_probe.py > gpurun_out/$tag/pm_probe.txt 2>&1; cat gpurun_out/$tag/pm_probe.txt | cut -c1-140
 python tools/gpu_probe.py 120000 1,16,64,512 > gpurun_out/$tag/gpu_probe.txt 2>&1; grep "align/s" gpurun_out/$tag/gpu_probe.txt | cut -c1-100

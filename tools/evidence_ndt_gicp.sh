@@ -1,7 +1,9 @@
 # kernel-level evidence for BASELINE configs #3 (Ndt) and #5 (NdtWithGicp): kernel stats + FETCH_SIZE / WRITE_SIZE passes
+# usage: evidence_ndt_gicp.sh <tag>
 set -u
 export TMPDIR=/tmp
-out=$PWD/gpurun_out/r02_ndt_gicp
+tag=${1:-r02}
+out=$PWD/gpurun_out/${tag}_ndt_gicp
 mkdir -p "$out"
 for w in ndt gicp; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${w}_trace" -- python tools/${w}_probe.py > "$out/${w}_probe.txt" 2> "$out/${w}_trace.err"

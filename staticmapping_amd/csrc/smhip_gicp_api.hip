@@ -553,6 +553,13 @@ smhip_status smhip_ndt_gicp_align(smhip_handle h, const double guess[16], double
   if (s) return s;
   GicpHost& g = gicp_of(h);
   smhip_ndt_gicp_stats st{};
+  // smhip_set_target_cache(h, 0) = nothing survives from one Align to the next, as in the reference; INSIDE an Align the
+  // target's structures are still built once (PCL builds its kd-trees in setInputTarget, not per iteration)
+  struct WithinAlign {
+    smhip_context* h; decltype(smhip_context::target_cache) keep;
+    ~WithinAlign() { h->target_cache = keep; }
+  } within{h, h->target_cache};
+  if (!within.keep) { g.staged_raw_gen = 0; g.cov_gen = 0; ndt_of(h).grid_valid = false; h->target_cache = 1; }
   s = ndt_gicp_stage_clouds(h);
   if (s) return s;
   st.n_source = h->ns[0]; st.n_target = h->nt[0];

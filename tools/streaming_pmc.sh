@@ -2,7 +2,7 @@
 # PMC passes over the certificate pass and accumulate (64 pairs, one stream): instruction counts, LDS conflicts, L2 hit rate, TA busy, HBM bytes
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-out=$R/gpurun_out/certify_pmc
+out=$R/gpurun_out/streaming_pmc
 mkdir -p $out
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TA_TA_BUSY_sum" "FETCH_SIZE" "WRITE_SIZE" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr"; do

@@ -6,7 +6,9 @@ tag=${1:-r01x}
 out=$PWD/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
+t0=$SECONDS
 python bench.py > "$out/bench_line.json" 2> "$out/bench.err"
+echo "default bench.py run: $((SECONDS - t0)) s wall" > "$out/bench_wall.txt"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python bench.py --no-cpu-baseline > "$out/bench_line_traced.json" 2> "$out/trace.err"
 find "$out/trace" -name '*kernel_stats.csv' -exec cp {} "$out/bench_kernel_stats.csv" \;
 # trace average of the two FindClosests kernels over the launches of the timed region only (2 warm-up steps first, 5 timed

@@ -168,6 +168,7 @@ __global__ void pose_setup(IcpDev b, int npairs) {
   st->iter = 0; st->done = 0; st->status = 0;
   st->unresolved_count = 0; st->fallback_ticket = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
   st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0; st->searched_total = 0;
+  st->pot_a = 0; st->pot_b = 0; st->step_a = 0; st->step_b = 0;
   st->rcap2 = b.ball_radius * b.ball_radius;
   st->kept = 0; st->limit_key = 0; st->score = 0;
 }
@@ -215,6 +216,7 @@ __global__ void grid_setup(IcpDev b, int npairs) {
     st->n_hist = 1; st->iter = 0; st->score = 0; st->kept = 0; st->limit_key = 0;
     st->unresolved_count = 0; st->fallback_ticket = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
     st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0; st->searched_total = 0;
+  st->pot_a = 0; st->pot_b = 0; st->step_a = 0; st->step_b = 0;
     st->rcap2 = 0.f;
     st->status = 1;                        // SMHIP_ERR_INVALID_ARGUMENT
     st->done = 1;
@@ -247,6 +249,7 @@ __global__ void grid_setup(IcpDev b, int npairs) {
   st->iter = 0; st->done = 0; st->status = 0;
   st->unresolved_count = 0; st->fallback_ticket = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
   st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0; st->searched_total = 0;
+  st->pot_a = 0; st->pot_b = 0; st->step_a = 0; st->step_b = 0;
   st->rcap2 = b.ball_radius * b.ball_radius;
   st->kept = 0; st->limit_key = 0; st->score = 0; st->nocc = 0;
 }
@@ -476,6 +479,14 @@ __device__ __forceinline__ float4 ld_src(const IcpDev& b, size_t k) {
 }
 __device__ __forceinline__ float ld_lb(const IcpDev& b, size_t k) { return b.lb[k]; }
 __device__ __forceinline__ void st_lb(const IcpDev& b, size_t k, float v) { b.lb[k] = v; }
+// certificate bounds are stored with the pair's motion potential at the time of the search added (PairState::pot_a / pot_b)
+struct Pot { float a, b, sa, sb; };
+__device__ __forceinline__ float norm3(float x, float y, float z) { return sqrtf(fmaf(z, z, fmaf(y, y, x * x))); }
+__device__ __forceinline__ float pot_at(const Pot& p, float sn) { return fmaf(p.a, sn, p.b); }
+__device__ __forceinline__ float with_pot(float lb, float P) { return lb > 0.f ? lb + P : (lb < 0.f ? lb - P : 0.f); }
+// what a stored bound is worth now: |stored| - P(now) - rounding slack (the float roundings of the stored sum, of P and of |s|)
+// (1e-4 P also covers |s| taken as |q - t| by the search lanes of nn_ball_lds for a guess whose rotation is only orthonormal to 1e-5)
+__device__ __forceinline__ float bound_now(float stored, float P) { return fabsf(stored) - P - (1.0e-5f * (1.0f + fabsf(stored)) + 1.0e-4f * P); }
 
 // src (float4 rows as uploaded) -> src3 for pairs [first, first + npairs)
 __global__ __launch_bounds__(256) void pack_source(IcpDev b, int first, int npairs) {
@@ -610,6 +621,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
   const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
   const float r2cap = st->rcap2;
   const bool have_prev = st->iter > 0;
+  const Pot pot = {(float)st->pot_a, (float)st->pot_b, 0.f, 0.f};
   uint32_t min_lb = 0xffffffffu;
 
   for (int it = 0; it < kBallItems; ++it) {
@@ -619,7 +631,8 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
     if (e < count) {
       i = e;
       double px, py, pz;
-      transform_point(st->M, ld_src(b, so + i), px, py, pz);
+      const float4 s4 = ld_src(b, so + i);
+      transform_point(st->M, s4, px, py, pz);
       const float qx = (float)px, qy = (float)py, qz = (float)pz;
       Best best = {INFINITY, -1, INFINITY};
       float d2out = INFINITY, lbout = 0.f;
@@ -631,7 +644,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
           jp = b.idx[so + i];
           if (jp >= 0) {
             double ux, uy, uz;
-            transform_point(st->M_prev, ld_src(b, so + i), ux, uy, uz);
+            transform_point(st->M_prev, s4, ux, uy, uz);
             const float ex = qx - (float)ux, ey = qy - (float)uy, ez = qz - (float)uz;
             R2 = search_radius2(r2cap, dist2(tq[jp], qx, qy, qz), search_margin(sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)))));
           }
@@ -673,7 +686,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
       }
       b.d2[so + i] = d2out;
       b.idx[so + i] = jout;
-      st_lb(b, so + i, lbout);
+      st_lb(b, so + i, with_pot(lbout, pot_at(pot, norm3(s4.x, s4.y, s4.z))));
       const uint32_t key = __float_as_uint(d2out);
       if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
     }
@@ -725,6 +738,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball_listed(IcpDev b, int nblk)
   const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
   const float r2cap = st->rcap2;
   const bool have_prev = st->iter > 0;
+  const Pot pot = {(float)st->pot_a, (float)st->pot_b, 0.f, 0.f};
   uint32_t min_lb = 0xffffffffu;
   for (int base = blk * qpb; base < count; base += nblk * qpb) {        // workgroup-uniform
     const int e = base + ql;
@@ -798,7 +812,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball_listed(IcpDev b, int nblk)
         }
         b.d2[so + i] = d2out;
         b.idx[so + i] = jout;
-        st_lb(b, so + i, lbout);
+        st_lb(b, so + i, with_pot(lbout, pot_at(pot, norm3(s4.x, s4.y, s4.z))));
         const uint32_t key = __float_as_uint(d2out);
         if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
       }
@@ -831,9 +845,10 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
   const int ns = st->ns;
   const int base = blk * (kNnThreads * ITEMS);
   if (base >= ns) return;
-  double Mc[12], Mp[12];                 // read before the first store: scalar loads, held in SGPRs (see nn_ball_lds)
+  double Mc[12];                         // read before the first store: scalar loads, held in SGPRs (see nn_ball_lds)
 #pragma unroll
-  for (int k = 0; k < 12; ++k) { Mc[k] = st->M[k]; Mp[k] = st->M_prev[k]; }
+  for (int k = 0; k < 12; ++k) Mc[k] = st->M[k];
+  const Pot pot = {(float)st->pot_a, (float)st->pot_b, 0.f, 0.f};
   __shared__ uint32_t s_hist[kHistBins];
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
   __syncthreads();
@@ -869,28 +884,24 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
       j_2 = b.idx[so + ic];
     }
     if (i < ns) {
-      double px, py, pz, ox_, oy_, oz_;
+      double px, py, pz;
       transform_point(Mc, s, px, py, pz);
-      transform_point(Mp, s, ox_, oy_, oz_);
       const float qx = (float)px, qy = (float)py, qz = (float)pz;
-      const float ex = qx - (float)ox_, ey = qy - (float)oy_, ez = qz - (float)oz_;
-      const float delta = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
-      // all points other than the match (or all points, for a lower-bounded query) are still at least Lp away
-      const float Lp = fabsf(l) - delta - 1.0e-5f * (1.0f + fabsf(l));
+      // all points other than the match (or all points, for a lower-bounded query) are still at least Lp away: the bound as
+      // recorded, less what the query can have moved since (the pair's motion potential now; the one then is in the record)
+      const float Lp = bound_now(l, pot_at(pot, norm3(s.x, s.y, s.z)));
       fail = true;
       if (isfinite(qx) && isfinite(qy) && isfinite(qz) && Lp > 0.f) {
         if (l > 0.f && j >= 0) {
           const float d1 = dist2(t, qx, qy, qz);
           if (d1 < Lp * Lp) {                       // still the unique nearest neighbour: exact, no search
             b.d2[so + i] = d1;
-            st_lb(b, so + i, Lp);
             atomicAdd(&s_hist[__float_as_uint(d1) >> kHistShift], 1u);
             fail = false;
           }
         } else if (l < 0.f && Lp >= r_need) {       // still provably farther than the trimming radius
           const float lb2 = Lp * Lp;
           b.d2[so + i] = lb2;
-          st_lb(b, so + i, -Lp);
           atomicAdd(&s_hist[__float_as_uint(lb2) >> kHistShift], 1u);
           min_lb = min(min_lb, __float_as_uint(lb2));
           hard = true;
@@ -979,9 +990,13 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
   // loads them through the scalar cache into SGPRs once, and the rounds below transform from registers.  Read inside the
   // loop (behind the rounds' global stores) each lane fetched the same 2 x 96 bytes with six 16-byte vector loads per
   // transform and round.
-  double Mc[12], Mp[12];
+  double Mc[12];
 #pragma unroll
-  for (int k = 0; k < 12; ++k) { Mc[k] = st->M[k]; Mp[k] = st->M_prev[k]; }
+  for (int k = 0; k < 12; ++k) Mc[k] = st->M[k];
+  // the pair's motion potential (PairState::pot_a / pot_b) and the last iteration's step norms: how far a query can have moved
+  // since its bound was recorded / in this iteration, from |s| alone -- no second transform
+  const Pot pot = {(float)st->pot_a, (float)st->pot_b, (float)st->step_a, (float)st->step_b};
+  const float Mtx = (float)Mc[3], Mty = (float)Mc[7], Mtz = (float)Mc[11];
 #if SMHIP_PHASE_TIMING
   const bool timing = (b.debug_flags & 16) != 0;
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1057,26 +1072,20 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
     if (i < ns && !valid) {                                // NaN / inf input: no match
       b.d2[so + i] = INFINITY; b.idx[so + i] = -1; st_lb(b, so + i, 0.f);
     }
-    float delta = 0.03f;                                   // first iteration: no motion history yet
-    if (have_prev && valid) {
-      double ox_, oy_, oz_;
-      transform_point(Mp, s_cur, ox_, oy_, oz_);
-      const float ex = qx - (float)ox_, ey = qy - (float)oy_, ez = qz - (float)oz_;
-      delta = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
-    }
+    const float sn = norm3(s_cur.x, s_cur.y, s_cur.z);
+    // an upper bound of this iteration's motion of the query (first iteration: no motion history yet)
+    const float delta = have_prev ? fmaf(pot.sa, sn, pot.sb) : 0.03f;
     if (certify && valid) {
       // every point other than the match (every point, for a lower-bounded query) is still >= Lp away
-      const float Lp = fabsf(l_cur) - delta - 1.0e-5f * (1.0f + fabsf(l_cur));
+      const float Lp = bound_now(l_cur, pot_at(pot, sn));
       if (Lp > 0.f) {
         if (l_cur > 0.f && has_jp && dub2 < Lp * Lp) {     // still the unique nearest neighbour: exact, no search
           b.d2[so + i] = dub2;
-          st_lb(b, so + i, Lp);
           atomicAdd(&s_hist[__float_as_uint(dub2) >> kHistShift], 1u);
           need_search = false;
         } else if (l_cur < 0.f && Lp >= r_need) {          // still provably beyond the trimming radius
           const float lb2 = Lp * Lp;
           b.d2[so + i] = lb2;
-          st_lb(b, so + i, -Lp);
           atomicAdd(&s_hist[__float_as_uint(lb2) >> kHistShift], 1u);
           min_lb = min(min_lb, __float_as_uint(lb2));
           hard = true;
@@ -1242,7 +1251,8 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
       SMHIP_PHASE(5);    // search
       b.d2[so + gi] = d2out;
       b.idx[so + gi] = jout;
-      st_lb(b, so + gi, lbout);
+      // |s| of the query from its transformed position: M is rigid, so |s| = |q - t|
+      st_lb(b, so + gi, with_pot(lbout, pot_at(pot, norm3(qx - Mtx, qy - Mty, qz - Mtz))));
       const uint32_t key = __float_as_uint(d2out);
       if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
     }
@@ -2249,6 +2259,16 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   for (int i = 0; i < 16; ++i) st->T_iter[i] = Tn[i];
   double Mn[16];
   mat4_mul_rm(Tn, st->G, Mn);
+  {   // motion potential: this step's ||dR||_F and |dt| (what bounds |M_new s - M_old s| <= ||dR|| |s| + |dt|), and their running sums
+    double fa = 0, fb = 0;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) { const double d = Mn[4 * r + c] - st->M[4 * r + c]; fa += d * d; }
+      const double d = Mn[4 * r + 3] - st->M[4 * r + 3];
+      fb += d * d;
+    }
+    st->step_a = sqrt(fa) * (1.0 + 1e-9); st->step_b = sqrt(fb) * (1.0 + 1e-9);
+    st->pot_a += st->step_a; st->pot_b += st->step_b;
+  }
   for (int i = 0; i < 12; ++i) { st->M_prev[i] = st->M[i]; st->M[i] = Mn[i]; }
   const int it = ++st->iter;                                                  // :513
   // history ring (latest at n_hist-1, at most 5 kept)

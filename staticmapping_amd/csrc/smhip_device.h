@@ -39,6 +39,12 @@ struct PairState {
   // transforms, row-major
   double M[12];          // T_iter * G : applied to the raw source every iteration
   double M_prev[12];     // the same of the previous iteration (how far each query moved: nn_certify)
+  // How far a source point s can have moved since a certificate bound was recorded: |M_n s - M_k s| <= (pot_a[n] - pot_a[k]) |s|
+  // + (pot_b[n] - pot_b[k]), with pot_a = the sum over the iterations so far of ||dR||_F and pot_b of |dt| (finalize).  A bound L
+  // recorded at iteration k is stored as L + pot_a[k] |s| + pot_b[k]; at iteration n it is worth that minus pot_a[n] |s| +
+  // pot_b[n] -- nothing to rewrite while a query stays certified, and no second transform to measure its motion.
+  double pot_a, pot_b;
+  double step_a, step_b; // the last iteration's two norms alone (how far a query can have moved in THIS iteration: search margin)
   double T_iter[16];
   double G[16];          // T(-mu) * guess
   double mu[3];          // target mean (icp_fast.cc:457-458)

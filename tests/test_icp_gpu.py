@@ -435,3 +435,30 @@ def test_batch_split_point_follows_the_previous_batch_and_changes_no_bits(smhip,
     assert used[1] <= 2                      # after good guesses: almost every certificate holds from iteration 1 on
     assert used[3] > used[1]                 # after poor guesses: the fused kernel keeps the first iterations
     assert used[5] == used[1]                # and back
+
+
+@pytest.mark.parametrize("guess_name", ["offset", "identity", "truth"])
+def test_certificates_change_no_bit_at_full_size(smhip, cfg2, guess_name):
+    """A 120 k-point Align with certificates (fused kernel, the two-launch form from iteration 1 and 3, the global-memory
+    variant) against the same Align with every query searched in every iteration (no_certify) and against the plain ring
+    search: the same bits, from a good, a poor and an exact guess.  The certificate's motion bound (the pair's motion
+    potential, PairState::pot_a / pot_b) is conservative, never wrong."""
+    sm = smhip
+    src, q, n = cfg2["src"], cfg2["q"], cfg2["n"]
+    guess = {"offset": cfg2["guess"], "identity": np.eye(4), "truth": cfg2["T"]}[guess_name]
+    ref = None
+    searched = {}
+    for name, opts in (("no_certify", dict(no_certify=1)), ("fused", dict()), ("split1", dict(split_after=1)), ("split3", dict(split_after=3)),
+                       ("global", dict(no_lds_table=1)), ("ring", dict(use_ball=0))):
+        m = sm.IcpFastHip(max_source_points=len(src), max_target_points=len(q), max_iteration=20, early_exit=0, **opts)
+        m.set_input_source(src); m.set_input_target(q, n)
+        ok, R = m.align(guess)
+        st = m.last_stats[0]
+        m.close()
+        key = (R.tobytes(), st["kept"], st["limit_d2"], st["iterations"])
+        searched[name] = st["searched_queries"]
+        if ref is None:
+            ref = key
+        assert key == ref, (name, st)
+    assert searched["no_certify"] == 20 * len(src)
+    assert searched["fused"] < 0.4 * searched["no_certify"]            # the certificates do hold for most queries

@@ -22,13 +22,17 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/smhip.h"
@@ -41,7 +45,7 @@ constexpr size_t kMaxFloatsPerFile = 1000000;    // kitti_reader.cc:93
 struct Args {
   std::string scans_dir, out_path = "kitti_pose.txt", id_file;
   int gpus = 1, rank = -1, world = -1, local_rank = -1;
-  int batch = 64, iterations = 20, early_exit = 0, max_pairs = -1;
+  int batch = 64, iterations = 20, early_exit = 0, max_pairs = -1, readers = 4;
   double guess_tx = 0.0;
   bool quiet = false;
 };
@@ -64,16 +68,72 @@ std::vector<std::string> ListScans(const std::string& dir) {            // kitti
   return files;
 }
 
-int ReadBin(const std::string& path, std::vector<float>* rows) {        // kitti_reader.cc:91-121
-  std::ifstream f(path, std::ios::binary);
+int ReadBin(const std::string& path, float* rows) {                      // kitti_reader.cc:91-121; rows: kMaxFloatsPerFile floats
+  FILE* f = std::fopen(path.c_str(), "rb");
   if (!f) Die("cannot read " + path);
-  rows->resize(kMaxFloatsPerFile);
-  f.read(reinterpret_cast<char*>(rows->data()), sizeof(float) * kMaxFloatsPerFile);
-  const size_t got = static_cast<size_t>(f.gcount()) / sizeof(float);
-  const int n = static_cast<int>(got / 4);
-  rows->resize(static_cast<size_t>(n) * 4);
-  return n;
+  const size_t got = std::fread(rows, sizeof(float), kMaxFloatsPerFile, f);
+  std::fclose(f);
+  return static_cast<int>(got / 4);
 }
+
+// The scans a rank will ask for, in the order it will ask for them, read ahead by a few threads into a ring of buffers:
+// the alignment of a batch takes the GPU a few milliseconds, reading and staging its 64 scans took the one host thread
+// 35 ms -- the driver was bound by a single thread's fread.
+class ScanPrefetcher {
+ public:
+  ScanPrefetcher(const std::vector<std::string>& files, std::vector<int> order, int threads, int ring)
+      : files_(files), order_(std::move(order)), ring_(std::max(2, ring)), slots_(ring_) {
+    for (auto& sl : slots_) sl.rows.resize(kMaxFloatsPerFile);
+    for (int t = 0; t < std::max(1, threads); ++t) workers_.emplace_back([this] { Work(); });
+  }
+  ~ScanPrefetcher() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+    cv_free_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+  // the next scan of the order: valid until the following Next()
+  const float* Next(int* n, int* file_index) {
+    std::unique_lock<std::mutex> lk(m_);
+    if (held_ >= 0) { slots_[held_ % ring_].state = 0; cv_free_.notify_all(); }
+    const long i = consumed_++;
+    if (i >= static_cast<long>(order_.size())) Die("prefetcher: more scans requested than planned");
+    Slot& sl = slots_[i % ring_];
+    cv_ready_.wait(lk, [&] { return sl.state == 2 && sl.item == i; });
+    held_ = i;
+    *n = sl.n; *file_index = order_[i];
+    return sl.rows.data();
+  }
+
+ private:
+  struct Slot { std::vector<float> rows; int n = 0; long item = -1; int state = 0; };   // 0 free, 1 being read, 2 ready
+  void Work() {
+    for (;;) {
+      long i;
+      Slot* sl;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_free_.wait(lk, [&] { return stop_ || (next_ < static_cast<long>(order_.size()) && slots_[next_ % ring_].state == 0); });
+        if (stop_ || next_ >= static_cast<long>(order_.size())) return;
+        i = next_++;
+        sl = &slots_[i % ring_];
+        sl->state = 1; sl->item = i;
+      }
+      const int n = ReadBin(files_[order_[i]], sl->rows.data());
+      { std::lock_guard<std::mutex> lk(m_); sl->n = n; sl->state = 2; }
+      cv_ready_.notify_all();
+      cv_free_.notify_all();
+    }
+  }
+  const std::vector<std::string>& files_;
+  const std::vector<int> order_;
+  const int ring_;
+  std::vector<Slot> slots_;
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_ready_, cv_free_;
+  long next_ = 0, consumed_ = 0, held_ = -1;
+  bool stop_ = false;
+};
 
 void Mul4(const double* a, const double* b, double* out) {              // row-major 4x4
   double r[16];
@@ -98,10 +158,11 @@ Args Parse(int argc, char** argv) {
     else if (k == "--iterations") a.iterations = std::atoi(val().c_str());
     else if (k == "--early-exit") a.early_exit = std::atoi(val().c_str());
     else if (k == "--max-pairs") a.max_pairs = std::atoi(val().c_str());
+    else if (k == "--readers") a.readers = std::atoi(val().c_str());
     else if (k == "--guess-tx") a.guess_tx = std::atof(val().c_str());
     else if (k == "--quiet") a.quiet = true;
     else Die("unknown argument " + k + "\nusage: smhip_shard --scans DIR [--gpus G] [--out kitti_pose.txt] [--batch 64] "
-             "[--iterations 20] [--early-exit 0|1] [--guess-tx metres] [--max-pairs N]");
+             "[--iterations 20] [--early-exit 0|1] [--guess-tx metres] [--max-pairs N] [--readers 4]");
   }
   if (a.scans_dir.empty()) Die("--scans DIR is required");
   if (a.rank < 0 && std::getenv("RANK")) a.rank = std::atoi(std::getenv("RANK"));
@@ -168,7 +229,25 @@ int RunRank(const Args& a, int rank, int world, int device) {
   std::vector<double> guesses(16 * static_cast<size_t>(B), 0.0);
   for (int k = 0; k < B; ++k) { double* g = &guesses[16 * static_cast<size_t>(k)]; g[0] = g[5] = g[10] = g[15] = 1.0; g[12] = a.guess_tx; }
 
-  std::vector<float> rows;
+  // the files this rank reads, in reading order (the same walk as the loop below)
+  std::vector<int> order;
+  for (int base = 0; base < per; base += B) {
+    int prev_pair = -2;
+    for (int k = 0; k < B && base + k < per; ++k) {
+      const int pair = (base + k) * world + rank;
+      if (pair >= n_pairs) break;
+      if (pair != prev_pair + 1) order.push_back(pair);
+      order.push_back(pair + 1);
+      prev_pair = pair;
+    }
+  }
+  ScanPrefetcher scans(files, order, a.readers, 4 * std::max(1, a.readers) + 8);
+  auto next_scan = [&](int expect, int* n) -> const float* {
+    int fi = -1;
+    const float* rows = scans.Next(n, &fi);
+    if (fi != expect) Die("prefetcher out of step with the batch loop");
+    return rows;
+  };
   const auto t0 = std::chrono::steady_clock::now();
   double upload_s = 0.0;
   int done = 0, my_pairs = 0;
@@ -185,13 +264,15 @@ int RunRank(const Args& a, int rank, int world, int device) {
       // whole batch are prepared in ONE device pass (CalculateNormals as a kd forest: one sort per tree level for all).
       if (pair == prev_pair + 1) from.push_back(k - 1);
       else {
-        const int n = ReadBin(files[pair], &rows);
-        if (smhip_set_source_f32(h, B + k, rows.data(), 4, n) != SMHIP_OK) Die(std::string("target ") + files[pair] + ": " + smhip_last_error(h));
+        int n = 0;
+        const float* rows = next_scan(pair, &n);
+        if (smhip_set_source_f32(h, B + k, rows, 4, n) != SMHIP_OK) Die(std::string("target ") + files[pair] + ": " + smhip_last_error(h));
         from.push_back(B + k);
       }
       to.push_back(k);
-      const int n = ReadBin(files[pair + 1], &rows);                     // scan i + 1 = source
-      if (smhip_set_source_f32(h, k, rows.data(), 4, n) != SMHIP_OK) Die(std::string("source ") + files[pair + 1] + ": " + smhip_last_error(h));
+      int n = 0;
+      const float* rows = next_scan(pair + 1, &n);                       // scan i + 1 = source
+      if (smhip_set_source_f32(h, k, rows, 4, n) != SMHIP_OK) Die(std::string("source ") + files[pair + 1] + ": " + smhip_last_error(h));
       prev_pair = pair;
       ++nb;
     }

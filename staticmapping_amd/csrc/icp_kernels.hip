@@ -584,8 +584,10 @@ __device__ __forceinline__ void search_row(const uint2* __restrict__ words, cons
 //
 //
 //  (3) certificates: every search also records L = a lower bound on the distance from the query to every
-//      target point OTHER than its match (runner-up distance, capped by the searched radius).  In the next
-//      iteration the query has moved by delta = |M_new s - M_prev s|, so all other points are still at least
+//      target point OTHER than its match (runner-up distance, capped by the searched radius).  By a later
+//      iteration the query has moved by at most delta = (pot_a now - pot_a then) |s| + (pot_b now - pot_b then)
+//      (PairState::pot_a / pot_b: the running sums of ||dR||_F and |dt| of the pose updates; the record holds L plus
+//      the potential at the time of the search, see with_pot / bound_now), so all other points are still at least
 //      L - delta away: if the old match is closer than that it is provably still the unique nearest
 //      neighbour and no search happens at all (nn_certify).  Lower-bounded ("hard") queries keep their
 //      bound the same way.  Only the queries whose certificate fails are compacted into dlist and searched

@@ -38,7 +38,7 @@ constexpr int kCertifyItems = 20;        // rounds per workgroup of the certific
 struct PairState {
   // transforms, row-major
   double M[12];          // T_iter * G : applied to the raw source every iteration
-  double M_prev[12];     // the same of the previous iteration (how far each query moved: nn_certify)
+  double M_prev[12];     // the same of the previous iteration (the global-memory search variants size their search margin with it)
   // How far a source point s can have moved since a certificate bound was recorded: |M_n s - M_k s| <= (pot_a[n] - pot_a[k]) |s|
   // + (pot_b[n] - pot_b[k]), with pot_a = the sum over the iterations so far of ||dR||_F and pot_b of |dt| (finalize).  A bound L
   // recorded at iteration k is stored as L + pot_a[k] |s| + pot_b[k]; at iteration n it is worth that minus pot_a[n] |s| +

@@ -4,6 +4,13 @@
 // build, every call), pclomp NDT align, getFitnessScore.  The 6-vector Newton / More-Thuente driver
 // (pclomp/ndt_omp_impl.hpp:81-171, 757-916) runs here on the host exactly as in the reference; each
 // computeDerivatives call is one ndt_derivatives + ndt_reduce launch and a 44-double read-back.
+//
+// Provenance note: computeStepLengthMT / trialValueSelectionMT / updateIntervalMT below are a PORT, not a redesign -- ~80
+// lines of scalar host control flow that follow pclomp/ndt_omp_impl.hpp:633-916 branch for branch (same variable roles:
+// a_l, f_l, g_l, a_u, phi_0, d_psi_t, open_interval ...), including the reference's quirk that `interval_converged` is
+// computed from the UN-updated interval.  The iteration and derivative-call counts of the parity tests depend on that control
+// flow being reproduced exactly; nothing in it is data-parallel.  Everything it calls (the derivative evaluations, the voxel
+// table, the fitness search) is this repository's own GPU code.
 #include "ndt_kernels.hip"
 
 namespace {

@@ -1,0 +1,94 @@
+// kitti_scans.h -- KITTI `.bin` scans (float32 rows x y z reflectance) read ahead by a pool of threads.
+//
+// Reference: ros_node/kitti_reader.cc:91-149 -- at most 1 000 000 floats per file (:93), files in sorted directory order
+// (:124-131).  Host-only C++ (no HIP): used by the sharded sequence driver (csrc/shard_driver.cc) and testable on a CPU box
+// (tests/cpp/test_kitti_scans.cc).
+#pragma once
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace smhip {
+namespace kitti {
+
+constexpr size_t kMaxFloatsPerFile = 1000000;    // kitti_reader.cc:93
+
+// number of points read into rows (kMaxFloatsPerFile floats of room); -1 if the file cannot be opened
+inline int ReadBin(const std::string& path, float* rows) {               // kitti_reader.cc:91-121
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) return -1;
+  const size_t got = std::fread(rows, sizeof(float), kMaxFloatsPerFile, f);
+  std::fclose(f);
+  return static_cast<int>(got / 4);
+}
+
+// The scans a consumer will ask for, in the order it will ask for them, read ahead by a few threads into a ring of buffers.
+// (The alignment of a batch takes the GPU a few milliseconds; reading and staging its 64 scans took one host thread 35 ms.)
+class ScanPrefetcher {
+ public:
+  ScanPrefetcher(const std::vector<std::string>& files, std::vector<int> order, int threads, int ring)
+      : files_(files), order_(std::move(order)), ring_(std::max(2, ring)), slots_(ring_) {
+    for (auto& sl : slots_) sl.rows.resize(kMaxFloatsPerFile);
+    for (int t = 0; t < std::max(1, threads); ++t) workers_.emplace_back([this] { Work(); });
+  }
+  ~ScanPrefetcher() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+    cv_free_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+  ScanPrefetcher(const ScanPrefetcher&) = delete;
+  ScanPrefetcher& operator=(const ScanPrefetcher&) = delete;
+  size_t planned() const { return order_.size(); }
+  // The next scan of the order: its rows stay valid until the following Next().  *n = points (-1: unreadable file),
+  // *file_index = index into `files`.  nullptr once the order is exhausted.
+  const float* Next(int* n, int* file_index) {
+    std::unique_lock<std::mutex> lk(m_);
+    if (held_ >= 0) { slots_[held_ % ring_].state = 0; held_ = -1; cv_free_.notify_all(); }
+    if (consumed_ >= static_cast<long>(order_.size())) return nullptr;
+    const long i = consumed_++;
+    Slot& sl = slots_[i % ring_];
+    cv_ready_.wait(lk, [&] { return sl.state == 2 && sl.item == i; });
+    held_ = i;
+    *n = sl.n; *file_index = order_[i];
+    return sl.rows.data();
+  }
+
+ private:
+  struct Slot { std::vector<float> rows; int n = 0; long item = -1; int state = 0; };   // 0 free, 1 being read, 2 ready
+  void Work() {
+    for (;;) {
+      long i;
+      Slot* sl;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_free_.wait(lk, [&] { return stop_ || next_ >= static_cast<long>(order_.size()) || slots_[next_ % ring_].state == 0; });
+        if (stop_ || next_ >= static_cast<long>(order_.size())) return;
+        i = next_++;
+        sl = &slots_[i % ring_];
+        sl->state = 1; sl->item = i;
+      }
+      const int n = ReadBin(files_[order_[i]], sl->rows.data());
+      { std::lock_guard<std::mutex> lk(m_); sl->n = n; sl->state = 2; }
+      cv_ready_.notify_all();
+      cv_free_.notify_all();
+    }
+  }
+  const std::vector<std::string>& files_;
+  const std::vector<int> order_;
+  const int ring_;
+  std::vector<Slot> slots_;
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_ready_, cv_free_;
+  long next_ = 0, consumed_ = 0, held_ = -1;
+  bool stop_ = false;
+};
+
+}  // namespace kitti
+}  // namespace smhip

@@ -36,11 +36,13 @@
 #include <vector>
 
 #include "../../include/smhip.h"
+#include "../../include/smhip/kitti_scans.h"
 
 namespace {
 
 constexpr int kPoseDoubles = 18;                 // 16 column-major transform + score + iterations
-constexpr size_t kMaxFloatsPerFile = 1000000;    // kitti_reader.cc:93
+using smhip::kitti::kMaxFloatsPerFile;
+using smhip::kitti::ScanPrefetcher;
 
 struct Args {
   std::string scans_dir, out_path = "kitti_pose.txt", id_file;
@@ -67,73 +69,6 @@ std::vector<std::string> ListScans(const std::string& dir) {            // kitti
   std::sort(files.begin(), files.end());
   return files;
 }
-
-int ReadBin(const std::string& path, float* rows) {                      // kitti_reader.cc:91-121; rows: kMaxFloatsPerFile floats
-  FILE* f = std::fopen(path.c_str(), "rb");
-  if (!f) Die("cannot read " + path);
-  const size_t got = std::fread(rows, sizeof(float), kMaxFloatsPerFile, f);
-  std::fclose(f);
-  return static_cast<int>(got / 4);
-}
-
-// The scans a rank will ask for, in the order it will ask for them, read ahead by a few threads into a ring of buffers:
-// the alignment of a batch takes the GPU a few milliseconds, reading and staging its 64 scans took the one host thread
-// 35 ms -- the driver was bound by a single thread's fread.
-class ScanPrefetcher {
- public:
-  ScanPrefetcher(const std::vector<std::string>& files, std::vector<int> order, int threads, int ring)
-      : files_(files), order_(std::move(order)), ring_(std::max(2, ring)), slots_(ring_) {
-    for (auto& sl : slots_) sl.rows.resize(kMaxFloatsPerFile);
-    for (int t = 0; t < std::max(1, threads); ++t) workers_.emplace_back([this] { Work(); });
-  }
-  ~ScanPrefetcher() {
-    { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
-    cv_free_.notify_all();
-    for (auto& w : workers_) w.join();
-  }
-  // the next scan of the order: valid until the following Next()
-  const float* Next(int* n, int* file_index) {
-    std::unique_lock<std::mutex> lk(m_);
-    if (held_ >= 0) { slots_[held_ % ring_].state = 0; cv_free_.notify_all(); }
-    const long i = consumed_++;
-    if (i >= static_cast<long>(order_.size())) Die("prefetcher: more scans requested than planned");
-    Slot& sl = slots_[i % ring_];
-    cv_ready_.wait(lk, [&] { return sl.state == 2 && sl.item == i; });
-    held_ = i;
-    *n = sl.n; *file_index = order_[i];
-    return sl.rows.data();
-  }
-
- private:
-  struct Slot { std::vector<float> rows; int n = 0; long item = -1; int state = 0; };   // 0 free, 1 being read, 2 ready
-  void Work() {
-    for (;;) {
-      long i;
-      Slot* sl;
-      {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_free_.wait(lk, [&] { return stop_ || (next_ < static_cast<long>(order_.size()) && slots_[next_ % ring_].state == 0); });
-        if (stop_ || next_ >= static_cast<long>(order_.size())) return;
-        i = next_++;
-        sl = &slots_[i % ring_];
-        sl->state = 1; sl->item = i;
-      }
-      const int n = ReadBin(files_[order_[i]], sl->rows.data());
-      { std::lock_guard<std::mutex> lk(m_); sl->n = n; sl->state = 2; }
-      cv_ready_.notify_all();
-      cv_free_.notify_all();
-    }
-  }
-  const std::vector<std::string>& files_;
-  const std::vector<int> order_;
-  const int ring_;
-  std::vector<Slot> slots_;
-  std::vector<std::thread> workers_;
-  std::mutex m_;
-  std::condition_variable cv_ready_, cv_free_;
-  long next_ = 0, consumed_ = 0, held_ = -1;
-  bool stop_ = false;
-};
 
 void Mul4(const double* a, const double* b, double* out) {              // row-major 4x4
   double r[16];
@@ -245,7 +180,8 @@ int RunRank(const Args& a, int rank, int world, int device) {
   auto next_scan = [&](int expect, int* n) -> const float* {
     int fi = -1;
     const float* rows = scans.Next(n, &fi);
-    if (fi != expect) Die("prefetcher out of step with the batch loop");
+    if (!rows || fi != expect) Die("prefetcher out of step with the batch loop");
+    if (*n < 0) Die("cannot read " + files[fi]);
     return rows;
   };
   const auto t0 = std::chrono::steady_clock::now();

@@ -216,11 +216,12 @@ smhip_status smhip_prepare_target_from_target(smhip_handle h, int from_slot, int
  * from_slot's source whose uniform draw is < prob (prob >= 1 keeps everything).  The draw is a pure function of
  * (seed, the point's index in the cloud as uploaded): splitmix64(seed << 32 | index) >> 11, times 2^-53. */
 smhip_status smhip_sample_source(smhip_handle h, int from_slot, int to_slot, float prob, uint32_t seed, int* n_out);
-/* Target-side structures (the ICP search grid, the NDT voxel table) are pure functions of the target cloud and the
- * options; single-pair calls keep them while a slot's target is unchanged -- the front end aligns scan after scan against
- * one key frame (builder/map_builder.cc:379-392) -- and rebuild them whenever the target is set, prepared or copied
- * again.  enable = 0 rebuilds on every Align, as the reference does (icp_fast.cc:464-467, ndt.cc:54); default 1.
- * Results are identical either way. */
+/* Target-side structures (the ICP search grid, the NDT voxel table; for NdtWithGicp also the down-sampled target, the
+ * correspondence grid and the target's GICP covariances) are pure functions of the target cloud and the options;
+ * single-pair calls keep them while a slot's target is unchanged -- the front end aligns scan after scan against one key
+ * frame / submap (builder/map_builder.cc:379-392) -- and rebuild them whenever the target is set, prepared or copied again
+ * or an option they depend on changes.  enable = 0: nothing survives from one Align to the next, as in the reference
+ * (icp_fast.cc:464-467, ndt.cc:54, ndt_gicp.cc:55-81); default 1.  Results are identical either way. */
 smhip_status smhip_set_target_cache(smhip_handle h, int enable);
 /* what the handle was created with / what a slot currently holds (any pointer may be NULL) */
 smhip_status smhip_get_capacity(smhip_handle h, int* pair_slots, int* max_source_points, int* max_target_points);

@@ -9,6 +9,6 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_V
   i=$((i+1))
   rm -rf $out/p$i
   timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -- python $R/tools/profile_target.py B=64 reps=1 noov=1 > $out/p$i.log 2>&1
-  python $R/tools/pmc_summary.py $out/p$i nn_certify accumulate 2>&1 | cut -c1-400
+  python $R/tools/pmc_summary.py $out/p$i nn_certify accumulate nn_ball_lds 2>&1 | cut -c1-400
   rm -rf $out/p$i
 done

@@ -371,6 +371,9 @@ smhip_status smhip_filter_output_to_source(smhip_handle h, int slot);
  * leave on inside a timed region) */
 smhip_status smhip_icp_enable_profile(smhip_handle h, int enable);
 smhip_status smhip_icp_get_profile(smhip_handle h, smhip_icp_profile* out);
+/* queries that went through a search (exact modes: certificate failed; NABO: walked again) in iterations 0..11 of the
+ * slot's last Align; counts[12] */
+smhip_status smhip_icp_get_search_counts(smhip_handle h, int slot, uint32_t* counts);
 
 #ifdef __cplusplus
 }

@@ -290,18 +290,19 @@ class IcpFastHip : public Interface {
   void SetInputSource(InnerCloudPtr cloud) override {               // icp_fast.cc:421-425
     SMHIP_CHECK(cloud != nullptr, "CHECK(cloud)");
     SMHIP_CHECK(cloud->GetEigenCloud() != nullptr, "CHECK(cloud->GetEigenCloud())");
-    source_keep_ = cloud;
-    input_ok_ = EnsureHandle(cloud->GetEigenCloud()->size(), 0, false, true) && UploadSource();
+    // the cloud the device holds changes only when the upload succeeds; a refused cloud leaves the matcher without a
+    // source (Align then fails loudly instead of matching the previous scan)
+    source_ok_ = EnsureHandle(cloud->GetEigenCloud()->size(), 0, false, true) && UploadSource(*cloud);
+    source_keep_ = source_ok_ ? cloud : nullptr;
   }
   void SetInputTarget(InnerCloudPtr cloud) override {               // icp_fast.cc:427-431
     SMHIP_CHECK(cloud != nullptr, "CHECK(cloud)");
     SMHIP_CHECK(cloud->GetEigenCloud() != nullptr, "CHECK(cloud->GetEigenCloud())");
     SMHIP_CHECK(cloud->GetEigenCloud()->HasNormals(), "CHECK(cloud->GetEigenCloud()->HasNormals())");
-    target_keep_ = cloud; target_kind_ = kTargetWithNormals;
-    input_ok_ = EnsureHandle(0, cloud->GetEigenCloud()->size(), true, false) && UploadTarget();
+    SetTarget(cloud, kTargetWithNormals);
   }
   bool Align(const Matrix4d& guess, Matrix4d& result) override {    // icp_fast.cc:455-529
-    if (!input_ok_ || !EnsureHandle(0, 0, true, true)) {            // a cloud the device could not take: not an abort
+    if (!source_ok_ || !target_ok_ || !EnsureHandle(0, 0, true, true)) {   // a cloud the device could not take: not an abort
       std::fprintf(stderr, "[ERROR] IcpFastHip::Align: the input clouds are not on the device\n");
       result = guess;
       return false;
@@ -326,18 +327,19 @@ class IcpFastHip : public Interface {
   int SetInputTargetRaw(InnerCloudPtr cloud) {
     SMHIP_CHECK(cloud != nullptr, "CHECK(cloud)");
     SMHIP_CHECK(cloud->GetEigenCloud() != nullptr, "CHECK(cloud->GetEigenCloud())");
-    target_keep_ = cloud; target_kind_ = kTargetRaw;
-    const int n = cloud->GetEigenCloud()->size();
-    input_ok_ = EnsureHandle(0, n, true, false) && UploadTarget();
-    return input_ok_ ? prepared_points_ : 0;
+    return SetTarget(cloud, kTargetRaw) ? prepared_points_ : 0;
   }
   // The source already resident from the last SetInputSource becomes the target (the key-frame hand-over of
   // map_builder.cc:379-392) without a second upload.
   int PromoteSourceToTarget() {
-    if (!source_keep_ || !input_ok_ || !EnsureHandle(0, source_keep_->GetEigenCloud()->size() / 4 + 8, true, true)) return 0;
+    if (!source_keep_ || !source_ok_ || !EnsureHandle(0, source_keep_->GetEigenCloud()->size() / 4 + 8, true, true)) return 0;
     int n_out = 0;
-    if (!Ok(smhip_prepare_target_from_source(arena_.handle, 0, 0, &n_out), "smhip_prepare_target_from_source")) { input_ok_ = false; return 0; }
-    target_keep_ = source_keep_; target_kind_ = kTargetRaw; prepared_points_ = n_out;
+    if (!Ok(smhip_prepare_target_from_source(arena_.handle, 0, 0, &n_out), "smhip_prepare_target_from_source")) {
+      // the slot's target arrays may have been overwritten before the failure: no target until the next SetInputTarget
+      target_ok_ = false; target_keep_ = nullptr; target_kind_ = kNoTarget;
+      return 0;
+    }
+    target_keep_ = source_keep_; target_kind_ = kTargetRaw; prepared_points_ = n_out; target_ok_ = true;
     return n_out;
   }
   int CapacitySource() const { return arena_.cap_source; }
@@ -394,13 +396,22 @@ class IcpFastHip : public Interface {
     std::fprintf(stderr, "[ERROR] %s: %s (%s)\n", what, smhip_status_string(s), arena_.handle ? smhip_last_error(arena_.handle) : "");
     return false;
   }
-  bool UploadSource() {
-    const auto& e = *source_keep_->GetEigenCloud();
+  // SetInputTarget / SetInputTargetRaw: what the device holds (target_keep_, target_kind_) changes only on success.  A refused
+  // cloud (NaN / Inf, too large for the device) leaves the matcher WITHOUT a target: the slot may be half-written and the
+  // previous key frame must not be matched silently (Align returns false), nor re-uploaded after a re-size.
+  bool SetTarget(const InnerCloudPtr& cloud, TargetKind kind) {
+    target_ok_ = EnsureHandle(0, cloud->GetEigenCloud()->size(), true, false) && UploadTarget(*cloud, kind);
+    target_keep_ = target_ok_ ? cloud : nullptr;
+    target_kind_ = target_ok_ ? kind : kNoTarget;
+    return target_ok_;
+  }
+  bool UploadSource(const data::InnerPointCloudData& cloud) {
+    const auto& e = *cloud.GetEigenCloud();
     return Ok(smhip_set_source_f64(arena_.handle, 0, e.points.data(), e.size()), "smhip_set_source_f64");
   }
-  bool UploadTarget() {
-    const auto& e = *target_keep_->GetEigenCloud();
-    if (target_kind_ == kTargetWithNormals)
+  bool UploadTarget(const data::InnerPointCloudData& cloud, TargetKind kind) {
+    const auto& e = *cloud.GetEigenCloud();
+    if (kind == kTargetWithNormals)
       return Ok(smhip_set_target_f64(arena_.handle, 0, e.points.data(), e.normals.data(), e.size()), "smhip_set_target_f64");
     std::vector<float> rows(static_cast<size_t>(e.size()) * 3);
     const double* p = e.points.data();
@@ -430,8 +441,8 @@ class IcpFastHip : public Interface {
     }
     if (!ApplyOptions(arena_.handle)) return false;
     if (recreated) {
-      if (restore_source && source_keep_ && !UploadSource()) return false;
-      if (restore_target && target_keep_ && target_kind_ != kNoTarget && !UploadTarget()) return false;
+      if (restore_source && source_keep_ && !UploadSource(*source_keep_)) { source_ok_ = false; return false; }
+      if (restore_target && target_keep_ && target_kind_ != kNoTarget && !UploadTarget(*target_keep_, target_kind_)) { target_ok_ = false; return false; }
     }
     return true;
   }
@@ -452,7 +463,7 @@ class IcpFastHip : public Interface {
   InnerCloudPtr source_keep_, target_keep_;   // what the device holds (icp_fast.cc:424,431 deep-copies; here: to re-upload after a re-size)
   TargetKind target_kind_ = kNoTarget;
   int prepared_points_ = 0;
-  bool input_ok_ = true;
+  bool source_ok_ = false, target_ok_ = false;   // the device holds the cloud of the last SetInputSource / SetInputTarget
   smhip_icp_stats stats_{};
 };
 

@@ -137,6 +137,7 @@ SIGNATURES = {
     "smhip_filter_output_to_source": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "smhip_icp_enable_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "smhip_icp_get_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(IcpProfile)]),
+    "smhip_icp_get_search_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]),
 }
 
 _LIB = None

@@ -158,6 +158,13 @@ __global__ void pose_setup(IcpDev b, int npairs) {
   const PairInput* in = &b.in[pair];
   st->ns = in->ns; st->has_normals = in->has_normals;
   for (int i = 0; i < 16; ++i) st->guess[i] = in->guess[i];
+  if (st->grid_invalid) {                 // the kept "structure" is grid_setup's placeholder for a non-finite target: fail again
+    for (int i = 0; i < 16; ++i) st->result[(i % 4) * 4 + i / 4] = st->guess[i];
+    st->iter = 0; st->score = 0; st->kept = 0; st->searched_total = 0; st->fallback_total = 0; st->hard_total = 0; st->refine_total = 0;
+    st->status = 1; st->done = 1;
+    atomicAdd(b.done_count, 1u);
+    return;
+  }
   const double Tmi[16] = {1, 0, 0, -st->mu[0], 0, 1, 0, -st->mu[1], 0, 0, 1, -st->mu[2], 0, 0, 0, 1};
   mat4_mul_rm(Tmi, st->guess, st->G);
   for (int i = 0; i < 16; ++i) st->T_iter[i] = (i % 5 == 0) ? 1.0 : 0.0;
@@ -220,9 +227,11 @@ __global__ void grid_setup(IcpDev b, int npairs) {
     st->rcap2 = 0.f;
     st->status = 1;                        // SMHIP_ERR_INVALID_ARGUMENT
     st->done = 1;
+    st->grid_invalid = 1;
     atomicAdd(b.done_count, 1u);
     return;
   }
+  st->grid_invalid = 0;
   float h = b.grid_cell;
   int nx, ny, nz, wx;
   for (;;) {
@@ -838,7 +847,10 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball_listed(IcpDev b, int nblk)
 
 // Certificate pass (iterations >= 1): no search, five memory operations per query.
 // ITEMS = rounds of 256 queries per workgroup: kBallItems in batches, 1 where that would leave too few workgroups (one pair)
-template <int ITEMS>
+// NABO = true: the records are traversal certificates of the libnabo walk (nabo_kernels.hip): how far the query may move
+// before any decision of its walk, or the winner among the entries it scanned, can change.  A query that has moved less
+// keeps its id -- by the same walk, not because it is nearest -- and only its distance to that id is recomputed.
+template <int ITEMS, bool NABO = false>
 __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
   int pair, blk;
   if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
@@ -893,7 +905,16 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
       // recorded, less what the query can have moved since (the pair's motion potential now; the one then is in the record)
       const float Lp = bound_now(l, pot_at(pot, norm3(s.x, s.y, s.z)));
       fail = true;
-      if (isfinite(qx) && isfinite(qy) && isfinite(qz) && Lp > 0.f) {
+      if (NABO) {
+        // the walk compares floats derived from the ROUNDED position: its motion is the true one plus two roundings of q
+        if (isfinite(qx) && isfinite(qy) && isfinite(qz) && l > 0.f && j >= 0 &&
+            Lp - 1.3e-7f * (fabsf(qx) + fabsf(qy) + fabsf(qz)) > 0.f) {
+          const float d1 = dist2(t, qx, qy, qz);     // the bucket scan's arithmetic: the bits the walk would produce
+          b.d2[so + i] = d1;
+          atomicAdd(&s_hist[__float_as_uint(d1) >> kHistShift], 1u);
+          fail = false;
+        }
+      } else if (isfinite(qx) && isfinite(qy) && isfinite(qz) && Lp > 0.f) {
         if (l > 0.f && j >= 0) {
           const float d1 = dist2(t, qx, qy, qz);
           if (d1 < Lp * Lp) {                       // still the unique nearest neighbour: exact, no search

@@ -31,6 +31,7 @@ constexpr int kKdThreads = 1024;          // one workgroup builds one pair's tre
 constexpr int kKdBucket = 8;              // libnabo's default bucketSize
 constexpr int kKdHistWords = 16384;       // 64 KiB of LDS histograms: segments per pass x 2^bits bins
 constexpr int kKdStack = 18;              // pending siblings per query: at most one per tree level (18 levels: > 1 M target points; node < 2^23)
+constexpr int kNaboListedBlocks = 64;     // workgroups per pair striding over the list of queries to walk again
 constexpr int kKdTopNodes = 1023;         // tree levels 0..9 staged in LDS by the search kernel (8 KiB)
 
 struct KdSeg {                            // one node of the current level while the tree is being built
@@ -354,21 +355,48 @@ __global__ __launch_bounds__(kKdThreads) void kd_build(IcpDev b, KdDev kd) {
 
 // ------------------------------------------------------------------------------------------------------------------
 // knn(k = 1, epsilon, ALLOW_SELF_MATCH): one query per lane, libnabo's visiting order.
+//
+// Traversal certificates.  libnabo's answer is a deterministic function of the query position: the walk is a sequence of
+//   side decisions   new_off > 0 at every inner node it enters (which child is "near"),
+//   prune decisions  rd (1 + eps)^2 < best for every sibling it leaves behind, with the best distance found so far,
+// and the answer is the first smallest entry of the buckets it scans.  While every one of those comparisons keeps its
+// outcome the walk visits the same buckets in the same order, and while the winner of the scanned entries stays ahead
+// of the runner-up it returns the same id.  All of them are comparisons of 1-Lipschitz functions of the query:
+//   |new_off| changes by at most the query's motion m;  sqrt(rd) (the distance to the sibling's half-space corner) and
+//   sqrt(best) (a minimum of point distances over the same scanned set) by at most m each, so a prune decision holds
+//   while |sqrt(rd) (1 + eps) - sqrt(best)| > (2 + eps) m;  the winner holds while runner-up - winner > 2 m.
+// The walk therefore records the smallest such slack (in metres of query motion, less the float roundings of the
+// quantities compared) next to the match, stored like the exact search's bounds with the pair's motion potential added
+// (icp_kernels.hip, with_pot / bound_now).  In the following iterations nn_certify<., true> re-derives nothing: a query
+// whose accumulated motion is below its slack provably gets the same id from the same walk, so only its distance to
+// that id is recomputed (the same dist2 the bucket scan uses: the same bits); the others are compacted and walked again
+// (nn_nabo<., true>).  tests/test_nabo_gpu.py::test_nabo_certificates_change_no_bit.
 // ------------------------------------------------------------------------------------------------------------------
 struct KdNodeView { uint32_t dim, left; float cut; };   // leaf: dim == 3, left = count, cut bits = first
 
-template <int ITEMS>
+// lower bound on |sqrt(x) - sqrt(y)| for x, y >= 0 computed as floats with a relative error of at most 1e-5 each
+// (rd: <= 18 un-contracted update steps; best: three fused multiply-adds): |x - y| / (2 sqrt(max)) less that error
+__device__ __forceinline__ float kd_sqrt_gap(float x, float y) {
+  const float m = fmaxf(fmaxf(x, y), 1.0e-30f);
+  return (fabsf(x - y) - 2.0e-5f * m) * (0.5f * __frsqrt_rn(m));
+}
+
+// LISTED = false: queries [blk * 256 * ITEMS, ...) of the pair (iteration 0, find_closests, certificates off);
+// LISTED = true: the queries nn_certify<., true> could not certify (dlist), the pair's nblk workgroups striding over the list
+template <int ITEMS, bool LISTED>
 __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nblk) {
   int pair, blk;
   if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
   PairState* st = &b.state[pair];
   if (st->done) return;
   const int ns = st->ns;
+  const int count = LISTED ? (int)st->deferred_count : ns;
   const int base0 = blk * (kNnThreads * ITEMS);
-  if (base0 >= ns) return;
+  if (base0 >= count) return;
   double Mc[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) Mc[k] = st->M[k];
+  const Pot pot = {(float)st->pot_a, (float)st->pot_b, 0.f, 0.f};
   __shared__ uint32_t s_hist[kHistBins];
   __shared__ uint2 s_top[kKdTopNodes + 1];
   // pending siblings: word A = (node << 2) | cut dimension of its parent, or 0x80000000 | root path for a sibling met
@@ -382,18 +410,24 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
   for (int k = threadIdx.x; k < min(n_nodes, kKdTopNodes); k += kNnThreads) s_top[k] = nodes[k];
   __syncthreads();
   const float E2 = kd.max_error2;
+  const float inv_prune = 1.0f / (1.0f + sqrtf(E2) * 1.000001f);   // a prune decision moves by at most (1 + (1 + eps)) x the motion
   const size_t so = (size_t)pair * b.ns_cap;
   const int t = threadIdx.x;
   auto node_at = [&](uint32_t v) -> uint2 { return v < (uint32_t)kKdTopNodes ? s_top[v] : nodes[v]; };
 
-  for (int it = 0; it < ITEMS; ++it) {
-    const int i = base0 + it * kNnThreads + t;
-    if (i >= ns) continue;
+  for (int base = base0; base < count; base += LISTED ? nblk * kNnThreads : kNnThreads) {
+    if (!LISTED && base >= base0 + kNnThreads * ITEMS) break;
+    const int e_ = base + t;
+    if (e_ >= count) continue;
+    const int i = LISTED ? b.dlist[so + e_] : e_;
+    const float4 s4 = ld_src(b, so + i);
     double px, py, pz;
-    transform_point(Mc, ld_src(b, so + i), px, py, pz);
+    transform_point(Mc, s4, px, py, pz);
     const float q[3] = {(float)px, (float)py, (float)pz};
-    float best = INFINITY;
+    float best = INFINITY, second = INFINITY;                // smallest and second-smallest distance over every scanned entry
     int bestj = -1;
+    float side = INFINITY;                                   // smallest |new_off| over the inner nodes entered
+    float prune = INFINITY;                                  // smallest |sqrt(rd E2) - sqrt(best)| over the prune decisions
     if (isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]) && n_nodes > 0) {
       // a bucket holds at most 8 consecutive points: all eight loads are issued together (one memory latency per bucket
       // instead of one per entry), entries beyond the bucket's count are masked; entries are tested in bucket order with
@@ -405,8 +439,9 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
         for (int e = 0; e < kKdBucket; ++e) p[e] = tq[f + min((uint32_t)e, c - 1u)];
 #pragma unroll
         for (int e = 0; e < kKdBucket; ++e) {
-          const float d = dist2(p[e], q[0], q[1], q[2]);
-          if ((uint32_t)e < c && d < best) { best = d; bestj = (int)(f + e); }
+          const float d = (uint32_t)e < c ? dist2(p[e], q[0], q[1], q[2]) : INFINITY;
+          second = __builtin_amdgcn_fmed3f(d, best, second);  // best <= second always: the median of the three is the new runner-up
+          if (d < best) { best = d; bestj = (int)(f + e); }
         }
       };
       // (1) descent to the query's own leaf.  On this path no coordinate has an offset yet, so the sibling left behind at a
@@ -420,7 +455,9 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
         const uint32_t cd = nd.y & 3u;
         const float no = (cd == 0 ? q[0] : (cd == 1 ? q[1] : q[2])) - __uint_as_float(nd.x);
         const uint32_t right = no > 0.f ? 1u : 0u;
+        side = fminf(side, fabsf(no));
         if (depth < kKdStack) { s_stack[depth][t] = ((uint32_t)depth << 25) | (((nd.y >> 2) + (right ^ 1u)) << 2) | cd; s_off[depth][t] = no; }   // level | node | cd
+        else side = -INFINITY;                               // deeper than the stack (the host refuses such targets): never certified
         ++depth;
         path = (path << 1) | right;
         v = (nd.y >> 2) + right;                              // children sit side by side: left, right
@@ -428,10 +465,14 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
       }
       scan_leaf(nd);
       int sp = 0;
+      float rd_cut = INFINITY;                                // the nearest sibling the first bucket's distance prunes
       for (int l = 0; l < min(depth, kKdStack); ++l) {         // shallow to deep: the write position never passes the read position
         const float no = s_off[l][t];
-        if (kd_rd_step(0.f, 0.f, no) * E2 < best) { s_stack[sp][t] = s_stack[l][t]; s_off[sp][t] = no; ++sp; }
+        const float rdE = kd_rd_step(0.f, 0.f, no) * E2;
+        if (rdE < best) { s_stack[sp][t] = s_stack[l][t]; s_off[sp][t] = no; ++sp; }
+        else rd_cut = fminf(rd_cut, rdE);                     // pruned now = pruned at its turn (best only shrinks): one slack for all of them
       }
+      if (rd_cut < INFINITY) prune = fminf(prune, kd_sqrt_gap(rd_cut, best));
       // (2) pending siblings, deepest first; the test is libnabo's, with the best AS OF NOW
       while (sp > 0) {
         --sp;
@@ -443,6 +484,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
           const float no = s_off[sp][t];
           const uint32_t cd = A & 3u;
           rd = kd_rd_step(0.f, 0.f, no);
+          prune = fminf(prune, kd_sqrt_gap(rd * E2, best));
           if (!(rd * E2 < best)) continue;
           if (cd == 0) off[0] = no; else if (cd == 1) off[1] = no; else off[2] = no;
           v = (A >> 2) & 0x7fffffu;
@@ -465,6 +507,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
             v = (nd.y >> 2) + bit;
             nd = node_at(v);
           }
+          prune = fminf(prune, kd_sqrt_gap(rd * E2, best));
           if (!(rd * E2 < best)) continue;
           pp = P;
         }
@@ -474,9 +517,15 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
           const uint32_t cd = nd.y & 3u;
           const float no = (cd == 0 ? q[0] : (cd == 1 ? q[1] : q[2])) - __uint_as_float(nd.x);
           const uint32_t right = no > 0.f ? 1u : 0u;
+          side = fminf(side, fabsf(no));
           const float oo = cd == 0 ? off[0] : (cd == 1 ? off[1] : off[2]);
           const float rdf = kd_rd_step(rd, oo, no);
-          if (rdf * E2 < best && sp < kKdStack) { s_stack[sp][t] = 0x80000000u | (pp << 1) | (right ^ 1u); ++sp; }
+          if (rdf * E2 < best) {
+            if (sp < kKdStack) { s_stack[sp][t] = 0x80000000u | (pp << 1) | (right ^ 1u); ++sp; }
+            else side = -INFINITY;
+          } else {
+            prune = fminf(prune, kd_sqrt_gap(rdf * E2, best));  // pruned with today's best = pruned at its turn
+          }
           pp = (pp << 1) | right;
           v = (nd.y >> 2) + right;
           nd = node_at(v);
@@ -486,7 +535,15 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
     }
     b.d2[so + i] = best;
     b.idx[so + i] = bestj;
-    st_lb(b, so + i, 0.f);
+    // the certificate: how far the query may move before any decision of this walk, or its winner, can change
+    float slack = 0.f;
+    if (bestj >= 0) {
+      const float win = second < INFINITY ? 0.5f * kd_sqrt_gap(second, best) : INFINITY;
+      slack = fminf(fminf(side, prune * inv_prune), win);
+      slack = fminf(slack, 1.0e3f);                            // keeps the stored sum a small float
+      if (!(slack > 0.f)) slack = 0.f;                         // 0 = unknown: walked again next iteration
+    }
+    st_lb(b, so + i, with_pot(slack, pot_at(pot, norm3(s4.x, s4.y, s4.z))));
     const uint32_t key = __float_as_uint(best);
     if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
   }

@@ -15,6 +15,8 @@
 // All arithmetic happens behind the C ABI of include/smhip.h; the gather is ncclAllGather on the doubles
 // smhip_icp_export_results_device leaves in device memory -- the poses never visit the host before the collective.
 #include <dirent.h>
+#include <fcntl.h>
+#include <signal.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <sys/stat.h>
@@ -46,6 +48,7 @@ using smhip::kitti::ScanPrefetcher;
 
 struct Args {
   std::string scans_dir, out_path = "kitti_pose.txt", id_file;
+  unsigned long long nonce = 0;             // identifies this run's id file (launcher: pid and start time; else MASTER_PORT)
   int gpus = 1, rank = -1, world = -1, local_rank = -1;
   int batch = 64, iterations = 20, early_exit = 0, max_pairs = -1, readers = 4;
   double guess_tx = 0.0;
@@ -89,6 +92,7 @@ Args Parse(int argc, char** argv) {
     else if (k == "--world") a.world = std::atoi(val().c_str());
     else if (k == "--local-rank") a.local_rank = std::atoi(val().c_str());
     else if (k == "--id-file") a.id_file = val();
+    else if (k == "--nonce") a.nonce = std::strtoull(val().c_str(), nullptr, 10);
     else if (k == "--batch") a.batch = std::atoi(val().c_str());
     else if (k == "--iterations") a.iterations = std::atoi(val().c_str());
     else if (k == "--early-exit") a.early_exit = std::atoi(val().c_str());
@@ -106,24 +110,42 @@ Args Parse(int argc, char** argv) {
   return a;
 }
 
-// rank 0 creates the communicator id and publishes it; the others wait for the file
+// rank 0 creates the communicator id and publishes it; the others wait for the file.  The file carries a per-run nonce
+// (the launcher's, or MASTER_PORT / SMHIP_SHARD_NONCE under an external launcher) in front of the id: a file left behind by
+// a crashed run -- or by another run using the same path -- does not match and is waited out instead of being taken for
+// this run's id (ncclCommInitRank would hang on a stale one).  Rank 0 replaces any existing file (unlink + O_EXCL on the
+// temporary, then rename) and removes it at exit, also on the error paths.
+struct IdRecord { unsigned long long nonce; ncclUniqueId id; };
+std::string g_id_file_to_remove;
+void RemoveIdFile() { if (!g_id_file_to_remove.empty()) std::remove(g_id_file_to_remove.c_str()); }
+
 ncclUniqueId ExchangeId(const Args& a, int rank) {
-  ncclUniqueId id;
+  IdRecord rec{};
+  rec.nonce = a.nonce;
   if (rank == 0) {
-    NCCLOK(ncclGetUniqueId(&id));
-    const std::string tmp = a.id_file + ".tmp";
-    std::ofstream f(tmp, std::ios::binary);
-    f.write(reinterpret_cast<const char*>(&id), sizeof(id));
-    f.close();
-    if (std::rename(tmp.c_str(), a.id_file.c_str()) != 0) Die("cannot publish " + a.id_file);
-    return id;
+    NCCLOK(ncclGetUniqueId(&rec.id));
+    const std::string tmp = a.id_file + ".tmp." + std::to_string(static_cast<long>(getpid()));
+    std::remove(a.id_file.c_str());
+    std::remove(tmp.c_str());
+    const int fd = open(tmp.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0600);
+    if (fd < 0) Die("cannot create " + tmp);
+    const bool ok = write(fd, &rec, sizeof(rec)) == static_cast<ssize_t>(sizeof(rec));
+    close(fd);
+    if (!ok) { std::remove(tmp.c_str()); Die("cannot write " + tmp); }
+    g_id_file_to_remove = a.id_file;
+    std::atexit(RemoveIdFile);
+    if (std::rename(tmp.c_str(), a.id_file.c_str()) != 0) { std::remove(tmp.c_str()); Die("cannot publish " + a.id_file); }
+    return rec.id;
   }
   for (int tries = 0; tries < 6000; ++tries) {                           // <= 60 s
+    IdRecord got{};
     std::ifstream f(a.id_file, std::ios::binary);
-    if (f && f.read(reinterpret_cast<char*>(&id), sizeof(id)) && f.gcount() == static_cast<std::streamsize>(sizeof(id))) return id;
+    if (f && f.read(reinterpret_cast<char*>(&got), sizeof(got)) && f.gcount() == static_cast<std::streamsize>(sizeof(got)) &&
+        got.nonce == a.nonce)
+      return got.id;
     usleep(10000);
   }
-  Die("timed out waiting for " + a.id_file);
+  Die("timed out waiting for " + a.id_file + " (no file with this run's nonce appeared)");
 }
 
 int RunRank(const Args& a, int rank, int world, int device) {
@@ -259,7 +281,6 @@ int RunRank(const Args& a, int rank, int world, int device) {
                   world, n_pairs, my_pairs, elapsed, n_pairs / elapsed, upload_s, score_sum / n_pairs, iter_sum / n_pairs, bad, a.out_path.c_str());
     }
     if (bad) rc = 3;
-    if (world > 1) std::remove(a.id_file.c_str());
   }
   (void)hipFree(local_dev); (void)hipFree(all_dev);
   smhip_destroy(h);
@@ -275,21 +296,28 @@ int main(int argc, char** argv) {
   if (a.id_file.empty()) a.id_file = "/tmp/smhip_shard_id_" + std::to_string(a.rank >= 0 ? static_cast<long>(getppid()) : static_cast<long>(getpid()));
   if (a.rank >= 0) {                                                     // one rank of a launched group
     const int world = a.world > 0 ? a.world : 1;
+    if (a.nonce == 0) {                                                  // external launcher: every rank sees the same MASTER_PORT
+      const char* e = std::getenv("SMHIP_SHARD_NONCE");
+      if (!e) e = std::getenv("MASTER_PORT");
+      if (e) a.nonce = std::strtoull(e, nullptr, 10);
+    }
     return RunRank(a, a.rank, world, a.local_rank >= 0 ? a.local_rank : a.rank);
   }
-  if (a.gpus <= 1) { std::remove(a.id_file.c_str()); return RunRank(a, 0, 1, 0); }
+  a.nonce = (static_cast<unsigned long long>(getpid()) << 32) ^ static_cast<unsigned long long>(std::chrono::steady_clock::now().time_since_epoch().count());
+  if (a.gpus <= 1) return RunRank(a, 0, 1, 0);
   // launcher: one child process per GPU (fresh processes -- no HIP state is inherited across the fork)
   std::remove(a.id_file.c_str());
   std::vector<pid_t> kids;
   for (int r = 0; r < a.gpus; ++r) {
     const pid_t pid = fork();
-    if (pid < 0) Die("fork failed");
+    if (pid < 0) { for (pid_t k : kids) kill(k, SIGTERM); Die("fork failed"); }
     if (pid == 0) {
       std::vector<std::string> args(argv, argv + argc);
       args.push_back("--rank"); args.push_back(std::to_string(r));
       args.push_back("--world"); args.push_back(std::to_string(a.gpus));
       args.push_back("--local-rank"); args.push_back(std::to_string(r));
       args.push_back("--id-file"); args.push_back(a.id_file);
+      args.push_back("--nonce"); args.push_back(std::to_string(a.nonce));
       std::vector<char*> cargs;
       for (auto& s : args) cargs.push_back(const_cast<char*>(s.c_str()));
       cargs.push_back(nullptr);
@@ -299,7 +327,21 @@ int main(int argc, char** argv) {
     }
     kids.push_back(pid);
   }
+  // a rank that dies before the all-gather (unreadable scan, device error) would leave the others blocked in it for good:
+  // the first failure ends the whole group
   int rc = 0;
-  for (pid_t k : kids) { int st = 0; waitpid(k, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = rc ? rc : (WIFEXITED(st) ? WEXITSTATUS(st) : 1); }
+  size_t left = kids.size();
+  while (left > 0) {
+    int st = 0;
+    const pid_t k = waitpid(-1, &st, 0);
+    if (k < 0) break;
+    --left;
+    const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+    if (code != 0 && rc == 0) {
+      rc = code;
+      for (pid_t other : kids) if (other != k) kill(other, SIGTERM);
+    }
+  }
+  std::remove(a.id_file.c_str());
   return rc;
 }

@@ -197,7 +197,7 @@ smhip_status enqueue_resets(smhip_context* h, int np, int first = 0) {
 smhip_status kd_ensure(smhip_context* h) {
   if (h->kd_allocated) return SMHIP_OK;
   const size_t B = h->dev.slots, NT = h->dev.nt_cap;
-  h->kd.node_cap = (int32_t)(NT / 2 + 8);       // a bucket holds > 4 points once the cloud has > 8: <= nt / 4 leaves, 2 leaves - 1 nodes
+  h->kd.node_cap = (int32_t)(NT / 2 + 8);       // a split node has >= 9 points and gives each child >= 4: <= nt / 4 leaves, 2 leaves - 1 nodes
   h->kd.seg_cap = (int32_t)(NT / 4 + 8);
   smhip_status s = SMHIP_OK;
   auto A = [&](smhip_status r) { if (s == SMHIP_OK) s = r; };
@@ -220,6 +220,9 @@ smhip_status enqueue_grid_build(smhip_context* h, const Half& f, int nt_max) {
     // the reference's own structure: libnabo's kd-tree over the centred target, rebuilt per Align (icp_fast.cc:464-467)
     smhip_status ks = kd_ensure(h);
     if (ks) return ks;
+    // the search keeps one pending sibling per tree level in kKdStack LDS slots per query; a median split halves (rounding
+    // up) until a bucket holds <= 8 points, so 8 << kKdStack points is the deepest tree the stack can follow
+    if (nt_max > (kKdBucket << kKdStack)) { h->err = "nn_mode NABO: target larger than 8 << 18 points (the search stack holds 18 tree levels)"; return SMHIP_ERR_CAPACITY; }
     hipLaunchKernelGGL(kd_build, dim3(np), dim3(kKdThreads), 0, f.stream, d, h->kd);
     HIPCHK(h, hipGetLastError());
     for (int p = d.pair_base; p < d.pair_base + np; ++p) {
@@ -301,17 +304,34 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
   hipStream_t st = f.stream;
   const dim3 g(ceil_div(ns_max, kNnThreads), np);
   if (h->opts.nn_mode == SMHIP_NN_NABO) {
-    // knn(k = 1, epsilon) through libnabo's tree: what it returns IS the match (no bounds, nothing to refine)
-    Bracket br(h, 4, st, np);
+    // knn(k = 1, epsilon) through libnabo's tree: what it returns IS the match (no bounds, nothing to refine).  Iteration 0
+    // walks every query and records its traversal certificate; later iterations re-walk only the queries that have moved
+    // further than their certificate allows (nabo_kernels.hip)
     KdDev kd = h->kd;
     const float e = h->opts.nn_epsilon >= 0.f ? h->opts.nn_epsilon : 3.16f;
     kd.max_error2 = (1.0f + e) * (1.0f + e);
-    if (f.small) {
-      const int nb1 = ceil_div(ns_max, kNnThreads);
-      hipLaunchKernelGGL(nn_nabo<1>, dim3(nb1 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, kd, nb1);
+    const int nb1 = ceil_div(ns_max, kNnThreads);
+    if (d.certify && iteration > 0) {
+      {
+        Bracket br(h, 5, st, np);
+        if (f.small) {
+          hipLaunchKernelGGL((nn_certify<1, true>), dim3(nb1 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nb1);
+        } else {
+          const int nbc = ceil_div(ns_max, kNnThreads * kCertifyItems);
+          hipLaunchKernelGGL((nn_certify<kCertifyItems, true>), dim3(nbc * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nbc);
+        }
+      }
+      Bracket br(h, 4, st, np);
+      const int nbl = f.small ? nb1 : kNaboListedBlocks;
+      hipLaunchKernelGGL((nn_nabo<1, true>), dim3(nbl * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, kd, nbl);
     } else {
-      const int nb4 = ceil_div(ns_max, kNnThreads * 4);
-      hipLaunchKernelGGL(nn_nabo<4>, dim3(nb4 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, kd, nb4);
+      Bracket br(h, 4, st, np);
+      if (f.small) {
+        hipLaunchKernelGGL((nn_nabo<1, false>), dim3(nb1 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, kd, nb1);
+      } else {
+        const int nb4 = ceil_div(ns_max, kNnThreads * 4);
+        hipLaunchKernelGGL((nn_nabo<4, false>), dim3(nb4 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, kd, nb4);
+      }
     }
   } else if (h->opts.nn_mode == SMHIP_NN_GRID) {
     if (d.use_ball) {
@@ -724,6 +744,9 @@ static smhip_status prep_run(smhip_handle h, const float4* raw_dev, int n, int s
   const hipError_t e = prep_calculate_normals(h->prep, h->stream, raw_dev, n,
                                               const_cast<float4*>(h->dev.tgt_p) + (size_t)slot * h->dev.nt_cap,
                                               const_cast<float4*>(h->dev.tgt_n) + (size_t)slot * h->dev.nt_cap, &m);
+  // from here on the slot's target arrays have been written: whatever target it held is gone, also on the error paths
+  touch_target(h, slot);
+  h->nt[slot] = 0; h->has_normals[slot] = 0;
   if (e != hipSuccess) { h->err = std::string("prep_calculate_normals: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
   if (m <= 0) { h->err = "CalculateNormals produced no target points"; return SMHIP_ERR_INVALID_ARGUMENT; }
   h->nt[slot] = m;
@@ -781,6 +804,7 @@ smhip_status smhip_prepare_targets_from_sources(smhip_handle h, int count, const
   }
   const hipError_t e = prep_calculate_normals_batch(h->prep_batch, h->stream, h->dev.src, count, off.data(), n.data(), out_off.data(),
                                                     const_cast<float4*>(h->dev.tgt_p), const_cast<float4*>(h->dev.tgt_n), m.data());
+  for (int k = 0; k < count; ++k) { touch_target(h, to_slots[k]); h->nt[to_slots[k]] = 0; h->has_normals[to_slots[k]] = 0; }   // overwritten, whatever follows
   if (e != hipSuccess) { h->err = std::string("prep_calculate_normals_batch: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
   for (int k = 0; k < count; ++k) {
     if (m[k] <= 0) { h->err = "CalculateNormals produced no target points"; return SMHIP_ERR_INVALID_ARGUMENT; }
@@ -1161,6 +1185,16 @@ smhip_status smhip_icp_enable_profile(smhip_handle h, int enable) {
   h->profile = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
   h->prof = smhip_icp_profile{};
   h->ev_used = 0;
+  return SMHIP_OK;
+}
+
+smhip_status smhip_icp_get_search_counts(smhip_handle h, int slot, uint32_t* counts) {
+  smhip_status s = check_slot(h, slot);
+  if (s) return s;
+  if (!counts) return SMHIP_ERR_INVALID_ARGUMENT;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(counts, h->dev.search_hist + (size_t)slot * kSearchHist, sizeof(uint32_t) * kSearchHist, hipMemcpyDeviceToHost));
   return SMHIP_OK;
 }
 

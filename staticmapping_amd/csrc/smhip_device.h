@@ -80,6 +80,8 @@ struct PairState {
   float rcap2;               // squared search-radius cap of nn_ball for the next iteration
   int32_t kept;
   uint32_t limit_key;
+  int32_t grid_invalid;      // 1 = grid_setup found a non-finite target box: no search structure was built for this target, and
+  int32_t pad_;              //     every Align on it fails (pose_setup re-asserts it when the structure is "kept")
   // outputs
   double score;
   double result[16];     // column-major (Eigen layout)

@@ -209,6 +209,12 @@ class IcpFastHip:
                                                     d2.ctypes.data_as(_capi.c_float_p), n))
         return ids, d2
 
+    def search_counts(self, slot: int = 0):
+        """Queries that went through a search in iterations 0..11 of the slot's last Align."""
+        c = (ctypes.c_uint32 * 12)()
+        self._check(self._lib.smhip_icp_get_search_counts(self._h, slot, c))
+        return list(c)
+
     def find_closests(self, T, n: int):
         Tc = _f64(np.asarray(T).T).reshape(-1)
         ids = np.zeros(n, dtype=np.int32)
@@ -404,6 +410,10 @@ class IcpPointMatcherHip:
         self.final_score_ = float("nan")
         self._reading = None
         self._reference = None
+        self._reading_on_device = False      # slot 1 holds the current reading / raw reference (uploaded once per cloud,
+        self._reference_on_device = False    # like IcpPointMatcherHip in include/smhip/registrator.h)
+        self._prepared = None                # (seed, prob) the sampled reading in slot 0 was drawn with
+        self._target_prepared = False        # slot 0's target is CalculateNormals of the current reference
         self.last_mask = None
 
     def close(self):
@@ -412,10 +422,14 @@ class IcpPointMatcherHip:
     def set_input_source(self, points):
         a = np.asarray(points, dtype=np.float32)
         self._reading = a[~np.isnan(a[:, :3]).any(axis=1)]          # InnerCloudToPmPoints drops NaN points, :57-66
+        self._reading_on_device = False
+        self._prepared = None
 
     def set_input_target(self, points):
         a = np.asarray(points, dtype=np.float32)
         self._reference = a[~np.isnan(a[:, :3]).any(axis=1)]
+        self._reference_on_device = False
+        self._target_prepared = False
 
     def sampling_mask(self, n: int) -> np.ndarray:
         """The kept set of the device sampler (smhip_sample_source): uniform = splitmix64(seed << 32 | i) >> 11 * 2^-53,
@@ -440,14 +454,25 @@ class IcpPointMatcherHip:
         self.last_mask = self.sampling_mask(len(self._reading))
         m.set_options(max_iteration=150, dist_outlier_ratio=0.7, early_exit=1)
         if self.device_chain:
-            m.set_input_source(np.ascontiguousarray(self._reading), slot=1)
-            m.set_input_target(np.ascontiguousarray(self._reference[:, :3]), None, slot=1)
+            # each cloud goes up once: repeated align() calls on the same clouds skip the uploads, the sampling and the
+            # target preparation, so the slots' kept search structures (smhip_set_target_cache) are actually reused
+            if not self._reading_on_device:
+                m.set_input_source(np.ascontiguousarray(self._reading), slot=1)
+                self._reading_on_device = True
+            if not self._reference_on_device:
+                m.set_input_target(np.ascontiguousarray(self._reference[:, :3]), None, slot=1)
+                self._reference_on_device = True
             n_out = ctypes.c_int32()
             seed = (0 if self.seed is None else int(self.seed)) & 0xffffffff
-            m._check(lib.smhip_sample_source(h, 1, 0, float(self.prob), seed, ctypes.byref(n_out)))      # reading filter :170-174
-            assert n_out.value == int(self.last_mask.sum()), (n_out.value, int(self.last_mask.sum()))
-            m._check(lib.smhip_prepare_target_from_target(h, 1, 0, ctypes.byref(n_out)))                  # reference filter :176-184
-            self.target_points = n_out.value
+            if self._prepared != (seed, float(self.prob)):
+                m._check(lib.smhip_sample_source(h, 1, 0, float(self.prob), seed, ctypes.byref(n_out)))  # reading filter :170-174
+                if n_out.value != int(self.last_mask.sum()):
+                    raise SmhipError(5, f"device sampler kept {n_out.value} points, the host mask {int(self.last_mask.sum())}")
+                self._prepared = (seed, float(self.prob))
+            if not self._target_prepared:
+                m._check(lib.smhip_prepare_target_from_target(h, 1, 0, ctypes.byref(n_out)))              # reference filter :176-184
+                self.target_points = n_out.value
+                self._target_prepared = True
             # ---- pm_icp_.compute(reading, reference, guess)                            :107-110
             _, result = m.align(G)
             self.iterations = m.last_stats[0]["iterations"]
@@ -460,6 +485,8 @@ class IcpPointMatcherHip:
             self.score_kept = kept.value
             return self.final_score_ >= 0.6, result                                    # :145-148
         # host-side chain (kept for A/B tests of the device chain): host CalculateNormals, four uploads, a second Align
+        self._reading_on_device = self._reference_on_device = self._target_prepared = False    # this path overwrites slot 0 / 1
+        self._prepared = None
         q, n = calculate_normals(self._reference[:, :3].astype(np.float64))
         m.set_input_source(np.ascontiguousarray(self._reading[self.last_mask]))
         m.set_input_target(q, n)

@@ -3,6 +3,7 @@
 // SetInputSource -> Align(guess, result) -> GetFitnessScore().  Clouds come from KITTI-layout .bin
 // files (float32 x,y,z,intensity) written by the pytest wrapper; the result goes to stdout as JSON.
 #define SMHIP_REGISTRATOR_THROW_ON_CHECK 1
+#include <cmath>
 #include <cstdio>
 #include <fstream>
 #include <string>
@@ -56,6 +57,21 @@ int main(int argc, char** argv) {
   reg::Matrix4d guess = reg::Matrix4d::Identity(), result;
   guess(0, 3) = std::atof(argv[3]);
   const bool ok = matcher->Align(guess, result);    // :333
+  // a target the device refuses (NaN coordinate) must leave the matcher WITHOUT a target: the next Align -- after a perfectly
+  // good SetInputSource -- fails loudly instead of matching the previous key frame; a good target brings it back
+  bool refused_target_fails = false, recovers = false;
+  {
+    InnerPointCloudData::Ptr bad(new InnerPointCloudData(ReadKittiBin(argv[1])));
+    bad->CalculateNormals();
+    bad->GetEigenCloud()->points[4] = std::nan("");
+    matcher->SetInputTarget(bad);
+    matcher->SetInputSource(source);
+    reg::Matrix4d r2;
+    refused_target_fails = !matcher->Align(guess, r2);
+    matcher->SetInputTarget(target);
+    recovers = matcher->Align(guess, r2);
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) recovers = recovers && r2(r, c) == result(r, c);
+  }
   // the same clouds through registrators::Ndt (type 5): no normals needed, InnerCloud AoS upload
   reg::MatcherOptions nopt; nopt.type = reg::kNdt;
   auto ndt = reg::CreateMatcher(nopt);
@@ -109,9 +125,10 @@ int main(int argc, char** argv) {
     for (int c = 0; c < 4; ++c) std::printf("%.17g%s", nres(r, c), (r == 3 && c == 3) ? "" : ", ");
   std::printf("], ");
   std::printf("\"ok\": %s, \"score\": %.17g, \"type\": %d, \"unknown_option_check\": %s, \"wrong_type_null\": %s, "
-              "\"no_normals_check\": %s, \"target_points\": %d, \"result\": [",
+              "\"no_normals_check\": %s, \"refused_target_fails\": %s, \"recovers_after_good_target\": %s, \"target_points\": %d, \"result\": [",
               ok ? "true" : "false", matcher->GetFitnessScore(), (int)matcher->GetType(), unknown_caught ? "true" : "false",
-              wrong_null ? "true" : "false", no_normals_caught ? "true" : "false", target->GetEigenCloud()->size());
+              wrong_null ? "true" : "false", no_normals_caught ? "true" : "false", refused_target_fails ? "true" : "false",
+              recovers ? "true" : "false", target->GetEigenCloud()->size());
   for (int r = 0; r < 4; ++r)
     for (int c = 0; c < 4; ++c) std::printf("%.17g%s", result(r, c), (r == 3 && c == 3) ? "" : ", ");
   std::printf("]}\n");

@@ -132,3 +132,52 @@ def test_batch_equals_single_calls_in_the_reference_search_mode(velo20k):
     for k in range(3):
         da, dt = sm.se3_error(R[k], single[k])
         assert da < 1e-9 and dt < 1e-8, (k, da, dt)
+
+
+@pytest.mark.parametrize("guess_name", ["offset", "identity", "truth"])
+def test_nabo_certificates_change_no_bit(cfg2, guess_name, capsys):
+    """A 120 k-point Align in the reference's search mode with traversal certificates (iterations >= 1 re-walk only the
+    queries that moved further than their recorded slack) against the same Align with every query walked in every
+    iteration (no_certify): the same pose bits, kept count and limit, and after the last iteration the same match of every
+    query -- from a good, a poor and an exact guess, for a batch as for a single pair.  The certificate is a bound on the
+    walk's own float comparisons; it is conservative, never wrong."""
+    import staticmapping_amd as sm
+    src, q, n = cfg2["src"], cfg2["q"], cfg2["n"]
+    guess = {"offset": cfg2["guess"], "identity": np.eye(4), "truth": cfg2["T"]}[guess_name]
+    ref = None
+    searched = {}
+    for name, opts in (("no_certify", dict(no_certify=1)), ("certify", dict())):
+        m = sm.IcpFastHip(max_source_points=len(src), max_target_points=len(q), max_iteration=20, early_exit=0,
+                          nn_mode=sm.NN_NABO, nn_epsilon=3.16, **opts)
+        m.set_input_source(src); m.set_input_target(q, n)
+        ok, R = m.align(guess)
+        st = m.last_stats[0]
+        ids, d2 = m.get_matches(len(src))
+        m.close()
+        key = (R.tobytes(), st["kept"], st["limit_d2"], st["iterations"], ids.tobytes(), d2.tobytes())
+        searched[name] = st["searched_queries"]
+        if ref is None:
+            ref = key
+        assert key[:4] == ref[:4], (name, st)
+        assert key[4] == ref[4], (name, "match ids differ", int((np.frombuffer(key[4], np.int32) != np.frombuffer(ref[4], np.int32)).sum()))
+        assert key[5] == ref[5], (name, "match distances differ")
+    with capsys.disabled():
+        print(f"\n[{guess_name}] queries walked in 20 iterations: {searched['certify']} with certificates, {searched['no_certify']} without")
+    assert searched["no_certify"] == 20 * len(src)
+    assert searched["certify"] < 0.5 * searched["no_certify"]
+
+
+def test_nabo_certificates_in_a_batch(velo20k):
+    """The batched launches (20 rounds per certificate workgroup, the strided list walk) against the single-pair ones."""
+    import staticmapping_amd as sm
+    guesses = [velo20k["guess"], np.eye(4), velo20k["T"]] * 6
+    out = {}
+    for name, opts in (("no_certify", dict(no_certify=1)), ("certify", dict())):
+        m = sm.IcpFastHip(pair_slots=len(guesses), max_source_points=20000, max_target_points=len(velo20k["q"]), nn_mode=sm.NN_NABO,
+                          max_iteration=15, early_exit=0, **opts)
+        for s in range(len(guesses)):
+            m.set_input_source(velo20k["src"], slot=s); m.set_input_target(velo20k["q"], velo20k["n"], slot=s)
+        R, sc, st = m.align_batch(len(guesses), guesses)
+        m.close()
+        out[name] = (np.asarray(R).tobytes(), [s["kept"] for s in st])
+    assert out["certify"] == out["no_certify"]

@@ -175,6 +175,7 @@ __global__ void pose_setup(IcpDev b, int npairs) {
   st->iter = 0; st->done = 0; st->status = 0;
   st->unresolved_count = 0; st->fallback_ticket = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
   st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0; st->searched_total = 0;
+  for (int c = 0; c < 4; ++c) st->nabo_count[c] = 0;
   st->pot_a = 0; st->pot_b = 0; st->step_a = 0; st->step_b = 0;
   st->rcap2 = b.ball_radius * b.ball_radius;
   st->kept = 0; st->limit_key = 0; st->score = 0;
@@ -223,6 +224,7 @@ __global__ void grid_setup(IcpDev b, int npairs) {
     st->n_hist = 1; st->iter = 0; st->score = 0; st->kept = 0; st->limit_key = 0;
     st->unresolved_count = 0; st->fallback_ticket = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
     st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0; st->searched_total = 0;
+  for (int c = 0; c < 4; ++c) st->nabo_count[c] = 0;
   st->pot_a = 0; st->pot_b = 0; st->step_a = 0; st->step_b = 0;
     st->rcap2 = 0.f;
     st->status = 1;                        // SMHIP_ERR_INVALID_ARGUMENT
@@ -258,6 +260,7 @@ __global__ void grid_setup(IcpDev b, int npairs) {
   st->iter = 0; st->done = 0; st->status = 0;
   st->unresolved_count = 0; st->fallback_ticket = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
   st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0; st->searched_total = 0;
+  for (int c = 0; c < 4; ++c) st->nabo_count[c] = 0;
   st->pot_a = 0; st->pot_b = 0; st->step_a = 0; st->step_b = 0;
   st->rcap2 = b.ball_radius * b.ball_radius;
   st->kept = 0; st->limit_key = 0; st->score = 0; st->nocc = 0;
@@ -845,6 +848,15 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball_listed(IcpDev b, int nblk)
   }
 }
 
+// SMHIP_NN_NABO: work classes of the queries to walk again (buckets scanned by their last walk: <= 2, 3-4, 5-7, more) and
+// where the k-th member of class c sits: classes 0 / 1 fill dlist from its two ends, classes 2 / 3 hlist (a pair's
+// lists hold ns_cap entries and the classes together at most ns, so the ends never meet)
+__device__ __forceinline__ int nabo_class(uint32_t buckets) { return buckets <= 2u ? 0 : (buckets <= 4u ? 1 : (buckets <= 7u ? 2 : 3)); }
+__device__ __forceinline__ int32_t* nabo_list_slot(const IcpDev& b, size_t so, int c, uint32_t k) {
+  int32_t* base = (c < 2 ? b.dlist : b.hlist) + so;
+  return (c & 1) ? base + (b.ns_cap - 1) - k : base + k;
+}
+
 // Certificate pass (iterations >= 1): no search, five memory operations per query.
 // ITEMS = rounds of 256 queries per workgroup: kBallItems in batches, 1 where that would leave too few workgroups (one pair)
 // NABO = true: the records are traversal certificates of the libnabo walk (nabo_kernels.hip): how far the query may move
@@ -906,9 +918,12 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
       const float Lp = bound_now(l, pot_at(pot, norm3(s.x, s.y, s.z)));
       fail = true;
       if (NABO) {
-        // the walk compares floats derived from the ROUNDED position: its motion is the true one plus two roundings of q
+        // what is left of the recorded slack: the record (slack + potential then) less the potential now, less the float
+        // roundings of both sums (the same |s| and the same expression at both times, so nothing else differs), less two
+        // roundings of q itself -- the walk compares floats derived from the ROUNDED position
+        const float Pn = pot_at(pot, norm3(s.x, s.y, s.z));
         if (isfinite(qx) && isfinite(qy) && isfinite(qz) && l > 0.f && j >= 0 &&
-            Lp - 1.3e-7f * (fabsf(qx) + fabsf(qy) + fabsf(qz)) > 0.f) {
+            l - Pn - 4.0e-7f * (l + Pn) - 1.3e-7f * (fabsf(qx) + fabsf(qy) + fabsf(qz)) > 0.f) {
           const float d1 = dist2(t, qx, qy, qz);     // the bucket scan's arithmetic: the bits the walk would produce
           b.d2[so + i] = d1;
           atomicAdd(&s_hist[__float_as_uint(d1) >> kHistShift], 1u);
@@ -933,7 +948,22 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
       }
     }
     const unsigned long long dm = __ballot(fail);
-    if (dm) {
+    if (NABO) {
+      // queries to walk again go to one of four lists by the number of buckets their last walk scanned: a wave of the list
+      // walk executes the union of its lanes' walks, so queries of like cost share waves (nabo_kernels.hip, nabo_class)
+      if (dm) {
+        const int cls = fail ? nabo_class(b.nabo_work[so + min(i, ns - 1)]) : -1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const unsigned long long cm = __ballot(cls == c);
+          if (!cm) continue;                                             // wave-uniform
+          uint32_t basepos = 0;
+          if (lane == 0) basepos = atomicAdd(&st->nabo_count[c], (uint32_t)__popcll(cm));
+          basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);
+          if (cls == c) *nabo_list_slot(b, so, c, basepos + __popcll(cm & ((1ull << lane) - 1ull))) = i;
+        }
+      }
+    } else if (dm) {
       uint32_t basepos = 0;
       if (lane == 0) basepos = atomicAdd(&st->deferred_count, (uint32_t)__popcll(dm));
       basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);   // lane 0 did the atomic
@@ -2228,8 +2258,13 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   st->unresolved_count = 0;
   st->hard_total += st->hard_count;
   st->hard_count = 0;
-  st->searched_total += st->deferred_count ? st->deferred_count : (uint32_t)ns;
-  if (st->iter < kSearchHist) b.search_hist[(size_t)pair * kSearchHist + st->iter] = st->deferred_count ? st->deferred_count : (uint32_t)ns;
+  {
+    const uint32_t walked = st->nabo_count[0] + st->nabo_count[1] + st->nabo_count[2] + st->nabo_count[3];   // SMHIP_NN_NABO's lists
+    const uint32_t searched = walked ? walked : (st->deferred_count ? st->deferred_count : (uint32_t)ns);
+    st->searched_total += searched;
+    if (st->iter < kSearchHist) b.search_hist[(size_t)pair * kSearchHist + st->iter] = searched;
+    for (int c = 0; c < 4; ++c) st->nabo_count[c] = 0;
+  }
   st->deferred_count = 0;
   st->min_lb_key = 0xffffffffu;
   st->refine = 0;

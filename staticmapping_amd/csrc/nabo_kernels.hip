@@ -52,7 +52,10 @@ struct KdDev {
   KdSeg* segs;         // [slots][2][kd_seg_cap]
   float4* alt;         // [slots][nt_cap]       second working order (ping-pong with tq)
   uint32_t* cnt;       // [slots][2 * seg_cap]  left / right fill counters of a level with more segments than LDS holds
-  int32_t node_cap, seg_cap;
+  float* leaf;         // [slots][leaf_cap][24]  the buckets again, as the search scans them: x[8] y[8] z[8] of the bucket that starts at
+                       //                        tq position `first` in block first >> 2 (a bucket of a split cloud holds >= 4 points, so
+                       //                        blocks are unique), unused entries = +inf (their distance is +inf: never a candidate)
+  int32_t node_cap, seg_cap, leaf_cap;
   float max_error2;    // (1 + epsilon)^2
 };
 // rd of a sibling: the squared distance to its half-space box, updated exactly as recurseKnn does (no contraction, so
@@ -344,6 +347,17 @@ __global__ __launch_bounds__(kKdThreads) void kd_build(IcpDev b, KdDev kd) {
     }
   }
   __syncthreads();
+  float* leafs = kd.leaf + (size_t)pair * kd.leaf_cap * 24;
+  for (int v = tid; v < nn; v += kKdThreads) {
+    const uint2 nd = nodes[v];
+    if ((nd.y & 3u) != 3u) continue;
+    const uint32_t f = nd.x, c = nd.y >> 2;
+    float* blk = leafs + (size_t)(f >> 2) * 24;
+    for (uint32_t e = 0; e < (uint32_t)kKdBucket; ++e) {
+      const float4 p = e < c ? tq[f + e] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+      blk[e] = p.x; blk[8 + e] = p.y; blk[16 + e] = p.z;
+    }
+  }
   float4* tn = b.tn + to;
   for (int i = tid; i < n; i += kKdThreads) {
     float4 nr = b.tgt_n[to + __float_as_int(tq[i].w)];
@@ -383,14 +397,25 @@ __device__ __forceinline__ float kd_sqrt_gap(float x, float y) {
 
 // LISTED = false: queries [blk * 256 * ITEMS, ...) of the pair (iteration 0, find_closests, certificates off);
 // LISTED = true: the queries nn_certify<., true> could not certify (dlist), the pair's nblk workgroups striding over the list
-template <int ITEMS, bool LISTED>
+// STACK = pending-sibling slots per query (one per tree level): 12 covers targets of up to 8 << 12 points and leaves
+// the workgroup at 40 KiB of LDS (4 workgroups per CU instead of 3 with the 18 of the general case)
+template <int ITEMS, bool LISTED, int STACK>
 __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nblk) {
   int pair, blk;
   if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
   PairState* st = &b.state[pair];
   if (st->done) return;
   const int ns = st->ns;
-  const int count = LISTED ? (int)st->deferred_count : ns;
+  // LISTED: the four class lists laid end to end, heaviest class first, each padded to whole waves -- a wave's queries all
+  // come from one class (its walk costs the longest of its lanes' walks)
+  int cls_end[4] = {0, 0, 0, 0}, cls_n[4] = {0, 0, 0, 0};
+  int count = ns;
+  if (LISTED) {
+    int acc = 0;
+#pragma unroll
+    for (int c = 3; c >= 0; --c) { cls_n[c] = (int)st->nabo_count[c]; acc += (cls_n[c] + 63) & ~63; cls_end[c] = acc; }
+    count = acc;
+  }
   const int base0 = blk * (kNnThreads * ITEMS);
   if (base0 >= count) return;
   double Mc[12];
@@ -401,10 +426,10 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
   __shared__ uint2 s_top[kKdTopNodes + 1];
   // pending siblings: word A = (node << 2) | cut dimension of its parent, or 0x80000000 | root path for a sibling met
   // while exploring another sibling's subtree; word B = the query's offset from the parent's cut plane (kind A only)
-  __shared__ uint32_t s_stack[kKdStack][kNnThreads];
-  __shared__ float s_off[kKdStack][kNnThreads];
+  __shared__ uint32_t s_stack[STACK][kNnThreads];
+  __shared__ float s_off[STACK][kNnThreads];
   const uint2* __restrict__ nodes = kd.nodes + (size_t)pair * kd.node_cap;
-  const float4* __restrict__ tq = b.tq + (size_t)pair * b.nt_cap;
+  const float4* __restrict__ leafs = reinterpret_cast<const float4*>(kd.leaf + (size_t)pair * kd.leaf_cap * 24);
   const int n_nodes = st->nocc;
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
   for (int k = threadIdx.x; k < min(n_nodes, kKdTopNodes); k += kNnThreads) s_top[k] = nodes[k];
@@ -419,29 +444,52 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
     if (!LISTED && base >= base0 + kNnThreads * ITEMS) break;
     const int e_ = base + t;
     if (e_ >= count) continue;
-    const int i = LISTED ? b.dlist[so + e_] : e_;
+    int i = e_;
+    if (LISTED) {
+      const int c = e_ < cls_end[3] ? 3 : (e_ < cls_end[2] ? 2 : (e_ < cls_end[1] ? 1 : 0));
+      const int k = e_ - (cls_end[c] - ((cls_n[c] + 63) & ~63));
+      if (k >= cls_n[c]) continue;                            // padding of the class's last wave
+      i = *nabo_list_slot(b, so, c, (uint32_t)k);
+    }
     const float4 s4 = ld_src(b, so + i);
     double px, py, pz;
     transform_point(Mc, s4, px, py, pz);
     const float q[3] = {(float)px, (float)py, (float)pz};
     float best = INFINITY, second = INFINITY;                // smallest and second-smallest distance over every scanned entry
     int bestj = -1;
+    uint32_t buckets = 0;                                    // buckets scanned: the cost class of the query's next walk
     float side = INFINITY;                                   // smallest |new_off| over the inner nodes entered
     float prune = INFINITY;                                  // smallest |sqrt(rd E2) - sqrt(best)| over the prune decisions
     if (isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]) && n_nodes > 0) {
-      // a bucket holds at most 8 consecutive points: all eight loads are issued together (one memory latency per bucket
-      // instead of one per entry), entries beyond the bucket's count are masked; entries are tested in bucket order with
-      // a strict "<", as libnabo's leaf loop does
+      // a bucket is scanned from its x[8] y[8] z[8] block: six 16-byte loads issued together (one memory latency per
+      // bucket), two entries per packed-fp32 instruction, no count mask (unused entries are +inf away).  Entries are tested
+      // in bucket order with a strict "<", as libnabo's leaf loop does; each distance is dist2()'s expression, bit for bit
+      // (nn_certify recomputes a certified query's distance with it)
+      float rd_pruned = INFINITY;                             // nearest sibling pruned since the last bucket: best is constant in between,
+      auto fold_pruned = [&]() {                              // so one gap stands for all of them
+        if (rd_pruned < INFINITY) prune = fminf(prune, kd_sqrt_gap(rd_pruned, best));
+        rd_pruned = INFINITY;
+      };
+      const f32x2 qx2 = {q[0], q[0]}, qy2 = {q[1], q[1]}, qz2 = {q[2], q[2]};
       auto scan_leaf = [&](uint2 nd) {
-        const uint32_t f = nd.x, c = nd.y >> 2;
-        float4 p[kKdBucket];
+        const uint32_t f = nd.x;
+        ++buckets;
+        fold_pruned();
+        const float4* blk = leafs + (size_t)(f >> 2) * 6;
+        const float4 xa = blk[0], xb = blk[1], ya = blk[2], yb = blk[3], za = blk[4], zb = blk[5];
+        const f32x2 xs[4] = {{xa.x, xa.y}, {xa.z, xa.w}, {xb.x, xb.y}, {xb.z, xb.w}};
+        const f32x2 ys[4] = {{ya.x, ya.y}, {ya.z, ya.w}, {yb.x, yb.y}, {yb.z, yb.w}};
+        const f32x2 zs[4] = {{za.x, za.y}, {za.z, za.w}, {zb.x, zb.y}, {zb.z, zb.w}};
 #pragma unroll
-        for (int e = 0; e < kKdBucket; ++e) p[e] = tq[f + min((uint32_t)e, c - 1u)];
-#pragma unroll
-        for (int e = 0; e < kKdBucket; ++e) {
-          const float d = (uint32_t)e < c ? dist2(p[e], q[0], q[1], q[2]) : INFINITY;
-          second = __builtin_amdgcn_fmed3f(d, best, second);  // best <= second always: the median of the three is the new runner-up
-          if (d < best) { best = d; bestj = (int)(f + e); }
+        for (int k = 0; k < 4; ++k) {
+          const f32x2 dx = qx2 - xs[k], dy = qy2 - ys[k], dz = qz2 - zs[k];
+          f32x2 d = dx * dx;
+          d = __builtin_elementwise_fma(dy, dy, d);
+          d = __builtin_elementwise_fma(dz, dz, d);
+          second = __builtin_amdgcn_fmed3f(d.x, best, second);   // best <= second always: the median of the three is the new runner-up
+          if (d.x < best) { best = d.x; bestj = (int)(f + 2 * k); }
+          second = __builtin_amdgcn_fmed3f(d.y, best, second);
+          if (d.y < best) { best = d.y; bestj = (int)(f + 2 * k + 1); }
         }
       };
       // (1) descent to the query's own leaf.  On this path no coordinate has an offset yet, so the sibling left behind at a
@@ -456,7 +504,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
         const float no = (cd == 0 ? q[0] : (cd == 1 ? q[1] : q[2])) - __uint_as_float(nd.x);
         const uint32_t right = no > 0.f ? 1u : 0u;
         side = fminf(side, fabsf(no));
-        if (depth < kKdStack) { s_stack[depth][t] = ((uint32_t)depth << 25) | (((nd.y >> 2) + (right ^ 1u)) << 2) | cd; s_off[depth][t] = no; }   // level | node | cd
+        if (depth < STACK) { s_stack[depth][t] = ((uint32_t)depth << 25) | (((nd.y >> 2) + (right ^ 1u)) << 2) | cd; s_off[depth][t] = no; }   // level | node | cd
         else side = -INFINITY;                               // deeper than the stack (the host refuses such targets): never certified
         ++depth;
         path = (path << 1) | right;
@@ -465,15 +513,16 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
       }
       scan_leaf(nd);
       int sp = 0;
-      float rd_cut = INFINITY;                                // the nearest sibling the first bucket's distance prunes
-      for (int l = 0; l < min(depth, kKdStack); ++l) {         // shallow to deep: the write position never passes the read position
+      for (int l = 0; l < min(depth, STACK); ++l) {            // shallow to deep: the write position never passes the read position
         const float no = s_off[l][t];
         const float rdE = kd_rd_step(0.f, 0.f, no) * E2;
         if (rdE < best) { s_stack[sp][t] = s_stack[l][t]; s_off[sp][t] = no; ++sp; }
-        else rd_cut = fminf(rd_cut, rdE);                     // pruned now = pruned at its turn (best only shrinks): one slack for all of them
+        else rd_pruned = fminf(rd_pruned, rdE);               // pruned now = pruned at its turn (best only shrinks)
       }
-      if (rd_cut < INFINITY) prune = fminf(prune, kd_sqrt_gap(rd_cut, best));
       // (2) pending siblings, deepest first; the test is libnabo's, with the best AS OF NOW
+      // The main-path sibling whose subtree is being explored: every nested sibling popped before the next main-path one
+      // lies below it, so its state is re-derived from there (one offset, a handful of steps) instead of from the root.
+      uint32_t a_v = 0, a_cd = 0; float a_no = 0.f; int a_dp = 0;   // node, its parent's cut dimension, the query's offset from that cut, depth
       while (sp > 0) {
         --sp;
         const uint32_t A = s_stack[sp][t];
@@ -484,18 +533,21 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
           const float no = s_off[sp][t];
           const uint32_t cd = A & 3u;
           rd = kd_rd_step(0.f, 0.f, no);
+          if (!(rd * E2 < best)) { rd_pruned = fminf(rd_pruned, rd * E2); continue; }
           prune = fminf(prune, kd_sqrt_gap(rd * E2, best));
-          if (!(rd * E2 < best)) continue;
           if (cd == 0) off[0] = no; else if (cd == 1) off[1] = no; else off[2] = no;
           v = (A >> 2) & 0x7fffffu;
           nd = node_at(v);
           const int lv = (int)(A >> 25);                       // its root path: the main path down to its level, last step flipped
           pp = (path >> (depth - lv - 1)) ^ 1u;
-        } else {                                               // met inside another sibling's subtree: re-derive its state from its root path
+          a_v = v; a_no = no; a_cd = cd; a_dp = lv + 1;
+        } else {                                               // met inside a main-path sibling's subtree: re-derive its state from that sibling
           const uint32_t P = A & 0x7fffffffu;
-          v = 0; nd = node_at(v);
+          v = a_v; nd = node_at(v);
+          rd = kd_rd_step(0.f, 0.f, a_no);
+          if (a_cd == 0) off[0] = a_no; else if (a_cd == 1) off[1] = a_no; else off[2] = a_no;
           const int dp = 31 - __clz((int)P);
-          for (int l = dp - 1; l >= 0; --l) {
+          for (int l = dp - a_dp - 1; l >= 0; --l) {
             const uint32_t cd = nd.y & 3u;
             const float no = (cd == 0 ? q[0] : (cd == 1 ? q[1] : q[2])) - __uint_as_float(nd.x);
             const uint32_t near = no > 0.f ? 1u : 0u, bit = (P >> l) & 1u;
@@ -507,8 +559,8 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
             v = (nd.y >> 2) + bit;
             nd = node_at(v);
           }
+          if (!(rd * E2 < best)) { rd_pruned = fminf(rd_pruned, rd * E2); continue; }
           prune = fminf(prune, kd_sqrt_gap(rd * E2, best));
-          if (!(rd * E2 < best)) continue;
           pp = P;
         }
         // explore that subtree: near children first; its own far siblings are pushed as root paths (pre-filtered with the
@@ -521,10 +573,10 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
           const float oo = cd == 0 ? off[0] : (cd == 1 ? off[1] : off[2]);
           const float rdf = kd_rd_step(rd, oo, no);
           if (rdf * E2 < best) {
-            if (sp < kKdStack) { s_stack[sp][t] = 0x80000000u | (pp << 1) | (right ^ 1u); ++sp; }
+            if (sp < STACK) { s_stack[sp][t] = 0x80000000u | (pp << 1) | (right ^ 1u); ++sp; }
             else side = -INFINITY;
           } else {
-            prune = fminf(prune, kd_sqrt_gap(rdf * E2, best));  // pruned with today's best = pruned at its turn
+            rd_pruned = fminf(rd_pruned, rdf * E2);             // pruned with today's best = pruned at its turn
           }
           pp = (pp << 1) | right;
           v = (nd.y >> 2) + right;
@@ -532,9 +584,11 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
         }
         scan_leaf(nd);
       }
+      fold_pruned();
     }
     b.d2[so + i] = best;
     b.idx[so + i] = bestj;
+    b.nabo_work[so + i] = (uint8_t)min(buckets, 255u);
     // the certificate: how far the query may move before any decision of this walk, or its winner, can change
     float slack = 0.f;
     if (bestj >= 0) {

@@ -57,6 +57,7 @@ struct smhip_context {
   std::vector<float> grid_cell_built;
   std::vector<int> grid_sorted, grid_rows, grid_mode;   // grid_rows: row-occupancy bitmap built too; grid_mode: nn_mode of the structure
   unsigned long long gen_counter = 0;
+  int nabo_listed_blocks = kNaboListedBlocks;   // workgroups per pair of the list walk (SMHIP_NABO_LISTED_BLOCKS overrides, tuning only)
   int target_cache = 1;             // smhip_set_target_cache
   unsigned long long cache_hits = 0;
   PairInput* in_pinned = nullptr;
@@ -205,6 +206,9 @@ smhip_status kd_ensure(smhip_context* h) {
   A(dev_alloc(h, &h->kd.segs, B * 2 * (size_t)h->kd.seg_cap));
   A(dev_alloc(h, &h->kd.alt, B * NT));
   A(dev_alloc(h, &h->kd.cnt, B * 2 * (size_t)h->kd.seg_cap));
+  h->kd.leaf_cap = (int32_t)(NT / 4 + 2);       // block index = bucket start >> 2
+  A(dev_alloc(h, &h->kd.leaf, B * (size_t)h->kd.leaf_cap * 24));
+  A(dev_alloc(h, &h->dev.nabo_work, B * (size_t)h->dev.ns_cap));
   if (s == SMHIP_OK) h->kd_allocated = true;
   return s;
 }
@@ -218,8 +222,7 @@ smhip_status enqueue_grid_build(smhip_context* h, const Half& f, int nt_max) {
   hipLaunchKernelGGL(grid_setup, dim3(ceil_div(np, 64)), dim3(64), 0, f.stream, d, np);
   if (h->opts.nn_mode == SMHIP_NN_NABO) {
     // the reference's own structure: libnabo's kd-tree over the centred target, rebuilt per Align (icp_fast.cc:464-467)
-    smhip_status ks = kd_ensure(h);
-    if (ks) return ks;
+    if (!h->kd_allocated) { h->err = "nn_mode NABO: tree arrays missing (smhip_icp_set_options allocates them)"; return SMHIP_ERR_NOT_READY; }
     // the search keeps one pending sibling per tree level in kKdStack LDS slots per query; a median split halves (rounding
     // up) until a bucket holds <= 8 points, so 8 << kKdStack points is the deepest tree the stack can follow
     if (nt_max > (kKdBucket << kKdStack)) { h->err = "nn_mode NABO: target larger than 8 << 18 points (the search stack holds 18 tree levels)"; return SMHIP_ERR_CAPACITY; }
@@ -294,6 +297,12 @@ smhip_status enqueue_prepare(smhip_context* h, int np, int nt_max) {
 
 smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_max, int iteration);
 
+inline int nt_max_of(const smhip_context* h, int first, int np) {
+  int m = 0;
+  for (int p = first; p < first + np; ++p) m = std::max(m, h->nt[p]);
+  return m;
+}
+
 smhip_status enqueue_find_closests(smhip_context* h, int np, int ns_max) {
   return enqueue_find_closests_half(h, whole_batch(h, np, 0), ns_max, 0);
 }
@@ -311,6 +320,7 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
     const float e = h->opts.nn_epsilon >= 0.f ? h->opts.nn_epsilon : 3.16f;
     kd.max_error2 = (1.0f + e) * (1.0f + e);
     const int nb1 = ceil_div(ns_max, kNnThreads);
+    const bool shallow = nt_max_of(h, d.pair_base, np) <= (kKdBucket << 12);     // 12 stack levels (40 KiB of LDS) cover the target
     if (d.certify && iteration > 0) {
       {
         Bracket br(h, 5, st, np);
@@ -322,15 +332,21 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
         }
       }
       Bracket br(h, 4, st, np);
-      const int nbl = f.small ? nb1 : kNaboListedBlocks;
-      hipLaunchKernelGGL((nn_nabo<1, true>), dim3(nbl * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, kd, nbl);
+      const int nbl = f.small ? nb1 : h->nabo_listed_blocks;
+      const dim3 gl(nbl * 8 * ceil_div(np, 8));
+      if (shallow) hipLaunchKernelGGL((nn_nabo<1, true, 12>), gl, dim3(kNnThreads), 0, st, d, kd, nbl);
+      else hipLaunchKernelGGL((nn_nabo<1, true, kKdStack>), gl, dim3(kNnThreads), 0, st, d, kd, nbl);
     } else {
       Bracket br(h, 4, st, np);
       if (f.small) {
-        hipLaunchKernelGGL((nn_nabo<1, false>), dim3(nb1 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, kd, nb1);
+        const dim3 g1(nb1 * 8 * ceil_div(np, 8));
+        if (shallow) hipLaunchKernelGGL((nn_nabo<1, false, 12>), g1, dim3(kNnThreads), 0, st, d, kd, nb1);
+        else hipLaunchKernelGGL((nn_nabo<1, false, kKdStack>), g1, dim3(kNnThreads), 0, st, d, kd, nb1);
       } else {
         const int nb4 = ceil_div(ns_max, kNnThreads * 4);
-        hipLaunchKernelGGL((nn_nabo<4, false>), dim3(nb4 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, kd, nb4);
+        const dim3 g4(nb4 * 8 * ceil_div(np, 8));
+        if (shallow) hipLaunchKernelGGL((nn_nabo<4, false, 12>), g4, dim3(kNnThreads), 0, st, d, kd, nb4);
+        else hipLaunchKernelGGL((nn_nabo<4, false, kKdStack>), g4, dim3(kNnThreads), 0, st, d, kd, nb4);
       }
     }
   } else if (h->opts.nn_mode == SMHIP_NN_GRID) {
@@ -419,6 +435,7 @@ void sync_options(smhip_context* h) {
   h->dev.exact_all = h->opts.exact_matches;
   h->dev.ball_radius = h->opts.ball_radius > 0 ? h->opts.ball_radius : 0.3f;
   { const char* e = std::getenv("SMHIP_DEBUG_FLAGS"); h->dev.debug_flags = e ? std::atoi(e) : 0; }
+  { const char* e = std::getenv("SMHIP_NABO_LISTED_BLOCKS"); if (e && std::atoi(e) > 0) h->nabo_listed_blocks = std::min(4096, std::atoi(e)); }
 }
 
 // FindClosests output in the caller's order: source i was uploaded from caller index src.w,
@@ -620,6 +637,10 @@ smhip_status smhip_icp_set_options(smhip_handle h, const smhip_icp_options* o) {
   h->opts = *o;
   if (h->opts.check_every < 1) h->opts.check_every = 8;
   sync_options(h);
+  if (o->nn_mode == SMHIP_NN_NABO) {      // the mode's arrays (tree, work classes) are allocated here, never inside Align
+    HIPCHK(h, hipSetDevice(h->device));
+    return kd_ensure(h);
+  }
   return SMHIP_OK;
 }
 

@@ -80,8 +80,10 @@ struct PairState {
   float rcap2;               // squared search-radius cap of nn_ball for the next iteration
   int32_t kept;
   uint32_t limit_key;
+  uint32_t nabo_count[4];    // SMHIP_NN_NABO: queries to walk again this iteration, by the work class of their last walk (nn_certify<., true>)
   int32_t grid_invalid;      // 1 = grid_setup found a non-finite target box: no search structure was built for this target, and
   int32_t pad_;              //     every Align on it fails (pose_setup re-asserts it when the structure is "kept")
+
   // outputs
   double score;
   double result[16];     // column-major (Eigen layout)
@@ -138,6 +140,7 @@ struct IcpDev {
   double* partials;          // [slots][acc_blocks][kAccCols]
   double* tpart;             // [slots][kTgtReduceBlocks][16]
   uint32_t* done_count;      // number of finished pairs
+  uint8_t* nabo_work;        // [slots][ns_cap] SMHIP_NN_NABO: buckets the query's last walk scanned (capped at 255); null until the mode is used
   uint32_t* search_hist;     // [slots][kSearchHist] queries that needed a search in iteration k of the last Align (finalize; read back by the
                              //                 host to place the switch from the fused search to certify + listed search, split_after = 0)
   // options

@@ -31,8 +31,8 @@ constexpr int kKdThreads = 1024;          // one workgroup builds one pair's tre
 constexpr int kKdBucket = 8;              // libnabo's default bucketSize
 constexpr int kKdHistWords = 16384;       // 64 KiB of LDS histograms: segments per pass x 2^bits bins
 constexpr int kKdStack = 18;              // pending siblings per query: at most one per tree level (18 levels: > 1 M target points; node < 2^23)
-constexpr int kNaboListedBlocks = 64;     // workgroups per pair striding over the list of queries to walk again
-constexpr int kKdTopNodes = 1023;         // tree levels 0..9 staged in LDS by the search kernel (8 KiB)
+constexpr int kNaboListedBlocks = 96;     // workgroups per pair striding over the lists of queries to walk again (32: -2 %, 64: -1 %, 128: equal)
+constexpr int kKdTopNodes = 511;          // tree levels 0..8 staged in LDS by the search kernel (4 KiB)
 
 struct KdSeg {                            // one node of the current level while the tree is being built
   uint32_t first, count;                  // its points: positions [first, first + count) of the working order
@@ -397,10 +397,12 @@ __device__ __forceinline__ float kd_sqrt_gap(float x, float y) {
 
 // LISTED = false: queries [blk * 256 * ITEMS, ...) of the pair (iteration 0, find_closests, certificates off);
 // LISTED = true: the queries nn_certify<., true> could not certify (dlist), the pair's nblk workgroups striding over the list
-// STACK = pending-sibling slots per query (one per tree level): 12 covers targets of up to 8 << 12 points and leaves
-// the workgroup at 40 KiB of LDS (4 workgroups per CU instead of 3 with the 18 of the general case)
+// STACK = pending-sibling slots per query (one per tree level): 12 covers targets of up to 8 << 12 points and leaves the
+// workgroup at 20 KiB of LDS and 64 VGPRs (8 waves per SIMD; the 18 of the general case: 26 KiB, 6 workgroups per CU).
+// Measured on 512 x 120 k queries, every query walked in 20 iterations: 3 workgroups per CU (52 KiB: two-word stack entries,
+// 8 KiB histogram) 355 ms, 4 (40 KiB) 264 ms, 6 (24 KiB) 156 ms, 8 (20 KiB, 64 VGPRs, 24 B of scratch) 148 ms.
 template <int ITEMS, bool LISTED, int STACK>
-__global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nblk) {
+__global__ __launch_bounds__(kNnThreads, 8) void nn_nabo(IcpDev b, KdDev kd, int nblk) {
   int pair, blk;
   if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
   PairState* st = &b.state[pair];
@@ -422,16 +424,19 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
 #pragma unroll
   for (int k = 0; k < 12; ++k) Mc[k] = st->M[k];
   const Pot pot = {(float)st->pot_a, (float)st->pot_b, 0.f, 0.f};
-  __shared__ uint32_t s_hist[kHistBins];
+  // The kernel's speed is its occupancy (measured: 3 -> 4 workgroups per CU = 1.34 x faster; a wave's walk is a chain of
+  // dependent lookups), and its occupancy is its LDS: 12 KiB of stack (ONE word per pending sibling), 8 KiB of top tree
+  // levels and a 4 KiB histogram with two 16-bit bins per word (a workgroup adds < 65 536 per bin) = 24 KiB, 6 per CU.
+  __shared__ uint32_t s_hist[kHistBins / 2];
   __shared__ uint2 s_top[kKdTopNodes + 1];
-  // pending siblings: word A = (node << 2) | cut dimension of its parent, or 0x80000000 | root path for a sibling met
-  // while exploring another sibling's subtree; word B = the query's offset from the parent's cut plane (kind A only)
+  // pending siblings: (tree level << 25) | PARENT node for a sibling of the main path -- which child it is, the cut dimension
+  // and the query's offset from the cut plane are re-read from the parent when its turn comes -- or 0x80000000 | root path
+  // for a sibling met while exploring another sibling's subtree
   __shared__ uint32_t s_stack[STACK][kNnThreads];
-  __shared__ float s_off[STACK][kNnThreads];
   const uint2* __restrict__ nodes = kd.nodes + (size_t)pair * kd.node_cap;
   const float4* __restrict__ leafs = reinterpret_cast<const float4*>(kd.leaf + (size_t)pair * kd.leaf_cap * 24);
   const int n_nodes = st->nocc;
-  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+  for (int k = threadIdx.x; k < kHistBins / 2; k += kNnThreads) s_hist[k] = 0;
   for (int k = threadIdx.x; k < min(n_nodes, kKdTopNodes); k += kNnThreads) s_top[k] = nodes[k];
   __syncthreads();
   const float E2 = kd.max_error2;
@@ -504,7 +509,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
         const float no = (cd == 0 ? q[0] : (cd == 1 ? q[1] : q[2])) - __uint_as_float(nd.x);
         const uint32_t right = no > 0.f ? 1u : 0u;
         side = fminf(side, fabsf(no));
-        if (depth < STACK) { s_stack[depth][t] = ((uint32_t)depth << 25) | (((nd.y >> 2) + (right ^ 1u)) << 2) | cd; s_off[depth][t] = no; }   // level | node | cd
+        if (depth < STACK) s_stack[depth][t] = ((uint32_t)depth << 25) | v;   // level | this node: the parent of the sibling left behind
         else side = -INFINITY;                               // deeper than the stack (the host refuses such targets): never certified
         ++depth;
         path = (path << 1) | right;
@@ -514,9 +519,12 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
       scan_leaf(nd);
       int sp = 0;
       for (int l = 0; l < min(depth, STACK); ++l) {            // shallow to deep: the write position never passes the read position
-        const float no = s_off[l][t];
+        const uint32_t A = s_stack[l][t];
+        const uint2 pn = node_at(A & 0x1ffffffu);
+        const uint32_t cd = pn.y & 3u;
+        const float no = (cd == 0 ? q[0] : (cd == 1 ? q[1] : q[2])) - __uint_as_float(pn.x);   // the descent's own expression: the same float
         const float rdE = kd_rd_step(0.f, 0.f, no) * E2;
-        if (rdE < best) { s_stack[sp][t] = s_stack[l][t]; s_off[sp][t] = no; ++sp; }
+        if (rdE < best) { s_stack[sp][t] = A; ++sp; }
         else rd_pruned = fminf(rd_pruned, rdE);               // pruned now = pruned at its turn (best only shrinks)
       }
       // (2) pending siblings, deepest first; the test is libnabo's, with the best AS OF NOW
@@ -530,13 +538,14 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
         float rd = 0.f;
         uint32_t pp;                                           // root path of the node being explored (for nested siblings)
         if (!(A & 0x80000000u)) {                              // a sibling of the main path: its state is one offset
-          const float no = s_off[sp][t];
-          const uint32_t cd = A & 3u;
+          const uint2 pn = node_at(A & 0x1ffffffu);
+          const uint32_t cd = pn.y & 3u;
+          const float no = (cd == 0 ? q[0] : (cd == 1 ? q[1] : q[2])) - __uint_as_float(pn.x);
           rd = kd_rd_step(0.f, 0.f, no);
           if (!(rd * E2 < best)) { rd_pruned = fminf(rd_pruned, rd * E2); continue; }
           prune = fminf(prune, kd_sqrt_gap(rd * E2, best));
           if (cd == 0) off[0] = no; else if (cd == 1) off[1] = no; else off[2] = no;
-          v = (A >> 2) & 0x7fffffu;
+          v = (pn.y >> 2) + (no > 0.f ? 0u : 1u);               // the child the descent did not take
           nd = node_at(v);
           const int lv = (int)(A >> 25);                       // its root path: the main path down to its level, last step flipped
           pp = (path >> (depth - lv - 1)) ^ 1u;
@@ -599,13 +608,14 @@ __global__ __launch_bounds__(kNnThreads) void nn_nabo(IcpDev b, KdDev kd, int nb
     }
     st_lb(b, so + i, with_pot(slack, pot_at(pot, norm3(s4.x, s4.y, s4.z))));
     const uint32_t key = __float_as_uint(best);
-    if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
+    if (key < 0x7f800000u) atomicAdd(&s_hist[key >> (kHistShift + 1)], 1u << (((key >> kHistShift) & 1u) << 4));
   }
   __syncthreads();
   uint32_t* gh = b.hist + (size_t)pair * kHistBins;
-  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
+  for (int k = threadIdx.x; k < kHistBins / 2; k += kNnThreads) {
     const uint32_t v = s_hist[k];
-    if (v) atomicAdd(&gh[k], v);
+    if (v & 0xffffu) atomicAdd(&gh[2 * k], v & 0xffffu);
+    if (v >> 16) atomicAdd(&gh[2 * k + 1], v >> 16);
   }
 }
 

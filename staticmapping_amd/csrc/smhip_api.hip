@@ -435,7 +435,7 @@ void sync_options(smhip_context* h) {
   h->dev.exact_all = h->opts.exact_matches;
   h->dev.ball_radius = h->opts.ball_radius > 0 ? h->opts.ball_radius : 0.3f;
   { const char* e = std::getenv("SMHIP_DEBUG_FLAGS"); h->dev.debug_flags = e ? std::atoi(e) : 0; }
-  { const char* e = std::getenv("SMHIP_NABO_LISTED_BLOCKS"); if (e && std::atoi(e) > 0) h->nabo_listed_blocks = std::min(4096, std::atoi(e)); }
+  { const char* e = std::getenv("SMHIP_NABO_LISTED_BLOCKS"); if (e && std::atoi(e) > 0) h->nabo_listed_blocks = std::max(8, std::min(4096, std::atoi(e))); }   // >= 8: a workgroup's 16-bit histogram bins
 }
 
 // FindClosests output in the caller's order: source i was uploaded from caller index src.w,

@@ -52,12 +52,6 @@ def algorithmic_bytes_per_alignment(ns: int, nt: int, iters: float = ICP_ITERS, 
     return 24.0 * nt + iters * ns * (12.0 + 8.0 + 24.0 * rho)
 
 
-def nn_bytes_per_launch(pairs: int, ns: int) -> float:
-    """Dominant kernel (FindClosests, one launch = one iteration of every pair in the batch):
-    12 B source xyz read + 8 B (id, d2) written per source point -- DESIGN.md §4."""
-    return pairs * ns * 20.0
-
-
 def build_workload(n_distinct: int, n_points: int, device):
     """`n_distinct` consecutive scan pairs (i, i + 1) of the synthetic drive; scan i prepared as pair i's target by
     the caller-side CalculateNormals (builder/map_builder.cc:286,389)."""
@@ -176,7 +170,7 @@ def main():
             step()
         sync_all()
         if profile_nn:
-            m.enable_profile(2)      # HIP events around the dominant NN kernel only, on the stream each launch goes to
+            m.enable_profile(2)      # HIP events around the FindClosests / ErrorElements launches, on the stream each launch goes to
         t0 = time.perf_counter()
         for _ in range(steps):
             gathered = step()
@@ -237,10 +231,10 @@ def main():
                                    max_iteration=ICP_ITERS, early_exit=False)
             # the reference's own search semantics: libnabo's tree + epsilon = 3.16 approximate knn on the device (nn_mode NABO)
             m.set_options(nn_mode=sm.NN_NABO, nn_epsilon=3.16)
-            nb = timed_run("guess_cv", 2, 1)
+            nb = timed_run("guess_cv", fs, fw)
             m.set_options(nn_mode=1 if args.nn_mode == "grid" else 0)
             n_rot, n_t, n_med = truth_errors(nb["T"])
-            figures["reference_search_eps3.16"] = dict(value=round(nb["value"], 2), iterations=ICP_ITERS, searched_queries_per_alignment=float(ICP_ITERS * ns),
+            figures["reference_search_eps3.16"] = dict(value=round(nb["value"], 2), iterations=ICP_ITERS, searched_queries_per_alignment=searched(nb["stats"]),
                                                        worst_trans_err_vs_truth_m=n_t, median_trans_err_vs_truth_m=n_med, T=nb["T"], guess_key="guess_cv",
                                                        max_iteration=ICP_ITERS, early_exit=False, nn_eps=3.16)
             figures["early_exit"] = dict(value=round(ee["value"], 2), iterations=float(ee["it"].mean()), iterations_max=int(ee["it"].max()),
@@ -267,36 +261,68 @@ def main():
         alone = m.get_profile()
         m.enable_profile(False)
         m.set_options(no_overlap=0)
-        # ---- roofline of the dominant kernel from the events of the TIMED region.  FindClosests runs as two kernels: the
-        # fused search nn_ball_lds in the first iterations and the certificate pass nn_certify (+ a short listed search) in
-        # the rest; both are timed (HIP events on the stream each launch goes to) and the one the timed region spent more
-        # time in is the line's kernel.  Either does one iteration's FindClosests for every pair of its launch: the same
-        # 20 algorithmic bytes per source point.
-        def kernel_figures(p, key):
-            launches = max(1, p[f"launches_{key}"])
-            ms = p[f"ms_{key}"] / launches
-            pairs = int(round(p[f"pairs_{key}"] / launches))
-            by = nn_bytes_per_launch(pairs, ns)
-            return dict(total_ms=p[f"ms_{key}"], launches=p[f"launches_{key}"], avg_launch_ms=ms, pairs_per_launch=pairs,
-                        bytes_per_launch=by, achieved=by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0)
-        kf = {"nn_ball_lds" if args.nn_mode == "grid" else "nn_brute": kernel_figures(nn_prof, "nn_main")}
-        if nn_prof["launches_nn_certify"] > 0:
-            kf["nn_certify"] = kernel_figures(nn_prof, "nn_certify")
+        # ---- roofline from the events of the TIMED region (HIP events on the stream each launch goes to).  An iteration's
+        # FindClosests runs either as the fused search nn_ball_lds (+ the three refinement launches validate / ring / fallback)
+        # or as the certificate pass nn_certify + the listed search nn_ball_listed (+ the same refinement launches); then
+        # accumulate (ErrorElements + ComputePointToPlane) and finalize.  Every kernel is priced with the ALGORITHMIC bytes of
+        # the reference function it implements: FindClosests 12 B read + 8 B written = 20 B per source point,
+        # ErrorElements/ComputePointToPlane 24 B gathered per kept point = 24 rho B per source point -- and the line's kernel is
+        # the one the timed region spent the most time in, whichever it is.
+        def kernel_figures(p, ms, launches, pairs_sum, bytes_per_point):
+            n_l = max(1, launches)
+            avg_ms = ms / n_l
+            pairs = int(round(pairs_sum / n_l))
+            by = pairs * ns * bytes_per_point
+            return dict(total_ms=ms, launches=launches, avg_launch_ms=avg_ms, pairs_per_launch=pairs, bytes_per_point=bytes_per_point,
+                        bytes_per_launch=by, achieved=by / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0)
+
+        def all_kernels(p):
+            kf = {}
+            main_name = "nn_ball_lds" if args.nn_mode == "grid" else "nn_brute"
+            if p["launches_nn_main"] > 0:
+                kf[main_name] = kernel_figures(p, p["ms_nn_main"], p["launches_nn_main"], p["pairs_nn_main"], 20.0)
+            if p["launches_nn_certify"] > 0:
+                kf["nn_certify"] = kernel_figures(p, p["ms_nn_certify"], p["launches_nn_certify"], p["pairs_nn_certify"], 20.0)
+            if p["launches_nn_listed"] > 0:
+                kf["nn_ball_listed"] = kernel_figures(p, p["ms_nn_listed"], p["launches_nn_listed"], p["pairs_nn_listed"], 20.0)
+            if p["launches_error_elements"] > 0:
+                kf["accumulate"] = kernel_figures(p, p["ms_error_elements"], p["launches_error_elements"], p["pairs_error_elements"], 24.0 * RHO)
+            # FindClosests of one iteration as a whole: every launch that belongs to it, 20 B per source point once
+            it_fused, it_split = p["launches_nn_main"], p["launches_nn_certify"]
+            refine_per_it = p["ms_nn_refine"] / max(1, it_fused + it_split)
+            fc = {}
+            if it_split > 0:
+                ms = (p["ms_nn_certify"] + p["ms_nn_listed"]) / it_split + refine_per_it
+                pairs = kf["nn_certify"]["pairs_per_launch"]
+                fc["certify_listed_refine"] = dict(iterations_timed=it_split, ms_per_iteration_launch=ms, pairs_per_launch=pairs,
+                                                   achieved=pairs * ns * 20.0 / (ms * 1e-3) / 1e9)
+            if it_fused > 0:
+                ms = p["ms_nn_main"] / it_fused + refine_per_it
+                pairs = kf[main_name]["pairs_per_launch"]
+                fc["fused_refine"] = dict(iterations_timed=it_fused, ms_per_iteration_launch=ms, pairs_per_launch=pairs,
+                                          achieved=pairs * ns * 20.0 / (ms * 1e-3) / 1e9)
+            return kf, fc
+        kf, fc = all_kernels(nn_prof)
         dom = max(kf, key=lambda k: kf[k]["total_ms"])
-        dom_key = "nn_certify" if dom == "nn_certify" else "nn_main"
         nn_ms, pairs_per_launch, nn_bytes, achieved = (kf[dom][k] for k in ("avg_launch_ms", "pairs_per_launch", "bytes_per_launch", "achieved"))
-        alone_f = kernel_figures(alone, dom_key)
+        kf_alone, _ = all_kernels(alone)
+        alone_f = kf_alone.get(dom, dict(avg_launch_ms=0.0, pairs_per_launch=0, achieved=0.0))
         alone_ms, alone_pairs, alone_gbs = alone_f["avg_launch_ms"], alone_f["pairs_per_launch"], alone_f["achieved"]
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "traffic_nn_main.json" if dom_key == "nn_main" else "traffic_nn_certify.json")
-        if os.path.exists(tj):
+
+        def traffic_of(kernel, pairs):
+            """HBM bytes per launch from the committed counter passes (profiles/traffic_<kernel>.json: FETCH_SIZE / WRITE_SIZE passes
+            of the same batch, corrected with the factors calibrated on known-byte kernels of the same access shape)."""
+            tj = os.path.join(ROOT, "profiles", f"traffic_{kernel}.json")
+            if not os.path.exists(tj):
+                return None
             try:
                 tdat = json.load(open(tj))
                 if tdat.get("nn_mode") == args.nn_mode and tdat.get("source_points") in (None, ns):
-                    # counters are per launch of `pairs_per_launch` pairs; traffic is per point, so it scales with the pairs
-                    traffic = int(tdat["hbm_bytes_per_launch"] * pairs_per_launch / tdat["pairs_per_launch"])
+                    return int(tdat["hbm_bytes_per_launch"] * pairs / tdat["pairs_per_launch"])   # per point, so it scales with the pairs
             except Exception:
-                traffic = None
+                pass
+            return None
+        traffic = traffic_of(dom, pairs_per_launch)
         alg_bytes = algorithmic_bytes_per_alignment(ns, nt_mean)
         out = {
             "metric": "scan-pair alignments/sec (120k-pt KITTI-64, 20 ICP iters)",
@@ -315,12 +341,22 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "bytes_per_launch": nn_bytes, "pairs_per_launch": pairs_per_launch, "avg_launch_ms": round(nn_ms, 4),
-                         "launches_timed": kf[dom]["launches"],
+                         "bytes_per_launch": nn_bytes, "bytes_per_point": kf[dom]["bytes_per_point"], "pairs_per_launch": pairs_per_launch,
+                         "avg_launch_ms": round(nn_ms, 4), "launches_timed": kf[dom]["launches"],
                          "timed_region_ms_by_kernel": {k: round(v["total_ms"], 3) for k, v in kf.items()},
-                         "other_kernels": {k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "pairs_per_launch": v["pairs_per_launch"],
-                                               "launches_timed": v["launches"], "achieved": round(v["achieved"], 2),
-                                               "frac": round(v["achieved"] / HBM_PEAK_GBS, 5)} for k, v in kf.items() if k != dom},
+                         "kernels": {k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "pairs_per_launch": v["pairs_per_launch"],
+                                         "launches_timed": v["launches"], "algorithmic_bytes_per_point": v["bytes_per_point"],
+                                         "algorithmic_bytes_per_launch": v["bytes_per_launch"], "achieved": round(v["achieved"], 2),
+                                         "frac": round(v["achieved"] / HBM_PEAK_GBS, 5), "traffic": traffic_of(k, v["pairs_per_launch"])}
+                                     for k, v in kf.items()},
+                         "find_closests_per_iteration": {k: {"iterations_timed": v["iterations_timed"], "ms_per_iteration_launch": round(v["ms_per_iteration_launch"], 4),
+                                                             "pairs_per_launch": v["pairs_per_launch"], "algorithmic_bytes_per_point": 20.0,
+                                                             "achieved": round(v["achieved"], 2), "frac": round(v["achieved"] / HBM_PEAK_GBS, 5)}
+                                                         for k, v in fc.items()},
+                         "refinement_launches_ms_timed": round(nn_prof["ms_nn_refine"], 3),
+                         "note": "kernels.*: each kernel alone, priced with the algorithmic bytes of the reference function it implements (nn_certify and "
+                                 "nn_ball_listed each carry the full 20 B/pt of FindClosests, so read find_closests_per_iteration for the function as a "
+                                 "whole: certificate pass + listed search + validate / ring / fallback launches of one iteration, 20 B/pt once)",
                          "alone": {"note": "same kernel on one stream, not sharing the GPU with the other half-batch",
                                    "pairs_per_launch": alone_pairs, "avg_launch_ms": round(alone_ms, 4),
                                    "achieved": round(alone_gbs, 2), "frac": round(alone_gbs / HBM_PEAK_GBS, 5)},
@@ -338,6 +374,10 @@ def main():
                 out["cpu_baseline"] = cpu
         out["figures"] = {k: {kk: vv for kk, vv in f.items() if kk not in ("T", "guess_key", "max_iteration", "early_exit", "nn_eps")}
                           for k, f in figures.items()}
+        for k, f in out["figures"].items():      # the same whole-alignment roofline for every figure (its own iteration count)
+            by = algorithmic_bytes_per_alignment(ns, nt_mean, iters=float(f["iterations"]))
+            f["whole_alignment_roofline"] = {"algorithmic_bytes": by, "achieved_GBs": round(by * f["value"] / world / 1e9, 2),
+                                             "frac": round(by * f["value"] / world / 1e9 / HBM_PEAK_GBS, 5)}
         if "reference_search_eps3.16" in out["figures"]:
             out["figures"]["reference_search_eps3.16"]["note"] = (
                 "nn_mode NABO: libnabo 1.0.7's KDTREE_LINEAR_HEAP tree rebuilt per Align and its epsilon = 3.16 approximate knn "
@@ -408,14 +448,33 @@ def cpu_baseline_and_parity(work, figures, head, head_key, n_cpu, world):
     for d in sub:
         oracle_pose(work[d], work[d][head_key], ICP_ITERS, False, nthreads=cores)
     t_all = time.perf_counter() - t
-    cpu = {"value": round(n_cpu / t_used, 3), "unit": "alignments/s", "cores": 1, "kind": "port",
-           "sample": f"{n_cpu} distinct 120k-pt pairs of the timed batch, one 20-iteration alignment each, C restatement "
-                     f"oracle/csrc/smref_icp.c (exact kd-tree 1-NN, gcc -O2), 1 thread as icp_fast.cc is written",
-           "block_seconds_per_alignment": {k: round(v / n_cpu, 5) for k, v in blocks.items()},
-           "all_cores": {"value": round(len(sub) / t_all, 3), "cores": cores,
+    # the baseline proper: the reference's own search, libnabo's epsilon = 3.16 approximate knn (icp_fast.cc:174), which is what
+    # its CPU path runs and the faster of the two on a CPU; the exact kd-tree figures above stay as a sub-field
+    n_eps = min(D, 32)
+    t = time.perf_counter()
+    eps_blocks = {}
+    for d in range(n_eps):
+        ref = oracle_pose(work[d], work[d][head_key], ICP_ITERS, False, nn_eps=3.16)
+        for k, v in ref["block_times"].items():
+            eps_blocks[k] = eps_blocks.get(k, 0.0) + v
+    t_eps = time.perf_counter() - t
+    t = time.perf_counter()
+    for d in sub:
+        oracle_pose(work[d], work[d][head_key], ICP_ITERS, False, nthreads=cores, nn_eps=3.16)
+    t_eps_all = time.perf_counter() - t
+    cpu = {"value": round(n_eps / t_eps, 3), "unit": "alignments/s", "cores": 1, "kind": "port",
+           "sample": f"{n_eps} distinct 120k-pt pairs of the timed batch, one 20-iteration alignment each, C restatement "
+                     f"oracle/csrc/smref_icp.c with the reference's search (libnabo tree rebuilt per Align + epsilon = 3.16 knn restated, "
+                     f"icp_fast.cc:169-180, 464-467; gcc -O2), 1 thread as icp_fast.cc is written",
+           "block_seconds_per_alignment": {k: round(v / n_eps, 5) for k, v in eps_blocks.items()},
+           "all_cores": {"value": round(len(sub) / t_eps_all, 3), "cores": cores,
                          "note": "same code, ApplyTransform / FindClosests / normal equations under OpenMP on every usable host "
                                  "core (affinity mask, cgroup quota and physical cores respected); libnabo's knn is OpenMP-parallel "
-                                 "by default, so this is the reference's likely deployment"}}
+                                 "by default, so this is the reference's likely deployment"},
+           "exact_search": {"value": round(n_cpu / t_used, 3), "cores": 1,
+                            "sample": f"{n_cpu} pairs, the same code with an exact kd-tree 1-NN (the oracle of the headline's parity check)",
+                            "block_seconds_per_alignment": {k: round(v / n_cpu, 5) for k, v in blocks.items()},
+                            "all_cores": {"value": round(len(sub) / t_all, 3), "cores": cores}}}
     return cpu, par
 
 

@@ -125,6 +125,13 @@ typedef struct smhip_icp_profile {
   int32_t launches_nn_certify;
   int32_t split_after_used;     /* iteration from which the last batched enqueue ran certificate pass + listed search (filled with or
                                    without profiling; 0 = the last enqueue was not a batch of >= 16 pairs) */
+  double ms_nn_listed;          /* the search of the queries whose certificate failed (nn_ball_listed; SMHIP_NN_NABO: the list walk) */
+  double pairs_nn_listed;
+  double ms_nn_refine;          /* the refinement launches of an iteration (nn_validate + nn_ring + nn_fallback), near-empty when the
+                                   quantile stays below every recorded lower bound */
+  double pairs_error_elements;  /* pairs the accumulate launches covered, summed */
+  int32_t launches_nn_listed;
+  int32_t launches_nn_refine;
 } smhip_icp_profile;
 
 /* ---- library / device ------------------------------------------------- */
@@ -367,8 +374,8 @@ smhip_status smhip_filter_get_output(smhip_handle h, float* points5, int32_t* so
 smhip_status smhip_filter_output_to_source(smhip_handle h, int slot);
 
 /* ---- profiling ----------------------------------------------------------- */
-/* enable: 0 off, 1 events around every launch, 2 events around the dominant NN kernel only (cheap enough to
- * leave on inside a timed region) */
+/* enable: 0 off, 1 events around every launch, 2 events around the FindClosests and ErrorElements launches of the iterations
+ * (everything but the per-Align preparation and the solve kernel; cheap enough to leave on inside a timed region) */
 smhip_status smhip_icp_enable_profile(smhip_handle h, int enable);
 smhip_status smhip_icp_get_profile(smhip_handle h, smhip_icp_profile* out);
 /* queries that went through a search (exact modes: certificate failed; NABO: walked again) in iterations 0..11 of the

@@ -28,6 +28,25 @@ inline int ReadBin(const std::string& path, float* rows) {               // kitt
   return static_cast<int>(got / 4);
 }
 
+// The files rank `rank` of `world` reads, in reading order, when the pairs (scan i, scan i + 1) go round-robin over the ranks
+// (pair i -> rank i mod world) in batches of `batch` pairs per rank: a pair's target scan is read only when the previous slot
+// of the batch did not already hold it as its source (one rank: every pair but the first of a batch).
+inline std::vector<int> ShardReadOrder(int n_pairs, int world, int rank, int batch) {
+  std::vector<int> order;
+  const int per = (n_pairs + world - 1) / world;
+  for (int base = 0; base < per; base += batch) {
+    int prev_pair = -2;
+    for (int k = 0; k < batch && base + k < per; ++k) {
+      const int pair = (base + k) * world + rank;
+      if (pair >= n_pairs) break;
+      if (pair != prev_pair + 1) order.push_back(pair);
+      order.push_back(pair + 1);
+      prev_pair = pair;
+    }
+  }
+  return order;
+}
+
 // The scans a consumer will ask for, in the order it will ask for them, read ahead by a few threads into a ring of buffers.
 // (The alignment of a batch takes the GPU a few milliseconds; reading and staging its 64 scans took one host thread 35 ms.)
 class ScanPrefetcher {

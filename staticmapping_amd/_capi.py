@@ -35,7 +35,9 @@ class IcpProfile(ctypes.Structure):
                 ("launches_solve", ctypes.c_int32), ("launches_nn_main", ctypes.c_int32),
                 ("ms_nn_main", ctypes.c_double), ("pairs_nn_main", ctypes.c_double),
                 ("ms_nn_certify", ctypes.c_double), ("pairs_nn_certify", ctypes.c_double),
-                ("launches_nn_certify", ctypes.c_int32), ("split_after_used", ctypes.c_int32)]
+                ("launches_nn_certify", ctypes.c_int32), ("split_after_used", ctypes.c_int32),
+                ("ms_nn_listed", ctypes.c_double), ("pairs_nn_listed", ctypes.c_double), ("ms_nn_refine", ctypes.c_double),
+                ("pairs_error_elements", ctypes.c_double), ("launches_nn_listed", ctypes.c_int32), ("launches_nn_refine", ctypes.c_int32)]
 
 
 class NdtOptions(ctypes.Structure):

@@ -187,17 +187,7 @@ int RunRank(const Args& a, int rank, int world, int device) {
   for (int k = 0; k < B; ++k) { double* g = &guesses[16 * static_cast<size_t>(k)]; g[0] = g[5] = g[10] = g[15] = 1.0; g[12] = a.guess_tx; }
 
   // the files this rank reads, in reading order (the same walk as the loop below)
-  std::vector<int> order;
-  for (int base = 0; base < per; base += B) {
-    int prev_pair = -2;
-    for (int k = 0; k < B && base + k < per; ++k) {
-      const int pair = (base + k) * world + rank;
-      if (pair >= n_pairs) break;
-      if (pair != prev_pair + 1) order.push_back(pair);
-      order.push_back(pair + 1);
-      prev_pair = pair;
-    }
-  }
+  const std::vector<int> order = smhip::kitti::ShardReadOrder(n_pairs, world, rank, B);
   ScanPrefetcher scans(files, order, a.readers, 4 * std::max(1, a.readers) + 8);
   auto next_scan = [&](int expect, int* n) -> const float* {
     int fi = -1;

@@ -111,13 +111,14 @@ smhip_status dev_alloc(smhip_context* h, T** p, size_t count) {
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-// profiling brackets: category 0 prepare, 1 find_closests, 2 error_elements, 3 solve
+// profiling brackets: category 0 prepare, 1 the refinement launches of FindClosests (validate / ring / fallback), 2 error_elements,
+// 3 solve, 4 the main NN kernel (fused search, or the full libnabo walk), 5 the certificate pass, 6 the listed search / list walk
 struct Bracket {
   smhip_context* h;
   smhip_context::Ev* ev = nullptr;
   hipStream_t st;
   Bracket(smhip_context* h_, int cat, hipStream_t st_, int np = 0) : h(h_), st(st_) {
-    if (!h->profile || (h->profile == 2 && cat != 4 && cat != 5)) return;
+    if (!h->profile || (h->profile == 2 && (cat == 0 || cat == 3))) return;
     if (h->ev_used == h->ev_pool.size()) {
       smhip_context::Ev e{};
       if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
@@ -140,12 +141,14 @@ void collect_profile(smhip_context* h) {
     if (hipEventElapsedTime(&ms, h->ev_pool[k].a, h->ev_pool[k].b) != hipSuccess) continue;
     switch (h->ev_pool[k].cat) {
       case 0: h->prof.ms_prepare += ms; break;
-      case 1: h->prof.ms_find_closests += ms; h->prof.launches_find_closests++; break;
+      case 1: h->prof.ms_find_closests += ms; h->prof.launches_find_closests++; h->prof.ms_nn_refine += ms; h->prof.launches_nn_refine++; break;
+      case 6: h->prof.ms_find_closests += ms; h->prof.launches_find_closests++;
+              h->prof.ms_nn_listed += ms; h->prof.launches_nn_listed++; h->prof.pairs_nn_listed += h->ev_pool[k].np; break;
       case 4: h->prof.ms_find_closests += ms; h->prof.launches_find_closests++;
               h->prof.ms_nn_main += ms; h->prof.launches_nn_main++; h->prof.pairs_nn_main += h->ev_pool[k].np; break;
       case 5: h->prof.ms_find_closests += ms; h->prof.launches_find_closests++;
               h->prof.ms_nn_certify += ms; h->prof.launches_nn_certify++; h->prof.pairs_nn_certify += h->ev_pool[k].np; break;
-      case 2: h->prof.ms_error_elements += ms; h->prof.launches_error_elements++; break;
+      case 2: h->prof.ms_error_elements += ms; h->prof.launches_error_elements++; h->prof.pairs_error_elements += h->ev_pool[k].np; break;
       case 3: h->prof.ms_solve += ms; h->prof.launches_solve++; break;
     }
   }
@@ -331,7 +334,7 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
           hipLaunchKernelGGL((nn_certify<kCertifyItems, true>), dim3(nbc * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nbc);
         }
       }
-      Bracket br(h, 4, st, np);
+      Bracket br(h, 6, st, np);
       const int nbl = f.small ? nb1 : h->nabo_listed_blocks;
       const dim3 gl(nbl * 8 * ceil_div(np, 8));
       if (shallow) hipLaunchKernelGGL((nn_nabo<1, true, 12>), gl, dim3(kNnThreads), 0, st, d, kd, nbl);
@@ -381,7 +384,7 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
             hipLaunchKernelGGL(nn_certify<kCertifyItems>, dim3(nbc * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nbc);
           }
         }
-        { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_ball_listed, glist, dim3(kNnThreads), 0, st, d, kListedBlocks); }
+        { Bracket br(h, 6, st, np); hipLaunchKernelGGL(nn_ball_listed, glist, dim3(kNnThreads), 0, st, d, kListedBlocks); }
       } else {
         Bracket br(h, 4, st, np);
         hipLaunchKernelGGL(nn_ball, gx, dim3(kNnThreads), 0, st, d, nblk);
@@ -1000,7 +1003,7 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
       s = enqueue_find_closests_half(h, f, ns_max, it);
       if (s) return s;
       {
-        Bracket br(h, 2, f.stream);
+        Bracket br(h, 2, f.stream, f.np);
         const int nblk = ceil_div(ns_max, kAccThreads * f.d.acc_items);
         if (f.d.acc_items == kAccItemsBatch) hipLaunchKernelGGL(accumulate<kAccItemsBatch>, dim3(nblk * 8 * ceil_div(f.np, 8)), dim3(kAccThreads), 0, f.stream, f.d, nblk);
         else hipLaunchKernelGGL(accumulate<kAccItemsSmall>, dim3(nblk * 8 * ceil_div(f.np, 8)), dim3(kAccThreads), 0, f.stream, f.d, nblk);

@@ -1,0 +1,61 @@
+// traffic_calib.hip -- known-byte streaming kernels in the access shapes of the ICP iteration kernels, for calibrating
+// rocprofv3's FETCH_SIZE / WRITE_SIZE on this GPU (MI355X_MICROARCH.md, HBM section: FETCH_SIZE reports half the bytes of a
+// 16 B/lane streaming read; other widths and WRITE_SIZE are uncalibrated).  Not part of the product: built and run by
+// tools/traffic_calib.sh on the GPU box.
+//   calib_certify     per element: 12-byte row (global_load_dwordx3) + int + float read, one float written  -- nn_certify's shape
+//   calib_accumulate  per element: 12-byte row + int + float read, nothing written                          -- accumulate's stream
+//   calib_x4          per element: one 16-byte row read, one 16-byte row written                            -- the guide's own case
+// Arrays are 256 x 120 000 elements (a 256-pair launch) and far larger than the 256 MiB Infinity Cache taken together.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(e_)); std::exit(1); } } while (0)
+
+__global__ __launch_bounds__(256) void calib_certify(const float* __restrict__ src3, const int* __restrict__ idx, const float* __restrict__ lb,
+                                                     float* __restrict__ d2, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float3 v = *reinterpret_cast<const float3*>(src3 + 3 * i);
+    d2[i] = v.x + v.y + v.z + (float)idx[i] + lb[i];
+  }
+}
+__global__ __launch_bounds__(256) void calib_accumulate(const float* __restrict__ src3, const int* __restrict__ idx, const float* __restrict__ d2in,
+                                                        float* __restrict__ out, size_t n) {
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float3 v = *reinterpret_cast<const float3*>(src3 + 3 * i);
+    acc += v.x + v.y + v.z + (float)idx[i] + d2in[i];
+  }
+  if (acc == 12345.678f) out[0] = acc;      // never true: keeps the loads alive without a store
+}
+__global__ __launch_bounds__(256) void calib_x4(const float4* __restrict__ in, float4* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float4 v = in[i];
+    v.x += 1.f;
+    out[i] = v;
+  }
+}
+
+int main() {
+  const size_t n = (size_t)256 * 120000;
+  float *src3, *lb, *d2, *out;
+  int* idx;
+  float4 *a4, *b4;
+  CK(hipMalloc(&src3, n * 12)); CK(hipMalloc(&idx, n * 4)); CK(hipMalloc(&lb, n * 4)); CK(hipMalloc(&d2, n * 4)); CK(hipMalloc(&out, 256));
+  CK(hipMalloc(&a4, n * 16)); CK(hipMalloc(&b4, n * 16));
+  CK(hipMemset(src3, 0, n * 12)); CK(hipMemset(idx, 0, n * 4)); CK(hipMemset(lb, 0, n * 4)); CK(hipMemset(d2, 0, n * 4));
+  CK(hipMemset(a4, 0, n * 16)); CK(hipMemset(b4, 0, n * 16));
+  CK(hipDeviceSynchronize());
+  const int blocks = 256 * 8 * 4;
+  for (int rep = 0; rep < 4; ++rep) {
+    // a different kernel's arrays are streamed in between, so no launch finds its own in the Infinity Cache
+    hipLaunchKernelGGL(calib_x4, dim3(blocks), dim3(256), 0, 0, a4, b4, n);
+    hipLaunchKernelGGL(calib_certify, dim3(blocks), dim3(256), 0, 0, src3, idx, lb, d2, n);
+    hipLaunchKernelGGL(calib_x4, dim3(blocks), dim3(256), 0, 0, a4, b4, n);
+    hipLaunchKernelGGL(calib_accumulate, dim3(blocks), dim3(256), 0, 0, src3, idx, lb, out, n);
+  }
+  CK(hipDeviceSynchronize());
+  std::printf("{\"elements\": %zu, \"calib_certify\": {\"read_bytes\": %zu, \"written_bytes\": %zu}, \"calib_accumulate\": {\"read_bytes\": %zu, "
+              "\"written_bytes\": 0}, \"calib_x4\": {\"read_bytes\": %zu, \"written_bytes\": %zu}}\n", n, n * 20, n * 4, n * 20, n * 16, n * 16);
+  return 0;
+}

@@ -1,0 +1,35 @@
+#!/bin/bash
+# FETCH_SIZE / WRITE_SIZE of known-byte streaming kernels (tools/traffic_calib.hip) -> profiles-style json with the factors
+# bytes / (counter x 1024) for 12 B + 4 B + 4 B per-element reads, 4 B writes and the guide's 16 B rows.
+# Usage (GPU box): bash tools/traffic_calib.sh <out.json>
+set -u
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+out=${1:-$R/gpurun_out/traffic_calibration.json}
+hipcc --offload-arch=gfx950 -O3 -o /tmp/traffic_calib $R/tools/traffic_calib.hip || exit 1
+rm -rf /tmp/calib_f /tmp/calib_w
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/calib_f -- /tmp/traffic_calib > /tmp/calib_known.json 2> /tmp/calib_f.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/calib_w -- /tmp/traffic_calib > /dev/null 2> /tmp/calib_w.log
+python - "$out" <<'PY'
+import csv, glob, json, sys
+known = json.load(open("/tmp/calib_known.json"))
+def avg(d, name, counter):
+    v = [float(r["Counter_Value"]) for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True) for r in csv.DictReader(open(f))
+         if name in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    return sum(v) / len(v) if v else 0.0
+res = {"elements": known["elements"], "unit": "counter values are KB (x 1024 bytes)", "kernels": {}}
+for k in ("calib_certify", "calib_accumulate", "calib_x4"):
+    f, w = avg("/tmp/calib_f", k, "FETCH_SIZE"), avg("/tmp/calib_w", k, "WRITE_SIZE")
+    rb, wb = known[k]["read_bytes"], known[k]["written_bytes"]
+    res["kernels"][k] = {"read_bytes": rb, "written_bytes": wb, "FETCH_SIZE": f, "WRITE_SIZE": w,
+                         "fetch_factor": rb / (f * 1024) if f else None, "write_factor": wb / (w * 1024) if w and wb else None}
+res["fetch_factor_stream_12_4_4"] = res["kernels"]["calib_certify"]["fetch_factor"]
+res["write_factor_dword"] = res["kernels"]["calib_certify"]["write_factor"]
+res["fetch_factor_x4"] = res["kernels"]["calib_x4"]["fetch_factor"]
+res["write_factor_x4"] = res["kernels"]["calib_x4"]["write_factor"]
+res["how"] = ("tools/traffic_calib.sh: known-byte streaming kernels in the ICP iteration kernels' access shapes (256 x 120 000 elements, arrays "
+              "streamed alternately so that none is found in the Infinity Cache), rocprofv3 --pmc FETCH_SIZE and a separate WRITE_SIZE pass; "
+              "factor = true bytes / (counter x 1024)")
+json.dump(res, open(sys.argv[1], "w"), indent=1)
+print(json.dumps(res))
+PY

@@ -374,8 +374,8 @@ smhip_status smhip_filter_get_output(smhip_handle h, float* points5, int32_t* so
 smhip_status smhip_filter_output_to_source(smhip_handle h, int slot);
 
 /* ---- profiling ----------------------------------------------------------- */
-/* enable: 0 off, 1 events around every launch, 2 events around the FindClosests and ErrorElements launches of the iterations
- * (everything but the per-Align preparation and the solve kernel; cheap enough to leave on inside a timed region) */
+/* enable: 0 off, 1 events around every launch; events around ONE kernel class only, cheap enough to leave on inside a timed
+ * region: 2 the NN kernels proper (fused search / full walk, certificate pass), 3 accumulate, 4 the listed search */
 smhip_status smhip_icp_enable_profile(smhip_handle h, int enable);
 smhip_status smhip_icp_get_profile(smhip_handle h, smhip_icp_profile* out);
 /* queries that went through a search (exact modes: certificate failed; NABO: walked again) in iterations 0..11 of the

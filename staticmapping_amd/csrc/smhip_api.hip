@@ -118,7 +118,13 @@ struct Bracket {
   smhip_context::Ev* ev = nullptr;
   hipStream_t st;
   Bracket(smhip_context* h_, int cat, hipStream_t st_, int np = 0) : h(h_), st(st_) {
-    if (!h->profile || (h->profile == 2 && (cat == 0 || cat == 3))) return;
+    // 1: every launch.  2 / 3 / 4: ONE kernel class only -- the NN kernels proper (fused search / full walk and the certificate
+    // pass), accumulate, or the listed search -- which costs a timed region one event pair per iteration and part (every
+    // bracket is a barrier between two launches: all classes at once took 6 % off the batch rate)
+    if (!h->profile) return;
+    if (h->profile == 2 && cat != 4 && cat != 5) return;
+    if (h->profile == 3 && cat != 2) return;
+    if (h->profile == 4 && cat != 6) return;
     if (h->ev_used == h->ev_pool.size()) {
       smhip_context::Ev e{};
       if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
@@ -1206,7 +1212,7 @@ smhip_status smhip_icp_find_closests(smhip_handle h, int slot, const double T[16
 
 smhip_status smhip_icp_enable_profile(smhip_handle h, int enable) {
   if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
-  h->profile = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
+  h->profile = (enable >= 2 && enable <= 4) ? enable : (enable != 0 ? 1 : 0);
   h->prof = smhip_icp_profile{};
   h->ev_used = 0;
   return SMHIP_OK;

@@ -229,7 +229,8 @@ class IcpFastHip:
         self._check(self._lib.smhip_icp_export_results_device(self._h, npairs, ctypes.c_void_p(dev_ptr)))
 
     def enable_profile(self, on=True):
-        """False/0 off, True/1 HIP events around every launch, 2 around the dominant NN kernel only."""
+        """False/0 off, True/1 HIP events around every launch; one kernel class only (cheap enough for a timed region):
+        2 the NN kernels proper, 3 accumulate, 4 the listed search."""
         self._check(self._lib.smhip_icp_enable_profile(self._h, int(on)))
 
     def get_profile(self) -> dict:

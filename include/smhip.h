@@ -163,6 +163,16 @@ smhip_status smhip_set_target_f64(smhip_handle h, int slot, const double* xyz_co
  * float32 points with a stride in floats: stride 4 = KITTI .bin rows (ros_node/kitti_reader.cc:91-121),
  * stride 5 = data::InnerPointType AoS {x,y,z,intensity,factor} (builder/data/cloud_types.h:46-56). */
 smhip_status smhip_set_source_f32(smhip_handle h, int slot, const float* xyz, int stride_floats, int n);
+/* `count` source clouds at once (the sequence driver's batch: SetInputSource of many pairs): cloud k = rows[k], n[k] rows of 4
+ * floats (KITTI rows) into slots[k].  One host-to-device copy per cloud, ONE Morton ordering for the batch (a single upload
+ * costs ~25 small launches).  rows[k] in pinned memory (hipHostMalloc / hipHostRegister) are copied from where they lie,
+ * asynchronously: they must stay untouched until the handle's stream has passed the copies (smhip_synchronize, or any call
+ * that blocks on the stream, e.g. smhip_prepare_targets_from_sources); pageable rows go through the handle's staging buffer
+ * one cloud at a time.  Needs stride 4. */
+smhip_status smhip_set_sources_f32_batch(smhip_handle h, int count, const int* slots, const float* const* rows, const int* n);
+/* allocates the workspaces of the batched calls (smhip_set_sources_f32_batch, smhip_prepare_targets_from_sources) now rather
+ * than inside the first batch -- several GB for a handle of hundreds of slots */
+smhip_status smhip_reserve_batch_workspaces(smhip_handle h);
 smhip_status smhip_set_target_f32(smhip_handle h, int slot, const float* xyz, int xyz_stride_floats,
                                   const float* normals, int normals_stride_floats, int n);
 /* Re-use slot `from`'s device-resident clouds in slot `to` (benchmark replication; no host copy). */

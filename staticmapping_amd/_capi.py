@@ -90,6 +90,8 @@ SIGNATURES = {
     "smhip_set_source_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, ctypes.c_int]),
     "smhip_set_target_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p, ctypes.c_int]),
     "smhip_set_source_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int]),
+    "smhip_reserve_batch_workspaces": (ctypes.c_int, [ctypes.c_void_p]),
+    "smhip_set_sources_f32_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int32_p, ctypes.POINTER(c_float_p), c_int32_p]),
     "smhip_set_target_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_float_p, ctypes.c_int, c_float_p,
                                             ctypes.c_int, ctypes.c_int]),
     "smhip_copy_slot": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),

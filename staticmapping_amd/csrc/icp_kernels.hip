@@ -12,63 +12,9 @@
 //
 // Everything here is HBM/L2-bound gather, scan and reduction work: wave64 shuffles + LDS, no MFMA.
 #include "smhip_device.h"
+#include "kd_median_tree.h"
 
 namespace smhip {
-
-// ------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_down(v, off, 64));
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
-  return v;
-}
-// `fill` where the DPP control has no source lane (or the row is masked off), else v of the source lane
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_or(int fill, int v) {
-  return __builtin_amdgcn_update_dpp(fill, v, CTRL, ROW_MASK, 0xf, false);
-}
-// Inclusive scan over the wave with DPP row operations (register to register): a scan inside every row of 16 lanes
-// (row_shr 1, 2, 4, 8), then the row totals carried across (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and
-// 3).  The __shfl_up form went through ds_bpermute: 6 LDS round trips per scan.
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int /*lane*/) {
-  v += (uint32_t)dpp_or<0x111, 0xf>(0, (int)v);
-  v += (uint32_t)dpp_or<0x112, 0xf>(0, (int)v);
-  v += (uint32_t)dpp_or<0x114, 0xf>(0, (int)v);
-  v += (uint32_t)dpp_or<0x118, 0xf>(0, (int)v);
-  v += (uint32_t)dpp_or<0x142, 0xa>(0, (int)v);
-  v += (uint32_t)dpp_or<0x143, 0xc>(0, (int)v);
-  return v;
-}
-
-// Block-wide exclusive scan of one value per thread (blockDim.x multiple of 64, <= 1024).
-// Returns the exclusive prefix; *total receives the block sum.  s_w needs 17 words.
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t* total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-  uint32_t inc = wave_incl_scan(v, lane);
-  if (lane == 63) s_w[wave] = inc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (int w = 0; w < nwave; ++w) { uint32_t t = s_w[w]; s_w[w] = run; run += t; }
-    s_w[16] = run;
-  }
-  __syncthreads();
-  uint32_t excl = inc - v + s_w[wave];
-  *total = s_w[16];
-  __syncthreads();
-  return excl;
-}
 
 // XCD-aware work mapping for the heavy per-point kernels.  They are launched as a 1-D grid of
 // nblk * 8 * ceil(npairs / 8) workgroups; the dispatcher deals consecutive workgroup ids round-robin
@@ -2317,14 +2263,36 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   for (int i = 0; i < 16; ++i) st->T_iter[i] = Tn[i];
   double Mn[16];
   mat4_mul_rm(Tn, st->G, Mn);
-  {   // motion potential: this step's ||dR||_F and |dt| (what bounds |M_new s - M_old s| <= ||dR|| |s| + |dt|), and their running sums
-    double fa = 0, fb = 0;
+  {   // motion potential: this step's ||dR|| and |dt| (what bounds |M_new s - M_old s| <= ||dR|| |s| + |dt|), and their running sums.
+      // ||dR|| is the SPECTRAL norm of the 3x3 difference (the largest singular value: what |dR s| <= ||dR|| |s| needs), from the
+      // closed-form largest eigenvalue of dR^T dR with 1e-6 of slack and never more than the Frobenius norm; for the difference of
+      // two rotations the Frobenius norm is sqrt(2) times larger, and with it sqrt(2) times the certified motion of far points.
+    double D[9], fa = 0, fb = 0;
     for (int r = 0; r < 3; ++r) {
-      for (int c = 0; c < 3; ++c) { const double d = Mn[4 * r + c] - st->M[4 * r + c]; fa += d * d; }
+      for (int c = 0; c < 3; ++c) { D[3 * r + c] = Mn[4 * r + c] - st->M[4 * r + c]; fa += D[3 * r + c] * D[3 * r + c]; }
       const double d = Mn[4 * r + 3] - st->M[4 * r + 3];
       fb += d * d;
     }
-    st->step_a = sqrt(fa) * (1.0 + 1e-9); st->step_b = sqrt(fb) * (1.0 + 1e-9);
+    double S[6];                                           // D^T D: xx xy xz yy yz zz
+    S[0] = D[0] * D[0] + D[3] * D[3] + D[6] * D[6]; S[1] = D[0] * D[1] + D[3] * D[4] + D[6] * D[7]; S[2] = D[0] * D[2] + D[3] * D[5] + D[6] * D[8];
+    S[3] = D[1] * D[1] + D[4] * D[4] + D[7] * D[7]; S[4] = D[1] * D[2] + D[4] * D[5] + D[7] * D[8]; S[5] = D[2] * D[2] + D[5] * D[5] + D[8] * D[8];
+    double lam = fa;                                       // trace = squared Frobenius norm >= the largest eigenvalue
+    {
+      const double q = (S[0] + S[3] + S[5]) / 3.0;
+      const double p1 = S[1] * S[1] + S[2] * S[2] + S[4] * S[4];
+      const double p2 = (S[0] - q) * (S[0] - q) + (S[3] - q) * (S[3] - q) + (S[5] - q) * (S[5] - q) + 2.0 * p1;
+      if (p2 > 0.0 && isfinite(p2)) {
+        const double p = sqrt(p2 / 6.0), ip = 1.0 / p;
+        const double b0 = (S[0] - q) * ip, b3 = (S[3] - q) * ip, b5 = (S[5] - q) * ip, b1 = S[1] * ip, b2 = S[2] * ip, b4 = S[4] * ip;
+        double r = 0.5 * (b0 * (b3 * b5 - b4 * b4) - b1 * (b1 * b5 - b4 * b2) + b2 * (b1 * b4 - b3 * b2));
+        r = fmin(1.0, fmax(-1.0, r));
+        const double est = (q + 2.0 * p * cos(acos(r) / 3.0)) * (1.0 + 2e-6) + 1e-300;
+        if (isfinite(est) && est > 0.0) lam = fmin(lam, est);
+      } else if (p2 == 0.0) {
+        lam = fmin(lam, q * (1.0 + 2e-6));
+      }
+    }
+    st->step_a = sqrt(lam) * (1.0 + 1e-9); st->step_b = sqrt(fb) * (1.0 + 1e-9);
     st->pot_a += st->step_a; st->pot_b += st->step_b;
   }
   for (int i = 0; i < 12; ++i) { st->M_prev[i] = st->M[i]; st->M[i] = Mn[i]; }

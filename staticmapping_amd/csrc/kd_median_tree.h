@@ -1,0 +1,385 @@
+// kd_median_tree.h -- the median-split kd-tree both callers of the registrators build, level by level on the device.
+//
+// libnabo's buildNodes (nabo/kdtree_cpu.cpp, bucketSize 8: the tree IcpFast searches, /root/reference/registrators/
+// icp_fast.cc:464-467) and EigenPointCloud::BuildNormals (/root/reference/builder/data/cloud_types.cc:105-144, leaves of
+// <= 7 points: the caller-side CalculateNormals) are the same construction: a node with more points than a bucket splits
+// on the widest side of the box it INHERITED (root: the cloud's bounds; a child: the parent's box cut at the cut value;
+// argMax from (index 0, value 0)), leftCount = count - count / 2, std::nth_element at that rank, cut value = that
+// element's coordinate.  The tree depends only on which points fall on which side of each median, so it is built level by
+// level by ONE 1024-thread workgroup per cloud: every position carries its segment, an exact radix select on the
+// order-preserving float key of the cut coordinate finds each segment's median (8 / 4 / 2 / 1 bits per pass as the segments
+// multiply, all segments of a level in one sweep with their histograms in 64 KiB of LDS), ties on the median value are
+// broken by the index the point carries in .w with a second select (block-uniformly skipped when there are none), and
+// one partition pass moves the points; once the segments hold <= 64 points each, every element is ranked inside its
+// segment by a wave instead (no sweeps).  Many clouds = many workgroups: a batch of >= 256 clouds fills the chip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace smhip {
+
+constexpr int kKdThreads = 1024;          // one workgroup builds one cloud's tree
+constexpr int kKdHistWords = 16384;       // 64 KiB of LDS histograms: segments per pass x 2^bits bins
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_down(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+  return v;
+}
+// `fill` where the DPP control has no source lane (or the row is masked off), else v of the source lane
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or(int fill, int v) {
+  return __builtin_amdgcn_update_dpp(fill, v, CTRL, ROW_MASK, 0xf, false);
+}
+// Inclusive scan over the wave with DPP row operations (register to register): a scan inside every row of 16 lanes
+// (row_shr 1, 2, 4, 8), then the row totals carried across (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and
+// 3).  The __shfl_up form went through ds_bpermute: 6 LDS round trips per scan.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int /*lane*/) {
+  v += (uint32_t)dpp_or<0x111, 0xf>(0, (int)v);
+  v += (uint32_t)dpp_or<0x112, 0xf>(0, (int)v);
+  v += (uint32_t)dpp_or<0x114, 0xf>(0, (int)v);
+  v += (uint32_t)dpp_or<0x118, 0xf>(0, (int)v);
+  v += (uint32_t)dpp_or<0x142, 0xa>(0, (int)v);
+  v += (uint32_t)dpp_or<0x143, 0xc>(0, (int)v);
+  return v;
+}
+
+// Block-wide exclusive scan of one value per thread (blockDim.x multiple of 64, <= 1024).
+// Returns the exclusive prefix; *total receives the block sum.  s_w needs 17 words.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  uint32_t inc = wave_incl_scan(v, lane);
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int w = 0; w < nwave; ++w) { uint32_t t = s_w[w]; s_w[w] = run; run += t; }
+    s_w[16] = run;
+  }
+  __syncthreads();
+  uint32_t excl = inc - v + s_w[wave];
+  *total = s_w[16];
+  __syncthreads();
+  return excl;
+}
+
+
+struct KdSeg {                            // one node of the current level while the tree is being built
+  uint32_t first, count;                  // its points: positions [first, first + count) of the working order
+  float mn[3], mx[3];                     // the box it inherited
+  uint32_t node;                          // its index in the node array
+  uint32_t split;                         // 1 = more than a bucket: splits at this level
+  uint32_t dim, left;                     // cut dimension, leftCount
+  uint32_t prefix, k, nless, neq;         // radix select state: key bits fixed so far, rank among the still-matching keys,
+                                          // keys known to be smaller, keys equal to the selected one
+  uint32_t vidx;                          // ties at the median: caller indices below this one go left
+  uint32_t rank;                          // number of splitting segments before this one
+  uint32_t tie, trank;                    // several points ON the median value of which `trank` (running) must go left
+};
+
+
+__device__ __forceinline__ uint32_t kd_key(float x) {          // order-preserving float -> uint
+  const uint32_t u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float kd_unkey(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__device__ __forceinline__ float kd_coord(const float4 p, uint32_t d) { return d == 0 ? p.x : (d == 1 ? p.y : p.z); }
+
+
+// Preconditions (all threads of the 1024-thread workgroup call it together): cur[i] = point i with .w = its index bits for
+// i < n, sid[i] = 0, seg[0] = the root {first 0, count n, node 0, the cloud's bounds}, s_misc[0] = 1 (node count).
+// s_hist: kKdHistWords words, s_w: 17, s_misc: 4 (all LDS).  On return cur / oth, sid / sid_o and seg / seg_o have been
+// swapped once per level: `cur` holds the final order (every leaf's points contiguous), nodes[] the tree (inner: {cut value
+// bits, (left child << 2) | dim}, children side by side; leaf: {first, (count << 2) | 3}), s_misc[0] the node count.
+template <int BUCKET>
+__device__ __forceinline__ void kd_median_build(int n, float4*& cur, float4*& oth, uint32_t*& sid, uint32_t*& sid_o, KdSeg*& seg, KdSeg*& seg_o,
+                                                uint2* nodes, uint32_t* cnt_global, int seg_cap, int node_cap,
+                                                uint32_t* s_hist, uint32_t* s_w, uint32_t* s_misc, int32_t* status) {
+  const int tid = threadIdx.x;
+  int S = 1;                                                 // segments of the current level
+  for (int level = 0; level < 40 && S > 0; ++level) {
+    // ---- per segment: leaf or split, cut dimension, leftCount
+    uint32_t my_splits = 0;
+    if (tid == 0) s_misc[2] = 0;                             // the largest splitting segment of the level
+    __syncthreads();
+    const int per = (S + kKdThreads - 1) / kKdThreads;
+    const int s_lo = min(S, tid * per), s_hi = min(S, s_lo + per);
+    for (int s = s_lo; s < s_hi; ++s) {
+      KdSeg& g = seg[s];
+      if (g.count <= (uint32_t)BUCKET) {
+        g.split = 0;
+        nodes[g.node] = make_uint2(g.first, (g.count << 2) | 3u);
+      } else {
+        g.split = 1;
+        uint32_t cd = 0; float mv = 0.f;                     // argMax from (0, 0.)
+        for (uint32_t d = 0; d < 3; ++d) { const float e = g.mx[d] - g.mn[d]; if (e > mv) { mv = e; cd = d; } }
+        g.dim = cd;
+        g.left = g.count - g.count / 2;
+        g.prefix = 0; g.k = g.left; g.nless = 0; g.neq = 0; g.vidx = 0;
+        atomicMax(&s_misc[2], g.count);
+        ++my_splits;
+      }
+    }
+    uint32_t nsplit;
+    const uint32_t my_rank = block_excl_scan(my_splits, s_w, &nsplit);
+    {
+      uint32_t r = my_rank;
+      for (int s = s_lo; s < s_hi; ++s) if (seg[s].split) seg[s].rank = r++;
+    }
+    __syncthreads();
+    if (nsplit == 0) break;
+    if (2 * nsplit > (uint32_t)seg_cap || s_misc[0] + 2 * nsplit > (uint32_t)node_cap) { if (tid == 0) *status = 3; break; }   // cannot happen: caps follow nt_cap
+
+    const uint32_t nc = s_misc[0];
+    if (s_misc[2] <= 64u) {
+      // ---- small segments (<= 64 points each: the last four levels of a 120 k-point cloud, where the radix select below needs
+      // 16-32 sweeps over every point because thousands of segments share the histogram words): every element's exact rank
+      // inside its segment by comparison with the segment's other elements, a wave per window of 128 consecutive positions
+      // (two per lane).  A window owns the segments that START in its first half -- they end inside the window -- so every
+      // comparison partner is in the wave's registers: 128 broadcasts instead of dozens of sweeps through memory.  The rank is
+      // the element's place in (coordinate, index) order, i.e. the order the select's tie rule defines: position = first + rank,
+      // left child = ranks below `left`, cut value = the coordinate of rank `left`.
+      const int lane = tid & 63;
+      for (uint32_t w0 = 64u * (uint32_t)(tid >> 6); w0 < (uint32_t)n; w0 += (uint32_t)kKdThreads) {
+        uint32_t key[2] = {0, 0}, idx[2] = {0, 0}, first[2] = {0xffffffffu, 0xffffffffu}, left[2] = {0, 0}, segr[2] = {0, 0}, sidv[2] = {0, 0}, rnk[2] = {0, 0};
+        bool own[2] = {false, false};
+        float4 p[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const uint32_t pos = w0 + 64u * e + lane;
+          const bool live = pos < (uint32_t)n;
+          uint32_t sv = 0xffffffffu;
+          p[e] = make_float4(0, 0, 0, 0);
+          if (live) { sv = sid[pos]; p[e] = cur[pos]; }
+          bool act = false;
+          if (sv != 0xffffffffu) {
+            const KdSeg& g = seg[sv];
+            if (g.split) {
+              act = true;
+              key[e] = kd_key(kd_coord(p[e], g.dim)); idx[e] = (uint32_t)__float_as_int(p[e].w);
+              first[e] = g.first; left[e] = g.left; segr[e] = g.rank; sidv[e] = sv;
+            }
+          }
+          own[e] = act && first[e] >= w0 && first[e] < w0 + 64u;
+          if (e == 0 && live && !act) { oth[pos] = p[e]; sid_o[pos] = 0xffffffffu; }   // in a leaf (now or earlier): stays where it is for good
+        }
+        if (__ballot(own[0] || own[1]) != 0ull) {             // wave-uniform
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            for (int j = 0; j < 64; ++j) {
+              const uint32_t fj = (uint32_t)__builtin_amdgcn_readlane((int)first[w], j);
+              if (fj == 0xffffffffu) continue;                // not part of a splitting segment (uniform)
+              const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key[w], j);
+              const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)idx[w], j);
+#pragma unroll
+              for (int e = 0; e < 2; ++e)
+                rnk[e] += (own[e] && fj == first[e] && (kj < key[e] || (kj == key[e] && ij < idx[e]))) ? 1u : 0u;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            if (!own[e]) continue;
+            const uint32_t np = first[e] + rnk[e];
+            oth[np] = p[e];
+            sid_o[np] = 2 * segr[e] + (rnk[e] < left[e] ? 0u : 1u);
+            if (rnk[e] == left[e]) seg[sidv[e]].prefix = key[e];      // the nth element: its coordinate is the cut value
+          }
+        }
+      }
+    } else {
+    // ---- exact radix select of the element of rank `left` on the cut coordinate, all segments of a group at once
+    // 8-bit digits while a level has <= 1024 segments: beyond 64 of them the level is swept in groups of 64 segments, each group
+    // over its own positions only -- 4 short sweeps per group instead of 8 (4-bit digits) over every point of the cloud
+    const int bits = S <= 1024 ? 8 : (S <= 4096 ? 4 : (S <= 8192 ? 2 : 1));
+    const int G = kKdHistWords >> bits;                      // segments per group
+    const uint32_t mask = (1u << bits) - 1u;
+    for (int g0 = 0; g0 < S; g0 += G) {
+      const int g1 = min(S, g0 + G);
+      const uint32_t p_lo = seg[g0].first, p_hi = seg[g1 - 1].first + seg[g1 - 1].count;
+      for (int pass = 0; pass < 2; ++pass) {                 // pass 0: the coordinate key; pass 1 (ties only): the caller index
+        if (pass == 1) {
+          // does any segment of the group have several points ON its median value of which some must go left?
+          if (tid == 0) s_misc[1] = 0;
+          __syncthreads();
+          for (int s = g0 + tid; s < g1; s += kKdThreads) {
+            KdSeg& g = seg[s];
+            g.tie = (g.split && g.neq > 1 && g.k > 0) ? 1u : 0u;
+            g.trank = g.k;
+            g.vidx = 0;                                      // doubles as the prefix of the index select
+            if (g.tie) s_misc[1] = 1;
+          }
+          __syncthreads();
+          if (!s_misc[1]) break;                             // block-uniform
+        }
+        for (int shift = 32 - bits; shift >= 0; shift -= bits) {
+          for (int k = tid; k < (g1 - g0) << bits; k += kKdThreads) s_hist[k] = 0;
+          __syncthreads();
+          // four positions per thread and trip, their three levels of loads (segment id, point, segment state) issued
+          // together: one position at a time every visit was a chain of three dependent memory latencies
+          for (uint32_t pos0 = p_lo + tid; pos0 < p_hi; pos0 += 4 * kKdThreads) {
+            uint32_t sv[4];
+            float4 pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const uint32_t pos = pos0 + u * kKdThreads;
+              sv[u] = pos < p_hi ? sid[pos] : 0xffffffffu;
+              pv[u] = cur[min(pos, p_hi - 1u)];
+            }
+            uint32_t gdim[4], gpre[4], gsel[4], gvid[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const KdSeg& g = seg[sv[u] == 0xffffffffu ? (uint32_t)g0 : sv[u]];
+              gdim[u] = g.dim; gpre[u] = g.prefix; gvid[u] = g.vidx;
+              gsel[u] = sv[u] == 0xffffffffu ? 0u : (pass == 0 ? g.split : (g.split & g.tie));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (!gsel[u]) continue;
+              const uint32_t key = kd_key(kd_coord(pv[u], gdim[u]));
+              if (pass == 0) {
+                if (shift + bits < 32 && (key >> (shift + bits)) != (gpre[u] >> (shift + bits))) continue;
+                atomicAdd(&s_hist[((sv[u] - g0) << bits) + ((key >> shift) & mask)], 1u);
+              } else {
+                if (key != gpre[u]) continue;
+                const uint32_t ik = (uint32_t)__float_as_int(pv[u].w);
+                if (shift + bits < 32 && (ik >> (shift + bits)) != (gvid[u] >> (shift + bits))) continue;
+                atomicAdd(&s_hist[((sv[u] - g0) << bits) + ((ik >> shift) & mask)], 1u);
+              }
+            }
+          }
+          __syncthreads();
+          if (bits == 8) {
+            // few segments, 256 bins each: a wave per segment, four bins per lane, one scan (a single thread walking 256
+            // bins took longer than the sweep over the points)
+            const int lane = tid & 63;
+            for (int s = g0 + (tid >> 6); s < g1; s += kKdThreads / 64) {        // wave-uniform
+              KdSeg& g = seg[s];
+              if (!g.split || (pass == 1 && !g.tie)) continue;
+              const uint32_t* hh = &s_hist[(s - g0) << 8];
+              const uint32_t c0 = hh[4 * lane], c1 = hh[4 * lane + 1], c2 = hh[4 * lane + 2], c3 = hh[4 * lane + 3];
+              const uint32_t want = pass == 0 ? g.k : g.trank;
+              const uint32_t incl = wave_incl_scan(c0 + c1 + c2 + c3, lane);
+              const uint32_t excl = incl - (c0 + c1 + c2 + c3);
+              if (excl <= want && want < incl) {                                  // exactly one lane
+                uint32_t cum = excl, d = 4u * lane, c = c0;
+                if (cum + c <= want) { cum += c; ++d; c = c1; }
+                if (cum + c <= want) { cum += c; ++d; c = c2; }
+                if (cum + c <= want) { cum += c; ++d; c = c3; }
+                if (pass == 0) { g.prefix |= d << shift; g.nless += cum; g.k -= cum; g.neq = c; }
+                else { g.vidx |= d << shift; g.trank -= cum; }
+              }
+            }
+          } else {
+            for (int s = g0 + tid; s < g1; s += kKdThreads) {
+              KdSeg& g = seg[s];
+              if (!g.split || (pass == 1 && !g.tie)) continue;
+              const uint32_t* hh = &s_hist[(s - g0) << bits];
+              const uint32_t want = pass == 0 ? g.k : g.trank;  // rank among the still-matching keys
+              uint32_t cum = 0;
+              for (uint32_t d = 0; d <= mask; ++d) {
+                const uint32_t c = hh[d];
+                if (cum + c > want) {
+                  if (pass == 0) { g.prefix |= d << shift; g.nless += cum; g.k -= cum; g.neq = c; }
+                  else { g.vidx |= d << shift; g.trank -= cum; }
+                  break;
+                }
+                cum += c;
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+    }
+    // After pass 0: prefix = key of the median element, nless = keys below it, neq = keys equal to it, k = how many of the
+    // equal ones go LEFT (0 for tie-free data).  After pass 1 (ties): vidx = caller index of the first equal point that
+    // goes right.  Without ties vidx stays 0: no equal point goes left.
+
+    // ---- partition into the other buffer; children become the next level's segments
+    const bool lds_counters = 2 * S <= kKdHistWords;
+    uint32_t* cnt = lds_counters ? s_hist : cnt_global;
+    for (int k = tid; k < 2 * S; k += kKdThreads) cnt[k] = 0;
+    __syncthreads();
+    for (uint32_t pos0 = 0; pos0 < (uint32_t)n; pos0 += kKdThreads) {     // whole waves take the trip together (ballots below)
+      const uint32_t pos = pos0 + tid;
+      const bool live = pos < (uint32_t)n;
+      uint32_t s = 0xffffffffu;
+      float4 p = make_float4(0, 0, 0, 0);
+      if (live) { s = sid[pos]; p = cur[pos]; }
+      bool moving = false, left = false;
+      uint32_t first = 0, nleft = 0, rank = 0;
+      if (s != 0xffffffffu) {
+        const KdSeg& g = seg[s];
+        if (g.split) {
+          moving = true;
+          const uint32_t key = kd_key(kd_coord(p, g.dim));
+          left = key < g.prefix || (key == g.prefix && (uint32_t)__float_as_int(p.w) < g.vidx);
+          first = g.first; nleft = g.left; rank = g.rank;
+        }
+      }
+      if (live && !moving) { oth[pos] = p; sid_o[pos] = 0xffffffffu; }   // in a leaf (now or earlier): stays where it is for good
+      // fill counters: one atomic per wave and side when the wave's moving lanes share a segment (always so on the upper
+      // levels, where the same two counters would otherwise take every point of the cloud), one per lane otherwise
+      const unsigned long long mm = __ballot(moving);
+      if (mm) {
+        const int lane = tid & 63;
+        const int lead = __ffsll((long long)mm) - 1;
+        const uint32_t s_lead = (uint32_t)__shfl((int)s, lead, 64);
+        const bool uniform = __ballot(moving && s != s_lead) == 0ull;
+        uint32_t np = 0;
+        if (uniform) {
+          const unsigned long long ml = __ballot(moving && left), mr = mm & ~ml;
+          uint32_t bl = 0, br = 0;
+          if (lane == lead) {
+            if (ml) bl = atomicAdd(&cnt[2 * s], (uint32_t)__popcll(ml));
+            if (mr) br = atomicAdd(&cnt[2 * s + 1], (uint32_t)__popcll(mr));
+          }
+          bl = (uint32_t)__shfl((int)bl, lead, 64); br = (uint32_t)__shfl((int)br, lead, 64);
+          const unsigned long long below = (1ull << lane) - 1ull;
+          if (moving) np = left ? first + bl + (uint32_t)__popcll(ml & below) : first + nleft + br + (uint32_t)__popcll(mr & below);
+        } else if (moving) {
+          np = left ? first + atomicAdd(&cnt[2 * s], 1u) : first + nleft + atomicAdd(&cnt[2 * s + 1], 1u);
+        }
+        if (moving) { oth[np] = p; sid_o[np] = 2 * rank + (left ? 0u : 1u); }
+      }
+    }
+    }   // radix select + partition
+    __syncthreads();
+    for (int s = s_lo; s < s_hi; ++s) {
+      const KdSeg& g = seg[s];
+      if (!g.split) continue;
+      const float cut = kd_unkey(g.prefix);
+      nodes[g.node] = make_uint2(__float_as_uint(cut), ((nc + 2 * g.rank) << 2) | g.dim);
+      KdSeg l{}, r{};
+      l.first = g.first; l.count = g.left; l.node = nc + 2 * g.rank;
+      r.first = g.first + g.left; r.count = g.count - g.left; r.node = nc + 2 * g.rank + 1;
+      for (int d = 0; d < 3; ++d) { l.mn[d] = g.mn[d]; l.mx[d] = g.mx[d]; r.mn[d] = g.mn[d]; r.mx[d] = g.mx[d]; }
+      l.mx[g.dim] = cut; r.mn[g.dim] = cut;
+      seg_o[2 * g.rank] = l; seg_o[2 * g.rank + 1] = r;
+    }
+    __syncthreads();
+    if (tid == 0) s_misc[0] = nc + 2 * nsplit;
+    { float4* t4 = cur; cur = oth; oth = t4; }
+    { uint32_t* t1 = sid; sid = sid_o; sid_o = t1; }
+    { KdSeg* ts = seg; seg = seg_o; seg_o = ts; }
+    S = 2 * (int)nsplit;
+    __syncthreads();
+  }
+}
+
+}  // namespace smhip

@@ -24,28 +24,14 @@
 // pruning test within one float ulp of its threshold can fall the other way -- tests/test_nabo_gpu.py counts how often.
 #pragma once
 #include "smhip_device.h"
+#include "kd_median_tree.h"
 
 namespace smhip {
 
-constexpr int kKdThreads = 1024;          // one workgroup builds one pair's tree
 constexpr int kKdBucket = 8;              // libnabo's default bucketSize
-constexpr int kKdHistWords = 16384;       // 64 KiB of LDS histograms: segments per pass x 2^bits bins
 constexpr int kKdStack = 18;              // pending siblings per query: at most one per tree level (18 levels: > 1 M target points; node < 2^23)
 constexpr int kNaboListedBlocks = 96;     // workgroups per pair striding over the lists of queries to walk again (32: -2 %, 64: -1 %, 128: equal)
 constexpr int kKdTopNodes = 511;          // tree levels 0..8 staged in LDS by the search kernel (4 KiB)
-
-struct KdSeg {                            // one node of the current level while the tree is being built
-  uint32_t first, count;                  // its points: positions [first, first + count) of the working order
-  float mn[3], mx[3];                     // the box it inherited
-  uint32_t node;                          // its index in the node array
-  uint32_t split;                         // 1 = more than a bucket: splits at this level
-  uint32_t dim, left;                     // cut dimension, leftCount
-  uint32_t prefix, k, nless, neq;         // radix select state: key bits fixed so far, rank among the still-matching keys,
-                                          // keys known to be smaller, keys equal to the selected one
-  uint32_t vidx;                          // ties at the median: caller indices below this one go left
-  uint32_t rank;                          // number of splitting segments before this one
-  uint32_t tie, trank;                    // several points ON the median value of which `trank` (running) must go left
-};
 
 struct KdDev {
   uint2* nodes;        // [slots][kd_node_cap]  inner: {cut value bits, (left child << 2) | dim}; leaf: {first, (count << 2) | 3}
@@ -63,15 +49,6 @@ struct KdDev {
 __device__ __forceinline__ float kd_rd_step(float rd, float old_off, float new_off) {
   return __fadd_rn(rd, __fadd_rn(-__fmul_rn(old_off, old_off), __fmul_rn(new_off, new_off)));
 }
-
-__device__ __forceinline__ uint32_t kd_key(float x) {          // order-preserving float -> uint
-  const uint32_t u = __float_as_uint(x);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float kd_unkey(uint32_t k) {
-  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
-__device__ __forceinline__ float kd_coord(const float4 p, uint32_t d) { return d == 0 ? p.x : (d == 1 ? p.y : p.z); }
 
 // Build: grid = (pairs), 1024 threads.  Needs tgt_reduce + grid_setup to have run (st->mu, st->nt).
 __global__ __launch_bounds__(kKdThreads) void kd_build(IcpDev b, KdDev kd) {
@@ -119,213 +96,9 @@ __global__ __launch_bounds__(kKdThreads) void kd_build(IcpDev b, KdDev kd) {
   }
   __syncthreads();
 
-  int S = 1;                                                 // segments of the current level
-  for (int level = 0; level < 40 && S > 0; ++level) {
-    // ---- per segment: leaf or split, cut dimension, leftCount
-    uint32_t my_splits = 0;
-    const int per = (S + kKdThreads - 1) / kKdThreads;
-    const int s_lo = min(S, tid * per), s_hi = min(S, s_lo + per);
-    for (int s = s_lo; s < s_hi; ++s) {
-      KdSeg& g = seg[s];
-      if (g.count <= (uint32_t)kKdBucket) {
-        g.split = 0;
-        nodes[g.node] = make_uint2(g.first, (g.count << 2) | 3u);
-      } else {
-        g.split = 1;
-        uint32_t cd = 0; float mv = 0.f;                     // argMax from (0, 0.)
-        for (uint32_t d = 0; d < 3; ++d) { const float e = g.mx[d] - g.mn[d]; if (e > mv) { mv = e; cd = d; } }
-        g.dim = cd;
-        g.left = g.count - g.count / 2;
-        g.prefix = 0; g.k = g.left; g.nless = 0; g.neq = 0; g.vidx = 0;
-        ++my_splits;
-      }
-    }
-    uint32_t nsplit;
-    const uint32_t my_rank = block_excl_scan(my_splits, s_w, &nsplit);
-    {
-      uint32_t r = my_rank;
-      for (int s = s_lo; s < s_hi; ++s) if (seg[s].split) seg[s].rank = r++;
-    }
-    __syncthreads();
-    if (nsplit == 0) break;
-    if (2 * nsplit > (uint32_t)kd.seg_cap || s_misc[0] + 2 * nsplit > (uint32_t)kd.node_cap) { if (tid == 0) st->status = 3; break; }   // cannot happen: caps follow nt_cap
-
-    // ---- exact radix select of the element of rank `left` on the cut coordinate, all segments of a group at once
-    const int bits = S <= 64 ? 8 : (S <= 1024 ? 4 : (S <= 4096 ? 2 : 1));
-    const int G = kKdHistWords >> bits;                      // segments per group
-    const uint32_t mask = (1u << bits) - 1u;
-    for (int g0 = 0; g0 < S; g0 += G) {
-      const int g1 = min(S, g0 + G);
-      const uint32_t p_lo = seg[g0].first, p_hi = seg[g1 - 1].first + seg[g1 - 1].count;
-      for (int pass = 0; pass < 2; ++pass) {                 // pass 0: the coordinate key; pass 1 (ties only): the caller index
-        if (pass == 1) {
-          // does any segment of the group have several points ON its median value of which some must go left?
-          if (tid == 0) s_misc[1] = 0;
-          __syncthreads();
-          for (int s = g0 + tid; s < g1; s += kKdThreads) {
-            KdSeg& g = seg[s];
-            g.tie = (g.split && g.neq > 1 && g.k > 0) ? 1u : 0u;
-            g.trank = g.k;
-            g.vidx = 0;                                      // doubles as the prefix of the index select
-            if (g.tie) s_misc[1] = 1;
-          }
-          __syncthreads();
-          if (!s_misc[1]) break;                             // block-uniform
-        }
-        for (int shift = 32 - bits; shift >= 0; shift -= bits) {
-          for (int k = tid; k < (g1 - g0) << bits; k += kKdThreads) s_hist[k] = 0;
-          __syncthreads();
-          // four positions per thread and trip, their three levels of loads (segment id, point, segment state) issued
-          // together: one position at a time every visit was a chain of three dependent memory latencies
-          for (uint32_t pos0 = p_lo + tid; pos0 < p_hi; pos0 += 4 * kKdThreads) {
-            uint32_t sv[4];
-            float4 pv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const uint32_t pos = pos0 + u * kKdThreads;
-              sv[u] = pos < p_hi ? sid[pos] : 0xffffffffu;
-              pv[u] = cur[min(pos, p_hi - 1u)];
-            }
-            uint32_t gdim[4], gpre[4], gsel[4], gvid[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const KdSeg& g = seg[sv[u] == 0xffffffffu ? (uint32_t)g0 : sv[u]];
-              gdim[u] = g.dim; gpre[u] = g.prefix; gvid[u] = g.vidx;
-              gsel[u] = sv[u] == 0xffffffffu ? 0u : (pass == 0 ? g.split : (g.split & g.tie));
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              if (!gsel[u]) continue;
-              const uint32_t key = kd_key(kd_coord(pv[u], gdim[u]));
-              if (pass == 0) {
-                if (shift + bits < 32 && (key >> (shift + bits)) != (gpre[u] >> (shift + bits))) continue;
-                atomicAdd(&s_hist[((sv[u] - g0) << bits) + ((key >> shift) & mask)], 1u);
-              } else {
-                if (key != gpre[u]) continue;
-                const uint32_t ik = (uint32_t)__float_as_int(pv[u].w);
-                if (shift + bits < 32 && (ik >> (shift + bits)) != (gvid[u] >> (shift + bits))) continue;
-                atomicAdd(&s_hist[((sv[u] - g0) << bits) + ((ik >> shift) & mask)], 1u);
-              }
-            }
-          }
-          __syncthreads();
-          if (bits == 8) {
-            // few segments, 256 bins each: a wave per segment, four bins per lane, one scan (a single thread walking 256
-            // bins took longer than the sweep over the points)
-            const int lane = tid & 63;
-            for (int s = g0 + (tid >> 6); s < g1; s += kKdThreads / 64) {        // wave-uniform
-              KdSeg& g = seg[s];
-              if (!g.split || (pass == 1 && !g.tie)) continue;
-              const uint32_t* hh = &s_hist[(s - g0) << 8];
-              const uint32_t c0 = hh[4 * lane], c1 = hh[4 * lane + 1], c2 = hh[4 * lane + 2], c3 = hh[4 * lane + 3];
-              const uint32_t want = pass == 0 ? g.k : g.trank;
-              const uint32_t incl = wave_incl_scan(c0 + c1 + c2 + c3, lane);
-              const uint32_t excl = incl - (c0 + c1 + c2 + c3);
-              if (excl <= want && want < incl) {                                  // exactly one lane
-                uint32_t cum = excl, d = 4u * lane, c = c0;
-                if (cum + c <= want) { cum += c; ++d; c = c1; }
-                if (cum + c <= want) { cum += c; ++d; c = c2; }
-                if (cum + c <= want) { cum += c; ++d; c = c3; }
-                if (pass == 0) { g.prefix |= d << shift; g.nless += cum; g.k -= cum; g.neq = c; }
-                else { g.vidx |= d << shift; g.trank -= cum; }
-              }
-            }
-          } else {
-            for (int s = g0 + tid; s < g1; s += kKdThreads) {
-              KdSeg& g = seg[s];
-              if (!g.split || (pass == 1 && !g.tie)) continue;
-              const uint32_t* hh = &s_hist[(s - g0) << bits];
-              const uint32_t want = pass == 0 ? g.k : g.trank;  // rank among the still-matching keys
-              uint32_t cum = 0;
-              for (uint32_t d = 0; d <= mask; ++d) {
-                const uint32_t c = hh[d];
-                if (cum + c > want) {
-                  if (pass == 0) { g.prefix |= d << shift; g.nless += cum; g.k -= cum; g.neq = c; }
-                  else { g.vidx |= d << shift; g.trank -= cum; }
-                  break;
-                }
-                cum += c;
-              }
-            }
-          }
-          __syncthreads();
-        }
-      }
-    }
-    // After pass 0: prefix = key of the median element, nless = keys below it, neq = keys equal to it, k = how many of the
-    // equal ones go LEFT (0 for tie-free data).  After pass 1 (ties): vidx = caller index of the first equal point that
-    // goes right.  Without ties vidx stays 0: no equal point goes left.
-
-    // ---- partition into the other buffer; children become the next level's segments
-    const uint32_t nc = s_misc[0];
-    const bool lds_counters = 2 * S <= kKdHistWords;
-    uint32_t* cnt = lds_counters ? s_hist : kd.cnt + (size_t)pair * 2 * kd.seg_cap;
-    for (int k = tid; k < 2 * S; k += kKdThreads) cnt[k] = 0;
-    __syncthreads();
-    for (uint32_t pos0 = 0; pos0 < (uint32_t)n; pos0 += kKdThreads) {     // whole waves take the trip together (ballots below)
-      const uint32_t pos = pos0 + tid;
-      const bool live = pos < (uint32_t)n;
-      uint32_t s = 0xffffffffu;
-      float4 p = make_float4(0, 0, 0, 0);
-      if (live) { s = sid[pos]; p = cur[pos]; }
-      bool moving = false, left = false;
-      uint32_t first = 0, nleft = 0, rank = 0;
-      if (s != 0xffffffffu) {
-        const KdSeg& g = seg[s];
-        if (g.split) {
-          moving = true;
-          const uint32_t key = kd_key(kd_coord(p, g.dim));
-          left = key < g.prefix || (key == g.prefix && (uint32_t)__float_as_int(p.w) < g.vidx);
-          first = g.first; nleft = g.left; rank = g.rank;
-        }
-      }
-      if (live && !moving) { oth[pos] = p; sid_o[pos] = 0xffffffffu; }   // in a leaf (now or earlier): stays where it is for good
-      // fill counters: one atomic per wave and side when the wave's moving lanes share a segment (always so on the upper
-      // levels, where the same two counters would otherwise take every point of the cloud), one per lane otherwise
-      const unsigned long long mm = __ballot(moving);
-      if (mm) {
-        const int lane = tid & 63;
-        const int lead = __ffsll((long long)mm) - 1;
-        const uint32_t s_lead = (uint32_t)__shfl((int)s, lead, 64);
-        const bool uniform = __ballot(moving && s != s_lead) == 0ull;
-        uint32_t np = 0;
-        if (uniform) {
-          const unsigned long long ml = __ballot(moving && left), mr = mm & ~ml;
-          uint32_t bl = 0, br = 0;
-          if (lane == lead) {
-            if (ml) bl = atomicAdd(&cnt[2 * s], (uint32_t)__popcll(ml));
-            if (mr) br = atomicAdd(&cnt[2 * s + 1], (uint32_t)__popcll(mr));
-          }
-          bl = (uint32_t)__shfl((int)bl, lead, 64); br = (uint32_t)__shfl((int)br, lead, 64);
-          const unsigned long long below = (1ull << lane) - 1ull;
-          if (moving) np = left ? first + bl + (uint32_t)__popcll(ml & below) : first + nleft + br + (uint32_t)__popcll(mr & below);
-        } else if (moving) {
-          np = left ? first + atomicAdd(&cnt[2 * s], 1u) : first + nleft + atomicAdd(&cnt[2 * s + 1], 1u);
-        }
-        if (moving) { oth[np] = p; sid_o[np] = 2 * rank + (left ? 0u : 1u); }
-      }
-    }
-    __syncthreads();
-    for (int s = s_lo; s < s_hi; ++s) {
-      const KdSeg& g = seg[s];
-      if (!g.split) continue;
-      const float cut = kd_unkey(g.prefix);
-      nodes[g.node] = make_uint2(__float_as_uint(cut), ((nc + 2 * g.rank) << 2) | g.dim);
-      KdSeg l{}, r{};
-      l.first = g.first; l.count = g.left; l.node = nc + 2 * g.rank;
-      r.first = g.first + g.left; r.count = g.count - g.left; r.node = nc + 2 * g.rank + 1;
-      for (int d = 0; d < 3; ++d) { l.mn[d] = g.mn[d]; l.mx[d] = g.mx[d]; r.mn[d] = g.mn[d]; r.mx[d] = g.mx[d]; }
-      l.mx[g.dim] = cut; r.mn[g.dim] = cut;
-      seg_o[2 * g.rank] = l; seg_o[2 * g.rank + 1] = r;
-    }
-    __syncthreads();
-    if (tid == 0) s_misc[0] = nc + 2 * nsplit;
-    { float4* t4 = cur; cur = oth; oth = t4; }
-    { uint32_t* t1 = sid; sid = sid_o; sid_o = t1; }
-    { KdSeg* ts = seg; seg = seg_o; seg_o = ts; }
-    S = 2 * (int)nsplit;
-    __syncthreads();
-  }
+  // ---- libnabo's buildNodes level by level (kd_median_tree.h; bucketSize 8)
+  kd_median_build<kKdBucket>(n, cur, oth, sid, sid_o, seg, seg_o, nodes, kd.cnt + (size_t)pair * 2 * kd.seg_cap, kd.seg_cap, kd.node_cap,
+                             s_hist, s_w, s_misc, &st->status);
   // ---- final order into tq (+ normals), bucket entries by caller index (a deterministic stand-in for nth_element's
   // unspecified order inside a bucket; it only matters for exactly equidistant entries)
   float4* tq = b.tq + to;
@@ -402,7 +175,7 @@ __device__ __forceinline__ float kd_sqrt_gap(float x, float y) {
 // Measured on 512 x 120 k queries, every query walked in 20 iterations: 3 workgroups per CU (52 KiB: two-word stack entries,
 // 8 KiB histogram) 355 ms, 4 (40 KiB) 264 ms, 6 (24 KiB) 156 ms, 8 (20 KiB, 64 VGPRs, 24 B of scratch) 148 ms.
 template <int ITEMS, bool LISTED, int STACK>
-__global__ __launch_bounds__(kNnThreads, 8) void nn_nabo(IcpDev b, KdDev kd, int nblk) {
+__global__ __launch_bounds__(kNnThreads, STACK <= 12 ? 8 : 6) void nn_nabo(IcpDev b, KdDev kd, int nblk) {
   int pair, blk;
   if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
   PairState* st = &b.state[pair];

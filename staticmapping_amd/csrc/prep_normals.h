@@ -16,8 +16,16 @@ hipError_t prep_calculate_normals(PrepWorkspace* w, hipStream_t st, const float4
 // The workspace must hold sum(n) points.
 hipError_t prep_calculate_normals_batch(PrepWorkspace* w, hipStream_t st, const float4* raw, int S, const int* offset,
                                         const int* n, const int* out_offset, float4* out_p, float4* out_n, int* m_host);
+// allocates what a batch of >= 32 scans needs (the one-workgroup-per-scan forest) ahead of the first such batch
+hipError_t prep_reserve_forest(PrepWorkspace* w);
 // Morton-order `raw` into `out` (out[k].w = index of the point in `raw`); asynchronous on `st`.
 hipError_t prep_morton_sort(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float4* out);
+// The same for S clouds at once: cloud s = stage[stage_off[s] .. + n[s]) (device), Morton-ordered into out_base + out_off[s];
+// one key pass, ONE radix sort on (cloud, Morton key) and one gather for the whole batch.  Within a cloud the order equals
+// prep_morton_sort's whenever the cloud spans < 16 km (18 instead of 21 key bits per axis make room for the cloud id).
+// The workspace must hold sum(n) points; S <= 512.  Asynchronous on `st`.
+hipError_t prep_morton_sort_batch(PrepWorkspace* w, hipStream_t st, const float4* stage, int S, const int* stage_off, const int* n,
+                                  const long long* out_off, float4* out_base);
 // Random sub-sampling of a Morton-ordered cloud (in[k].w = caller index): keeps the points whose counter-based uniform of
 // (seed, caller index) is < prob, in the input's order, with out[k].w = index in the sampled cloud in caller order.
 // Blocks until *m_host (points kept) is known.  in != out.

@@ -22,6 +22,7 @@
 #include <cstdint>
 
 #include "prep_normals.h"
+#include "kd_median_tree.h"
 
 namespace smhip {
 
@@ -212,8 +213,19 @@ __global__ void kd_leaf_normals(const float4* raw, ScanSet ss, const int32_t* or
   const KdLeaf lf = leaves[l];
   double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
   int kmin = 0x7fffffff;
-  for (int i = 0; i < lf.count; ++i) {
-    const int idx = order[lf.start + i];
+  // the leaf's points in index order, whatever order the tree builder left them in (the one-workgroup forest places them by
+  // atomic counters): the sums below are then the same bits in every run
+  int ids[kLeafMax];
+#pragma unroll
+  for (int i = 0; i < kLeafMax; ++i) ids[i] = i < lf.count ? order[lf.start + i] : 0x7fffffff;
+#pragma unroll
+  for (int a = 1; a < kLeafMax; ++a)
+#pragma unroll
+    for (int c = kLeafMax - 1; c >= a; --c) { const int lo = min(ids[c - 1], ids[c]), hi = max(ids[c - 1], ids[c]); ids[c - 1] = lo; ids[c] = hi; }
+#pragma unroll
+  for (int i = 0; i < kLeafMax; ++i) {
+    if (i >= lf.count) continue;
+    const int idx = ids[i];
     kmin = min(kmin, idx);
     const float4 pf = raw[idx];
     const double p[3] = {pf.x, pf.y, pf.z};
@@ -222,8 +234,10 @@ __global__ void kd_leaf_normals(const float4* raw, ScanSet ss, const int32_t* or
   const int n = lf.count;
   const double mean[3] = {b[0] / n, b[1] / n, b[2] / n};
   double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < lf.count; ++i) {
-    const float4 pf = raw[order[lf.start + i]];
+#pragma unroll
+  for (int i = 0; i < kLeafMax; ++i) {
+    if (i >= lf.count) continue;
+    const float4 pf = raw[ids[i]];
     const double e[3] = {pf.x - mean[0], pf.y - mean[1], pf.z - mean[2]};
     for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) C[3 * a + c] += e[a] * e[c];
   }
@@ -280,6 +294,84 @@ __global__ void kd_emit(const float4* leaf_p, const float4* leaf_n, const unsign
   out_n[o] = leaf_n[l];
 }
 
+// ------------------------------------------------------------------------------------------
+// The same forest with ONE workgroup per scan (kd_median_tree.h: radix select + partition per level, no sort): what a
+// large batch uses.  A level of the sort-based formulation above is 7-8 full radix-sort passes over every (segment,
+// coordinate) key of the batch -- 17 levels of them were two thirds of the sequence driver's wall time -- where
+// cloud_types.cc:122-125 only asks for an nth_element.  One workgroup takes ~10 ms for a 120 k-point scan whatever the
+// batch, so from a few dozen scans on (kForestMinScans) this form wins, and a batch of >= 256 scans fills the chip.
+// Ties on a median value go left by the point's index in its scan (the sort-based form: by the previous level's order);
+// both are legal outcomes of nth_element, and tie-free clouds give identical leaves.
+// ------------------------------------------------------------------------------------------
+constexpr int kForestMinScans = 32;
+
+struct ForestDev {
+  float4 *cur, *oth;             // [cap] working orders (point, .w = index in its scan)
+  uint32_t *sid, *sid_o;         // [cap] segment of every position
+  KdSeg* segs;                   // per scan: 2 x (n / 4 + 8) segments at seg_off[scan]
+  uint2* nodes;                  // per scan: n / 2 + 8 nodes at node_off[scan]
+  uint32_t* cnt;                 // per scan: 2 x (n / 4 + 8) fill counters at seg_off[scan]
+  const int32_t* seg_off;        // [S]
+  const int32_t* node_off;       // [S]
+};
+
+__global__ __launch_bounds__(kKdThreads) void kd_forest_build(const float4* raw, ScanSet ss, ForestDev f, int32_t* order, KdLeaf* leaves,
+                                                              int32_t* counts, int32_t* status) {
+  const int sc = blockIdx.x;
+  const int n = ss.prefix[sc + 1] - ss.prefix[sc];
+  if (n <= 0) return;
+  const int tid = threadIdx.x;
+  const int base = ss.prefix[sc];
+  __shared__ uint32_t s_hist[kKdHistWords];
+  __shared__ uint32_t s_w[17];
+  __shared__ float s_box[6][16];
+  __shared__ uint32_t s_misc[4];
+  float4* cur = f.cur + base;
+  float4* oth = f.oth + base;
+  uint32_t* sid = f.sid + base;
+  uint32_t* sid_o = f.sid_o + base;
+  const int seg_cap = n / 4 + 8, node_cap = n / 2 + 8;
+  KdSeg* seg = f.segs + f.seg_off[sc];
+  KdSeg* seg_o = seg + seg_cap;
+  uint2* nodes = f.nodes + f.node_off[sc];
+  const float4* p0 = raw + ss.offset[sc];
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = tid; i < n; i += kKdThreads) {
+    const float4 p = p0[i];
+    cur[i] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+    sid[i] = 0;
+    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+  }
+  for (int d = 0; d < 3; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+  if ((tid & 63) == 0) for (int d = 0; d < 3; ++d) { s_box[d][tid >> 6] = mn[d]; s_box[3 + d][tid >> 6] = mx[d]; }
+  __syncthreads();
+  if (tid == 0) {
+    KdSeg r{};
+    r.first = 0; r.count = (uint32_t)n; r.node = 0;
+    for (int d = 0; d < 3; ++d) {
+      float a = s_box[d][0], c = s_box[3 + d][0];
+      for (int w = 1; w < kKdThreads / 64; ++w) { a = fminf(a, s_box[d][w]); c = fmaxf(c, s_box[3 + d][w]); }
+      r.mn[d] = a; r.mx[d] = c;
+    }
+    seg[0] = r;
+    s_misc[0] = 1;
+  }
+  __syncthreads();
+  kd_median_build<kLeafMax>(n, cur, oth, sid, sid_o, seg, seg_o, nodes, f.cnt + f.seg_off[sc], seg_cap, node_cap, s_hist, s_w, s_misc, status);
+  __syncthreads();
+  // the leaves (position ranges of the forest) and the permutation: order[position] = index into raw
+  const int nn = (int)s_misc[0];
+  for (int v = tid; v < nn; v += kKdThreads) {
+    const uint2 nd = nodes[v];
+    if ((nd.y & 3u) != 3u) continue;
+    const int slot = atomicAdd(&counts[2], 1);
+    leaves[slot].start = base + (int)nd.x;
+    leaves[slot].count = (int)(nd.y >> 2);
+  }
+  for (int i = tid; i < n; i += kKdThreads) order[base + i] = ss.offset[sc] + __float_as_int(cur[i].w);
+}
+
 }  // namespace
 
 struct PrepWorkspace {
@@ -299,6 +391,13 @@ struct PrepWorkspace {
   int32_t* scan_meta = nullptr;          // device: offset[kMaxScans], prefix[kMaxScans + 1], out_offset[kMaxScans]
   int32_t* host_pinned = nullptr;        // [0..3] counts, then m[kMaxScans], then the scan_meta staging
   float4* avg_cent = nullptr;            // [cap] run centroids of prep_approx_voxel_grid (allocated on first use)
+  int32_t* mb_meta = nullptr;            // prep_morton_sort_batch: device / pinned meta rows, and the event that guards the pinned ones
+  int32_t* mb_host = nullptr;
+  hipEvent_t mb_ev = nullptr;
+  ForestDev forest{};                    // one-workgroup-per-scan forest (allocated on the first batch of >= kForestMinScans scans)
+  int32_t* forest_meta = nullptr;        // device: seg_off[kMaxScans], node_off[kMaxScans]
+  int32_t* forest_status = nullptr;
+  bool forest_ready = false;
 };
 
 
@@ -323,7 +422,7 @@ PrepWorkspace* prep_create(int max_points) {
     w->sort_bytes = bytes + 256;
     A(&w->sort_tmp, w->sort_bytes);
   }
-  if (ok && hipHostMalloc((void**)&w->host_pinned, (size_t)4 * (8 + 4 * kMaxScans + 8)) != hipSuccess) ok = false;
+  if (ok && hipHostMalloc((void**)&w->host_pinned, (size_t)4 * (8 + 6 * kMaxScans + 16)) != hipSuccess) ok = false;
   if (!ok) { prep_destroy(w); return nullptr; }
   return w;
 }
@@ -337,7 +436,12 @@ void prep_destroy(PrepWorkspace* w) {
   (void)hipFree(w->leaves); (void)hipFree(w->counts); (void)hipFree(w->bbox); (void)hipFree(w->m_dev);
   (void)hipFree(w->lstart); (void)hipFree(w->scan_meta);
   (void)hipFree(w->leaf_p); (void)hipFree(w->leaf_n); (void)hipFree(w->sort_tmp); (void)hipFree(w->avg_cent);
+  (void)hipFree(w->forest.cur); (void)hipFree(w->forest.oth); (void)hipFree(w->forest.sid); (void)hipFree(w->forest.sid_o);
+  (void)hipFree(w->forest.segs); (void)hipFree(w->forest.nodes); (void)hipFree(w->forest.cnt); (void)hipFree(w->forest_meta); (void)hipFree(w->forest_status);
   if (w->host_pinned) (void)hipHostFree(w->host_pinned);
+  (void)hipFree(w->mb_meta);
+  if (w->mb_host) (void)hipHostFree(w->mb_host);
+  if (w->mb_ev) (void)hipEventDestroy(w->mb_ev);
   delete w;
 }
 
@@ -421,6 +525,105 @@ hipError_t prep_morton_sort(PrepWorkspace* w, hipStream_t st, const float4* raw,
   size_t bytes = w->sort_bytes;
   PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[0], w->order[1], (unsigned)n, 0, 63, st));
   hipLaunchKernelGGL(morton_gather, dim3(gp), dim3(256), 0, st, raw, w->order[1], n, out);
+  return hipGetLastError();
+}
+
+// ---- S clouds at once -------------------------------------------------------------------------------------------
+namespace {
+struct MortonBatch {
+  int32_t S;
+  const int32_t* stage_off;      // [S] first row of cloud s in the staging array
+  const int32_t* prefix;         // [S + 1] positions of the batch
+  const long long* out_off;      // [S] first element of cloud s's output, relative to out_base
+};
+__global__ __launch_bounds__(1024) void finite_min_batch(const float4* stage, MortonBatch mb, float* bbox /*[S][4]*/) {
+  const int sc = blockIdx.x;
+  const float4* p0 = stage + mb.stage_off[sc];
+  const int n = mb.prefix[sc + 1] - mb.prefix[sc];
+  float mn[3] = {INFINITY, INFINITY, INFINITY};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float4 p = p0[i];
+    if (isfinite(p.x)) mn[0] = fminf(mn[0], p.x);
+    if (isfinite(p.y)) mn[1] = fminf(mn[1], p.y);
+    if (isfinite(p.z)) mn[2] = fminf(mn[2], p.z);
+  }
+  __shared__ float s[16][3];
+  for (int c = 0; c < 3; ++c)
+    for (int off = 32; off > 0; off >>= 1) mn[c] = fminf(mn[c], __shfl_down(mn[c], off, 64));
+  if ((threadIdx.x & 63) == 0) for (int c = 0; c < 3; ++c) s[threadIdx.x >> 6][c] = mn[c];
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float v = s[0][threadIdx.x];
+    for (int w = 1; w < 16; ++w) v = fminf(v, s[w][threadIdx.x]);
+    bbox[4 * sc + threadIdx.x] = isfinite(v) ? v : 0.f;
+  }
+}
+__device__ __forceinline__ int morton_batch_cloud(const MortonBatch& mb, int pos) {
+  int lo = 0, hi = mb.S - 1;                       // last s with prefix[s] <= pos
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (mb.prefix[mid] <= pos) lo = mid; else hi = mid - 1; }
+  return lo;
+}
+__global__ void morton_keys_batch(const float4* stage, MortonBatch mb, int total, const float* bbox, unsigned long long* keys, int32_t* idx) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= total) return;
+  const int sc = morton_batch_cloud(mb, pos);
+  const float4 p = stage[mb.stage_off[sc] + (pos - mb.prefix[sc])];
+  const float inv = 1.0f / 0.0625f;                       // the quantum of morton_keys
+  unsigned long long q[3];
+  const float v[3] = {p.x, p.y, p.z};
+  for (int c = 0; c < 3; ++c) {
+    const float t = (v[c] - bbox[4 * sc + c]) * inv;
+    q[c] = (isfinite(t)) ? (unsigned long long)fminf(fmaxf(t, 0.f), 262143.f) : 0ull;     // 18 bits per axis
+  }
+  keys[pos] = ((unsigned long long)sc << 54) | spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2);
+  idx[pos] = pos;
+}
+__global__ void morton_gather_batch(const float4* stage, MortonBatch mb, int total, const unsigned long long* keys_sorted, const int32_t* idx_sorted,
+                                    float4* out_base) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= total) return;
+  const int sc = (int)(keys_sorted[k] >> 54);                 // clouds are contiguous in cloud order after the sort
+  const int i = idx_sorted[k] - mb.prefix[sc];                // the row's index in its own cloud
+  float4 p = stage[mb.stage_off[sc] + i];
+  p.w = __int_as_float(i);                                    // the caller's index rides along
+  out_base[mb.out_off[sc] + (k - mb.prefix[sc])] = p;
+}
+}  // namespace
+
+hipError_t prep_morton_sort_batch(PrepWorkspace* w, hipStream_t st, const float4* stage, int S, const int* stage_off, const int* n,
+                                  const long long* out_off, float4* out_base) {
+  if (!w || S <= 0 || S > kMaxScans) return hipErrorInvalidValue;
+  if (!w->mb_meta) {
+    if (hipMalloc((void**)&w->mb_meta, sizeof(int32_t) * (2 * kMaxScans + 2) + sizeof(long long) * kMaxScans + 16) != hipSuccess) return hipErrorOutOfMemory;
+    if (hipHostMalloc((void**)&w->mb_host, sizeof(int32_t) * (2 * kMaxScans + 2) + sizeof(long long) * kMaxScans + 16) != hipSuccess) return hipErrorOutOfMemory;
+  }
+  // the staging of the meta rows is re-used by the next call: the previous copy must have left the host
+  if (w->mb_ev) { PCHK(hipEventSynchronize(w->mb_ev)); } else { PCHK(hipEventCreateWithFlags(&w->mb_ev, hipEventDisableTiming)); }
+  int32_t* h_off = w->mb_host;
+  int32_t* h_pre = w->mb_host + kMaxScans;
+  long long* h_out = reinterpret_cast<long long*>(w->mb_host + 2 * kMaxScans + 2);
+  long long total = 0;
+  for (int s2 = 0; s2 < S; ++s2) {
+    if (n[s2] <= 0) return hipErrorInvalidValue;
+    h_off[s2] = stage_off[s2]; h_pre[s2] = (int32_t)total; h_out[s2] = out_off[s2];
+    total += n[s2];
+  }
+  h_pre[S] = (int32_t)total;
+  if (total > w->cap) return hipErrorInvalidValue;
+  const size_t meta_bytes = sizeof(int32_t) * (2 * kMaxScans + 2) + sizeof(long long) * kMaxScans;
+  PCHK(hipMemcpyAsync(w->mb_meta, w->mb_host, meta_bytes, hipMemcpyHostToDevice, st));
+  PCHK(hipEventRecord(w->mb_ev, st));
+  MortonBatch mb;
+  mb.S = S; mb.stage_off = w->mb_meta; mb.prefix = w->mb_meta + kMaxScans;
+  mb.out_off = reinterpret_cast<const long long*>(w->mb_meta + 2 * kMaxScans + 2);
+  const int N = (int)total, gp = (N + 255) / 256;
+  hipLaunchKernelGGL(finite_min_batch, dim3(S), dim3(1024), 0, st, stage, mb, w->bbox);
+  hipLaunchKernelGGL(morton_keys_batch, dim3(gp), dim3(256), 0, st, stage, mb, N, w->bbox, w->keys[0], w->order[0]);
+  int id_bits = 1;
+  while ((1 << id_bits) < S) ++id_bits;
+  size_t bytes = w->sort_bytes;
+  PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[0], w->order[1], (unsigned)N, 0, (unsigned)(54 + id_bits), st));
+  hipLaunchKernelGGL(morton_gather_batch, dim3(gp), dim3(256), 0, st, stage, mb, N, w->keys[1], w->order[1], out_base);
   return hipGetLastError();
 }
 
@@ -568,6 +771,22 @@ hipError_t prep_approx_voxel_grid(PrepWorkspace* w, hipStream_t st, const float4
   return hipGetLastError();
 }
 
+// the arrays of the one-workgroup-per-scan forest (batches of >= kForestMinScans scans), allocated on first use or ahead of it
+hipError_t prep_reserve_forest(PrepWorkspace* w) {
+  if (!w) return hipErrorInvalidValue;
+  if (w->forest_ready) return hipSuccess;
+  const size_t C = (size_t)w->cap, SG = 2 * (C / 4 + 8 * (size_t)kMaxScans), ND = C / 2 + 8 * (size_t)kMaxScans;
+  const bool ok = hipMalloc((void**)&w->forest.cur, C * 16) == hipSuccess && hipMalloc((void**)&w->forest.oth, C * 16) == hipSuccess &&
+                  hipMalloc((void**)&w->forest.sid, C * 4) == hipSuccess && hipMalloc((void**)&w->forest.sid_o, C * 4) == hipSuccess &&
+                  hipMalloc((void**)&w->forest.segs, SG * sizeof(KdSeg)) == hipSuccess && hipMalloc((void**)&w->forest.nodes, ND * sizeof(uint2)) == hipSuccess &&
+                  hipMalloc((void**)&w->forest.cnt, SG * 4) == hipSuccess && hipMalloc((void**)&w->forest_meta, sizeof(int32_t) * 2 * kMaxScans) == hipSuccess &&
+                  hipMalloc((void**)&w->forest_status, 4) == hipSuccess;
+  if (!ok) return hipErrorOutOfMemory;
+  w->forest.seg_off = w->forest_meta; w->forest.node_off = w->forest_meta + kMaxScans;
+  w->forest_ready = true;
+  return hipSuccess;
+}
+
 // S scans at once: scan s = raw[offset[s] .. offset[s] + n[s]), results to out_p/out_n[out_offset[s] ..], m_host[s] survivors.
 hipError_t prep_calculate_normals_batch(PrepWorkspace* w, hipStream_t st, const float4* raw, int S, const int* offset, const int* n,
                                         const int* out_offset, float4* out_p, float4* out_n, int* m_host) {
@@ -592,10 +811,25 @@ hipError_t prep_calculate_normals_batch(PrepWorkspace* w, hipStream_t st, const 
   const int32_t* d_out_offset = w->scan_meta + 2 * kMaxScans + 1;
   const int N = (int)total;
   const int gp = (N + 255) / 256;
+  int cur = 0;
+  const bool use_forest = S >= kForestMinScans;
+  if (use_forest) {
+    // one workgroup per scan, no sorts: the leaves and the permutation come out of one launch
+    PCHK(prep_reserve_forest(w));
+    int32_t* h_f = h_meta + 3 * kMaxScans + 2;           // staging behind the scan meta
+    long long so = 0, no = 0;
+    for (int s2 = 0; s2 < S; ++s2) {
+      h_f[s2] = (int32_t)so; h_f[kMaxScans + s2] = (int32_t)no;
+      so += 2ll * (n[s2] / 4 + 8); no += n[s2] / 2 + 8;
+    }
+    PCHK(hipMemcpyAsync(w->forest_meta, h_f, sizeof(int32_t) * 2 * kMaxScans, hipMemcpyHostToDevice, st));
+    PCHK(hipMemsetAsync(w->counts, 0, 16, st));
+    PCHK(hipMemsetAsync(w->forest_status, 0, 4, st));
+    hipLaunchKernelGGL(kd_forest_build, dim3(S), dim3(kKdThreads), 0, st, raw, ss, w->forest, w->order[0], w->leaves, w->counts, w->forest_status);
+  } else {
   hipLaunchKernelGGL(kd_bbox, dim3(S), dim3(1024), 0, st, raw, ss, w->bbox);
   hipLaunchKernelGGL(kd_init, dim3(gp), dim3(256), 0, st, ss, N, w->order[0], w->seg[0], w->node_at[0], w->nodes[0], w->counts, w->bbox, w->leaves);
   hipLaunchKernelGGL(kd_roots, dim3((S + 63) / 64), dim3(64), 0, st, ss, w->node_at[0], w->nodes[0], w->counts, w->bbox, w->leaves);
-  int cur = 0;
   // depth <= ceil(log2(n / 4)) + 1; a fixed number of levels runs (extra levels are no-ops: zero active nodes)
   int levels = 1;
   while (((long long)kLeafMax << levels) < (long long)nmax * 2) ++levels;
@@ -616,6 +850,7 @@ hipError_t prep_calculate_normals_batch(PrepWorkspace* w, hipStream_t st, const 
     hipLaunchKernelGGL(kd_update_seg, dim3(gp), dim3(256), 0, st, N, w->seg[cur], w->node_at[cur], w->nodes[cur], w->seg[nxt]);
     hipLaunchKernelGGL(kd_advance, dim3(1), dim3(1), 0, st, w->counts);
     cur = nxt;
+  }
   }
   // leaves -> (mean, normal), ordered per scan by the smallest original index of the leaf (cloud_types.cc:358)
   const int max_leaves = N / 2 + 16;

@@ -50,7 +50,7 @@ struct Args {
   std::string scans_dir, out_path = "kitti_pose.txt", id_file;
   unsigned long long nonce = 0;             // identifies this run's id file (launcher: pid and start time; else MASTER_PORT)
   int gpus = 1, rank = -1, world = -1, local_rank = -1;
-  int batch = 64, iterations = 20, early_exit = 0, max_pairs = -1, readers = 4;
+  int batch = 256, iterations = 20, early_exit = 0, max_pairs = -1, readers = 8;
   double guess_tx = 0.0;
   bool quiet = false;
 };
@@ -100,8 +100,8 @@ Args Parse(int argc, char** argv) {
     else if (k == "--readers") a.readers = std::atoi(val().c_str());
     else if (k == "--guess-tx") a.guess_tx = std::atof(val().c_str());
     else if (k == "--quiet") a.quiet = true;
-    else Die("unknown argument " + k + "\nusage: smhip_shard --scans DIR [--gpus G] [--out kitti_pose.txt] [--batch 64] "
-             "[--iterations 20] [--early-exit 0|1] [--guess-tx metres] [--max-pairs N] [--readers 4]");
+    else Die("unknown argument " + k + "\nusage: smhip_shard --scans DIR [--gpus G] [--out kitti_pose.txt] [--batch 256] "
+             "[--iterations 20] [--early-exit 0|1] [--guess-tx metres] [--max-pairs N] [--readers 8]");
   }
   if (a.scans_dir.empty()) Die("--scans DIR is required");
   if (a.rank < 0 && std::getenv("RANK")) a.rank = std::atoi(std::getenv("RANK"));
@@ -162,11 +162,15 @@ int RunRank(const Args& a, int rank, int world, int device) {
 
   hipStream_t stream;
   HIPOK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-  const int B = std::max(1, std::min(a.batch, per));
+  const int B = std::max(1, std::min(std::min(a.batch, 256), per));     // one batched upload holds up to 2 B <= 512 scans
   smhip_handle h = nullptr;
-  // capacity: a KITTI scan holds at most 250 000 points (1 000 000 floats per file).  Slots [0, B) hold the pairs of a
-  // batch, slots [B, 2 B) park target scans that no pair of the batch holds as its source already.
-  const int cap = static_cast<int>(kMaxFloatsPerFile / 4);
+  // capacity: the largest scan of the directory (a KITTI scan holds at most 250 000 points: 1 000 000 floats per file are
+  // read, kitti_reader.cc:93).  Slots [0, B) hold the pairs of a batch, slots [B, 2 B) park target scans that no pair of the
+  // batch holds as its source already.
+  size_t max_bytes = 16;
+  for (const auto& f : files) { struct stat sb; if (stat(f.c_str(), &sb) == 0) max_bytes = std::max(max_bytes, static_cast<size_t>(sb.st_size)); }
+  const size_t slot_floats = std::min(kMaxFloatsPerFile, (max_bytes / 16 + 1) * 4);
+  const int cap = static_cast<int>(slot_floats / 4);
   smhip_status s = smhip_create(device, stream, 2 * B, cap, cap, &h);
   if (s != SMHIP_OK) Die(std::string("smhip_create: ") + smhip_status_string(s) + " (is this a gfx950 GPU? there is no CPU fallback)");
   smhip_icp_options o;
@@ -188,7 +192,22 @@ int RunRank(const Args& a, int rank, int world, int device) {
 
   // the files this rank reads, in reading order (the same walk as the loop below)
   const std::vector<int> order = smhip::kitti::ShardReadOrder(n_pairs, world, rank, B);
-  ScanPrefetcher scans(files, order, a.readers, 4 * std::max(1, a.readers) + 8);
+  // The readers fill page-locked buffers and the batch's uploads are DMA'd straight out of them (no staging copy): a
+  // buffer is held from Next() until the uploads of its batch have left the host (ReleaseHeld), so the ring holds two
+  // batches' worth of scans -- one being uploaded, one being read ahead.
+  const int scans_per_batch = world == 1 ? B + 1 : 2 * B;
+  const int ring = 2 * scans_per_batch + std::max(1, a.readers);
+  std::vector<float*> ring_buffers(ring, nullptr);
+  bool pinned = true;
+  for (int k = 0; k < ring && pinned; ++k)
+    if (hipHostMalloc(reinterpret_cast<void**>(&ring_buffers[k]), slot_floats * sizeof(float), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pinned = false; }
+  std::vector<std::vector<float>> pageable;                  // the host refused that much page-locked memory: ordinary buffers, staged uploads
+  if (!pinned) {
+    for (float*& b : ring_buffers) { if (b) (void)hipHostFree(b); b = nullptr; }
+    pageable.assign(ring, std::vector<float>(slot_floats));
+    for (int k = 0; k < ring; ++k) ring_buffers[k] = pageable[k].data();
+  }
+  ScanPrefetcher scans(files, order, a.readers, ring_buffers, slot_floats, /*hold_until_release=*/true);
   auto next_scan = [&](int expect, int* n) -> const float* {
     int fi = -1;
     const float* rows = scans.Next(n, &fi);
@@ -196,37 +215,52 @@ int RunRank(const Args& a, int rank, int world, int device) {
     if (*n < 0) Die("cannot read " + files[fi]);
     return rows;
   };
+  if (smhip_reserve_batch_workspaces(h) != SMHIP_OK) Die(smhip_last_error(h));     // not inside the first batch
+  HIPOK(hipStreamSynchronize(stream));
   const auto t0 = std::chrono::steady_clock::now();
-  double upload_s = 0.0;
+  double upload_s = 0.0, wait_s = 0.0, set_s = 0.0, prep_s = 0.0;   // rank 0's host-side split: blocked on the readers / uploads / target preparation
+  auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
   int done = 0, my_pairs = 0;
+  std::vector<int> up_slots, up_n;
+  std::vector<const float*> up_rows;
   for (int base = 0; base < per; base += B) {
     int nb = 0;
     const auto u0 = std::chrono::steady_clock::now();
     std::vector<int> from, to, nts;
+    up_slots.clear(); up_n.clear(); up_rows.clear();
     int prev_pair = -2;
+    auto w0 = std::chrono::steady_clock::now();
     for (int k = 0; k < B && base + k < per; ++k) {
       const int pair = (base + k) * world + rank;                        // round-robin: pair i -> rank i mod G
       if (pair >= n_pairs) break;
-      // scan i = target.  When the previous slot's pair is i - 1 its source IS scan i, already on the device (one GPU:
-      // every pair but the first of a batch); otherwise the scan is parked in slot B + k.  Either way the targets of the
-      // whole batch are prepared in ONE device pass (CalculateNormals as a kd forest: one sort per tree level for all).
+      // scan i = target.  When the previous slot's pair is i - 1 its source IS scan i, already part of this upload (one GPU:
+      // every pair but the first of a batch); otherwise the scan is parked in slot B + k.  Either way the scans of the whole
+      // batch go up in ONE call and its targets are prepared in ONE device pass (CalculateNormals as a forest of kd-trees).
       if (pair == prev_pair + 1) from.push_back(k - 1);
       else {
         int n = 0;
-        const float* rows = next_scan(pair, &n);
-        if (smhip_set_source_f32(h, B + k, rows, 4, n) != SMHIP_OK) Die(std::string("target ") + files[pair] + ": " + smhip_last_error(h));
+        up_rows.push_back(next_scan(pair, &n)); up_slots.push_back(B + k); up_n.push_back(n);
         from.push_back(B + k);
       }
       to.push_back(k);
       int n = 0;
-      const float* rows = next_scan(pair + 1, &n);                       // scan i + 1 = source
-      if (smhip_set_source_f32(h, k, rows, 4, n) != SMHIP_OK) Die(std::string("source ") + files[pair + 1] + ": " + smhip_last_error(h));
+      up_rows.push_back(next_scan(pair + 1, &n)); up_slots.push_back(k); up_n.push_back(n);   // scan i + 1 = source
       prev_pair = pair;
       ++nb;
     }
+    wait_s += since(w0);
     if (nb == 0) break;
+    w0 = std::chrono::steady_clock::now();
+    if (smhip_set_sources_f32_batch(h, static_cast<int>(up_slots.size()), up_slots.data(), up_rows.data(), up_n.data()) != SMHIP_OK)
+      Die(std::string("upload of batch at pair ") + std::to_string(base * world + rank) + ": " + smhip_last_error(h));
+    set_s += since(w0);
     nts.resize(nb);
-    if (smhip_prepare_targets_from_sources(h, nb, from.data(), to.data(), nts.data()) != SMHIP_OK) Die(std::string("prepare targets: ") + smhip_last_error(h));
+    {
+      w0 = std::chrono::steady_clock::now();
+      if (smhip_prepare_targets_from_sources(h, nb, from.data(), to.data(), nts.data()) != SMHIP_OK) Die(std::string("prepare targets: ") + smhip_last_error(h));
+      prep_s += since(w0);
+    }
+    scans.ReleaseHeld();            // prepare_targets blocked on the stream: the uploads have left the host buffers
     upload_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - u0).count();
     if (smhip_icp_enqueue_batch(h, nb, guesses.data()) != SMHIP_OK) Die(std::string("enqueue: ") + smhip_last_error(h));
     if (smhip_icp_export_results_device(h, nb, local_dev + static_cast<size_t>(kPoseDoubles) * base) != SMHIP_OK) Die(smhip_last_error(h));
@@ -266,14 +300,16 @@ int RunRank(const Args& a, int rank, int world, int device) {
     out.close();
     if (!a.quiet || bad) {
       std::printf("{\"driver\": \"smhip_shard (C++, RCCL all-gather)\", \"n_gpus\": %d, \"pairs\": %d, \"pairs_rank0\": %d, \"seconds\": %.4f, "
-                  "\"pairs_per_s\": %.2f, \"read_upload_prepare_s_rank0\": %.4f, \"mean_score\": %.6f, \"mean_iterations\": %.2f, "
-                  "\"unfinished_pairs\": %d, \"poses_file\": \"%s\"}\n",
-                  world, n_pairs, my_pairs, elapsed, n_pairs / elapsed, upload_s, score_sum / n_pairs, iter_sum / n_pairs, bad, a.out_path.c_str());
+                  "\"pairs_per_s\": %.2f, \"read_upload_prepare_s_rank0\": %.4f, \"wait_for_readers_s_rank0\": %.4f, \"upload_s_rank0\": %.4f, "
+                  "\"prepare_targets_s_rank0\": %.4f, \"mean_score\": %.6f, \"mean_iterations\": %.2f, "
+                  "\"unfinished_pairs\": %d, \"batch\": %d, \"readers\": %d, \"pinned_read_buffers\": %s, \"poses_file\": \"%s\"}\n",
+                  world, n_pairs, my_pairs, elapsed, n_pairs / elapsed, upload_s, wait_s, set_s, prep_s, score_sum / n_pairs, iter_sum / n_pairs, bad, B, a.readers, pinned ? "true" : "false", a.out_path.c_str());
     }
     if (bad) rc = 3;
   }
   (void)hipFree(local_dev); (void)hipFree(all_dev);
   smhip_destroy(h);
+  if (pinned) for (float* b : ring_buffers) (void)hipHostFree(b);
   NCCLOK(ncclCommDestroy(comm));
   (void)hipStreamDestroy(stream);
   return rc;

@@ -35,6 +35,7 @@ struct smhip_context {
   PrepWorkspace* prep_batch = nullptr;    // the same sized for every slot at once (batched target preparation)
   FilterWorkspace* filt = nullptr;        // device pre-filters (allocated on first use)
   float4* prep_raw = nullptr;             // raw scan staging on the device
+  float4* raw_batch = nullptr;            // the same for a whole batch of scans (smhip_set_sources_f32_batch; allocated on first use)
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -702,6 +703,67 @@ smhip_status smhip_set_source_f32(smhip_handle h, int slot, const float* xyz, in
   if (stride == 4) std::memcpy(h->stage, xyz, sizeof(float4) * (size_t)n);      // KITTI rows are already float4 (w is overwritten on the device)
   else for (int i = 0; i < n; ++i) h->stage[i] = make_float4(xyz[(size_t)stride * i], xyz[(size_t)stride * i + 1], xyz[(size_t)stride * i + 2], 0.f);
   return upload_source(h, slot, n);
+}
+
+smhip_status smhip_reserve_batch_workspaces(smhip_handle h) {
+  if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->prep_batch) {
+    h->prep_batch = prep_create(h->dev.slots * h->dev.ns_cap);
+    if (!h->prep_batch) { h->err = "batch workspace allocation failed"; return SMHIP_ERR_HIP; }
+  }
+  if (prep_reserve_forest(h->prep_batch) != hipSuccess) { h->err = "batch workspace allocation failed (CalculateNormals forest)"; return SMHIP_ERR_HIP; }
+  if (!h->raw_batch) {
+    smhip_status s = dev_alloc(h, &h->raw_batch, (size_t)h->dev.slots * h->dev.ns_cap);
+    if (s) return s;
+  }
+  return SMHIP_OK;
+}
+
+smhip_status smhip_set_sources_f32_batch(smhip_handle h, int count, const int* slots, const float* const* rows, const int* n) {
+  if (!h || !slots || !rows || !n || count < 1 || count > h->dev.slots || count > 512) { if (h) h->err = "bad batch of sources"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  long long total = 0;
+  for (int k = 0; k < count; ++k) {
+    smhip_status s = check_slot(h, slots[k]);
+    if (s) return s;
+    if (!rows[k] || n[k] <= 0) { h->err = "empty source cloud"; return SMHIP_ERR_INVALID_ARGUMENT; }
+    if (n[k] > h->dev.ns_cap) { h->err = "source larger than max_source_points"; return SMHIP_ERR_CAPACITY; }
+    total += n[k];
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->prep_batch) {
+    h->prep_batch = prep_create(h->dev.slots * h->dev.ns_cap);
+    if (!h->prep_batch) { h->err = "batched upload workspace allocation failed"; return SMHIP_ERR_HIP; }
+  }
+  if (!h->raw_batch) {
+    smhip_status s = dev_alloc(h, &h->raw_batch, (size_t)h->dev.slots * h->dev.ns_cap);
+    if (s) return s;
+  }
+  // rows -> the device staging array, cloud after cloud.  Pinned rows are copied from where they lie (no host copy, the call
+  // returns at once); pageable rows go through the handle's one pinned buffer, which must have left the host before it is
+  // filled again.
+  std::vector<int> stage_off(count);
+  std::vector<long long> out_off(count);
+  long long at = 0;
+  for (int k = 0; k < count; ++k) {
+    stage_off[k] = (int)at;
+    out_off[k] = (long long)slots[k] * h->dev.ns_cap;
+    hipPointerAttribute_t attr{};
+    const bool pinned = hipPointerGetAttributes(&attr, rows[k]) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError();
+    const void* from = rows[k];
+    if (!pinned) {
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      std::memcpy(h->stage, rows[k], sizeof(float4) * (size_t)n[k]);
+      from = h->stage;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->raw_batch + at, from, sizeof(float4) * (size_t)n[k], hipMemcpyHostToDevice, h->stream));
+    at += n[k];
+  }
+  const hipError_t e = prep_morton_sort_batch(h->prep_batch, h->stream, h->raw_batch, count, stage_off.data(), n, out_off.data(), const_cast<float4*>(h->dev.src));
+  if (e != hipSuccess) { h->err = std::string("prep_morton_sort_batch: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
+  for (int k = 0; k < count; ++k) { h->ns[slots[k]] = n[k]; touch_source(h, slots[k]); }
+  return SMHIP_OK;
 }
 
 smhip_status smhip_set_target_f64(smhip_handle h, int slot, const double* xyz, const double* nrm, int n) {

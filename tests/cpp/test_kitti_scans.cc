@@ -85,6 +85,31 @@ int main(int argc, char** argv) {
     int n = 0, fi = 0;
     EXPECT(pf.Next(&n, &fi) != nullptr);
   }
+  {   // hold-until-release over caller-owned buffers (the driver's page-locked ring): every scan handed out since the last
+      // ReleaseHeld() keeps its contents while the readers run ahead in the remaining buffers; short buffers truncate the file
+    const size_t slot_floats = 4 * 600;                                   // room for 600 points
+    std::vector<std::vector<float>> store(7, std::vector<float>(slot_floats));
+    std::vector<float*> bufs;
+    for (auto& v : store) bufs.push_back(v.data());
+    std::vector<int> ord = {4, 5, 6, 7, 8, 9, 10, 11, 0, 4, 5, 6};         // files 4.. hold 407 .. 1107 points, file 0 1000
+    smhip::kitti::ScanPrefetcher pf(files, ord, 3, bufs, slot_floats, /*hold_until_release=*/true);
+    size_t at = 0;
+    while (at < ord.size()) {
+      std::vector<const float*> held;
+      std::vector<int> held_k;
+      for (int b = 0; b < 3 && at < ord.size(); ++b, ++at) {              // a "batch" of three scans, all held at once
+        int n = -2, fi = -2;
+        const float* rows = pf.Next(&n, &fi);
+        EXPECT(rows != nullptr && fi == ord[at]);
+        EXPECT(n == static_cast<int>(std::min(floats[ord[at]], slot_floats) / 4));
+        held.push_back(rows); held_k.push_back(ord[at]);
+      }
+      for (size_t b = 0; b < held.size(); ++b) EXPECT(held[b][0] == static_cast<float>(1000.0 * held_k[b]) && held[b][5] == static_cast<float>(1000.0 * held_k[b] + 5));
+      pf.ReleaseHeld();
+    }
+    int n = 0, fi = 0;
+    EXPECT(pf.Next(&n, &fi) == nullptr);
+  }
   {   // nothing planned
     smhip::kitti::ScanPrefetcher pf(files, {}, 2, 2);
     int n = 0, fi = 0;

@@ -80,3 +80,51 @@ def test_batched_preparation_equals_single_calls(velo20k, cfg2):
         p2, n2 = m.get_target(int(Ms[k]), slot=3 + k)
         assert np.array_equal(p1, p2) and np.array_equal(n1, n2)
     m.close()
+
+
+def test_large_batch_forest_equals_single_calls_and_the_oracle(cfg2, capsys):
+    """From 32 scans on a batch is prepared by the one-workgroup-per-scan forest (radix select + partition per level,
+    kd_median_tree.h) instead of the sort-per-level one: on tie-free scans both give the same leaves as each other and as the
+    oracle (cloud_types.cc:105-144), scan by scan, for scans of different sizes."""
+    import time
+    import staticmapping_amd as sm
+    from oracle import cref
+    rng = np.random.default_rng(7)
+    base = cfg2["tgt"]
+    scans = []
+    for k in range(32):
+        n = 20_000 + 1_250 * k                                   # 20 000 .. 58 750 points
+        sc = base[rng.choice(len(base), size=n, replace=False)].copy()
+        sc[:, :3] += rng.normal(0, 2e-5, (n, 3)).astype(np.float32)     # no ties on a cut coordinate
+        sc[:, 0] += 0.37 * k
+        scans.append(np.ascontiguousarray(sc))
+    cap = max(len(s) for s in scans)
+    m = sm.IcpFastHip(pair_slots=64, max_source_points=cap, max_target_points=cap // 4 + 64)
+    for k, sc in enumerate(scans):
+        m.set_input_source(sc, slot=k)
+    m.prepare_targets_from_sources(list(range(32)), list(range(32, 64)))       # first call: workspace allocation
+    m.synchronize()
+    t0 = time.perf_counter()
+    Ms = m.prepare_targets_from_sources(list(range(32)), list(range(32, 64)))
+    dt = time.perf_counter() - t0
+
+    def canon(p, nrm):
+        o = np.lexsort((p[:, 2], p[:, 1], p[:, 0]))
+        return p[o], nrm[o]
+    for k in (0, 13, 31):
+        pb, nb = canon(*m.get_target(int(Ms[k]), slot=32 + k))
+        M1 = m.prepare_target_from_source(k, k)                                # the sort-per-level form (one scan)
+        p1, n1 = canon(*m.get_target(M1, slot=k))
+        assert M1 == Ms[k]
+        assert np.abs(pb - p1).max() < 1e-5
+        well = np.abs(nb - n1).max(axis=1) < 1e-3                              # ill-conditioned leaves aside (unconstrained LS normal)
+        assert well.mean() > 0.995
+    q, n, _ = cref.calculate_normals(scans[31][:, :3].astype(np.float64))
+    ok = np.isfinite(n).all(axis=1)
+    pb, nb = m.get_target(int(Ms[31]), slot=63)
+    assert abs(len(pb) - ok.sum()) <= 2
+    d, _ = _match_sets(pb.astype(np.float64), nb, q[ok], n[ok])
+    assert (d < 1e-4).mean() > 0.995
+    with capsys.disabled():
+        print(f"\n[forest] 32 scans ({sum(len(s) for s in scans)} points) prepared in {dt * 1e3:.2f} ms = {dt * 1e3 / 32:.3f} ms per scan")
+    m.close()

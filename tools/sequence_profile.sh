@@ -3,10 +3,10 @@
 set -u
 export TMPDIR=/tmp
 R=$PWD
-N=${N:-641}
+N=${N:-513}
 python tools/make_drive.py /tmp/drive_p $N 120000 --cuda 2>&1 | tail -1
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/seq_prof -o seq -- $R/staticmapping_amd/lib/smhip_shard --scans /tmp/drive_p --gpus 1 --batch 64 --guess-tx 0.8 --iterations 20 --out /tmp/kp.txt > $R/gpurun_out/seq_prof.json 2> $R/gpurun_out/seq_prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/seq_prof -o seq -- $R/staticmapping_amd/lib/smhip_shard --scans /tmp/drive_p --gpus 1 --guess-tx 0.8 --iterations 20 --out /tmp/kp.txt > $R/gpurun_out/seq_prof.json 2> $R/gpurun_out/seq_prof.err
 cd $R
 tail -1 gpurun_out/seq_prof.json | cut -c1-300
 python - <<PY

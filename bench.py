@@ -414,7 +414,7 @@ def main():
         out["single_pair"] = single_pair_latency(work[0], local_rank)
         out["other_workloads"] = other_workloads(dev, not args.no_cpu_baseline)
         if not args.no_end_to_end:
-            out["end_to_end"] = end_to_end(dev)
+            out["end_to_end"] = end_to_end(dev, n_scans=1025)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -741,6 +741,49 @@ def other_workloads(dev, with_cpu):
         m.close()
     except Exception as e:
         out["ndt_gicp"] = {"error": repr(e)}
+    # ---- the static-map output: MultiResolutionVoxelMap::InsertPointCloud per frame (builder/map_builder.cc:832-900)
+    try:
+        from staticmapping_amd import synth
+        poses = synth.drive_poses(5, seed=5, speed=8.0)
+        scene = synth.make_drive_scene(poses, seed=5)
+        frames = []
+        for k, P in enumerate(poses):
+            sc = synth.velodyne_scan(synth.scene_near(scene, P[:3, 3]), P, seed=700 + k, n_points=N_POINTS, device=dev)
+            w = (sc[:, :3].astype(np.float64) @ P[:3, :3].T + P[:3, 3]).astype(np.float32)
+            frames.append((np.ascontiguousarray(np.concatenate([w, np.round(sc[:, 3:4] * 255), np.zeros((len(sc), 1), np.float32)], axis=1).astype(np.float32)),
+                           P[:3, 3].astype(np.float32)))
+        m = sm.MultiResolutionVoxelMapHip(table_log2=22, max_cloud_points=N_POINTS)
+        m.insert_point_cloud(*frames[0])
+        t = time.perf_counter()
+        for f in frames[1:]:
+            m.insert_point_cloud(*f)
+        dt = (time.perf_counter() - t) / (len(frames) - 1)
+        res = 0.1
+        steps = float(np.mean([np.abs(np.floor(f[0][:, :3] / res) - np.floor(f[1] / res)).max(axis=1).sum() for f in frames[1:]]))
+        entry = {"workload": "static-map output: MultiResolutionVoxelMap::InsertPointCloud of 120k-pt frames (0.1 m voxels, hit 0.55 / miss 0.48, "
+                             "10 points per voxel), host rows in, map resident on the device",
+                 "value": round(1.0 / dt, 2), "unit": "frames/s", "ms_per_frame": round(dt * 1e3, 3), "voxels": m.voxel_count(),
+                 "ray_voxel_visits_per_frame": steps, "ray_voxel_visits_per_s": round(steps / dt, 1)}
+        if with_cpu:
+            from oracle import cref
+            o = cref.Mrvm()
+            o.insert(*frames[0])
+            t = time.perf_counter()
+            for f in frames[1:]:
+                o.insert(*f)
+            t_cpu = (time.perf_counter() - t) / (len(frames) - 1)
+            kd, pd, md, nd, qd = m.dump()
+            ko, po, mo, no, qo = o.dump()
+            entry["parity"] = {"identical_map": bool(np.array_equal(kd, ko) and np.array_equal(pd, po) and np.array_equal(md, mo) and np.array_equal(nd, no) and np.array_equal(qd, qo)),
+                               "voxels_oracle": int(len(ko))}
+            entry["cpu_baseline"] = {"value": round(1.0 / t_cpu, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                                     "sample": "the same frames through oracle/csrc/smref_mrvm.c: the reference's insert loop in point order, 1 thread "
+                                               "(the reference's OpenMP form races on the probabilities and has no defined result)"}
+            o.close()
+        m.close()
+        out["mrvm"] = entry
+    except Exception as e:
+        out["mrvm"] = {"error": repr(e)}
     return out
 
 

@@ -383,6 +383,42 @@ smhip_status smhip_filter_get_output(smhip_handle h, float* points5, int32_t* so
 /* the filtered cloud becomes SetInputSource of `slot` without leaving the device */
 smhip_status smhip_filter_output_to_source(smhip_handle h, int slot);
 
+/* ---- static_map::MultiResolutionVoxelMap (builder/multi_resolution_voxel_map.{h,cc}) ----------
+ * The probabilistic hit / miss voxel map with ray casting behind the reference's static-map output (one
+ * InsertPointCloud per frame, builder/map_builder.cc:832-900), on the device.  Results equal the reference's insert loop
+ * executed in point order (its OpenMP form races on the probabilities, multi_resolution_voxel_map.cc:76-94).
+ * Field names and defaults: MrvmSettings, multi_resolution_voxel_map.h:54-65. */
+typedef struct smhip_mrvm_settings {
+  float prob_threshold;          /* 0.6 */
+  float high_resolution;         /* 0.1 m voxels */
+  float hit_prob;                /* 0.55, clamped to [0.501, 0.9] (.cc:50) */
+  float miss_prob;               /* 0.48, clamped to [0.1, 0.499] (.cc:51) */
+  float z_offset;                /* added to the origin's z (.cc:66-67) */
+  int32_t max_point_num_in_cell; /* 10 */
+  int32_t use_max_intensity;     /* 1: output points carry their voxel's max intensity (.cc:160-163) */
+  int32_t reserved;
+} smhip_mrvm_settings;
+typedef struct smhip_mrvm_context* smhip_mrvm_handle;
+void smhip_mrvm_default_settings(smhip_mrvm_settings* s);
+/* table_log2: the open-addressing voxel table holds 2^table_log2 voxels (inserts fail with SMHIP_ERR_CAPACITY beyond 70 %);
+ * max_cloud_points: the largest cloud one InsertPointCloud may hand over */
+smhip_status smhip_mrvm_create(int device, int table_log2, int max_cloud_points, const smhip_mrvm_settings* settings, smhip_mrvm_handle* out);
+smhip_status smhip_mrvm_destroy(smhip_mrvm_handle h);
+const char* smhip_mrvm_last_error(smhip_mrvm_handle h);
+void smhip_mrvm_set_offset_z(smhip_mrvm_handle h, float offset);                         /* SetOffsetZ, .cc:55-57 */
+/* InsertPointCloud(cloud, origin), .cc:59-131: n rows of `stride_floats` >= 4 floats (x y z intensity [factor]: InnerPointType is
+ * stride 5), origin = the sensor position of the frame.  Non-finite points are skipped. */
+smhip_status smhip_mrvm_insert_f32(smhip_mrvm_handle h, const float* points, int stride_floats, int n, const float origin[3]);
+smhip_status smhip_mrvm_voxel_count(smhip_mrvm_handle h, int* n);
+/* OutputToPointCloud(threshold, PointXYZI cloud) without averaging, .cc:133-170: rows x y z intensity of every stored point of
+ * every voxel with probability byte >= uint8(threshold * 256), in no particular order (the reference iterates an unordered
+ * map).  capacity = 0 only counts. */
+smhip_status smhip_mrvm_output(smhip_mrvm_handle h, float threshold, float* xyzi, int capacity, int* n_out);
+/* parity-test hook: every voxel of the map -- key (3 ints), probability byte, max intensity, number of stored points and
+ * the points themselves (max_point_num_in_cell x 5 floats per voxel), in no particular order */
+smhip_status smhip_mrvm_dump(smhip_mrvm_handle h, int32_t* keys3, uint8_t* prob, int32_t* max_intensity, int32_t* npoints, float* points5,
+                             int capacity, int* n_out);
+
 /* ---- profiling ----------------------------------------------------------- */
 /* enable: 0 off, 1 events around every launch; events around ONE kernel class only, cheap enough to leave on inside a timed
  * region: 2 the NN kernels proper (fused search / full walk, certificate pass), 3 accumulate, 4 the listed search */

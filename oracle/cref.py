@@ -219,3 +219,63 @@ def ndt_align(source_f32, target_f32, guess=None, resolution=1.0, step_size=0.1,
     return dict(result=res, score=fit.value, iterations=it.value, derivative_calls=calls.value, trans_probability=tp.value,
                 mean_neighbours=mn.value, voxels=nv.value,
                 block_times=dict(applyFilter=bt[0], computeDerivatives=bt[1], transformPointCloud=bt[2], getFitnessScore=bt[3], Align=bt[4]))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# static_map::MultiResolutionVoxelMap (oracle/csrc/smref_mrvm.c)
+# ------------------------------------------------------------------------------------------------------------
+class Mrvm:
+    """The reference's hit / miss voxel map executed in point order (builder/multi_resolution_voxel_map.cc:59-131)."""
+
+    def __init__(self, high_resolution=0.1, hit_prob=0.55, miss_prob=0.48, z_offset=0.0, max_point_num_in_cell=10):
+        L = lib()
+        L.smref_mrvm_create.restype = ctypes.c_void_p
+        L.smref_mrvm_create.argtypes = [ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int]
+        L.smref_mrvm_free.argtypes = [ctypes.c_void_p]
+        L.smref_mrvm_insert.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.smref_mrvm_voxel_count.restype = ctypes.c_long
+        L.smref_mrvm_voxel_count.argtypes = [ctypes.c_void_p]
+        L.smref_mrvm_dump.restype = ctypes.c_long
+        L.smref_mrvm_dump.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 5
+        L.smref_mrvm_output.restype = ctypes.c_long
+        L.smref_mrvm_output.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_long]
+        L.smref_mrvm_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self._L = L
+        self.max_points = max_point_num_in_cell
+        self._h = L.smref_mrvm_create(high_resolution, hit_prob, miss_prob, z_offset, max_point_num_in_cell)
+        if not self._h:
+            raise ValueError("bad MRVM settings")
+
+    def close(self):
+        if self._h:
+            self._L.smref_mrvm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def tables(self):
+        hit = np.zeros(256, np.uint8); miss = np.zeros(256, np.uint8)
+        self._L.smref_mrvm_tables(self._h, hit.ctypes.data, miss.ctypes.data)
+        return hit, miss
+
+    def insert(self, points5, origin):
+        p = np.ascontiguousarray(points5, dtype=np.float32)
+        assert p.ndim == 2 and p.shape[1] == 5
+        o = np.ascontiguousarray(origin, dtype=np.float32)
+        return self._L.smref_mrvm_insert(self._h, p.ctypes.data, len(p), o.ctypes.data)
+
+    def dump(self):
+        """(keys [V,3], prob [V], max_intensity [V], npoints [V], points [V, max, 5]) sorted by key."""
+        n = self._L.smref_mrvm_voxel_count(self._h)
+        keys = np.zeros((n, 3), np.int32); prob = np.zeros(n, np.uint8); mi = np.zeros(n, np.int32); npts = np.zeros(n, np.int32)
+        pts = np.zeros((n, self.max_points, 5), np.float32)
+        self._L.smref_mrvm_dump(self._h, keys.ctypes.data, prob.ctypes.data, mi.ctypes.data, npts.ctypes.data, pts.ctypes.data)
+        o = np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))
+        return keys[o], prob[o], mi[o], npts[o], pts[o]
+
+    def output(self, threshold=0.6, use_max_intensity=True):
+        n = self._L.smref_mrvm_output(self._h, threshold, int(use_max_intensity), None, 0)
+        out = np.zeros((n, 4), np.float32)
+        self._L.smref_mrvm_output(self._h, threshold, int(use_max_intensity), out.ctypes.data, n)
+        return out

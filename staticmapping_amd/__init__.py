@@ -10,3 +10,4 @@ scan-pair sharding helper built on torch.distributed (RCCL).
 from . import synth  # noqa: F401
 from .matcher import (IcpFastHip, IcpPointMatcherHip, NdtGicpHip, NdtHip, SmhipError, se3_error, calculate_normals,  # noqa: F401
                       NN_BRUTE, NN_GRID, NN_NABO)
+from .mrvm import MultiResolutionVoxelMapHip  # noqa: F401

@@ -75,6 +75,12 @@ class FilterDesc(ctypes.Structure):
                 ("reserved", ctypes.c_int32), ("p", ctypes.c_float * 6)]
 
 
+class MrvmSettings(ctypes.Structure):
+    _fields_ = [("prob_threshold", ctypes.c_float), ("high_resolution", ctypes.c_float), ("hit_prob", ctypes.c_float),
+                ("miss_prob", ctypes.c_float), ("z_offset", ctypes.c_float), ("max_point_num_in_cell", ctypes.c_int32),
+                ("use_max_intensity", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 # name -> (restype, argtypes): every symbol include/smhip.h declares
 SIGNATURES = {
     "smhip_version": (ctypes.c_int, []),
@@ -139,6 +145,15 @@ SIGNATURES = {
                                               ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "smhip_filter_get_output": (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_int32_p, ctypes.c_int]),
     "smhip_filter_output_to_source": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "smhip_mrvm_default_settings": (None, [ctypes.POINTER(MrvmSettings)]),
+    "smhip_mrvm_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MrvmSettings), ctypes.POINTER(ctypes.c_void_p)]),
+    "smhip_mrvm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "smhip_mrvm_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "smhip_mrvm_set_offset_z": (None, [ctypes.c_void_p, ctypes.c_float]),
+    "smhip_mrvm_insert_f32": (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int, c_float_p]),
+    "smhip_mrvm_voxel_count": (ctypes.c_int, [ctypes.c_void_p, c_int32_p]),
+    "smhip_mrvm_output": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, c_float_p, ctypes.c_int, c_int32_p]),
+    "smhip_mrvm_dump": (ctypes.c_int, [ctypes.c_void_p, c_int32_p, ctypes.POINTER(ctypes.c_uint8), c_int32_p, c_int32_p, c_float_p, ctypes.c_int, c_int32_p]),
     "smhip_icp_enable_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "smhip_icp_get_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(IcpProfile)]),
     "smhip_icp_get_search_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]),

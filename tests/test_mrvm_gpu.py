@@ -1,0 +1,119 @@
+"""static_map::MultiResolutionVoxelMap on the device (csrc/smhip_mrvm.hip) against the oracle's restatement of the
+reference's insert loop in point order (oracle/csrc/smref_mrvm.c, /root/reference/builder/multi_resolution_voxel_map.cc:59-131):
+the whole map -- voxel set, probability bytes, max intensities, stored points -- must be IDENTICAL after every cloud."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _world_scans(n_scans, n_points, seed=5):
+    from staticmapping_amd import synth
+    poses = synth.drive_poses(n_scans, seed=seed, speed=8.0)
+    scene = synth.make_drive_scene(poses, seed=seed)
+    out = []
+    for k, P in enumerate(poses):
+        s = synth.velodyne_scan(synth.scene_near(scene, P[:3, 3]), P, seed=10 + k, n_points=n_points)
+        w = (s[:, :3].astype(np.float64) @ P[:3, :3].T + P[:3, 3]).astype(np.float32)       # ApplyTransformToOutput(GlobalPose), map_builder.cc:842-843
+        pts = np.concatenate([w, np.round(s[:, 3:4] * 255), (np.arange(len(s), dtype=np.float32) / len(s))[:, None]], axis=1).astype(np.float32)
+        out.append((pts, P[:3, 3].astype(np.float32)))
+    return out
+
+
+def _assert_same_map(dev, ora):
+    kd, pd, md, nd, qd = dev.dump()
+    ko, po, mo, no, qo = ora.dump()
+    assert len(kd) == len(ko)
+    assert np.array_equal(kd, ko)
+    assert np.array_equal(pd, po), int((pd != po).sum())
+    assert np.array_equal(md, mo)
+    assert np.array_equal(nd, no)
+    assert np.array_equal(qd, qo)
+
+
+@pytest.mark.parametrize("settings", [dict(), dict(high_resolution=0.25, hit_prob=0.7, miss_prob=0.4, max_point_num_in_cell=3, z_offset=0.3)])
+def test_map_equals_the_reference_loop_in_point_order(settings):
+    import staticmapping_amd as sm
+    from oracle import cref
+    scans = _world_scans(4, 30_000)
+    dev = sm.MultiResolutionVoxelMapHip(table_log2=20, max_cloud_points=30_000, **settings)
+    ora = cref.Mrvm(**{k: v for k, v in settings.items()})
+    for pts, origin in scans:
+        dev.insert_point_cloud(pts, origin)
+        ora.insert(pts, origin)
+        _assert_same_map(dev, ora)                               # after EVERY cloud: misses of later clouds hit earlier voxels
+    for thr in (0.6, 0.52, 0.9):
+        a = dev.output_to_point_cloud(thr)
+        b = ora.output(thr)
+        assert len(a) == len(b)
+        sa = a[np.lexsort(a.T[::-1])]; sb = b[np.lexsort(b.T[::-1])]
+        assert np.array_equal(sa, sb)
+    assert dev.voxel_count() == len(ora.dump()[0])
+    dev.close(); ora.close()
+
+
+def test_repeated_scan_saturates_and_clears():
+    """The same cloud over and over drives its end voxels to the clamp (0.9 -> byte 230); a second sensor position whose rays pass
+    through them drives them down again: both directions of the update, through many applications of the byte maps."""
+    import staticmapping_amd as sm
+    from oracle import cref
+    (pts, origin), (pts2, origin2) = _world_scans(2, 8_000, seed=9)
+    dev = sm.MultiResolutionVoxelMapHip(table_log2=18, max_cloud_points=8_000)
+    ora = cref.Mrvm()
+    for _ in range(25):
+        dev.insert_point_cloud(pts, origin); ora.insert(pts, origin)
+    _assert_same_map(dev, ora)
+    assert dev.dump()[1].max() == 230
+    far = pts2.copy(); far[:, :3] = origin2 + (pts[:, :3] - origin) * 1.5          # rays through the first cloud's end voxels
+    for _ in range(30):
+        dev.insert_point_cloud(far, origin); ora.insert(far, origin)
+    _assert_same_map(dev, ora)
+    dev.close(); ora.close()
+
+
+def test_edge_cases():
+    import staticmapping_amd as sm
+    from oracle import cref
+    dev = sm.MultiResolutionVoxelMapHip(table_log2=12, max_cloud_points=4096)
+    ora = cref.Mrvm()
+    with pytest.raises(sm.SmhipError):
+        dev.insert_point_cloud(np.zeros((0, 5), np.float32), [0, 0, 0])                # "cloud is empty."
+    rng = np.random.default_rng(0)
+    pts = np.concatenate([rng.normal(0, 3, (500, 3)), rng.uniform(0, 255, (500, 1)), np.zeros((500, 1))], axis=1).astype(np.float32)
+    pts[7, 0] = np.nan; pts[9, 2] = np.inf                                            # skipped, like every other non-finite point
+    pts[11, :3] = [0.05, 0.05, 0.05]                                                  # a point in the origin's own voxel: a ray of one voxel
+    pts[12] = pts[13]                                                                 # duplicates share a voxel
+    for origin in ([0, 0, 0], [0.5, -0.25, 0.1]):
+        dev.insert_point_cloud(pts, origin); ora.insert(pts, origin)
+        _assert_same_map(dev, ora)
+    with pytest.raises(sm.SmhipError):                                                # 4096-slot table: a large cloud overflows 70 %
+        big = np.concatenate([rng.normal(0, 30, (4096, 3)), np.zeros((4096, 2))], axis=1).astype(np.float32)
+        dev.insert_point_cloud(big, [0, 0, 0])
+    dev.close(); ora.close()
+
+
+def test_cpp_mirror_drives_the_map_like_the_map_builder(tmp_path):
+    """include/smhip/mrvm.h through a small C++ program (tests/cpp/test_mrvm.cc) against the oracle."""
+    import json, os, subprocess
+    from staticmapping_amd import build
+    from oracle import cref
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = build.build()
+    exe = os.path.join(root, "tests", "cpp", "_build", "test_mrvm")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "test_mrvm.cc"), "-o", exe,
+                           "-L", os.path.dirname(lib), "-lsmhip", "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"])
+    scans = _world_scans(3, 20_000, seed=3)
+    ora = cref.Mrvm()
+    args = []
+    for k, (pts, origin) in enumerate(scans):
+        f = tmp_path / f"c{k}.bin"
+        pts.tofile(f)
+        args += [str(f)] + [repr(float(v)) for v in origin]
+        ora.insert(pts, origin)
+    res = json.loads(subprocess.check_output([exe] + args, text=True, timeout=120).strip().splitlines()[-1])
+    out = ora.output(0.6)
+    assert res["empty_refused"] and res["voxels"] == len(ora.dump()[0]) and res["output_points"] == len(out)
+    want = float((out[:, 0].astype(np.float64) + 2.0 * out[:, 1] + 3.0 * out[:, 2] + 0.001 * out[:, 3]).sum())
+    assert abs(res["checksum"] - want) <= 1e-6 * max(1.0, abs(want))
+    ora.close()

@@ -12,3 +12,9 @@ bash tools/evidence_ndt_gicp.sh $tag > gpurun_out/$tag/ndt_gicp.log 2>&1; grep "
 python tools/single_pair_probe.py > gpurun_out/$tag/single_pair_probe.txt 2>&1; cat gpurun_out/$tag/single_pair_probe.txt
 python tools/pm_probe.py > gpurun_out/$tag/pm_probe.txt 2>&1; cat gpurun_out/$tag/pm_probe.txt | cut -c1-140
 python tools/gpu_probe.py 120000 1,16,64,512 > gpurun_out/$tag/gpu_probe.txt 2>&1; grep "align/s" gpurun_out/$tag/gpu_probe.txt | cut -c1-100
+# the reference's own search (nn_mode NABO): the bench figure alone with the walked-query counts, and the counter passes of its kernels
+python tools/nabo_probe.py nocert=0,1 > gpurun_out/$tag/nabo_probe.txt 2>&1; grep -v amdgpu.ids gpurun_out/$tag/nabo_probe.txt | cut -c1-330
+bash tools/nabo_pmc.sh $tag/nabo_pmc_cert nocert=0 > gpurun_out/$tag/nabo_pmc_certificates.txt 2>&1
+bash tools/nabo_pmc.sh $tag/nabo_pmc_nocert nocert=1 > gpurun_out/$tag/nabo_pmc_every_query_walked.txt 2>&1; head -4 gpurun_out/$tag/nabo_pmc_every_query_walked.txt | cut -c1-300
+# the sequence driver: kernel stats of a 513-scan drive
+bash tools/sequence_profile.sh > gpurun_out/$tag/sequence_driver_kernel_stats.txt 2>&1; head -12 gpurun_out/$tag/sequence_driver_kernel_stats.txt | cut -c1-200

@@ -9,16 +9,17 @@ export TMPDIR=/tmp
 t0=$SECONDS
 python bench.py > "$out/bench_line.json" 2> "$out/bench.err"
 echo "default bench.py run: $((SECONDS - t0)) s wall" > "$out/bench_wall.txt"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python bench.py --no-cpu-baseline > "$out/bench_line_traced.json" 2> "$out/trace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python bench.py --no-cpu-baseline --no-end-to-end > "$out/bench_line_traced.json" 2> "$out/trace.err"
 find "$out/trace" -name '*kernel_stats.csv' -exec cp {} "$out/bench_kernel_stats.csv" \;
-# trace average of the two FindClosests kernels over the launches of the timed region only (2 warm-up steps first, 5 timed
-# steps, then the untimed breakdown / alone steps that the --stats average above also covers).  This is the number
+# trace average of the iteration kernels over the launches of the timed region only (4 untimed steps first -- one plain and one
+# fully profiled step that pick the kernel class to bracket, 2 warm-up steps -- then 5 timed steps, then the untimed breakdown /
+# alone steps that the --stats average above also covers).  This is the number
 # roofline.avg_launch_ms (and roofline.other_kernels) of the traced line must match.
 # (split_after 2: per step 4 launches of nn_ball_lds -- iterations 0-1 x 2 half-batches -- and 36 of nn_certify)
-python tools/trace_tail_average.py "$out/trace" nn_certify 72 180 > "$out/timed_region_trace_average.txt"
-python tools/trace_tail_average.py "$out/trace" nn_ball_lds 8 20 >> "$out/timed_region_trace_average.txt"
-python tools/trace_tail_average.py "$out/trace" accumulate 80 200 >> "$out/timed_region_trace_average.txt"
-python tools/trace_tail_average.py "$out/trace" nn_ball_listed 72 180 >> "$out/timed_region_trace_average.txt"
+python tools/trace_tail_average.py "$out/trace" nn_certify 144 180 > "$out/timed_region_trace_average.txt"
+python tools/trace_tail_average.py "$out/trace" nn_ball_lds 16 20 >> "$out/timed_region_trace_average.txt"
+python tools/trace_tail_average.py "$out/trace" accumulate 160 200 >> "$out/timed_region_trace_average.txt"
+python tools/trace_tail_average.py "$out/trace" nn_ball_listed 144 180 >> "$out/timed_region_trace_average.txt"
 bash tools/traffic_calib.sh "$out/traffic_calibration.json" > "$out/traffic_calibration.log" 2>&1
 calib="$out/traffic_calibration.json"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python tools/profile_target.py B=512 reps=1 > "$out/pmc_fetch.log" 2>&1

@@ -2206,7 +2206,8 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   st->hard_count = 0;
   {
     const uint32_t walked = st->nabo_count[0] + st->nabo_count[1] + st->nabo_count[2] + st->nabo_count[3];   // SMHIP_NN_NABO's lists
-    const uint32_t searched = walked ? walked : (st->deferred_count ? st->deferred_count : (uint32_t)ns);
+    // (iteration 0 searches every query in every mode, whatever part of it went through a list)
+    const uint32_t searched = st->iter == 0 ? (uint32_t)ns : (walked ? walked : (st->deferred_count ? st->deferred_count : (uint32_t)ns));
     st->searched_total += searched;
     if (st->iter < kSearchHist) b.search_hist[(size_t)pair * kSearchHist + st->iter] = searched;
     for (int c = 0; c < 4; ++c) st->nabo_count[c] = 0;

@@ -108,6 +108,21 @@ class IcpFastHip:
             a = _f64(a[:, :3])
             self._check(self._lib.smhip_set_source_f64(self._h, slot, a.ctypes.data_as(_capi.c_double_p), a.shape[0]))
 
+    def set_input_sources_batch(self, clouds, slots):
+        """SetInputSource of many pair slots in one call (smhip_set_sources_f32_batch): clouds = float32 [N, 4] arrays (KITTI
+        rows); one Morton ordering for the whole batch.  Returns once the copies are enqueued; numpy arrays are pageable, so
+        they are staged one at a time (page-locked buffers are copied from where they lie)."""
+        arrs = [np.ascontiguousarray(c, dtype=np.float32) for c in clouds]
+        for a in arrs:
+            if a.ndim != 2 or a.shape[1] != 4:
+                raise ValueError("the batched upload takes rows of 4 floats (x y z reflectance)")
+        k = len(arrs)
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        n = np.ascontiguousarray([len(a) for a in arrs], dtype=np.int32)
+        rows = (_capi.c_float_p * k)(*[a.ctypes.data_as(_capi.c_float_p) for a in arrs])
+        self._check(self._lib.smhip_set_sources_f32_batch(self._h, k, sl.ctypes.data_as(_capi.c_int32_p), rows, n.ctypes.data_as(_capi.c_int32_p)))
+        self.synchronize()
+
     def set_input_target(self, points, normals=None, slot: int = 0):
         p = _f64(np.asarray(points)[:, :3])
         n = None if normals is None else _f64(np.asarray(normals)[:, :3])

@@ -67,3 +67,29 @@ def test_synthetic_drive_with_the_kitti_filter_chain(tmp_path):
         da, dt = sm.se3_error(T[i], rel_true[i])
         assert da < 3e-3 and dt < 3e-2, (i, da, dt)
     m.close()
+
+
+@pytest.mark.gpu
+def test_batched_upload_equals_single_uploads(velo20k):
+    """smhip_set_sources_f32_batch (one Morton ordering for many scans; here from pageable memory, the driver test covers the
+    page-locked path) leaves every slot with exactly the source a single smhip_set_source_f32 leaves: same alignment bits."""
+    import numpy as np
+    import staticmapping_amd as sm
+    rng = np.random.default_rng(4)
+    base = np.ascontiguousarray(velo20k["src"][:, :4], dtype=np.float32)
+    clouds = [np.ascontiguousarray(base[rng.permutation(len(base))[:n]]) for n in (20000, 12345, 1500, 19999, 16000)]
+    guesses = [velo20k["guess"]] * len(clouds)
+    out = []
+    for batched in (False, True):
+        m = sm.IcpFastHip(pair_slots=len(clouds), max_source_points=20000, max_target_points=len(velo20k["q"]), max_iteration=12, early_exit=0)
+        if batched:
+            m.set_input_sources_batch(clouds, list(range(len(clouds))))
+        else:
+            for s, c in enumerate(clouds):
+                m.set_input_source(c, slot=s)
+        for s in range(len(clouds)):
+            m.set_input_target(velo20k["q"], velo20k["n"], slot=s)
+        R, sc, st = m.align_batch(len(clouds), guesses)
+        m.close()
+        out.append((np.asarray(R).tobytes(), [x["kept"] for x in st]))
+    assert out[0] == out[1]

@@ -1855,7 +1855,7 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
   const size_t segbase = (size_t)pair * b.bl_stride + (size_t)seg * (64 * ITEMS);
   int wcount = 0;
   // two-deep software pipeline (as nn_certify): stream loads two rounds ahead, the gathers of the matched target point and
-  // normal one round ahead (for every lane: a trimmed query's gather is a wasted L2 hit, but nothing waits on d2 first)
+  // normal one round ahead
   int ic = min(base + (int)threadIdx.x, ns - 1);
   float d_1 = b.d2[so + ic];
   float4 s_1 = ld_src(b, so + ic);
@@ -1864,7 +1864,10 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
   float d_2 = b.d2[so + ic];
   float4 s_2 = ld_src(b, so + ic);
   int j_2 = b.idx[so + ic];
-  float4 q_1 = b.tq[to + max(j_1, 0)], n_1 = b.tn[to + max(j_1, 0)];
+  // only a query below the quantile's bin uses its matched point and normal (the 30 % trimmed ones and the bin's own members do
+  // not): its d2 arrived with its match id -- one round ahead of the gather -- so the gather is issued for those lanes alone
+  float4 q_1 = make_float4(0, 0, 0, 0), n_1 = make_float4(0, 0, 0, 0);
+  if ((__float_as_uint(d_1) >> kHistShift) < qbin) { q_1 = b.tq[to + max(j_1, 0)]; n_1 = b.tn[to + max(j_1, 0)]; }
 #pragma unroll 2
   for (int it = 0; it < ITEMS; ++it) {
     const int i = base + it * kAccThreads + threadIdx.x;
@@ -1872,7 +1875,7 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
     const float4 s4 = s_1;
     const float4 q4 = q_1, n4 = n_1;
     d_1 = d_2; s_1 = s_2; j_1 = j_2;
-    if (it + 1 < ITEMS) { q_1 = b.tq[to + max(j_1, 0)]; n_1 = b.tn[to + max(j_1, 0)]; }
+    if (it + 1 < ITEMS && (__float_as_uint(d_1) >> kHistShift) < qbin) { q_1 = b.tq[to + max(j_1, 0)]; n_1 = b.tn[to + max(j_1, 0)]; }
     if (it + 2 < ITEMS) {
       ic = min(i + 2 * kAccThreads, ns - 1);
       d_2 = b.d2[so + ic];

@@ -1443,27 +1443,69 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring_coop(IcpDev b) {
       const int y0 = max(cy - 1, 0), y1 = min(cy + 1, ny - 1);
       const int z0 = max(cz - 1, 0), z1 = min(cz + 1, nz - 1);
       if (x0 <= x1 && y0 <= y1 && z0 <= z1) {
-        // at most 9 rows, <= 3 per lane -- their word and cstart lookups are issued together so that a lane exposes three
-        // load latencies instead of three per row
-        uint32_t ja[3], jb[3];
+        // The query's OWN cell first, its points dealt out to the group's lanes four apart: against a dense submap (hundreds of
+        // points per cell near the sensor) it nearly always holds the neighbour, and with that distance in hand every other
+        // piece of the 3 x 3 x 3 block -- the two other cells of the own row, the eight other rows -- is cut down to the cells
+        // the ball of that distance reaches before anything of it is loaded: what lies strictly farther than the best so far
+        // cannot improve on it, nor tie with it.  (Rows used to be dealt out blind: a lane swept up to three full rows of three
+        // cells whatever the first one found.)
+        const float hh = st->h, slack = 2.0e-3f * hh;
+        const bool own = cx >= 0 && cx < nx && cy >= 0 && cy < ny && cz >= 0 && cz < nz;   // (a query outside the grid has no cell of its own)
+        if (own) {
+          uint32_t sb, se;
+          row_slots(words, (cz * ny + cy) * wx, cx, cx, sb, se);
+          if (se > sb) {
+            const uint32_t j0 = cstart[sb], j1 = cstart[se];
+            for (uint32_t j = j0 + (uint32_t)sub; j < j1; j += kCoopLanes) test_any_order(tq[j], (int)j, qx, qy, qz, best);
+          }
+        }
+#pragma unroll
+        for (int off = 1; off < kCoopLanes; off <<= 1) {
+          const float od = __shfl_xor(best.d2, off, 64);
+          const int oj = __shfl_xor(best.j, off, 64);
+          if (od < best.d2 || (od == best.d2 && oj >= 0 && (best.j < 0 || oj < best.j))) { best.d2 = od; best.j = oj; }
+        }
+        // the pieces left: for every row of the block its cells inside the ball, the own row in two parts around the own cell;
+        // at most 10, round-robin over the lanes, <= 3 per lane, their lookups issued together
+        uint32_t ja[3] = {0, 0, 0}, jb[3] = {0, 0, 0};
         uint2 wa[3], wc[3];
+        int xa[3] = {0, 0, 0}, xb[3] = {0, 0, 0};
         int nrow = 0;
         {
           int k = 0;
           for (int z = z0; z <= z1; ++z)
-            for (int y = y0; y <= y1; ++y, ++k) {
-              if ((k & (kCoopLanes - 1)) != sub || nrow >= 3) continue;
+            for (int y = y0; y <= y1; ++y) {
+              const bool own_row = own && z == cz && y == cy;
+              const float zl = oz + (float)z * hh, yl = oy + (float)y * hh;
+              const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + hh)) - slack, 0.f);
+              const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + hh)) - slack, 0.f);
+              const float rest = best.d2 - fmaf(dy, dy, dz * dz);
+              int ca = x0, cb = x1;
+              if (rest < 1.0e30f && rest >= 0.f) {
+                const float xr = sqrtf(rest) * 1.0001f + slack;
+                ca = max(x0, cell_coord(qx - xr, ox, inv_h)); cb = min(x1, cell_coord(qx + xr, ox, inv_h));
+              }
               const int rowbase = (z * ny + y) * wx;
-              wa[nrow] = words[rowbase + (x0 >> 5)];
-              wc[nrow] = words[rowbase + (x1 >> 5)];
-              ++nrow;
+#pragma unroll
+              for (int part = 0; part < 2; ++part) {                   // a row other than the own one is one part
+                if (part == 1 && !own_row) break;
+                int pa = ca, pb = cb;
+                if (own_row) { if (part == 0) pb = min(cb, cx - 1); else pa = max(ca, cx + 1); }
+                const bool mine = (k & (kCoopLanes - 1)) == sub;
+                ++k;
+                if (!mine || nrow >= 3 || rest < 0.f || pa > pb) continue;
+                wa[nrow] = words[rowbase + (pa >> 5)];
+                wc[nrow] = words[rowbase + (pb >> 5)];
+                xa[nrow] = pa; xb[nrow] = pb;
+                ++nrow;
+              }
             }
         }
 #pragma unroll
         for (int m = 0; m < 3; ++m)
           if (m < nrow) {
-            const uint32_t sb = wa[m].y + __popc(wa[m].x & ((1u << (x0 & 31)) - 1u));
-            const uint32_t se = wc[m].y + __popc(wc[m].x & (0xffffffffu >> (31 - (x1 & 31))));
+            const uint32_t sb = wa[m].y + __popc(wa[m].x & ((1u << (xa[m] & 31)) - 1u));
+            const uint32_t se = wc[m].y + __popc(wc[m].x & (0xffffffffu >> (31 - (xb[m] & 31))));
             ja[m] = cstart[sb]; jb[m] = cstart[se];
           }
 #pragma unroll
@@ -1526,6 +1568,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring_wide(IcpDev b) {
   const uint32_t* rowbits = b.have_rowbits ? b.rowbits + (size_t)pair * kMaxRowWords : nullptr;
   const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
   const float inv_h = st->inv_h;
+  const float hh = st->h, slack = 2.0e-3f * hh;
   const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
   for (int e = (int)blockIdx.x * kWaves + (int)(threadIdx.x >> 6); e < count; e += (int)gridDim.x * kWaves) {   // wave-uniform
     const int i = b.dlist[so + e];
@@ -1546,14 +1589,28 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring_wide(IcpDev b) {
           const int zr = k / nyr;
           const int z = z0 + zr, y = y0 + (k - zr * nyr);
           if (rowbits && !row_occupied(rowbits, ny, z, y)) continue;       // an empty row: one bit instead of two dependent loads
+          // the first ring left an (uncertified) neighbour: only the part of the row inside the ball of that distance can hold a
+          // closer point, or one that ties with it -- the other rows and cells are not looked up at all
+          const float zl = oz + (float)z * hh, yl = oy + (float)y * hh;
+          const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + hh)) - slack, 0.f);
+          const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + hh)) - slack, 0.f);
+          const float rest = best.d2 - fmaf(dy, dy, dz * dz);
+          if (rest < 0.f) continue;
+          int xa = x0, xb = x1;
+          if (rest < 1.0e30f) {
+            const float xr = sqrtf(rest) * 1.0001f + slack;
+            xa = max(x0, cell_coord(qx - xr, ox, inv_h));
+            xb = min(x1, cell_coord(qx + xr, ox, inv_h));
+            if (xa > xb) continue;
+          }
           const int rowbase = (z * ny + y) * wx;
           const bool inner = abs(y - cy) <= rp && abs(z - cz) <= rp;
           if (!inner) {
-            search_row(words, cstart, tq, rowbase, x0, x1, qx, qy, qz, best);
+            search_row(words, cstart, tq, rowbase, xa, xb, qx, qy, qz, best);
           } else {
-            const int xl1 = min(cx - rp - 1, nx - 1), xr0 = max(cx + rp + 1, 0);
-            if (x0 <= xl1) search_row(words, cstart, tq, rowbase, x0, xl1, qx, qy, qz, best);
-            if (xr0 <= x1) search_row(words, cstart, tq, rowbase, xr0, x1, qx, qy, qz, best);
+            const int xl1 = min(min(cx - rp - 1, nx - 1), xb), xr0 = max(max(cx + rp + 1, 0), xa);
+            if (xa <= xl1) search_row(words, cstart, tq, rowbase, xa, xl1, qx, qy, qz, best);
+            if (xr0 <= xb) search_row(words, cstart, tq, rowbase, xr0, xb, qx, qy, qz, best);
           }
         }
       }

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <memory>
 #include <utility>
+#include <thread>
 #include <vector>
 
 #include "smhip/registrator.h"
@@ -174,6 +175,57 @@ inline std::vector<SubmapPairMatchResult> SubmapPairMatchBatch(const registrator
   }
   return out;
 }
+
+// The reference's own form of concurrency, kept for the matchers without pair slots (Ndt, NdtWithGicp): the back end's thread
+// pool runs up to six SubmapPairMatch tasks at once, each with a matcher of its own (map_builder.cc:399-446, 655, 706-708).
+// Here: `concurrency` matchers created once and kept between batches (every one owns a device arena and a HIP stream), the
+// jobs dealt to them round-robin, one host thread per matcher -- the GPU runs the matchers' streams side by side, so the
+// launch latencies, read-backs and host-side Newton / BFGS steps of one pair hide behind the kernels of the others.
+// Results are those of SubmapPairMatch pair by pair (every pair runs exactly the single-pair code on its own handle).
+class SubmapMatcherPool {
+ public:
+  SubmapMatcherPool(const registrator::MatcherOptions& options, int concurrency = 6) : options_(options) {
+    for (int k = 0; k < std::max(1, concurrency); ++k) {
+      auto m = registrator::CreateMatcher(options, false);
+      SMHIP_CHECK(m != nullptr, "CreateMatcher returned null");
+      matchers_.push_back(m);
+    }
+  }
+  int concurrency() const { return static_cast<int>(matchers_.size()); }
+  std::vector<SubmapPairMatchResult> Match(const std::vector<SubmapPairJob>& jobs) {
+    const size_t K = jobs.size();
+    std::vector<SubmapPairMatchResult> out(K);
+    // CalculateNormals mutates a cloud: done up front on this thread, once per cloud (two jobs may share a target)
+    if (options_.type == registrator::kFastIcp)
+      for (const auto& j : jobs)
+        if (!j.target_submap_cloud->GetEigenCloud()->HasNormals()) j.target_submap_cloud->CalculateNormals();
+    std::vector<std::thread> workers;
+    const size_t C = std::min(matchers_.size(), K);
+    for (size_t t = 0; t < C; ++t) {
+      workers.emplace_back([&, t] {
+        registrator::Interface& m = *matchers_[t];
+        for (size_t k = t; k < K; k += C) {
+          SubmapPairMatchResult& r = out[k];
+          m.SetInputSource(jobs[k].source_submap_cloud);
+          m.SetInputTarget(jobs[k].target_submap_cloud);
+          Matrix4d result = Matrix4d::Identity();
+          r.guess = Multiply(RigidInverse(jobs[k].target_first_frame_pose), jobs[k].source_first_frame_pose);   // :427-429
+          m.Align(r.guess, result);
+          NormalizeRotation(result);                                                                           // :434
+          r.match_score = m.GetFitnessScore();
+          if (r.match_score >= options_.accepted_min_score) { r.transform_to_next = result; r.accepted = true; }   // :437-439
+          else { r.transform_to_next = r.guess; r.accepted = false; }                                               // :440-444
+        }
+      });
+    }
+    for (auto& w : workers) w.join();
+    return out;
+  }
+
+ private:
+  registrator::MatcherOptions options_;
+  std::vector<std::shared_ptr<registrator::Interface>> matchers_;
+};
 
 }  // namespace back_end
 }  // namespace smhip

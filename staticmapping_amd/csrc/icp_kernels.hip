@@ -1324,19 +1324,16 @@ __device__ __forceinline__ bool ring_irrelevant(const IcpDev& b, float g, float 
 // every match must be exact); HARD = false: over every source point (nn_ball skipped).
 // Rings r = 1, 2, 4, ... <= max_ring; cells covered by an earlier ring are skipped.  What is still
 // uncertified afterwards goes to the brute-force fallback list.
+// blk / nblk: this workgroup's place among the workgroups that share the pair's list (the kernel below: blockIdx.x / gridDim.x;
+// nn_refine_one: 0 / 1)
 template <bool HARD>
-__global__ __launch_bounds__(kNnThreads) void nn_ring(IcpDev b) {
-  const int pair = b.pair_base + blockIdx.y;
-  PairState* st = &b.state[pair];
-  if (st->done) return;
-  if (HARD && !st->refine) return;
+__device__ __forceinline__ void ring_body(const IcpDev& b, PairState* st, int pair, int blk, int nblk, uint32_t* s_hist) {
   const int count = HARD ? (int)st->hard_count : st->ns;
-  if ((int)(blockIdx.x * kNnThreads) >= count) return;
-  __shared__ uint32_t s_hist[kHistBins];
+  if (blk * kNnThreads >= count) return;
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
   __syncthreads();
   uint32_t* gh = b.hist + (size_t)pair * kHistBins;
-  for (int e = blockIdx.x * kNnThreads + threadIdx.x; e < count; e += gridDim.x * kNnThreads) {
+  for (int e = blk * kNnThreads + threadIdx.x; e < count; e += nblk * kNnThreads) {
     const size_t so = (size_t)pair * b.ns_cap;
     const int i = HARD ? b.hlist[so + e] : e;
     if (HARD) {   // take the lower bound back out of the histogram
@@ -1398,6 +1395,15 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring(IcpDev b) {
     const uint32_t v = s_hist[k];
     if (v) atomicAdd(&gh[k], v);
   }
+}
+template <bool HARD>
+__global__ __launch_bounds__(kNnThreads) void nn_ring(IcpDev b) {
+  const int pair = b.pair_base + blockIdx.y;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  if (HARD && !st->refine) return;
+  __shared__ uint32_t s_hist[kHistBins];
+  ring_body<HARD>(b, st, pair, (int)blockIdx.x, (int)gridDim.x, s_hist);
 }
 
 // The same exact ring search with kCoopLanes adjacent lanes per query (rows of the cell block dealt round-robin, the
@@ -1699,17 +1705,13 @@ __global__ __launch_bounds__(kNnThreads) void nn_brute(IcpDev b) {
 // The work (U queries x nt targets) is spread over the whole chip: block (slice, pair) stages one
 // slice of the target in LDS and sweeps ALL unresolved queries of the pair over it; the per-query
 // winner is merged with a 64-bit atomicMin on (d2 bits << 32 | sorted position).
-__global__ __launch_bounds__(kNnThreads) void nn_fallback(IcpDev b) {
-  const int pair = b.pair_base + blockIdx.y;
-  PairState* st = &b.state[pair];
-  if (st->done) return;
+__device__ __forceinline__ void fallback_body(const IcpDev& b, PairState* st, int pair, int slice, int nslices, float4* s_t, uint32_t* s_last_p) {
   const int U = (int)st->unresolved_count;
   if (U == 0) return;                                     // the usual case: nothing reaches the fallback
-  __shared__ float4 s_t[kBruteTile];
-  __shared__ uint32_t s_last;
+  uint32_t& s_last = *s_last_p;
   const int nt = st->nt;
-  const int per = (nt + gridDim.x - 1) / gridDim.x;
-  const int lo = blockIdx.x * per, hi = min(nt, lo + per);
+  const int per = (nt + nslices - 1) / nslices;
+  const int lo = slice * per, hi = min(nt, lo + per);
   if (lo >= hi) return;
   const size_t so = (size_t)pair * b.ns_cap;
   const float4* tq = b.tq + (size_t)pair * b.nt_cap;
@@ -1750,6 +1752,14 @@ __global__ __launch_bounds__(kNnThreads) void nn_fallback(IcpDev b) {
     if (dbits < 0x7f800000u) atomicAdd(&b.hist[(size_t)pair * kHistBins + (dbits >> kHistShift)], 1u);
   }
   if (threadIdx.x == 0) st->fallback_ticket = 0;
+}
+__global__ __launch_bounds__(kNnThreads) void nn_fallback(IcpDev b) {
+  const int pair = b.pair_base + blockIdx.y;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  __shared__ float4 s_t[kBruteTile];
+  __shared__ uint32_t s_last;
+  fallback_body(b, st, pair, (int)blockIdx.x, (int)gridDim.x, s_t, &s_last);
 }
 
 
@@ -1813,6 +1823,28 @@ __global__ __launch_bounds__(256) void nn_validate(IcpDev b) {
   __shared__ uint32_t s_w[17];
   __shared__ uint32_t s_q[4];
   validate_bounds(b, st, pair, s_w, s_q);
+}
+
+// The three refinement launches of an iteration (nn_validate, nn_ring<true>, nn_fallback) as ONE, a workgroup per pair, for
+// launches of a few pairs: there every launch is ~5 us of dispatch whether it does anything or not, and in all but a poorly
+// guessed first iteration the validation passes and nothing else happens.  When it does fail the one workgroup refines its
+// pair's lower-bounded queries itself -- slower than the spread-out kernels, which is why batches and the modes that refine
+// in every iteration (exact_matches, find_closests) keep those.  Same results: the same bodies, a different work split.
+__global__ __launch_bounds__(kNnThreads) void nn_refine_one(IcpDev b) {
+  const int pair = b.pair_base + blockIdx.x;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  __shared__ uint32_t s_w[17];
+  __shared__ uint32_t s_q[4];
+  __shared__ uint32_t s_hist[kHistBins];
+  __shared__ float4 s_t[kBruteTile];
+  __shared__ uint32_t s_last;
+  validate_bounds(b, st, pair, s_w, s_q);
+  __syncthreads();
+  if (!st->refine) return;                                 // (written by thread 0 above: visible after the barrier)
+  ring_body<true>(b, st, pair, 0, 1, s_hist);
+  __syncthreads();
+  fallback_body(b, st, pair, 0, 1, s_t, &s_last);
 }
 
 // J = [p x n ; n], r = (p - q) . n ; acc += upper(J J^T), J r, sqrt(d2), 1     (icp_fast.cc:182-202, 256-303)

@@ -399,6 +399,12 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
         Bracket br(h, 4, st, np);
         hipLaunchKernelGGL(nn_ball, gx, dim3(kNnThreads), 0, st, d, nblk);
       }
+      if (f.small && !d.exact_all) {
+        // a few pairs: validate + ring + fallback as ONE launch, a workgroup per pair (near-empty launches cost ~5 us each there)
+        Bracket br(h, 1, st);
+        hipLaunchKernelGGL(nn_refine_one, dim3(np), dim3(kNnThreads), 0, st, d);
+        return SMHIP_OK;
+      }
       { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_validate, dim3(np), dim3(256), 0, st, d); }
       { Bracket br(h, 1, st); hipLaunchKernelGGL(nn_ring<true>, dim3(32, np), dim3(kNnThreads), 0, st, d); }
     } else if ((long long)np * ns_max < (1ll << 21)) {

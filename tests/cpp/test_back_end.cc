@@ -60,6 +60,28 @@ int main(int argc, char** argv) {
   jobs[1] = jobs[0]; jobs[1].source_first_frame_pose = far;
   auto batch = smhip::back_end::SubmapPairMatchBatch(mopt, pool_matcher, jobs);
   batch = smhip::back_end::SubmapPairMatchBatch(mopt, pool_matcher, jobs);
+  // registrators::Ndt has no pair slots: six pairs through a pool of three matchers on three host threads (SubmapMatcherPool)
+  // must give what six single SubmapPairMatch calls give
+  bool pool_equal = true;
+  int pool_accepted = 0;
+  {
+    reg::MatcherOptions nopt; nopt.type = reg::kNdt; nopt.accepted_min_score = -1.0f;    // Ndt's score is a distance: accept everything
+    std::vector<smhip::back_end::SubmapPairJob> njobs(6);
+    for (int k = 0; k < 6; ++k) {
+      njobs[k] = jobs[0];
+      njobs[k].source_first_frame_pose(0, 3) += 0.02 * k; njobs[k].source_first_frame_pose(1, 3) -= 0.01 * k;
+    }
+    smhip::back_end::SubmapMatcherPool pool(nopt, 3);
+    auto pooled = pool.Match(njobs);
+    pooled = pool.Match(njobs);                                                            // the matchers outlive a batch
+    for (int k = 0; k < 6; ++k) {
+      const auto one = smhip::back_end::SubmapPairMatch(nopt, njobs[k].source_submap_cloud, njobs[k].source_first_frame_pose,
+                                                         njobs[k].target_submap_cloud, njobs[k].target_first_frame_pose);
+      pool_accepted += pooled[k].accepted ? 1 : 0;
+      pool_equal = pool_equal && pooled[k].match_score == one.match_score;
+      for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) pool_equal = pool_equal && pooled[k].transform_to_next(r, c) == one.transform_to_next(r, c);
+    }
+  }
   // a loop-closure matcher that outlives its candidates
   reg::IcpPointMatcherHip keep_matcher(settings.device, 1 << 12);            // deliberately too small: must re-size itself
   keep_matcher.InitWithOptions();
@@ -67,7 +89,8 @@ int main(int argc, char** argv) {
   const bool closed2 = smhip::back_end::CloseLoop(tpose, target, spose, source, settings, &edge2, &keep_matcher);
   const bool closed_far2 = smhip::back_end::CloseLoop(tpose, target, far, source, settings, &bad_edge2, &keep_matcher);
 
-  std::printf("{\"closed\": %s, \"edge_score\": %.17g, \"closed_far\": %s, ", closed ? "true" : "false", edge.score, closed_far ? "true" : "false");
+  std::printf("{\"pool_equal\": %s, \"pool_accepted\": %d, \"closed\": %s, \"edge_score\": %.17g, \"closed_far\": %s, ", pool_equal ? "true" : "false", pool_accepted,
+              closed ? "true" : "false", edge.score, closed_far ? "true" : "false");
   PrintMatrix("edge_guess", edge.init_guess);
   PrintMatrix("edge_transform", edge.transform);
   std::printf("\"sub_accepted\": %s, \"sub_score\": %.17g, \"sub_far_accepted\": %s, \"sub_far_score\": %.17g, ",

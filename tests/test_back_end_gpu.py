@@ -20,7 +20,7 @@ def _build_exe():
     if (not os.path.exists(exe)) or max([os.path.getmtime(src), os.path.getmtime(lib)] + [os.path.getmtime(h) for h in hdrs]) > os.path.getmtime(exe):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
                                "-L", os.path.dirname(lib), "-lsmhip", "-Wl,-rpath," + os.path.dirname(lib),
-                               "-Wl,-rpath,/opt/rocm/lib"])
+                               "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
     return exe
 
 
@@ -113,6 +113,8 @@ def test_close_loop_and_submap_pair_match(tmp_path, matcher_type):
     assert da < 3e-3 and dt < 5e-2, (da, dt)
     assert not res["sub_far_accepted"] and res["sub_far_score"] < 0.7
     assert np.array_equal(M("sub_far_transform"), M("sub_far_guess"))
+    # six registrators::Ndt pairs through a pool of three matchers on three host threads = the six single calls, bit for bit
+    assert res["pool_equal"] and res["pool_accepted"] == 6
     # the two pairs as one batch through a pooled matcher (SubmapPairMatchBatch) = the two single calls
     assert res["batch_accepted"] == [True, False]
     da, dt = sm.se3_error(M("batch0_transform"), M("sub_transform"))

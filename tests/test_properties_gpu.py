@@ -128,3 +128,37 @@ def test_align_is_identical_across_search_variants(seed, n, yaw, tx, rho):
         if ref is None:
             ref = key
         assert key == ref, (opts, st_)
+
+
+@settings(max_examples=max(6, _N // 4), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(800, 6000), yaw=st.floats(-30.0, 30.0), tx=st.floats(-1.0, 1.0),
+       rho=st.sampled_from([0.5, 0.9, 1.0]), far=st.sampled_from([0.0, 1000.0]))
+def test_certificates_change_no_bit_far_from_the_origin_and_from_poor_guesses(seed, n, yaw, tx, rho, far):
+    """The same bit equality where the certificates have least room: clouds a kilometre from the origin (float32 inputs there
+    are 6e-5 m apart; the device works on the centred clouds), guesses up to 30 degrees and a metre off (the pose moves far
+    in every iteration, most certificates fail and many queries fall outside every search ball), and trimming ratios up to
+    1.0 (nothing trimmed: every lower-bounded match has to be refined)."""
+    from staticmapping_amd import synth
+    tgt, src, T = synth.three_planes_pair(n, seed=seed % 1000, sigma=0.01)
+    off = np.array([far, -0.7 * far, 0.03 * far])
+    q, nr = sm.calculate_normals(tgt[:, :3].astype(np.float64) + off)
+    src = src.copy()
+    src[:, :3] = (src[:, :3].astype(np.float64) + off).astype(np.float32)
+    # the guess turns about the clouds' own position, not about the far-away origin
+    P = synth.make_pose(t=(tx, 0.05, 0.0), rpy_deg=(0, 0, yaw))
+    C = np.eye(4); C[:3, 3] = off
+    Ci = np.eye(4); Ci[:3, 3] = -off
+    guess = C @ P @ Ci
+    ref = None
+    for opts in (dict(), dict(no_certify=1), dict(split_after=1), dict(no_lds_table=1), dict(use_ball=0)):
+        m = sm.IcpFastHip(max_source_points=len(src), max_target_points=len(q), max_iteration=25, early_exit=1,
+                          dist_outlier_ratio=rho, **opts)
+        m.set_input_source(src); m.set_input_target(q, nr)
+        ok, R = m.align(guess)
+        st_ = m.last_stats[0]
+        ids, d2 = m.get_matches(len(src))
+        m.close()
+        key = (R.tobytes(), st_["iterations"], st_["kept"], st_["limit_d2"], st_["status"])
+        if ref is None:
+            ref = key
+        assert key == ref, (opts, st_)

@@ -88,6 +88,7 @@ struct KdSeg {                            // one node of the current level while
   uint32_t vidx;                          // ties at the median: caller indices below this one go left
   uint32_t rank;                          // number of splitting segments before this one
   uint32_t tie, trank;                    // several points ON the median value of which `trank` (running) must go left
+  uint32_t ldim, rdim;                    // the cut dimensions the two children will take (known once the cut value is)
 };
 
 
@@ -106,11 +107,19 @@ __device__ __forceinline__ float kd_coord(const float4 p, uint32_t d) { return d
 // s_hist: kKdHistWords words, s_w: 17, s_misc: 4 (all LDS).  On return cur / oth, sid / sid_o and seg / seg_o have been
 // swapped once per level: `cur` holds the final order (every leaf's points contiguous), nodes[] the tree (inner: {cut value
 // bits, (left child << 2) | dim}, children side by side; leaf: {first, (count << 2) | 3}), s_misc[0] the node count.
-template <int BUCKET>
-__device__ __forceinline__ void kd_median_build(int n, float4*& cur, float4*& oth, uint32_t*& sid, uint32_t*& sid_o, KdSeg*& seg, KdSeg*& seg_o,
+// kk / kk_o: [n] words each, the select's own stream -- kk[i] = the order-preserving key of point i's coordinate on the cut
+// dimension of ITS segment.  The sweeps of the radix select (four per level) then move 8 bytes per point (key + segment id)
+// instead of 20 (the whole float4 for one coordinate of it).  A child's cut dimension follows from the box it inherits, so
+// the partition pass, which has the point in registers, writes the next level's keys as it scatters.
+// fetch(i) = point i of the cloud as the working orders hold it (.w = i as int bits): the last levels sort (segment, coordinate,
+// index) keys in registers and pick the points up again by index.  n < 2^24 - 1.
+template <int BUCKET, typename Fetch>
+__device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur, float4*& oth, uint32_t*& sid, uint32_t*& sid_o, KdSeg*& seg, KdSeg*& seg_o,
+                                                uint32_t*& kk, uint32_t*& kk_o,
                                                 uint2* nodes, uint32_t* cnt_global, int seg_cap, int node_cap,
                                                 uint32_t* s_hist, uint32_t* s_w, uint32_t* s_misc, int32_t* status) {
   const int tid = threadIdx.x;
+  if (n >= 0xffffff) { if (tid == 0) *status = 3; return; }  // (the sort keys of the last levels hold 24 index bits; the callers' own caps are far below)
   int S = 1;                                                 // segments of the current level
   for (int level = 0; level < 40 && S > 0; ++level) {
     // ---- per segment: leaf or split, cut dimension, leftCount
@@ -146,59 +155,81 @@ __device__ __forceinline__ void kd_median_build(int n, float4*& cur, float4*& ot
     if (2 * nsplit > (uint32_t)seg_cap || s_misc[0] + 2 * nsplit > (uint32_t)node_cap) { if (tid == 0) *status = 3; break; }   // cannot happen: caps follow nt_cap
 
     const uint32_t nc = s_misc[0];
+    if (level == 0 && s_misc[2] > 64u) {                     // the root's keys (every later level's come from the partition below)
+      const uint32_t d0 = seg[0].dim;
+      for (int i = tid; i < n; i += kKdThreads) kk[i] = kd_key(kd_coord(cur[i], d0));
+      __syncthreads();
+    }
     if (s_misc[2] <= 64u) {
-      // ---- small segments (<= 64 points each: the last four levels of a 120 k-point cloud, where the radix select below needs
-      // 16-32 sweeps over every point because thousands of segments share the histogram words): every element's exact rank
-      // inside its segment by comparison with the segment's other elements, a wave per window of 128 consecutive positions
-      // (two per lane).  A window owns the segments that START in its first half -- they end inside the window -- so every
-      // comparison partner is in the wave's registers: 128 broadcasts instead of dozens of sweeps through memory.  The rank is
-      // the element's place in (coordinate, index) order, i.e. the order the select's tie rule defines: position = first + rank,
-      // left child = ranks below `left`, cut value = the coordinate of rank `left`.
+      // ---- small segments (<= 64 points each: the last levels, where the radix select below needs 16-32 sweeps over every point
+      // because thousands of segments share the histogram words): a wave sorts a window of 128 consecutive positions (two per
+      // lane) by (segment, coordinate, index) in registers.  A window owns the segments that START in its first half -- they end
+      // inside the window -- so the sorted window holds each of them complete and in the select's order: position = where the
+      // key lands, left child = ranks below `left`, cut value = the coordinate of rank `left`.  (The first form compared every
+      // element with 128 broadcasts: 2 600 instructions per window against ~450 for the 28 compare-exchange stages.)
       const int lane = tid & 63;
       for (uint32_t w0 = 64u * (uint32_t)(tid >> 6); w0 < (uint32_t)n; w0 += (uint32_t)kKdThreads) {
-        uint32_t key[2] = {0, 0}, idx[2] = {0, 0}, first[2] = {0xffffffffu, 0xffffffffu}, left[2] = {0, 0}, segr[2] = {0, 0}, sidv[2] = {0, 0}, rnk[2] = {0, 0};
-        bool own[2] = {false, false};
-        float4 p[2];
+        // a 64-bit sort key per element: [63:56] where its segment starts in the window (+ 64: segments that started in the
+        // previous window come first), [55:24] the coordinate key, [23:0] the point's index in its cloud.  Elements outside
+        // every splitting segment take their own position for the first field (and an all-ones index): they are not moved.
+        unsigned long long kq[2];
+        uint32_t sv0 = 0, left0 = 0, segr0 = 0;
+        bool any_owned = false;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const uint32_t pos = w0 + 64u * e + lane;
           const bool live = pos < (uint32_t)n;
           uint32_t sv = 0xffffffffu;
-          p[e] = make_float4(0, 0, 0, 0);
-          if (live) { sv = sid[pos]; p[e] = cur[pos]; }
+          float4 p = make_float4(0, 0, 0, 0);
+          if (live) { sv = sid[pos]; p = cur[pos]; }
           bool act = false;
+          kq[e] = ((unsigned long long)(64u * e + lane + 64u) << 56) | 0xffffffull;
           if (sv != 0xffffffffu) {
             const KdSeg& g = seg[sv];
             if (g.split) {
               act = true;
-              key[e] = kd_key(kd_coord(p[e], g.dim)); idx[e] = (uint32_t)__float_as_int(p[e].w);
-              first[e] = g.first; left[e] = g.left; segr[e] = g.rank; sidv[e] = sv;
+              const uint32_t key = kd_key(kd_coord(p, g.dim)), idx = (uint32_t)__float_as_int(p.w);
+              kq[e] = ((unsigned long long)(g.first + 64u - w0) << 56) | ((unsigned long long)key << 24) | (unsigned long long)idx;
+              if (e == 0) { sv0 = sv; left0 = g.left; segr0 = g.rank; }
+              any_owned = any_owned || (g.first >= w0 && g.first < w0 + 64u);
             }
           }
-          own[e] = act && first[e] >= w0 && first[e] < w0 + 64u;
-          if (e == 0 && live && !act) { oth[pos] = p[e]; sid_o[pos] = 0xffffffffu; }   // in a leaf (now or earlier): stays where it is for good
+          if (e == 0 && live && !act) { oth[pos] = p; sid_o[pos] = 0xffffffffu; }   // in a leaf (now or earlier): stays where it is for good
         }
-        if (__ballot(own[0] || own[1]) != 0ull) {             // wave-uniform
+        if (__ballot(any_owned) == 0ull) continue;            // wave-uniform
+        // bitonic network over the window's 128 keys, two per lane (window index = lane and lane + 64): 28 stages
 #pragma unroll
-          for (int w = 0; w < 2; ++w) {
-            for (int j = 0; j < 64; ++j) {
-              const uint32_t fj = (uint32_t)__builtin_amdgcn_readlane((int)first[w], j);
-              if (fj == 0xffffffffu) continue;                // not part of a splitting segment (uniform)
-              const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key[w], j);
-              const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)idx[w], j);
+        for (int k = 2; k <= 128; k <<= 1) {
 #pragma unroll
-              for (int e = 0; e < 2; ++e)
-                rnk[e] += (own[e] && fj == first[e] && (kj < key[e] || (kj == key[e] && ij < idx[e]))) ? 1u : 0u;
+          for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j == 64) {
+              const unsigned long long lo = kq[0] < kq[1] ? kq[0] : kq[1], hi = kq[0] < kq[1] ? kq[1] : kq[0];
+              kq[0] = lo; kq[1] = hi;
+            } else {
+              const bool lower = (lane & j) == 0;
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const unsigned long long o = __shfl_xor(kq[e], j, 64);
+                const bool up = k == 128 ? true : (k == 64 ? e == 0 : (lane & k) == 0);
+                const bool take_min = up == lower;
+                const bool o_less = o < kq[e];
+                kq[e] = (take_min == o_less) ? o : kq[e];
+              }
             }
           }
+        }
+        // the key now in slot i belongs at position w0 + i; the segment it is part of started at window index [63:56] - 64
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            if (!own[e]) continue;
-            const uint32_t np = first[e] + rnk[e];
-            oth[np] = p[e];
-            sid_o[np] = 2 * segr[e] + (rnk[e] < left[e] ? 0u : 1u);
-            if (rnk[e] == left[e]) seg[sidv[e]].prefix = key[e];      // the nth element: its coordinate is the cut value
-          }
+        for (int e = 0; e < 2; ++e) {
+          const uint32_t a = (uint32_t)(kq[e] >> 56), idx = (uint32_t)(kq[e] & 0xffffffull), key = (uint32_t)(kq[e] >> 24);
+          const bool mine = a >= 64u && a < 128u && idx != 0xffffffu;        // an element of a segment this window owns
+          const int fl = mine ? (int)(a - 64u) : 0;
+          const uint32_t sv_s = (uint32_t)__shfl((int)sv0, fl, 64), left_s = (uint32_t)__shfl((int)left0, fl, 64), segr_s = (uint32_t)__shfl((int)segr0, fl, 64);
+          if (!mine) continue;
+          const uint32_t i = 64u * e + lane, rnk = i - (uint32_t)fl;
+          oth[w0 + i] = fetch(idx);
+          sid_o[w0 + i] = 2 * segr_s + (rnk < left_s ? 0u : 1u);
+          if (rnk == left_s) seg[sv_s].prefix = key;                           // the nth element: its coordinate is the cut value
         }
       }
     } else {
@@ -232,34 +263,50 @@ __device__ __forceinline__ void kd_median_build(int n, float4*& cur, float4*& ot
           // four positions per thread and trip, their three levels of loads (segment id, point, segment state) issued
           // together: one position at a time every visit was a chain of three dependent memory latencies
           for (uint32_t pos0 = p_lo + tid; pos0 < p_hi; pos0 += 4 * kKdThreads) {
-            uint32_t sv[4];
-            float4 pv[4];
+            uint32_t sv[4], kv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const uint32_t pos = pos0 + u * kKdThreads;
               sv[u] = pos < p_hi ? sid[pos] : 0xffffffffu;
-              pv[u] = cur[min(pos, p_hi - 1u)];
+              kv[u] = kk[min(pos, p_hi - 1u)];
             }
-            uint32_t gdim[4], gpre[4], gsel[4], gvid[4];
+            uint32_t gpre[4], gsel[4], gvid[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const KdSeg& g = seg[sv[u] == 0xffffffffu ? (uint32_t)g0 : sv[u]];
-              gdim[u] = g.dim; gpre[u] = g.prefix; gvid[u] = g.vidx;
+              gpre[u] = g.prefix; gvid[u] = g.vidx;
               gsel[u] = sv[u] == 0xffffffffu ? 0u : (pass == 0 ? g.split : (g.split & g.tie));
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-              if (!gsel[u]) continue;
-              const uint32_t key = kd_key(kd_coord(pv[u], gdim[u]));
+              bool sel = gsel[u] != 0u;
+              uint32_t bin = 0;
+              const uint32_t key = kv[u];
               if (pass == 0) {
-                if (shift + bits < 32 && (key >> (shift + bits)) != (gpre[u] >> (shift + bits))) continue;
-                atomicAdd(&s_hist[((sv[u] - g0) << bits) + ((key >> shift) & mask)], 1u);
+                sel = sel && !(shift + bits < 32 && (key >> (shift + bits)) != (gpre[u] >> (shift + bits)));
+                bin = ((sv[u] - g0) << bits) + ((key >> shift) & mask);
               } else {
-                if (key != gpre[u]) continue;
-                const uint32_t ik = (uint32_t)__float_as_int(pv[u].w);
-                if (shift + bits < 32 && (ik >> (shift + bits)) != (gvid[u] >> (shift + bits))) continue;
-                atomicAdd(&s_hist[((sv[u] - g0) << bits) + ((ik >> shift) & mask)], 1u);
+                sel = sel && key == gpre[u];
+                uint32_t ik = 0;
+                if (sel) ik = (uint32_t)__float_as_int(cur[pos0 + u * kKdThreads].w);           // (ties only: the point's index in its cloud)
+                sel = sel && !(shift + bits < 32 && (ik >> (shift + bits)) != (gvid[u] >> (shift + bits)));
+                bin = ((sv[u] - g0) << bits) + ((ik >> shift) & mask);
               }
+              // neighbours in the working order are neighbours in space: on the upper levels (and in every segment's leading
+              // digits) a whole wave lands in one or two bins, and 64 atomics on one LDS word run one after the other -- the
+              // lanes that share the first two bins met send one atomic each
+              unsigned long long rem = __ballot(sel);
+#pragma unroll
+              for (int r = 0; r < 2; ++r) {
+                if (!rem) break;                                                  // wave-uniform
+                const int lead = __ffsll((long long)rem) - 1;
+                const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)bin, lead);
+                const unsigned long long m = __ballot(sel && bin == bl);
+                if ((tid & 63) == lead) atomicAdd(&s_hist[bl], (uint32_t)__popcll(m));
+                sel = sel && bin != bl;
+                rem &= ~m;
+              }
+              if (sel) atomicAdd(&s_hist[bin], 1u);
             }
           }
           __syncthreads();
@@ -310,6 +357,25 @@ __device__ __forceinline__ void kd_median_build(int n, float4*& cur, float4*& ot
     // equal ones go LEFT (0 for tie-free data).  After pass 1 (ties): vidx = caller index of the first equal point that
     // goes right.  Without ties vidx stays 0: no equal point goes left.
 
+    // ---- the children's cut dimensions (their boxes: the parent's with the cut value on one side), for the keys the partition writes
+    const bool next_ranks = (s_misc[2] + 1u) / 2u <= 64u;    // the next level ranks its segments in registers: it reads no keys
+    if (!next_ranks) {
+      for (int s = s_lo; s < s_hi; ++s) {
+        KdSeg& g = seg[s];
+        if (!g.split) continue;
+        const float cut = kd_unkey(g.prefix);
+        for (int side = 0; side < 2; ++side) {
+          uint32_t cd = 0; float mv = 0.f;
+          for (uint32_t d = 0; d < 3; ++d) {
+            const float lo = (side == 1 && d == g.dim) ? cut : g.mn[d], hi = (side == 0 && d == g.dim) ? cut : g.mx[d];
+            const float e = hi - lo;
+            if (e > mv) { mv = e; cd = d; }
+          }
+          if (side == 0) g.ldim = cd; else g.rdim = cd;
+        }
+      }
+      __syncthreads();
+    }
     // ---- partition into the other buffer; children become the next level's segments
     const bool lds_counters = 2 * S <= kKdHistWords;
     uint32_t* cnt = lds_counters ? s_hist : cnt_global;
@@ -322,7 +388,7 @@ __device__ __forceinline__ void kd_median_build(int n, float4*& cur, float4*& ot
       float4 p = make_float4(0, 0, 0, 0);
       if (live) { s = sid[pos]; p = cur[pos]; }
       bool moving = false, left = false;
-      uint32_t first = 0, nleft = 0, rank = 0;
+      uint32_t first = 0, nleft = 0, rank = 0, ndim = 0;
       if (s != 0xffffffffu) {
         const KdSeg& g = seg[s];
         if (g.split) {
@@ -330,6 +396,7 @@ __device__ __forceinline__ void kd_median_build(int n, float4*& cur, float4*& ot
           const uint32_t key = kd_key(kd_coord(p, g.dim));
           left = key < g.prefix || (key == g.prefix && (uint32_t)__float_as_int(p.w) < g.vidx);
           first = g.first; nleft = g.left; rank = g.rank;
+          ndim = left ? g.ldim : g.rdim;
         }
       }
       if (live && !moving) { oth[pos] = p; sid_o[pos] = 0xffffffffu; }   // in a leaf (now or earlier): stays where it is for good
@@ -355,7 +422,10 @@ __device__ __forceinline__ void kd_median_build(int n, float4*& cur, float4*& ot
         } else if (moving) {
           np = left ? first + atomicAdd(&cnt[2 * s], 1u) : first + nleft + atomicAdd(&cnt[2 * s + 1], 1u);
         }
-        if (moving) { oth[np] = p; sid_o[np] = 2 * rank + (left ? 0u : 1u); }
+        if (moving) {
+          oth[np] = p; sid_o[np] = 2 * rank + (left ? 0u : 1u);
+          if (!next_ranks) kk_o[np] = kd_key(kd_coord(p, ndim));
+        }
       }
     }
     }   // radix select + partition
@@ -376,6 +446,7 @@ __device__ __forceinline__ void kd_median_build(int n, float4*& cur, float4*& ot
     if (tid == 0) s_misc[0] = nc + 2 * nsplit;
     { float4* t4 = cur; cur = oth; oth = t4; }
     { uint32_t* t1 = sid; sid = sid_o; sid_o = t1; }
+    { uint32_t* t1 = kk; kk = kk_o; kk_o = t1; }
     { KdSeg* ts = seg; seg = seg_o; seg_o = ts; }
     S = 2 * (int)nsplit;
     __syncthreads();

@@ -51,7 +51,7 @@ __device__ __forceinline__ float kd_rd_step(float rd, float old_off, float new_o
 }
 
 // Build: grid = (pairs), 1024 threads.  Needs tgt_reduce + grid_setup to have run (st->mu, st->nt).
-__global__ __launch_bounds__(kKdThreads) void kd_build(IcpDev b, KdDev kd) {
+__global__ __launch_bounds__(kKdThreads, 8) void kd_build(IcpDev b, KdDev kd) {
   const int pair = b.pair_base + blockIdx.x;
   PairState* st = &b.state[pair];
   if (st->done) return;
@@ -66,6 +66,8 @@ __global__ __launch_bounds__(kKdThreads) void kd_build(IcpDev b, KdDev kd) {
   float4* oth = kd.alt + to;
   uint32_t* sid = b.tcell + to;                              // segment of every position (0xffffffff = already in a leaf)
   uint32_t* sid_o = b.tslot + to;
+  uint32_t* kk = b.tord + to;                                // the select's keys (the grid's arrays are free in this mode)
+  uint32_t* kk_o = b.ccount + (size_t)pair * (b.nt_cap + 1);
   KdSeg* seg = kd.segs + (size_t)pair * 2 * kd.seg_cap;
   KdSeg* seg_o = seg + kd.seg_cap;
   uint2* nodes = kd.nodes + (size_t)pair * kd.node_cap;
@@ -97,7 +99,9 @@ __global__ __launch_bounds__(kKdThreads) void kd_build(IcpDev b, KdDev kd) {
   __syncthreads();
 
   // ---- libnabo's buildNodes level by level (kd_median_tree.h; bucketSize 8)
-  kd_median_build<kKdBucket>(n, cur, oth, sid, sid_o, seg, seg_o, nodes, kd.cnt + (size_t)pair * 2 * kd.seg_cap, kd.seg_cap, kd.node_cap,
+  const float4* raw_t = b.tgt_p + to;
+  auto fetch = [&](uint32_t i) { const float3 c = centre_point(raw_t[i], mu); return make_float4(c.x, c.y, c.z, __int_as_float((int)i)); };
+  kd_median_build<kKdBucket>(n, fetch, cur, oth, sid, sid_o, seg, seg_o, kk, kk_o, nodes, kd.cnt + (size_t)pair * 2 * kd.seg_cap, kd.seg_cap, kd.node_cap,
                              s_hist, s_w, s_misc, &st->status);
   // ---- final order into tq (+ normals), bucket entries by caller index (a deterministic stand-in for nth_element's
   // unspecified order inside a bucket; it only matters for exactly equidistant entries)

@@ -308,6 +308,7 @@ constexpr int kForestMinScans = 32;
 struct ForestDev {
   float4 *cur, *oth;             // [cap] working orders (point, .w = index in its scan)
   uint32_t *sid, *sid_o;         // [cap] segment of every position
+  uint32_t *kk, *kk_o;           // [cap] the median select's keys (kd_median_tree.h)
   KdSeg* segs;                   // per scan: 2 x (n / 4 + 8) segments at seg_off[scan]
   uint2* nodes;                  // per scan: n / 2 + 8 nodes at node_off[scan]
   uint32_t* cnt;                 // per scan: 2 x (n / 4 + 8) fill counters at seg_off[scan]
@@ -330,6 +331,8 @@ __global__ __launch_bounds__(kKdThreads) void kd_forest_build(const float4* raw,
   float4* oth = f.oth + base;
   uint32_t* sid = f.sid + base;
   uint32_t* sid_o = f.sid_o + base;
+  uint32_t* kk = f.kk + base;
+  uint32_t* kk_o = f.kk_o + base;
   const int seg_cap = n / 4 + 8, node_cap = n / 2 + 8;
   KdSeg* seg = f.segs + f.seg_off[sc];
   KdSeg* seg_o = seg + seg_cap;
@@ -358,7 +361,8 @@ __global__ __launch_bounds__(kKdThreads) void kd_forest_build(const float4* raw,
     s_misc[0] = 1;
   }
   __syncthreads();
-  kd_median_build<kLeafMax>(n, cur, oth, sid, sid_o, seg, seg_o, nodes, f.cnt + f.seg_off[sc], seg_cap, node_cap, s_hist, s_w, s_misc, status);
+  auto fetch = [&](uint32_t i) { const float4 p = p0[i]; return make_float4(p.x, p.y, p.z, __int_as_float((int)i)); };
+  kd_median_build<kLeafMax>(n, fetch, cur, oth, sid, sid_o, seg, seg_o, kk, kk_o, nodes, f.cnt + f.seg_off[sc], seg_cap, node_cap, s_hist, s_w, s_misc, status);
   __syncthreads();
   // the leaves (position ranges of the forest) and the permutation: order[position] = index into raw
   const int nn = (int)s_misc[0];
@@ -436,7 +440,7 @@ void prep_destroy(PrepWorkspace* w) {
   (void)hipFree(w->leaves); (void)hipFree(w->counts); (void)hipFree(w->bbox); (void)hipFree(w->m_dev);
   (void)hipFree(w->lstart); (void)hipFree(w->scan_meta);
   (void)hipFree(w->leaf_p); (void)hipFree(w->leaf_n); (void)hipFree(w->sort_tmp); (void)hipFree(w->avg_cent);
-  (void)hipFree(w->forest.cur); (void)hipFree(w->forest.oth); (void)hipFree(w->forest.sid); (void)hipFree(w->forest.sid_o);
+  (void)hipFree(w->forest.cur); (void)hipFree(w->forest.oth); (void)hipFree(w->forest.sid); (void)hipFree(w->forest.sid_o); (void)hipFree(w->forest.kk); (void)hipFree(w->forest.kk_o);
   (void)hipFree(w->forest.segs); (void)hipFree(w->forest.nodes); (void)hipFree(w->forest.cnt); (void)hipFree(w->forest_meta); (void)hipFree(w->forest_status);
   if (w->host_pinned) (void)hipHostFree(w->host_pinned);
   (void)hipFree(w->mb_meta);
@@ -778,6 +782,7 @@ hipError_t prep_reserve_forest(PrepWorkspace* w) {
   const size_t C = (size_t)w->cap, SG = 2 * (C / 4 + 8 * (size_t)kMaxScans), ND = C / 2 + 8 * (size_t)kMaxScans;
   const bool ok = hipMalloc((void**)&w->forest.cur, C * 16) == hipSuccess && hipMalloc((void**)&w->forest.oth, C * 16) == hipSuccess &&
                   hipMalloc((void**)&w->forest.sid, C * 4) == hipSuccess && hipMalloc((void**)&w->forest.sid_o, C * 4) == hipSuccess &&
+                  hipMalloc((void**)&w->forest.kk, C * 4) == hipSuccess && hipMalloc((void**)&w->forest.kk_o, C * 4) == hipSuccess &&
                   hipMalloc((void**)&w->forest.segs, SG * sizeof(KdSeg)) == hipSuccess && hipMalloc((void**)&w->forest.nodes, ND * sizeof(uint2)) == hipSuccess &&
                   hipMalloc((void**)&w->forest.cnt, SG * 4) == hipSuccess && hipMalloc((void**)&w->forest_meta, sizeof(int32_t) * 2 * kMaxScans) == hipSuccess &&
                   hipMalloc((void**)&w->forest_status, 4) == hipSuccess;

@@ -17,6 +17,7 @@ streams = int(kv.get("streams", "0"))
 dev = torch.device("cuda", 0)
 work = bench.build_workload(D, 120_000, dev)
 ns = max(len(w["src"]) for w in work); nt = max(len(w["q"]) for w in work)
+print(f"source points {ns}, target points {nt}", flush=True)
 for nocert in nocerts:
     m = sm.IcpFastHip(pair_slots=B, max_source_points=ns, max_target_points=nt, max_iteration=20, early_exit=0,
                       nn_mode=sm.NN_NABO, nn_epsilon=3.16, no_certify=nocert, overlap_streams=streams)

@@ -119,6 +119,7 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
                                                 uint2* nodes, uint32_t* cnt_global, int seg_cap, int node_cap,
                                                 uint32_t* s_hist, uint32_t* s_w, uint32_t* s_misc, int32_t* status) {
   const int tid = threadIdx.x;
+  __shared__ uint32_t s_gst[3 * 64];                         // select state of a group's segments during a sweep
   if (n >= 0xffffff) { if (tid == 0) *status = 3; return; }  // (the sort keys of the last levels hold 24 index bits; the callers' own caps are far below)
   int S = 1;                                                 // segments of the current level
   for (int level = 0; level < 40 && S > 0; ++level) {
@@ -259,9 +260,16 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
         }
         for (int shift = 32 - bits; shift >= 0; shift -= bits) {
           for (int k = tid; k < (g1 - g0) << bits; k += kKdThreads) s_hist[k] = 0;
+          // a group of 8-bit digits is at most 64 segments: their select state goes to LDS for the sweep (per position it was a
+          // dependent global load between the segment id and the histogram atomic)
+          const bool staged = bits == 8;
+          if (staged && tid < g1 - g0) {
+            const KdSeg& g = seg[g0 + tid];
+            s_gst[tid] = g.prefix; s_gst[64 + tid] = pass == 0 ? g.split : (g.split & g.tie); s_gst[128 + tid] = g.vidx;
+          }
           __syncthreads();
-          // four positions per thread and trip, their three levels of loads (segment id, point, segment state) issued
-          // together: one position at a time every visit was a chain of three dependent memory latencies
+          // four positions per thread and trip, their levels of loads (segment id + key, segment state) issued together:
+          // one position at a time every visit was a chain of dependent memory latencies
           for (uint32_t pos0 = p_lo + tid; pos0 < p_hi; pos0 += 4 * kKdThreads) {
             uint32_t sv[4], kv[4];
 #pragma unroll
@@ -273,9 +281,15 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
             uint32_t gpre[4], gsel[4], gvid[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-              const KdSeg& g = seg[sv[u] == 0xffffffffu ? (uint32_t)g0 : sv[u]];
-              gpre[u] = g.prefix; gvid[u] = g.vidx;
-              gsel[u] = sv[u] == 0xffffffffu ? 0u : (pass == 0 ? g.split : (g.split & g.tie));
+              if (staged) {
+                const uint32_t sl = sv[u] == 0xffffffffu ? 0u : sv[u] - (uint32_t)g0;
+                gpre[u] = s_gst[sl]; gvid[u] = s_gst[128 + sl];
+                gsel[u] = sv[u] == 0xffffffffu ? 0u : s_gst[64 + sl];
+              } else {
+                const KdSeg& g = seg[sv[u] == 0xffffffffu ? (uint32_t)g0 : sv[u]];
+                gpre[u] = g.prefix; gvid[u] = g.vidx;
+                gsel[u] = sv[u] == 0xffffffffu ? 0u : (pass == 0 ? g.split : (g.split & g.tie));
+              }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -380,23 +394,50 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
     const bool lds_counters = 2 * S <= kKdHistWords;
     uint32_t* cnt = lds_counters ? s_hist : cnt_global;
     for (int k = tid; k < 2 * S; k += kKdThreads) cnt[k] = 0;
+    // while the segments' fields fit next to the fill counters (levels of up to 1 489 segments) the pass reads them from LDS
+    const bool pstaged = 11 * S <= kKdHistWords;
+    uint32_t* sf = s_hist + 2 * S;                             // [9][S]: split, dim, prefix, vidx, first, left, rank, ldim, rdim
+    if (pstaged)
+      for (int k = tid; k < S; k += kKdThreads) {
+        const KdSeg& g = seg[k];
+        sf[k] = g.split; sf[S + k] = g.dim; sf[2 * S + k] = g.prefix; sf[3 * S + k] = g.vidx; sf[4 * S + k] = g.first;
+        sf[5 * S + k] = g.left; sf[6 * S + k] = g.rank; sf[7 * S + k] = g.ldim; sf[8 * S + k] = g.rdim;
+      }
     __syncthreads();
-    for (uint32_t pos0 = 0; pos0 < (uint32_t)n; pos0 += kKdThreads) {     // whole waves take the trip together (ballots below)
-      const uint32_t pos = pos0 + tid;
+    constexpr int kPU = 4;                                    // positions per thread and trip, their loads issued together
+    for (uint32_t pos0 = 0; pos0 < (uint32_t)n; pos0 += kPU * kKdThreads) {     // whole waves take the trip together (ballots below)
+      uint32_t sq[kPU];
+      float4 pq[kPU];
+#pragma unroll
+      for (int u = 0; u < kPU; ++u) {
+        const uint32_t pos = pos0 + u * kKdThreads + tid;
+        sq[u] = 0xffffffffu;
+        pq[u] = make_float4(0, 0, 0, 0);
+        if (pos < (uint32_t)n) { sq[u] = sid[pos]; pq[u] = cur[pos]; }
+      }
+#pragma unroll
+      for (int u = 0; u < kPU; ++u) {
+      const uint32_t pos = pos0 + u * kKdThreads + tid;
       const bool live = pos < (uint32_t)n;
-      uint32_t s = 0xffffffffu;
-      float4 p = make_float4(0, 0, 0, 0);
-      if (live) { s = sid[pos]; p = cur[pos]; }
+      const uint32_t s = sq[u];
+      const float4 p = pq[u];
       bool moving = false, left = false;
       uint32_t first = 0, nleft = 0, rank = 0, ndim = 0;
       if (s != 0xffffffffu) {
-        const KdSeg& g = seg[s];
-        if (g.split) {
+        uint32_t g_split, g_dim, g_prefix, g_vidx, g_ldim, g_rdim;
+        if (pstaged) {
+          g_split = sf[s]; g_dim = sf[S + s]; g_prefix = sf[2 * S + s]; g_vidx = sf[3 * S + s]; first = sf[4 * S + s];
+          nleft = sf[5 * S + s]; rank = sf[6 * S + s]; g_ldim = sf[7 * S + s]; g_rdim = sf[8 * S + s];
+        } else {
+          const KdSeg& g = seg[s];
+          g_split = g.split; g_dim = g.dim; g_prefix = g.prefix; g_vidx = g.vidx; first = g.first; nleft = g.left; rank = g.rank;
+          g_ldim = g.ldim; g_rdim = g.rdim;
+        }
+        if (g_split) {
           moving = true;
-          const uint32_t key = kd_key(kd_coord(p, g.dim));
-          left = key < g.prefix || (key == g.prefix && (uint32_t)__float_as_int(p.w) < g.vidx);
-          first = g.first; nleft = g.left; rank = g.rank;
-          ndim = left ? g.ldim : g.rdim;
+          const uint32_t key = kd_key(kd_coord(p, g_dim));
+          left = key < g_prefix || (key == g_prefix && (uint32_t)__float_as_int(p.w) < g_vidx);
+          ndim = left ? g_ldim : g_rdim;
         }
       }
       if (live && !moving) { oth[pos] = p; sid_o[pos] = 0xffffffffu; }   // in a leaf (now or earlier): stays where it is for good
@@ -426,6 +467,7 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
           oth[np] = p; sid_o[np] = 2 * rank + (left ? 0u : 1u);
           if (!next_ranks) kk_o[np] = kd_key(kd_coord(p, ndim));
         }
+      }
       }
     }
     }   // radix select + partition

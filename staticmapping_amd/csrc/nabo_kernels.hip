@@ -51,7 +51,7 @@ __device__ __forceinline__ float kd_rd_step(float rd, float old_off, float new_o
 }
 
 // Build: grid = (pairs), 1024 threads.  Needs tgt_reduce + grid_setup to have run (st->mu, st->nt).
-__global__ __launch_bounds__(kKdThreads, 8) void kd_build(IcpDev b, KdDev kd) {
+__global__ __launch_bounds__(kKdThreads) void kd_build(IcpDev b, KdDev kd) {
   const int pair = b.pair_base + blockIdx.x;
   PairState* st = &b.state[pair];
   if (st->done) return;

@@ -24,6 +24,8 @@ struct GicpDev {
   float4* qraw;            // [ns_cap] matched raw target point; w = 1 if the correspondence is kept
   double* partials;        // [kGicpMaxBlocks][kGicpCols]
   double* out;             // [kGicpCols]
+  uint32_t* ticket;        // workgroups of the running gicp_fdf that have written their partial sums
+  double* out_host;        // [kGicpCols + 1] page-locked host memory: the folded sums and, last, the evaluation's sequence number
   uint32_t* count;         // kept correspondences
 };
 
@@ -198,7 +200,10 @@ struct GicpPose {
 };
 
 // sums of the functor over the kept correspondences: f (:272), g_t (:316-318), R (:320-321)
-__global__ __launch_bounds__(256) void gicp_fdf(IcpDev b, GicpDev g, int ns, GicpPose P) {
+// The workgroup that finishes last folds the partial sums (gicp_reduce's order) and stores them straight into page-locked
+// host memory, the evaluation's sequence number after them: the host, which needs f and g before it can choose the next
+// point, spins on that number instead of paying for a second launch, a copy and a stream synchronise per evaluation.
+__global__ __launch_bounds__(256) void gicp_fdf(IcpDev b, GicpDev g, int ns, GicpPose P, unsigned long long seq) {
   double acc[13];
 #pragma unroll
   for (int k = 0; k < 13; ++k) acc[k] = 0.0;
@@ -237,9 +242,38 @@ __global__ __launch_bounds__(256) void gicp_fdf(IcpDev b, GicpDev g, int ns, Gic
     s_red[wave][13] = cnt; s_red[wave][14] = 0; s_red[wave][15] = 0;
   }
   __syncthreads();
-  if (threadIdx.x < kGicpCols)
+  if (threadIdx.x < kGicpCols) {
     g.partials[(size_t)blockIdx.x * kGicpCols + threadIdx.x] =
         s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+    __threadfence();
+  }
+  __shared__ uint32_t s_last;
+  __shared__ double s_g[16][kGicpCols];
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(g.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  {
+    const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;            // 16 strided groups, then the groups in turn: gicp_reduce's order
+    double t = 0;
+    for (int k = grp; k < (int)gridDim.x; k += 16) t += g.partials[(size_t)k * kGicpCols + c];
+    s_g[grp][c] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < kGicpCols) {
+    double t = 0;
+    for (int k = 0; k < 16; ++k) t += s_g[k][threadIdx.x];
+    g.out[threadIdx.x] = t;
+    g.out_host[threadIdx.x] = t;
+    __threadfence_system();
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *g.ticket = 0;
+    __threadfence_system();
+    *reinterpret_cast<volatile unsigned long long*>(g.out_host + kGicpCols) = seq;
+  }
 }
 
 // fixed-order fold of the block partials (repeated evaluations at one x are bitwise identical)

@@ -6,6 +6,7 @@
 // The matcher keeps its raw clouds in private device buffers (the reference converts its stored clouds in every
 // Align, ndt_gicp.cc:59-76) and uses pair slot 0 as the working pair for the down-sampled clouds and slot 1 as
 // scratch for the source's neighbour search, so the handle needs pair_slots >= 2.
+#include <chrono>
 #include <cstdlib>
 #include <cstdio>
 #include "gicp_kernels.hip"
@@ -24,6 +25,7 @@ struct GicpHost {
   double* rot_dev = nullptr;          // 9 doubles
   uint32_t* count_pinned = nullptr;
   int evals = 0;
+  unsigned long long seq = 0;         // evaluations launched so far: the number gicp_fdf stores after its sums
   // what is derived from the target alone is kept while the target is (smhip_set_target_cache, default on): the front end
   // aligns scan after scan against one submap, and ndt_gicp.cc filters / rebuilds / re-estimates all of it in every Align
   unsigned long long raw_tgt_gen = 0;       // bumped by every smhip_ndt_gicp_set_target_f32
@@ -53,16 +55,20 @@ smhip_status gicp_ensure(smhip_context* h) {
   A(dev_alloc(h, &g.dev.partials, (size_t)kGicpMaxBlocks * kGicpCols));
   A(dev_alloc(h, &g.dev.out, (size_t)kGicpCols));
   A(dev_alloc(h, &g.dev.count, 4));
+  A(dev_alloc(h, &g.dev.ticket, 4));
   A(dev_alloc(h, &g.raw_src, NS));
   A(dev_alloc(h, &g.raw_tgt, NT));
   A(dev_alloc(h, &g.ds_tmp, std::max(NS, NT)));
   A(dev_alloc(h, &g.rot_dev, 9));
   if (s) return s;
-  if (hipHostMalloc(reinterpret_cast<void**>(&g.out_pinned), sizeof(double) * kGicpCols) != hipSuccess ||
+  if (hipHostMalloc(reinterpret_cast<void**>(&g.out_pinned), sizeof(double) * (kGicpCols + 1)) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&g.count_pinned), sizeof(uint32_t) * 4) != hipSuccess) {
     h->err = "hipHostMalloc failed (GICP)";
     return SMHIP_ERR_HIP;
   }
+  std::memset(g.out_pinned, 0, sizeof(double) * (kGicpCols + 1));
+  g.dev.out_host = g.out_pinned;                       // (page-locked host memory is device-addressable at the same pointer)
+  if (hipMemsetAsync(g.dev.ticket, 0, sizeof(uint32_t) * 4, h->stream) != hipSuccess) { h->err = "hipMemsetAsync failed (GICP)"; return SMHIP_ERR_HIP; }
   g.allocated = true;
   return SMHIP_OK;
 }
@@ -118,10 +124,19 @@ struct GicpFunctor {
     apply_state_f32(base, x, T);
     for (int i = 0; i < 12; ++i) { P.T[i] = T[i]; P.B[i] = base[i]; }
     const int blocks = std::min(kGicpMaxBlocks, std::max(1, ceil_div(ns, 256)));
-    hipLaunchKernelGGL(gicp_fdf, dim3(blocks), dim3(256), 0, h->stream, h->dev, G.dev, ns, P);
-    hipLaunchKernelGGL(gicp_reduce, dim3(1), dim3(16 * 64), 0, h->stream, G.dev, blocks);
-    if (hipMemcpyAsync(G.out_pinned, G.dev.out, sizeof(double) * kGicpCols, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-        hipStreamSynchronize(h->stream) != hipSuccess) { status = SMHIP_ERR_HIP; f = 0; for (int i = 0; i < 6; ++i) g[i] = 0; return; }
+    // one launch; its last workgroup stores the sums and then this evaluation's number into page-locked memory (gicp_fdf)
+    const unsigned long long seq = ++G.seq;
+    hipLaunchKernelGGL(gicp_fdf, dim3(blocks), dim3(256), 0, h->stream, h->dev, G.dev, ns, P, seq);
+    bool ok = hipGetLastError() == hipSuccess;
+    if (ok) {
+      volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(G.out_pinned + kGicpCols);
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (__atomic_load_n(const_cast<unsigned long long*>(flag), __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { ok = false; break; }   // a lost launch: report, do not hang
+      }
+    }
+    if (!ok) { (void)hipStreamSynchronize(h->stream); status = SMHIP_ERR_HIP; f = 0; for (int i = 0; i < 6; ++i) g[i] = 0; return; }
     const double* o = G.out_pinned;
     const double m = o[13];
     f = o[0] / m;

@@ -745,6 +745,36 @@ def other_workloads(dev, with_cpu):
                                            "note": "down-sampled target, NDT voxel table, correspondence grid and the target's GICP covariances kept "
                                                    "across Aligns on an unchanged target (smhip_set_target_cache, default on)"},
                            "cpu_baseline": None}
+        # the back end's form (six SubmapPairMatch tasks, a matcher each): six handles on six host threads, everything rebuilt
+        try:
+            import threading
+            pool = [m]
+            for _ in range(5):
+                mk = sm.NdtGicpHip(max_source_points=len(src), max_target_points=len(tgt))
+                mk.set_input_source(src); mk.set_input_target(tgt)
+                pool.append(mk)
+            for mk in pool:
+                mk.set_target_cache(False); mk.align(G)
+            res = [None] * len(pool)
+
+            def run(k):
+                for _ in range(reps):
+                    res[k] = pool[k].align(G)[1]
+            ths = [threading.Thread(target=run, args=(k,)) for k in range(len(pool))]
+            t = time.perf_counter()
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            dt_pool = (time.perf_counter() - t) / (reps * len(pool))
+            out["ndt_gicp"]["six_concurrent_matchers"] = {"value": round(1.0 / dt_pool, 2), "unit": "alignments/s", "matchers": len(pool),
+                                                          "identical_to_single": bool(all(np.array_equal(r, R) for r in res)),
+                                                          "note": "six handles (own arena + stream) on six host threads, everything rebuilt per Align"}
+            for mk in pool[1:]:
+                mk.close()
+            m.set_target_cache(True)
+        except Exception as e:
+            out["ndt_gicp"]["six_concurrent_matchers"] = {"error": repr(e)}
         recorded = os.path.join(ROOT, "profiles", "r02_gicp_cpu_baseline.json")
         if not (with_cpu and os.environ.get("SMHIP_BENCH_GICP_CPU", "1") == "1") and os.path.exists(recorded):
             # the numpy oracle needs ~30 s for this case on the GPU box: when it is switched off (SMHIP_BENCH_GICP_CPU=0 or

@@ -120,7 +120,7 @@ __global__ void pose_setup(IcpDev b, int npairs) {
   st->n_hist = 1;
   st->iter = 0; st->done = 0; st->status = 0;
   st->unresolved_count = 0; st->fallback_ticket = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
-  st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0; st->searched_total = 0; st->qv_valid = 0;
+  st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0; st->searched_total = 0;
   for (int c = 0; c < 4; ++c) st->nabo_count[c] = 0;
   st->pot_a = 0; st->pot_b = 0; st->step_a = 0; st->step_b = 0;
   st->rcap2 = b.ball_radius * b.ball_radius;
@@ -169,7 +169,7 @@ __global__ void grid_setup(IcpDev b, int npairs) {
     for (int i = 0; i < 12; ++i) { st->M[i] = st->guess[i]; st->M_prev[i] = st->guess[i]; }
     st->n_hist = 1; st->iter = 0; st->score = 0; st->kept = 0; st->limit_key = 0;
     st->unresolved_count = 0; st->fallback_ticket = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
-    st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0; st->searched_total = 0; st->qv_valid = 0;
+    st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0; st->searched_total = 0;
   for (int c = 0; c < 4; ++c) st->nabo_count[c] = 0;
   st->pot_a = 0; st->pot_b = 0; st->step_a = 0; st->step_b = 0;
     st->rcap2 = 0.f;
@@ -205,7 +205,7 @@ __global__ void grid_setup(IcpDev b, int npairs) {
   st->n_hist = 1;
   st->iter = 0; st->done = 0; st->status = 0;
   st->unresolved_count = 0; st->fallback_ticket = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
-  st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0; st->searched_total = 0; st->qv_valid = 0;
+  st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0; st->searched_total = 0;
   for (int c = 0; c < 4; ++c) st->nabo_count[c] = 0;
   st->pot_a = 0; st->pot_b = 0; st->step_a = 0; st->step_b = 0;
   st->rcap2 = b.ball_radius * b.ball_radius;
@@ -1813,10 +1813,6 @@ __device__ __forceinline__ void validate_bounds(const IcpDev& b, PairState* st, 
     const bool below = (st->min_lb_key >> kHistShift) <= s_q[0];
     st->refine = (any && (b.exact_all || below || s_q[2] == 0)) ? 1 : 0;
     if (st->refine) st->refine_total += 1;
-    // nothing touches the histogram between here and finalize unless the bounds are refined: the bin found here is the one
-    // accumulate's workgroups and finalize would each find again
-    st->qv[0] = s_q[0]; st->qv[1] = s_q[1]; st->qv[2] = s_q[2]; st->qv[3] = s_q[3];
-    st->qv_valid = st->refine ? 0 : 1;
   }
 }
 
@@ -1935,9 +1931,8 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
   __shared__ uint32_t s_q[4];
   __shared__ double s_red[4][29];
   __shared__ double s_out[29];
-  uint32_t qbin;
-  if (st->qv_valid) qbin = st->qv[0];                         // (block-uniform: scalar loads)
-  else { find_quantile_bin(b.hist + (size_t)pair * kHistBins, b.rho, s_w, s_q); qbin = s_q[0]; }
+  find_quantile_bin(b.hist + (size_t)pair * kHistBins, b.rho, s_w, s_q);
+  const uint32_t qbin = s_q[0];
   double acc[29];
 #pragma unroll
   for (int c = 0; c < 29; ++c) acc[c] = 0.0;
@@ -2128,8 +2123,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   __shared__ double s_part[8][32];
   __shared__ uint32_t s_keys[kFinalizeKeyCap];
   uint32_t* gh = b.hist + (size_t)pair * kHistBins;
-  if (st->qv_valid) { if (threadIdx.x < 4) s_q[threadIdx.x] = st->qv[threadIdx.x]; __syncthreads(); }
-  else find_quantile_bin(gh, b.rho, s_w, s_q);
+  find_quantile_bin(gh, b.rho, s_w, s_q);
   const uint32_t qbin = s_q[0], below = s_q[1], n_valid = s_q[2], krank = s_q[3];
   const size_t so = (size_t)pair * b.ns_cap;
   const int ns = st->ns;
@@ -2313,7 +2307,6 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   st->deferred_count = 0;
   st->min_lb_key = 0xffffffffu;
   st->refine = 0;
-  st->qv_valid = 0;
   {   // next search radius: cap_factor x the quantile distance, clamped to [0.05 m, ball_radius]
     const float lim = sqrtf(__uint_as_float(limit_key));
     float rc = fminf(fmaxf(b.cap_factor * lim, 0.05f), b.ball_radius);

@@ -82,9 +82,7 @@ struct PairState {
   uint32_t limit_key;
   uint32_t nabo_count[4];    // SMHIP_NN_NABO: queries to walk again this iteration, by the work class of their last walk (nn_certify<., true>)
   int32_t grid_invalid;      // 1 = grid_setup found a non-finite target box: no search structure was built for this target, and
-                             //     every Align on it fails (pose_setup re-asserts it when the structure is "kept")
-  int32_t qv_valid;          // 1 = qv[] is this iteration's quantile bin as nn_validate found it and nothing has touched the histogram since
-  uint32_t qv[4];            //     (find_quantile_bin's four words: bin, entries below it, valid entries, rank): accumulate / finalize read them
+  int32_t pad_;              //     every Align on it fails (pose_setup re-asserts it when the structure is "kept")
 
   // outputs
   double score;

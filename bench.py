@@ -393,7 +393,7 @@ def main():
             "parity": {"worst_rot_err_vs_truth_rad": h_rot, "worst_trans_err_vs_truth_m": h_t, "median_trans_err_vs_truth_m": h_med},
             "workload_generation_s": round(t_gen, 1),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and rank == 0:     # (the CPU oracle legs: rank 0 alone, the other ranks wait at the final barrier)
             cpu, par = cpu_baseline_and_parity(work, figures, head, head_key, args.cpu_pairs or D, world)
             out["parity"].update(par)
             if world == 1:

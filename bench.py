@@ -115,8 +115,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SMHIP_BENCH_SHARED_GPU=1: a dry run of the multi-rank control flow on a box with fewer GPUs than ranks (ranks share
+    # devices, gloo instead of RCCL, the collectives' tensors on the host): the same sequence of collectives, no valid timing
+    shared_gpu = os.environ.get("SMHIP_BENCH_SHARED_GPU") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if shared_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = torch.device("cpu") if shared_gpu else dev
     # rank 0 prints ONE JSON line on stdout: RCCL's version banner and its warnings (it logs to stdout by default,
     # some of them at process exit) go to stderr instead
     if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
@@ -125,7 +130,10 @@ def main():
     under_torchrun = "RANK" in os.environ and "MASTER_PORT" in os.environ
     if world > 1 or under_torchrun:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B = args.pairs
     n_total = B * world
@@ -141,7 +149,7 @@ def main():
     tstream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
-    m = sm.IcpFastHip(device=local_rank, pair_slots=B, max_source_points=ns, max_target_points=nt, stream=stream,
+    m = sm.IcpFastHip(device=dev_index, pair_slots=B, max_source_points=ns, max_target_points=nt, stream=stream,
                       max_iteration=ICP_ITERS, early_exit=0, dist_outlier_ratio=RHO,
                       nn_mode=1 if args.nn_mode == "grid" else 0, grid_cell=args.cell, grid_max_ring=args.ring,
                       split_after=args.split_after, ball_radius=args.ball_radius, overlap_streams=args.streams)
@@ -166,6 +174,8 @@ def main():
         def step():
             m.enqueue_batch(B, guesses)
             m.export_results_device(B, poses_local.data_ptr())
+            if shared_gpu:
+                return shard.gather_poses(poses_local.cpu(), n_total)
             return shard.gather_poses(poses_local, n_total)
         for _ in range(warmup):
             step()
@@ -178,7 +188,7 @@ def main():
         sync_all()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         res, scores, stats = m.fetch_batch(B)
@@ -220,7 +230,7 @@ def main():
     dom_single = max(single, key=lambda k: single[k])
     prof_class = {"nn_main": 2, "nn_certify": 2, "accumulate": 3, "nn_listed": 4}[dom_single]
     if world > 1:      # every rank must time the same thing
-        t = torch.tensor([prof_class], dtype=torch.int32, device=dev)
+        t = torch.tensor([prof_class], dtype=torch.int32, device=coll_dev)
         dist.broadcast(t, 0)
         prof_class = int(t.item())
     head = timed_run(head_key, args.steps, args.warmup, profile_nn=prof_class)
@@ -411,7 +421,7 @@ def main():
                 "approximate search -- the parity the exact modes cannot have (see parity.exact_vs_reference_eps3.16)")
     m.close()
     if rank == 0 and world == 1 and not args.no_other:
-        out["single_pair"] = single_pair_latency(work[0], local_rank)
+        out["single_pair"] = single_pair_latency(work[0], dev_index)
         out["other_workloads"] = other_workloads(dev, not args.no_cpu_baseline)
         if not args.no_end_to_end:
             out["end_to_end"] = end_to_end(dev, n_scans=1025)

@@ -94,3 +94,25 @@ def test_two_ranks_with_the_real_matcher(tmp_path):
         da, dt = sm.se3_error(T2[k], T1[k])
         assert da < 1e-7 and dt < 1e-6, (k, da, dt)              # same kernels; only the batch composition differs
         assert abs(s2[k] - s1[k]) < 1e-7
+
+
+@pytest.mark.gpu
+def test_bench_runs_its_multi_rank_sequence_to_the_end(tmp_path):
+    """bench.py under torch.distributed.run with two ranks, as the driver launches it for N > 1 -- on this one-GPU box in its
+    dry-run mode (SMHIP_BENCH_SHARED_GPU=1: the ranks share the device, gloo carries the collectives): every rank must
+    reach the same barriers, gathers, the reduce of the timing and the broadcast of the profiled class, and rank 0 must
+    print one line for two GPUs whose poses are right."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SMHIP_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--pairs", "32", "--distinct", "8", "--cpu-pairs", "2"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-500:]                  # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["parity"]["worst_trans_err_vs_truth_m"] < 0.05
+    assert "cpu_baseline" not in d                           # the CPU legs are a one-GPU report
+    assert set(d["figures"]) >= {"extrapolated_guess", "identity_guess", "reference_search_eps3.16", "early_exit"}

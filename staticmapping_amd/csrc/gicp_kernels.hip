@@ -129,11 +129,20 @@ __global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pa
     rp = r;
   }
   // covariance of the k neighbours from the RAW coordinates; the products pt.x * pt.y are float products (:95-103)
+  // The set's slots are filled in visiting order, and the order of the points inside a grid cell is whatever the build's
+  // atomics made it (these grids skip the per-cell sort): summed slot by slot the covariance would differ in its last bits
+  // between two builds of the same grid -- seen as 5e-10 on a pose when two matchers ran side by side.  The neighbours are
+  // summed in the order of their indices in the caller's cloud instead (k passes over the k slots).
   const float4* raw = b.tgt_p + (size_t)pair * b.nt_cap;
+  for (int m = 0; m < k; ++m) s_j[m][t] = __float_as_int(tq[s_j[m][t]].w);
   double mean[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
+  int last = -1;
   for (int m = 0; m < k; ++m) {
-    const int jj = s_j[m][t];
-    const float4 p = raw[__float_as_int(tq[jj].w)];
+    int nxt = 0x7fffffff;
+#pragma unroll
+    for (int e = 0; e < KMAX; ++e) { const int o = s_j[e][t]; nxt = (e < k && o > last && o < nxt) ? o : nxt; }
+    last = nxt;
+    const float4 p = raw[nxt];
     mean[0] += p.x; mean[1] += p.y; mean[2] += p.z;
     const float xx = p.x * p.x, yx = p.y * p.x, yy = p.y * p.y, zx = p.z * p.x, zy = p.z * p.y, zz = p.z * p.z;
     c[0] += (double)xx; c[1] += (double)yx; c[2] += (double)zx; c[3] += (double)yy; c[4] += (double)zy; c[5] += (double)zz;

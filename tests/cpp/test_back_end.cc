@@ -82,6 +82,23 @@ int main(int argc, char** argv) {
       for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) pool_equal = pool_equal && pooled[k].transform_to_next(r, c) == one.transform_to_next(r, c);
     }
   }
+  // the same through registrators::NdtWithGicp (host-driven BFGS per pair): four pairs, two matchers
+  bool gicp_pool_equal = true;
+  {
+    reg::MatcherOptions gopt; gopt.type = reg::kNdtWithGicp; gopt.accepted_min_score = -1.0f;
+    std::vector<smhip::back_end::SubmapPairJob> gjobs(4);
+    for (int k = 0; k < 4; ++k) { gjobs[k] = jobs[0]; gjobs[k].source_first_frame_pose(0, 3) += 0.03 * k; }
+    smhip::back_end::SubmapMatcherPool gpool(gopt, 2);
+    const auto pooled = gpool.Match(gjobs);
+    for (int k = 0; k < 4; ++k) {
+      const auto one = smhip::back_end::SubmapPairMatch(gopt, gjobs[k].source_submap_cloud, gjobs[k].source_first_frame_pose,
+                                                         gjobs[k].target_submap_cloud, gjobs[k].target_first_frame_pose);
+      // (to one float ulp of the float 4x4 GICP works in: in this flow -- a new handle per call -- an NdtWithGicp result
+      // flips between two values 4.7e-10 apart from one run to the next, single calls among themselves included)
+      gicp_pool_equal = gicp_pool_equal && std::fabs(pooled[k].match_score - one.match_score) < 1e-8;
+      for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) gicp_pool_equal = gicp_pool_equal && std::fabs(pooled[k].transform_to_next(r, c) - one.transform_to_next(r, c)) < 1e-8;
+    }
+  }
   // a loop-closure matcher that outlives its candidates
   reg::IcpPointMatcherHip keep_matcher(settings.device, 1 << 12);            // deliberately too small: must re-size itself
   keep_matcher.InitWithOptions();
@@ -89,7 +106,7 @@ int main(int argc, char** argv) {
   const bool closed2 = smhip::back_end::CloseLoop(tpose, target, spose, source, settings, &edge2, &keep_matcher);
   const bool closed_far2 = smhip::back_end::CloseLoop(tpose, target, far, source, settings, &bad_edge2, &keep_matcher);
 
-  std::printf("{\"pool_equal\": %s, \"pool_accepted\": %d, \"closed\": %s, \"edge_score\": %.17g, \"closed_far\": %s, ", pool_equal ? "true" : "false", pool_accepted,
+  std::printf("{\"pool_equal\": %s, \"gicp_pool_equal\": %s, \"pool_accepted\": %d, \"closed\": %s, \"edge_score\": %.17g, \"closed_far\": %s, ", pool_equal ? "true" : "false", gicp_pool_equal ? "true" : "false", pool_accepted,
               closed ? "true" : "false", edge.score, closed_far ? "true" : "false");
   PrintMatrix("edge_guess", edge.init_guess);
   PrintMatrix("edge_transform", edge.transform);

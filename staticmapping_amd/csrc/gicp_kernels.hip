@@ -49,6 +49,17 @@ __device__ __forceinline__ void sym_inverse(const double* a, double* o) {
 // the x-extent of a grid row is one contiguous run of the cell-sorted target (row_slots).  A shell ends the
 // search once the k-th distance is within the distance to the nearest unexplored face (block_guarantee).
 // cov is indexed by the point's position in the pair's raw target array (tq.w), so it survives grid rebuilds.
+// the slow path of gicp_knn_cov's neighbour set (ties at the set's largest distance; kept out of line so that the loop over
+// the slots does not end up in the hot path's registers): among the members at distance `w`, the slot of the one with the
+// largest caller index, and that index
+template <int KMAX>
+__device__ __noinline__ int knn_largest_index_at(const float (*s_d)[kGicpKnnThreads], const int (*s_j)[kGicpKnnThreads], int t, float w, int* slot) {
+  int wo = -1, wp = 0;
+  for (int m = 0; m < KMAX; ++m) if (s_d[m][t] == w) { const int o = s_j[m][t]; if (o > wo) { wo = o; wp = m; } }
+  *slot = wp;
+  return wo;
+}
+
 template <int KMAX>
 __global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pair, int k, double gicp_epsilon, double* cov) {
   __shared__ float s_d[KMAX][kGicpKnnThreads];
@@ -75,10 +86,25 @@ __global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pa
     row_slots(words, rowbase, xa, xb, sa, sb);
     if (sa == sb) return;                       // empty stretch of the row (most of a large shell): no run to fetch
     const uint32_t pa = cstart[sa], pb = cstart[sb];
-    auto consider = [&](const float4 c, uint32_t p) {
+    // The set is the k smallest by (distance, index in the caller's cloud).  Two candidates at the same float distance from the
+    // query are not rare enough to ignore (a 37 k-point submap had one point whose 20th and 21st neighbours tie): with "first
+    // visited stays" the set -- and that point's covariance, by 2e-2 -- followed the order of the points inside a grid cell,
+    // which the builds of these grids leave to their atomics.  Ties only cost when they happen: a candidate AT the set's
+    // largest distance, or an eviction that leaves another member at the evicted one's distance, takes the slow path.
+    auto consider = [&](const float4 c, uint32_t) {
       const float d = dist2(c, q.x, q.y, q.z);
-      if (!(d < worst)) return;
-      s_d[wpos][t] = d; s_j[wpos][t] = (int)p;          // evict the farthest member
+      if (!(d <= worst)) return;
+      const int co = __float_as_int(c.w);
+      if (d == worst) {
+        if (!(worst < INFINITY)) return;
+        int wp2;                                          // the member at this distance with the largest index ...
+        const int wo = knn_largest_index_at<KMAX>(s_d, s_j, t, worst, &wp2);
+        if (co < wo) s_j[wp2][t] = co;                    // ... makes way for a candidate with a smaller one (same distance: worst, wpos stand)
+        return;
+      }
+      const float old = worst;
+      const int old_o = s_j[wpos][t];
+      s_d[wpos][t] = d; s_j[wpos][t] = co;              // evict the farthest member
       // new farthest member: KMAX independent LDS reads issued back to back (compile-time trip count: with a run-time
       // bound every read waited for the one before it, and a wave pays this whenever ANY of its lanes accepts a candidate)
       float dm[KMAX];
@@ -88,6 +114,12 @@ __global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pa
       int wp = 0;
 #pragma unroll
       for (int m = 0; m < KMAX; ++m) { const bool g = dm[m] > w; w = g ? dm[m] : w; wp = g ? m : wp; }
+      if (w == old && old < INFINITY) {
+        // another member sat at the evicted one's distance: of all of them the one with the largest index is the one to go
+        int wp2;
+        const int wo = knn_largest_index_at<KMAX>(s_d, s_j, t, w, &wp2);
+        if (old_o < wo) s_j[wp2][t] = old_o;              // the evicted member comes back in that one's place
+      }
       worst = w; wpos = wp;
     };
     uint32_t p = pa;
@@ -129,12 +161,10 @@ __global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pa
     rp = r;
   }
   // covariance of the k neighbours from the RAW coordinates; the products pt.x * pt.y are float products (:95-103)
-  // The set's slots are filled in visiting order, and the order of the points inside a grid cell is whatever the build's
-  // atomics made it (these grids skip the per-cell sort): summed slot by slot the covariance would differ in its last bits
-  // between two builds of the same grid -- seen as 5e-10 on a pose when two matchers ran side by side.  The neighbours are
-  // summed in the order of their indices in the caller's cloud instead (k passes over the k slots).
+  // The set's slots are filled in visiting order, which follows the order of the points inside a grid cell: summed slot by
+  // slot the covariance would differ in its last bits between two builds of the same grid.  The neighbours (s_j holds their
+  // indices in the caller's cloud) are summed in index order instead: k passes over the k slots.
   const float4* raw = b.tgt_p + (size_t)pair * b.nt_cap;
-  for (int m = 0; m < k; ++m) s_j[m][t] = __float_as_int(tq[s_j[m][t]].w);
   double mean[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
   int last = -1;
   for (int m = 0; m < k; ++m) {

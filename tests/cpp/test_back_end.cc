@@ -93,10 +93,8 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 4; ++k) {
       const auto one = smhip::back_end::SubmapPairMatch(gopt, gjobs[k].source_submap_cloud, gjobs[k].source_first_frame_pose,
                                                          gjobs[k].target_submap_cloud, gjobs[k].target_first_frame_pose);
-      // (to one float ulp of the float 4x4 GICP works in: in this flow -- a new handle per call -- an NdtWithGicp result
-      // flips between two values 4.7e-10 apart from one run to the next, single calls among themselves included)
-      gicp_pool_equal = gicp_pool_equal && std::fabs(pooled[k].match_score - one.match_score) < 1e-8;
-      for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) gicp_pool_equal = gicp_pool_equal && std::fabs(pooled[k].transform_to_next(r, c) - one.transform_to_next(r, c)) < 1e-8;
+      gicp_pool_equal = gicp_pool_equal && pooled[k].match_score == one.match_score;
+      for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) gicp_pool_equal = gicp_pool_equal && pooled[k].transform_to_next(r, c) == one.transform_to_next(r, c);
     }
   }
   // a loop-closure matcher that outlives its candidates

@@ -742,6 +742,7 @@ smhip_status smhip_set_sources_f32_batch(smhip_handle h, int count, const int* s
     if (n[k] > h->dev.ns_cap) { h->err = "source larger than max_source_points"; return SMHIP_ERR_CAPACITY; }
     total += n[k];
   }
+  if (total > 0x7fffffffll) { h->err = "batch of sources holds more than 2^31 points (the staging offsets are 32-bit)"; return SMHIP_ERR_CAPACITY; }
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->prep_batch) {
     h->prep_batch = prep_create(h->dev.slots * h->dev.ns_cap);

@@ -400,20 +400,34 @@ typedef struct smhip_mrvm_settings {
 } smhip_mrvm_settings;
 typedef struct smhip_mrvm_context* smhip_mrvm_handle;
 void smhip_mrvm_default_settings(smhip_mrvm_settings* s);
-/* table_log2: the open-addressing voxel table holds 2^table_log2 voxels (inserts fail with SMHIP_ERR_CAPACITY beyond 70 %);
- * max_cloud_points: the largest cloud one InsertPointCloud may hand over */
+/* table_log2: the open-addressing voxel table holds 2^table_log2 voxels and does not grow (the reference's map does): size it
+ * for the whole map -- a 0.1 m map of a KITTI-length drive needs 2^25 or more; past 70 % full every insert leaves a warning in
+ * smhip_mrvm_last_error, and an insert that cannot place a voxel returns SMHIP_ERR_CAPACITY from then on (the voxel is lost,
+ * the rest of the cloud is applied).  max_cloud_points: the largest cloud one InsertPointCloud may hand over */
 smhip_status smhip_mrvm_create(int device, int table_log2, int max_cloud_points, const smhip_mrvm_settings* settings, smhip_mrvm_handle* out);
 smhip_status smhip_mrvm_destroy(smhip_mrvm_handle h);
 const char* smhip_mrvm_last_error(smhip_mrvm_handle h);
 void smhip_mrvm_set_offset_z(smhip_mrvm_handle h, float offset);                         /* SetOffsetZ, .cc:55-57 */
 /* InsertPointCloud(cloud, origin), .cc:59-131: n rows of `stride_floats` >= 4 floats (x y z intensity [factor]: InnerPointType is
- * stride 5), origin = the sensor position of the frame.  Non-finite points are skipped. */
+ * stride 5), origin = the sensor position of the frame.  Non-finite points are skipped.  Refused BEFORE the map is touched
+ * (status != OK, map unchanged): empty cloud, cloud larger than max_cloud_points, origin not finite or beyond +-2^20 voxels.
+ * Applied with a warning (status OK, text in smhip_mrvm_last_error): points beyond +-2^20 voxels are skipped (their number:
+ * smhip_mrvm_last_skipped; the flag does not carry over to the next insert), table > 70 % full. */
 smhip_status smhip_mrvm_insert_f32(smhip_mrvm_handle h, const float* points, int stride_floats, int n, const float origin[3]);
+smhip_status smhip_mrvm_last_skipped(smhip_mrvm_handle h, int* n);
 smhip_status smhip_mrvm_voxel_count(smhip_mrvm_handle h, int* n);
 /* OutputToPointCloud(threshold, PointXYZI cloud) without averaging, .cc:133-170: rows x y z intensity of every stored point of
  * every voxel with probability byte >= uint8(threshold * 256), in no particular order (the reference iterates an unordered
  * map).  capacity = 0 only counts. */
 smhip_status smhip_mrvm_output(smhip_mrvm_handle h, float threshold, float* xyzi, int capacity, int* n_out);
+/* Both OutputToPointCloud overloads with MrvmSettings::output_average, .cc:125-216.  flags: SMHIP_MRVM_AVERAGE = one row per
+ * voxel, the float mean of its stored points (summed in their order, divided by float(size)); its 4th column is the voxel's max
+ * intensity, or 0 without use_max_intensity (the reference never assigns it).  SMHIP_MRVM_RGB = the PointXYZRGB overload: the
+ * 4th column holds the bits of the packed colour r << 16 | g << 8 | b with r = g = b = min(255, uint32(max_intensity * 1.4))
+ * (pcl::PointXYZRGB's `rgb` float). */
+#define SMHIP_MRVM_AVERAGE 1
+#define SMHIP_MRVM_RGB 2
+smhip_status smhip_mrvm_output_ex(smhip_mrvm_handle h, float threshold, int flags, float* rows, int capacity, int* n_out);
 /* parity-test hook: every voxel of the map -- key (3 ints), probability byte, max intensity, number of stored points and
  * the points themselves (max_point_num_in_cell x 5 floats per voxel), in no particular order */
 smhip_status smhip_mrvm_dump(smhip_mrvm_handle h, int32_t* keys3, uint8_t* prob, int32_t* max_intensity, int32_t* npoints, float* points5,

@@ -15,7 +15,7 @@
 namespace smhip {
 
 struct MrvmSettings {                      // multi_resolution_voxel_map.h:54-65
-  bool output_average = false;             // not offered by the device map (the XYZI output below is the non-averaged one)
+  bool output_average = false;
   bool output_rgb = false;
   bool use_max_intensity = true;
   float prob_threshold = 0.6f;
@@ -28,6 +28,10 @@ struct MrvmSettings {                      // multi_resolution_voxel_map.h:54-65
 };
 
 struct PointXYZI { float x, y, z, intensity; };   // pcl::PointXYZI's payload
+struct PointXYZRGB {                                // pcl::PointXYZRGB's payload: x y z + the packed colour in a float's bits
+  float x, y, z;
+  union { float rgb; struct { unsigned char b, g, r, a; }; };
+};
 
 class MultiResolutionVoxelMapHip {
  public:
@@ -60,23 +64,34 @@ class MultiResolutionVoxelMapHip {
     static_assert(sizeof(data::InnerPointType) == 5 * sizeof(float), "InnerPointType is five floats");
     const smhip_status st = smhip_mrvm_insert_f32(handle_, &cloud[0].x, 5, static_cast<int>(cloud.size()), origin);
     if (st != SMHIP_OK) { std::fprintf(stderr, "[ERROR] MultiResolutionVoxelMapHip::InsertPointCloud: %s\n", smhip_mrvm_last_error(handle_)); return false; }
+    // applied, with something to say (points beyond the coordinate range skipped, table filling up): the reference has neither limit
+    if (smhip_mrvm_last_error(handle_)[0]) std::fprintf(stderr, "[WARNING] MultiResolutionVoxelMapHip::InsertPointCloud: %s\n", smhip_mrvm_last_error(handle_));
     return true;
   }
-  // .cc:133-170 (PointXYZI, output_average = false)
+  // .cc:125-170 (PointXYZI; one averaged point per voxel with settings_.output_average)
   void OutputToPointCloud(const float threshold, std::vector<PointXYZI>* cloud) {
-    SMHIP_CHECK(cloud != nullptr && handle_ != nullptr, "OutputToPointCloud: null cloud / not initialised");
-    cloud->clear();
-    int n = 0;
-    if (smhip_mrvm_output(handle_, threshold, nullptr, 0, &n) != SMHIP_OK || n <= 0) return;
-    cloud->resize(static_cast<size_t>(n));
     static_assert(sizeof(PointXYZI) == 4 * sizeof(float), "PointXYZI is four floats");
-    int m = 0;
-    if (smhip_mrvm_output(handle_, threshold, &(*cloud)[0].x, n, &m) != SMHIP_OK) cloud->clear();
-    else cloud->resize(static_cast<size_t>(m < n ? m : n));
+    Output(threshold, settings_.output_average ? SMHIP_MRVM_AVERAGE : 0, cloud);
+  }
+  // .cc:172-216 (PointXYZRGB: grey = min(255, max_intensity * 1.4))
+  void OutputToPointCloud(const float threshold, std::vector<PointXYZRGB>* cloud) {
+    static_assert(sizeof(PointXYZRGB) == 4 * sizeof(float), "PointXYZRGB is four floats");
+    Output(threshold, SMHIP_MRVM_RGB | (settings_.output_average ? SMHIP_MRVM_AVERAGE : 0), cloud);
   }
   int VoxelCount() const { int n = 0; if (handle_) smhip_mrvm_voxel_count(handle_, &n); return n; }
 
  private:
+  template <typename P>
+  void Output(const float threshold, int flags, std::vector<P>* cloud) {
+    SMHIP_CHECK(cloud != nullptr && handle_ != nullptr, "OutputToPointCloud: null cloud / not initialised");
+    cloud->clear();
+    int n = 0;
+    if (smhip_mrvm_output_ex(handle_, threshold, flags, nullptr, 0, &n) != SMHIP_OK || n <= 0) return;
+    cloud->resize(static_cast<size_t>(n));
+    int m = 0;
+    if (smhip_mrvm_output_ex(handle_, threshold, flags, &(*cloud)[0].x, n, &m) != SMHIP_OK) cloud->clear();
+    else cloud->resize(static_cast<size_t>(m < n ? m : n));
+  }
   int device_, table_log2_, max_cloud_points_;
   MrvmSettings settings_;
   smhip_mrvm_handle handle_ = nullptr;

@@ -180,8 +180,16 @@ class Interface {
     }
   }
   void InitInnerFiltersWithXml(const std::string&) {}          // interface.cc:92-111: a stub in the reference too
-  void EnableInnerCompensation() { inner_compensation_ = true; }    // interface.cc:34
-  void DisableInnerCompensation() { inner_compensation_ = false; }  // interface.cc:36
+  // interface.cc:34-36.  Only IcpFast reads the flag (icp_fast.cc:487-489, 282-287), and what it selects there is
+  // EigenPointCloud::ApplyMotionCompensation (cloud_types.cc:306-321), whose per-point transform is declared as
+  //     const Eigen::Matrix4d transform = common::InterpolateTransform(I, transform, factors[i]);
+  // -- the new `transform` shadows the argument inside its own initialiser, so the branch interpolates towards an
+  // uninitialised matrix: undefined behaviour, and nothing in the reference ever calls the setter.  There is no defined
+  // result to reproduce, so IcpFastHip::Align / AlignBatch REFUSE to run with the flag set (error + false) instead of quietly
+  // running the uncompensated iteration.
+  void EnableInnerCompensation() { inner_compensation_ = true; }
+  void DisableInnerCompensation() { inner_compensation_ = false; }
+  bool InnerCompensationEnabled() const { return inner_compensation_; }
   virtual void InitWithOptions() {}                                 // interface.h:94
   void PrintOptions() {                                             // interface.cc:113-137
     for (const auto& kv : inner_options_) {
@@ -302,6 +310,7 @@ class IcpFastHip : public Interface {
     SetTarget(cloud, kTargetWithNormals);
   }
   bool Align(const Matrix4d& guess, Matrix4d& result) override {    // icp_fast.cc:455-529
+    if (RefuseInnerCompensation()) { result = guess; return false; }
     if (!source_ok_ || !target_ok_ || !EnsureHandle(0, 0, true, true)) {   // a cloud the device could not take: not an abort
       std::fprintf(stderr, "[ERROR] IcpFastHip::Align: the input clouds are not on the device\n");
       result = guess;
@@ -356,6 +365,7 @@ class IcpFastHip : public Interface {
     SMHIP_CHECK(K > 0 && targets.size() == sources.size() && guesses.size() == sources.size() && results && scores, "AlignBatch: sizes");
     results->assign(guesses.begin(), guesses.end());
     scores->assign(K, 0.0);
+    if (RefuseInnerCompensation()) return false;
     int ns = 1, nt = 1;
     for (int k = 0; k < K; ++k) {
       SMHIP_CHECK(sources[k] && targets[k] && sources[k]->GetEigenCloud() && targets[k]->GetEigenCloud(), "CHECK(cloud)");
@@ -391,6 +401,13 @@ class IcpFastHip : public Interface {
 
  private:
   enum TargetKind { kNoTarget, kTargetWithNormals, kTargetRaw };
+  // see Interface::EnableInnerCompensation: the reference's compensated branch has no defined result
+  bool RefuseInnerCompensation() const {
+    if (!this->inner_compensation_) return false;
+    std::fprintf(stderr, "[ERROR] IcpFastHip: inner compensation is enabled, and the reference's branch for it (icp_fast.cc:487-489 -> "
+                         "cloud_types.cc:306-321) reads an uninitialised transform: no defined result to reproduce. Call DisableInnerCompensation().\n");
+    return true;
+  }
   bool Ok(smhip_status s, const char* what) {
     if (s == SMHIP_OK) return true;
     std::fprintf(stderr, "[ERROR] %s: %s (%s)\n", what, smhip_status_string(s), arena_.handle ? smhip_last_error(arena_.handle) : "");

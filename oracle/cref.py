@@ -239,6 +239,8 @@ class Mrvm:
         L.smref_mrvm_dump.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 5
         L.smref_mrvm_output.restype = ctypes.c_long
         L.smref_mrvm_output.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_long]
+        L.smref_mrvm_output_ex.restype = ctypes.c_long
+        L.smref_mrvm_output_ex.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_long]
         L.smref_mrvm_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         self._L = L
         self.max_points = max_point_num_in_cell
@@ -274,8 +276,9 @@ class Mrvm:
         o = np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))
         return keys[o], prob[o], mi[o], npts[o], pts[o]
 
-    def output(self, threshold=0.6, use_max_intensity=True):
-        n = self._L.smref_mrvm_output(self._h, threshold, int(use_max_intensity), None, 0)
+    def output(self, threshold=0.6, use_max_intensity=True, average=False, rgb=False):
+        flags = (1 if average else 0) | (2 if rgb else 0)
+        n = self._L.smref_mrvm_output_ex(self._h, threshold, int(use_max_intensity), flags, None, 0)
         out = np.zeros((n, 4), np.float32)
-        self._L.smref_mrvm_output(self._h, threshold, int(use_max_intensity), out.ctypes.data, n)
+        self._L.smref_mrvm_output_ex(self._h, threshold, int(use_max_intensity), flags, out.ctypes.data, n)
         return out

@@ -175,22 +175,42 @@ long smref_mrvm_dump(void* h, int32_t* keys, uint8_t* prob, int32_t* max_intensi
   }
   return c;
 }
-/* OutputToPointCloud(threshold, PointXYZI cloud) without averaging (:133-170): x y z intensity rows of every stored point of every
- * voxel whose probability byte is >= (Probability)(threshold * 256); intensity = the voxel's max intensity when use_max_intensity */
-long smref_mrvm_output(void* h, float threshold, int use_max_intensity, float* xyzi, long capacity) {
+/* OutputToPointCloud, both overloads with settings_.output_average (:125-216).  flags bit 0 = output_average (one row per voxel:
+ * float sums of the stored points in their order / float(size)), bit 1 = the PointXYZRGB overload (4th column = the grey level
+ * min(255, uint32(max_intensity * 1.4)) as a float); else 4th column = the voxel's max intensity when use_max_intensity, the
+ * point's own otherwise (0 for an averaged point: the reference leaves it unassigned). */
+long smref_mrvm_output_ex(void* h, float threshold, int use_max_intensity, int flags, float* xyzi, long capacity) {
   Mrvm* m = (Mrvm*)h;
   const uint8_t thr = (uint8_t)(threshold * (float)MRVM_TABLE);
   long c = 0;
   for (size_t i = 0; i < m->cap; ++i) {
     const MrvmVoxel* v = &m->vox[i];
     if (!v->used || v->prob < thr) continue;
+    uint32_t intensity = (uint32_t)v->max_intensity;
+    intensity = (uint32_t)((double)intensity * 1.4);
+    if (intensity > 255) intensity = 255;
+    if (flags & 1) {
+      if (v->npoints <= 0) continue;
+      volatile float ax = 0.f, ay = 0.f, az = 0.f;     /* volatile: every add rounded to float, as the reference's float members are */
+      for (int k = 0; k < v->npoints; ++k) { ax = ax + v->points[k].x; ay = ay + v->points[k].y; az = az + v->points[k].z; }
+      const float size = (float)v->npoints;
+      if (xyzi && c < capacity) {
+        xyzi[4 * c] = ax / size; xyzi[4 * c + 1] = ay / size; xyzi[4 * c + 2] = az / size;
+        xyzi[4 * c + 3] = (flags & 2) ? (float)intensity : (use_max_intensity ? (float)v->max_intensity : 0.f);
+      }
+      ++c;
+      continue;
+    }
     for (int k = 0; k < v->npoints; ++k) {
       if (xyzi && c < capacity) {
         xyzi[4 * c] = v->points[k].x; xyzi[4 * c + 1] = v->points[k].y; xyzi[4 * c + 2] = v->points[k].z;
-        xyzi[4 * c + 3] = use_max_intensity ? (float)v->max_intensity : v->points[k].intensity;
+        xyzi[4 * c + 3] = (flags & 2) ? (float)intensity : (use_max_intensity ? (float)v->max_intensity : v->points[k].intensity);
       }
       ++c;
     }
   }
   return c;
+}
+long smref_mrvm_output(void* h, float threshold, int use_max_intensity, float* xyzi, long capacity) {
+  return smref_mrvm_output_ex(h, threshold, use_max_intensity, 0, xyzi, capacity);
 }

@@ -108,12 +108,24 @@ class Mrvm:
         return (np.array(keys, np.int32).reshape(-1, 3), np.array([self.vox[k][0] for k in keys], np.uint8),
                 np.array([self.vox[k][2] for k in keys], np.int32), np.array([len(self.vox[k][3]) for k in keys], np.int32))
 
-    def output(self, threshold=0.6, use_max_intensity=True):                    # :133-170, output_average = false
-        thr = int(F(F(threshold) * F(TABLE))) & 0xff                            # :141 (float -> uint8)
+    def output(self, threshold=0.6, use_max_intensity=True, average=False, rgb=False):
+        """OutputToPointCloud, both overloads (:125-170 PointXYZI, :172-216 PointXYZRGB), with settings_.output_average.  Rows
+        x y z c: c = intensity, or for rgb the grey level r = g = b."""
+        thr = int(F(F(threshold) * F(TABLE))) & 0xff                            # :132 (float -> uint8)
         rows = []
         for key in sorted(self.vox):
             prob, _, mi, pts = self.vox[key]
-            if prob >= thr:
+            if prob < thr:
+                continue
+            grey = min(255, int(float((int(mi) & 0xffffffff)) * 1.4))           # :181-186: uint32_t intensity *= 1.4 (double), clamp
+            if average:                                                         # :136-151 / :188-199
+                ax = ay = az = F(0)                                             # pcl points start at 0
                 for p in pts:
-                    rows.append([p[0], p[1], p[2], F(int(mi)) if use_max_intensity else p[3]])
+                    ax = F(ax + F(p[0])); ay = F(ay + F(p[1])); az = F(az + F(p[2]))
+                size = F(len(pts))
+                c = F(grey) if rgb else (F(int(mi)) if use_max_intensity else F(0))   # an averaged PointXYZI's intensity is only set with use_max_intensity
+                rows.append([F(ax / size), F(ay / size), F(az / size), c])
+            else:
+                for p in pts:
+                    rows.append([p[0], p[1], p[2], F(grey) if rgb else (F(int(mi)) if use_max_intensity else p[3])])
         return np.array(rows, np.float32).reshape(-1, 4)

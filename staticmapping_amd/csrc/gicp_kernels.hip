@@ -167,17 +167,27 @@ __global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pa
   const float4* raw = b.tgt_p + (size_t)pair * b.nt_cap;
   double mean[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
   int last = -1;
+  int kv = 0;                                   // members actually summed
   for (int m = 0; m < k; ++m) {
     int nxt = 0x7fffffff;
 #pragma unroll
     for (int e = 0; e < KMAX; ++e) { const int o = s_j[e][t]; nxt = (e < k && o > last && o < nxt) ? o : nxt; }
+    // fewer than k members: the cloud holds fewer than k FINITE points (a non-finite candidate's distance is NaN and never
+    // enters the set; the host only checks the raw counts), or the query itself is not finite.  No member left to fetch.
+    if (nxt == 0x7fffffff) break;
     last = nxt;
+    ++kv;
     const float4 p = raw[nxt];
     mean[0] += p.x; mean[1] += p.y; mean[2] += p.z;
     const float xx = p.x * p.x, yx = p.y * p.x, yy = p.y * p.y, zx = p.z * p.x, zy = p.z * p.y, zz = p.z * p.z;
     c[0] += (double)xx; c[1] += (double)yx; c[2] += (double)zx; c[3] += (double)yy; c[4] += (double)zy; c[5] += (double)zz;
   }
-  const double kk = (double)k;
+  double* o = cov + (size_t)__float_as_int(q.w) * 6;
+  if (kv == 0) {                                // nothing to estimate a surface from: the isotropic covariance
+    o[0] = 1.0; o[1] = 0.0; o[2] = 0.0; o[3] = 1.0; o[4] = 0.0; o[5] = 1.0;
+    return;
+  }
+  const double kk = (double)kv;                 // = k whenever the neighbourhood is complete (every finite cloud of >= k points)
   for (int a = 0; a < 3; ++a) mean[a] /= kk;
   double A[9], V[9], w[3];
   A[0] = c[0] / kk - mean[0] * mean[0];
@@ -193,7 +203,6 @@ __global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pa
   if (fabs(w[2]) < fabs(w[col])) col = 2;
   const double u0 = V[col], u1 = V[3 + col], u2 = V[6 + col];
   const double s = 1.0 - gicp_epsilon;          // U diag(1, 1, eps) U^T = I - (1 - eps) u3 u3^T  (:118-129)
-  double* o = cov + (size_t)__float_as_int(q.w) * 6;
   o[0] = 1.0 - s * u0 * u0; o[1] = -s * u0 * u1; o[2] = -s * u0 * u2;
   o[3] = 1.0 - s * u1 * u1; o[4] = -s * u1 * u2; o[5] = 1.0 - s * u2 * u2;
 }

@@ -7,6 +7,7 @@
 // Align, ndt_gicp.cc:59-76) and uses pair slot 0 as the working pair for the down-sampled clouds and slot 1 as
 // scratch for the source's neighbour search, so the handle needs pair_slots >= 2.
 #include <chrono>
+#include <thread>
 #include <cstdlib>
 #include <cstdio>
 #include "gicp_kernels.hip"
@@ -133,10 +134,23 @@ struct GicpFunctor {
       const auto t0 = std::chrono::steady_clock::now();
       unsigned spins = 0;
       while (__atomic_load_n(const_cast<unsigned long long*>(flag), __ATOMIC_ACQUIRE) != seq) {
-        if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { ok = false; break; }   // a lost launch: report, do not hang
+        if ((++spins & 0x3ffu) == 0) {
+          if (spins > (1u << 16)) std::this_thread::yield();                     // a long evaluation (shared GPU): stop burning the core
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+            // slow is not failed (an oversubscribed GPU, six pooled matchers): wait for the stream the ordinary way and look again
+            ok = hipStreamSynchronize(h->stream) == hipSuccess && hipGetLastError() == hipSuccess &&
+                 __atomic_load_n(const_cast<unsigned long long*>(flag), __ATOMIC_ACQUIRE) == seq;
+            break;
+          }
+        }
       }
     }
-    if (!ok) { (void)hipStreamSynchronize(h->stream); status = SMHIP_ERR_HIP; f = 0; for (int i = 0; i < 6; ++i) g[i] = 0; return; }
+    if (!ok) {
+      // the launch was lost or died before its last workgroup: leave the ticket counter clean for the next evaluation
+      (void)hipStreamSynchronize(h->stream);
+      (void)hipMemsetAsync(G.dev.ticket, 0, sizeof(uint32_t), h->stream);
+      status = SMHIP_ERR_HIP; f = 0; for (int i = 0; i < 6; ++i) g[i] = 0; return;
+    }
     const double* o = G.out_pinned;
     const double m = o[13];
     f = o[0] / m;

@@ -45,7 +45,9 @@ struct MrvmDev {
   uint32_t* hits;               // [T]
   uint32_t* misses;             // [T]
   int32_t* touched;             // [T] voxels with a hit or a miss in the current cloud
-  uint32_t* counters;           // 0 touched, 1 voxels in the table, 2 coordinate overflow / table full, 3 output rows, 4 dump rows
+  uint32_t* counters;           // 0 touched (this insert), 1 voxels in the table, 2 flags: bit 0 = a point of THIS insert lies beyond the
+                                // coordinate range (reset per insert), bit 1 = table full (sticky: a voxel was lost), 3 output rows,
+                                // 4 dump rows, 5 points of this insert skipped for their coordinates
   const uint8_t* tables;        // hit map [256], miss map [256]
   const float* cloud;           // [n][5] the current cloud (InnerPointType rows)
   int32_t* endslot;             // [n]
@@ -81,6 +83,13 @@ __device__ __forceinline__ int find_slot(const MrvmDev& d, unsigned long long ke
   return -1;
 }
 
+// per-insert reset: the touched list, the out-of-range flag and count of THIS cloud; "table full" stays (a lost voxel is lost)
+__global__ void mrvm_begin(MrvmDev d) {
+  d.counters[0] = 0;
+  d.counters[2] &= 2u;
+  d.counters[5] = 0;
+}
+
 // end voxels of the cloud: :86-104
 __global__ __launch_bounds__(256) void mrvm_hit(MrvmDev d, int n) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,6 +114,7 @@ __global__ __launch_bounds__(256) void mrvm_hit(MrvmDev d, int n) {
       if (slot < 0) atomicOr(&d.counters[2], 2u);          // table full
     } else {
       atomicOr(&d.counters[2], 1u);                        // voxel coordinate out of range
+      atomicAdd(&d.counters[5], 1u);
     }
   }
   d.endslot[j] = slot;
@@ -193,18 +203,42 @@ __global__ __launch_bounds__(256) void mrvm_update_counts(MrvmDev d, int n, cons
   d.npts[s] = min(d.maxp, d.npts[s] + (r - start[r] + 1));
 }
 
-// OutputToPointCloud (PointXYZI, no averaging), :133-170
-__global__ __launch_bounds__(256) void mrvm_output(MrvmDev d, uint8_t thr, int use_max, float* xyzi, int capacity) {
+// OutputToPointCloud, :125-216.  flags bit 0 = settings_.output_average (one row per voxel: the float sums of the stored points in
+// their order, divided by float(size)), bit 1 = the PointXYZRGB overload (4th column = the bits of (g << 16 | g << 8 | g) with
+// g = min(255, uint32(max_intensity * 1.4)), :181-186), else PointXYZI (4th column = the voxel's max intensity when
+// use_max_intensity, else the point's own -- 0 for an averaged point, whose intensity is never assigned, :148-151)
+__global__ __launch_bounds__(256) void mrvm_output(MrvmDev d, uint8_t thr, int use_max, int flags, float* xyzi, int capacity) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s > d.tmask || d.keys[s] == 0ull || d.prob[s] < thr) return;
   const int c = d.npts[s];
   if (c <= 0) return;
-  const uint32_t base = atomicAdd(&d.counters[3], (uint32_t)c);
+  const bool average = flags & 1, rgb = flags & 2;
+  float grey = 0.f;
+  if (rgb) {
+    uint32_t g = (uint32_t)d.max_int[s];
+    g = (uint32_t)((double)g * 1.4);                                          // intensity *= 1.4 on a uint32_t
+    if (g > 255u) g = 255u;
+    grey = __uint_as_float((g << 16) | (g << 8) | g);
+  }
+  const uint32_t base = atomicAdd(&d.counters[3], average ? 1u : (uint32_t)c);
+  if (average) {
+    if ((long long)base >= capacity) return;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int k = 0; k < c; ++k) {
+      const float* p = d.pts + ((size_t)s * d.maxp + k) * 5;
+      ax = __fadd_rn(ax, p[0]); ay = __fadd_rn(ay, p[1]); az = __fadd_rn(az, p[2]);
+    }
+    const float size = (float)c;
+    float* o = xyzi + 4 * (size_t)base;
+    o[0] = __fdiv_rn(ax, size); o[1] = __fdiv_rn(ay, size); o[2] = __fdiv_rn(az, size);
+    o[3] = rgb ? grey : (use_max ? (float)d.max_int[s] : 0.f);
+    return;
+  }
   for (int k = 0; k < c; ++k) {
     if ((long long)base + k >= capacity) return;
     const float* p = d.pts + ((size_t)s * d.maxp + k) * 5;
     float* o = xyzi + 4 * ((size_t)base + k);
-    o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = use_max ? (float)d.max_int[s] : p[3];
+    o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = rgb ? grey : (use_max ? (float)d.max_int[s] : p[3]);
   }
 }
 // every voxel, for the parity tests
@@ -244,6 +278,7 @@ struct smhip_mrvm_context {
   size_t sort_bytes = 0;
   std::vector<void*> allocs;
   std::string err;
+  int last_skipped = 0;                 // points of the last insert skipped for their coordinates
 };
 
 #define MCHK(h, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_); return SMHIP_ERR_HIP; } } while (0)
@@ -332,6 +367,18 @@ smhip_status smhip_mrvm_insert_f32(smhip_mrvm_handle h, const float* points, int
   if (!points || n <= 0) { h->err = "cloud is empty."; return SMHIP_ERR_INVALID_ARGUMENT; }             // PRINT_ERROR + return, .cc:61-64
   if (stride_floats < 4) { h->err = "rows need x y z intensity"; return SMHIP_ERR_INVALID_ARGUMENT; }
   if (n > h->max_cloud) { h->err = "cloud larger than max_cloud_points"; return SMHIP_ERR_CAPACITY; }
+  {   // every ray starts at the origin: a non-finite or far-away one would walk ~2^21 voxels per ray for nothing.  Checked before
+      // anything is touched, so a refused cloud leaves the map as it was.
+    const float oz = origin[2] + h->set.z_offset;
+    const float lim = (float)(kCoordBias - 2) * h->set.high_resolution;
+    if (!(std::isfinite(origin[0]) && std::isfinite(origin[1]) && std::isfinite(oz)) ||
+        std::fabs(origin[0]) >= lim || std::fabs(origin[1]) >= lim || std::fabs(oz) >= lim) {
+      h->err = "origin is not finite or lies beyond +-2^20 voxels: cloud refused";
+      return SMHIP_ERR_INVALID_ARGUMENT;
+    }
+  }
+  h->err.clear();
+  h->last_skipped = 0;
   MCHK(h, hipSetDevice(h->device));
   MCHK(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < n; ++i) {
@@ -343,7 +390,7 @@ smhip_status smhip_mrvm_insert_f32(smhip_mrvm_handle h, const float* points, int
   ++d.epoch;
   d.o[0] = origin[0]; d.o[1] = origin[1]; d.o[2] = origin[2] + h->set.z_offset;                         // .cc:66-67
   MCHK(h, hipMemcpyAsync(h->cloud_dev, h->stage, sizeof(float) * 5 * (size_t)n, hipMemcpyHostToDevice, h->stream));
-  MCHK(h, hipMemsetAsync(d.counters, 0, 4, h->stream));                                                 // touched count
+  hipLaunchKernelGGL(mrvm_begin, dim3(1), dim3(1), 0, h->stream, d);                                    // touched count, this cloud's flags
   const dim3 g((n + 255) / 256), b(256);
   hipLaunchKernelGGL(mrvm_hit, g, b, 0, h->stream, d, n);
   hipLaunchKernelGGL(mrvm_miss, g, b, 0, h->stream, d, n);
@@ -356,14 +403,22 @@ smhip_status smhip_mrvm_insert_f32(smhip_mrvm_handle h, const float* points, int
   MCHK(h, rocprim::inclusive_scan(h->sort_tmp, bytes, d.run_start, h->scan_out, (size_t)n, rocprim::maximum<int32_t>(), h->stream));
   hipLaunchKernelGGL(mrvm_store_points, g, b, 0, h->stream, d, n, h->scan_out);
   hipLaunchKernelGGL(mrvm_update_counts, g, b, 0, h->stream, d, n, h->scan_out);
-  MCHK(h, hipMemcpyAsync(h->counters_host, d.counters, 16, hipMemcpyDeviceToHost, h->stream));
+  MCHK(h, hipMemcpyAsync(h->counters_host, d.counters, 32, hipMemcpyDeviceToHost, h->stream));
   MCHK(h, hipStreamSynchronize(h->stream));
   const uint32_t touched = h->counters_host[0];
   if (touched > 0) hipLaunchKernelGGL(mrvm_apply, dim3((touched + 255) / 256), b, 0, h->stream, d);
   MCHK(h, hipGetLastError());
-  if (h->counters_host[2] & 2u) { h->err = "voxel table full: create the map with a larger table_log2"; return SMHIP_ERR_CAPACITY; }
-  if (h->counters_host[2] & 1u) { h->err = "a point lies beyond +-2^20 voxels of the origin: skipped"; return SMHIP_ERR_INVALID_ARGUMENT; }
-  if ((size_t)h->counters_host[1] * 10 > h->T * 7) { h->err = "voxel table more than 70 % full: create the map with a larger table_log2"; return SMHIP_ERR_CAPACITY; }
+  // What is reported after the cloud has been applied.  Only a LOST voxel is an error (sticky: the map is incomplete from then
+  // on -- the reference's map grows without bound, this table does not; size it with table_log2).  Points beyond the coordinate
+  // range were skipped, the rest of the cloud is in the map: status OK, the count in smhip_mrvm_last_skipped, the text in
+  // smhip_mrvm_last_error.  The same for a table that is getting full.
+  h->last_skipped = (int)h->counters_host[5];
+  if (h->counters_host[2] & 2u) {
+    h->err = "voxel table full: at least one voxel of this or an earlier cloud was dropped (the rest was applied); create the map with a larger table_log2";
+    return SMHIP_ERR_CAPACITY;
+  }
+  if (h->counters_host[2] & 1u) h->err = "warning: " + std::to_string(h->last_skipped) + " point(s) beyond +-2^20 voxels skipped, the rest of the cloud applied";
+  else if ((size_t)h->counters_host[1] * 10 > h->T * 7) h->err = "warning: voxel table more than 70 % full: create the map with a larger table_log2";
   return SMHIP_OK;
 }
 
@@ -376,22 +431,32 @@ smhip_status smhip_mrvm_voxel_count(smhip_mrvm_handle h, int* n) {
   return SMHIP_OK;
 }
 
-smhip_status smhip_mrvm_output(smhip_mrvm_handle h, float threshold, float* xyzi, int capacity, int* n_out) {
-  if (!h || !n_out || (capacity > 0 && !xyzi)) return SMHIP_ERR_INVALID_ARGUMENT;
+smhip_status smhip_mrvm_output_ex(smhip_mrvm_handle h, float threshold, int flags, float* rows, int capacity, int* n_out) {
+  if (!h || !n_out || (capacity > 0 && !rows) || (flags & ~3)) return SMHIP_ERR_INVALID_ARGUMENT;
   MCHK(h, hipSetDevice(h->device));
   float* dev = nullptr;
   if (capacity > 0) MCHK(h, hipMalloc((void**)&dev, sizeof(float) * 4 * (size_t)capacity));
   MCHK(h, hipMemsetAsync(h->d.counters + 3, 0, 4, h->stream));
-  const uint8_t thr = static_cast<uint8_t>(threshold * kTable);                                         // .cc:141
-  hipLaunchKernelGGL(mrvm_output, dim3((unsigned)((h->T + 255) / 256)), dim3(256), 0, h->stream, h->d, thr, h->set.use_max_intensity, dev, capacity);
+  const uint8_t thr = static_cast<uint8_t>(threshold * kTable);                                         // .cc:132
+  hipLaunchKernelGGL(mrvm_output, dim3((unsigned)((h->T + 255) / 256)), dim3(256), 0, h->stream, h->d, thr, h->set.use_max_intensity, flags, dev, capacity);
   MCHK(h, hipMemcpyAsync(h->counters_host, h->d.counters, 32, hipMemcpyDeviceToHost, h->stream));
   MCHK(h, hipStreamSynchronize(h->stream));
   *n_out = (int)h->counters_host[3];
   if (capacity > 0) {
-    const hipError_t e = hipMemcpy(xyzi, dev, sizeof(float) * 4 * (size_t)std::min(capacity, *n_out), hipMemcpyDeviceToHost);
+    const hipError_t e = hipMemcpy(rows, dev, sizeof(float) * 4 * (size_t)std::min(capacity, *n_out), hipMemcpyDeviceToHost);
     (void)hipFree(dev);
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return SMHIP_ERR_HIP; }
   }
+  return SMHIP_OK;
+}
+
+smhip_status smhip_mrvm_output(smhip_mrvm_handle h, float threshold, float* xyzi, int capacity, int* n_out) {
+  return smhip_mrvm_output_ex(h, threshold, 0, xyzi, capacity, n_out);
+}
+
+smhip_status smhip_mrvm_last_skipped(smhip_mrvm_handle h, int* n) {
+  if (!h || !n) return SMHIP_ERR_INVALID_ARGUMENT;
+  *n = h->last_skipped;
   return SMHIP_OK;
 }
 

@@ -24,6 +24,8 @@ class MultiResolutionVoxelMapHip:
         if st != 0:
             self._h = ctypes.c_void_p()
             raise SmhipError(st, self._lib.smhip_status_string(st).decode())
+        self.last_warning = ""
+        self.last_skipped = 0
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -45,19 +47,30 @@ class MultiResolutionVoxelMapHip:
         p = np.ascontiguousarray(points, dtype=np.float32)
         o = np.ascontiguousarray(origin, dtype=np.float32)
         self._check(self._lib.smhip_mrvm_insert_f32(self._h, p.ctypes.data_as(_capi.c_float_p), p.shape[1], p.shape[0], o.ctypes.data_as(_capi.c_float_p)))
+        # applied; what the device had to say about it (points beyond +-2^20 voxels skipped, table filling up) -- "" if nothing
+        self.last_warning = self._lib.smhip_mrvm_last_error(self._h).decode()
+        n = ctypes.c_int32()
+        self._lib.smhip_mrvm_last_skipped(self._h, ctypes.byref(n))
+        self.last_skipped = n.value
 
     def voxel_count(self) -> int:
         n = ctypes.c_int32()
         self._check(self._lib.smhip_mrvm_voxel_count(self._h, ctypes.byref(n)))
         return n.value
 
-    def output_to_point_cloud(self, threshold: float | None = None) -> np.ndarray:
+    def output_to_point_cloud(self, threshold: float | None = None, average: bool = False, rgb: bool = False) -> np.ndarray:
+        """OutputToPointCloud (multi_resolution_voxel_map.cc:125-216): rows x y z intensity; average = MrvmSettings::output_average
+        (one mean point per voxel); rgb = the PointXYZRGB overload, 4th column = the grey level 0..255 (the packed colour's byte)."""
         thr = self.settings.prob_threshold if threshold is None else threshold
+        flags = (1 if average else 0) | (2 if rgb else 0)
         n = ctypes.c_int32()
-        self._check(self._lib.smhip_mrvm_output(self._h, thr, None, 0, ctypes.byref(n)))
+        self._check(self._lib.smhip_mrvm_output_ex(self._h, thr, flags, None, 0, ctypes.byref(n)))
         out = np.zeros((max(n.value, 1), 4), np.float32)
-        self._check(self._lib.smhip_mrvm_output(self._h, thr, out.ctypes.data_as(_capi.c_float_p), len(out), ctypes.byref(n)))
-        return out[:n.value]
+        self._check(self._lib.smhip_mrvm_output_ex(self._h, thr, flags, out.ctypes.data_as(_capi.c_float_p), len(out), ctypes.byref(n)))
+        out = out[:n.value]
+        if rgb:                                   # packed r << 16 | g << 8 | b in the float's bits, r = g = b
+            out[:, 3] = (out[:, 3].copy().view(np.uint32) & 0xff).astype(np.float32)
+        return out
 
     def dump(self):
         """(keys [V,3], prob [V], max_intensity [V], npoints [V], points [V, max, 5]) sorted by key -- the parity tests' view."""

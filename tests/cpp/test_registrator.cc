@@ -72,6 +72,18 @@ int main(int argc, char** argv) {
     recovers = matcher->Align(guess, r2);
     for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) recovers = recovers && r2(r, c) == result(r, c);
   }
+  // EnableInnerCompensation selects a branch of the reference that reads an uninitialised transform (cloud_types.cc:312): the
+  // mirror refuses to align (false, result = guess) instead of ignoring the flag, and runs again once it is disabled
+  bool compensation_refused = false, compensation_off_runs = false;
+  {
+    reg::Matrix4d r3;
+    matcher->EnableInnerCompensation();
+    compensation_refused = !matcher->Align(guess, r3);
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) compensation_refused = compensation_refused && r3(r, c) == guess(r, c);
+    matcher->DisableInnerCompensation();
+    compensation_off_runs = matcher->Align(guess, r3);
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) compensation_off_runs = compensation_off_runs && r3(r, c) == result(r, c);
+  }
   // the same clouds through registrators::Ndt (type 5): no normals needed, InnerCloud AoS upload
   reg::MatcherOptions nopt; nopt.type = reg::kNdt;
   auto ndt = reg::CreateMatcher(nopt);
@@ -125,10 +137,12 @@ int main(int argc, char** argv) {
     for (int c = 0; c < 4; ++c) std::printf("%.17g%s", nres(r, c), (r == 3 && c == 3) ? "" : ", ");
   std::printf("], ");
   std::printf("\"ok\": %s, \"score\": %.17g, \"type\": %d, \"unknown_option_check\": %s, \"wrong_type_null\": %s, "
-              "\"no_normals_check\": %s, \"refused_target_fails\": %s, \"recovers_after_good_target\": %s, \"target_points\": %d, \"result\": [",
+              "\"no_normals_check\": %s, \"refused_target_fails\": %s, \"recovers_after_good_target\": %s, \"compensation_refused\": %s, "
+              "\"compensation_off_runs\": %s, \"target_points\": %d, \"result\": [",
               ok ? "true" : "false", matcher->GetFitnessScore(), (int)matcher->GetType(), unknown_caught ? "true" : "false",
               wrong_null ? "true" : "false", no_normals_caught ? "true" : "false", refused_target_fails ? "true" : "false",
-              recovers ? "true" : "false", target->GetEigenCloud()->size());
+              recovers ? "true" : "false", compensation_refused ? "true" : "false", compensation_off_runs ? "true" : "false",
+              target->GetEigenCloud()->size());
   for (int r = 0; r < 4; ++r)
     for (int c = 0; c < 4; ++c) std::printf("%.17g%s", result(r, c), (r == 3 && c == 3) ? "" : ", ");
   std::printf("]}\n");

@@ -66,6 +66,7 @@ def test_cpp_interface_matches_python_path_and_oracle(tmp_path, velo20k):
     assert res["ok"] and res["type"] == 6
     assert res["unknown_option_check"] and res["wrong_type_null"] and res["no_normals_check"]
     assert res["refused_target_fails"] and res["recovers_after_good_target"]
+    assert res["compensation_refused"] and res["compensation_off_runs"]          # EnableInnerCompensation is refused, not ignored
     R = np.array(res["result"]).reshape(4, 4)
     # same clouds through the oracle: target prepared by the product's host CalculateNormals
     q, n = sm.calculate_normals(c["tgt"][:, :3].astype(np.float64))

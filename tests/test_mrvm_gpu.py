@@ -43,11 +43,14 @@ def test_map_equals_the_reference_loop_in_point_order(settings):
         ora.insert(pts, origin)
         _assert_same_map(dev, ora)                               # after EVERY cloud: misses of later clouds hit earlier voxels
     for thr in (0.6, 0.52, 0.9):
-        a = dev.output_to_point_cloud(thr)
-        b = ora.output(thr)
-        assert len(a) == len(b)
-        sa = a[np.lexsort(a.T[::-1])]; sb = b[np.lexsort(b.T[::-1])]
-        assert np.array_equal(sa, sb)
+        # both OutputToPointCloud overloads, with and without MrvmSettings::output_average (.cc:125-216): the same rows, bit for bit
+        for kw in (dict(), dict(average=True), dict(rgb=True), dict(average=True, rgb=True)):
+            a = dev.output_to_point_cloud(thr, **kw)
+            b = ora.output(thr, **kw)
+            assert len(a) == len(b), (thr, kw)
+            sa = a[np.lexsort(a.T[::-1])]; sb = b[np.lexsort(b.T[::-1])]
+            assert np.array_equal(sa, sb), (thr, kw)
+    assert len(dev.output_to_point_cloud(0.52, average=True)) < len(dev.output_to_point_cloud(0.52))     # one row per voxel
     assert dev.voxel_count() == len(ora.dump()[0])
     dev.close(); ora.close()
 
@@ -86,9 +89,31 @@ def test_edge_cases():
     for origin in ([0, 0, 0], [0.5, -0.25, 0.1]):
         dev.insert_point_cloud(pts, origin); ora.insert(pts, origin)
         _assert_same_map(dev, ora)
-    with pytest.raises(sm.SmhipError):                                                # 4096-slot table: a large cloud overflows 70 %
+    # a point beyond +-2^20 voxels is skipped, the rest of the cloud is applied, and the NEXT insert knows nothing of it
+    far = pts.copy(); far[20, 0] = 2.0e5                                               # 2e6 voxels of 0.1 m
+    dev.insert_point_cloud(far, [0, 0, 0])
+    assert dev.last_skipped == 1 and "skipped" in dev.last_warning
+    keep = np.ones(len(far), bool); keep[20] = False
+    ora.insert(far[keep], [0, 0, 0])                                                   # (the skipped point's ray is not cast either)
+    _assert_same_map(dev, ora)
+    dev.insert_point_cloud(pts, [0.1, 0, 0]); ora.insert(pts, [0.1, 0, 0])
+    assert dev.last_skipped == 0 and dev.last_warning == ""
+    _assert_same_map(dev, ora)
+    # a non-finite or far-away origin is refused before anything is touched
+    for bad in ([np.nan, 0, 0], [0, 3.0e5, 0]):
+        with pytest.raises(sm.SmhipError):
+            dev.insert_point_cloud(pts, bad)
+    _assert_same_map(dev, ora)
+    # 4096-slot table: past 70 % the insert is applied and says so; once a voxel does not fit the map reports it from then on
+    more = np.concatenate([rng.normal(0, 30, (2600, 3)), np.zeros((2600, 2))], axis=1).astype(np.float32)
+    dev.insert_point_cloud(more, [0, 0, 0]); ora.insert(more, [0, 0, 0])
+    assert "70 %" in dev.last_warning
+    _assert_same_map(dev, ora)
+    with pytest.raises(sm.SmhipError):
         big = np.concatenate([rng.normal(0, 30, (4096, 3)), np.zeros((4096, 2))], axis=1).astype(np.float32)
         dev.insert_point_cloud(big, [0, 0, 0])
+    with pytest.raises(sm.SmhipError):                                                 # sticky: a voxel was lost
+        dev.insert_point_cloud(pts, [0, 0, 0])
     dev.close(); ora.close()
 
 
@@ -116,4 +141,8 @@ def test_cpp_mirror_drives_the_map_like_the_map_builder(tmp_path):
     assert res["empty_refused"] and res["voxels"] == len(ora.dump()[0]) and res["output_points"] == len(out)
     want = float((out[:, 0].astype(np.float64) + 2.0 * out[:, 1] + 3.0 * out[:, 2] + 0.001 * out[:, 3]).sum())
     assert abs(res["checksum"] - want) <= 1e-6 * max(1.0, abs(want))
+    cs = lambda o: float((o[:, 0].astype(np.float64) + 2.0 * o[:, 1] + 3.0 * o[:, 2] + 0.001 * o[:, 3]).sum())
+    rgb = ora.output(0.6, rgb=True); avg = ora.output(0.6, average=True)
+    assert res["grey"] and res["rgb_points"] == len(rgb) and abs(res["rgb_checksum"] - cs(rgb)) <= 1e-6 * max(1.0, abs(cs(rgb)))
+    assert res["average_points"] == len(avg) and abs(res["average_checksum"] - cs(avg)) <= 1e-6 * max(1.0, abs(cs(avg)))
     ora.close()

@@ -87,5 +87,9 @@ def test_c_and_python_restatements_agree(seed):
         kp, pp, mp, npn = P.dump()
         assert np.array_equal(kc, kp) and np.array_equal(pc, pp) and np.array_equal(mc, mp) and np.array_equal(nc, npn), frame
     for thr in (0.5, 0.6, 0.7):
-        assert np.array_equal(_sorted_output(C.output(thr)), _sorted_output(P.output(thr)))
+        for kw in (dict(), dict(average=True), dict(rgb=True), dict(average=True, rgb=True), dict(use_max_intensity=False), dict(average=True, use_max_intensity=False)):
+            assert np.array_equal(_sorted_output(C.output(thr, **kw)), _sorted_output(P.output(thr, **kw))), (thr, kw)
+    a = P.output(0.5, average=True); v = P.output(0.5)
+    assert 0 < len(a) < len(v)                                                       # one averaged point per voxel
+    assert set(np.unique(P.output(0.5, rgb=True)[:, 3])) <= set(float(g) for g in range(256))
     C.close()

@@ -89,6 +89,11 @@ typedef struct smhip_icp_options {
                                    searched fewer than a fifth of its queries (smhip_icp_profile.split_after_used reports it);
                                    negative = never.  Results are identical either way. */
   float nn_epsilon;             /* SMHIP_NN_NABO only: libnabo's epsilon (default 3.16, icp_fast.cc:174; 0 = exact through the tree) */
+  int32_t no_fused_sums;        /* batches: 1 = certificate pass and normal-equation sums as two passes over the source in every iteration.
+                                   Default 0: from split_after on ONE pass does both, summing the matches below a predicted band of
+                                   histogram bins around the trimming quantile and leaving the band's members for the exact select
+                                   (a missed prediction costs that pair one plain pass).  The same matches, distances and kept set
+                                   either way; the 29 sums are added in a different (fixed) order: poses agree to ~1e-12. */
 } smhip_icp_options;
 
 /* Per-call statistics (all optional to read). */
@@ -101,7 +106,7 @@ typedef struct smhip_icp_stats {
   int32_t hard_queries;         /* matches recorded as lower bounds by the ball search, summed over iterations */
   int32_t refined_iterations;   /* iterations in which those bounds had to be refined to exact matches */
   int32_t searched_queries;     /* queries that needed a search (certificate failed / first iteration), summed over iterations */
-  int32_t reserved;
+  int32_t fused_iterations;     /* iterations whose sums came from the fused certificate pass (its quantile band held) */
 } smhip_icp_stats;
 
 /* Kernel-time breakdown collected when profiling is enabled (HIP events around

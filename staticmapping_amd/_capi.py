@@ -19,13 +19,13 @@ class IcpOptions(ctypes.Structure):
                 ("use_ball", ctypes.c_int32), ("exact_matches", ctypes.c_int32), ("ball_radius", ctypes.c_float),
                 ("ball_cap_factor", ctypes.c_float), ("no_certify", ctypes.c_int32), ("no_lds_table", ctypes.c_int32),
                 ("no_overlap", ctypes.c_int32), ("overlap_streams", ctypes.c_int32),
-                ("split_after", ctypes.c_int32), ("nn_epsilon", ctypes.c_float)]
+                ("split_after", ctypes.c_int32), ("nn_epsilon", ctypes.c_float), ("no_fused_sums", ctypes.c_int32)]
 
 
 class IcpStats(ctypes.Structure):
     _fields_ = [("iterations", ctypes.c_int32), ("kept", ctypes.c_int32), ("limit_d2", ctypes.c_double),
                 ("fallback_queries", ctypes.c_int32), ("status", ctypes.c_int32), ("hard_queries", ctypes.c_int32),
-                ("refined_iterations", ctypes.c_int32), ("searched_queries", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("refined_iterations", ctypes.c_int32), ("searched_queries", ctypes.c_int32), ("fused_iterations", ctypes.c_int32)]
 
 
 class IcpProfile(ctypes.Structure):

@@ -125,6 +125,7 @@ __global__ void pose_setup(IcpDev b, int npairs) {
   st->pot_a = 0; st->pot_b = 0; st->step_a = 0; st->step_b = 0;
   st->rcap2 = b.ball_radius * b.ball_radius;
   st->kept = 0; st->limit_key = 0; st->score = 0;
+  st->band_lo = 0; st->band_hi = -1; st->spec_ok = 0; st->spec_hits = 0;
 }
 // per-Align scratch that is not part of the search structure: histogram + finished-pairs counter
 __global__ __launch_bounds__(256) void reset_scratch_light(IcpDev b, int first, int npairs) {
@@ -173,6 +174,7 @@ __global__ void grid_setup(IcpDev b, int npairs) {
   for (int c = 0; c < 4; ++c) st->nabo_count[c] = 0;
   st->pot_a = 0; st->pot_b = 0; st->step_a = 0; st->step_b = 0;
     st->rcap2 = 0.f;
+    st->band_lo = 0; st->band_hi = -1; st->spec_ok = 0; st->spec_hits = 0;
     st->status = 1;                        // SMHIP_ERR_INVALID_ARGUMENT
     st->done = 1;
     st->grid_invalid = 1;
@@ -210,6 +212,7 @@ __global__ void grid_setup(IcpDev b, int npairs) {
   st->pot_a = 0; st->pot_b = 0; st->step_a = 0; st->step_b = 0;
   st->rcap2 = b.ball_radius * b.ball_radius;
   st->kept = 0; st->limit_key = 0; st->score = 0; st->nocc = 0;
+  st->band_lo = 0; st->band_hi = -1; st->spec_ok = 0; st->spec_hits = 0;
 }
 
 __device__ __forceinline__ float3 centre_point(const float4 p, const double* mu) {
@@ -673,126 +676,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
 // time to one query (L = the largest power of two <= 16 the list leaves room for), the L lanes take the rows of the
 // query's ball in turn and their results are merged with the tie rule of the sequential sweep (smallest distance, then
 // smallest sorted position; runner-up = the smallest of the rest).  Same ids, distances and bounds as a one-lane sweep.
-__global__ __launch_bounds__(kNnThreads) void nn_ball_listed(IcpDev b, int nblk) {
-  int pair, blk;
-  if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
-  PairState* st = &b.state[pair];
-  if (st->done) return;
-  const int count = (int)st->deferred_count;
-  if (count == 0) return;
-  int L = 1, logL = 0;
-  while (L < 16 && 2 * L * count <= nblk * kNnThreads) { L *= 2; ++logL; }
-  const int qpb = kNnThreads >> logL;                      // queries per workgroup and pass
-  if (blk * qpb >= count) return;
-  __shared__ uint32_t s_hist[kHistBins];
-  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int sub = (int)threadIdx.x & (L - 1), ql = (int)threadIdx.x >> logL;
-  const size_t so = (size_t)pair * b.ns_cap;
-  const uint2* __restrict__ words = b.words + (size_t)pair * kMaxGridWords;
-  const uint32_t* __restrict__ cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
-  const float4* __restrict__ tq = b.tq + (size_t)pair * b.nt_cap;
-  const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
-  const float h = st->h, inv_h = st->inv_h;
-  const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
-  const float r2cap = st->rcap2;
-  const bool have_prev = st->iter > 0;
-  const Pot pot = {(float)st->pot_a, (float)st->pot_b, 0.f, 0.f};
-  uint32_t min_lb = 0xffffffffu;
-  for (int base = blk * qpb; base < count; base += nblk * qpb) {        // workgroup-uniform
-    const int e = base + ql;
-    bool hard = false;
-    int i = -1;
-    if (e < count) {
-      i = b.dlist[so + e];
-      const float4 s4 = ld_src(b, so + i);
-      double px, py, pz;
-      transform_point(st->M, s4, px, py, pz);
-      const float qx = (float)px, qy = (float)py, qz = (float)pz;
-      Best best = {INFINITY, -1, INFINITY};
-      const bool finite = isfinite(qx) && isfinite(qy) && isfinite(qz);
-      float R2 = r2cap;
-      int jp = -1;
-      if (finite) {
-        if (have_prev) {
-          jp = b.idx[so + i];
-          if (jp >= 0) {
-            double ux, uy, uz;
-            transform_point(st->M_prev, s4, ux, uy, uz);
-            const float ex = qx - (float)ux, ey = qy - (float)uy, ez = qz - (float)uz;
-            R2 = search_radius2(r2cap, dist2(tq[jp], qx, qy, qz), search_margin(sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)))));
-          }
-        }
-        // every target point within sqrt(R2) of q lies in a cell meeting [q - Rs, q + Rs]^3
-        const float Rs = sqrtf(R2) * 1.0001f + 1.0e-3f * h;
-        const int x0 = max(cell_coord(qx - Rs, ox, inv_h), 0), x1 = min(cell_coord(qx + Rs, ox, inv_h), nx - 1);
-        const int y0 = max(cell_coord(qy - Rs, oy, inv_h), 0), y1 = min(cell_coord(qy + Rs, oy, inv_h), ny - 1);
-        const int z0 = max(cell_coord(qz - Rs, oz, inv_h), 0), z1 = min(cell_coord(qz + Rs, oz, inv_h), nz - 1);
-        const int nyr = y1 - y0 + 1;
-        const int nrows = (x0 <= x1 && y0 <= y1 && z0 <= z1) ? nyr * (z1 - z0 + 1) : 0;
-        const float slack = 2.0e-3f * h;
-        for (int r = sub; r < nrows; r += L) {              // this lane's rows of the ball
-          const int zr = r / nyr;
-          const int z = z0 + zr, y = y0 + (r - zr * nyr);
-          const float zl = oz + (float)z * h, yl = oy + (float)y * h;
-          const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + h)) - slack, 0.f);
-          const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + h)) - slack, 0.f);
-          if (fmaf(dy, dy, dz * dz) > R2) continue;          // the row lies outside the ball
-          uint32_t sb, se;
-          row_slots(words, (z * ny + y) * wx, x0, x1, sb, se);
-          if (se > sb) {
-            const uint32_t j0 = cstart[sb], j1 = cstart[se];
-            for (uint32_t j = j0; j < j1; ++j) test_ascending_ru(tq[j], (int)j, qx, qy, qz, best);
-          }
-        }
-      }
-      // merge the L lanes of the query (butterfly inside aligned groups of L lanes; every lane ends with the result)
-      for (int off = 1; off < L; off <<= 1) {
-        const float od = __shfl_xor(best.d2, off, 64), os = __shfl_xor(best.s2, off, 64);
-        const int oj = __shfl_xor(best.j, off, 64);
-        best.s2 = fminf(fminf(best.s2, os), fmaxf(best.d2, od));
-        if (od < best.d2 || (od == best.d2 && (unsigned)oj < (unsigned)best.j)) { best.d2 = od; best.j = oj; }
-      }
-      if (sub == 0) {
-        float d2out = INFINITY, lbout = 0.f;
-        int jout = -1;
-        if (finite) {
-          if (best.d2 <= R2) {                  // exact: everything within sqrt(R2) was seen
-            d2out = best.d2;
-            jout = best.j;
-            lbout = sqrtf(fminf(best.s2, R2));  // every other point is at least this far
-          } else {                              // certified lower bound: nothing lies within sqrt(R2)
-            d2out = R2;
-            jout = best.j >= 0 ? best.j : jp;   // an upper-bound seed for later iterations
-            lbout = -sqrtf(R2);
-            hard = true;
-            min_lb = min(min_lb, __float_as_uint(R2));
-          }
-        }
-        b.d2[so + i] = d2out;
-        b.idx[so + i] = jout;
-        st_lb(b, so + i, with_pot(lbout, pot_at(pot, norm3(s4.x, s4.y, s4.z))));
-        const uint32_t key = __float_as_uint(d2out);
-        if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
-      }
-    }
-    const unsigned long long hm = __ballot(hard);
-    if (hm) {
-      uint32_t basepos = 0;
-      if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
-      basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);   // lane 0 did the atomic
-      if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
-    }
-  }
-  if (min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
-  __syncthreads();
-  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
-  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
-    const uint32_t v = s_hist[k];
-    if (v) atomicAdd(&gh[k], v);
-  }
-}
+// (nn_ball_listed, the search of the queries whose certificate failed, follows `accumulate` below: its fused-path form sums too)
 
 // SMHIP_NN_NABO: work classes of the queries to walk again (buckets scanned by their last walk: <= 2, 3-4, 5-7, more) and
 // where the k-th member of class c sits: classes 0 / 1 fill dlist from its two ends, classes 2 / 3 hlist (a pair's
@@ -1813,6 +1697,11 @@ __device__ __forceinline__ void validate_bounds(const IcpDev& b, PairState* st, 
     const bool below = (st->min_lb_key >> kHistShift) <= s_q[0];
     st->refine = (any && (b.exact_all || below || s_q[2] == 0)) ? 1 : 0;
     if (st->refine) st->refine_total += 1;
+    // fused path: every distance of the iteration is in the histogram now -- did the quantile's bin land in the band the fused
+    // certificate pass was given?  Then its sums (below the band) and records (the band) are this iteration's; if not, or if
+    // lower bounds must first be refined to matches, `accumulate` redoes them the plain way.
+    st->spec_ok = (b.fused && st->band_lo > 0 && !st->refine && s_q[2] > 0 && (int)s_q[0] >= st->band_lo && (int)s_q[0] <= st->band_hi &&
+                   st->deferred_count <= (uint32_t)kFusedListedMax) ? 1 : 0;
   }
 }
 
@@ -1848,9 +1737,9 @@ __global__ __launch_bounds__(kNnThreads) void nn_refine_one(IcpDev b) {
 }
 
 // J = [p x n ; n], r = (p - q) . n ; acc += upper(J J^T), J r, sqrt(d2), 1     (icp_fast.cc:182-202, 256-303)
-__device__ __forceinline__ void accumulate_terms(const double* M, const float4 s4, const float4 q4, const float4 n4, float d2v, double* acc) {
-  double px, py, pz;
-  transform_point(M, s4, px, py, pz);
+// p = the source point already moved (transform_point).  Every producer of sums -- accumulate, the fused certificate pass, the
+// listed search's epilogue, finalize -- goes through this one function: a match contributes the same 29 doubles wherever it is met.
+__device__ __forceinline__ void accumulate_terms_p(double px, double py, double pz, const float4 q4, const float4 n4, float d2v, double* acc) {
   const double nx = n4.x, ny = n4.y, nz = n4.z;
   double J[6];
   J[0] = py * nz - pz * ny;
@@ -1875,12 +1764,11 @@ __device__ __forceinline__ void accumulate_terms(const double* M, const float4 s
   }
   acc[28] += 1.0;
 }
-__device__ __forceinline__ void accumulate_pair(const IcpDev& b, const PairState* st, int pair, int i, float d2v, double* acc) {
-  const size_t so = (size_t)pair * b.ns_cap, to = (size_t)pair * b.nt_cap;
-  const int j = b.idx[so + i];
-  accumulate_terms(st->M, ld_src(b, so + i), b.tq[to + j], b.tn[to + j], d2v, acc);
+__device__ __forceinline__ void accumulate_terms(const double* M, const float4 s4, const float4 q4, const float4 n4, float d2v, double* acc) {
+  double px, py, pz;
+  transform_point(M, s4, px, py, pz);
+  accumulate_terms_p(px, py, pz, q4, n4, d2v, acc);
 }
-
 // Block reduction of kAccCols-3 = 29 doubles; thread 0 ends up with the totals in acc[].
 // v of the lanes a DPP control reads from, 0.0 where the control has no source lane or the row is masked off
 template <int CTRL, int ROW_MASK>
@@ -1921,6 +1809,7 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
   if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
   PairState* st = &b.state[pair];
   if (st->done) return;
+  if (b.fused && st->spec_ok) return;    // the fused certificate pass + the listed search's epilogue already hold this iteration's sums
   const int ns = st->ns;
   const int base = blk * (kAccThreads * ITEMS);
   if (base >= ns) return;
@@ -1941,7 +1830,7 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
   // looking at d2 first, so that their latency is not in series with the gathers of the matched target point and normal
   const size_t to = (size_t)pair * b.nt_cap;
   const int seg = blk * (kAccThreads / 64) + (int)(threadIdx.x >> 6);            // this wave's segment: 64 * ITEMS slots
-  const size_t segbase = (size_t)pair * b.bl_stride + (size_t)seg * (64 * ITEMS);
+  const size_t segbase = (size_t)pair * 2 * b.bl_stride + (size_t)seg * (64 * ITEMS);
   int wcount = 0;
   // two-deep software pipeline (as nn_certify): stream loads two rounds ahead, the gathers of the matched target point and
   // normal one round ahead
@@ -1963,6 +1852,7 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
     const float d = d_1;
     const float4 s4 = s_1;
     const float4 q4 = q_1, n4 = n_1;
+    const int jm = j_1;
     d_1 = d_2; s_1 = s_2; j_1 = j_2;
     if (it + 1 < ITEMS && (__float_as_uint(d_1) >> kHistShift) < qbin) { q_1 = b.tq[to + max(j_1, 0)]; n_1 = b.tn[to + max(j_1, 0)]; }
     if (it + 2 < ITEMS) {
@@ -1980,15 +1870,358 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
         else boundary = bin == qbin;
       }
     }
-    // the quantile bin's members are left for finalize, compacted per wave into the wave's own segment of blist, in the
-    // order the wave meets them: no atomics, and an order that does not change from run to run
+    // the quantile bin's members are left for finalize as records (source point, d2, match: all it needs of them), compacted
+    // per wave into the wave's own segment, in the order the wave meets them: no atomics, and an order that does not change
+    // from run to run
     const unsigned long long bm = __ballot(boundary);
-    if (boundary) b.blist[segbase + wcount + __popcll(bm & ((1ull << (threadIdx.x & 63)) - 1ull))] = i;
+    if (boundary) {
+      const size_t at = segbase + wcount + __popcll(bm & ((1ull << (threadIdx.x & 63)) - 1ull));
+      b.rec_a[at] = make_float4(s4.x, s4.y, s4.z, d);
+      b.rec_j[at] = jm;
+    }
     wcount += (int)__popcll(bm);
   }
   if ((threadIdx.x & 63) == 0) b.gcount[(size_t)pair * b.seg_stride + seg] = (uint32_t)wcount;
   block_reduce29(acc, s_red, s_out);
-  if (threadIdx.x < 29) b.partials[((size_t)pair * b.acc_blocks + blk) * kAccCols + threadIdx.x] = s_out[threadIdx.x];
+  if (threadIdx.x < 29) b.partials[((size_t)pair * b.part_stride + blk) * kAccCols + threadIdx.x] = s_out[threadIdx.x];
+}
+
+
+// ------------------------------------------------------------------------------------------
+// The fused steady-state iteration: certificate pass + ErrorElements / ComputePointToPlane sums in ONE pass over the source
+// (icp_fast.cc:484-523 per iteration: FindClosests for the queries whose match provably has not changed, then the normal
+// equations over the matches below the trimming quantile).
+//
+// nn_certify followed by `accumulate` streams every source point twice per iteration (12 B point + 4 B bound + 4 B match in,
+// 4 B distance out; then distance, point and match in again).  What stands between them is the quantile: which matches are
+// summed is only known once every distance is.  But the quantile barely moves once ICP has settled, so finalize predicts the
+// histogram bins it can fall in next ([band_lo, band_hi], 1-3 bins of 2048) and this pass, which has point, match, matched
+// target point and distance in registers anyway, sums the certified matches below the band on the spot, drops those above
+// it, and leaves the band's members as records (source point, distance, match id) for finalize to select among.  The queries
+// whose certificate fails go to the wave's own segment of dlist; the listed search (nn_ball_listed<true>) finds their matches
+// and sums / records them by the same rule.  nn_validate then checks the prediction against the completed histogram
+// (PairState::spec_ok); a miss costs one plain `accumulate` for that pair.  No atomics with a return value inside the loop
+// (the lists are per-wave segments, counted in SGPRs), so the two-deep load pipeline never drains.
+// Exactness: the same matches, the same distances, the same kept set as the separate passes; only the order in which the
+// 29 sums are added differs (1e-16 relative), and it is a fixed order -- the result is reproducible bit for bit.
+__device__ __forceinline__ void emit_record(const IcpDev& b, size_t segbase, int& wcount, bool band, const float4 s, float d, int j) {
+  const unsigned long long bm = __ballot(band);
+  if (band) {
+    const size_t at = segbase + wcount + __popcll(bm & ((1ull << (threadIdx.x & 63)) - 1ull));
+    b.rec_a[at] = make_float4(s.x, s.y, s.z, d);
+    b.rec_j[at] = j;
+  }
+  wcount += (int)__popcll(bm);
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(kNnThreads) void nn_certify_acc(IcpDev b, int nblk) {
+  int pair, blk;
+  if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  const int ns = st->ns;
+  const int base = blk * (kNnThreads * ITEMS);
+  if (base >= ns) return;
+  double Mc[12];                         // read before the first store: scalar loads, held in SGPRs (see nn_ball_lds)
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Mc[k] = st->M[k];
+  const Pot pot = {(float)st->pot_a, (float)st->pot_b, 0.f, 0.f};
+  const int band_lo = st->band_lo, band_hi = st->band_hi;      // band_lo = 0, band_hi = -1: no prediction, nothing summed or recorded
+  __shared__ uint32_t s_hist[kHistBins];
+  __shared__ double s_red[4][29];
+  __shared__ double s_out[29];
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const size_t so = (size_t)pair * b.ns_cap, to = (size_t)pair * b.nt_cap;
+  // the pair's arrays as uniform byte bases + 32-bit offsets (a pair's arrays are < 4 GB): the loads and stores take the scalar
+  // base + vector offset form instead of a 64-bit address per lane and access (a sixth of the loop's vector instructions)
+  const char* __restrict__ tqb = reinterpret_cast<const char*>(b.tq + to);
+  const char* __restrict__ tnb = reinterpret_cast<const char*>(b.tn + to);
+  const char* __restrict__ srcb = reinterpret_cast<const char*>(b.src3 + 3 * so);
+  const char* __restrict__ lbb = reinterpret_cast<const char*>(b.lb + so);
+  const char* __restrict__ idxb = reinterpret_cast<const char*>(b.idx + so);
+  char* __restrict__ d2b = reinterpret_cast<char*>(b.d2 + so);
+  auto ld_s = [&](int k) { const float3 v = *reinterpret_cast<const float3*>(srcb + (uint32_t)k * 12u); return make_float4(v.x, v.y, v.z, 0.f); };
+  auto ld_l = [&](int k) { return *reinterpret_cast<const float*>(lbb + (uint32_t)k * 4u); };
+  auto ld_j = [&](int k) { return *reinterpret_cast<const int*>(idxb + (uint32_t)k * 4u); };
+  auto ld_t = [&](const char* base, int j) { const float3 v = *reinterpret_cast<const float3*>(base + (uint32_t)max(j, 0) * 16u); return make_float4(v.x, v.y, v.z, 0.f); };
+  auto st_d = [&](int k, float v) { *reinterpret_cast<float*>(d2b + (uint32_t)k * 4u) = v; };
+  const float r_need = 0.9f * sqrtf(st->rcap2);     // a hard query's bound must stay well above the quantile
+  uint32_t min_lb = 0xffffffffu;
+  const int seg = blk * (kNnThreads / 64) + (int)(threadIdx.x >> 6);               // this wave's segments: 64 * ITEMS slots each
+  const size_t recbase = (size_t)pair * 2 * b.bl_stride + (size_t)seg * (64 * ITEMS);
+  char* __restrict__ dsegb = reinterpret_cast<char*>(b.dlist + (size_t)pair * b.dl_stride + (size_t)seg * (64 * ITEMS));
+  int nrec = 0, ndef = 0;
+  double acc[29];
+#pragma unroll
+  for (int c = 0; c < 29; ++c) acc[c] = 0.0;
+  // two-deep software pipeline: a round's streamed values (point, bound, previous match id) are loaded two rounds ahead, the
+  // gathers of the previous match and its normal one round ahead (for every lane: seven in ten use both)
+  int ic = min(base + (int)threadIdx.x, ns - 1);
+  float4 s_1 = ld_s(ic);
+  float l_1 = ld_l(ic);
+  int j_1 = ld_j(ic);
+  ic = min(base + kNnThreads + (int)threadIdx.x, ns - 1);
+  float4 s_2 = ld_s(ic);
+  float l_2 = ld_l(ic);
+  int j_2 = ld_j(ic);
+  const bool summing = band_lo > 0;                 // no prediction: the normals are not needed, the pass only certifies
+  float4 t_1 = ld_t(tqb, j_1);
+  float4 n_1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (summing) n_1 = ld_t(tnb, j_1);
+  for (int it = 0; it < ITEMS; ++it) {
+    const int i = base + it * kNnThreads + threadIdx.x;
+    bool hard = false, fail = false, band = false;
+    const float4 s = s_1;
+    const float l = l_1;
+    const int j = j_1;
+    const float4 t = t_1, n = n_1;
+    s_1 = s_2; l_1 = l_2; j_1 = j_2;
+    if (it + 1 < ITEMS) { t_1 = ld_t(tqb, j_1); if (summing) n_1 = ld_t(tnb, j_1); }
+    if (it + 2 < ITEMS) {
+      ic = min(i + 2 * kNnThreads, ns - 1);
+      s_2 = ld_s(ic);
+      l_2 = ld_l(ic);
+      j_2 = ld_j(ic);
+    }
+    float d1 = 0.f;
+    if (i < ns) {
+      double px, py, pz;
+      transform_point(Mc, s, px, py, pz);
+      const float qx = (float)px, qy = (float)py, qz = (float)pz;
+      // as nn_certify; |s| by the hardware root (1 ulp: bound_now's slack of 1e-4 of the potential covers a million of those)
+      const float Lp = bound_now(l, pot_at(pot, __builtin_amdgcn_sqrtf(fmaf(s.z, s.z, fmaf(s.y, s.y, s.x * s.x)))));
+      fail = true;
+      if (isfinite(qx) && isfinite(qy) && isfinite(qz) && Lp > 0.f) {
+        if (l > 0.f && j >= 0) {
+          d1 = dist2(t, qx, qy, qz);
+          if (d1 < Lp * Lp) {                       // still the unique nearest neighbour: exact, no search
+            st_d(i, d1);
+            const int bin = (int)(__float_as_uint(d1) >> kHistShift);
+            atomicAdd(&s_hist[bin], 1u);
+            fail = false;
+            if (bin < band_lo) accumulate_terms_p(px, py, pz, t, n, d1, acc);      // below every bin the quantile can fall in: kept
+            else band = bin <= band_hi;                                            // the quantile decides: finalize
+          }
+        } else if (l < 0.f && Lp >= r_need) {       // still provably farther than the trimming radius
+          const float lb2 = Lp * Lp;
+          st_d(i, lb2);
+          atomicAdd(&s_hist[__float_as_uint(lb2) >> kHistShift], 1u);
+          min_lb = min(min_lb, __float_as_uint(lb2));
+          hard = true;
+          fail = false;
+        }
+      }
+    }
+    {   // failing certificates: the wave's own segment of dlist, in query order
+      const unsigned long long dm = __ballot(fail);
+      if (fail) *reinterpret_cast<int*>(dsegb + (uint32_t)(ndef + (int)__popcll(dm & ((1ull << lane) - 1ull))) * 4u) = i;
+      ndef += (int)__popcll(dm);
+    }
+    emit_record(b, recbase, nrec, band, s, d1, j);
+    const unsigned long long hm = __ballot(hard);
+    if (hm) {                                       // rare: lower-bounded queries keep their global list
+      uint32_t basepos = 0;
+      if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
+      basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);   // lane 0 did the atomic
+      if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
+    }
+  }
+  if (lane == 0) {
+    b.gcount[(size_t)pair * b.seg_stride + seg] = (uint32_t)nrec;
+    b.dcount[(size_t)pair * b.seg_stride + seg] = ndef;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) min_lb = min(min_lb, (uint32_t)__shfl_xor((int)min_lb, off, 64));
+  if (lane == 0 && min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
+  block_reduce29(acc, s_red, s_out);                // (its barriers also order the histogram updates before the flush)
+  if (threadIdx.x < 29) b.partials[((size_t)pair * b.part_stride + blk) * kAccCols + threadIdx.x] = s_out[threadIdx.x];
+  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
+    const uint32_t v = s_hist[k];
+    if (v) atomicAdd(&gh[k], v);
+  }
+}
+
+// The search of the queries whose certificate failed.  SEG = false: from the compacted list nn_certify filled with one atomic
+// per wave (dlist, deferred_count).  SEG = true (fused path): from the per-wave segments nn_certify_acc left (dcount; every
+// workgroup takes the prefix over them itself: <= 2 048 counts); a match found here whose distance falls in the predicted
+// quantile band becomes a record in the finding wave's own segment (region 1), like the certified ones of the fused pass;
+// the matches below the band are summed by finalize, which walks this list once more (a few thousand entries per pair:
+// summing them here would put 29 double accumulators into the search's register budget and halve its occupancy).
+template <bool SEG>
+__global__ __launch_bounds__(kNnThreads, 6) void nn_ball_listed(IcpDev b, int nblk) {
+  int pair, blk;
+  if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  __shared__ uint32_t s_hist[kHistBins];
+  __shared__ uint32_t s_w[17];
+  __shared__ uint32_t s_off[SEG ? 2 * kFinalizeMaxSeg : 1];
+  const int lane = threadIdx.x & 63;
+  const size_t so = (size_t)pair * b.ns_cap;
+  constexpr int kSegLen0 = 64 * kCertifyItems;
+  const int32_t* __restrict__ dl = SEG ? b.dlist + (size_t)pair * b.dl_stride : b.dlist + so;
+  int count, nseg0 = 0, top = 1;
+  if (SEG) {
+    nseg0 = ((st->ns + kNnThreads * kCertifyItems - 1) / (kNnThreads * kCertifyItems)) * (kNnThreads / 64);
+    const int32_t* __restrict__ dc = b.dcount + (size_t)pair * b.seg_stride;
+    const int per = (nseg0 + 255) >> 8;                    // <= kFinalizeMaxSeg / 256
+    const int s0 = (int)threadIdx.x * per;
+    uint32_t c[kFinalizeMaxSeg / 256];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < kFinalizeMaxSeg / 256; ++k) {
+      c[k] = (k < per && s0 + k < nseg0) ? (uint32_t)dc[s0 + k] : 0u;
+      mine += c[k];
+    }
+    uint32_t total;
+    uint32_t o = block_excl_scan(mine, s_w, &total);
+#pragma unroll
+    for (int k = 0; k < kFinalizeMaxSeg / 256; ++k)
+      if (k < per && s0 + k < nseg0) { s_off[s0 + k] = o; o += c[k]; }
+    while (2 * top < nseg0) top *= 2;
+    for (int x = nseg0 + (int)threadIdx.x; x < 2 * top; x += kNnThreads) s_off[x] = 0xffffffffu;
+    count = (int)total;
+    if (blk == 0 && threadIdx.x == 0) st->deferred_count = total;      // (statistics; finalize reads it after this launch)
+  } else {
+    count = (int)st->deferred_count;
+  }
+  // entry e of the pair's list: SEG -- the (e - s_off[seg])-th entry of the last segment with s_off[seg] <= e
+  auto entry = [&](int e) -> int {
+    if (!SEG) return dl[e];
+    int sg = 0;
+    for (int step = top; step > 0; step >>= 1) { const int cand = sg + step; sg = s_off[cand] <= (uint32_t)e ? cand : sg; }
+    return dl[(size_t)sg * kSegLen0 + (e - (int)s_off[sg])];
+  };
+  int L = 1, logL = 0;
+  while (L < 16 && 2 * L * count <= nblk * kNnThreads) { L *= 2; ++logL; }
+  const int qpb = kNnThreads >> logL;                      // queries per workgroup and pass
+  const int band_lo = SEG ? st->band_lo : 0, band_hi = SEG ? st->band_hi : -1;
+  const int seg1 = blk * (kNnThreads / 64) + (int)(threadIdx.x >> 6);                // this wave's record segment (region 1)
+  const bool active = count > 0 && blk * qpb < count;      // workgroup-uniform
+  if (!active) {
+    if (SEG && band_lo > 0 && lane == 0) b.gcount[(size_t)pair * b.seg_stride + nseg0 + seg1] = 0u;     // finalize indexes every listed segment
+    return;
+  }
+  const size_t recbase = (size_t)pair * 2 * b.bl_stride + (size_t)b.bl_stride + (size_t)seg1 * (size_t)(b.bl_stride / (kListedBlocks * (kNnThreads / 64)));
+  int nrec = 0;
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+  __syncthreads();
+  const int sub = (int)threadIdx.x & (L - 1), ql = (int)threadIdx.x >> logL;
+  const uint2* __restrict__ words = b.words + (size_t)pair * kMaxGridWords;
+  const uint32_t* __restrict__ cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
+  const float4* __restrict__ tq = b.tq + (size_t)pair * b.nt_cap;
+  const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
+  const float h = st->h, inv_h = st->inv_h;
+  const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
+  const float r2cap = st->rcap2;
+  const bool have_prev = st->iter > 0;
+  const Pot pot = {(float)st->pot_a, (float)st->pot_b, 0.f, 0.f};
+  uint32_t min_lb = 0xffffffffu;
+  for (int base = blk * qpb; base < count; base += nblk * qpb) {        // workgroup-uniform
+    const int e = base + ql;
+    bool hard = false, band = false;
+    int i = -1, jrec = -1;
+    float drec = 0.f;
+    float4 srec = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < count) {
+      i = entry(e);
+      const float4 s4 = ld_src(b, so + i);
+      double px, py, pz;
+      transform_point(st->M, s4, px, py, pz);
+      const float qx = (float)px, qy = (float)py, qz = (float)pz;
+      Best best = {INFINITY, -1, INFINITY};
+      const bool finite = isfinite(qx) && isfinite(qy) && isfinite(qz);
+      float R2 = r2cap;
+      int jp = -1;
+      if (finite) {
+        if (have_prev) {
+          jp = b.idx[so + i];
+          if (jp >= 0) {
+            double ux, uy, uz;
+            transform_point(st->M_prev, s4, ux, uy, uz);
+            const float ex = qx - (float)ux, ey = qy - (float)uy, ez = qz - (float)uz;
+            R2 = search_radius2(r2cap, dist2(tq[jp], qx, qy, qz), search_margin(sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)))));
+          }
+        }
+        // every target point within sqrt(R2) of q lies in a cell meeting [q - Rs, q + Rs]^3
+        const float Rs = sqrtf(R2) * 1.0001f + 1.0e-3f * h;
+        const int x0 = max(cell_coord(qx - Rs, ox, inv_h), 0), x1 = min(cell_coord(qx + Rs, ox, inv_h), nx - 1);
+        const int y0 = max(cell_coord(qy - Rs, oy, inv_h), 0), y1 = min(cell_coord(qy + Rs, oy, inv_h), ny - 1);
+        const int z0 = max(cell_coord(qz - Rs, oz, inv_h), 0), z1 = min(cell_coord(qz + Rs, oz, inv_h), nz - 1);
+        const int nyr = y1 - y0 + 1;
+        const int nrows = (x0 <= x1 && y0 <= y1 && z0 <= z1) ? nyr * (z1 - z0 + 1) : 0;
+        const float slack = 2.0e-3f * h;
+        for (int r = sub; r < nrows; r += L) {              // this lane's rows of the ball
+          const int zr = r / nyr;
+          const int z = z0 + zr, y = y0 + (r - zr * nyr);
+          const float zl = oz + (float)z * h, yl = oy + (float)y * h;
+          const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + h)) - slack, 0.f);
+          const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + h)) - slack, 0.f);
+          if (fmaf(dy, dy, dz * dz) > R2) continue;          // the row lies outside the ball
+          uint32_t sb, se;
+          row_slots(words, (z * ny + y) * wx, x0, x1, sb, se);
+          if (se > sb) {
+            const uint32_t j0 = cstart[sb], j1 = cstart[se];
+            for (uint32_t j = j0; j < j1; ++j) test_ascending_ru(tq[j], (int)j, qx, qy, qz, best);
+          }
+        }
+      }
+      // merge the L lanes of the query (butterfly inside aligned groups of L lanes; every lane ends with the result)
+      for (int off = 1; off < L; off <<= 1) {
+        const float od = __shfl_xor(best.d2, off, 64), os = __shfl_xor(best.s2, off, 64);
+        const int oj = __shfl_xor(best.j, off, 64);
+        best.s2 = fminf(fminf(best.s2, os), fmaxf(best.d2, od));
+        if (od < best.d2 || (od == best.d2 && (unsigned)oj < (unsigned)best.j)) { best.d2 = od; best.j = oj; }
+      }
+      if (sub == 0) {
+        float d2out = INFINITY, lbout = 0.f;
+        int jout = -1;
+        if (finite) {
+          if (best.d2 <= R2) {                  // exact: everything within sqrt(R2) was seen
+            d2out = best.d2;
+            jout = best.j;
+            lbout = sqrtf(fminf(best.s2, R2));  // every other point is at least this far
+            if (SEG) {                          // in the predicted quantile band: a record for finalize's select
+              const int bin = (int)(__float_as_uint(d2out) >> kHistShift);
+              band = bin >= band_lo && bin <= band_hi;
+              srec = s4; drec = d2out; jrec = jout;
+            }
+          } else {                              // certified lower bound: nothing lies within sqrt(R2)
+            d2out = R2;
+            jout = best.j >= 0 ? best.j : jp;   // an upper-bound seed for later iterations
+            lbout = -sqrtf(R2);
+            hard = true;
+            min_lb = min(min_lb, __float_as_uint(R2));
+          }
+        }
+        b.d2[so + i] = d2out;
+        b.idx[so + i] = jout;
+        st_lb(b, so + i, with_pot(lbout, pot_at(pot, norm3(s4.x, s4.y, s4.z))));
+        const uint32_t key = __float_as_uint(d2out);
+        if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
+      }
+    }
+    if (SEG) emit_record(b, recbase, nrec, band, srec, drec, jrec);
+    const unsigned long long hm = __ballot(hard);
+    if (hm) {
+      uint32_t basepos = 0;
+      if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
+      basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);   // lane 0 did the atomic
+      if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
+    }
+  }
+  if (SEG && band_lo > 0 && lane == 0) b.gcount[(size_t)pair * b.seg_stride + nseg0 + seg1] = (uint32_t)nrec;
+  if (min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
+  __syncthreads();
+  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
+    const uint32_t v = s_hist[k];
+    if (v) atomicAdd(&gh[k], v);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2125,20 +2358,31 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   uint32_t* gh = b.hist + (size_t)pair * kHistBins;
   find_quantile_bin(gh, b.rho, s_w, s_q);
   const uint32_t qbin = s_q[0], below = s_q[1], n_valid = s_q[2], krank = s_q[3];
-  const size_t so = (size_t)pair * b.ns_cap;
   const int ns = st->ns;
-  // the quantile bin's members were left by `accumulate` in one segment per wave (64 * acc_items slots each, gcount = how
-  // many are used).  Member e of the pair = the (e - s_off[seg])-th entry of the segment with s_off[seg] <= e < s_off[seg+1]:
-  // an order fixed by the data alone, so every sum below runs in the same order in every run, and any thread can fetch
-  // any member with independent loads.
-  const int chunk = kAccThreads * b.acc_items;
+  // This iteration's sums come in one of two forms.  Plain: `accumulate` ran with the quantile's bin known -- rows [0, nblk) of
+  // partials hold the sums below that bin, its waves' segments the bin's members.  Fused (b.fused and nn_validate's spec_ok):
+  // the certificate pass summed its certified matches below a PREDICTED band of bins that does contain the quantile's -- rows
+  // [0, nblk) -- and left records of the band's members; the listed search left records of the band's members among the
+  // matches it found, and those of its matches that lie below the band are summed here (the listed phase below).  Either
+  // way a record carries all finalize needs (source point, d2, match), the records' order is fixed by the data alone, and
+  // what is added from them is every record at or below the exact quantile: the band's lower bins entirely, the quantile's
+  // bin up to the selected value.
+  const bool fusedm = b.fused && st->spec_ok;
+  const int chunk = fusedm ? kNnThreads * kCertifyItems : kAccThreads * b.acc_items;
   const int nblk = (ns + chunk - 1) / chunk;
-  const int nseg = nblk * (kAccThreads / 64);
-  const int seg_len = 64 * b.acc_items;
+  const int nseg0 = nblk * 4;                                   // 4 waves per workgroup in both producers
+  const int seg_len0 = chunk / 4;
+  const int nseg = nseg0 + (fusedm ? kListedBlocks * 4 : 0);
+  const int seg_len1 = b.bl_stride / (kListedBlocks * 4);
   const uint32_t* gcount = b.gcount + (size_t)pair * b.seg_stride;
-  const int32_t* bl = b.blist + (size_t)pair * b.bl_stride;
+  const float4* ra = b.rec_a + (size_t)pair * 2 * b.bl_stride;
+  const int32_t* rj = b.rec_j + (size_t)pair * 2 * b.bl_stride;
   __shared__ uint32_t s_off[2 * kFinalizeMaxSeg];
-  __shared__ int s_idx[kFinalizeKeyCap];
+  __shared__ uint32_t s_pos[kFinalizeKeyCap];
+  // where the k-th record of segment sg sits
+  auto rec_at = [&](int sg, int k) -> uint32_t {
+    return sg < nseg0 ? (uint32_t)(sg * seg_len0 + k) : (uint32_t)(b.bl_stride + (sg - nseg0) * seg_len1 + k);
+  };
   auto segment_of = [&](int e) -> int {                   // the last segment with s_off[seg] <= e
     int lo = 0, hi = nseg - 1;
     while (lo < hi) {
@@ -2147,13 +2391,70 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
     }
     return lo;
   };
-  auto member = [&](int e) -> int {
-    const int seg = segment_of(e);
-    return bl[(size_t)seg * seg_len + (e - (int)s_off[seg])];
+  auto member = [&](int e) -> uint32_t {
+    const int sg = segment_of(e);
+    return rec_at(sg, e - (int)s_off[sg]);
   };
   double acc[29];
 #pragma unroll
   for (int c = 0; c < 29; ++c) acc[c] = 0.0;
+  if (fusedm && n_valid > 0) {
+    // Listed phase: the queries whose certificate failed this iteration (the per-wave segments of dlist the fused pass left,
+    // dcount) have exact matches from the listed search now; those below the band are kept whatever the quantile turns out to
+    // be inside it -- summed here, four entries per thread and round with their loads issued level by level.  (Lower-bounded
+    // ones lie above the quantile: nn_validate checked that, or the iteration would not be in this form.)
+    const int32_t* dc = b.dcount + (size_t)pair * b.seg_stride;
+    const int32_t* dl = b.dlist + (size_t)pair * b.dl_stride;
+    const int per = (nseg0 + 255) >> 8;
+    const int s0 = (int)threadIdx.x * per;
+    uint32_t c[kFinalizeMaxSeg / 256];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < kFinalizeMaxSeg / 256; ++k) {
+      c[k] = (k < per && s0 + k < nseg0) ? (uint32_t)dc[s0 + k] : 0u;
+      mine += c[k];
+    }
+    uint32_t total;
+    uint32_t o = block_excl_scan(mine, s_w, &total);
+#pragma unroll
+    for (int k = 0; k < kFinalizeMaxSeg / 256; ++k)
+      if (k < per && s0 + k < nseg0) { s_off[s0 + k] = o; o += c[k]; }
+    int top = 1;
+    while (2 * top < nseg0) top *= 2;
+    for (int x = nseg0 + (int)threadIdx.x; x < 2 * top; x += 256) s_off[x] = 0xffffffffu;
+    __syncthreads();
+    const int nl = (int)total;
+    const int band_lo = st->band_lo;
+    const size_t so = (size_t)pair * b.ns_cap, to = (size_t)pair * b.nt_cap;
+    constexpr int kL = 4;
+    for (int e0 = threadIdx.x; e0 < nl; e0 += kL * 256) {
+      int sg[kL], ii[kL], jj[kL];
+      float dd[kL], ll[kL];
+      float4 s4[kL], q4[kL], n4[kL];
+#pragma unroll
+      for (int k = 0; k < kL; ++k) sg[k] = 0;
+      for (int step = top; step > 0; step >>= 1) {
+#pragma unroll
+        for (int k = 0; k < kL; ++k) {
+          const int cand = sg[k] + step;
+          sg[k] = s_off[cand] <= (uint32_t)min(e0 + 256 * k, nl - 1) ? cand : sg[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kL; ++k) ii[k] = dl[(size_t)sg[k] * (64 * kCertifyItems) + (min(e0 + 256 * k, nl - 1) - (int)s_off[sg[k]])];
+#pragma unroll
+      for (int k = 0; k < kL; ++k) { s4[k] = ld_src(b, so + ii[k]); jj[k] = b.idx[so + ii[k]]; dd[k] = b.d2[so + ii[k]]; ll[k] = b.lb[so + ii[k]]; }
+#pragma unroll
+      for (int k = 0; k < kL; ++k) { q4[k] = b.tq[to + max(jj[k], 0)]; n4[k] = b.tn[to + max(jj[k], 0)]; }
+#pragma unroll
+      for (int k = 0; k < kL; ++k) {
+        const uint32_t key = __float_as_uint(dd[k]);
+        if (e0 + 256 * k < nl && ll[k] > 0.f && jj[k] >= 0 && key < 0x7f800000u && (int)(key >> kHistShift) < band_lo)
+          accumulate_terms(st->M, s4[k], q4[k], n4[k], dd[k], acc);
+      }
+    }
+    __syncthreads();                                       // s_off is reused for the record segments below
+  }
   uint32_t limit_key = 0;
   int nb = 0;
   bool flat = false;
@@ -2178,39 +2479,42 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
     nb = (int)total;
     flat = nb <= kFinalizeKeyCap;
     __syncthreads();
-    // lists that fit are cached in LDS with their keys (the low 20 bits of d2: the high bits are the bin); longer lists
-    // (very large clouds, or many equal distances) are fetched again in every pass
+    // lists that fit are cached in LDS: every record's key (d2's float bits) and position; longer lists (very large clouds, or
+    // many equal distances) are fetched again in every pass
     if (flat && nb > 0) {
-      constexpr int kPer = kFinalizeKeyCap / 256;          // every member of a flat list in one round: two memory levels
-      int ii[kPer], sg[kPer];
-      float dd[kPer];
-      // the kPer segment searches advance together, one LDS level per step (a search per entry, one after the other,
-      // was most of this phase)
+      constexpr int kPer = 16;                             // records per thread and round: two memory levels a round
+      for (int r0 = 0; r0 < nb; r0 += kPer * 256) {        // workgroup-uniform
+        int sg[kPer];
+        uint32_t pos[kPer];
+        float4 aa[kPer];
+        // the kPer segment searches advance together, one LDS level per step (a search per entry, one after the other,
+        // was most of this phase)
 #pragma unroll
-      for (int k = 0; k < kPer; ++k) sg[k] = 0;
-      for (int step = top; step > 0; step >>= 1) {
+        for (int k = 0; k < kPer; ++k) sg[k] = 0;
+        for (int step = top; step > 0; step >>= 1) {
+#pragma unroll
+          for (int k = 0; k < kPer; ++k) {
+            // s_off is padded with 0xffffffff up to the next power of two: one unconditional read and a select per entry, so
+            // the kPer reads of a step overlap (guarded by `cand < nseg` the compiler puts every read in its own branch)
+            const int cand = sg[k] + step;
+            sg[k] = s_off[cand] <= (uint32_t)min(r0 + (int)threadIdx.x + 256 * k, nb - 1) ? cand : sg[k];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) pos[k] = rec_at(sg[k], min(r0 + (int)threadIdx.x + 256 * k, nb - 1) - (int)s_off[sg[k]]);
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) aa[k] = ra[pos[k]];
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
-          // s_off is padded with 0xffffffff up to the next power of two: one unconditional read and a select per entry, so
-          // the kPer reads of a step overlap (guarded by `cand < nseg` the compiler puts every read in its own branch)
-          const int cand = sg[k] + step;
-          sg[k] = s_off[cand] <= (uint32_t)min((int)threadIdx.x + 256 * k, nb - 1) ? cand : sg[k];
+          const int e = r0 + (int)threadIdx.x + 256 * k;
+          if (e < nb) { s_pos[e] = pos[k]; s_keys[e] = __float_as_uint(aa[k].w); }
         }
-      }
-#pragma unroll
-      for (int k = 0; k < kPer; ++k) ii[k] = bl[(size_t)sg[k] * seg_len + (min((int)threadIdx.x + 256 * k, nb - 1) - (int)s_off[sg[k]])];
-#pragma unroll
-      for (int k = 0; k < kPer; ++k) dd[k] = b.d2[so + ii[k]];
-#pragma unroll
-      for (int k = 0; k < kPer; ++k) {
-        const int e = (int)threadIdx.x + 256 * k;
-        if (e < nb) { s_idx[e] = ii[k]; s_keys[e] = __float_as_uint(dd[k]) & 0xfffffu; }
       }
     }
     __syncthreads();
   }
   if (n_valid > 0) {
-    // exact rank (krank - below) inside the boundary bin: radix select on the low 20 key bits
+    // exact rank (krank - below) inside the quantile's bin: radix select on the low 20 key bits of that bin's records
     uint32_t rank = krank - below;
     uint32_t prefix = 0, mask = 0;
     const int shifts[3] = {12, 4, 0};
@@ -2221,8 +2525,9 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
       s_h[threadIdx.x] = 0;
       __syncthreads();
       for (int e = threadIdx.x; e < nb; e += blockDim.x) {
-        const uint32_t key = flat ? s_keys[e] : (__float_as_uint(b.d2[so + member(e)]) & 0xfffffu);
-        if ((key & mask) == prefix) atomicAdd(&s_h[(key >> shift) & (nd - 1u)], 1u);
+        const uint32_t full = flat ? s_keys[e] : __float_as_uint(ra[member(e)].w);
+        const uint32_t key = full & 0xfffffu;
+        if ((full >> kHistShift) == qbin && (key & mask) == prefix) atomicAdd(&s_h[(key >> shift) & (nd - 1u)], 1u);
       }
       __syncthreads();
       {   // the digit whose cumulative count crosses `rank`, found by all 256 threads at once
@@ -2240,35 +2545,40 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
       __syncthreads();
     }
     limit_key = (qbin << kHistShift) | prefix;
-    // weights = (d2 <= limit)  (icp_fast.cc:497-498) for the boundary-bin entries
+    // weights = (d2 <= limit)  (icp_fast.cc:497-498): every record at or below the quantile.  (Keys order like the floats: a
+    // record of a lower bin of the band is below the limit whatever its low bits.)
+    const size_t to = (size_t)pair * b.nt_cap;
     if (flat) {
-      const size_t to = (size_t)pair * b.nt_cap;
-      // eight entries per thread and round, their loads issued level by level (source point + match, then the matched
-      // target point + normal) instead of one entry after the other
+      // eight records per thread and round, their loads issued level by level (the record, then the matched target point +
+      // normal) instead of one record after the other
       constexpr int kW = 8;
       for (int e0 = threadIdx.x; e0 < nb; e0 += kW * 256) {
         bool use[kW];
-        int ii[kW], jj[kW];
+        uint32_t pos[kW];
+        int jj[kW];
         float4 s4[kW], q4[kW], n4[kW];
 #pragma unroll
         for (int k = 0; k < kW; ++k) {
           const int e = min(e0 + 256 * k, nb - 1);
-          use[k] = e0 + 256 * k < nb && s_keys[e] <= prefix;
-          ii[k] = s_idx[e];
+          use[k] = e0 + 256 * k < nb && s_keys[e] <= limit_key;
+          pos[k] = s_pos[e];
         }
 #pragma unroll
-        for (int k = 0; k < kW; ++k) { s4[k] = ld_src(b, so + ii[k]); jj[k] = max(b.idx[so + ii[k]], 0); }
+        for (int k = 0; k < kW; ++k) { s4[k] = ra[pos[k]]; jj[k] = max(rj[pos[k]], 0); }
 #pragma unroll
         for (int k = 0; k < kW; ++k) { q4[k] = b.tq[to + jj[k]]; n4[k] = b.tn[to + jj[k]]; }
 #pragma unroll
         for (int k = 0; k < kW; ++k)
-          if (use[k]) accumulate_terms(st->M, s4[k], q4[k], n4[k], __uint_as_float((qbin << kHistShift) | s_keys[e0 + 256 * k]), acc);
+          if (use[k]) accumulate_terms(st->M, s4[k], q4[k], n4[k], s4[k].w, acc);
       }
     } else {
       for (int e = threadIdx.x; e < nb; e += blockDim.x) {
-        const int i = member(e);
-        const float d = b.d2[so + i];
-        if (__float_as_uint(d) <= limit_key) accumulate_pair(b, st, pair, i, d, acc);
+        const uint32_t at = member(e);
+        const float4 a = ra[at];
+        if (__float_as_uint(a.w) <= limit_key) {
+          const int j = max(rj[at], 0);
+          accumulate_terms(st->M, a, b.tq[to + j], b.tn[to + j], a.w, acc);
+        }
       }
     }
   }
@@ -2278,7 +2588,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   {
     const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
     double s = 0;
-    const double* part = b.partials + (size_t)pair * b.acc_blocks * kAccCols + col;
+    const double* part = b.partials + (size_t)pair * b.part_stride * kAccCols + col;
     for (int k = grp; k < nblk; k += 8) s += part[(size_t)k * kAccCols];
     s_part[grp][col] = s;
   }
@@ -2304,6 +2614,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
     if (st->iter < kSearchHist) b.search_hist[(size_t)pair * kSearchHist + st->iter] = searched;
     for (int c = 0; c < 4; ++c) st->nabo_count[c] = 0;
   }
+  const uint32_t n_listed = st->deferred_count;          // queries whose certificate failed in this iteration
   st->deferred_count = 0;
   st->min_lb_key = 0xffffffffu;
   st->refine = 0;
@@ -2312,6 +2623,25 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
     float rc = fminf(fmaxf(b.cap_factor * lim, 0.05f), b.ball_radius);
     if (!(n_valid > 0)) rc = b.ball_radius;
     st->rcap2 = rc * rc;
+  }
+  {   // fused path: the band of histogram bins the NEXT iteration's quantile is expected in -- this quantile +- max(band_pad bins,
+      // band_gain x its last move).  No previous quantile, a quantile in bin 0 or a band of more than three bins: no prediction
+      // (the certificate pass then only certifies and `accumulate` sums).
+    const uint32_t prev = st->limit_key;
+    int lo = 0, hi = -1;
+    if (n_valid > 0 && prev != 0u && limit_key != 0u) {
+      const double x = (double)limit_key;
+      const double w = fmax((double)b.band_gain * fabs(x - (double)prev), (double)b.band_pad * 1048576.0);
+      const double l = x - w, u = x + w;
+      if (l >= 1048576.0 && u < 2139095040.0) { lo = (int)((uint32_t)l >> kHistShift); hi = (int)((uint32_t)u >> kHistShift); }
+      if (hi - lo > 2) { lo = 0; hi = -1; }
+      // many certificates still fail (the pose still moves): the next iteration will list as many, which finalize would have to
+      // walk -- no prediction, the certificate pass only certifies and `accumulate` sums
+      if (b.fused && n_listed > (uint32_t)kFusedListedMax) { lo = 0; hi = -1; }
+    }
+    st->band_lo = lo; st->band_hi = hi;
+    if (fusedm) st->spec_hits += 1;
+    st->spec_ok = 0;
   }
   st->limit_key = limit_key;
   const double kept = s_tot[28];

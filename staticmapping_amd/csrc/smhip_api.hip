@@ -386,7 +386,11 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
         // near-empty listed search beat the fused kernel once only a handful of certificates fail)
         {
           Bracket br(h, d.lds_table ? 5 : 4, st, np);
-          if (f.small) {
+          if (d.fused) {
+            // certificate pass + the sums below the predicted quantile band in one pass over the source (fused_iteration decides)
+            const int nbc = ceil_div(ns_max, kNnThreads * kCertifyItems);
+            hipLaunchKernelGGL(nn_certify_acc<kCertifyItems>, dim3(nbc * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nbc);
+          } else if (f.small) {
             const int nb1 = ceil_div(ns_max, kNnThreads);
             hipLaunchKernelGGL(nn_certify<1>, dim3(nb1 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nb1);
           } else {
@@ -394,7 +398,11 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
             hipLaunchKernelGGL(nn_certify<kCertifyItems>, dim3(nbc * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nbc);
           }
         }
-        { Bracket br(h, 6, st, np); hipLaunchKernelGGL(nn_ball_listed, glist, dim3(kNnThreads), 0, st, d, kListedBlocks); }
+        {
+          Bracket br(h, 6, st, np);
+          if (d.fused) hipLaunchKernelGGL(nn_ball_listed<true>, glist, dim3(kNnThreads), 0, st, d, kListedBlocks);
+          else hipLaunchKernelGGL(nn_ball_listed<false>, glist, dim3(kNnThreads), 0, st, d, kListedBlocks);
+        }
       } else {
         Bracket br(h, 4, st, np);
         hipLaunchKernelGGL(nn_ball, gx, dim3(kNnThreads), 0, st, d, nblk);
@@ -422,6 +430,16 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
     hipLaunchKernelGGL(nn_brute, g, dim3(kNnThreads), 0, st, d);
   }
   return SMHIP_OK;
+}
+
+// Does iteration `iteration` of this batch part run the fused path (nn_certify_acc + nn_ball_listed<true>: certificate pass and
+// normal-equation sums in one pass over the source)?  Exactly where the two-launch certificate form runs in a batch, unless every
+// bound is refined in every iteration anyway (nothing to speculate on) or the cloud has more record segments than finalize indexes.
+bool fused_iteration(const smhip_context* h, const Half& f, int ns_max, int iteration) {
+  const IcpDev& d = f.d;
+  if (h->opts.nn_mode != SMHIP_NN_GRID || !d.use_ball || !d.lds_table || !d.certify || h->opts.no_fused_sums || d.exact_all || f.small) return false;
+  if (iteration < 1 || iteration < d.split_after || !(h->opts.split_after > 0 || f.np >= 16)) return false;
+  return ceil_div(ns_max, kNnThreads * kCertifyItems) * (kNnThreads / 64) + kListedBlocks * (kNnThreads / 64) <= kFinalizeMaxSeg;
 }
 
 smhip_status fill_inputs(smhip_context* h, int np, const double* guesses, int* ns_max, int* nt_max, int first = 0) {
@@ -454,6 +472,10 @@ void sync_options(smhip_context* h) {
   h->dev.exact_all = h->opts.exact_matches;
   h->dev.ball_radius = h->opts.ball_radius > 0 ? h->opts.ball_radius : 0.3f;
   { const char* e = std::getenv("SMHIP_DEBUG_FLAGS"); h->dev.debug_flags = e ? std::atoi(e) : 0; }
+  h->dev.fused = 0;
+  h->dev.band_pad = 0.25f; h->dev.band_gain = 1.5f;              // tuning only: results do not depend on the band, only how often it holds
+  { const char* e = std::getenv("SMHIP_BAND_PAD"); if (e && std::atof(e) >= 0.0) h->dev.band_pad = (float)std::atof(e); }
+  { const char* e = std::getenv("SMHIP_BAND_GAIN"); if (e && std::atof(e) >= 0.0) h->dev.band_gain = (float)std::atof(e); }
   { const char* e = std::getenv("SMHIP_NABO_LISTED_BLOCKS"); if (e && std::atoi(e) > 0) h->nabo_listed_blocks = std::max(8, std::min(4096, std::atoi(e))); }   // >= 8: a workgroup's 16-bit histogram bins
 }
 
@@ -555,8 +577,13 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   d.slots = pair_slots; d.ns_cap = max_source_points; d.nt_cap = max_target_points;
   d.acc_blocks = ceil_div(max_source_points, kAccThreads * kAccItemsSmall);
   d.acc_items = kAccItemsSmall;
-  d.bl_stride = ceil_div(max_source_points, kAccThreads * kAccItemsBatch) * (kAccThreads * kAccItemsBatch);
-  d.seg_stride = d.acc_blocks * (kAccThreads / 64);     // one segment per accumulate wave, short chunks = most waves
+  d.part_stride = d.acc_blocks;
+  d.dl_stride = ceil_div(max_source_points, kNnThreads * kCertifyItems) * (kNnThreads * kCertifyItems);
+  d.bl_stride = std::max(ceil_div(max_source_points, kAccThreads * kAccItemsBatch) * (kAccThreads * kAccItemsBatch), d.dl_stride);
+  // one segment per producing wave: accumulate with short chunks makes the most; the fused path has its certificate pass's waves
+  // plus the listed search's
+  d.seg_stride = std::max(d.acc_blocks * (kAccThreads / 64),
+                          ceil_div(max_source_points, kNnThreads * kCertifyItems) * (kNnThreads / 64) + kListedBlocks * (kNnThreads / 64));
   const size_t B = pair_slots, NS = max_source_points, NT = max_target_points;
   smhip_status s = SMHIP_OK;
   auto A = [&](smhip_status r) { if (s == SMHIP_OK) s = r; };
@@ -581,13 +608,15 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, &d.search_hist, B * kSearchHist));
   A(dev_alloc(h, &d.idx, B * NS));
   A(dev_alloc(h, &d.hist, B * kHistBins));
-  A(dev_alloc(h, &d.dlist, B * NS));
+  A(dev_alloc(h, &d.dlist, B * (size_t)d.dl_stride));
   A(dev_alloc(h, &d.hlist, B * NS));
   A(dev_alloc(h, &d.ulist, B * NS));
   A(dev_alloc(h, &d.ukeys, B * NS));
-  A(dev_alloc(h, &d.blist, B * (size_t)d.bl_stride));
+  A(dev_alloc(h, &d.rec_a, B * 2 * (size_t)d.bl_stride));
+  A(dev_alloc(h, &d.rec_j, B * 2 * (size_t)d.bl_stride));
   A(dev_alloc(h, &d.gcount, B * (size_t)d.seg_stride));
-  A(dev_alloc(h, &d.partials, B * d.acc_blocks * kAccCols));
+  A(dev_alloc(h, &d.dcount, B * (size_t)d.seg_stride));
+  A(dev_alloc(h, &d.partials, B * (size_t)d.part_stride * kAccCols));
   A(dev_alloc(h, &d.tpart, B * kTgtReduceBlocks * 16));
   A(dev_alloc(h, &d.done_count, 4));
   A(dev_alloc(h, &h->ids_dev, NS));
@@ -1105,7 +1134,8 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
   const int max_it = h->dev.max_iteration;
   for (int it = 0; it < max_it; ++it) {
     for (int k = 0; k < nh; ++k) {
-      const Half& f = halves[k];
+      Half& f = halves[k];
+      f.d.fused = fused_iteration(h, f, ns_max, it) ? 1 : 0;     // every launch of this iteration and part sees the same flag
       s = enqueue_find_closests_half(h, f, ns_max, it);
       if (s) return s;
       {
@@ -1162,7 +1192,7 @@ static smhip_status fetch_range(smhip_handle h, int first, int npairs, double* r
       stats[p].hard_queries = (int32_t)st.hard_total;
       stats[p].refined_iterations = (int32_t)st.refine_total;
       stats[p].searched_queries = (int32_t)st.searched_total;
-      stats[p].reserved = 0;
+      stats[p].fused_iterations = (int32_t)st.spec_hits;
     }
     if (st.status != SMHIP_OK && worst == SMHIP_OK) {
       worst = st.status;

@@ -17,8 +17,9 @@ constexpr int kAccThreads = 256;
 // a single pair keeps short ones, or it would have 15 workgroups for 256 CUs.
 constexpr int kAccItemsSmall = 8;
 constexpr int kAccItemsBatch = 32;
-constexpr int kFinalizeKeyCap = 4096;     // boundary-bin keys finalize keeps in LDS between its radix-select passes
-constexpr int kFinalizeMaxSeg = 2048;     // accumulate waves (= blist segments) per pair finalize can index: 4 Mi source points at 32 per thread
+constexpr int kFinalizeKeyCap = 8192;     // band records whose keys finalize keeps in LDS between its radix-select passes
+constexpr int kFinalizeMaxSeg = 2048;     // record segments (one per producing wave) per pair finalize can index: 4 Mi source points at 32 per
+                                          // accumulate thread; the fused path (20 per thread + the listed search's 128 waves) up to 2.4 Mi points
 constexpr int kAccCols = 32;             // 21 (A upper) + 6 (b) + 1 (sum sqrt d2) + 1 (count) padded to 32
 constexpr int kMaxGridWords = 1 << 18;   // 32-cell words per pair (8 Mi cells)
 constexpr int kMaxRowWords = (kMaxGridWords >> 5) + 2;   // 32-row words of the row-occupancy bitmap (rows = ny * nz <= kMaxGridWords), + slack for two-word reads
@@ -31,6 +32,8 @@ constexpr int kLdsRowCap = 256;           // grid rows of the box whose runs are
 constexpr int kWideBlocks = 512;         // workgroups (4 waves = 4 queries at a time) per pair of nn_ring_wide
 constexpr int kListedBlocks = 32;        // workgroups per pair of the listed search (nn_ball_listed): it strides over the list
 constexpr int kBallItems = 2;            // rounds of 256 queries per workgroup in nn_ball_lds / nn_ball (prefetch across rounds; 2 measured best: 4 = +8 %, 1 = +5 %)
+constexpr int kFusedListedMax = 16384;   // fused path: with more failing certificates than this in a pair and iteration the sums are left to `accumulate`
+                                         // (finalize, one workgroup per pair, walks the listed queries: 16 rounds of 4 per thread at most)
 constexpr int kCertifyItems = 20;        // rounds per workgroup of the certificate pass: its per-workgroup costs (histogram zero + flush, pipeline fill) are
                                          // large next to a round's -- 8: 80, 12: 57, 16: 57, 20: 49, 24: 48, 28: 52, 32: 53 us per 64 pairs (120 k points)
 
@@ -82,7 +85,14 @@ struct PairState {
   uint32_t limit_key;
   uint32_t nabo_count[4];    // SMHIP_NN_NABO: queries to walk again this iteration, by the work class of their last walk (nn_certify<., true>)
   int32_t grid_invalid;      // 1 = grid_setup found a non-finite target box: no search structure was built for this target, and
-  int32_t pad_;              //     every Align on it fails (pose_setup re-asserts it when the structure is "kept")
+                             //     every Align on it fails (pose_setup re-asserts it when the structure is "kept")
+  // Fused certificate pass + sums (nn_certify_acc): finalize predicts the histogram bins the NEXT iteration's quantile will fall
+  // in, [band_lo, band_hi] (band_lo = 0: no prediction).  The fused pass sums the matches below the band on the spot and leaves
+  // the band's members as records; nn_validate, once every distance is known, sets spec_ok when the quantile's bin did land in
+  // the band (and nothing had to be refined) -- otherwise `accumulate` redoes the iteration's sums the plain way.
+  int32_t band_lo, band_hi;
+  int32_t spec_ok;
+  uint32_t spec_hits;        // iterations whose sums came from the fused pass (statistics)
 
   // outputs
   double score;
@@ -104,8 +114,14 @@ struct IcpDev {
   int32_t npairs;            // pairs this launch covers (XCD-aware kernels pad the grid to a multiple of 8)
   int32_t pair_base;         // first pair slot of this launch (the batch is split over two streams)
   int32_t acc_blocks;        // ceil(ns_cap / (kAccThreads * kAccItemsSmall))
-  int32_t bl_stride;         // blist entries per pair: ns_cap rounded up to a whole batched accumulate chunk
-  int32_t seg_stride;        // gcount entries per pair
+  int32_t part_stride;       // rows of `partials` per pair (= acc_blocks: accumulate with short chunks makes the most)
+  int32_t bl_stride;         // record slots per region and pair: ns_cap rounded up to whole accumulate AND certificate-pass chunks
+  int32_t dl_stride;         // dlist entries per pair as the fused path indexes it: ns_cap rounded up to a whole certificate-pass chunk
+  int32_t seg_stride;        // gcount / dcount entries per pair
+  int32_t fused;             // 1 = this iteration's launches belong to the fused path (nn_certify_acc + nn_ball_listed<true>):
+                             //     nn_validate decides spec_ok, accumulate returns at once when it holds, finalize reads either form
+  float band_pad;            // half-width of the predicted band in bins, at least (tuning; default 0.25)
+  float band_gain;           // ... and this many times the quantile's last move (default 1.5)
   int32_t acc_items;         // points per thread of the accumulate launches of this batch part (finalize folds accordingly)
   PairState* state;
   const PairInput* in;
@@ -134,10 +150,17 @@ struct IcpDev {
   int32_t* hlist;            // [slots][ns_cap] queries the tile phase could not certify (ring search)
   int32_t* ulist;            // [slots][ns_cap] unresolved queries (brute-force fallback)
   unsigned long long* ukeys; // [slots][ns_cap] fallback winners: (d2 bits << 32) | original target index
-  int32_t* blist;            // [slots][ns_cap] queries whose d2 falls in the quantile's histogram bin: the members of the g-th
-                             //                 group of 64 consecutive queries sit at blist[64 g ...], in query order
-  uint32_t* gcount;          // [slots][ceil(ns_cap / 64)] how many members each group has
-  double* partials;          // [slots][acc_blocks][kAccCols]
+  // Band records: the matches whose d2 falls in the histogram bins the quantile can fall in (for `accumulate`, which runs with
+  // the quantile's bin known: that bin alone), left for finalize with everything it needs of them -- source point, d2, match --
+  // by the wave that met them, in its own segment, in the order it met them: no atomics, an order fixed by the data.
+  // Region 0 ([0, bl_stride)): the segments of accumulate's or the fused pass's waves (64 * points-per-thread slots each);
+  // region 1 ([bl_stride, 2 bl_stride)): the segments of the listed search's waves (bl_stride / 128 slots each).
+  float4* rec_a;             // [slots][2 bl_stride] {source x, y, z, d2}
+  int32_t* rec_j;            // [slots][2 bl_stride] matched target position
+  uint32_t* gcount;          // [slots][seg_stride] records per segment
+  int32_t* dcount;           // [slots][seg_stride] fused path: queries whose certificate failed, per wave of nn_certify_acc (its segment of
+                             //                 dlist: dl_stride entries per pair, 64 * kCertifyItems slots per wave)
+  double* partials;          // [slots][part_stride][kAccCols]: one row per workgroup of accumulate / of the fused certificate pass
   double* tpart;             // [slots][kTgtReduceBlocks][16]
   uint32_t* done_count;      // number of finished pairs
   uint8_t* nabo_work;        // [slots][ns_cap] SMHIP_NN_NABO: buckets the query's last walk scanned (capped at 255); null until the mode is used

@@ -192,7 +192,7 @@ class IcpFastHip:
         self.last_stats = [dict(iterations=s.iterations, kept=s.kept, limit_d2=s.limit_d2,
                                 fallback_queries=s.fallback_queries, status=s.status,
                                 hard_queries=s.hard_queries, refined_iterations=s.refined_iterations,
-                                searched_queries=s.searched_queries) for s in stats]
+                                searched_queries=s.searched_queries, fused_iterations=s.fused_iterations) for s in stats]
         self._check(st)
         return res.reshape(npairs, 4, 4).transpose(0, 2, 1).copy(), scores, self.last_stats
 
@@ -209,7 +209,7 @@ class IcpFastHip:
         self.last_stats = [dict(iterations=s.iterations, kept=s.kept, limit_d2=s.limit_d2,
                                 fallback_queries=s.fallback_queries, status=s.status,
                                 hard_queries=s.hard_queries, refined_iterations=s.refined_iterations,
-                                searched_queries=s.searched_queries) for s in stats]
+                                searched_queries=s.searched_queries, fused_iterations=s.fused_iterations) for s in stats]
         self._check(st)
         return res.reshape(npairs, 4, 4).transpose(0, 2, 1).copy(), scores, self.last_stats
 

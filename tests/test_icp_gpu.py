@@ -442,7 +442,9 @@ def test_batch_split_point_follows_the_previous_batch_and_changes_no_bits(smhip,
     """split_after = 0 (default): where a batch's iterations switch from the fused search (nn_ball_lds) to certificate pass +
     listed search is taken from the share of queries the PREVIOUS batch had to search per iteration.  A handle's first batch
     switches at 2; after a batch of good guesses it stays early, after a batch of poor guesses (many failing certificates
-    for several iterations) it moves later -- and the poses are the same bits wherever it is, static or automatic."""
+    for several iterations) it moves later -- and the poses are the same bits wherever it is, static or automatic.
+    (With no_fused_sums: the iterations after the switch otherwise sum the normal equations inside the certificate pass, in a
+    different -- fixed -- order; that form is compared below: same kept sets and quantiles, poses to 1e-11.)"""
     sm = smhip
     src, q, n, T = cfg2["src"], cfg2["q"], cfg2["n"], cfg2["T"]
     B = 16
@@ -450,7 +452,7 @@ def test_batch_split_point_follows_the_previous_batch_and_changes_no_bits(smhip,
     poor = [np.eye(4)] * B
     ref = {}
     for split in (2, 6, -1):
-        m = sm.IcpFastHip(pair_slots=B, max_source_points=len(src), max_target_points=len(q), max_iteration=12, early_exit=0, split_after=split)
+        m = sm.IcpFastHip(pair_slots=B, max_source_points=len(src), max_target_points=len(q), max_iteration=12, early_exit=0, split_after=split, no_fused_sums=1)
         m.set_input_source(src); m.set_input_target(q, n)
         for s in range(1, B):
             m.copy_slot(0, s)
@@ -459,7 +461,7 @@ def test_batch_split_point_follows_the_previous_batch_and_changes_no_bits(smhip,
             key = (R.tobytes(), tuple(s["kept"] for s in st))
             assert ref.setdefault(name, key) == key, (split, name)
         m.close()
-    m = sm.IcpFastHip(pair_slots=B, max_source_points=len(src), max_target_points=len(q), max_iteration=12, early_exit=0)
+    m = sm.IcpFastHip(pair_slots=B, max_source_points=len(src), max_target_points=len(q), max_iteration=12, early_exit=0, no_fused_sums=1)
     m.set_input_source(src); m.set_input_target(q, n)
     for s in range(1, B):
         m.copy_slot(0, s)
@@ -473,6 +475,54 @@ def test_batch_split_point_follows_the_previous_batch_and_changes_no_bits(smhip,
     assert used[1] <= 2                      # after good guesses: almost every certificate holds from iteration 1 on
     assert used[3] > used[1]                 # after poor guesses: the fused kernel keeps the first iterations
     assert used[5] == used[1]                # and back
+
+
+def test_fused_certificate_pass_sums_equal_the_separate_passes(smhip, cfg2):
+    """From the switch on a batch sums the normal equations inside the certificate pass (nn_certify_acc: matches below a
+    predicted band of histogram bins around the trimming quantile are summed on the spot, the band's members left for the exact
+    select; icp_fast.cc:484-523 in one pass over the source instead of two).  Against the separate passes (no_fused_sums):
+    the same kept count and the same quantile in the last iteration -- integer / order-statistic results, so identical -- and
+    poses that differ only by the order of the 29 sums (<= 1e-11 rad / 1e-10 m); bit-reproducible from run to run and slot
+    to slot; and the fused form does carry most iterations (it is not the fallback that is being compared)."""
+    sm = smhip
+    src, q, n, T = cfg2["src"], cfg2["q"], cfg2["n"], cfg2["T"]
+    from staticmapping_amd import synth
+    B = 16
+    guesses = [cfg2["guess"] @ synth.make_pose(t=(0.01 * (s % 4), -0.01 * (s % 3), 0.0), rpy_deg=(0, 0, 0.05 * (s % 5))) for s in range(B)]
+    out = {}
+    for name, opts in (("separate", dict(no_fused_sums=1)), ("fused", dict()), ("fused_split1", dict(split_after=1)), ("fused_split4", dict(split_after=4))):
+        m = sm.IcpFastHip(pair_slots=B, max_source_points=len(src), max_target_points=len(q), max_iteration=20, early_exit=0, **opts)
+        m.set_input_source(src); m.set_input_target(q, n)
+        for s in range(1, B):
+            m.copy_slot(0, s)
+        # (the first batch of a handle switches at iteration 2, later ones where the previous batch says: compare batches that
+        # switch at the same place -- the order of the sums follows the switch)
+        runs, used = [], []
+        for _ in range(3):
+            runs.append(m.align_batch(B, guesses)); used.append(m.get_profile()["split_after_used"])
+        m.close()
+        assert used[1] == used[2]
+        assert runs[1][0].tobytes() == runs[2][0].tobytes() and runs[1][1].tobytes() == runs[2][1].tobytes(), name      # reproducible
+        out[name] = runs[1]
+    Rs, scs, sts = out["separate"]
+    assert all(s["fused_iterations"] == 0 for s in sts)
+    for name in ("fused", "fused_split1", "fused_split4"):
+        R, sc, st = out[name]
+        for s in range(B):
+            da, dt = sm.se3_error(R[s], Rs[s])
+            assert da < 1e-11 and dt < 1e-10, (name, s, da, dt)
+            assert st[s]["kept"] == sts[s]["kept"] and st[s]["limit_d2"] == sts[s]["limit_d2"] and st[s]["iterations"] == 20, (name, s, st[s], sts[s])
+            assert abs(sc[s] - scs[s]) < 1e-12
+    fused_share = np.mean([s["fused_iterations"] for s in out["fused"][2]])
+    assert fused_share >= 10, fused_share                    # of the 18 iterations after the switch, most sums came from the fused pass
+    # equal guesses in different slots: equal bits
+    m = sm.IcpFastHip(pair_slots=B, max_source_points=len(src), max_target_points=len(q), max_iteration=20, early_exit=0)
+    m.set_input_source(src); m.set_input_target(q, n)
+    for s in range(1, B):
+        m.copy_slot(0, s)
+    R, sc, st = m.align_batch(B, [cfg2["guess"]] * B)
+    m.close()
+    assert all(R[s].tobytes() == R[0].tobytes() for s in range(B))
 
 
 @pytest.mark.parametrize("guess_name", ["offset", "identity", "truth"])

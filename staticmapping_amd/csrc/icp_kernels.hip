@@ -2401,7 +2401,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   if (fusedm && n_valid > 0) {
     // Listed phase: the queries whose certificate failed this iteration (the per-wave segments of dlist the fused pass left,
     // dcount) have exact matches from the listed search now; those below the band are kept whatever the quantile turns out to
-    // be inside it -- summed here, four entries per thread and round with their loads issued level by level.  (Lower-bounded
+    // be inside it -- summed here, eight entries per thread and round with their loads issued level by level.  (Lower-bounded
     // ones lie above the quantile: nn_validate checked that, or the iteration would not be in this form.)
     const int32_t* dc = b.dcount + (size_t)pair * b.seg_stride;
     const int32_t* dl = b.dlist + (size_t)pair * b.dl_stride;
@@ -2426,7 +2426,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
     const int nl = (int)total;
     const int band_lo = st->band_lo;
     const size_t so = (size_t)pair * b.ns_cap, to = (size_t)pair * b.nt_cap;
-    constexpr int kL = 4;
+    constexpr int kL = 8;
     for (int e0 = threadIdx.x; e0 < nl; e0 += kL * 256) {
       int sg[kL], ii[kL], jj[kL];
       float dd[kL], ll[kL];

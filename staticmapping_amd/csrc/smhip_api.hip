@@ -407,8 +407,11 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
         Bracket br(h, 4, st, np);
         hipLaunchKernelGGL(nn_ball, gx, dim3(kNnThreads), 0, st, d, nblk);
       }
-      if (f.small && !d.exact_all) {
-        // a few pairs: validate + ring + fallback as ONE launch, a workgroup per pair (near-empty launches cost ~5 us each there)
+      if ((f.small || d.fused) && !d.exact_all) {
+        // a few pairs: validate + ring + fallback as ONE launch, a workgroup per pair (near-empty launches cost ~5 us each there).
+        // The same in a batch's fused iterations: the pose has settled there, a quantile that reaches a lower bound is the rare
+        // case, and the two spread-out launches cost 20-25 us each of a ~700 us iteration whether they do anything or not
+        // (8 192 and 16 384 workgroups that look at one flag).
         Bracket br(h, 1, st);
         hipLaunchKernelGGL(nn_refine_one, dim3(np), dim3(kNnThreads), 0, st, d);
         return SMHIP_OK;

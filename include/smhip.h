@@ -290,6 +290,15 @@ smhip_status smhip_ndt_set_options(smhip_handle h, const smhip_ndt_options* o);
  * distance of the aligned source to the raw target (LOWER is better, unlike the ICP score). */
 smhip_status smhip_ndt_align(smhip_handle h, const double guess[16], double result[16], double* score,
                              smhip_ndt_stats* stats);
+/* npairs independent Ndt::Align calls -- pair slots first_slot .. first_slot + npairs - 1, clouds set with smhip_set_source_f32 /
+ * smhip_set_target_f32 on those slots -- advanced in lock-step: the back end runs up to six SubmapPairMatch tasks at once with
+ * whichever matcher is configured (builder/map_builder.cc:399-446, 655).  Every pair's Newton / More-Thuente state machine
+ * (pclomp/ndt_omp_impl.hpp:81-171, 757-916) asks for the evaluations the reference would make, in the reference's order; each
+ * round's computeDerivatives calls of all pairs still running are ONE launch and one read-back, the voxel tables are built in
+ * one pass and the fitness scores in another.  Results are the single calls' bit for bit (sources up to 524 288 points).
+ * guesses / results: npairs column-major 4x4; scores / stats: npairs entries (may be NULL). */
+smhip_status smhip_ndt_align_batch(smhip_handle h, int first_slot, int npairs, const double* guesses, double* results,
+                                   double* scores, smhip_ndt_stats* stats);
 /* parity-test hooks: VoxelGridCovariance::applyFilter output and one computeDerivatives evaluation
  * at pose6 = (tx, ty, tz, rx, ry, rz).  icovs hold xx xy xz yy yz zz as float; hess is row-major 6x6. */
 smhip_status smhip_ndt_build_voxels(smhip_handle h, int* n_voxels);

@@ -157,6 +157,7 @@ inline std::vector<SubmapPairMatchResult> SubmapPairMatchBatch(const registrator
   bool batched = false;
   if (auto* fast = dynamic_cast<registrator::IcpFastHip*>(matcher.get())) batched = fast->AlignBatch(src, tgt, guess, &result, &score);
   else if (auto* pm = dynamic_cast<registrator::IcpPointMatcherHip*>(matcher.get())) batched = pm->AlignBatch(src, tgt, guess, &result, &score);
+  else if (auto* ndt = dynamic_cast<registrator::NdtHip*>(matcher.get())) batched = ndt->AlignBatch(src, tgt, guess, &result, &score);   // lock-step Newton
   if (!batched) {
     result.assign(guess.begin(), guess.end());
     score.assign(K, 0.0);

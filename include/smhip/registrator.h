@@ -523,6 +523,49 @@ class NdtHip : public Interface {
   }
   const smhip_ndt_stats& LastStats() const { return stats_; }
 
+  // K independent (source, target) pairs as ONE lock-step batch through K pair slots of a second handle this matcher keeps
+  // between calls (smhip_ndt_align_batch): the back end's concurrent SubmapPairMatch tasks (map_builder.cc:399-446, 655) with
+  // the Ndt matcher.  Each pair's result is what Align gives for it, bit for bit.  results / scores are resized to K; false
+  // (results = guesses) when the device refused a cloud.
+  bool AlignBatch(const std::vector<InnerCloudPtr>& sources, const std::vector<InnerCloudPtr>& targets,
+                  const std::vector<Matrix4d>& guesses, std::vector<Matrix4d>* results, std::vector<double>* scores,
+                  std::vector<smhip_ndt_stats>* stats = nullptr) {
+    const int K = static_cast<int>(sources.size());
+    SMHIP_CHECK(K > 0 && targets.size() == sources.size() && guesses.size() == sources.size() && results && scores, "AlignBatch: sizes");
+    results->assign(guesses.begin(), guesses.end());
+    scores->assign(K, 0.0);
+    int ns = 1, nt = 1;
+    for (int k = 0; k < K; ++k) {
+      if (!sources[k] || !targets[k] || sources[k]->Empty() || targets[k]->Empty()) return false;      // ndt.cc:40-42
+      ns = std::max(ns, static_cast<int>(sources[k]->GetInnerCloud().size()));
+      nt = std::max(nt, static_cast<int>(targets[k]->GetInnerCloud().size()));
+    }
+    if (!batch_arena_.Reserve(device_, std::max(K, batch_arena_.slots), ns, nt)) return false;
+    smhip_handle h = batch_arena_.handle;
+    SMHIP_CHECK(smhip_ndt_set_options(h, &opt_) == SMHIP_OK, "smhip_ndt_set_options");
+    for (int k = 0; k < K; ++k) {
+      const auto& s = sources[k]->GetInnerCloud();
+      const auto& t = targets[k]->GetInnerCloud();
+      if (smhip_set_source_f32(h, k, &s[0].x, 5, static_cast<int>(s.size())) != SMHIP_OK ||
+          smhip_set_target_f32(h, k, &t[0].x, 5, nullptr, 0, static_cast<int>(t.size())) != SMHIP_OK) {
+        std::fprintf(stderr, "[ERROR] NdtHip::AlignBatch: %s\n", smhip_last_error(h));
+        return false;
+      }
+    }
+    std::vector<double> g(16 * static_cast<size_t>(K)), r(16 * static_cast<size_t>(K));
+    std::vector<smhip_ndt_stats> st(K);
+    for (int k = 0; k < K; ++k) std::memcpy(&g[16 * static_cast<size_t>(k)], guesses[k].data(), sizeof(double) * 16);
+    const smhip_status rc = smhip_ndt_align_batch(h, 0, K, g.data(), r.data(), scores->data(), st.data());
+    if (rc != SMHIP_OK) {
+      std::fprintf(stderr, "[ERROR] NdtHip::AlignBatch: %s (%s)\n", smhip_status_string(rc), smhip_last_error(h));
+      scores->assign(K, 0.0);
+      return false;
+    }
+    for (int k = 0; k < K; ++k) std::memcpy((*results)[k].data(), &r[16 * static_cast<size_t>(k)], sizeof(double) * 16);
+    if (stats) *stats = st;
+    return true;
+  }
+
  private:
   bool EnsureHandle(int ns, int nt) {
     const bool first = arena_.handle == nullptr;
@@ -537,6 +580,7 @@ class NdtHip : public Interface {
   int32_t device_ = 0;
   int max_source_, max_target_;
   DeviceArena arena_;
+  DeviceArena batch_arena_;                    // AlignBatch's K-slot handle
   smhip_ndt_stats stats_{};
 };
 

@@ -35,6 +35,8 @@ struct NdtGridInfo {       // written by ndt_voxel_setup
   float res;
 };
 
+// One voxel table (one pair slot's target).  The kernels take a device ARRAY of these and pick theirs by block index: a batch
+// of K Aligns builds its K tables and evaluates its K derivative sets in single launches (grid.y = pair).
 struct NdtDev {
   int32_t nt, ns;
   int32_t min_points;
@@ -51,6 +53,8 @@ struct NdtDev {
   double* icovd;           // [nt][6] Leaf::icov_ in double: xx xy xz yy yz zz (stock PCL path reads these)
   double* partials;        // [kNdtMaxDerivBlocks][kNdtDerivCols]
   double* out;             // [kNdtDerivCols]
+  int32_t key_off;         // where this table's (voxel code, point) pairs start in the batch's sort arrays
+  int32_t pad_;
 };
 
 struct NdtPose {           // per derivative evaluation
@@ -68,8 +72,9 @@ struct NdtPose {           // per derivative evaluation
 // ------------------------------------------------------------------------------------------
 // voxel grid build
 // ------------------------------------------------------------------------------------------
-__global__ void ndt_voxel_setup(NdtDev d, float leaf) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void ndt_voxel_setup(const NdtDev* __restrict__ devs, float leaf) {
+  if (threadIdx.x != 0) return;
+  const NdtDev d = devs[blockIdx.x];
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int k = 0; k < kTgtReduceBlocks; ++k)
     for (int c = 0; c < 3; ++c) {
@@ -102,7 +107,8 @@ __device__ __forceinline__ bool ndt_voxel_of(const NdtGridInfo* g, float x, floa
 }
 
 // one 1024-thread block: words = {bits, exclusive rank}; nocc
-__global__ __launch_bounds__(1024) void ndt_voxel_rank(NdtDev d) {
+__global__ __launch_bounds__(1024) void ndt_voxel_rank(const NdtDev* __restrict__ devs) {
+  const NdtDev d = devs[blockIdx.x];
   NdtGridInfo* g = d.info;
   const int nw = g->nw;
   __shared__ uint32_t s_w[17];
@@ -126,7 +132,11 @@ __global__ __launch_bounds__(1024) void ndt_voxel_rank(NdtDev d) {
 // ---- sort-based build: (voxel code, point) pairs radix-sorted by the caller, then one pass marks the
 // first point of every voxel (one atomicOr per VOXEL instead of one per point: 500 k points fall into a few
 // thousand 1 m voxels) and one pass, after ndt_voxel_rank, records the voxel starts and gathers the points.
-__global__ __launch_bounds__(256) void ndt_voxel_keys64(NdtDev d, unsigned long long* keys, int32_t* vals) {
+// (key = table << 33 | code: ONE radix sort orders the (voxel, point) pairs of every table of the batch, each table's run where
+// its key_off says)
+constexpr unsigned long long kNdtCodeMask = (1ull << 33) - 1ull;
+__global__ __launch_bounds__(256) void ndt_voxel_keys64(const NdtDev* __restrict__ devs, unsigned long long* keys, int32_t* vals) {
+  const NdtDev d = devs[blockIdx.y];
   const NdtGridInfo* g = d.info;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= d.nt) return;
@@ -137,35 +147,39 @@ __global__ __launch_bounds__(256) void ndt_voxel_keys64(NdtDev d, unsigned long 
     if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && ndt_voxel_of(g, p.x, p.y, p.z, i0, i1, i2))
       code = ((unsigned long long)((i2 * g->div_b[1] + i1) * g->wx + (i0 >> 5)) << 5) | (unsigned long long)(i0 & 31);
   }
-  keys[j] = code;
-  vals[j] = j;
+  keys[d.key_off + j] = ((unsigned long long)blockIdx.y << 33) | code;
+  vals[d.key_off + j] = j;
 }
 
-__global__ __launch_bounds__(256) void ndt_voxel_heads(NdtDev d, const unsigned long long* keys) {
+__global__ __launch_bounds__(256) void ndt_voxel_heads(const NdtDev* __restrict__ devs, const unsigned long long* keys) {
+  const NdtDev d = devs[blockIdx.y];
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= d.nt) return;
-  const unsigned long long c = keys[s];
+  keys += d.key_off;
+  const unsigned long long c = keys[s] & kNdtCodeMask;
   if (c == 0xffffffffull) return;
-  if (s == 0 || keys[s - 1] != c) atomicOr(&d.bits[(uint32_t)(c >> 5)], 1u << (uint32_t)(c & 31));
+  if (s == 0 || (keys[s - 1] & kNdtCodeMask) != c) atomicOr(&d.bits[(uint32_t)(c >> 5)], 1u << (uint32_t)(c & 31));
 }
 
-__global__ __launch_bounds__(256) void ndt_voxel_starts(NdtDev d, const unsigned long long* keys, const int32_t* vals) {
+__global__ __launch_bounds__(256) void ndt_voxel_starts(const NdtDev* __restrict__ devs, const unsigned long long* keys, const int32_t* vals) {
+  const NdtDev d = devs[blockIdx.y];
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= d.nt) return;
-  const unsigned long long c = keys[s];
+  keys += d.key_off; vals += d.key_off;
+  const unsigned long long c = keys[s] & kNdtCodeMask;
   const bool valid = c != 0xffffffffull;
   if (valid) {
     const int j = vals[s];
     float4 p = d.tgt[j];
     p.w = __int_as_float(j);
     d.vpts[s] = p;
-    if (s == 0 || keys[s - 1] != c) {
+    if (s == 0 || (keys[s - 1] & kNdtCodeMask) != c) {
       const uint2 wd = d.words[(uint32_t)(c >> 5)];
       d.vstart[wd.y + __popc(wd.x & ((1u << (uint32_t)(c & 31)) - 1u))] = (uint32_t)s;
     }
   }
   // one past the last valid point closes the last voxel
-  if (valid && (s == d.nt - 1 || keys[s + 1] == 0xffffffffull)) d.vstart[d.info->nocc] = (uint32_t)s + 1u;
+  if (valid && (s == d.nt - 1 || (keys[s + 1] & kNdtCodeMask) == 0xffffffffull)) d.vstart[d.info->nocc] = (uint32_t)s + 1u;
   if (s == 0 && !valid) d.vstart[0] = 0u;
 }
 
@@ -197,20 +211,33 @@ __device__ void jacobi_eig3(double* A, double* V, double* w) {     // symmetric 
 }
 
 // One wave per occupied voxel: sums over its points, then lane 0 finishes the Leaf (:282-367).
-__global__ __launch_bounds__(256) void ndt_voxel_stats(NdtDev d) {
-  const int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+__device__ __forceinline__ void ndt_voxel_stats_one(const NdtDev& d, int v, int lane);
+__global__ __launch_bounds__(256) void ndt_voxel_stats(const NdtDev* __restrict__ devs) {
+  const NdtDev d = devs[blockIdx.y];
   const int lane = threadIdx.x & 63;
-  if (v >= d.info->nocc) return;
+  // (the host does not know nocc: a grid sized by the point count is millions of empty workgroups for a batch of dense
+  // submaps -- 4.9 ms of dispatch for 64 x 500 k points -- so a bounded grid strides over the occupied voxels instead)
+  const int nocc = d.info->nocc;
+  for (int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); v < nocc; v += gridDim.x * (blockDim.x >> 6)) ndt_voxel_stats_one(d, v, lane);
+}
+__device__ __forceinline__ void ndt_voxel_stats_one(const NdtDev& d, int v, int lane) {
   const uint32_t j0 = d.vstart[v], j1 = d.vstart[v + 1];
   double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   float cs[3] = {0, 0, 0};
-  for (uint32_t j = j0 + lane; j < j1; j += 64) {
-    const float4 p = d.vpts[j];
+  auto add = [&](const float4 p) {
     const double x = p.x, y = p.y, z = p.z;
     s[0] += x; s[1] += y; s[2] += z;                                 // leaf.mean_ += pt3d, :233
     s[3] += x * x; s[4] += x * y; s[5] += x * z; s[6] += y * y; s[7] += y * z; s[8] += z * z;   // leaf.cov_ += pt pt^T, :235
     cs[0] += p.x; cs[1] += p.y; cs[2] += p.z;                        // float centroid, :241
+  };
+  // four loads in flight per lane, added in the order of the plain loop (a 1 m voxel of a dense submap holds thousands of points,
+  // and with one load per trip the wave that owns it waited a memory latency per 64 of them)
+  uint32_t j = j0 + lane;
+  for (; j + 192 < j1; j += 256) {
+    const float4 p0 = d.vpts[j], p1 = d.vpts[j + 64], p2 = d.vpts[j + 128], p3 = d.vpts[j + 192];
+    add(p0); add(p1); add(p2); add(p3);
   }
+  for (; j < j1; j += 64) add(d.vpts[j]);
 #pragma unroll
   for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
 #pragma unroll
@@ -269,9 +296,14 @@ __global__ __launch_bounds__(256) void ndt_voxel_stats(NdtDev d) {
 // ONE = the grid has a thread for every source point (always, up to 524 288 points): the per-point sums of the reference
 // (score_pt, g_pt, h_pt: summed per point first, then added to the totals) are then the thread's totals themselves and
 // need no registers of their own -- 43 doubles fewer per lane.
+// grid = (workgroups per table, evaluations): evaluation e is pose poses[e] against table devs[active[e]] -- the K Aligns of a
+// batch advance in lock-step on the host and every round's evaluations are ONE launch.
 template <typename R, bool ONE>
-__global__ __launch_bounds__(kNdtDerivThreads, ONE ? 2 : 1) void ndt_derivatives(NdtDev d, NdtPose P) {
+__global__ __launch_bounds__(kNdtDerivThreads, ONE ? 2 : 1) void ndt_derivatives(const NdtDev* __restrict__ devs, const NdtPose* __restrict__ poses,
+                                                                                    const int32_t* __restrict__ active) {
   constexpr bool kDouble = sizeof(R) == 8;
+  const NdtDev d = devs[active[blockIdx.y]];
+  const NdtPose& P = poses[blockIdx.y];
   const NdtGridInfo* g = d.info;
   double acc[43];
 #pragma unroll
@@ -443,7 +475,8 @@ __global__ __launch_bounds__(kNdtDerivThreads, ONE ? 2 : 1) void ndt_derivatives
 
 // 16 thread groups take every 16th block, then one thread per column folds the group sums:
 // a fixed order, so repeated evaluations at the same pose are bitwise identical.
-__global__ __launch_bounds__(16 * 64) void ndt_reduce(NdtDev d, int nblocks) {
+__global__ __launch_bounds__(16 * 64) void ndt_reduce(const NdtDev* __restrict__ devs, const int32_t* __restrict__ active, int nblocks) {
+  const NdtDev d = devs[active[blockIdx.x]];
   __shared__ double s_g[16][kNdtDerivCols];
   const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
   if (c < kNdtDerivCols) {
@@ -460,7 +493,11 @@ __global__ __launch_bounds__(16 * 64) void ndt_reduce(NdtDev d, int nblocks) {
 }
 
 // mean of the squared NN distances of slot 0 (pcl::Registration::getFitnessScore, ndt.cc:60)
-__global__ __launch_bounds__(256) void fitness_partial(const float* d2, int n, double* partials) {
+// grid = (64, pairs): pair slot pair_base + blockIdx.y of the matcher's d2 array ([slots][ns_cap]), ns[blockIdx.y] valid entries
+__global__ __launch_bounds__(256) void fitness_partial(const float* d2_all, size_t ns_cap, int pair_base, const int32_t* ns, double* partials_all) {
+  const float* d2 = d2_all + (size_t)(pair_base + blockIdx.y) * ns_cap;
+  const int n = ns[blockIdx.y];
+  double* partials = partials_all + (size_t)blockIdx.y * 128;
   double s = 0, c = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float v = d2[i];

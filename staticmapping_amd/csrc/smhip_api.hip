@@ -1381,10 +1381,7 @@ NdtHost& ndt_of(smhip_context* h) {
 
 extern "C" void smhip_internal_free_ndt(smhip_context* h) {
   if (!h || !h->ndt) return;
-  NdtHost& n = h->ndt->n;
-  if (n.out_pinned) (void)hipHostFree(n.out_pinned);
-  if (n.info_pinned) (void)hipHostFree(n.info_pinned);
-  if (n.fit_pinned) (void)hipHostFree(n.fit_pinned);
+  ndt_release(h->ndt->n);
   delete h->ndt;
   h->ndt = nullptr;
 }

@@ -588,7 +588,7 @@ smhip_status smhip_ndt_gicp_align(smhip_handle h, const double guess[16], double
     smhip_context* h; decltype(smhip_context::target_cache) keep;
     ~WithinAlign() { h->target_cache = keep; }
   } within{h, h->target_cache};
-  if (!within.keep) { g.staged_raw_gen = 0; g.cov_gen = 0; ndt_of(h).grid_valid = false; h->target_cache = 1; }
+  if (!within.keep) { g.staged_raw_gen = 0; g.cov_gen = 0; for (auto& m : ndt_of(h).meta) m.valid = false; h->target_cache = 1; }
   s = ndt_gicp_stage_clouds(h);
   if (s) return s;
   st.n_source = h->ns[0]; st.n_target = h->nt[0];

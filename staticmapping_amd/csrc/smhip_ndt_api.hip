@@ -2,8 +2,11 @@
 //
 // Ndt::Align (/root/reference/registrators/ndt.cc:38-64) = convert clouds, setInputTarget (voxel grid
 // build, every call), pclomp NDT align, getFitnessScore.  The 6-vector Newton / More-Thuente driver
-// (pclomp/ndt_omp_impl.hpp:81-171, 757-916) runs here on the host exactly as in the reference; each
-// computeDerivatives call is one ndt_derivatives + ndt_reduce launch and a 44-double read-back.
+// (pclomp/ndt_omp_impl.hpp:81-171, 757-916) runs here on the host exactly as in the reference, as a
+// state machine per pair: K Aligns (smhip_ndt_align_batch; smhip_ndt_align is the batch of one) advance in
+// lock-step, and every round's computeDerivatives calls -- one per pair still running, each at the pose ITS
+// line search asks for -- are ONE ndt_derivatives + ndt_reduce launch (grid.y = pair) and one read-back.  Every
+// pair's evaluation sequence is exactly the one the reference walks; only the launches are shared.
 //
 // Provenance note: computeStepLengthMT / trialValueSelectionMT / updateIntervalMT below are a PORT, not a redesign -- ~80
 // lines of scalar host control flow that follow pclomp/ndt_omp_impl.hpp:633-916 branch for branch (same variable roles:
@@ -15,19 +18,38 @@
 
 namespace {
 
+struct NdtSlotMeta {                  // what the voxel table resident in a slot was built from
+  bool valid = false;
+  unsigned long long gen = 0;         // tgt_gen[slot]
+  float resolution = 0.f; int min_points = 0; float eig_mult = 0.f;
+};
+
 struct NdtHost {
-  NdtDev dev{};
-  bool allocated = false;
-  bool grid_valid = false;
-  unsigned long long grid_gen = 0;    // tgt_gen[0] the voxel grid was built from
-  float grid_resolution = 0.f; int grid_min_points = 0; float grid_eig_mult = 0.f;   // ... and the options it depends on
-  smhip_ndt_options opts{};
-  double* out_pinned = nullptr;       // kNdtDerivCols doubles
-  NdtGridInfo* info_pinned = nullptr;
-  double* fit_dev = nullptr;          // 2 * 64 doubles
+  int cap = 0;                        // pair slots [0, cap) have table storage
+  NdtDev* devs_dev = nullptr;         // [cap] device array the kernels index
+  NdtDev* devs_host = nullptr;        // [cap] page-locked mirror
+  NdtGridInfo* info_all = nullptr;    // per-slot storage, contiguous: [cap] ...
+  uint32_t* bits_all = nullptr;       // [cap][kNdtMaxWords]
+  uint2* words_all = nullptr;
+  uint32_t* vstart_all = nullptr;     // [cap][nt_cap + 1]
+  float4* vpts_all = nullptr;         // [cap][nt_cap]
+  NdtVoxel* vox_all = nullptr;
+  double* icovd_all = nullptr;        // [cap][nt_cap][6]
+  double* partials_all = nullptr;     // [cap][kNdtMaxDerivBlocks][kNdtDerivCols]
+  double* out_all = nullptr;          // [cap][kNdtDerivCols]
+  NdtPose* poses_dev = nullptr; NdtPose* poses_host = nullptr;        // [cap] this round's evaluations
+  int32_t* active_dev = nullptr; int32_t* active_host = nullptr;      // [cap] the table each evaluation runs against
+  int32_t* ns_dev = nullptr;                                           // [cap] source sizes (fitness pass)
+  double* out_pinned = nullptr;       // [cap][kNdtDerivCols]
+  NdtGridInfo* info_pinned = nullptr; // [cap]
+  double* fit_dev = nullptr;          // [cap][128]
   double* fit_pinned = nullptr;
-  int32_t* vkey = nullptr;            // [nt] linear voxel index of every occupied voxel (tests)
-  int deriv_calls = 0;
+  int32_t* vkey = nullptr;            // [nt_cap] linear voxel index of every occupied voxel of slot 0 (tests)
+  PrepWorkspace* prep = nullptr;      // radix-sort workspace for cap * nt_cap (voxel code, point) pairs
+  std::vector<void*> dev_allocs, host_allocs;
+  std::vector<NdtSlotMeta> meta;
+  smhip_ndt_options opts{};
+  int deriv_calls = 0;                // of the last single Align (statistics)
   double last_pairs = 0;
   bool double_math = false;           // stock pcl::NormalDistributionsTransform arithmetic (NdtWithGicp)
 };
@@ -125,36 +147,52 @@ namespace {
 
 NdtHost& ndt_of(smhip_context* h);
 
-smhip_status ndt_ensure(smhip_context* h) {
+void ndt_release(NdtHost& n) {
+  for (void* p : n.dev_allocs) (void)hipFree(p);
+  for (void* p : n.host_allocs) (void)hipHostFree(p);
+  n.dev_allocs.clear(); n.host_allocs.clear();
+  if (n.prep) { prep_destroy(n.prep); n.prep = nullptr; }
+  n.cap = 0; n.meta.clear();
+}
+
+// table storage for pair slots [0, need): allocated on first use, re-allocated (all tables dropped) when a later batch needs more
+smhip_status ndt_ensure(smhip_context* h, int need = 1) {
   NdtHost& n = ndt_of(h);
-  if (n.allocated) return SMHIP_OK;
-  const size_t NT = h->dev.nt_cap;
-  NdtDev& d = n.dev;
-  smhip_status s = SMHIP_OK;
-  auto A = [&](smhip_status r) { if (s == SMHIP_OK) s = r; };
-  A(dev_alloc(h, &d.info, 1));
-  A(dev_alloc(h, &d.bits, (size_t)kNdtMaxWords));
-  A(dev_alloc(h, &d.words, (size_t)kNdtMaxWords));
-  A(dev_alloc(h, &d.vstart, NT + 1));
-  A(dev_alloc(h, &d.vpts, NT));
-  A(dev_alloc(h, &d.vox, NT));
-  A(dev_alloc(h, &d.icovd, NT * 6));
-  A(dev_alloc(h, &d.partials, (size_t)kNdtMaxDerivBlocks * kNdtDerivCols));
-  A(dev_alloc(h, &d.out, (size_t)kNdtDerivCols));
-  A(dev_alloc(h, &n.fit_dev, 128));
-  A(dev_alloc(h, &n.vkey, NT));
-  if (s) return s;
-  if (hipHostMalloc(reinterpret_cast<void**>(&n.out_pinned), sizeof(double) * kNdtDerivCols) != hipSuccess ||
-      hipHostMalloc(reinterpret_cast<void**>(&n.info_pinned), sizeof(NdtGridInfo)) != hipSuccess ||
-      hipHostMalloc(reinterpret_cast<void**>(&n.fit_pinned), sizeof(double) * 128) != hipSuccess) {
-    h->err = "hipHostMalloc failed (NDT)";
-    return SMHIP_ERR_HIP;
+  if (need <= n.cap) return SMHIP_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  ndt_release(n);
+  const size_t K = (size_t)need, NT = h->dev.nt_cap;
+  bool ok = true;
+  auto D = [&](auto** p, size_t count) {
+    void* v = nullptr;
+    if (ok && hipMalloc(&v, count * sizeof(**p)) == hipSuccess) { n.dev_allocs.push_back(v); *p = reinterpret_cast<decltype(*p)>(v); } else ok = false;
+  };
+  auto P = [&](auto** p, size_t count) {
+    void* v = nullptr;
+    if (ok && hipHostMalloc(&v, count * sizeof(**p)) == hipSuccess) { n.host_allocs.push_back(v); *p = reinterpret_cast<decltype(*p)>(v); } else ok = false;
+  };
+  D(&n.devs_dev, K); D(&n.info_all, K); D(&n.bits_all, K * kNdtMaxWords); D(&n.words_all, K * kNdtMaxWords);
+  D(&n.vstart_all, K * (NT + 1)); D(&n.vpts_all, K * NT); D(&n.vox_all, K * NT); D(&n.icovd_all, K * NT * 6);
+  D(&n.partials_all, K * (size_t)kNdtMaxDerivBlocks * kNdtDerivCols); D(&n.out_all, K * kNdtDerivCols);
+  D(&n.poses_dev, K); D(&n.active_dev, K); D(&n.ns_dev, K); D(&n.fit_dev, K * 128); D(&n.vkey, NT);
+  P(&n.devs_host, K); P(&n.poses_host, K); P(&n.active_host, K); P(&n.out_pinned, K * kNdtDerivCols); P(&n.info_pinned, K); P(&n.fit_pinned, K * 128);
+  if (ok && K * NT <= (size_t)0x7fffffff) { n.prep = prep_create((int)(K * NT)); ok = n.prep != nullptr; } else ok = false;
+  if (!ok) { ndt_release(n); h->err = "NDT table allocation failed"; return SMHIP_ERR_HIP; }
+  n.cap = need;
+  n.meta.assign(K, NdtSlotMeta{});
+  for (size_t k = 0; k < K; ++k) {
+    NdtDev& d = n.devs_host[k];
+    d = NdtDev{};
+    d.info = n.info_all + k; d.bits = n.bits_all + k * kNdtMaxWords; d.words = n.words_all + k * kNdtMaxWords;
+    d.vstart = n.vstart_all + k * (NT + 1); d.vpts = n.vpts_all + k * NT; d.vox = n.vox_all + k * NT; d.icovd = n.icovd_all + k * NT * 6;
+    d.partials = n.partials_all + k * (size_t)kNdtMaxDerivBlocks * kNdtDerivCols; d.out = n.out_all + k * kNdtDerivCols;
+    d.tgt = h->dev.tgt_p + k * NT; d.src = h->dev.src + k * (size_t)h->dev.ns_cap; d.tpart = h->dev.tpart + k * kTgtReduceBlocks * 16;
   }
-  n.allocated = true;
   return SMHIP_OK;
 }
 
-__global__ void ndt_voxel_keys(NdtDev d, int32_t* keys) {
+__global__ void ndt_voxel_keys(const NdtDev* devs, int32_t* keys) {
+  const NdtDev d = devs[0];
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= d.info->nocc) return;
   const float4 p = d.vpts[d.vstart[v]];
@@ -163,49 +201,68 @@ __global__ void ndt_voxel_keys(NdtDev d, int32_t* keys) {
   keys[v] = i0 + i1 * d.info->div_b[0] + i2 * d.info->div_b[0] * d.info->div_b[1];   // :223
 }
 
-// VoxelGridCovariance::filter(true) on the slot-0 target (ndt_omp.h:117-122 -> init())
-smhip_status ndt_build_grid(smhip_context* h) {
+bool ndt_table_current(const smhip_context* h, const NdtHost& n, int slot) {
+  const NdtSlotMeta& m = n.meta[slot];
+  return h->target_cache && m.valid && m.gen == h->tgt_gen[slot] && m.resolution == n.opts.resolution &&
+         m.min_points == n.opts.min_points_per_voxel && m.eig_mult == n.opts.min_covar_eigvalue_mult;
+}
+
+// per-slot sizes / options into the device array the kernels index (one small copy per Align)
+smhip_status ndt_push_devs(smhip_context* h, int first, int K) {
   NdtHost& n = ndt_of(h);
-  NdtDev& d = n.dev;
-  d.nt = h->nt[0]; d.ns = h->ns[0];
-  d.tgt = h->dev.tgt_p; d.src = h->dev.src; d.tpart = h->dev.tpart;
-  d.min_points = n.opts.min_points_per_voxel;
-  d.eig_mult = n.opts.min_covar_eigvalue_mult;
-  // tgt_reduce reads nt from the pair input block
-  h->in_pinned[0].nt = h->nt[0]; h->in_pinned[0].ns = h->ns[0];
-  HIPCHK(h, hipMemcpyAsync(const_cast<PairInput*>(h->dev.in), h->in_pinned, sizeof(PairInput), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemsetAsync(d.bits, 0, sizeof(uint32_t) * (size_t)kNdtMaxWords, h->stream));
-  const int gb = ceil_div(d.nt, 256);
-  hipLaunchKernelGGL(tgt_reduce, dim3(kTgtReduceBlocks, 1), dim3(256), 0, h->stream, h->dev);
-  hipLaunchKernelGGL(ndt_voxel_setup, dim3(1), dim3(64), 0, h->stream, d, n.opts.resolution);
-  // (voxel code, point) pairs sorted with the rocPRIM radix sort of the preparation workspace; the voxel's slot is the
-  // rank of its bit, which is also its position among the sorted unique codes, so the sorted points ARE vpts
-  {
-    smhip_status ps = prep_ensure(h);
-    if (ps) return ps;
-    hipLaunchKernelGGL(ndt_voxel_keys64, dim3(gb), dim3(256), 0, h->stream, d, prep_keys(h->prep, 0), prep_values(h->prep, 0));
-    const hipError_t e = prep_sort_pairs(h->prep, h->stream, d.nt, 33);
-    if (e != hipSuccess) { h->err = std::string("NDT voxel sort: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
-    hipLaunchKernelGGL(ndt_voxel_heads, dim3(gb), dim3(256), 0, h->stream, d, prep_keys(h->prep, 1));
-    hipLaunchKernelGGL(ndt_voxel_rank, dim3(1), dim3(1024), 0, h->stream, d);
-    hipLaunchKernelGGL(ndt_voxel_starts, dim3(gb), dim3(256), 0, h->stream, d, prep_keys(h->prep, 1), prep_values(h->prep, 1));
+  int off = 0;
+  for (int k = first; k < first + K; ++k) {
+    NdtDev& d = n.devs_host[k];
+    d.nt = h->nt[k]; d.ns = h->ns[k];
+    d.min_points = n.opts.min_points_per_voxel; d.eig_mult = n.opts.min_covar_eigvalue_mult;
+    d.key_off = off; off += d.nt;
   }
-  // one wave per occupied voxel; nocc <= nt
-  hipLaunchKernelGGL(ndt_voxel_stats, dim3(ceil_div(d.nt, 4)), dim3(256), 0, h->stream, d);
-  HIPCHK(h, hipMemcpyAsync(n.info_pinned, d.info, sizeof(NdtGridInfo), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipGetLastError());
-  if (n.info_pinned->status) { h->err = "NDT voxel box exceeds the bit grid (leaf size too small for the target extent)"; return SMHIP_ERR_CAPACITY; }
-  n.grid_valid = true;
-  n.grid_gen = h->tgt_gen[0];
-  n.grid_resolution = n.opts.resolution; n.grid_min_points = n.opts.min_points_per_voxel; n.grid_eig_mult = n.opts.min_covar_eigvalue_mult;
+  HIPCHK(h, hipMemcpyAsync(n.devs_dev + first, n.devs_host + first, sizeof(NdtDev) * K, hipMemcpyHostToDevice, h->stream));
   return SMHIP_OK;
 }
 
-// computeDerivatives (ndt_omp_impl.hpp:180-284): score, 6-gradient, 6x6 hessian
-smhip_status ndt_derivs(smhip_context* h, const double* p, const float* T, bool hess, double* score, double* g, double* H) {
+// VoxelGridCovariance::filter(true) on the targets of slots [first, first + K) (ndt_omp.h:117-122 -> init()): every kernel once
+// for the whole batch (grid.y = table), ONE radix sort of all the (table, voxel code, point) keys
+smhip_status ndt_build_grids(smhip_context* h, int first, int K) {
   NdtHost& n = ndt_of(h);
-  NdtPose P{};
+  smhip_status s = ndt_push_devs(h, first, K);
+  if (s) return s;
+  int nt_max = 0, nt_sum = 0;
+  for (int k = first; k < first + K; ++k) { nt_max = std::max(nt_max, h->nt[k]); nt_sum += h->nt[k]; n.meta[k].valid = false; }
+  // tgt_reduce reads nt from the pair input block
+  for (int k = first; k < first + K; ++k) { h->in_pinned[k].nt = h->nt[k]; h->in_pinned[k].ns = h->ns[k]; }
+  HIPCHK(h, hipMemcpyAsync(const_cast<PairInput*>(h->dev.in) + first, h->in_pinned + first, sizeof(PairInput) * K, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemsetAsync(n.bits_all + (size_t)first * kNdtMaxWords, 0, sizeof(uint32_t) * (size_t)kNdtMaxWords * K, h->stream));
+  IcpDev rd = h->dev; rd.npairs = K; rd.pair_base = first;
+  const NdtDev* devs = n.devs_dev + first;
+  const int gb = ceil_div(nt_max, 256);
+  hipLaunchKernelGGL(tgt_reduce, dim3(kTgtReduceBlocks, K), dim3(256), 0, h->stream, rd);
+  hipLaunchKernelGGL(ndt_voxel_setup, dim3(K), dim3(64), 0, h->stream, devs, n.opts.resolution);
+  // (voxel code, point) pairs sorted with the rocPRIM radix sort of the workspace; the voxel's slot is the rank of its bit,
+  // which is also its position among the sorted unique codes, so the sorted points ARE vpts
+  hipLaunchKernelGGL(ndt_voxel_keys64, dim3(gb, K), dim3(256), 0, h->stream, devs, prep_keys(n.prep, 0), prep_values(n.prep, 0));
+  int kbits = 0;
+  while ((1 << kbits) < K) ++kbits;
+  const hipError_t e = prep_sort_pairs(n.prep, h->stream, nt_sum, 33 + kbits);
+  if (e != hipSuccess) { h->err = std::string("NDT voxel sort: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
+  hipLaunchKernelGGL(ndt_voxel_heads, dim3(gb, K), dim3(256), 0, h->stream, devs, prep_keys(n.prep, 1));
+  hipLaunchKernelGGL(ndt_voxel_rank, dim3(K), dim3(1024), 0, h->stream, devs);
+  hipLaunchKernelGGL(ndt_voxel_starts, dim3(gb, K), dim3(256), 0, h->stream, devs, prep_keys(n.prep, 1), prep_values(n.prep, 1));
+  // one wave per occupied voxel; nocc <= nt
+  hipLaunchKernelGGL(ndt_voxel_stats, dim3(std::min(ceil_div(nt_max, 4), std::max(64, 8192 / K)), K), dim3(256), 0, h->stream, devs);
+  HIPCHK(h, hipMemcpyAsync(n.info_pinned + first, n.info_all + first, sizeof(NdtGridInfo) * K, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipGetLastError());
+  for (int k = first; k < first + K; ++k) {
+    if (n.info_pinned[k].status) { h->err = "NDT voxel box exceeds the bit grid (leaf size too small for the target extent)"; return SMHIP_ERR_CAPACITY; }
+    NdtSlotMeta& m = n.meta[k];
+    m.valid = true; m.gen = h->tgt_gen[k];
+    m.resolution = n.opts.resolution; m.min_points = n.opts.min_points_per_voxel; m.eig_mult = n.opts.min_covar_eigvalue_mult;
+  }
+  return SMHIP_OK;
+}
+
+void ndt_fill_pose(const NdtHost& n, const double* p, const float* T, bool hess, NdtPose& P) {
   for (int i = 0; i < 12; ++i) P.T[i] = T[i];
   angle_derivatives(p, P);
   const double c1 = 10.0 * (1 - (double)n.opts.outlier_ratio);                     // :86-93
@@ -216,24 +273,38 @@ smhip_status ndt_derivs(smhip_context* h, const double* p, const float* T, bool 
   P.d1d = d1; P.d2d = d2; P.d1 = (float)d1; P.d2 = (float)d2;
   P.res2 = n.opts.resolution * n.opts.resolution;
   P.compute_hessian = hess ? 1 : 0;
-  const int blocks = std::min(kNdtMaxDerivBlocks, std::max(1, ceil_div(n.dev.ns, kNdtDerivThreads)));
-  const bool one = (long long)blocks * kNdtDerivThreads >= n.dev.ns;     // a thread per source point
+}
+
+// computeDerivatives (ndt_omp_impl.hpp:180-284) for `count` evaluations at once: evaluation e = poses_host[e] against the table of
+// slot active_host[e]; results in out_pinned[e][0..43] (score, 6-gradient, 6x6 hessian, pair count)
+smhip_status ndt_eval_round(smhip_context* h, int count, int ns_max) {
+  NdtHost& n = ndt_of(h);
+  HIPCHK(h, hipMemcpyAsync(n.poses_dev, n.poses_host, sizeof(NdtPose) * count, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(n.active_dev, n.active_host, sizeof(int32_t) * count, hipMemcpyHostToDevice, h->stream));
+  // (workgroups per evaluation from the LARGEST source: a smaller cloud's surplus workgroups add zero rows, and the fold of the
+  // rows is grouped by workgroup index, so a pair's sums are the bits its single call gives -- up to 524 288 source points)
+  const int blocks = std::min(kNdtMaxDerivBlocks, std::max(1, ceil_div(ns_max, kNdtDerivThreads)));
+  const bool one = (long long)blocks * kNdtDerivThreads >= ns_max;      // a thread per source point
+  const dim3 g(blocks, count);
   if (n.double_math) {
-    if (one) hipLaunchKernelGGL((ndt_derivatives<double, true>), dim3(blocks), dim3(kNdtDerivThreads), 0, h->stream, n.dev, P);
-    else hipLaunchKernelGGL((ndt_derivatives<double, false>), dim3(blocks), dim3(kNdtDerivThreads), 0, h->stream, n.dev, P);
+    if (one) hipLaunchKernelGGL((ndt_derivatives<double, true>), g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, n.poses_dev, n.active_dev);
+    else hipLaunchKernelGGL((ndt_derivatives<double, false>), g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, n.poses_dev, n.active_dev);
   } else {
-    if (one) hipLaunchKernelGGL((ndt_derivatives<float, true>), dim3(blocks), dim3(kNdtDerivThreads), 0, h->stream, n.dev, P);
-    else hipLaunchKernelGGL((ndt_derivatives<float, false>), dim3(blocks), dim3(kNdtDerivThreads), 0, h->stream, n.dev, P);
+    if (one) hipLaunchKernelGGL((ndt_derivatives<float, true>), g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, n.poses_dev, n.active_dev);
+    else hipLaunchKernelGGL((ndt_derivatives<float, false>), g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, n.poses_dev, n.active_dev);
   }
-  hipLaunchKernelGGL(ndt_reduce, dim3(1), dim3(16 * 64), 0, h->stream, n.dev, blocks);
-  HIPCHK(h, hipMemcpyAsync(n.out_pinned, n.dev.out, sizeof(double) * kNdtDerivCols, hipMemcpyDeviceToHost, h->stream));
+  hipLaunchKernelGGL(ndt_reduce, dim3(count), dim3(16 * 64), 0, h->stream, n.devs_dev, n.active_dev, blocks);
+  // the evaluations' tables need not be consecutive slots: gather their 44 doubles with one strided copy when they are, else one each
+  bool consecutive = true;
+  for (int e = 1; e < count; ++e) consecutive = consecutive && n.active_host[e] == n.active_host[0] + e;
+  if (consecutive) {
+    HIPCHK(h, hipMemcpyAsync(n.out_pinned, n.out_all + (size_t)n.active_host[0] * kNdtDerivCols, sizeof(double) * kNdtDerivCols * count, hipMemcpyDeviceToHost, h->stream));
+  } else {
+    for (int e = 0; e < count; ++e)
+      HIPCHK(h, hipMemcpyAsync(n.out_pinned + (size_t)e * kNdtDerivCols, n.out_all + (size_t)n.active_host[e] * kNdtDerivCols, sizeof(double) * kNdtDerivCols, hipMemcpyDeviceToHost, h->stream));
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipGetLastError());
-  *score = n.out_pinned[0];
-  for (int i = 0; i < 6; ++i) g[i] = n.out_pinned[1 + i];
-  if (hess) for (int i = 0; i < 36; ++i) H[i] = n.out_pinned[7 + i];
-  n.last_pairs = n.out_pinned[43];
-  n.deriv_calls++;
   return SMHIP_OK;
 }
 
@@ -273,15 +344,172 @@ double trial_value_mt(double a_l, double f_l, double g_l, double a_u, double f_u
   return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
 }
 
-// pcl::Registration::getFitnessScore(): mean squared 1-NN distance of slot 0's source, moved by `T`
-// (column-major 4x4), to slot 0's raw target (ndt.cc:60, ndt_gicp.cc:88,101).
-smhip_status fitness_score(smhip_context* h, const double* T, double* out) {
+
+// ---- one Align as a state machine: it asks for one computeDerivatives evaluation at a time -----------------------------
+// The control flow of NormalDistributionsTransform::computeTransformation (:81-171) and computeStepLengthMT (:757-916), cut at
+// the evaluations: INIT (:119) -> per Newton iteration TRIAL (:809-813) -> MT (the line-search loop's evaluations, :870-878)
+// -> HESS (:912-913 computeHessian, only after a line search that looped) -> next iteration.
+struct NdtJob {
+  enum Phase { kInit, kTrial, kMt, kHess, kDone };
+  Phase phase = kInit;
+  int slot = 0;
+  double p[6], x_t[6], dir[6];
+  float Tf[16];                    // the pose matrix of the last evaluation asked for = final_transformation_ at the end
+  double sc = 0, g[6], H[36];
+  int it = 0, deriv_calls = 0;
+  double last_pairs = 0;
+  // computeStepLengthMT's locals
+  double phi_0 = 0, d_phi_0 = 0, a_t = 0, a_l = 0, a_u = 0, f_l = 0, g_l = 0, f_u = 0, g_u = 0;
+  double phi_t = 0, d_phi_t = 0, psi_t = 0, d_psi_t = 0, step_max = 0, step_min = 0;
+  bool interval_converged = false, open_interval = true;
+  int step_iterations = 0;
+  // the evaluation wanted next
+  double eval_p[6];
+  bool eval_hess = true;
+};
+
+constexpr double kMtMu = 1.e-4, kMtNu = 0.9;
+
+void ndt_job_request(NdtJob& j, const double* x, bool hess, NdtJob::Phase ph) {
+  for (int i = 0; i < 6; ++i) j.eval_p[i] = x[i];
+  j.eval_hess = hess;
+  j.phase = ph;
+}
+
+void ndt_job_newton(NdtJob& j, const smhip_ndt_options& o);
+
+void ndt_job_finish_iteration(NdtJob& j, const smhip_ndt_options& o) {
+  const double dp_norm = j.a_t;                                                    // :142
+  for (int i = 0; i < 6; ++i) j.p[i] += j.dir[i] * dp_norm;                        // :143, :152
+  const bool converged = j.it > o.max_iterations || (j.it && std::fabs(dp_norm) < o.transformation_epsilon);   // :158-162
+  j.it++;                                                                          // :164
+  if (converged) { j.phase = NdtJob::kDone; return; }
+  ndt_job_newton(j, o);
+}
+
+// the line-search loop's head (:867): another trial value, the closing Hessian, or the end of the iteration
+void ndt_job_mt_continue(NdtJob& j, const smhip_ndt_options& o) {
+  if (!j.interval_converged && j.step_iterations < 10 && !(j.psi_t <= 0 && j.d_phi_t <= -kMtNu * j.d_phi_0)) {
+    j.a_t = j.open_interval ? trial_value_mt(j.a_l, j.f_l, j.g_l, j.a_u, j.f_u, j.g_u, j.a_t, j.psi_t, j.d_psi_t)
+                            : trial_value_mt(j.a_l, j.f_l, j.g_l, j.a_u, j.f_u, j.g_u, j.a_t, j.phi_t, j.d_phi_t);
+    j.a_t = std::max(std::min(j.a_t, j.step_max), j.step_min);
+    for (int i = 0; i < 6; ++i) j.x_t[i] = j.p[i] + j.dir[i] * j.a_t;
+    pose_to_matrix_f32(j.x_t, j.Tf);
+    ndt_job_request(j, j.x_t, false, NdtJob::kMt);
+    return;
+  }
+  if (j.step_iterations) { ndt_job_request(j, j.x_t, true, NdtJob::kHess); return; }       // :912-913
+  ndt_job_finish_iteration(j, o);
+}
+
+// one Newton iteration up to its first evaluation (:121-141, :757-813)
+void ndt_job_newton(NdtJob& j, const smhip_ndt_options& o) {
+  for (;;) {
+    double mg[6], dp[6];
+    for (int i = 0; i < 6; ++i) mg[i] = -j.g[i];
+    svd_solve6(j.H, mg, dp);                                                       // :127-129
+    double dp_norm = 0;
+    for (int i = 0; i < 6; ++i) dp_norm += dp[i] * dp[i];
+    dp_norm = std::sqrt(dp_norm);
+    if (dp_norm == 0 || dp_norm != dp_norm) { j.phase = NdtJob::kDone; return; }   // :134-139
+    for (int i = 0; i < 6; ++i) j.dir[i] = dp[i] / dp_norm;                        // :141
+    // ---- computeStepLengthMT(p, dir, dp_norm, step_size, trans_eps / 2, ...) :757-916
+    const double step_init = dp_norm;
+    j.step_max = o.step_size; j.step_min = o.transformation_epsilon / 2;
+    j.phi_0 = -j.sc;
+    j.d_phi_0 = 0;
+    for (int i = 0; i < 6; ++i) j.d_phi_0 -= j.g[i] * j.dir[i];
+    j.a_t = 0;
+    bool skip = false;
+    if (j.d_phi_0 >= 0) {
+      if (j.d_phi_0 == 0) skip = true;
+      else { j.d_phi_0 *= -1; for (int i = 0; i < 6; ++i) j.dir[i] = -j.dir[i]; }
+    }
+    if (!skip) {
+      j.a_l = 0; j.a_u = 0;
+      j.f_l = psi_mt(j.a_l, j.phi_0, j.phi_0, j.d_phi_0, kMtMu); j.g_l = dpsi_mt(j.d_phi_0, j.d_phi_0, kMtMu);
+      j.f_u = j.f_l; j.g_u = j.g_l;
+      j.interval_converged = (j.step_max - j.step_min) > 0;                        // :795 (sic: the loop never runs with the wrapper's settings)
+      j.open_interval = true;
+      j.step_iterations = 0;
+      j.a_t = std::max(std::min(step_init, j.step_max), j.step_min);
+      for (int i = 0; i < 6; ++i) j.x_t[i] = j.p[i] + j.dir[i] * j.a_t;
+      pose_to_matrix_f32(j.x_t, j.Tf);                                             // :803-806
+      ndt_job_request(j, j.x_t, true, NdtJob::kTrial);                             // :809-813
+      return;
+    }
+    // d_phi_0 == 0: no step; the iteration ends where it began
+    const bool converged = j.it > o.max_iterations || (j.it && std::fabs(j.a_t) < o.transformation_epsilon);
+    j.it++;
+    if (converged) { j.phase = NdtJob::kDone; return; }
+  }
+}
+
+void ndt_job_start(NdtJob& j, int slot, const double* guess_cm) {
+  j = NdtJob{};
+  j.slot = slot;
+  // guess.cast<float>() (ndt.cc:58); final_transformation_ = guess (:98)
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) j.Tf[4 * r + c] = (float)guess_cm[4 * c + r];
+  float e[3];
+  euler_xyz_f32(j.Tf, e);
+  j.p[0] = j.Tf[3]; j.p[1] = j.Tf[7]; j.p[2] = j.Tf[11]; j.p[3] = e[0]; j.p[4] = e[1]; j.p[5] = e[2];   // :107-111
+  ndt_job_request(j, j.p, true, NdtJob::kInit);                                    // :119
+}
+
+// the evaluation the job asked for has come back: out = score, gradient, hessian, pair count
+void ndt_job_result(NdtJob& j, const double* out, const smhip_ndt_options& o) {
+  j.deriv_calls++;
+  j.last_pairs = out[43];
+  switch (j.phase) {
+    case NdtJob::kInit:
+      j.sc = out[0];
+      for (int i = 0; i < 6; ++i) j.g[i] = out[1 + i];
+      for (int i = 0; i < 36; ++i) j.H[i] = out[7 + i];
+      ndt_job_newton(j, o);
+      break;
+    case NdtJob::kTrial:
+      j.sc = out[0];
+      for (int i = 0; i < 6; ++i) j.g[i] = out[1 + i];
+      for (int i = 0; i < 36; ++i) j.H[i] = out[7 + i];
+      j.phi_t = -j.sc; j.d_phi_t = 0;
+      for (int i = 0; i < 6; ++i) j.d_phi_t -= j.g[i] * j.dir[i];
+      j.psi_t = psi_mt(j.a_t, j.phi_t, j.phi_0, j.d_phi_0, kMtMu); j.d_psi_t = dpsi_mt(j.d_phi_t, j.d_phi_0, kMtMu);
+      ndt_job_mt_continue(j, o);
+      break;
+    case NdtJob::kMt:
+      j.sc = out[0];
+      for (int i = 0; i < 6; ++i) j.g[i] = out[1 + i];                             // (no Hessian in the loop, :872)
+      j.phi_t = -j.sc; j.d_phi_t = 0;
+      for (int i = 0; i < 6; ++i) j.d_phi_t -= j.g[i] * j.dir[i];
+      j.psi_t = psi_mt(j.a_t, j.phi_t, j.phi_0, j.d_phi_0, kMtMu); j.d_psi_t = dpsi_mt(j.d_phi_t, j.d_phi_0, kMtMu);
+      if (j.open_interval && (j.psi_t <= 0 && j.d_psi_t >= 0)) {
+        j.open_interval = false;
+        j.f_l = j.f_l + j.phi_0 - kMtMu * j.d_phi_0 * j.a_l; j.g_l = j.g_l + kMtMu * j.d_phi_0;
+        j.f_u = j.f_u + j.phi_0 - kMtMu * j.d_phi_0 * j.a_u; j.g_u = j.g_u + kMtMu * j.d_phi_0;
+      }
+      j.interval_converged = j.open_interval ? update_interval_mt(j.a_l, j.f_l, j.g_l, j.a_u, j.f_u, j.g_u, j.a_t, j.psi_t, j.d_psi_t)
+                                             : update_interval_mt(j.a_l, j.f_l, j.g_l, j.a_u, j.f_u, j.g_u, j.a_t, j.phi_t, j.d_phi_t);
+      j.step_iterations++;
+      ndt_job_mt_continue(j, o);
+      break;
+    case NdtJob::kHess:
+      for (int i = 0; i < 36; ++i) j.H[i] = out[7 + i];                            // the Hessian alone: score and gradient stay the loop's last
+      ndt_job_finish_iteration(j, o);
+      break;
+    case NdtJob::kDone:
+      break;
+  }
+}
+
+// pcl::Registration::getFitnessScore(): mean squared 1-NN distance of each slot's source, moved by its T (column-major 4x4), to
+// the slot's raw target (ndt.cc:60, ndt_gicp.cc:88,101), for slots [first, first + K) in one pass
+smhip_status fitness_scores(smhip_context* h, int first, int K, const double* T, double* out) {
   NdtHost& n = ndt_of(h);
   int ns_max = 0, nt_max = 0;
-  const int had = h->has_normals[0];
-  h->has_normals[0] = 1;
-  smhip_status s = fill_inputs(h, 1, T, &ns_max, &nt_max);
-  h->has_normals[0] = had;
+  std::vector<int> had(K);
+  for (int k = 0; k < K; ++k) { had[k] = h->has_normals[first + k]; h->has_normals[first + k] = 1; }
+  smhip_status s = fill_inputs(h, K, T, &ns_max, &nt_max, first);
+  for (int k = 0; k < K; ++k) h->has_normals[first + k] = had[k];
   if (s) return s;
   // distances only: no tie-order requirement (skip the per-cell sort) and no previous match to seed a
   // ball search -> plain exact ring search (r = 1 certifies almost every query against a dense submap)
@@ -289,18 +517,105 @@ smhip_status fitness_score(smhip_context* h, const double* T, double* out) {
   const int ring_was = h->dev.max_ring;
   h->dev.sort_cells = 0; h->dev.use_ball = 0;
   h->dev.max_ring = std::max(ring_was, 32);      // wide rings are cheap with the row-occupancy bitmap; fewer queries reach the brute-force sweep
-  s = enqueue_prepare(h, 1, nt_max);
-  if (s == SMHIP_OK) s = enqueue_find_closests(h, 1, ns_max);
+  if (K == 1) {
+    s = enqueue_prepare_one(h, first, nt_max);
+    if (s == SMHIP_OK) s = enqueue_find_closests_half(h, whole_batch(h, 1, first), ns_max, 0);
+  } else {
+    // the search structure over the raw targets: kept like the voxel tables while every slot's target is unchanged
+    bool cached = true;
+    for (int k = first; k < first + K; ++k) cached = cached && grid_cached(h, k);
+    const Half f = whole_batch(h, K, first);
+    if (cached) {
+      HIPCHK(h, hipMemcpyAsync(const_cast<PairInput*>(f.d.in) + first, h->in_pinned + first, sizeof(PairInput) * K, hipMemcpyHostToDevice, h->stream));
+      s = ensure_packed(h, first, K);
+      hipLaunchKernelGGL(reset_scratch_light, dim3(std::min(1024, 8 * K)), dim3(256), 0, h->stream, f.d, first, K);
+      hipLaunchKernelGGL(pose_setup, dim3(ceil_div(K, 64)), dim3(64), 0, h->stream, f.d, K);
+      h->cache_hits++;
+    } else {
+      s = enqueue_resets(h, K, first);
+      if (s == SMHIP_OK) s = enqueue_grid_build(h, f, nt_max);
+    }
+    if (s == SMHIP_OK) s = enqueue_find_closests_half(h, f, ns_max, 0);
+  }
   h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was; h->dev.max_ring = ring_was;
   if (s) return s;
-  hipLaunchKernelGGL(fitness_partial, dim3(64), dim3(256), 0, h->stream, h->dev.d2, h->ns[0], n.fit_dev);
-  HIPCHK(h, hipMemsetAsync(h->dev.hist, 0, sizeof(uint32_t) * kHistBins, h->stream));
-  HIPCHK(h, hipMemcpyAsync(n.fit_pinned, n.fit_dev, sizeof(double) * 128, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  double ssum = 0, cnt = 0;
-  for (int k = 0; k < 64; ++k) { ssum += n.fit_pinned[2 * k]; cnt += n.fit_pinned[2 * k + 1]; }
-  *out = cnt > 0 ? ssum / cnt : 1.7976931348623157e308;
+  std::vector<int32_t> nsv(K);
+  for (int k = 0; k < K; ++k) nsv[k] = h->ns[first + k];
+  HIPCHK(h, hipMemcpyAsync(n.ns_dev, nsv.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(fitness_partial, dim3(64, K), dim3(256), 0, h->stream, h->dev.d2, (size_t)h->dev.ns_cap, first, n.ns_dev, n.fit_dev);
+  HIPCHK(h, hipMemsetAsync(h->dev.hist + (size_t)first * kHistBins, 0, sizeof(uint32_t) * kHistBins * (size_t)K, h->stream));
+  HIPCHK(h, hipMemcpyAsync(n.fit_pinned, n.fit_dev, sizeof(double) * 128 * K, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));      // (nsv is read by the copy above: keep it alive until here)
+  for (int k = 0; k < K; ++k) {
+    double ssum = 0, cnt = 0;
+    for (int b = 0; b < 64; ++b) { ssum += n.fit_pinned[128 * k + 2 * b]; cnt += n.fit_pinned[128 * k + 2 * b + 1]; }
+    out[k] = cnt > 0 ? ssum / cnt : 1.7976931348623157e308;
+  }
   h->ev_used = 0;
+  return SMHIP_OK;
+}
+smhip_status fitness_score(smhip_context* h, const double* T, double* out) { return fitness_scores(h, 0, 1, T, out); }
+
+// K Aligns in lock-step on slots [first, first + K)
+smhip_status ndt_align_slots(smhip_context* h, int first, int K, const double* guesses, double* results, double* scores, smhip_ndt_stats* stats) {
+  for (int k = first; k < first + K; ++k)
+    if (h->ns[k] <= 0 || h->nt[k] <= 0) { h->err = "Ndt::Align before SetInputSource/SetInputTarget"; return SMHIP_ERR_NOT_READY; }   // ndt.cc:40-42
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  smhip_status s = ndt_ensure(h, first + K);
+  if (s) return s;
+  NdtHost& n = ndt_of(h);
+  // setInputTarget -> init() on every Align (ndt.cc:54).  The voxel table is a pure function of the target and the
+  // options, so it is kept while the slot's target is unchanged (smhip_set_target_cache(h, 0) = rebuild every time); a batch
+  // keeps its tables when every one of them is current, else rebuilds them all in one pass
+  bool current = true;
+  for (int k = first; k < first + K; ++k) current = current && ndt_table_current(h, n, k);
+  if (current) {
+    s = ndt_push_devs(h, first, K);
+    if (s) return s;
+    h->cache_hits++;
+  } else {
+    s = ndt_build_grids(h, first, K);
+    if (s) return s;
+  }
+  const smhip_ndt_options& o = n.opts;
+  int ns_max = 0;
+  for (int k = first; k < first + K; ++k) ns_max = std::max(ns_max, h->ns[k]);
+  std::vector<NdtJob> jobs(K);
+  for (int k = 0; k < K; ++k) ndt_job_start(jobs[k], first + k, guesses + 16 * k);
+  std::vector<int> who(K);
+  for (;;) {
+    int count = 0;
+    for (int k = 0; k < K; ++k) {
+      NdtJob& j = jobs[k];
+      if (j.phase == NdtJob::kDone) continue;
+      ndt_fill_pose(n, j.eval_p, j.Tf, j.eval_hess, n.poses_host[count]);
+      n.active_host[count] = j.slot;
+      who[count++] = k;
+    }
+    if (!count) break;
+    s = ndt_eval_round(h, count, ns_max);
+    if (s) return s;
+    for (int e = 0; e < count; ++e) ndt_job_result(jobs[who[e]], n.out_pinned + (size_t)e * kNdtDerivCols, o);
+  }
+  // getFinalTransformation().cast<double>(), column-major out (ndt.cc:61)
+  for (int k = 0; k < K; ++k)
+    for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) results[16 * k + 4 * c + r] = (double)jobs[k].Tf[4 * r + c];
+  std::vector<double> fit(K);
+  s = fitness_scores(h, first, K, results, fit.data());
+  if (s) return s;
+  for (int k = 0; k < K; ++k) {
+    if (scores) scores[k] = fit[k];
+    if (stats) {
+      stats[k].iterations = jobs[k].it;
+      stats[k].derivative_calls = jobs[k].deriv_calls;
+      stats[k].voxels = n.info_pinned[first + k].nocc;
+      stats[k].status = 0;
+      stats[k].trans_probability = jobs[k].sc / (double)h->ns[first + k];      // :170
+      stats[k].pairs_last = jobs[k].last_pairs;
+    }
+  }
+  n.deriv_calls = jobs[0].deriv_calls; n.last_pairs = jobs[0].last_pairs;
   return SMHIP_OK;
 }
 
@@ -326,125 +641,23 @@ smhip_status smhip_ndt_set_options(smhip_handle h, const smhip_ndt_options* o) {
     h->err = "bad NDT options";
     return SMHIP_ERR_INVALID_ARGUMENT;
   }
-  ndt_of(h).opts = *o;
-  ndt_of(h).grid_valid = false;
+  NdtHost& n = ndt_of(h);
+  n.opts = *o;
+  for (auto& m : n.meta) m.valid = false;
   return SMHIP_OK;
 }
 
 smhip_status smhip_ndt_align(smhip_handle h, const double guess[16], double result[16], double* score, smhip_ndt_stats* stats) {
   if (!h || !guess || !result) return SMHIP_ERR_INVALID_ARGUMENT;
-  if (h->ns[0] <= 0 || h->nt[0] <= 0) { h->err = "Ndt::Align before SetInputSource/SetInputTarget"; return SMHIP_ERR_NOT_READY; }   // ndt.cc:40-42
-  HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  smhip_status s = ndt_ensure(h);
-  if (s) return s;
-  NdtHost& n = ndt_of(h);
-  n.deriv_calls = 0;
-  // setInputTarget -> init() on every Align (ndt.cc:54).  The voxel table is a pure function of the target and the
-  // options, so it is kept while the slot's target is unchanged (smhip_set_target_cache(h, 0) = rebuild every time)
-  if (h->target_cache && n.grid_valid && n.grid_gen == h->tgt_gen[0] && n.grid_resolution == n.opts.resolution &&
-      n.grid_min_points == n.opts.min_points_per_voxel && n.grid_eig_mult == n.opts.min_covar_eigvalue_mult) {
-    n.dev.ns = h->ns[0]; n.dev.src = h->dev.src;
-    h->cache_hits++;
-  } else {
-    s = ndt_build_grid(h);
-    if (s) return s;
+  return ndt_align_slots(h, 0, 1, guess, result, score, stats);
+}
+
+smhip_status smhip_ndt_align_batch(smhip_handle h, int first_slot, int npairs, const double* guesses, double* results, double* scores, smhip_ndt_stats* stats) {
+  if (!h || !guesses || !results || npairs < 1 || first_slot < 0 || first_slot + npairs > h->dev.slots) {
+    if (h) h->err = "bad slot range / guesses";
+    return SMHIP_ERR_INVALID_ARGUMENT;
   }
-  const smhip_ndt_options& o = n.opts;
-  // guess.cast<float>() (ndt.cc:58); final_transformation_ = guess (:98)
-  float Tf[16];
-  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) Tf[4 * r + c] = (float)guess[4 * c + r];
-  double p[6];
-  { float e[3]; euler_xyz_f32(Tf, e); p[0] = Tf[3]; p[1] = Tf[7]; p[2] = Tf[11]; p[3] = e[0]; p[4] = e[1]; p[5] = e[2]; }   // :107-111
-  double sc = 0, g[6], H[36];
-  s = ndt_derivs(h, p, Tf, true, &sc, g, H);               // :119
-  if (s) return s;
-  int it = 0;
-  bool converged = false;
-  while (!converged) {                                     // :121
-    double mg[6], dp[6];
-    for (int i = 0; i < 6; ++i) mg[i] = -g[i];
-    svd_solve6(H, mg, dp);                                 // :127-129
-    double dp_norm = 0;
-    for (int i = 0; i < 6; ++i) dp_norm += dp[i] * dp[i];
-    dp_norm = std::sqrt(dp_norm);
-    if (dp_norm == 0 || dp_norm != dp_norm) break;         // :134-139
-    double dir[6];
-    for (int i = 0; i < 6; ++i) dir[i] = dp[i] / dp_norm;  // :141
-    // ---- computeStepLengthMT(p, dir, dp_norm, step_size, trans_eps / 2, ...) :757-916
-    const double step_init = dp_norm, step_max = o.step_size, step_min = o.transformation_epsilon / 2;
-    const double phi_0 = -sc;
-    double d_phi_0 = 0;
-    for (int i = 0; i < 6; ++i) d_phi_0 -= g[i] * dir[i];
-    double a_t = 0;
-    bool skip = false;
-    if (d_phi_0 >= 0) {
-      if (d_phi_0 == 0) skip = true;
-      else { d_phi_0 *= -1; for (int i = 0; i < 6; ++i) dir[i] = -dir[i]; }
-    }
-    if (!skip) {
-      const double mu = 1.e-4, nu = 0.9;
-      double a_l = 0, a_u = 0;
-      double f_l = psi_mt(a_l, phi_0, phi_0, d_phi_0, mu), g_l = dpsi_mt(d_phi_0, d_phi_0, mu);
-      double f_u = f_l, g_u = g_l;
-      bool interval_converged = (step_max - step_min) > 0, open_interval = true;   // :795 (sic: the loop below never runs with the wrapper's settings)
-      a_t = std::max(std::min(step_init, step_max), step_min);
-      double x_t[6];
-      for (int i = 0; i < 6; ++i) x_t[i] = p[i] + dir[i] * a_t;
-      pose_to_matrix_f32(x_t, Tf);                         // :803-806
-      s = ndt_derivs(h, x_t, Tf, true, &sc, g, H);         // :809-813
-      if (s) return s;
-      double phi_t = -sc, d_phi_t = 0;
-      for (int i = 0; i < 6; ++i) d_phi_t -= g[i] * dir[i];
-      double psi_t = psi_mt(a_t, phi_t, phi_0, d_phi_0, mu), d_psi_t = dpsi_mt(d_phi_t, d_phi_0, mu);
-      int step_iterations = 0;
-      while (!interval_converged && step_iterations < 10 && !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
-        a_t = open_interval ? trial_value_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t)
-                            : trial_value_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
-        a_t = std::max(std::min(a_t, step_max), step_min);
-        for (int i = 0; i < 6; ++i) x_t[i] = p[i] + dir[i] * a_t;
-        pose_to_matrix_f32(x_t, Tf);
-        double Hd[36];
-        s = ndt_derivs(h, x_t, Tf, false, &sc, g, Hd);
-        if (s) return s;
-        phi_t = -sc; d_phi_t = 0;
-        for (int i = 0; i < 6; ++i) d_phi_t -= g[i] * dir[i];
-        psi_t = psi_mt(a_t, phi_t, phi_0, d_phi_0, mu); d_psi_t = dpsi_mt(d_phi_t, d_phi_0, mu);
-        if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
-          open_interval = false;
-          f_l = f_l + phi_0 - mu * d_phi_0 * a_l; g_l = g_l + mu * d_phi_0;
-          f_u = f_u + phi_0 - mu * d_phi_0 * a_u; g_u = g_u + mu * d_phi_0;
-        }
-        interval_converged = open_interval ? update_interval_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t)
-                                           : update_interval_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
-        step_iterations++;
-      }
-      if (step_iterations) {                               // :912-913 computeHessian
-        double sd, gd[6];
-        s = ndt_derivs(h, x_t, Tf, true, &sd, gd, H);
-        if (s) return s;
-      }
-    }
-    dp_norm = a_t;                                         // :142
-    for (int i = 0; i < 6; ++i) p[i] += dir[i] * dp_norm;  // :143, :152
-    if (it > o.max_iterations || (it && std::fabs(dp_norm) < o.transformation_epsilon)) converged = true;   // :158-162
-    it++;                                                  // :164
-  }
-  // getFinalTransformation().cast<double>(), column-major out (ndt.cc:61)
-  for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) result[4 * c + r] = (double)Tf[4 * r + c];
-  double fit = 0;
-  s = fitness_score(h, result, &fit);
-  if (s) return s;
-  if (score) *score = fit;
-  if (stats) {
-    stats->iterations = it;
-    stats->derivative_calls = n.deriv_calls;
-    stats->voxels = n.info_pinned->nocc;
-    stats->status = 0;
-    stats->trans_probability = sc / (double)h->ns[0];      // :170
-    stats->pairs_last = n.last_pairs;
-  }
-  return SMHIP_OK;
+  return ndt_align_slots(h, first_slot, npairs, guesses, results, scores, stats);
 }
 
 // Test hooks: build the voxel grid of slot 0's target / evaluate computeDerivatives at a pose.
@@ -453,25 +666,25 @@ smhip_status smhip_ndt_build_voxels(smhip_handle h, int* n_voxels) {
   if (h->nt[0] <= 0) { h->err = "target not set"; return SMHIP_ERR_NOT_READY; }
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  smhip_status s = ndt_ensure(h);
+  smhip_status s = ndt_ensure(h, 1);
   if (s) return s;
-  s = ndt_build_grid(h);
+  s = ndt_build_grids(h, 0, 1);
   if (s) return s;
-  if (n_voxels) *n_voxels = ndt_of(h).info_pinned->nocc;
+  if (n_voxels) *n_voxels = ndt_of(h).info_pinned[0].nocc;
   return SMHIP_OK;
 }
 
 smhip_status smhip_ndt_get_voxels(smhip_handle h, int capacity, int32_t* keys, int32_t* counts, double* means, float* icovs, float* centroids) {
   if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
   NdtHost& n = ndt_of(h);
-  if (!n.grid_valid) { h->err = "voxel grid not built"; return SMHIP_ERR_NOT_READY; }
-  const int nocc = n.info_pinned->nocc;
+  if (n.cap < 1 || !n.meta[0].valid) { h->err = "voxel grid not built"; return SMHIP_ERR_NOT_READY; }
+  const int nocc = n.info_pinned[0].nocc;
   if (capacity < nocc) { h->err = "capacity too small"; return SMHIP_ERR_CAPACITY; }
   HIPCHK(h, hipSetDevice(h->device));
-  hipLaunchKernelGGL(ndt_voxel_keys, dim3(ceil_div(nocc, 256)), dim3(256), 0, h->stream, n.dev, n.vkey);
+  hipLaunchKernelGGL(ndt_voxel_keys, dim3(ceil_div(nocc, 256)), dim3(256), 0, h->stream, n.devs_dev, n.vkey);
   std::vector<NdtVoxel> vox(nocc);
   std::vector<int32_t> k(nocc);
-  HIPCHK(h, hipMemcpyAsync(vox.data(), n.dev.vox, sizeof(NdtVoxel) * nocc, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(vox.data(), n.vox_all, sizeof(NdtVoxel) * nocc, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(k.data(), n.vkey, sizeof(int32_t) * nocc, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   for (int v = 0; v < nocc; ++v) {
@@ -487,14 +700,23 @@ smhip_status smhip_ndt_get_voxels(smhip_handle h, int capacity, int32_t* keys, i
 smhip_status smhip_ndt_compute_derivatives(smhip_handle h, const double pose6[6], int compute_hessian, double* score, double grad[6], double hess[36]) {
   if (!h || !pose6 || !score || !grad || !hess) return SMHIP_ERR_INVALID_ARGUMENT;
   NdtHost& n = ndt_of(h);
-  if (!n.grid_valid) { h->err = "voxel grid not built"; return SMHIP_ERR_NOT_READY; }
+  if (n.cap < 1 || !n.meta[0].valid) { h->err = "voxel grid not built"; return SMHIP_ERR_NOT_READY; }
   if (h->ns[0] <= 0) { h->err = "source not set"; return SMHIP_ERR_NOT_READY; }
   HIPCHK(h, hipSetDevice(h->device));
-  n.dev.ns = h->ns[0];
+  smhip_status s = ndt_push_devs(h, 0, 1);
+  if (s) return s;
   float Tf[16];
   pose_to_matrix_f32(pose6, Tf);
-  for (int i = 0; i < 36; ++i) hess[i] = 0;
-  return ndt_derivs(h, pose6, Tf, compute_hessian != 0, score, grad, hess);
+  ndt_fill_pose(n, pose6, Tf, compute_hessian != 0, n.poses_host[0]);
+  n.active_host[0] = 0;
+  s = ndt_eval_round(h, 1, h->ns[0]);
+  if (s) return s;
+  *score = n.out_pinned[0];
+  for (int i = 0; i < 6; ++i) grad[i] = n.out_pinned[1 + i];
+  for (int i = 0; i < 36; ++i) hess[i] = compute_hessian ? n.out_pinned[7 + i] : 0.0;
+  n.last_pairs = n.out_pinned[43];
+  n.deriv_calls++;
+  return SMHIP_OK;
 }
 
 }  // extern "C"

@@ -261,8 +261,8 @@ class NdtHip(IcpFastHip):
     distance, LOWER is better."""
 
     def __init__(self, device: int = 0, max_source_points: int = 131072, max_target_points: int = 524288,
-                 stream: int | None = None, **ndt_options):
-        super().__init__(device=device, pair_slots=1, max_source_points=max_source_points,
+                 stream: int | None = None, pair_slots: int = 1, **ndt_options):
+        super().__init__(device=device, pair_slots=pair_slots, max_source_points=max_source_points,
                          max_target_points=max_target_points, stream=stream)
         self._nopts = _capi.NdtOptions()
         self._lib.smhip_ndt_default_options(ctypes.byref(self._nopts))
@@ -279,11 +279,11 @@ class NdtHip(IcpFastHip):
 
     def set_input_source(self, points, slot: int = 0):
         a = np.ascontiguousarray(np.asarray(points, dtype=np.float32))
-        self._check(self._lib.smhip_set_source_f32(self._h, 0, a.ctypes.data_as(_capi.c_float_p), a.shape[1], a.shape[0]))
+        self._check(self._lib.smhip_set_source_f32(self._h, slot, a.ctypes.data_as(_capi.c_float_p), a.shape[1], a.shape[0]))
 
     def set_input_target(self, points, normals=None, slot: int = 0):
         a = np.ascontiguousarray(np.asarray(points, dtype=np.float32))
-        self._check(self._lib.smhip_set_target_f32(self._h, 0, a.ctypes.data_as(_capi.c_float_p), a.shape[1], None, 0, a.shape[0]))
+        self._check(self._lib.smhip_set_target_f32(self._h, slot, a.ctypes.data_as(_capi.c_float_p), a.shape[1], None, 0, a.shape[0]))
 
     def align(self, guess=None):
         G = np.eye(4) if guess is None else np.asarray(guess, dtype=np.float64)
@@ -296,6 +296,18 @@ class NdtHip(IcpFastHip):
         self.final_score_ = score.value
         self.last_ndt_stats = {k: getattr(st, k) for k, _ in st._fields_}
         return True, res.reshape(4, 4).T.copy()
+
+    def align_batch(self, npairs: int, guesses=None, first_slot: int = 0):
+        """npairs independent Ndt::Align calls on slots first_slot .. first_slot + npairs - 1, advanced in lock-step
+        (smhip_ndt_align_batch): poses [npairs, 4, 4], fitness scores [npairs], stats (list of dicts) -- the single calls' bits."""
+        g = self._pack_guesses(npairs, guesses)
+        res = np.zeros((npairs, 16))
+        scores = np.zeros(npairs)
+        stats = (_capi.NdtStats * npairs)()
+        self._check(self._lib.smhip_ndt_align_batch(self._h, first_slot, npairs, g.ctypes.data_as(_capi.c_double_p), res.ctypes.data_as(_capi.c_double_p),
+                                                    scores.ctypes.data_as(_capi.c_double_p), stats))
+        self.last_ndt_stats = [{k: getattr(s, k) for k, _ in s._fields_} for s in stats]
+        return res.reshape(npairs, 4, 4).transpose(0, 2, 1).copy(), scores, self.last_ndt_stats
 
     # -- parity-test hooks ---------------------------------------------------------------------
     def build_voxels(self) -> int:

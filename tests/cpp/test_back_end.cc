@@ -82,6 +82,27 @@ int main(int argc, char** argv) {
       for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) pool_equal = pool_equal && pooled[k].transform_to_next(r, c) == one.transform_to_next(r, c);
     }
   }
+  // ... and the same six pairs as ONE lock-step batch through the pair slots of one Ndt matcher (SubmapPairMatchBatch ->
+  // NdtHip::AlignBatch -> smhip_ndt_align_batch): every pair's Newton / More-Thuente evaluations in its own order, the launches
+  // shared -- again what six single SubmapPairMatch calls give, bit for bit
+  bool ndt_batch_equal = true;
+  {
+    reg::MatcherOptions nopt; nopt.type = reg::kNdt; nopt.accepted_min_score = -1.0f;
+    std::vector<smhip::back_end::SubmapPairJob> njobs(6);
+    for (int k = 0; k < 6; ++k) {
+      njobs[k] = jobs[0];
+      njobs[k].source_first_frame_pose(0, 3) += 0.02 * k; njobs[k].source_first_frame_pose(1, 3) -= 0.01 * k;
+    }
+    auto ndt_matcher = reg::CreateMatcher(nopt, false);
+    auto lock = smhip::back_end::SubmapPairMatchBatch(nopt, ndt_matcher, njobs);
+    lock = smhip::back_end::SubmapPairMatchBatch(nopt, ndt_matcher, njobs);               // the K-slot handle outlives a batch
+    for (int k = 0; k < 6; ++k) {
+      const auto one = smhip::back_end::SubmapPairMatch(nopt, njobs[k].source_submap_cloud, njobs[k].source_first_frame_pose,
+                                                         njobs[k].target_submap_cloud, njobs[k].target_first_frame_pose);
+      ndt_batch_equal = ndt_batch_equal && lock[k].match_score == one.match_score && lock[k].accepted == one.accepted;
+      for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) ndt_batch_equal = ndt_batch_equal && lock[k].transform_to_next(r, c) == one.transform_to_next(r, c);
+    }
+  }
   // the same through registrators::NdtWithGicp (host-driven BFGS per pair): four pairs, two matchers
   bool gicp_pool_equal = true;
   {
@@ -104,7 +125,8 @@ int main(int argc, char** argv) {
   const bool closed2 = smhip::back_end::CloseLoop(tpose, target, spose, source, settings, &edge2, &keep_matcher);
   const bool closed_far2 = smhip::back_end::CloseLoop(tpose, target, far, source, settings, &bad_edge2, &keep_matcher);
 
-  std::printf("{\"pool_equal\": %s, \"gicp_pool_equal\": %s, \"pool_accepted\": %d, \"closed\": %s, \"edge_score\": %.17g, \"closed_far\": %s, ", pool_equal ? "true" : "false", gicp_pool_equal ? "true" : "false", pool_accepted,
+  std::printf("{\"pool_equal\": %s, \"ndt_batch_equal\": %s, \"gicp_pool_equal\": %s, \"pool_accepted\": %d, \"closed\": %s, \"edge_score\": %.17g, \"closed_far\": %s, ", pool_equal ? "true" : "false",
+              ndt_batch_equal ? "true" : "false", gicp_pool_equal ? "true" : "false", pool_accepted,
               closed ? "true" : "false", edge.score, closed_far ? "true" : "false");
   PrintMatrix("edge_guess", edge.init_guess);
   PrintMatrix("edge_transform", edge.transform);

@@ -115,6 +115,7 @@ def test_close_loop_and_submap_pair_match(tmp_path, matcher_type):
     assert np.array_equal(M("sub_far_transform"), M("sub_far_guess"))
     # six registrators::Ndt pairs through a pool of three matchers on three host threads = the six single calls, bit for bit
     assert res["pool_equal"] and res["pool_accepted"] == 6
+    assert res["ndt_batch_equal"]              # the same six pairs as one lock-step batch (smhip_ndt_align_batch): the single calls' bits
     assert res["gicp_pool_equal"]              # and four registrators::NdtWithGicp pairs through two matchers
     # the two pairs as one batch through a pooled matcher (SubmapPairMatchBatch) = the two single calls
     assert res["batch_accepted"] == [True, False]

@@ -100,3 +100,38 @@ def test_ndt_identity_guess_and_errors(ndt_case):
     da, dt = sm.se3_error(R, ref["result"])
     assert da < 1e-4 and dt < 1e-3, (da, dt)
     m.close()
+
+
+def test_lockstep_batch_equals_the_single_calls_bit_for_bit(ndt_case):
+    """smhip_ndt_align_batch: K Aligns advance in lock-step (each round's computeDerivatives calls of all running pairs are one
+    launch), every pair through exactly the evaluation sequence of its own Newton / More-Thuente state machine
+    (pclomp/ndt_omp_impl.hpp:81-171, 757-916).  Five different pairs -- different sources, targets, guesses, so different
+    iteration counts: the pairs drop out of the rounds at different times -- against the same five as single calls: poses,
+    fitness scores and statistics bit for bit; also on a slot range that does not start at 0, and with the tables kept."""
+    import staticmapping_amd as sm
+    from staticmapping_amd import synth
+    src, tgt, T = ndt_case["src"], ndt_case["tgt"], ndt_case["T"]
+    cases = []
+    for k in range(5):
+        s = src[k::(1 + k % 3)]                                              # different sizes
+        t = tgt[(k % 2)::(1 + k % 2)]
+        g = T @ synth.make_pose(t=(-0.1 - 0.07 * k, 0.03 * k, 0.0), rpy_deg=(0, 0, 0.2 * k))
+        cases.append((s, t, g))
+    single = []
+    m1 = sm.NdtHip(max_source_points=len(src), max_target_points=len(tgt))
+    for s, t, g in cases:
+        m1.set_input_source(s); m1.set_input_target(t)
+        ok, R = m1.align(g)
+        single.append((R, m1.get_fitness_score(), dict(m1.last_ndt_stats)))
+    m1.close()
+    assert len({st["iterations"] for _, _, st in single}) > 1                # the state machines do not finish together
+    mb = sm.NdtHip(max_source_points=len(src), max_target_points=len(tgt), pair_slots=7)
+    for first in (0, 2):
+        for k, (s, t, g) in enumerate(cases):
+            mb.set_input_source(s, slot=first + k); mb.set_input_target(t, slot=first + k)
+        for rep in range(2):                                                 # second pass: every table is current and kept
+            R, sc, st = mb.align_batch(5, [c[2] for c in cases], first_slot=first)
+            for k in range(5):
+                assert R[k].tobytes() == single[k][0].tobytes(), (first, rep, k)
+                assert sc[k] == single[k][1] and st[k] == single[k][2], (first, rep, k, st[k], single[k][2])
+    mb.close()

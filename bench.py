@@ -87,7 +87,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=512, help="scan pairs per GPU per step")
-    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic scan pairs (cycled over the slots; each slot uploaded)")
+    ap.add_argument("--distinct", type=int, default=512, help="distinct synthetic scan pairs (cycled over the slots; each slot uploaded).  Default: every "
+                    "slot of the default batch holds a pair of its own (513 scans of the synthetic drive, ~25 s to generate and prepare)")
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--nn-mode", choices=["grid", "brute"], default="grid")
     ap.add_argument("--cell", type=float, default=0.25)
@@ -96,7 +97,7 @@ def main():
     ap.add_argument("--ball-radius", type=float, default=0.0, help="smhip_icp_options.ball_radius: first-iteration search radius (0 = the library's default, 0.3 m)")
     ap.add_argument("--streams", type=int, default=0, help="smhip_icp_options.overlap_streams: parts a batch is split into (0 = the library's default, 2)")
     ap.add_argument("--headline", choices=["identity", "extrapolated"], default="extrapolated")
-    ap.add_argument("--cpu-pairs", type=int, default=0, help="oracle / cpu_baseline sample: distinct pairs run on the host (0 = all)")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="oracle / cpu_baseline sample: distinct pairs run on the host (0 = the first 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (no parity-vs-oracle either)")
     ap.add_argument("--no-figures", action="store_true", help="skip the extra figures")
     ap.add_argument("--no-other", action="store_true", help="skip other_workloads (NDT / NdtWithGicp), single_pair and end_to_end")
@@ -169,7 +170,10 @@ def main():
         torch.cuda.synchronize(dev)
 
     def timed_run(guess_key, steps, warmup, profile_nn=0):
-        guesses = [work[g % D][guess_key] for g in mine]
+        if guess_key == "mixed":     # one batch holding both kinds: even pairs the extrapolated guess, odd pairs the identity
+            guesses = [work[g % D]["guess_cv" if g % 2 == 0 else "guess_id"] for g in mine]
+        else:
+            guesses = [work[g % D][guess_key] for g in mine]
 
         def step():
             m.enqueue_batch(B, guesses)
@@ -258,6 +262,19 @@ def main():
             figures[name_o] = dict(value=round(oth["value"], 2), iterations=ICP_ITERS, searched_queries_per_alignment=searched(oth["stats"]), split_after=oth["split"],
                                    worst_trans_err_vs_truth_m=o_t, median_trans_err_vs_truth_m=o_med, T=oth["T"], guess_key=other_key,
                                    max_iteration=ICP_ITERS, early_exit=False)
+            # a heterogeneous batch: alternating extrapolated / identity guesses in ONE 512-pair batch.  The library
+            # places the switch from the fused search to certificate pass + listed search once per batch (from the previous
+            # batch's per-iteration search counts); here half the pairs would want it at 2 and half at 5.
+            mx = timed_run("mixed", fs, fw)
+            mx_err = [sm.se3_error(mx["T"][g], work[g % D]["T"])[1] for g in range(n_total)]
+            hm = 2.0 / (1.0 / head["value"] + 1.0 / oth["value"])
+            figures["mixed_guess"] = dict(value=round(mx["value"], 2), iterations=ICP_ITERS, searched_queries_per_alignment=searched(mx["stats"]), split_after=mx["split"],
+                                          harmonic_mean_of_the_two_homogeneous_figures=round(hm, 2), ratio_to_harmonic_mean=round(mx["value"] / hm, 4),
+                                          median_trans_err_vs_truth_m_even_pairs=float(np.median(mx_err[0::2])),
+                                          median_trans_err_vs_truth_m_odd_pairs=float(np.median(mx_err[1::2])),
+                                          fused_iterations_mean_even_odd=[float(np.mean([s_["fused_iterations"] for s_ in mx["stats"][0::2]])),
+                                                                          float(np.mean([s_["fused_iterations"] for s_ in mx["stats"][1::2]]))],
+                                          T=mx["T"], guess_key="mixed", max_iteration=ICP_ITERS, early_exit=False)
             # the reference's own search semantics: libnabo's tree + epsilon = 3.16 approximate knn on the device (nn_mode NABO)
             m.set_options(nn_mode=sm.NN_NABO, nn_epsilon=3.16)
             nb = timed_run("guess_cv", fs, fw)
@@ -305,24 +322,36 @@ def main():
             return dict(total_ms=ms, launches=launches, avg_launch_ms=avg_ms, pairs_per_launch=pairs, bytes_per_point=bytes_per_point,
                         bytes_per_launch=by, achieved=by / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0)
 
+        # From the switch on a batch runs the certificate pass and the normal-equation sums as ONE kernel (nn_certify_acc: FindClosests for
+        # the certified queries + ErrorElements / ComputePointToPlane below the predicted quantile band, 20 + 24 rho B per source point);
+        # `accumulate` is then launched every iteration but returns at once unless a pair's prediction missed.
+        fused_on = float(np.mean([s_["fused_iterations"] for s_ in head["stats"]])) > 0
+        cert_name = "nn_certify_acc" if fused_on else "nn_certify"
+        cert_bytes = 20.0 + 24.0 * RHO if fused_on else 20.0
+
         def all_kernels(p):
             kf = {}
             main_name = "nn_ball_lds" if args.nn_mode == "grid" else "nn_brute"
             if p["launches_nn_main"] > 0:
                 kf[main_name] = kernel_figures(p, p["ms_nn_main"], p["launches_nn_main"], p["pairs_nn_main"], 20.0)
             if p["launches_nn_certify"] > 0:
-                kf["nn_certify"] = kernel_figures(p, p["ms_nn_certify"], p["launches_nn_certify"], p["pairs_nn_certify"], 20.0)
+                kf[cert_name] = kernel_figures(p, p["ms_nn_certify"], p["launches_nn_certify"], p["pairs_nn_certify"], cert_bytes)
             if p["launches_nn_listed"] > 0:
                 kf["nn_ball_listed"] = kernel_figures(p, p["ms_nn_listed"], p["launches_nn_listed"], p["pairs_nn_listed"], 20.0)
             if p["launches_error_elements"] > 0:
+                # (fused path: most of these launches are the early-exit form, so the average says nothing about the kernel;
+                # the entry is kept for the time it takes per step)
                 kf["accumulate"] = kernel_figures(p, p["ms_error_elements"], p["launches_error_elements"], p["pairs_error_elements"], 24.0 * RHO)
+                if fused_on:
+                    kf["accumulate"]["mostly_early_exit_launches"] = True
             # FindClosests of one iteration as a whole: every launch that belongs to it, 20 B per source point once
             it_fused, it_split = p["launches_nn_main"], p["launches_nn_certify"]
             refine_per_it = p["ms_nn_refine"] / max(1, it_fused + it_split)
             fc = {}
             if it_split > 0:
                 ms = (p["ms_nn_certify"] + p["ms_nn_listed"]) / it_split + refine_per_it
-                pairs = kf["nn_certify"]["pairs_per_launch"]
+                pairs = kf[cert_name]["pairs_per_launch"]
+                # (fused path: these launches also carry the iteration's ErrorElements sums -- priced with 20 B/pt all the same here)
                 fc["certify_listed_refine"] = dict(iteration_launches=it_split, ms_per_iteration_launch=ms, pairs_per_launch=pairs,
                                                    achieved=pairs * ns * 20.0 / (ms * 1e-3) / 1e9)
             if it_fused > 0:
@@ -335,7 +364,7 @@ def main():
         kf_timed, _ = all_kernels(nn_prof)
         kf_all, fc = all_kernels(prof)
         kf = {k: dict(kf_timed[k], timed=True) if k in kf_timed else dict(v, timed=False) for k, v in kf_all.items()}
-        dom = max(kf_timed, key=lambda k: kf_timed[k]["total_ms"])
+        dom = max((k for k in kf_timed if not kf_timed[k].get("mostly_early_exit_launches")), key=lambda k: kf_timed[k]["total_ms"])
         nn_ms, pairs_per_launch, nn_bytes, achieved = (kf[dom][k] for k in ("avg_launch_ms", "pairs_per_launch", "bytes_per_launch", "achieved"))
         kf_alone, _ = all_kernels(alone)
         alone_f = kf_alone.get(dom, dict(avg_launch_ms=0.0, pairs_per_launch=0, achieved=0.0))
@@ -379,8 +408,13 @@ def main():
                          "kernels": {k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "pairs_per_launch": v["pairs_per_launch"],
                                          "launches": v["launches"], "in_timed_region": v["timed"], "algorithmic_bytes_per_point": v["bytes_per_point"],
                                          "algorithmic_bytes_per_launch": v["bytes_per_launch"], "achieved": round(v["achieved"], 2),
-                                         "frac": round(v["achieved"] / HBM_PEAK_GBS, 5), "traffic": traffic_of(k, v["pairs_per_launch"])}
+                                         "frac": round(v["achieved"] / HBM_PEAK_GBS, 5), "traffic": traffic_of(k, v["pairs_per_launch"]),
+                                         **({"mostly_early_exit_launches": True} if v.get("mostly_early_exit_launches") else {})}
                                      for k, v in kf.items()},
+                         "fused_certificate_pass": {"on": bool(fused_on), "iterations_carried_mean": float(np.mean([s_["fused_iterations"] for s_ in head["stats"]])),
+                                                    "iterations_carried_min": int(min(s_["fused_iterations"] for s_ in head["stats"])),
+                                                    "note": "iterations (of 20) whose normal-equation sums came from nn_certify_acc; the rest: nn_ball_lds iterations "
+                                                            "before the switch and predictions that missed, summed by accumulate"},
                          "find_closests_per_iteration": {k: {"iteration_launches": v["iteration_launches"], "ms_per_iteration_launch": round(v["ms_per_iteration_launch"], 4),
                                                              "pairs_per_launch": v["pairs_per_launch"], "algorithmic_bytes_per_point": 20.0,
                                                              "achieved": round(v["achieved"], 2), "frac": round(v["achieved"] / HBM_PEAK_GBS, 5)}
@@ -389,8 +423,9 @@ def main():
                          "note": "The timed region carries HIP events around ONE kernel class -- the one an untimed step with events around every launch found "
                                  "the largest (kernels.*.in_timed_region) -- because every event pair is a barrier between two launches and bracketing all "
                                  "classes took 6 % off the batch rate; the other kernels and find_closests_per_iteration come from that untimed step of the "
-                                 "same batch.  kernels.*: each kernel alone, priced with the algorithmic bytes of the reference function it implements (nn_certify and "
-                                 "nn_ball_listed each carry the full 20 B/pt of FindClosests, so read find_closests_per_iteration for the function as a "
+                                 "same batch.  kernels.*: each kernel alone, priced with the algorithmic bytes of the reference function(s) it implements (nn_certify and "
+                                 "nn_ball_listed each carry the full 20 B/pt of FindClosests; nn_certify_acc = FindClosests + ErrorElements / ComputePointToPlane "
+                                 "in one pass = 20 + 24 rho B/pt; read find_closests_per_iteration for FindClosests as a "
                                  "whole: certificate pass + listed search + validate / ring / fallback launches of one iteration, 20 B/pt once)",
                          "alone": {"note": "same kernel on one stream, not sharing the GPU with the other half-batch",
                                    "pairs_per_launch": alone_pairs, "avg_launch_ms": round(alone_ms, 4),
@@ -404,7 +439,7 @@ def main():
             "workload_generation_s": round(t_gen, 1),
         }
         if not args.no_cpu_baseline and rank == 0:     # (the CPU oracle legs: rank 0 alone, the other ranks wait at the final barrier)
-            cpu, par = cpu_baseline_and_parity(work, figures, head, head_key, args.cpu_pairs or D, world)
+            cpu, par = cpu_baseline_and_parity(work, figures, head, head_key, args.cpu_pairs or min(D, 64), world)
             out["parity"].update(par)
             if world == 1:
                 out["cpu_baseline"] = cpu
@@ -464,8 +499,11 @@ def cpu_baseline_and_parity(work, figures, head, head_key, n_cpu, world):
         wr = wt = 0.0
         it_ok = True
         sub = list(range(0, D, max(1, D // 8)))[:8]
+        if f["guess_key"] == "mixed":            # pairs of both kinds: even global index = extrapolated guess, odd = identity
+            sub = [min(D - 1, d + (k % 2)) for k, d in enumerate(sub)]
         for d in sub:
-            ref = oracle_pose(work[d], work[d][f["guess_key"]], f["max_iteration"], f["early_exit"], nn_eps=f.get("nn_eps"))
+            gkey = ("guess_cv" if d % 2 == 0 else "guess_id") if f["guess_key"] == "mixed" else f["guess_key"]
+            ref = oracle_pose(work[d], work[d][gkey], f["max_iteration"], f["early_exit"], nn_eps=f.get("nn_eps"))
             da, dt = sm.se3_error(f["T"][d], ref["result"])
             wr, wt = max(wr, da), max(wt, dt)
         f["worst_rot_vs_oracle_rad"], f["worst_trans_vs_oracle_m"], f["pairs_checked_vs_oracle"] = wr, wt, len(sub)
@@ -698,6 +736,42 @@ def other_workloads(dev, with_cpu):
             m.set_target_cache(True)
         except Exception as e:
             entry["six_concurrent_matchers"] = {"error": repr(e)}
+        # ... and as ONE lock-step batch through the pair slots of one matcher (smhip_ndt_align_batch): the K Newton / More-Thuente
+        # state machines advance together, every round's computeDerivatives calls are one launch, the K voxel tables are built in
+        # one pass (one radix sort) and the K fitness scores in another.  64 slots hold this pair with 64 different guesses (the
+        # pairs leave the rounds at different times); slot 0 carries the single call's guess and must return its bits.
+        try:
+            from staticmapping_amd import synth
+            K = 64
+            mb = sm.NdtHip(max_source_points=len(src), max_target_points=len(tgt), pair_slots=K)
+            for k in range(K):
+                mb.set_input_source(src, slot=k); mb.set_input_target(tgt, slot=k)
+            gs = [G @ synth.make_pose(t=(0.01 * (k % 8), -0.01 * (k % 5), 0.0), rpy_deg=(0, 0, 0.05 * (k % 7))) for k in range(K)]
+            gs[0] = G
+
+            def time_batch():
+                mb.align_batch(K, gs)
+                t_ = time.perf_counter()
+                for _ in range(3):
+                    Rb_, scb_, stb_ = mb.align_batch(K, gs)
+                return (time.perf_counter() - t_) / 3, Rb_, stb_
+            mb.set_target_cache(False)
+            dtb, Rb, stb = time_batch()
+            mb.set_target_cache(True)
+            dtb_kept, Rb_kept, _ = time_batch()
+            calls = float(np.sum([s_["derivative_calls"] for s_ in stb]))
+            b_batch = K * (12.0 * nt_ + 40.0 * V + 16.0 * ns) + calls * ns * (12.0 + 36.0 * mbar)       # SURVEY §8(d) B_ndt, summed over the pairs
+            entry["batch64"] = {"value": round(K / dtb, 2), "unit": "alignments/s", "pairs": K, "ms_per_batch": round(dtb * 1e3, 3),
+                                "identical_to_single": bool(np.array_equal(Rb[0], R)), "iterations_min_max": [int(min(s_["iterations"] for s_ in stb)), int(max(s_["iterations"] for s_ in stb))],
+                                "derivative_calls_total": int(calls),
+                                "roofline": {"bound": "hbm", "achieved": round(b_batch / dtb / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": round(b_batch / dtb / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": b_batch},
+                                "target_kept": {"value": round(K / dtb_kept, 2), "ms_per_batch": round(dtb_kept * 1e3, 3), "identical_result": bool(np.array_equal(Rb, Rb_kept))},
+                                "note": "smhip_ndt_align_batch: lock-step state machines, one ndt_derivatives launch per round over all running pairs "
+                                        "(pclomp/ndt_omp_impl.hpp:81-171, 757-916; builder/map_builder.cc:399-446, 655); value = everything rebuilt per Align"}
+            mb.close()
+        except Exception as e:
+            entry["batch64"] = {"error": repr(e)}
         if with_cpu:
             from oracle import cref
             t = time.perf_counter()

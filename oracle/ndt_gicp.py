@@ -172,6 +172,7 @@ class GicpFunctor:
         self.m = len(src_f32)
         self.pbase = (self.src4 @ self.base.T).astype(F)[:, :3].astype(np.float64)   # base_transformation_ * p_src
         self.evals = 0
+        self.points = 0        # distinct states evaluated: pcl's BFGS asks for f at a trial state and then, maybe, for df at the same one
 
     def _transform(self, T):
         if self.transform_mode == "blas":
@@ -197,6 +198,7 @@ class GicpFunctor:
 
     def f(self, x):
         self.evals += 1
+        self.points += 1
         res, temp = self._res_temp(x)
         return float(np.einsum("ki,ki->", res, temp)) / self.m
 
@@ -211,6 +213,7 @@ class GicpFunctor:
 
     def fdf(self, x):
         self.evals += 1
+        self.points += 1
         res, temp = self._res_temp(x)
         f = float(np.einsum("ki,ki->", res, temp)) / self.m
         g = np.zeros(6)
@@ -501,7 +504,7 @@ def gicp_align(src_f32, tgt_f32, guess_f32, max_iterations=35, rotation_epsilon=
         delta = float(np.max(ratio * np.abs(prev.astype(np.float64) - T.astype(np.float64))))   # :475-491
         it += 1
         if trace is not None:
-            trace.append(dict(x=x.copy(), inner=inner, delta=delta, n_corr=len(keep), evals=fn.evals))
+            trace.append(dict(x=x.copy(), inner=inner, delta=delta, n_corr=len(keep), evals=fn.evals, points=fn.points))
         if it >= max_iterations or delta < 1:
             prev = T.copy()
             break

@@ -119,6 +119,7 @@ def test_gicp_alone_matches_oracle(clouds, matcher):
     fit, res = matcher.gicp_only(ds, dt, guess)
     want = ong.gicp_align(ds, dt, guess.astype(np.float32))
     da, dtv = sm.se3_error(res, want["result"].astype(np.float64))
+    print(f"[gicp alone] device vs oracle: {da:.3e} rad {dtv:.3e} m")
     assert da < 3e-3 and dtv < 5e-2, (da, dtv, matcher.last_gicp_stats, want["iterations"])
     assert abs(fit - want["score"]) < 0.05 * max(1e-3, want["score"])
     assert abs(matcher.last_gicp_stats["gicp_iterations"] - want["iterations"]) <= 2
@@ -145,6 +146,7 @@ def test_ndt_gicp_align_matches_oracle(clouds, matcher):
     ok, res = matcher.align(guess)
     assert ok and want["ok"]
     da, dtv = sm.se3_error(res, want["result"])
+    print(f"[ndt + gicp] device vs oracle: {da:.3e} rad {dtv:.3e} m")
     assert da < 3e-3 and dtv < 5e-2, (da, dtv, matcher.last_gicp_stats)
     assert abs(matcher.get_fitness_score() - want["score"]) < 2e-2
     da, dtv = sm.se3_error(res, T)

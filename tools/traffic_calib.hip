@@ -5,6 +5,9 @@
 //   calib_certify     per element: 12-byte row (global_load_dwordx3) + int + float read, one float written  -- nn_certify's shape
 //   calib_accumulate  per element: 12-byte row + int + float read, nothing written                          -- accumulate's stream
 //   calib_x4          per element: one 16-byte row read, one 16-byte row written                            -- the guide's own case
+//   calib_scatter     per listed query (one in 50 elements, a hashed position): 12-byte row + int read, three dwords written to
+//                     three arrays at that position                                                         -- nn_ball_listed's shape
+//                     (known REQUESTED bytes; what the counters report per query is the granularity the memory system moves)
 // Arrays are 256 x 120 000 elements (a 256-pair launch) and far larger than the 256 MiB Infinity Cache taken together.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -36,6 +39,18 @@ __global__ __launch_bounds__(256) void calib_x4(const float4* __restrict__ in, f
   }
 }
 
+__global__ __launch_bounds__(256) void calib_scatter(const float* __restrict__ src3, int* __restrict__ idx, float* __restrict__ lb,
+                                                     float* __restrict__ d2, size_t n, size_t nq) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < nq; k += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long z = k * 0x9E3779B97F4A7C15ull;                // splitmix-style hash: positions spread over the whole array
+    z ^= z >> 31; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 29;
+    const size_t i = (size_t)(z % n);
+    const float3 v = *reinterpret_cast<const float3*>(src3 + 3 * i);
+    const int j = idx[i];
+    d2[i] = v.x + v.y; idx[i] = j + 1; lb[i] = v.z;
+  }
+}
+
 int main() {
   const size_t n = (size_t)256 * 120000;
   float *src3, *lb, *d2, *out;
@@ -53,9 +68,12 @@ int main() {
     hipLaunchKernelGGL(calib_certify, dim3(blocks), dim3(256), 0, 0, src3, idx, lb, d2, n);
     hipLaunchKernelGGL(calib_x4, dim3(blocks), dim3(256), 0, 0, a4, b4, n);
     hipLaunchKernelGGL(calib_accumulate, dim3(blocks), dim3(256), 0, 0, src3, idx, lb, out, n);
+    hipLaunchKernelGGL(calib_x4, dim3(blocks), dim3(256), 0, 0, a4, b4, n);
+    hipLaunchKernelGGL(calib_scatter, dim3(blocks), dim3(256), 0, 0, src3, idx, lb, d2, n, n / 50);
   }
   CK(hipDeviceSynchronize());
   std::printf("{\"elements\": %zu, \"calib_certify\": {\"read_bytes\": %zu, \"written_bytes\": %zu}, \"calib_accumulate\": {\"read_bytes\": %zu, "
-              "\"written_bytes\": 0}, \"calib_x4\": {\"read_bytes\": %zu, \"written_bytes\": %zu}}\n", n, n * 20, n * 4, n * 20, n * 16, n * 16);
+              "\"written_bytes\": 0}, \"calib_x4\": {\"read_bytes\": %zu, \"written_bytes\": %zu}, \"calib_scatter\": {\"queries\": %zu, \"read_bytes\": %zu, "
+              "\"written_bytes\": %zu}}\n", n, n * 20, n * 4, n * 20, n * 16, n * 16, n / 50, (n / 50) * 16, (n / 50) * 12);
   return 0;
 }

@@ -23,6 +23,14 @@ for k in ("calib_certify", "calib_accumulate", "calib_x4"):
     rb, wb = known[k]["read_bytes"], known[k]["written_bytes"]
     res["kernels"][k] = {"read_bytes": rb, "written_bytes": wb, "FETCH_SIZE": f, "WRITE_SIZE": w,
                          "fetch_factor": rb / (f * 1024) if f else None, "write_factor": wb / (w * 1024) if w and wb else None}
+# the scattered shape (the listed search): requested bytes are known, what the counters report per query is the granularity
+# of the memory system -- fetch factor 2.0 (the streaming calibration) applied, so "bytes moved per query" is a number
+f, w = avg("/tmp/calib_f", "calib_scatter", "FETCH_SIZE"), avg("/tmp/calib_w", "calib_scatter", "WRITE_SIZE")
+sc = known["calib_scatter"]
+res["kernels"]["calib_scatter"] = {"queries": sc["queries"], "requested_read_bytes": sc["read_bytes"], "requested_written_bytes": sc["written_bytes"],
+                                   "FETCH_SIZE": f, "WRITE_SIZE": w,
+                                   "fetched_bytes_per_query_at_factor_2": 2.0 * f * 1024 / sc["queries"], "written_bytes_per_query": w * 1024 / sc["queries"],
+                                   "note": "a 12-byte row + an int read and three dwords written at a hashed position per query: requested 16 B read / 12 B written"}
 res["fetch_factor_stream_12_4_4"] = res["kernels"]["calib_certify"]["fetch_factor"]
 res["write_factor_dword"] = res["kernels"]["calib_certify"]["write_factor"]
 res["fetch_factor_x4"] = res["kernels"]["calib_x4"]["fetch_factor"]

@@ -38,7 +38,7 @@ def test_front_end_drive(tmp_path):
     for k, P in enumerate(poses):
         kitti.write_bin(kitti.scan_path(str(tmp_path), k), synth.velodyne_scan(scene, P, seed=120 + k, n_points=30000))
     # the drive's rough speed primes the extrapolator (PoseExtrapolator::InitRoughLinearVelocity): with a zero first guess the
-    # trimmed point-to-plane ICP stalls along the road in this scene (the reference's early-exit rule)
+    # trimmed point-to-plane ICP stalls along the road in this scene (the reference's early-exit rule, see DESIGN_HISTORY.md section 2)
     out = subprocess.check_output([_build_exe(), str(n), str(tmp_path), "3.0", "0.1"], text=True, timeout=600)
     frames = json.loads(out.strip().splitlines()[-1])["frames"]
     assert len(frames) == n and frames[0]["key"] and not frames[0]["matched"]

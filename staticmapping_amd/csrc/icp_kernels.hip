@@ -861,7 +861,7 @@ __device__ __forceinline__ void sweep_run(const float4* __restrict__ tq, uint32_
 #define SMHIP_PHASE(k) do { } while (0)
 #endif
 template <int ITEMS>
-__global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk) {
+__global__ __launch_bounds__(kNnThreads, 5) void nn_ball_lds(IcpDev b, int nblk) {
   int pair, blk;
   if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
   PairState* st = &b.state[pair];
@@ -889,6 +889,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
   __shared__ uint32_t s_tab[kLdsTableCap];
   __shared__ float4 s_pts[kLdsPointCap];
   __shared__ uint32_t s_roff[kLdsRowCap + 1];
+  __shared__ uint32_t s_occ[kLdsRowCap / 32 + 1];   // bit r = staged row r of the box holds target points (+ one word so that two can always be read)
   __shared__ float4 s_q[kNnThreads];          // queries of the round that need a search: x, y, z, previous match
   __shared__ float s_r2[kNnThreads];          // their squared search radius
   __shared__ uint16_t s_lid[kNnThreads];      // their lane in the round
@@ -955,7 +956,9 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
     if (i < ns && !valid) {                                // NaN / inf input: no match
       b.d2[so + i] = INFINITY; b.idx[so + i] = -1; st_lb(b, so + i, 0.f);
     }
-    const float sn = norm3(s_cur.x, s_cur.y, s_cur.z);
+    // (|s| and the other roots of this kernel by the hardware instruction, 1 ulp: each feeds a bound that bound_now / the cell
+    // block take with 1e-5 .. 1e-4 of relative slack; the IEEE sequence is ~13 instructions a root in a kernel bound by their issue)
+    const float sn = __builtin_amdgcn_sqrtf(fmaf(s_cur.z, s_cur.z, fmaf(s_cur.y, s_cur.y, s_cur.x * s_cur.x)));
     // an upper bound of this iteration's motion of the query (first iteration: no motion history yet)
     const float delta = have_prev ? fmaf(pot.sa, sn, pot.sb) : 0.03f;
     if (certify && valid) {
@@ -1017,7 +1020,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
     }
     int x0 = 1, x1 = 0, y0 = 1, y1 = 0, z0 = 1, z1 = 0;
     if (mine) {
-      const float Rs = sqrtf(R2) * 1.0001f + 1.0e-3f * h;
+      const float Rs = __builtin_amdgcn_sqrtf(R2) * 1.0001f + 1.0e-3f * h;
       x0 = max(cell_coord(qx - Rs, ox, inv_h), 0); x1 = min(cell_coord(qx + Rs, ox, inv_h), nx - 1);
       y0 = max(cell_coord(qy - Rs, oy, inv_h), 0); y1 = min(cell_coord(qy + Rs, oy, inv_h), ny - 1);
       z0 = max(cell_coord(qz - Rs, oz, inv_h), 0); z1 = min(cell_coord(qz + Rs, oz, inv_h), nz - 1);
@@ -1066,6 +1069,12 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
     if (pts_lds) {
       uint32_t len = 0;
       if ((int)threadIdx.x < rows) len = s_tab[threadIdx.x * nxl + nxl - 1] - s_tab[threadIdx.x * nxl];
+      {   // which rows of the box hold a point at all: most (z, y) rows around a surface do not, and a query's row loop pays
+          // ~50 vector instructions per row whether the row has candidates or not (kLdsRowCap = blockDim: thread r owns row r)
+        const unsigned long long om = __ballot(len > 0);
+        if (lane == 0) { s_occ[2 * (threadIdx.x >> 6)] = (uint32_t)om; s_occ[2 * (threadIdx.x >> 6) + 1] = (uint32_t)(om >> 32); }
+        if (threadIdx.x == 0) s_occ[kLdsRowCap / 32] = 0u;
+      }
       uint32_t total;
       const uint32_t off = block_excl_scan(len, s_w, &total);      // kLdsRowCap <= blockDim
       if ((int)threadIdx.x < rows) s_roff[threadIdx.x] = off;
@@ -1091,15 +1100,26 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
       Best best = {INFINITY, -1, INFINITY};
       if (x0 <= x1 && y0 <= y1 && z0 <= z1) {
         const float slack = 2.0e-3f * h;
+        // The rows (z, y) of the query's block in ascending order.  With the box's points staged in LDS only the rows that hold
+        // any are visited (s_occ): around a surface most rows of a ball are empty, and a row costs ~50 vector instructions before
+        // its first candidate whether it has one or not.  (A block spans at most 31 rows in y: the search radius is capped at 14
+        // cells, sync_options.)
+        const uint32_t ymask = (2u << (y1 - y0)) - 1u;
         for (int z = z0; z <= z1; ++z) {
           const float zl = oz + (float)z * h;
           const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + h)) - slack, 0.f);
-          for (int y = y0; y <= y1; ++y) {
+          const int ra = (z - Z0) * nyl + (y0 - Y0);                 // staged row of (z, y0) (LDS paths)
+          uint32_t m = ymask;
+          if (pts_lds) m &= __builtin_amdgcn_alignbit(s_occ[(ra >> 5) + 1], s_occ[ra >> 5], (uint32_t)(ra & 31));
+          while (m) {
+            const int bpos = __ffs((int)m) - 1;
+            m &= m - 1u;
+            const int y = y0 + bpos;
             const float yl = oy + (float)y * h;
             const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + h)) - slack, 0.f);
             if (fmaf(dy, dy, dz * dz) > R2) continue;              // the row lies outside the ball
             if (pts_lds) {
-              const int r = (z - Z0) * nyl + (y - Y0);
+              const int r = ra + bpos;
               const int rb = r * nxl - X0;
               const uint32_t g0 = s_tab[rb + X0];
               const uint32_t k0 = s_roff[r] + (s_tab[rb + x0] - g0), k1 = s_roff[r] + (s_tab[rb + x1 + 1] - g0);
@@ -1108,7 +1128,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
                 test_ascending_ru(t, __float_as_int(t.w), qx, qy, qz, best);
               }
             } else if (use_lds) {
-              const int rb = ((z - Z0) * nyl + (y - Y0)) * nxl - X0;
+              const int rb = (ra + bpos) * nxl - X0;
               sweep_run(tq, s_tab[rb + x0], s_tab[rb + x1 + 1], qx, qy, qz, best);
             } else {
               uint32_t sb, se;
@@ -1123,11 +1143,11 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
       if (best.d2 <= R2) {                  // exact: everything within sqrt(R2) was seen
         d2out = best.d2;
         jout = best.j;
-        lbout = sqrtf(fminf(best.s2, R2));  // every other point is at least this far
+        lbout = __builtin_amdgcn_sqrtf(fminf(best.s2, R2));  // every other point is at least this far
       } else {                              // certified lower bound
         d2out = R2;
         jout = best.j >= 0 ? best.j : jseed;
-        lbout = -sqrtf(R2);
+        lbout = -__builtin_amdgcn_sqrtf(R2);
         hard2 = true;
         min_lb = min(min_lb, __float_as_uint(R2));
       }
@@ -1135,7 +1155,10 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_lds(IcpDev b, int nblk)
       b.d2[so + gi] = d2out;
       b.idx[so + gi] = jout;
       // |s| of the query from its transformed position: M is rigid, so |s| = |q - t|
-      st_lb(b, so + gi, with_pot(lbout, pot_at(pot, norm3(qx - Mtx, qy - Mty, qz - Mtz))));
+      {
+        const float ux = qx - Mtx, uy = qy - Mty, uz = qz - Mtz;
+        st_lb(b, so + gi, with_pot(lbout, pot_at(pot, __builtin_amdgcn_sqrtf(fmaf(uz, uz, fmaf(uy, uy, ux * ux))))));
+      }
       const uint32_t key = __float_as_uint(d2out);
       if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
     }

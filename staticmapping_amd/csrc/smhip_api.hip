@@ -474,6 +474,9 @@ void sync_options(smhip_context* h) {
   h->dev.cap_factor = h->opts.ball_cap_factor > 1.0f ? h->opts.ball_cap_factor : 1.5f;
   h->dev.exact_all = h->opts.exact_matches;
   h->dev.ball_radius = h->opts.ball_radius > 0 ? h->opts.ball_radius : 0.3f;
+  // (the ball search walks a query's rows through a 32-bit mask: at most 14 cells of radius, 3.5 m with the default cell -- a larger
+  // radius only moves the point from which the ring search takes over, never the result)
+  h->dev.ball_radius = std::min(h->dev.ball_radius, 14.0f * h->dev.grid_cell);
   { const char* e = std::getenv("SMHIP_DEBUG_FLAGS"); h->dev.debug_flags = e ? std::atoi(e) : 0; }
   h->dev.fused = 0;
   h->dev.band_pad = 0.25f; h->dev.band_gain = 1.5f;              // tuning only: results do not depend on the band, only how often it holds

@@ -120,7 +120,10 @@ def test_gicp_alone_matches_oracle(clouds, matcher):
     want = ong.gicp_align(ds, dt, guess.astype(np.float32))
     da, dtv = sm.se3_error(res, want["result"].astype(np.float64))
     print(f"[gicp alone] device vs oracle: {da:.3e} rad {dtv:.3e} m")
-    assert da < 3e-3 and dtv < 5e-2, (da, dtv, matcher.last_gicp_stats, want["iterations"])
+    # north_star's tolerance.  Measured on this case: 1.9e-9 rad / 0 m (device and oracle take the same line-search decisions
+    # throughout); the oracle's own repeatability under legal float roundings is 3.7e-4 rad / 0.14 m on another pair
+    # (tests/test_oracle_ndt_gicp.py), so a failure here after a change means a decision flipped, not necessarily an error
+    assert da < 1e-4 and dtv < 1e-3, (da, dtv, matcher.last_gicp_stats, want["iterations"], "measured 1.9e-9 rad / 0 m when written")
     assert abs(fit - want["score"]) < 0.05 * max(1e-3, want["score"])
     assert abs(matcher.last_gicp_stats["gicp_iterations"] - want["iterations"]) <= 2
 
@@ -147,7 +150,8 @@ def test_ndt_gicp_align_matches_oracle(clouds, matcher):
     assert ok and want["ok"]
     da, dtv = sm.se3_error(res, want["result"])
     print(f"[ndt + gicp] device vs oracle: {da:.3e} rad {dtv:.3e} m")
-    assert da < 3e-3 and dtv < 5e-2, (da, dtv, matcher.last_gicp_stats)
+    # north_star's tolerance for the whole matcher; measured on this case 2.3e-10 rad / 3.7e-9 m
+    assert da < 1e-4 and dtv < 1e-3, (da, dtv, matcher.last_gicp_stats, "measured 2.3e-10 rad / 3.7e-9 m when written")
     assert abs(matcher.get_fitness_score() - want["score"]) < 2e-2
     da, dtv = sm.se3_error(res, T)
     assert da < 3e-3 and dtv < 0.06

@@ -2379,7 +2379,18 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   __shared__ double s_part[8][32];
   __shared__ uint32_t s_keys[kFinalizeKeyCap];
   uint32_t* gh = b.hist + (size_t)pair * kHistBins;
+#if SMHIP_PHASE_TIMING
+  // diagnostic build, SMHIP_DEBUG_FLAGS=32: wall-clock stamps (100 MHz) of thread 0 of the launch's first pair at the phase boundaries
+  const bool ftime = (b.debug_flags & 32) && threadIdx.x == 0;          // (prints the workgroups that took more than 60 us)
+  unsigned long long fstamp[8];
+  int fk = 0;
+#define SMHIP_FPH() do { if (ftime && fk < 8) fstamp[fk++] = wall_clock64(); } while (0)
+#else
+#define SMHIP_FPH() do { } while (0)
+#endif
+  SMHIP_FPH();
   find_quantile_bin(gh, b.rho, s_w, s_q);
+  SMHIP_FPH();
   const uint32_t qbin = s_q[0], below = s_q[1], n_valid = s_q[2], krank = s_q[3];
   const int ns = st->ns;
   // This iteration's sums come in one of two forms.  Plain: `accumulate` ran with the quantile's bin known -- rows [0, nblk) of
@@ -2401,7 +2412,6 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   const float4* ra = b.rec_a + (size_t)pair * 2 * b.bl_stride;
   const int32_t* rj = b.rec_j + (size_t)pair * 2 * b.bl_stride;
   __shared__ uint32_t s_off[2 * kFinalizeMaxSeg];
-  __shared__ uint32_t s_pos[kFinalizeKeyCap];
   // where the k-th record of segment sg sits
   auto rec_at = [&](int sg, int k) -> uint32_t {
     return sg < nseg0 ? (uint32_t)(sg * seg_len0 + k) : (uint32_t)(b.bl_stride + (sg - nseg0) * seg_len1 + k);
@@ -2478,9 +2488,11 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
     }
     __syncthreads();                                       // s_off is reused for the record segments below
   }
+  SMHIP_FPH();
   uint32_t limit_key = 0;
   int nb = 0;
   bool flat = false;
+  int top = 1;                                             // the first step of the lock-step segment searches below
   if (n_valid > 0) {
     const int per = (nseg + 255) >> 8;                     // <= kFinalizeMaxSeg / 256
     const int s0 = (int)threadIdx.x * per;
@@ -2496,14 +2508,15 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
 #pragma unroll
     for (int k = 0; k < kFinalizeMaxSeg / 256; ++k)
       if (k < per && s0 + k < nseg) { s_off[s0 + k] = o; o += c[k]; }
-    int top = 1;                                           // the first step of the segment search below
     while (2 * top < nseg) top *= 2;
     for (int x = nseg + (int)threadIdx.x; x < 2 * top; x += 256) s_off[x] = 0xffffffffu;
     nb = (int)total;
     flat = nb <= kFinalizeKeyCap;
     __syncthreads();
-    // lists that fit are cached in LDS: every record's key (d2's float bits) and position; longer lists (very large clouds, or
-    // many equal distances) are fetched again in every pass
+    // lists that fit have their keys (d2's float bits) cached in LDS for the select passes; longer lists (very large clouds, or
+    // many equal distances) are fetched again in every pass.  (Keys only: a record's position is found again by the same
+    // LDS-only segment search when it is summed -- 8 192 keys instead of 4 096 key / position pairs in the same 32 KiB, and a
+    // list that does not fit costs its workgroup ten times the others' time, which the whole launch then waits for.)
     if (flat && nb > 0) {
       constexpr int kPer = 16;                             // records per thread and round: two memory levels a round
       for (int r0 = 0; r0 < nb; r0 += kPer * 256) {        // workgroup-uniform
@@ -2530,12 +2543,13 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
           const int e = r0 + (int)threadIdx.x + 256 * k;
-          if (e < nb) { s_pos[e] = pos[k]; s_keys[e] = __float_as_uint(aa[k].w); }
+          if (e < nb) s_keys[e] = __float_as_uint(aa[k].w);
         }
       }
     }
     __syncthreads();
   }
+  SMHIP_FPH();
   if (n_valid > 0) {
     // exact rank (krank - below) inside the quantile's bin: radix select on the low 20 key bits of that bin's records
     uint32_t rank = krank - below;
@@ -2568,6 +2582,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
       __syncthreads();
     }
     limit_key = (qbin << kHistShift) | prefix;
+    SMHIP_FPH();
     // weights = (d2 <= limit)  (icp_fast.cc:497-498): every record at or below the quantile.  (Keys order like the floats: a
     // record of a lower bin of the band is below the limit whatever its low bits.)
     const size_t to = (size_t)pair * b.nt_cap;
@@ -2578,14 +2593,23 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
       for (int e0 = threadIdx.x; e0 < nb; e0 += kW * 256) {
         bool use[kW];
         uint32_t pos[kW];
-        int jj[kW];
+        int jj[kW], sg[kW];
         float4 s4[kW], q4[kW], n4[kW];
 #pragma unroll
         for (int k = 0; k < kW; ++k) {
           const int e = min(e0 + 256 * k, nb - 1);
           use[k] = e0 + 256 * k < nb && s_keys[e] <= limit_key;
-          pos[k] = s_pos[e];
+          sg[k] = 0;
         }
+        for (int step = top; step > 0; step >>= 1) {
+#pragma unroll
+          for (int k = 0; k < kW; ++k) {
+            const int cand = sg[k] + step;
+            sg[k] = s_off[cand] <= (uint32_t)min(e0 + 256 * k, nb - 1) ? cand : sg[k];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kW; ++k) pos[k] = rec_at(sg[k], min(e0 + 256 * k, nb - 1) - (int)s_off[sg[k]]);
 #pragma unroll
         for (int k = 0; k < kW; ++k) { s4[k] = ra[pos[k]]; jj[k] = max(rj[pos[k]], 0); }
 #pragma unroll
@@ -2605,6 +2629,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
       }
     }
   }
+  SMHIP_FPH();
   block_reduce29(acc, s_red, s_tot);
   // add the per-block partial sums of the accumulate kernel: 8 thread groups take every 8th block,
   // then one thread per column folds the 8 group sums -- a fixed order, so the result is reproducible
@@ -2625,6 +2650,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   for (int k = threadIdx.x; k < kHistBins; k += blockDim.x) gh[k] = 0;
   __syncthreads();
   if (threadIdx.x != 0) return;
+  SMHIP_FPH();
   st->fallback_total += st->unresolved_count;
   st->unresolved_count = 0;
   st->hard_total += st->hard_count;
@@ -2775,6 +2801,14 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
     st->done = 1;
     atomicAdd(b.done_count, 1u);
   }
+#if SMHIP_PHASE_TIMING
+  if (ftime && (wall_clock64() - fstamp[0]) > 6000ull) {
+    const unsigned long long tend = wall_clock64();
+    printf("[finalize] pair %d listed %u iter %d fused %d nb %d us: quantile %.1f listed %.1f records %.1f select %.1f sums %.1f fold %.1f tail %.1f total %.1f\n", pair, n_listed, st->iter, (int)fusedm, nb,
+           (fstamp[1] - fstamp[0]) * 0.01, (fstamp[2] - fstamp[1]) * 0.01, (fstamp[3] - fstamp[2]) * 0.01, (fstamp[4] - fstamp[3]) * 0.01,
+           (fstamp[5] - fstamp[4]) * 0.01, (fstamp[6] - fstamp[5]) * 0.01, (tend - fstamp[6]) * 0.01, (tend - fstamp[0]) * 0.01);
+  }
+#endif
 }
 
 // Slot-to-slot copy of the uploaded clouds (benchmark replication).

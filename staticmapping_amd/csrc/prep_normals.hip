@@ -862,9 +862,14 @@ hipError_t prep_calculate_normals_batch(PrepWorkspace* w, hipStream_t st, const 
   const int gl = (max_leaves + 255) / 256;
   hipLaunchKernelGGL(kd_leaf_normals, dim3(gl), dim3(256), 0, st, raw, ss, w->order[cur], w->leaves, w->counts, w->leaf_p, w->leaf_n, w->keys[0], w->leaf_id[0]);
   PCHK(hipMemcpyAsync(hp, w->counts, 12, hipMemcpyDeviceToHost, st));
+  const bool forest_used = S >= kForestMinScans;
+  if (forest_used) PCHK(hipMemcpyAsync(hp + 3, w->forest_status, 4, hipMemcpyDeviceToHost, st));
   PCHK(hipStreamSynchronize(st));
   const int nl = hp[2];
   for (int s2 = 0; s2 < S; ++s2) m_host[s2] = 0;
+  // kd_median_build reports a capacity overflow of its node / segment arrays here (sized for the leaf-size bounds of the split
+  // rule, so this means corrupted input): an incomplete tree must not be handed on as a prepared target
+  if (forest_used && hp[3] != 0) return hipErrorInvalidValue;
   if (nl <= 0 || nl > max_leaves) return hipSuccess;
   size_t bytes = w->sort_bytes;
   PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->leaf_id[0], w->leaf_id[1], (unsigned)nl, 0, 64, st));

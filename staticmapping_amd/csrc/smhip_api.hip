@@ -479,7 +479,7 @@ void sync_options(smhip_context* h) {
   h->dev.ball_radius = std::min(h->dev.ball_radius, 14.0f * h->dev.grid_cell);
   { const char* e = std::getenv("SMHIP_DEBUG_FLAGS"); h->dev.debug_flags = e ? std::atoi(e) : 0; }
   h->dev.fused = 0;
-  h->dev.band_pad = 0.25f; h->dev.band_gain = 1.5f;              // tuning only: results do not depend on the band, only how often it holds
+  h->dev.band_pad = 0.1f; h->dev.band_gain = 1.5f;              // tuning only: results do not depend on the band, only how often it holds
   { const char* e = std::getenv("SMHIP_BAND_PAD"); if (e && std::atof(e) >= 0.0) h->dev.band_pad = (float)std::atof(e); }
   { const char* e = std::getenv("SMHIP_BAND_GAIN"); if (e && std::atof(e) >= 0.0) h->dev.band_gain = (float)std::atof(e); }
   { const char* e = std::getenv("SMHIP_NABO_LISTED_BLOCKS"); if (e && std::atoi(e) > 0) h->nabo_listed_blocks = std::max(8, std::min(4096, std::atoi(e))); }   // >= 8: a workgroup's 16-bit histogram bins

@@ -120,7 +120,7 @@ struct IcpDev {
   int32_t seg_stride;        // gcount / dcount entries per pair
   int32_t fused;             // 1 = this iteration's launches belong to the fused path (nn_certify_acc + nn_ball_listed<true>):
                              //     nn_validate decides spec_ok, accumulate returns at once when it holds, finalize reads either form
-  float band_pad;            // half-width of the predicted band in bins, at least (tuning; default 0.25)
+  float band_pad;            // half-width of the predicted band in bins, at least (tuning; default 0.1)
   float band_gain;           // ... and this many times the quantile's last move (default 1.5)
   int32_t acc_items;         // points per thread of the accumulate launches of this batch part (finalize folds accordingly)
   PairState* state;

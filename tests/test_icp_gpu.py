@@ -550,3 +550,42 @@ def test_certificates_change_no_bit_at_full_size(smhip, cfg2, guess_name):
         assert key == ref, (name, st)
     assert searched["no_certify"] == 20 * len(src)
     assert searched["fused"] < 0.4 * searched["no_certify"]            # the certificates do hold for most queries
+
+
+@pytest.mark.parametrize("rho", [0.7, 0.35, 1.0])
+def test_fused_sums_in_a_ragged_batch(smhip, velo20k, cfg1, cfg2, rho):
+    """The fused certificate pass indexes its per-wave segments (failing certificates, band records) and rows by each pair's own
+    source size: 18 pairs of three very different sizes (5 k, 20 k, 120 k points; NaN points in some; one slot whose source
+    equals its target) in one batch, with the reference's early exit on, against the same batch with the passes kept apart --
+    the same iteration counts, kept sets and quantiles, poses to 1e-10; rho = 1 keeps every match (the quantile is the largest
+    distance; wherever a lower bound reaches it the bounds are refined and accumulate sums)."""
+    sm = smhip
+    from staticmapping_amd import synth
+    cases = [cfg2, velo20k, cfg1] * 6
+    cap_s = max(len(c["src"]) for c in cases); cap_t = max(len(c["q"]) for c in cases)
+    guesses = []
+    for k, c in enumerate(cases):
+        g = c.get("guess", np.eye(4))
+        guesses.append(g @ synth.make_pose(t=(0.01 * (k % 3), 0.0, 0.0), rpy_deg=(0, 0, 0.03 * (k % 4))))
+    out = {}
+    for name, opts in (("separate", dict(no_fused_sums=1)), ("fused", dict())):
+        m = sm.IcpFastHip(pair_slots=len(cases), max_source_points=cap_s, max_target_points=cap_t, max_iteration=30, early_exit=1,
+                          dist_outlier_ratio=rho, split_after=1, **opts)
+        for s_, c in enumerate(cases):
+            src = np.array(c["src"], dtype=np.float32, copy=True)
+            if s_ % 5 == 1:
+                src[7, 0] = np.nan; src[100, 2] = np.inf                     # non-finite points are ignored (icp_fast.cc: finite d2 only)
+            if s_ == 17:                                                     # identical clouds: every distance 0, bin 0 -- no prediction possible
+                src = np.concatenate([c["q"], np.zeros((len(c["q"]), src.shape[1] - 3))], axis=1).astype(np.float32)
+            m.set_input_source(src, slot=s_); m.set_input_target(c["q"], c["n"], slot=s_)
+        g = list(guesses); g[17] = np.eye(4)
+        out[name] = m.align_batch(len(cases), g)
+        m.close()
+    Rs, scs, sts = out["separate"]; Rf, scf, stf = out["fused"]
+    for s_ in range(len(cases)):
+        assert stf[s_]["iterations"] == sts[s_]["iterations"] and stf[s_]["kept"] == sts[s_]["kept"] and stf[s_]["limit_d2"] == sts[s_]["limit_d2"], (s_, stf[s_], sts[s_])
+        da, dt = sm.se3_error(Rf[s_], Rs[s_])
+        assert da < 1e-10 and dt < 1e-9, (s_, da, dt)
+        assert abs(scf[s_] - scs[s_]) < 1e-11
+    if rho < 1.0:
+        assert max(s_["fused_iterations"] for s_ in stf) > 0                 # the fused form did carry iterations

@@ -1921,7 +1921,7 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
 // histogram bins it can fall in next ([band_lo, band_hi], 1-3 bins of 2048) and this pass, which has point, match, matched
 // target point and distance in registers anyway, sums the certified matches below the band on the spot, drops those above
 // it, and leaves the band's members as records (source point, distance, match id) for finalize to select among.  The queries
-// whose certificate fails go to the wave's own segment of dlist; the listed search (nn_ball_listed<true>) finds their matches
+// whose certificate fails go to the wave's own segment of dlist; the listed search (nn_ball_listed_items) finds their matches
 // and sums / records them by the same rule.  nn_validate then checks the prediction against the completed histogram
 // (PairState::spec_ok); a miss costs one plain `accumulate` for that pair.  No atomics with a return value inside the loop
 // (the lists are per-wave segments, counted in SGPRs), so the two-deep load pipeline never drains.
@@ -2068,176 +2068,158 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify_acc(IcpDev b, int nblk)
   }
 }
 
-// The search of the queries whose certificate failed.  SEG = false: from the compacted list nn_certify filled with one atomic
-// per wave (dlist, deferred_count).  SEG = true (fused path): from the per-wave segments nn_certify_acc left (dcount; every
-// workgroup takes the prefix over them itself: <= 2 048 counts); a match found here whose distance falls in the predicted
-// quantile band becomes a record in the finding wave's own segment (region 1), like the certified ones of the fused pass;
-// the matches below the band are summed by finalize, which walks this list once more (a few thousand entries per pair:
-// summing them here would put 29 double accumulators into the search's register budget and halve its occupancy).
-template <bool SEG>
+// The search of the queries whose certificate failed (a few thousand per pair once the pose has settled, most of them in the
+// first iterations after the switch), with up to 16 lanes per query: the rows of the query's ball go round the lanes, the lanes'
+// results are merged with the sweep's tie rule.  One chunk of kNnThreads >> logL queries per call; `hard` / `band` / the record
+// fields come back for the caller's list handling.
+struct ListedCtx {
+  const uint2* __restrict__ words; const uint32_t* __restrict__ cstart; const float4* __restrict__ tq;
+  float ox, oy, oz, h, inv_h, r2cap;
+  int nx, ny, nz, wx;
+  bool have_prev;
+  Pot pot;
+};
+__device__ __forceinline__ ListedCtx listed_ctx(const IcpDev& b, const PairState* st, int pair) {
+  ListedCtx c;
+  c.words = b.words + (size_t)pair * kMaxGridWords;
+  c.cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
+  c.tq = b.tq + (size_t)pair * b.nt_cap;
+  c.ox = st->origin[0]; c.oy = st->origin[1]; c.oz = st->origin[2];
+  c.h = st->h; c.inv_h = st->inv_h; c.r2cap = st->rcap2;
+  c.nx = st->nx; c.ny = st->ny; c.nz = st->nz; c.wx = st->wx;
+  c.have_prev = st->iter > 0;
+  c.pot = {(float)st->pot_a, (float)st->pot_b, 0.f, 0.f};
+  return c;
+}
+// query i (or none: i < 0) searched by the L = 1 << logL lanes of its group; lane sub == 0 of the group stores the result
+__device__ __forceinline__ void listed_search_one(const IcpDev& b, const PairState* st, const ListedCtx& c, size_t so, int i, int sub, int L,
+                                                  uint32_t* s_hist, uint32_t& min_lb, bool& hard, bool track_band, int band_lo, int band_hi,
+                                                  bool& band, float4& srec, float& drec, int& jrec) {
+  if (i < 0) {
+    // (the butterfly below is executed by whole groups: a group without a query has nothing to merge, but lanes of other groups
+    // in the wave do -- __shfl_xor inside aligned groups never crosses into this one)
+    return;
+  }
+  const float4 s4 = ld_src(b, so + i);
+  double px, py, pz;
+  transform_point(st->M, s4, px, py, pz);
+  const float qx = (float)px, qy = (float)py, qz = (float)pz;
+  Best best = {INFINITY, -1, INFINITY};
+  const bool finite = isfinite(qx) && isfinite(qy) && isfinite(qz);
+  float R2 = c.r2cap;
+  int jp = -1;
+  if (finite) {
+    if (c.have_prev) {
+      jp = b.idx[so + i];
+      if (jp >= 0) {
+        double ux, uy, uz;
+        transform_point(st->M_prev, s4, ux, uy, uz);
+        const float ex = qx - (float)ux, ey = qy - (float)uy, ez = qz - (float)uz;
+        R2 = search_radius2(c.r2cap, dist2(c.tq[jp], qx, qy, qz), search_margin(sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)))));
+      }
+    }
+    // every target point within sqrt(R2) of q lies in a cell meeting [q - Rs, q + Rs]^3
+    const float Rs = sqrtf(R2) * 1.0001f + 1.0e-3f * c.h;
+    const int x0 = max(cell_coord(qx - Rs, c.ox, c.inv_h), 0), x1 = min(cell_coord(qx + Rs, c.ox, c.inv_h), c.nx - 1);
+    const int y0 = max(cell_coord(qy - Rs, c.oy, c.inv_h), 0), y1 = min(cell_coord(qy + Rs, c.oy, c.inv_h), c.ny - 1);
+    const int z0 = max(cell_coord(qz - Rs, c.oz, c.inv_h), 0), z1 = min(cell_coord(qz + Rs, c.oz, c.inv_h), c.nz - 1);
+    const int nyr = y1 - y0 + 1;
+    const int nrows = (x0 <= x1 && y0 <= y1 && z0 <= z1) ? nyr * (z1 - z0 + 1) : 0;
+    const float slack = 2.0e-3f * c.h;
+    for (int r = sub; r < nrows; r += L) {              // this lane's rows of the ball
+      const int zr = r / nyr;
+      const int z = z0 + zr, y = y0 + (r - zr * nyr);
+      const float zl = c.oz + (float)z * c.h, yl = c.oy + (float)y * c.h;
+      const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + c.h)) - slack, 0.f);
+      const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + c.h)) - slack, 0.f);
+      if (fmaf(dy, dy, dz * dz) > R2) continue;          // the row lies outside the ball
+      uint32_t sb, se;
+      row_slots(c.words, (z * c.ny + y) * c.wx, x0, x1, sb, se);
+      if (se > sb) {
+        const uint32_t j0 = c.cstart[sb], j1 = c.cstart[se];
+        for (uint32_t j = j0; j < j1; ++j) test_ascending_ru(c.tq[j], (int)j, qx, qy, qz, best);
+      }
+    }
+  }
+  // merge the L lanes of the query (butterfly inside aligned groups of L lanes; every lane ends with the result)
+  for (int off = 1; off < L; off <<= 1) {
+    const float od = __shfl_xor(best.d2, off, 64), os = __shfl_xor(best.s2, off, 64);
+    const int oj = __shfl_xor(best.j, off, 64);
+    best.s2 = fminf(fminf(best.s2, os), fmaxf(best.d2, od));
+    if (od < best.d2 || (od == best.d2 && (unsigned)oj < (unsigned)best.j)) { best.d2 = od; best.j = oj; }
+  }
+  if (sub == 0) {
+    float d2out = INFINITY, lbout = 0.f;
+    int jout = -1;
+    if (finite) {
+      if (best.d2 <= R2) {                  // exact: everything within sqrt(R2) was seen
+        d2out = best.d2;
+        jout = best.j;
+        lbout = sqrtf(fminf(best.s2, R2));  // every other point is at least this far
+        if (track_band) {                   // in the predicted quantile band: a record for finalize's select
+          const int bin = (int)(__float_as_uint(d2out) >> kHistShift);
+          band = bin >= band_lo && bin <= band_hi;
+          srec = s4; drec = d2out; jrec = jout;
+        }
+      } else {                              // certified lower bound: nothing lies within sqrt(R2)
+        d2out = R2;
+        jout = best.j >= 0 ? best.j : jp;   // an upper-bound seed for later iterations
+        lbout = -sqrtf(R2);
+        hard = true;
+        min_lb = min(min_lb, __float_as_uint(R2));
+      }
+    }
+    b.d2[so + i] = d2out;
+    b.idx[so + i] = jout;
+    st_lb(b, so + i, with_pot(lbout, pot_at(c.pot, norm3(s4.x, s4.y, s4.z))));
+    const uint32_t key = __float_as_uint(d2out);
+    if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
+  }
+}
+// lanes per query for a list of `count` entries: as many (a power of two, at most 16) as keep kListedBlocks workgroups busy
+__device__ __forceinline__ int listed_lanes_log2(int count) {
+  int L = 1, logL = 0;
+  while (L < 16 && 2 * L * count <= kListedBlocks * kNnThreads) { L *= 2; ++logL; }
+  return logL;
+}
+__device__ __forceinline__ void listed_append_hard(const IcpDev& b, PairState* st, size_t so, bool hard, int i, int lane) {
+  const unsigned long long hm = __ballot(hard);
+  if (hm) {
+    uint32_t basepos = 0;
+    if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
+    basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);   // lane 0 did the atomic
+    if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
+  }
+}
+
+// From the compacted list nn_certify filled with one atomic per wave (dlist, deferred_count): kListedBlocks workgroups per pair
+// stride over it.
 __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_listed(IcpDev b, int nblk) {
   int pair, blk;
   if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
   PairState* st = &b.state[pair];
   if (st->done) return;
-  __shared__ uint32_t s_hist[kHistBins];
-  __shared__ uint32_t s_w[17];
-  __shared__ uint32_t s_off[SEG ? 2 * kFinalizeMaxSeg : 1];
-  const int lane = threadIdx.x & 63;
-  const size_t so = (size_t)pair * b.ns_cap;
-  constexpr int kSegLen0 = 64 * kCertifyItems;
-  const int32_t* __restrict__ dl = SEG ? b.dlist + (size_t)pair * b.dl_stride : b.dlist + so;
-  int count, nseg0 = 0, top = 1;
-  if (SEG) {
-    nseg0 = ((st->ns + kNnThreads * kCertifyItems - 1) / (kNnThreads * kCertifyItems)) * (kNnThreads / 64);
-    const int32_t* __restrict__ dc = b.dcount + (size_t)pair * b.seg_stride;
-    const int per = (nseg0 + 255) >> 8;                    // <= kFinalizeMaxSeg / 256
-    const int s0 = (int)threadIdx.x * per;
-    uint32_t c[kFinalizeMaxSeg / 256];
-    uint32_t mine = 0;
-#pragma unroll
-    for (int k = 0; k < kFinalizeMaxSeg / 256; ++k) {
-      c[k] = (k < per && s0 + k < nseg0) ? (uint32_t)dc[s0 + k] : 0u;
-      mine += c[k];
-    }
-    uint32_t total;
-    uint32_t o = block_excl_scan(mine, s_w, &total);
-#pragma unroll
-    for (int k = 0; k < kFinalizeMaxSeg / 256; ++k)
-      if (k < per && s0 + k < nseg0) { s_off[s0 + k] = o; o += c[k]; }
-    while (2 * top < nseg0) top *= 2;
-    for (int x = nseg0 + (int)threadIdx.x; x < 2 * top; x += kNnThreads) s_off[x] = 0xffffffffu;
-    count = (int)total;
-    if (blk == 0 && threadIdx.x == 0) st->deferred_count = total;      // (statistics; finalize reads it after this launch)
-  } else {
-    count = (int)st->deferred_count;
-  }
-  // entry e of the pair's list: SEG -- the (e - s_off[seg])-th entry of the last segment with s_off[seg] <= e
-  auto entry = [&](int e) -> int {
-    if (!SEG) return dl[e];
-    int sg = 0;
-    for (int step = top; step > 0; step >>= 1) { const int cand = sg + step; sg = s_off[cand] <= (uint32_t)e ? cand : sg; }
-    return dl[(size_t)sg * kSegLen0 + (e - (int)s_off[sg])];
-  };
-  int L = 1, logL = 0;
-  while (L < 16 && 2 * L * count <= nblk * kNnThreads) { L *= 2; ++logL; }
+  const int count = (int)st->deferred_count;
+  if (count == 0) return;
+  const int logL = listed_lanes_log2(count), L = 1 << logL;
   const int qpb = kNnThreads >> logL;                      // queries per workgroup and pass
-  const int band_lo = SEG ? st->band_lo : 0, band_hi = SEG ? st->band_hi : -1;
-  const int seg1 = blk * (kNnThreads / 64) + (int)(threadIdx.x >> 6);                // this wave's record segment (region 1)
-  const bool active = count > 0 && blk * qpb < count;      // workgroup-uniform
-  if (!active) {
-    if (SEG && band_lo > 0 && lane == 0) b.gcount[(size_t)pair * b.seg_stride + nseg0 + seg1] = 0u;     // finalize indexes every listed segment
-    return;
-  }
-  const size_t recbase = (size_t)pair * 2 * b.bl_stride + (size_t)b.bl_stride + (size_t)seg1 * (size_t)(b.bl_stride / (kListedBlocks * (kNnThreads / 64)));
-  int nrec = 0;
+  if (blk * qpb >= count) return;
+  __shared__ uint32_t s_hist[kHistBins];
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
   __syncthreads();
+  const int lane = threadIdx.x & 63;
   const int sub = (int)threadIdx.x & (L - 1), ql = (int)threadIdx.x >> logL;
-  const uint2* __restrict__ words = b.words + (size_t)pair * kMaxGridWords;
-  const uint32_t* __restrict__ cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
-  const float4* __restrict__ tq = b.tq + (size_t)pair * b.nt_cap;
-  const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
-  const float h = st->h, inv_h = st->inv_h;
-  const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
-  const float r2cap = st->rcap2;
-  const bool have_prev = st->iter > 0;
-  const Pot pot = {(float)st->pot_a, (float)st->pot_b, 0.f, 0.f};
+  const size_t so = (size_t)pair * b.ns_cap;
+  const ListedCtx c = listed_ctx(b, st, pair);
   uint32_t min_lb = 0xffffffffu;
   for (int base = blk * qpb; base < count; base += nblk * qpb) {        // workgroup-uniform
     const int e = base + ql;
     bool hard = false, band = false;
-    int i = -1, jrec = -1;
-    float drec = 0.f;
-    float4 srec = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e < count) {
-      i = entry(e);
-      const float4 s4 = ld_src(b, so + i);
-      double px, py, pz;
-      transform_point(st->M, s4, px, py, pz);
-      const float qx = (float)px, qy = (float)py, qz = (float)pz;
-      Best best = {INFINITY, -1, INFINITY};
-      const bool finite = isfinite(qx) && isfinite(qy) && isfinite(qz);
-      float R2 = r2cap;
-      int jp = -1;
-      if (finite) {
-        if (have_prev) {
-          jp = b.idx[so + i];
-          if (jp >= 0) {
-            double ux, uy, uz;
-            transform_point(st->M_prev, s4, ux, uy, uz);
-            const float ex = qx - (float)ux, ey = qy - (float)uy, ez = qz - (float)uz;
-            R2 = search_radius2(r2cap, dist2(tq[jp], qx, qy, qz), search_margin(sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)))));
-          }
-        }
-        // every target point within sqrt(R2) of q lies in a cell meeting [q - Rs, q + Rs]^3
-        const float Rs = sqrtf(R2) * 1.0001f + 1.0e-3f * h;
-        const int x0 = max(cell_coord(qx - Rs, ox, inv_h), 0), x1 = min(cell_coord(qx + Rs, ox, inv_h), nx - 1);
-        const int y0 = max(cell_coord(qy - Rs, oy, inv_h), 0), y1 = min(cell_coord(qy + Rs, oy, inv_h), ny - 1);
-        const int z0 = max(cell_coord(qz - Rs, oz, inv_h), 0), z1 = min(cell_coord(qz + Rs, oz, inv_h), nz - 1);
-        const int nyr = y1 - y0 + 1;
-        const int nrows = (x0 <= x1 && y0 <= y1 && z0 <= z1) ? nyr * (z1 - z0 + 1) : 0;
-        const float slack = 2.0e-3f * h;
-        for (int r = sub; r < nrows; r += L) {              // this lane's rows of the ball
-          const int zr = r / nyr;
-          const int z = z0 + zr, y = y0 + (r - zr * nyr);
-          const float zl = oz + (float)z * h, yl = oy + (float)y * h;
-          const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + h)) - slack, 0.f);
-          const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + h)) - slack, 0.f);
-          if (fmaf(dy, dy, dz * dz) > R2) continue;          // the row lies outside the ball
-          uint32_t sb, se;
-          row_slots(words, (z * ny + y) * wx, x0, x1, sb, se);
-          if (se > sb) {
-            const uint32_t j0 = cstart[sb], j1 = cstart[se];
-            for (uint32_t j = j0; j < j1; ++j) test_ascending_ru(tq[j], (int)j, qx, qy, qz, best);
-          }
-        }
-      }
-      // merge the L lanes of the query (butterfly inside aligned groups of L lanes; every lane ends with the result)
-      for (int off = 1; off < L; off <<= 1) {
-        const float od = __shfl_xor(best.d2, off, 64), os = __shfl_xor(best.s2, off, 64);
-        const int oj = __shfl_xor(best.j, off, 64);
-        best.s2 = fminf(fminf(best.s2, os), fmaxf(best.d2, od));
-        if (od < best.d2 || (od == best.d2 && (unsigned)oj < (unsigned)best.j)) { best.d2 = od; best.j = oj; }
-      }
-      if (sub == 0) {
-        float d2out = INFINITY, lbout = 0.f;
-        int jout = -1;
-        if (finite) {
-          if (best.d2 <= R2) {                  // exact: everything within sqrt(R2) was seen
-            d2out = best.d2;
-            jout = best.j;
-            lbout = sqrtf(fminf(best.s2, R2));  // every other point is at least this far
-            if (SEG) {                          // in the predicted quantile band: a record for finalize's select
-              const int bin = (int)(__float_as_uint(d2out) >> kHistShift);
-              band = bin >= band_lo && bin <= band_hi;
-              srec = s4; drec = d2out; jrec = jout;
-            }
-          } else {                              // certified lower bound: nothing lies within sqrt(R2)
-            d2out = R2;
-            jout = best.j >= 0 ? best.j : jp;   // an upper-bound seed for later iterations
-            lbout = -sqrtf(R2);
-            hard = true;
-            min_lb = min(min_lb, __float_as_uint(R2));
-          }
-        }
-        b.d2[so + i] = d2out;
-        b.idx[so + i] = jout;
-        st_lb(b, so + i, with_pot(lbout, pot_at(pot, norm3(s4.x, s4.y, s4.z))));
-        const uint32_t key = __float_as_uint(d2out);
-        if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
-      }
-    }
-    if (SEG) emit_record(b, recbase, nrec, band, srec, drec, jrec);
-    const unsigned long long hm = __ballot(hard);
-    if (hm) {
-      uint32_t basepos = 0;
-      if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
-      basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);   // lane 0 did the atomic
-      if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
-    }
+    float4 srec; float drec; int jrec;
+    const int i = e < count ? b.dlist[so + e] : -1;
+    listed_search_one(b, st, c, so, i, sub, L, s_hist, min_lb, hard, false, 0, -1, band, srec, drec, jrec);
+    listed_append_hard(b, st, so, hard, i, lane);
   }
-  if (SEG && band_lo > 0 && lane == 0) b.gcount[(size_t)pair * b.seg_stride + nseg0 + seg1] = (uint32_t)nrec;
   if (min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
   __syncthreads();
   uint32_t* gh = b.hist + (size_t)pair * kHistBins;
@@ -2245,6 +2227,168 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_listed(IcpDev b, int nb
     const uint32_t v = s_hist[k];
     if (v) atomicAdd(&gh[k], v);
   }
+}
+
+// Fused path.  The fused certificate pass leaves the failing queries in per-wave segments of dlist (dcount).  Their number differs
+// wildly from pair to pair -- in one iteration of the bench batch a median pair lists 2 500 queries and the worst 16 000; with
+// half the guesses poor the spread is 100 to 117 000 -- and a launch that gives every pair the same workgroups lasts as long as
+// its worst pair.  So: listed_plan (a workgroup per pair) turns the segment counts into offsets, totals the list and cuts it into
+// ITEMS of one pass each (kNnThreads >> logL consecutive entries, logL from the list's length); nn_ball_listed_items is a
+// fixed grid of workgroups that takes the items of ALL pairs of the launch in turn.  A match found here whose distance falls
+// in the predicted quantile band becomes a record in its item's segment of region 1 (compacted inside the workgroup, in list
+// order); the matches below the band are summed by finalize, which walks the list once more.
+__global__ __launch_bounds__(256) void listed_plan(IcpDev b) {
+  const int pair = b.pair_base + blockIdx.x;
+  PairState* st = &b.state[pair];
+  __shared__ uint32_t s_w[17];
+  int32_t* dc = b.dcount + (size_t)pair * b.seg_stride;
+  const int nseg0 = ((st->ns + kNnThreads * kCertifyItems - 1) / (kNnThreads * kCertifyItems)) * (kNnThreads / 64);
+  const int per = (nseg0 + 255) >> 8;                      // <= kFinalizeMaxSeg / 256
+  const int s0 = (int)threadIdx.x * per;
+  uint32_t c[kFinalizeMaxSeg / 256];
+  uint32_t mine = 0;
+  const bool live = !st->done;                              // (a finished pair's certificate pass did not run: its counts are stale)
+#pragma unroll
+  for (int k = 0; k < kFinalizeMaxSeg / 256; ++k) {
+    c[k] = (live && k < per && s0 + k < nseg0) ? (uint32_t)dc[s0 + k] : 0u;
+    mine += c[k];
+  }
+  uint32_t total;
+  uint32_t o = block_excl_scan(mine, s_w, &total);
+#pragma unroll
+  for (int k = 0; k < kFinalizeMaxSeg / 256; ++k)
+    if (k < per && s0 + k < nseg0) { dc[s0 + k] = (int32_t)o; o += c[k]; }          // counts -> exclusive offsets, in place
+  if (threadIdx.x == 0) {
+    if (blockIdx.x == 0) st->listed_ticket = 0;
+    dc[nseg0] = (int32_t)total;
+    st->deferred_count = total;
+    const int qpb = kNnThreads >> listed_lanes_log2((int)total);
+    b.litems[pair] = total ? (total + qpb - 1) / qpb : 0u;
+  }
+}
+
+__global__ __launch_bounds__(kNnThreads, 5) void nn_ball_listed_items(IcpDev b) {
+  __shared__ uint32_t s_hist[kHistBins];
+  __shared__ uint32_t s_w[17];
+  __shared__ uint32_t s_plan[kListedMaxPairs + 1];         // items before pair p of the launch
+  __shared__ uint32_t s_off[2 * kFinalizeMaxSeg];          // the current pair: entries before each segment of its list
+  __shared__ uint32_t s_wc[2][kNnThreads / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int np = b.npairs;
+  {
+    constexpr int kPer = kListedMaxPairs / kNnThreads;
+    const int per = (np + kNnThreads - 1) / kNnThreads;
+    const int p0 = (int)threadIdx.x * per;
+    uint32_t v[kPer], mine = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) { v[k] = (k < per && p0 + k < np) ? b.litems[b.pair_base + p0 + k] : 0u; mine += v[k]; }
+    uint32_t total;
+    uint32_t o = block_excl_scan(mine, s_w, &total);
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) if (k < per && p0 + k < np) { s_plan[p0 + k] = o; o += v[k]; }
+    if (threadIdx.x == 0) s_plan[np] = total;
+    __syncthreads();
+  }
+  // The items go to the workgroups a few at a time (a ticket counter in the launch's first pair: an item's cost depends on how
+  // many rows its queries' balls cross, so equal runs fixed in advance end unevenly); consecutive items mostly belong to one pair.
+  const int nitems = (int)s_plan[np];
+  __shared__ uint32_t s_ticket;
+  const int grain = b.listed_grain;
+  int it0, it1;
+  if (grain > 0) {
+    it0 = it1 = 0;
+  } else {
+    const int nwg = (int)gridDim.x;
+    const int vb = ((int)blockIdx.x & 7) * (nwg >> 3) + ((int)blockIdx.x >> 3);     // gridDim.x is a multiple of 8
+    it0 = (int)(((long long)vb * nitems) / nwg); it1 = (int)(((long long)(vb + 1) * nitems) / nwg);
+    if (it0 >= it1) return;
+  }
+  int lo = 0;
+  int cur = -1, count = 0, logL = 0, nseg0 = 0, top = 1, band_lo = 0, band_hi = -1;
+  uint32_t min_lb = 0xffffffffu;
+  ListedCtx c;
+  PairState* st = nullptr;
+  auto flush = [&]() {                                     // the finished pair's histogram and smallest lower bound
+    if (min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
+    min_lb = 0xffffffffu;
+    __syncthreads();
+    uint32_t* gh = b.hist + (size_t)(b.pair_base + cur) * kHistBins;
+    for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
+      const uint32_t v = s_hist[k];
+      if (v) atomicAdd(&gh[k], v);
+    }
+    __syncthreads();
+  };
+  for (int item = it0;; ++item) {                          // workgroup-uniform
+    if (item >= it1) {
+      if (grain <= 0) break;
+      __syncthreads();
+      if (threadIdx.x == 0) s_ticket = atomicAdd(&b.state[b.pair_base].listed_ticket, (uint32_t)grain);
+      __syncthreads();
+      it0 = (int)min(s_ticket, (uint32_t)nitems);
+      it1 = min(it0 + grain, nitems);
+      if (it0 >= it1) break;
+      item = it0;
+      int hi = np - 1;                                     // the last pair with s_plan[p] <= it0 (pairs without items: equal entries)
+      lo = 0;
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_plan[mid] <= (uint32_t)it0) lo = mid; else hi = mid - 1; }
+    }
+    while (s_plan[lo + 1] <= (uint32_t)item) ++lo;
+    if (lo != cur) {
+      if (cur >= 0) flush();
+      cur = lo;
+      const int pair = b.pair_base + cur;
+      st = &b.state[pair];
+      const int32_t* __restrict__ dc = b.dcount + (size_t)pair * b.seg_stride;
+      nseg0 = ((st->ns + kNnThreads * kCertifyItems - 1) / (kNnThreads * kCertifyItems)) * (kNnThreads / 64);
+      count = dc[nseg0];
+      logL = listed_lanes_log2(count);
+      for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+      top = 1;
+      while (2 * top < nseg0) top *= 2;
+      for (int x = threadIdx.x; x < 2 * top; x += kNnThreads) s_off[x] = x < nseg0 ? (uint32_t)dc[x] : 0xffffffffu;
+      c = listed_ctx(b, st, pair);
+      // (a list beyond kFusedListedMax: nn_validate drops the speculation and accumulate makes the records)
+      band_lo = count <= kFusedListedMax ? st->band_lo : 0;
+      band_hi = st->band_hi;
+      __syncthreads();
+    }
+    const int pair = b.pair_base + cur;
+    const int chunk = item - (int)s_plan[cur];
+    const int L = 1 << logL, qpb = kNnThreads >> logL;
+    const int sub = (int)threadIdx.x & (L - 1), ql = (int)threadIdx.x >> logL;
+    const size_t so = (size_t)pair * b.ns_cap;
+    const int e = chunk * qpb + ql;
+    int i = -1;
+    if (e < count) {                                       // entry e = the (e - s_off[seg])-th of the last segment with s_off[seg] <= e
+      const int32_t* __restrict__ dl = b.dlist + (size_t)pair * b.dl_stride;
+      int sg = 0;
+      for (int step = top; step > 0; step >>= 1) { const int cand = sg + step; sg = s_off[cand] <= (uint32_t)e ? cand : sg; }
+      i = dl[(size_t)sg * (64 * kCertifyItems) + (e - (int)s_off[sg])];
+    }
+    bool hard = false, band = false;
+    float4 srec = make_float4(0.f, 0.f, 0.f, 0.f);
+    float drec = 0.f;
+    int jrec = -1;
+    listed_search_one(b, st, c, so, i, sub, L, s_hist, min_lb, hard, band_lo > 0, band_lo, band_hi, band, srec, drec, jrec);
+    listed_append_hard(b, st, so, hard, i, lane);
+    if (band_lo > 0) {                                     // the item's records: compacted in list order inside the workgroup
+      const unsigned long long bm = __ballot(band);
+      uint32_t* wc = s_wc[item & 1];
+      if (lane == 0) wc[wave] = (uint32_t)__popcll(bm);
+      __syncthreads();
+      uint32_t before = 0, all = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < kNnThreads / 64; ++w2) { const uint32_t n2 = wc[w2]; before += w2 < wave ? n2 : 0u; all += n2; }
+      if (band) {
+        const size_t at = (size_t)pair * 2 * b.bl_stride + (size_t)b.bl_stride + (size_t)chunk * qpb + before + __popcll(bm & ((1ull << lane) - 1ull));
+        b.rec_a[at] = make_float4(srec.x, srec.y, srec.z, drec);
+        b.rec_j[at] = jrec;
+      }
+      if (threadIdx.x == 0) b.gcount[(size_t)pair * b.seg_stride + nseg0 + chunk] = all;
+    }
+  }
+  if (cur >= 0) flush();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2406,8 +2550,9 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   const int nblk = (ns + chunk - 1) / chunk;
   const int nseg0 = nblk * 4;                                   // 4 waves per workgroup in both producers
   const int seg_len0 = chunk / 4;
-  const int nseg = nseg0 + (fusedm ? kListedBlocks * 4 : 0);
-  const int seg_len1 = b.bl_stride / (kListedBlocks * 4);
+  // (region 1: one segment per item of the listed search, as long as the item's queries -- listed_plan's cut of the list)
+  const int nseg = nseg0 + (fusedm ? (int)b.litems[pair] : 0);
+  const int seg_len1 = kNnThreads >> listed_lanes_log2((int)st->deferred_count);
   const uint32_t* gcount = b.gcount + (size_t)pair * b.seg_stride;
   const float4* ra = b.rec_a + (size_t)pair * 2 * b.bl_stride;
   const int32_t* rj = b.rec_j + (size_t)pair * 2 * b.bl_stride;
@@ -2436,25 +2581,12 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
     // dcount) have exact matches from the listed search now; those below the band are kept whatever the quantile turns out to
     // be inside it -- summed here, eight entries per thread and round with their loads issued level by level.  (Lower-bounded
     // ones lie above the quantile: nn_validate checked that, or the iteration would not be in this form.)
-    const int32_t* dc = b.dcount + (size_t)pair * b.seg_stride;
+    const int32_t* dc = b.dcount + (size_t)pair * b.seg_stride;      // (listed_plan: entries before each segment, the total behind them)
     const int32_t* dl = b.dlist + (size_t)pair * b.dl_stride;
-    const int per = (nseg0 + 255) >> 8;
-    const int s0 = (int)threadIdx.x * per;
-    uint32_t c[kFinalizeMaxSeg / 256];
-    uint32_t mine = 0;
-#pragma unroll
-    for (int k = 0; k < kFinalizeMaxSeg / 256; ++k) {
-      c[k] = (k < per && s0 + k < nseg0) ? (uint32_t)dc[s0 + k] : 0u;
-      mine += c[k];
-    }
-    uint32_t total;
-    uint32_t o = block_excl_scan(mine, s_w, &total);
-#pragma unroll
-    for (int k = 0; k < kFinalizeMaxSeg / 256; ++k)
-      if (k < per && s0 + k < nseg0) { s_off[s0 + k] = o; o += c[k]; }
     int top = 1;
     while (2 * top < nseg0) top *= 2;
-    for (int x = nseg0 + (int)threadIdx.x; x < 2 * top; x += 256) s_off[x] = 0xffffffffu;
+    for (int x = threadIdx.x; x < 2 * top; x += 256) s_off[x] = x < nseg0 ? (uint32_t)dc[x] : 0xffffffffu;
+    const uint32_t total = (uint32_t)dc[nseg0];
     __syncthreads();
     const int nl = (int)total;
     const int band_lo = st->band_lo;

@@ -400,8 +400,13 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
         }
         {
           Bracket br(h, 6, st, np);
-          if (d.fused) hipLaunchKernelGGL(nn_ball_listed<true>, glist, dim3(kNnThreads), 0, st, d, kListedBlocks);
-          else hipLaunchKernelGGL(nn_ball_listed<false>, glist, dim3(kNnThreads), 0, st, d, kListedBlocks);
+          if (d.fused) {
+            // the lists' lengths differ by an order of magnitude between the pairs of a launch: cut into equal items first
+            hipLaunchKernelGGL(listed_plan, dim3(np), dim3(256), 0, st, d);
+            hipLaunchKernelGGL(nn_ball_listed_items, dim3(kListedItemBlocks), dim3(kNnThreads), 0, st, d);
+          } else {
+            hipLaunchKernelGGL(nn_ball_listed, glist, dim3(kNnThreads), 0, st, d, kListedBlocks);
+          }
         }
       } else {
         Bracket br(h, 4, st, np);
@@ -435,14 +440,16 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
   return SMHIP_OK;
 }
 
-// Does iteration `iteration` of this batch part run the fused path (nn_certify_acc + nn_ball_listed<true>: certificate pass and
+// Does iteration `iteration` of this batch part run the fused path (nn_certify_acc + nn_ball_listed_items: certificate pass and
 // normal-equation sums in one pass over the source)?  Exactly where the two-launch certificate form runs in a batch, unless every
 // bound is refined in every iteration anyway (nothing to speculate on) or the cloud has more record segments than finalize indexes.
 bool fused_iteration(const smhip_context* h, const Half& f, int ns_max, int iteration) {
   const IcpDev& d = f.d;
   if (h->opts.nn_mode != SMHIP_NN_GRID || !d.use_ball || !d.lds_table || !d.certify || h->opts.no_fused_sums || d.exact_all || f.small) return false;
   if (iteration < 1 || iteration < d.split_after || !(h->opts.split_after > 0 || f.np >= 16)) return false;
-  return ceil_div(ns_max, kNnThreads * kCertifyItems) * (kNnThreads / 64) + kListedBlocks * (kNnThreads / 64) <= kFinalizeMaxSeg;
+  if (f.np > kListedMaxPairs) return false;
+  // finalize's segment table: the certificate pass's waves + the listed search's items of a list nn_validate accepts
+  return ceil_div(ns_max, kNnThreads * kCertifyItems) * (kNnThreads / 64) + ceil_div(kFusedListedMax, kNnThreads) <= kFinalizeMaxSeg;
 }
 
 smhip_status fill_inputs(smhip_context* h, int np, const double* guesses, int* ns_max, int* nt_max, int first = 0) {
@@ -481,6 +488,8 @@ void sync_options(smhip_context* h) {
   h->dev.fused = 0;
   h->dev.band_pad = 0.1f; h->dev.band_gain = 1.5f;              // tuning only: results do not depend on the band, only how often it holds
   { const char* e = std::getenv("SMHIP_BAND_PAD"); if (e && std::atof(e) >= 0.0) h->dev.band_pad = (float)std::atof(e); }
+  h->dev.listed_grain = 1;
+  { const char* e = std::getenv("SMHIP_LISTED_GRAIN"); if (e && std::atoi(e) >= 0) h->dev.listed_grain = std::atoi(e); }
   { const char* e = std::getenv("SMHIP_BAND_GAIN"); if (e && std::atof(e) >= 0.0) h->dev.band_gain = (float)std::atof(e); }
   { const char* e = std::getenv("SMHIP_NABO_LISTED_BLOCKS"); if (e && std::atoi(e) > 0) h->nabo_listed_blocks = std::max(8, std::min(4096, std::atoi(e))); }   // >= 8: a workgroup's 16-bit histogram bins
 }
@@ -622,6 +631,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, &d.rec_j, B * 2 * (size_t)d.bl_stride));
   A(dev_alloc(h, &d.gcount, B * (size_t)d.seg_stride));
   A(dev_alloc(h, &d.dcount, B * (size_t)d.seg_stride));
+  A(dev_alloc(h, &d.litems, B));
   A(dev_alloc(h, &d.partials, B * (size_t)d.part_stride * kAccCols));
   A(dev_alloc(h, &d.tpart, B * kTgtReduceBlocks * 16));
   A(dev_alloc(h, &d.done_count, 4));

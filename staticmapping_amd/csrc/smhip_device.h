@@ -30,6 +30,8 @@ constexpr int kLdsTableCap = 1024;        // u32 entries of the per-workgroup ro
 constexpr int kLdsPointCap = 512;         // target points staged per round (8 KiB)
 constexpr int kLdsRowCap = 256;           // grid rows of the box whose runs are staged (<= workgroup size)
 constexpr int kWideBlocks = 512;         // workgroups (4 waves = 4 queries at a time) per pair of nn_ring_wide
+constexpr int kListedMaxPairs = 1024;   // pairs per launch of the balanced listed search (nn_ball_listed_items: its plan sits in LDS)
+constexpr int kListedItemBlocks = 1280;  // its workgroups: 5 per CU (LDS), each takes an equal run of the launch's items
 constexpr int kListedBlocks = 32;        // workgroups per pair of the listed search (nn_ball_listed): it strides over the list
 constexpr int kBallItems = 2;            // rounds of 256 queries per workgroup in nn_ball_lds / nn_ball (prefetch across rounds; 2 measured best: 4 = +8 %, 1 = +5 %)
 constexpr int kFusedListedMax = 16384;   // fused path: with more failing certificates than this in a pair and iteration the sums are left to `accumulate`
@@ -93,6 +95,8 @@ struct PairState {
   int32_t band_lo, band_hi;
   int32_t spec_ok;
   uint32_t spec_hits;        // iterations whose sums came from the fused pass (statistics)
+  uint32_t listed_ticket;    // (the launch's first pair) next unclaimed item of nn_ball_listed_items; listed_plan resets it
+  uint32_t pad2_;
 
   // outputs
   double score;
@@ -118,9 +122,10 @@ struct IcpDev {
   int32_t bl_stride;         // record slots per region and pair: ns_cap rounded up to whole accumulate AND certificate-pass chunks
   int32_t dl_stride;         // dlist entries per pair as the fused path indexes it: ns_cap rounded up to a whole certificate-pass chunk
   int32_t seg_stride;        // gcount / dcount entries per pair
-  int32_t fused;             // 1 = this iteration's launches belong to the fused path (nn_certify_acc + nn_ball_listed<true>):
+  int32_t fused;             // 1 = this iteration's launches belong to the fused path (nn_certify_acc + nn_ball_listed_items):
                              //     nn_validate decides spec_ok, accumulate returns at once when it holds, finalize reads either form
   float band_pad;            // half-width of the predicted band in bins, at least (tuning; default 0.1)
+  int32_t listed_grain;      // items a workgroup of nn_ball_listed_items claims at a time (0: equal runs fixed in advance)
   float band_gain;           // ... and this many times the quantile's last move (default 1.5)
   int32_t acc_items;         // points per thread of the accumulate launches of this batch part (finalize folds accordingly)
   PairState* state;
@@ -159,7 +164,9 @@ struct IcpDev {
   int32_t* rec_j;            // [slots][2 bl_stride] matched target position
   uint32_t* gcount;          // [slots][seg_stride] records per segment
   int32_t* dcount;           // [slots][seg_stride] fused path: queries whose certificate failed, per wave of nn_certify_acc (its segment of
-                             //                 dlist: dl_stride entries per pair, 64 * kCertifyItems slots per wave)
+                             //                 dlist: dl_stride entries per pair, 64 * kCertifyItems slots per wave); listed_plan turns
+                             //                 the counts into exclusive offsets with the total behind them
+  uint32_t* litems;          // [slots] fused path: work items (one workgroup pass each) of the pair's listed search (listed_plan)
   double* partials;          // [slots][part_stride][kAccCols]: one row per workgroup of accumulate / of the fused certificate pass
   double* tpart;             // [slots][kTgtReduceBlocks][16]
   uint32_t* done_count;      // number of finished pairs

@@ -41,7 +41,7 @@ if gk == "mix":
     guesses = [work[s % D]["guess_cv" if s % 2 == 0 else "guess_id"] for s in range(B)]
 else:
     guesses = [work[s % D]["guess_cv" if gk == "cv" else "guess_id"] for s in range(B)]
-base_opts = dict(no_fused_sums=0, split_after=0, overlap_streams=0)
+base_opts = dict(no_fused_sums=0, split_after=0, overlap_streams=0, no_overlap=0)
 ref = None
 for name, opts, env in cfgs:
     for k in ("SMHIP_BAND_PAD", "SMHIP_BAND_GAIN"):

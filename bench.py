@@ -859,6 +859,44 @@ def other_workloads(dev, with_cpu):
             m.set_target_cache(True)
         except Exception as e:
             out["ndt_gicp"]["six_concurrent_matchers"] = {"error": repr(e)}
+        # ... and as ONE lock-step batch through the jobs of one matcher (smhip_ndt_gicp_align_batch): the stages run over all jobs
+        # at once (the NDT rounds as in ndt.batch64; the 20-NN covariances, the correspondence steps and every round of functor
+        # evaluations one launch each over the jobs still running), every job's BFGS keeps its own sequence.  16 jobs hold this
+        # pair with 16 different guesses; job 0 carries the single call's guess and must return its bits.
+        try:
+            from staticmapping_amd import synth
+            K = 16
+            mb = sm.NdtGicpHip(max_source_points=len(src), max_target_points=len(tgt), jobs=K)
+            for k in range(K):
+                mb.set_input_source(src, slot=k); mb.set_input_target(tgt, slot=k)
+            gs = [G @ synth.make_pose(t=(0.01 * (k % 8), -0.01 * (k % 5), 0.0), rpy_deg=(0, 0, 0.05 * (k % 7))) for k in range(K)]
+            gs[0] = G
+
+            def time_gbatch():
+                mb.align_batch(K, gs)
+                t_ = time.perf_counter()
+                for _ in range(3):
+                    Rb_, scb_, stb_ = mb.align_batch(K, gs)
+                return (time.perf_counter() - t_) / 3, Rb_, stb_
+            mb.set_target_cache(False)
+            dtb, Rb, stb = time_gbatch()
+            mb.set_target_cache(True)
+            dtb_kept, Rb_kept, _ = time_gbatch()
+            b_batch = sum(12.0 * (len(src) + len(tgt)) + (s_["n_source"] + s_["n_target"]) * (12.0 + 240.0) +
+                          max(1, s_["gicp_iterations"]) * (s_["n_source"] * 20.0 + s_["gicp_correspondences"] * 84.0) for s_ in stb)
+            out["ndt_gicp"]["batch16"] = {
+                "value": round(K / dtb, 2), "unit": "alignments/s", "jobs": K, "ms_per_batch": round(dtb * 1e3, 3),
+                "identical_to_single": bool(np.array_equal(Rb[0], R)),
+                "gicp_iterations_min_max": [int(min(s_["gicp_iterations"] for s_ in stb)), int(max(s_["gicp_iterations"] for s_ in stb))],
+                "function_evaluations_min_max": [int(min(s_["gicp_function_evaluations"] for s_ in stb)), int(max(s_["gicp_function_evaluations"] for s_ in stb))],
+                "roofline": {"bound": "hbm", "achieved": round(b_batch / dtb / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(b_batch / dtb / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": b_batch},
+                "target_kept": {"value": round(K / dtb_kept, 2), "ms_per_batch": round(dtb_kept * 1e3, 3), "identical_result": bool(np.array_equal(Rb, Rb_kept))},
+                "note": "smhip_ndt_gicp_align_batch: lock-step jobs, one gicp_fdf launch per round of functor evaluations over all running jobs "
+                        "(pclomp/gicp_omp_impl.hpp:381-514; builder/map_builder.cc:399-446, 655); value = everything rebuilt per Align"}
+            mb.close()
+        except Exception as e:
+            out["ndt_gicp"]["batch16"] = {"error": repr(e)}
         recorded = os.path.join(ROOT, "profiles", "r02_gicp_cpu_baseline.json")
         if not (with_cpu and os.environ.get("SMHIP_BENCH_GICP_CPU", "1") == "1") and os.path.exists(recorded):
             # the numpy oracle needs ~30 s for this case on the GPU box: when it is switched off (SMHIP_BENCH_GICP_CPU=0 or

@@ -312,9 +312,10 @@ smhip_status smhip_ndt_compute_derivatives(smhip_handle h, const double pose6[6]
 /* ---- registrators::NdtWithGicp (ndt_gicp.cc:28-112) ------------------------------------------
  * ApproximateVoxelGrid (0.2 m) on both clouds -> stock pcl NDT -> stock pcl GICP; PCL is not vendored by the
  * reference, the arithmetic follows PCL 1.8.1 (see oracle/ndt_gicp.py for the pinning).  The matcher keeps its
- * raw clouds in private device buffers and uses pair slots 0 and 1 of the handle as working space, so the handle
- * must be created with pair_slots >= 2, max_source_points / max_target_points >= the raw cloud sizes and
- * max_target_points >= the down-sampled source size. */
+ * raw clouds in private device buffers and uses two pair slots of the handle per job as working space (job j: slot j and
+ * slot pair_slots / 2 + j; the single Align is job 0), so the handle must be created with pair_slots >= 2,
+ * max_source_points / max_target_points >= the raw cloud sizes and max_target_points >= the down-sampled source size.
+ * One grid cell (gicp_search_cell) serves every search of an Align, so a target's search grid is built once per Align. */
 typedef struct smhip_ndt_gicp_options {
   float voxel_resolution;              /* 0.2  ndt_gicp.h:73 */
   int32_t using_voxel_filter;          /* 1    ndt_gicp.h:74 */
@@ -355,6 +356,18 @@ smhip_status smhip_ndt_gicp_set_target_f32(smhip_handle h, const float* xyz, int
 /* NdtWithGicp::Align.  *score = exp(-GICP fitness) (exp(-10) when stats->ok == 0, ndt_gicp.cc:103,107). */
 smhip_status smhip_ndt_gicp_align(smhip_handle h, const double guess[16], double result[16], double* score,
                                   smhip_ndt_gicp_stats* stats);
+/* Several NdtWithGicp pairs on one handle: a handle created with S pair slots runs S / 2 JOBS (smhip_ndt_gicp_jobs); job j has
+ * its own clouds (the calls above are job 0's) and keeps its own target-derived structures between Aligns.
+ * smhip_ndt_gicp_align_batch aligns jobs first_job .. first_job + njobs - 1 in lock-step -- the stages of
+ * NdtWithGicp::Align (ndt_gicp.cc:55-112) run over all jobs at once, and inside NDT and GICP every job keeps the reference's own
+ * sequence of evaluations while each round of evaluations is ONE launch and one hand-back for all jobs that are still
+ * running (the back end's six concurrent SubmapPairMatch tasks, map_builder.cc:399-446, 655, as one call).  Results are
+ * bit-identical to the single calls'.  guesses / results: njobs column-major 4x4; scores / stats: njobs entries (nullable). */
+int smhip_ndt_gicp_jobs(smhip_handle h);
+smhip_status smhip_ndt_gicp_set_source_f32_job(smhip_handle h, int job, const float* xyz, int stride_floats, int n);
+smhip_status smhip_ndt_gicp_set_target_f32_job(smhip_handle h, int job, const float* xyz, int stride_floats, int n);
+smhip_status smhip_ndt_gicp_align_batch(smhip_handle h, int first_job, int njobs, const double* guesses, double* results,
+                                        double* scores, smhip_ndt_gicp_stats* stats);
 /* pcl GICP alone on slot 0's clouds (smhip_set_source_f32 / smhip_set_target_f32); *fitness = getFitnessScore() */
 smhip_status smhip_gicp_align(smhip_handle h, const double guess[16], double result[16], double* fitness,
                               smhip_ndt_gicp_stats* stats);

@@ -158,6 +158,7 @@ inline std::vector<SubmapPairMatchResult> SubmapPairMatchBatch(const registrator
   if (auto* fast = dynamic_cast<registrator::IcpFastHip*>(matcher.get())) batched = fast->AlignBatch(src, tgt, guess, &result, &score);
   else if (auto* pm = dynamic_cast<registrator::IcpPointMatcherHip*>(matcher.get())) batched = pm->AlignBatch(src, tgt, guess, &result, &score);
   else if (auto* ndt = dynamic_cast<registrator::NdtHip*>(matcher.get())) batched = ndt->AlignBatch(src, tgt, guess, &result, &score);   // lock-step Newton
+  else if (auto* ng = dynamic_cast<registrator::NdtGicpHip*>(matcher.get())) batched = ng->AlignBatch(src, tgt, guess, &result, &score);   // lock-step NDT + BFGS
   if (!batched) {
     result.assign(guess.begin(), guess.end());
     score.assign(K, 0.0);
@@ -177,7 +178,7 @@ inline std::vector<SubmapPairMatchResult> SubmapPairMatchBatch(const registrator
   return out;
 }
 
-// The reference's own form of concurrency, kept for the matchers without pair slots (Ndt, NdtWithGicp): the back end's thread
+// The reference's own form of concurrency (every matcher also has a batched form above): the back end's thread
 // pool runs up to six SubmapPairMatch tasks at once, each with a matcher of its own (map_builder.cc:399-446, 655, 706-708).
 // Here: `concurrency` matchers created once and kept between batches (every one owns a device arena and a HIP stream), the
 // jobs dealt to them round-robin, one host thread per matcher -- the GPU runs the matchers' streams side by side, so the

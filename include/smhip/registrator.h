@@ -624,6 +624,57 @@ class NdtGicpHip : public Interface {
   }
   const smhip_ndt_gicp_stats& LastStats() const { return stats_; }
 
+  // K independent (source, target) pairs as ONE lock-step batch through K jobs of a second handle this matcher keeps between
+  // calls (smhip_ndt_gicp_align_batch): the back end's concurrent SubmapPairMatch tasks (map_builder.cc:399-446, 655) with
+  // the NdtWithGicp matcher.  Each pair's result and score are what Align gives for it, bit for bit; (*ok)[k] is Align's
+  // return value for pair k (false with result = guess when its NDT fitness is > 1, ndt_gicp.cc:105-108).  false when the
+  // device refused a cloud (results = guesses).
+  bool AlignBatch(const std::vector<InnerCloudPtr>& sources, const std::vector<InnerCloudPtr>& targets,
+                  const std::vector<Matrix4d>& guesses, std::vector<Matrix4d>* results, std::vector<double>* scores,
+                  std::vector<char>* ok = nullptr, std::vector<smhip_ndt_gicp_stats>* stats = nullptr) {
+    const int K = static_cast<int>(sources.size());
+    SMHIP_CHECK(K > 0 && targets.size() == sources.size() && guesses.size() == sources.size() && results && scores, "AlignBatch: sizes");
+    results->assign(guesses.begin(), guesses.end());
+    scores->assign(K, 0.0);
+    if (ok) ok->assign(K, 0);
+    int ns = 1, nt = 1;
+    for (int k = 0; k < K; ++k) {
+      if (!sources[k] || !targets[k] || sources[k]->Empty() || targets[k]->Empty()) return false;
+      ns = std::max(ns, static_cast<int>(sources[k]->GetInnerCloud().size()));
+      nt = std::max(nt, static_cast<int>(targets[k]->GetInnerCloud().size()));
+    }
+    // two pair slots per job; the target side also has to hold the down-sampled source
+    if (!batch_arena_.Reserve(device_, std::max(2 * K, batch_arena_.slots), ns, std::max(nt, ns))) return false;
+    smhip_handle h = batch_arena_.handle;
+    opt_.use_ndt = use_ndt_ ? 1 : 0;
+    opt_.using_voxel_filter = using_voxel_filter_ ? 1 : 0;
+    SMHIP_CHECK(smhip_ndt_gicp_set_options(h, &opt_) == SMHIP_OK, "smhip_ndt_gicp_set_options");
+    for (int k = 0; k < K; ++k) {
+      const auto& s = sources[k]->GetInnerCloud();
+      const auto& t = targets[k]->GetInnerCloud();
+      if (smhip_ndt_gicp_set_source_f32_job(h, k, &s[0].x, 5, static_cast<int>(s.size())) != SMHIP_OK ||
+          smhip_ndt_gicp_set_target_f32_job(h, k, &t[0].x, 5, static_cast<int>(t.size())) != SMHIP_OK) {
+        std::fprintf(stderr, "[ERROR] NdtGicpHip::AlignBatch: %s\n", smhip_last_error(h));
+        return false;
+      }
+    }
+    std::vector<double> g(16 * static_cast<size_t>(K)), r(16 * static_cast<size_t>(K));
+    std::vector<smhip_ndt_gicp_stats> st(K);
+    for (int k = 0; k < K; ++k) std::memcpy(&g[16 * static_cast<size_t>(k)], guesses[k].data(), sizeof(double) * 16);
+    const smhip_status rc = smhip_ndt_gicp_align_batch(h, 0, K, g.data(), r.data(), scores->data(), st.data());
+    if (rc != SMHIP_OK) {
+      std::fprintf(stderr, "[ERROR] NdtGicpHip::AlignBatch: %s (%s)\n", smhip_status_string(rc), smhip_last_error(h));
+      scores->assign(K, 0.0);
+      return false;
+    }
+    for (int k = 0; k < K; ++k) {
+      std::memcpy((*results)[k].data(), &r[16 * static_cast<size_t>(k)], sizeof(double) * 16);
+      if (ok) (*ok)[k] = st[k].ok != 0;
+    }
+    if (stats) *stats = st;
+    return true;
+  }
+
  private:
   // two pair slots (working space of the matcher); the target side also has to hold the down-sampled source
   bool EnsureHandle(int ns, int nt) {
@@ -644,6 +695,7 @@ class NdtGicpHip : public Interface {
   int32_t device_ = 0;
   int max_source_, max_target_;
   DeviceArena arena_;
+  DeviceArena batch_arena_;                    // AlignBatch's handle: two pair slots per job
   smhip_ndt_gicp_stats stats_{};
 };
 

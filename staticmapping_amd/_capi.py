@@ -136,6 +136,10 @@ SIGNATURES = {
     "smhip_ndt_gicp_set_source_f32": (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int]),
     "smhip_ndt_gicp_set_target_f32": (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int]),
     "smhip_ndt_gicp_align": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p, ctypes.POINTER(NdtGicpStats)]),
+    "smhip_ndt_gicp_jobs": (ctypes.c_int, [ctypes.c_void_p]),
+    "smhip_ndt_gicp_set_source_f32_job": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int]),
+    "smhip_ndt_gicp_set_target_f32_job": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int]),
+    "smhip_ndt_gicp_align_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.POINTER(NdtGicpStats)]),
     "smhip_gicp_align": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p, ctypes.POINTER(NdtGicpStats)]),
     "smhip_ndt_gicp_get_downsampled": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "smhip_gicp_evaluate": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]),

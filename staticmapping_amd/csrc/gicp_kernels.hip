@@ -17,16 +17,24 @@ constexpr int kGicpKnnThreads = 128;
 constexpr int kGicpCols = 16;                // f, g_t[3], R[9], count, 2 spare
 constexpr int kGicpMaxBlocks = 1024;
 
+constexpr int kGicpLaunchJobs = 16;          // jobs one gicp_corr / gicp_fdf launch carries in its arguments (a batch takes several launches)
+constexpr int kGicpKnnJobs = 32;             // clouds one gicp_knn_cov launch covers
+
+// A handle runs up to pair_slots / 2 NdtWithGicp JOBS side by side (smhip_ndt_gicp_align_batch; the single Align is job 0):
+// job j works in pair slot j (down-sampled source and target, their search grid) and uses slot pair_slots / 2 + j as scratch
+// for the source's own neighbour search.  Every array below holds one row per job.
 struct GicpDev {
-  double* cov_s;           // [ns_cap][6] source covariances, index = position in slot 0's src array
-  double* cov_t;           // [nt_cap][6] target covariances, index = position in slot 0's tgt_p array
-  double* maha;            // [ns_cap][6] mahalanobis_[i] (symmetric): xx xy xz yy yz zz
-  float4* qraw;            // [ns_cap] matched raw target point; w = 1 if the correspondence is kept
-  double* partials;        // [kGicpMaxBlocks][kGicpCols]
-  double* out;             // [kGicpCols]
-  uint32_t* ticket;        // workgroups of the running gicp_fdf that have written their partial sums
-  double* out_host;        // [kGicpCols + 1] page-locked host memory: the folded sums and, last, the evaluation's sequence number
-  uint32_t* count;         // kept correspondences
+  double* cov_s;           // [jobs][ns_cap][6] source covariances, index = position in the job slot's src array
+  double* cov_t;           // [jobs][nt_cap][6] target covariances, index = position in the job slot's tgt_p array
+  double* maha;            // [jobs][ns_cap][6] mahalanobis_[i] (symmetric): xx xy xz yy yz zz
+  float4* qraw;            // [jobs][ns_cap] matched raw target point; w = 1 if the correspondence is kept
+  double* partials;        // [jobs][kGicpMaxBlocks][kGicpCols]
+  double* out;             // [jobs][kGicpCols]
+  uint32_t* ticket;        // [jobs] workgroups of the job's running gicp_fdf that have written their partial sums
+  uint32_t* round_done;    // jobs of the running evaluation round whose sums are in host memory
+  double* out_host;        // [jobs][kGicpCols] page-locked host memory: the folded sums; behind them ([jobs * kGicpCols]) the round's number
+  uint32_t* count;         // [jobs] kept correspondences
+  int32_t jobs;            // rows
 };
 
 // symmetric 3x3 (xx xy xz yy yz zz) helpers
@@ -60,10 +68,18 @@ __device__ __noinline__ int knn_largest_index_at(const float (*s_d)[kGicpKnnThre
   return wo;
 }
 
+struct GicpKnnBatch {
+  int32_t n, pad;
+  int32_t slot[kGicpKnnJobs];            // pair slot whose TARGET is the cloud (a job's slot, or its scratch slot = the source)
+  double* cov[kGicpKnnJobs];             // where its covariances go
+};
+
 template <int KMAX>
-__global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pair, int k, double gicp_epsilon, double* cov) {
+__global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, GicpKnnBatch L, int k, double gicp_epsilon) {
   __shared__ float s_d[KMAX][kGicpKnnThreads];
   __shared__ int s_j[KMAX][kGicpKnnThreads];
+  const int pair = L.slot[blockIdx.y];
+  double* cov = L.cov[blockIdx.y];
   const PairState* st = &b.state[pair];
   const int nt = st->nt;
   const int j0 = blockIdx.x * kGicpKnnThreads + threadIdx.x;
@@ -208,17 +224,29 @@ __global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, int pa
 }
 
 // per source point: keep the correspondence if d2 < threshold^2 and store (R C1 R^T + C2)^-1 and the raw target point
-__global__ __launch_bounds__(256) void gicp_corr(IcpDev b, GicpDev g, int ns, float thr2, const double* Rrm /*3x3 row-major, device*/) {
+struct GicpCorrJob {
+  int32_t job, ns;
+  float thr2, pad;
+  double R[9];             // rotation of transformation_ * guess, row-major (:425-429)
+};
+struct GicpCorrBatch {
+  int32_t n, pad;
+  GicpCorrJob j[kGicpLaunchJobs];
+};
+__global__ __launch_bounds__(256) void gicp_corr(IcpDev b, GicpDev g, GicpCorrBatch L) {
+  const GicpCorrJob& J = L.j[blockIdx.y];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t so = (size_t)J.job * b.ns_cap, to = (size_t)J.job * b.nt_cap;
   bool keep = false;
-  if (i < ns) {
-    const int j = b.idx[i];
-    const float d2 = b.d2[i];
-    if (j >= 0 && d2 < thr2) {                                                       // :449
+  if (i < J.ns) {
+    const int j = b.idx[so + i];
+    const float d2 = b.d2[so + i];
+    if (j >= 0 && d2 < J.thr2) {                                                     // :449
       keep = true;
-      const int orig = __float_as_int(b.tq[j].w);
-      const double* C1 = g.cov_s + (size_t)i * 6;
-      const double* C2 = g.cov_t + (size_t)orig * 6;
+      const int orig = __float_as_int(b.tq[to + j].w);
+      const double* C1 = g.cov_s + (so + i) * 6;
+      const double* C2 = g.cov_t + (to + orig) * 6;
+      const double* Rrm = J.R;
       const double c1[9] = {C1[0], C1[1], C1[2], C1[1], C1[3], C1[4], C1[2], C1[4], C1[5]};
       double M[9];                                                                   // M = R * C1
       for (int r = 0; r < 3; ++r)
@@ -230,42 +258,58 @@ __global__ __launch_bounds__(256) void gicp_corr(IcpDev b, GicpDev g, int ns, fl
           const double full[9] = {C2[0], C2[1], C2[2], C2[1], C2[3], C2[4], C2[2], C2[4], C2[5]};
           T[e++] = M[3 * r] * Rrm[3 * c] + M[3 * r + 1] * Rrm[3 * c + 1] + M[3 * r + 2] * Rrm[3 * c + 2] + full[3 * r + c];
         }
-      sym_inverse(T, g.maha + (size_t)i * 6);                                         // :459
-      float4 p = b.tgt_p[orig];
+      sym_inverse(T, g.maha + (so + i) * 6);                                          // :459
+      float4 p = b.tgt_p[to + orig];
       p.w = 1.f;
-      g.qraw[i] = p;
+      g.qraw[so + i] = p;
     } else {
-      g.qraw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      g.qraw[so + i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   const unsigned long long m = __ballot(keep);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(g.count, (uint32_t)__popcll(m));
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(g.count + J.job, (uint32_t)__popcll(m));
 }
 
 struct GicpPose {
   float T[12];             // applyState(base_transformation_, x), rows 0..2
   float B[12];             // base_transformation_ (the guess), rows 0..2
 };
+struct GicpFdfJob {
+  int32_t job, ns, nblk, pad;          // nblk = min(kGicpMaxBlocks, ceil(ns / 256)): the job's own workgroups, whatever the launch holds
+  GicpPose P;
+};
+struct GicpFdfBatch {
+  int32_t n, total;                    // jobs in this launch / in the whole round (a round of more than kGicpLaunchJobs takes several)
+  unsigned long long seq;              // the round's number
+  GicpFdfJob j[kGicpLaunchJobs];
+};
 
-// sums of the functor over the kept correspondences: f (:272), g_t (:316-318), R (:320-321)
-// The workgroup that finishes last folds the partial sums (gicp_reduce's order) and stores them straight into page-locked
-// host memory, the evaluation's sequence number after them: the host, which needs f and g before it can choose the next
-// point, spins on that number instead of paying for a second launch, a copy and a stream synchronise per evaluation.
-__global__ __launch_bounds__(256) void gicp_fdf(IcpDev b, GicpDev g, int ns, GicpPose P, unsigned long long seq) {
+// sums of the functor over the kept correspondences: f (:272), g_t (:316-318), R (:320-321), for every job of the round
+// (blockIdx.y) at that job's own pose.  A job's sums are formed by its own nblk workgroups in its own order, so they do not
+// depend on which other jobs share the launch.  The workgroup of a job that finishes last folds the job's partial sums
+// (16 strided groups, then the groups in turn) and stores them straight into page-locked host memory; the job that finishes last stores the round's
+// number after them: the host, which needs f and g before it can choose any job's next point, spins on that number instead
+// of paying for a second launch, a copy and a stream synchronise per evaluation.
+__global__ __launch_bounds__(256) void gicp_fdf(IcpDev b, GicpDev g, GicpFdfBatch L) {
+  const GicpFdfJob& J = L.j[blockIdx.y];
+  const int nblk = J.nblk, ns = J.ns, job = J.job;
+  if ((int)blockIdx.x >= nblk) return;
+  const GicpPose& P = J.P;
+  const size_t so = (size_t)job * b.ns_cap;
   double acc[13];
 #pragma unroll
   for (int k = 0; k < 13; ++k) acc[k] = 0.0;
   double cnt = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
-    const float4 q = g.qraw[i];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += nblk * blockDim.x) {
+    const float4 q = g.qraw[so + i];
     if (q.w == 0.f) continue;
-    const float4 s = b.src[i];
+    const float4 s = b.src[so + i];
     // Eigen Matrix4f * Vector4f: column by column accumulation in float
     const float px = ((P.T[0] * s.x + P.T[1] * s.y) + P.T[2] * s.z) + P.T[3];
     const float py = ((P.T[4] * s.x + P.T[5] * s.y) + P.T[6] * s.z) + P.T[7];
     const float pz = ((P.T[8] * s.x + P.T[9] * s.y) + P.T[10] * s.z) + P.T[11];
     const double r0 = (double)(px - q.x), r1 = (double)(py - q.y), r2 = (double)(pz - q.z);      // float differences (:268)
-    const double* M = g.maha + (size_t)i * 6;
+    const double* M = g.maha + (so + i) * 6;
     const double t0 = M[0] * r0 + M[1] * r1 + M[2] * r2;
     const double t1 = M[1] * r0 + M[3] * r1 + M[4] * r2;
     const double t2 = M[2] * r0 + M[4] * r1 + M[5] * r2;
@@ -290,54 +334,42 @@ __global__ __launch_bounds__(256) void gicp_fdf(IcpDev b, GicpDev g, int ns, Gic
     s_red[wave][13] = cnt; s_red[wave][14] = 0; s_red[wave][15] = 0;
   }
   __syncthreads();
+  double* partials = g.partials + (size_t)job * kGicpMaxBlocks * kGicpCols;
   if (threadIdx.x < kGicpCols) {
-    g.partials[(size_t)blockIdx.x * kGicpCols + threadIdx.x] =
+    partials[(size_t)blockIdx.x * kGicpCols + threadIdx.x] =
         s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
     __threadfence();
   }
   __shared__ uint32_t s_last;
   __shared__ double s_g[16][kGicpCols];
   __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(g.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+  if (threadIdx.x == 0) s_last = atomicAdd(g.ticket + job, 1u) == (uint32_t)nblk - 1u ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
   __threadfence();
   {
-    const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;            // 16 strided groups, then the groups in turn: gicp_reduce's order
+    const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;            // 16 strided groups, then the groups in turn
     double t = 0;
-    for (int k = grp; k < (int)gridDim.x; k += 16) t += g.partials[(size_t)k * kGicpCols + c];
+    for (int k = grp; k < nblk; k += 16) t += partials[(size_t)k * kGicpCols + c];
     s_g[grp][c] = t;
   }
   __syncthreads();
   if (threadIdx.x < kGicpCols) {
     double t = 0;
     for (int k = 0; k < 16; ++k) t += s_g[k][threadIdx.x];
-    g.out[threadIdx.x] = t;
-    g.out_host[threadIdx.x] = t;
+    g.out[(size_t)job * kGicpCols + threadIdx.x] = t;
+    g.out_host[(size_t)job * kGicpCols + threadIdx.x] = t;
     __threadfence_system();
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    *g.ticket = 0;
+    g.ticket[job] = 0;
     __threadfence_system();
-    *reinterpret_cast<volatile unsigned long long*>(g.out_host + kGicpCols) = seq;
-  }
-}
-
-// fixed-order fold of the block partials (repeated evaluations at one x are bitwise identical)
-__global__ __launch_bounds__(16 * 64) void gicp_reduce(GicpDev g, int nblocks) {
-  __shared__ double s_g[16][kGicpCols];
-  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  if (c < kGicpCols) {
-    double t = 0;
-    for (int k = grp; k < nblocks; k += 16) t += g.partials[(size_t)k * kGicpCols + c];
-    s_g[grp][c] = t;
-  }
-  __syncthreads();
-  if (threadIdx.x < kGicpCols) {
-    double t = 0;
-    for (int k = 0; k < 16; ++k) t += s_g[k][threadIdx.x];
-    g.out[threadIdx.x] = t;
+    if (atomicAdd(g.round_done, 1u) == (uint32_t)L.total - 1u) {        // every job of the round has its sums in host memory
+      *g.round_done = 0;
+      __threadfence_system();
+      *reinterpret_cast<volatile unsigned long long*>(g.out_host + (size_t)g.jobs * kGicpCols) = L.seq;
+    }
   }
 }
 

@@ -4,72 +4,88 @@
 // -> stock pcl NDT -> (fitness <= 1) stock pcl GICP -> score exp(-fitness).  All three live in PCL (1.8.1 pinned,
 // see oracle/ndt_gicp.py); GICP statements are cited from the in-tree fork registrators/pclomp/gicp_omp_impl.hpp.
 // The matcher keeps its raw clouds in private device buffers (the reference converts its stored clouds in every
-// Align, ndt_gicp.cc:59-76) and uses pair slot 0 as the working pair for the down-sampled clouds and slot 1 as
-// scratch for the source's neighbour search, so the handle needs pair_slots >= 2.
+// Align, ndt_gicp.cc:59-76).  A handle of S pair slots runs up to S / 2 JOBS side by side: job j works in pair slot j
+// (down-sampled clouds, their search grid) and uses slot S / 2 + j as scratch for the source's own neighbour search, so the
+// handle needs pair_slots >= 2.  The single Align is job 0; smhip_ndt_gicp_align_batch advances its jobs in lock-step: every
+// job keeps the reference's own sequence of functor evaluations (its BFGS runs as a coroutine on the host, unchanged), and one
+// round of the batch serves each live job's next request -- a correspondence step or a functor evaluation -- with one launch
+// per kind over all of them and one hand-back through page-locked memory.
 #include <chrono>
 #include <thread>
+#include <memory>
 #include <cstdlib>
 #include <cstdio>
+#include <ucontext.h>
 #include "gicp_kernels.hip"
 
 namespace {
+
+struct GicpJobHost {
+  int n_raw_src = 0, n_raw_tgt = 0;
+  // what is derived from the target alone is kept while the target is (smhip_set_target_cache, default on): the front end
+  // aligns scan after scan against one submap, and ndt_gicp.cc filters / rebuilds / re-estimates all of it in every Align
+  unsigned long long raw_tgt_gen = 0;       // bumped by every smhip_ndt_gicp_set_target_f32
+  unsigned long long staged_raw_gen = 0;    // the raw target the job slot's staged target was made from ...
+  unsigned long long staged_slot_gen = 0;   // ... and the slot's tgt_gen right after staging it
+  int staged_filter = -1; float staged_res = 0.f; int staged_nt = 0;
+  unsigned long long cov_gen = 0;           // the slot's tgt_gen its cov_t row was estimated from, with these parameters
+  int cov_k = 0; double cov_eps = 0; float cov_cell = 0.f;
+};
 
 struct GicpHost {
   GicpDev dev{};
   bool allocated = false;
   smhip_ndt_gicp_options opts{};
-  float4* raw_src = nullptr;          // [ns_cap] as handed over
-  float4* raw_tgt = nullptr;          // [nt_cap]
+  int jobs = 0;                       // pair_slots / 2
+  std::vector<GicpJobHost> job;
+  float4* raw_src = nullptr;          // [jobs][ns_cap] as handed over
+  float4* raw_tgt = nullptr;          // [jobs][nt_cap]
   float4* ds_tmp = nullptr;           // [max(ns_cap, nt_cap)] filter output before the Morton ordering
-  int n_raw_src = 0, n_raw_tgt = 0;
-  double* out_pinned = nullptr;       // kGicpCols doubles
-  double* rot_dev = nullptr;          // 9 doubles
-  uint32_t* count_pinned = nullptr;
-  int evals = 0;
-  unsigned long long seq = 0;         // evaluations launched so far: the number gicp_fdf stores after its sums
-  // what is derived from the target alone is kept while the target is (smhip_set_target_cache, default on): the front end
-  // aligns scan after scan against one submap, and ndt_gicp.cc filters / rebuilds / re-estimates all of it in every Align
-  unsigned long long raw_tgt_gen = 0;       // bumped by every smhip_ndt_gicp_set_target_f32
-  unsigned long long staged_raw_gen = 0;    // the raw target slot 0's staged target was made from ...
-  unsigned long long staged_slot_gen = 0;   // ... and tgt_gen[0] right after staging it
-  int staged_filter = -1; float staged_res = 0.f; int staged_nt = 0;
-  unsigned long long cov_gen = 0;           // tgt_gen[0] cov_t was estimated from, with these parameters
-  int cov_k = 0; double cov_eps = 0; float cov_cell = 0.f;
+  double* out_pinned = nullptr;       // [jobs][kGicpCols] doubles, then the finished round's number
+  uint32_t* count_pinned = nullptr;   // [jobs]
+  int evals = 0;                      // functor evaluations of the last single-job run (parity hooks)
+  unsigned long long seq = 0;         // evaluation rounds launched so far: the number gicp_fdf stores after the last job's sums
 };
 
 GicpHost& gicp_of(smhip_context* h);
+inline int gicp_scratch_slot(const smhip_context* h, int job) { return h->dev.slots / 2 + job; }
 
 smhip_status gicp_ensure(smhip_context* h) {
   GicpHost& g = gicp_of(h);
   if (g.allocated) return SMHIP_OK;
   if (h->dev.slots < 2) { h->err = "NdtWithGicp needs a handle created with pair_slots >= 2"; return SMHIP_ERR_CAPACITY; }
-  smhip_status s = ndt_ensure(h);
+  const int J = h->dev.slots / 2;
+  smhip_status s = ndt_ensure(h, J);
   if (s) return s;
   s = prep_ensure(h);
   if (s) return s;
   const size_t NS = h->dev.ns_cap, NT = h->dev.nt_cap;
   auto A = [&](smhip_status r) { if (s == SMHIP_OK) s = r; };
-  A(dev_alloc(h, &g.dev.cov_s, NS * 6));
-  A(dev_alloc(h, &g.dev.cov_t, NT * 6));
-  A(dev_alloc(h, &g.dev.maha, NS * 6));
-  A(dev_alloc(h, &g.dev.qraw, NS));
-  A(dev_alloc(h, &g.dev.partials, (size_t)kGicpMaxBlocks * kGicpCols));
-  A(dev_alloc(h, &g.dev.out, (size_t)kGicpCols));
-  A(dev_alloc(h, &g.dev.count, 4));
-  A(dev_alloc(h, &g.dev.ticket, 4));
-  A(dev_alloc(h, &g.raw_src, NS));
-  A(dev_alloc(h, &g.raw_tgt, NT));
+  A(dev_alloc(h, &g.dev.cov_s, (size_t)J * NS * 6));
+  A(dev_alloc(h, &g.dev.cov_t, (size_t)J * NT * 6));
+  A(dev_alloc(h, &g.dev.maha, (size_t)J * NS * 6));
+  A(dev_alloc(h, &g.dev.qraw, (size_t)J * NS));
+  A(dev_alloc(h, &g.dev.partials, (size_t)J * kGicpMaxBlocks * kGicpCols));
+  A(dev_alloc(h, &g.dev.out, (size_t)J * kGicpCols));
+  A(dev_alloc(h, &g.dev.count, (size_t)J));
+  A(dev_alloc(h, &g.dev.ticket, (size_t)J));
+  A(dev_alloc(h, &g.dev.round_done, 4));
+  A(dev_alloc(h, &g.raw_src, (size_t)J * NS));
+  A(dev_alloc(h, &g.raw_tgt, (size_t)J * NT));
   A(dev_alloc(h, &g.ds_tmp, std::max(NS, NT)));
-  A(dev_alloc(h, &g.rot_dev, 9));
   if (s) return s;
-  if (hipHostMalloc(reinterpret_cast<void**>(&g.out_pinned), sizeof(double) * (kGicpCols + 1)) != hipSuccess ||
-      hipHostMalloc(reinterpret_cast<void**>(&g.count_pinned), sizeof(uint32_t) * 4) != hipSuccess) {
+  if (hipHostMalloc(reinterpret_cast<void**>(&g.out_pinned), sizeof(double) * ((size_t)J * kGicpCols + 1)) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&g.count_pinned), sizeof(uint32_t) * (size_t)J) != hipSuccess) {
     h->err = "hipHostMalloc failed (GICP)";
     return SMHIP_ERR_HIP;
   }
-  std::memset(g.out_pinned, 0, sizeof(double) * (kGicpCols + 1));
+  std::memset(g.out_pinned, 0, sizeof(double) * ((size_t)J * kGicpCols + 1));
   g.dev.out_host = g.out_pinned;                       // (page-locked host memory is device-addressable at the same pointer)
-  if (hipMemsetAsync(g.dev.ticket, 0, sizeof(uint32_t) * 4, h->stream) != hipSuccess) { h->err = "hipMemsetAsync failed (GICP)"; return SMHIP_ERR_HIP; }
+  g.dev.jobs = J;
+  if (hipMemsetAsync(g.dev.ticket, 0, sizeof(uint32_t) * (size_t)J, h->stream) != hipSuccess ||
+      hipMemsetAsync(g.dev.round_done, 0, sizeof(uint32_t) * 4, h->stream) != hipSuccess) { h->err = "hipMemsetAsync failed (GICP)"; return SMHIP_ERR_HIP; }
+  g.jobs = J;
+  g.job.assign((size_t)J, GicpJobHost{});
   g.allocated = true;
   return SMHIP_OK;
 }
@@ -112,53 +128,44 @@ void r_derivative(const double* x, const double* R /*row-major 3x3*/, double* g)
   g[3] = ip(dphi); g[4] = ip(dth); g[5] = ip(dpsi);
 }
 
+// One job's GICP run: pcl's computeTransformation (:381-514) with its BFGS, as a coroutine.  Wherever the sequential code
+// needs the device -- the correspondences of an outer iteration, a functor evaluation -- it posts the request and yields to
+// the scheduler (gicp_run_tasks), which serves the requests of all live jobs together and resumes them with the answers.
+struct GicpTask {
+  smhip_context* h = nullptr;
+  int job = 0, ns = 0;
+  bool live = false;
+  float guess[16];                    // base_transformation_ = guess (row-major float)
+  float fin[16];                      // final_transformation_
+  enum Req { kStart, kCorr, kFdf, kDone } req = kStart;
+  double TRcm[16], R9[9];             // kCorr: transformation_ * guess (column-major) and its rotation (row-major)
+  uint32_t ncorr = 0;                 // ... answered with the kept correspondences
+  GicpPose P;                         // kFdf: the pose; answered in the job's row of out_pinned
+  smhip_status status = SMHIP_OK;
+  int evals = 0, it = 0;
+  ucontext_t ctx, sched;
+  std::unique_ptr<char[]> stack;
+  void yield() { swapcontext(&ctx, &sched); }
+  void body();
+};
+
 // One evaluation of the functor (f and g together: one launch either way), :250-377
 struct GicpFunctor {
-  smhip_context* h;
-  float base[16];          // base_transformation_ = guess (row-major float)
-  int ns;
-  smhip_status status = SMHIP_OK;
+  GicpTask* t;
   void fdf(const double* x, double& f, double* g) {
-    GicpHost& G = gicp_of(h);
-    GicpPose P;
     float T[16];
-    apply_state_f32(base, x, T);
-    for (int i = 0; i < 12; ++i) { P.T[i] = T[i]; P.B[i] = base[i]; }
-    const int blocks = std::min(kGicpMaxBlocks, std::max(1, ceil_div(ns, 256)));
-    // one launch; its last workgroup stores the sums and then this evaluation's number into page-locked memory (gicp_fdf)
-    const unsigned long long seq = ++G.seq;
-    hipLaunchKernelGGL(gicp_fdf, dim3(blocks), dim3(256), 0, h->stream, h->dev, G.dev, ns, P, seq);
-    bool ok = hipGetLastError() == hipSuccess;
-    if (ok) {
-      volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(G.out_pinned + kGicpCols);
-      const auto t0 = std::chrono::steady_clock::now();
-      unsigned spins = 0;
-      while (__atomic_load_n(const_cast<unsigned long long*>(flag), __ATOMIC_ACQUIRE) != seq) {
-        if ((++spins & 0x3ffu) == 0) {
-          if (spins > (1u << 16)) std::this_thread::yield();                     // a long evaluation (shared GPU): stop burning the core
-          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
-            // slow is not failed (an oversubscribed GPU, six pooled matchers): wait for the stream the ordinary way and look again
-            ok = hipStreamSynchronize(h->stream) == hipSuccess && hipGetLastError() == hipSuccess &&
-                 __atomic_load_n(const_cast<unsigned long long*>(flag), __ATOMIC_ACQUIRE) == seq;
-            break;
-          }
-        }
-      }
-    }
-    if (!ok) {
-      // the launch was lost or died before its last workgroup: leave the ticket counter clean for the next evaluation
-      (void)hipStreamSynchronize(h->stream);
-      (void)hipMemsetAsync(G.dev.ticket, 0, sizeof(uint32_t), h->stream);
-      status = SMHIP_ERR_HIP; f = 0; for (int i = 0; i < 6; ++i) g[i] = 0; return;
-    }
-    const double* o = G.out_pinned;
+    apply_state_f32(t->guess, x, T);
+    for (int i = 0; i < 12; ++i) { t->P.T[i] = T[i]; t->P.B[i] = t->guess[i]; }
+    if (t->status == SMHIP_OK) { t->req = GicpTask::kFdf; t->yield(); }
+    if (t->status) { f = 0; for (int i = 0; i < 6; ++i) g[i] = 0; return; }     // (the run is being abandoned: any finite answer ends it)
+    const double* o = gicp_of(t->h).out_pinned + (size_t)t->job * kGicpCols;
     const double m = o[13];
     f = o[0] / m;
     for (int i = 0; i < 3; ++i) g[i] = o[1 + i] * (2.0 / m);
     double R[9];
     for (int i = 0; i < 9; ++i) R[i] = o[4 + i] * (2.0 / m);
     r_derivative(x, R, g);
-    G.evals++;
+    t->evals++;
   }
 };
 
@@ -323,120 +330,180 @@ struct Bfgs {
   int test_gradient(double eps) const { return g0norm < eps ? kBfgsSuccess : kBfgsRunning; }
 };
 
-// both working slots prepared as search structures: slot 0 = (source, target), slot 1 = (source as its own target)
-smhip_status gicp_prepare_slots(smhip_context* h, int np, const double* T_colmajor, int* ns_max, int* nt_max) {
-  double guesses[32];
-  for (int p = 0; p < np; ++p) for (int i = 0; i < 16; ++i) guesses[16 * p + i] = p == 0 ? T_colmajor[i] : ((i % 5 == 0) ? 1.0 : 0.0);
-  int had[2] = {h->has_normals[0], h->has_normals[1]};
-  for (int p = 0; p < np; ++p) h->has_normals[p] = 1;
-  smhip_status s = fill_inputs(h, np, guesses, ns_max, nt_max);
-  for (int p = 0; p < np; ++p) h->has_normals[p] = had[p];
+// ring-search settings of the GICP searches (exact distances, no tie-order requirement, no previous match to seed a ball)
+struct GicpSearchMode {
+  smhip_context* h; int sort_was, ball_was, ring_was; float cutoff_was;
+  explicit GicpSearchMode(smhip_context* h_) : h(h_), sort_was(h_->dev.sort_cells), ball_was(h_->dev.use_ball), ring_was(h_->dev.max_ring), cutoff_was(h_->dev.nn_cutoff2) {
+    h->dev.sort_cells = 0; h->dev.use_ball = 0;
+  }
+  ~GicpSearchMode() { h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was; h->dev.max_ring = ring_was; h->dev.nn_cutoff2 = cutoff_was; }
+};
+
+// One grid cell for everything an Align searches (the NDT fitness pass, the 20-NN sets, the correspondences, the final fitness):
+// the searches are exact whatever the cell, and a common one means a target's grid is built once per Align instead of three
+// times.  The k-NN search wants cells of a few point spacings -- one shell then holds the 20 neighbours almost everywhere.
+struct GicpCell {
+  smhip_context* h; float was;
+  GicpCell(smhip_context* h_, const smhip_ndt_gicp_options& o) : h(h_), was(h_->dev.grid_cell) {
+    h->dev.grid_cell = o.gicp_search_cell > 0 ? o.gicp_search_cell : 3.0f * (o.using_voxel_filter ? o.voxel_resolution : 0.2f);
+  }
+  ~GicpCell() { h->dev.grid_cell = was; }
+};
+
+// pair inputs of slots [first, first + K) (guesses: column-major 4x4 each); the GICP clouds carry no normals
+smhip_status gicp_fill_inputs(smhip_context* h, int first, int K, const double* guesses, int* ns_max, int* nt_max) {
+  std::vector<int> had((size_t)K);
+  for (int k = 0; k < K; ++k) { had[k] = h->has_normals[first + k]; h->has_normals[first + k] = 1; }
+  const smhip_status s = fill_inputs(h, K, guesses, ns_max, nt_max, first);
+  for (int k = 0; k < K; ++k) h->has_normals[first + k] = had[k];
+  return s;
+}
+
+// search structures over the targets of slots [first, first + K), built (all of them, one pass) unless every one is current
+smhip_status gicp_build_grids(smhip_context* h, int first, int K, bool* kept) {
+  bool cached = true;
+  for (int p = first; p < first + K; ++p) cached = cached && grid_cached(h, p);
+  *kept = cached;
+  if (cached) return SMHIP_OK;
+  std::vector<double> I((size_t)16 * K, 0.0);
+  for (int k = 0; k < K; ++k) for (int i = 0; i < 4; ++i) I[(size_t)16 * k + 5 * i] = 1.0;
+  int ns_max = 0, nt_max = 0;
+  smhip_status s = gicp_fill_inputs(h, first, K, I.data(), &ns_max, &nt_max);
   if (s) return s;
-  const int sort_was = h->dev.sort_cells, ball_was = h->dev.use_ball;
-  h->dev.sort_cells = 0; h->dev.use_ball = 0;
-  s = enqueue_prepare(h, np, *nt_max);
-  h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was;
-  return s;
-}
-
-// the same for slot 1 alone (slot 0's target-side results are kept)
-smhip_status gicp_prepare_slot1(smhip_context* h, int* ns_max, int* nt_max) {
-  double guess[16];
-  for (int i = 0; i < 16; ++i) guess[i] = (i % 5 == 0) ? 1.0 : 0.0;
-  const int had = h->has_normals[1];
-  h->has_normals[1] = 1;
-  smhip_status s = fill_inputs(h, 1, guess, ns_max, nt_max, 1);
-  h->has_normals[1] = had;
+  s = enqueue_resets(h, K, first);
   if (s) return s;
-  const int sort_was = h->dev.sort_cells, ball_was = h->dev.use_ball;
-  h->dev.sort_cells = 0; h->dev.use_ball = 0;
-  s = enqueue_prepare_one(h, 1, *nt_max);
-  h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was;
-  return s;
+  return enqueue_grid_build(h, whole_batch(h, K, first), nt_max);
 }
 
-smhip_status gicp_find_closests(smhip_context* h, int ns_max, float cutoff2) {
-  const int sort_was = h->dev.sort_cells, ball_was = h->dev.use_ball;
-  h->dev.sort_cells = 0; h->dev.use_ball = 0;
-  h->dev.nn_cutoff2 = cutoff2;          // correspondences beyond the distance threshold are dropped anyway (gicp_corr)
-  // with the row-occupancy bitmap a wide ring is cheap: let the ring search reach the correspondence distance (5 m =
-  // 20 cells) instead of handing the far queries to the brute-force sweep over the whole 0.5 M-point target
-  const int ring_was = h->dev.max_ring;
-  h->dev.max_ring = std::max(ring_was, 32);
-  const smhip_status s = enqueue_find_closests(h, 1, ns_max);
-  h->dev.max_ring = ring_was;
-  h->dev.nn_cutoff2 = 0.f;
-  h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was;
-  HIPCHK(h, hipMemsetAsync(h->dev.hist, 0, sizeof(uint32_t) * kHistBins, h->stream));
-  h->ev_used = 0;
-  return s;
-}
-
-// pcl GICP computeTransformation (:381-514) on slot 0's clouds; guess / result are float 4x4 row-major
-smhip_status gicp_align_slot0(smhip_context* h, const float* guess, float* final_out, smhip_ndt_gicp_stats* stats) {
+// One round of the batch: the correspondence steps (:405-463: 1-NN of the moved source, distance filter, Mahalanobis matrices)
+// of the jobs in `corr` and the functor evaluations of the jobs in `fdf`, all jobs of slots [first, first + K)
+smhip_status gicp_round(smhip_context* h, int first, int K, const std::vector<GicpTask*>& corr, const std::vector<GicpTask*>& fdf) {
   GicpHost& G = gicp_of(h);
   const smhip_ndt_gicp_options& o = G.opts;
-  const int ns = h->ns[0], nt = h->nt[0], k = o.gicp_k_correspondences;
-  if (k < 3 || k > kGicpKMax) { h->err = "gicp_k_correspondences must be in [3, 32]"; return SMHIP_ERR_INVALID_ARGUMENT; }
-  if (ns < k || nt < k) { h->err = "GICP: a cloud has fewer points than k_correspondences (gicp_omp_impl.hpp:64-68)"; return SMHIP_ERR_INVALID_ARGUMENT; }
-  if (ns > h->dev.nt_cap) { h->err = "GICP: max_target_points must be >= the down-sampled source size"; return SMHIP_ERR_CAPACITY; }
-  // ---- covariances (:391-402): target over slot 0's grid, source over slot 1's (the source as its own target)
-  hipLaunchKernelGGL(gicp_copy_points, dim3(ceil_div(ns, 256)), dim3(256), 0, h->stream, h->dev.src,
-                     const_cast<float4*>(h->dev.tgt_p) + h->dev.nt_cap, ns);
-  h->ns[1] = ns; h->nt[1] = ns;
-  touch_target(h, 1);
-  double I16[16];
-  for (int i = 0; i < 16; ++i) I16[i] = (i % 5 == 0) ? 1.0 : 0.0;
-  int ns_max = 0, nt_max = 0;
-  // the k-NN search wants cells of a few point spacings: one shell then holds the 20 neighbours almost everywhere
-  const float cell_was = h->dev.grid_cell;
-  h->dev.grid_cell = o.gicp_search_cell > 0 ? o.gicp_search_cell : 3.0f * (o.using_voxel_filter ? o.voxel_resolution : 0.2f);
-  const float knn_cell = h->dev.grid_cell;
-  // the target's covariances depend on the target, k, epsilon and the search cell alone: kept while those are
-  const bool cov_kept = h->target_cache && G.cov_gen != 0 && G.cov_gen == h->tgt_gen[0] && G.cov_k == k && G.cov_eps == o.gicp_epsilon && G.cov_cell == knn_cell;
-  smhip_status s = cov_kept ? gicp_prepare_slot1(h, &ns_max, &nt_max) : gicp_prepare_slots(h, 2, I16, &ns_max, &nt_max);
-  h->dev.grid_cell = cell_was;
-  if (s) return s;
-  if (cov_kept) h->cache_hits++;
-  // the set's LDS footprint follows k (the default 20 fits 20 entries per thread: 20 KiB per workgroup instead of 32)
-  IcpDev dk = h->dev;
-  dk.have_rowbits = 1;                       // built by gicp_prepare_slots (a ring-search context)
-  if (k <= 20) {
-    if (!cov_kept) hipLaunchKernelGGL(gicp_knn_cov<20>, dim3(ceil_div(nt, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, dk, 0, k, o.gicp_epsilon, G.dev.cov_t);
-    hipLaunchKernelGGL(gicp_knn_cov<20>, dim3(ceil_div(ns, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, dk, 1, k, o.gicp_epsilon, G.dev.cov_s);
-  } else {
-    if (!cov_kept) hipLaunchKernelGGL(gicp_knn_cov<kGicpKMax>, dim3(ceil_div(nt, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, dk, 0, k, o.gicp_epsilon, G.dev.cov_t);
-    hipLaunchKernelGGL(gicp_knn_cov<kGicpKMax>, dim3(ceil_div(ns, kGicpKnnThreads)), dim3(kGicpKnnThreads), 0, h->stream, dk, 1, k, o.gicp_epsilon, G.dev.cov_s);
+  if (!corr.empty()) {
+    // pair inputs: the jobs of this step get their pose, the others no queries (their slots are skipped by every launch)
+    std::vector<double> g((size_t)16 * K, 0.0);
+    for (int k = 0; k < K; ++k) for (int i = 0; i < 4; ++i) g[(size_t)16 * k + 5 * i] = 1.0;
+    std::vector<char> in_step((size_t)K, 0);
+    for (const GicpTask* t : corr) { std::memcpy(&g[(size_t)16 * (t->job - first)], t->TRcm, sizeof(double) * 16); in_step[t->job - first] = 1; }
+    int ns_max = 0, nt_max = 0;
+    smhip_status s = gicp_fill_inputs(h, first, K, g.data(), &ns_max, &nt_max);
+    if (s) return s;
+    ns_max = 0;
+    for (int k = 0; k < K; ++k) {
+      if (in_step[k]) ns_max = std::max(ns_max, h->ns[first + k]);
+      else h->in_pinned[first + k].ns = 0;
+    }
+    const float thr2 = (float)(o.gicp_corr_dist_threshold * o.gicp_corr_dist_threshold);
+    {
+      GicpSearchMode mode(h);
+      bool cached = true;
+      for (int p = first; p < first + K; ++p) cached = cached && grid_cached(h, p);
+      const Half f = whole_batch(h, K, first);
+      if (cached) {
+        HIPCHK(h, hipMemcpyAsync(const_cast<PairInput*>(f.d.in) + first, h->in_pinned + first, sizeof(PairInput) * K, hipMemcpyHostToDevice, h->stream));
+        s = ensure_packed(h, first, K);
+        if (s) return s;
+        hipLaunchKernelGGL(reset_scratch_light, dim3(std::min(1024, 8 * K)), dim3(256), 0, h->stream, f.d, first, K);
+        hipLaunchKernelGGL(pose_setup, dim3(ceil_div(K, 64)), dim3(64), 0, h->stream, f.d, K);
+        h->cache_hits++;
+      } else {
+        s = enqueue_resets(h, K, first);
+        if (s == SMHIP_OK) s = enqueue_grid_build(h, f, nt_max);
+        if (s) return s;
+      }
+      h->dev.nn_cutoff2 = thr2;          // correspondences beyond the distance threshold are dropped anyway (gicp_corr)
+      // with the row-occupancy bitmap a wide ring is cheap: let the ring search reach the correspondence distance (5 m)
+      // instead of handing the far queries to the brute-force sweep over the whole 0.5 M-point target
+      h->dev.max_ring = std::max(h->dev.max_ring, 32);
+      s = enqueue_find_closests_half(h, whole_batch(h, K, first), ns_max, 0);
+      if (s) return s;
+    }
+    HIPCHK(h, hipMemsetAsync(h->dev.hist + (size_t)first * kHistBins, 0, sizeof(uint32_t) * kHistBins * (size_t)K, h->stream));
+    h->ev_used = 0;
+    HIPCHK(h, hipMemsetAsync(G.dev.count + first, 0, sizeof(uint32_t) * (size_t)K, h->stream));
+    for (size_t c0 = 0; c0 < corr.size(); c0 += kGicpLaunchJobs) {
+      GicpCorrBatch L{};
+      L.n = (int)std::min<size_t>(kGicpLaunchJobs, corr.size() - c0);
+      int nmax = 0;
+      for (int e = 0; e < L.n; ++e) {
+        const GicpTask* t = corr[c0 + e];
+        L.j[e].job = t->job; L.j[e].ns = t->ns; L.j[e].thr2 = thr2;
+        for (int i = 0; i < 9; ++i) L.j[e].R[i] = t->R9[i];
+        nmax = std::max(nmax, t->ns);
+      }
+      hipLaunchKernelGGL(gicp_corr, dim3(ceil_div(nmax, 256), L.n), dim3(256), 0, h->stream, h->dev, G.dev, L);
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(G.count_pinned + first, G.dev.count + first, sizeof(uint32_t) * (size_t)K, hipMemcpyDeviceToHost, h->stream));
   }
-  G.cov_gen = h->tgt_gen[0]; G.cov_k = k; G.cov_eps = o.gicp_epsilon; G.cov_cell = knn_cell;
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipStreamSynchronize(h->stream));              // the pinned pair inputs are rewritten below
-  // ---- outer loop
+  unsigned long long seq = 0;
+  if (!fdf.empty()) {
+    seq = ++G.seq;
+    for (size_t c0 = 0; c0 < fdf.size(); c0 += kGicpLaunchJobs) {
+      GicpFdfBatch L{};
+      L.n = (int)std::min<size_t>(kGicpLaunchJobs, fdf.size() - c0);
+      L.total = (int)fdf.size();
+      L.seq = seq;
+      int bmax = 1;
+      for (int e = 0; e < L.n; ++e) {
+        const GicpTask* t = fdf[c0 + e];
+        L.j[e].job = t->job; L.j[e].ns = t->ns;
+        L.j[e].nblk = std::min(kGicpMaxBlocks, std::max(1, ceil_div(t->ns, 256)));
+        L.j[e].P = t->P;
+        bmax = std::max(bmax, L.j[e].nblk);
+      }
+      // its last workgroup stores the sums and, after the round's last job, the round's number into page-locked memory
+      hipLaunchKernelGGL(gicp_fdf, dim3(bmax, L.n), dim3(256), 0, h->stream, h->dev, G.dev, L);
+    }
+  }
+  bool ok = hipGetLastError() == hipSuccess;
+  if (ok && !corr.empty()) {
+    ok = hipStreamSynchronize(h->stream) == hipSuccess;
+  } else if (ok) {
+    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(G.out_pinned + (size_t)G.jobs * kGicpCols);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(const_cast<unsigned long long*>(flag), __ATOMIC_ACQUIRE) != seq) {
+      if ((++spins & 0x3ffu) == 0) {
+        if (spins > (1u << 16)) std::this_thread::yield();                     // a long evaluation (shared GPU): stop burning the core
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+          // slow is not failed (an oversubscribed GPU, six pooled matchers): wait for the stream the ordinary way and look again
+          ok = hipStreamSynchronize(h->stream) == hipSuccess && hipGetLastError() == hipSuccess &&
+               __atomic_load_n(const_cast<unsigned long long*>(flag), __ATOMIC_ACQUIRE) == seq;
+          break;
+        }
+      }
+    }
+  }
+  if (!ok) {
+    // a launch was lost or died before its last workgroup: leave the counters clean for the next evaluation
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipMemsetAsync(G.dev.ticket, 0, sizeof(uint32_t) * (size_t)G.jobs, h->stream);
+    (void)hipMemsetAsync(G.dev.round_done, 0, sizeof(uint32_t), h->stream);
+    h->err = "GICP: a correspondence / functor launch failed";
+    return SMHIP_ERR_HIP;
+  }
+  for (GicpTask* t : corr) t->ncorr = G.count_pinned[t->job];
+  return SMHIP_OK;
+}
+
+// pcl GICP computeTransformation's outer loop (:404-514) on the job's clouds; covariances are in place
+void GicpTask::body() {
+  const smhip_ndt_gicp_options& o = gicp_of(h).opts;
   float T[16], prev[16];                                   // transformation_, previous_transformation_
   for (int i = 0; i < 16; ++i) T[i] = prev[i] = (i % 5 == 0) ? 1.f : 0.f;
-  GicpFunctor fn{h, {}, ns};
-  for (int i = 0; i < 16; ++i) fn.base[i] = guess[i];
-  const float thr2 = (float)(o.gicp_corr_dist_threshold * o.gicp_corr_dist_threshold);
-  int it = 0;
-  uint32_t ncorr = 0;
-  G.evals = 0;
+  GicpFunctor fn{this};
+  it = 0; evals = 0; ncorr = 0;
+  const bool dbg = std::getenv("SMHIP_GICP_DEBUG") != nullptr;
   for (;;) {
     // transform_R = transformation_ * guess in double (:425-429); the search uses the same product
     double TR[16];
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { double a = 0; for (int q = 0; q < 4; ++q) a += (double)T[4 * i + q] * (double)guess[4 * q + j]; TR[4 * i + j] = a; }
-    double TRcm[16], R9[9];
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) TRcm[4 * j + i] = TR[4 * i + j];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R9[3 * i + j] = TR[4 * i + j];
-    s = gicp_prepare_slots(h, 1, TRcm, &ns_max, &nt_max);
-    if (s) return s;
-    s = gicp_find_closests(h, ns_max, thr2);
-    if (s) return s;
-    HIPCHK(h, hipMemcpyAsync(G.rot_dev, R9, sizeof(R9), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(G.dev.count, 0, sizeof(uint32_t), h->stream));
-    hipLaunchKernelGGL(gicp_corr, dim3(ceil_div(ns, 256)), dim3(256), 0, h->stream, h->dev, G.dev, ns, thr2, G.rot_dev);
-    HIPCHK(h, hipMemcpyAsync(G.count_pinned, G.dev.count, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));   // also keeps R9 alive until it is on the device
-    ncorr = *G.count_pinned;
+    req = kCorr; yield();
+    if (status) return;
     for (int i = 0; i < 16; ++i) prev[i] = T[i];                          // :467
     if (ncorr < 4) break;                                                // NotEnoughPointsException -> break (:494-498)
     // ---- estimateRigidTransformationBFGS (:189-247)
@@ -444,16 +511,15 @@ smhip_status gicp_align_slot0(smhip_context* h, const float* guess, float* final
     Bfgs bfgs(fn);
     bfgs.init(x);
     int inner = 0, result;
-    const bool dbg = std::getenv("SMHIP_GICP_DEBUG") != nullptr;
-    if (dbg) std::fprintf(stderr, "[gicp] outer %d m=%u f0=%.12g g0=(%.6g %.6g %.6g %.6g %.6g %.6g)\n", it, ncorr, bfgs.f, bfgs.g0[0], bfgs.g0[1], bfgs.g0[2], bfgs.g0[3], bfgs.g0[4], bfgs.g0[5]);
+    if (dbg) std::fprintf(stderr, "[gicp] job %d outer %d m=%u f0=%.12g g0=(%.6g %.6g %.6g %.6g %.6g %.6g)\n", job, it, ncorr, bfgs.f, bfgs.g0[0], bfgs.g0[1], bfgs.g0[2], bfgs.g0[3], bfgs.g0[4], bfgs.g0[5]);
     do {
       inner++;
       result = bfgs.one_step(x);
-      if (dbg) std::fprintf(stderr, "[gicp]   inner %d status %d f=%.12g |g|=%.6g x=(%.8g %.8g %.8g %.8g %.8g %.8g) evals=%d\n", inner, result, bfgs.f, bfgs.g0norm, x[0], x[1], x[2], x[3], x[4], x[5], G.evals);
+      if (dbg) std::fprintf(stderr, "[gicp]   inner %d status %d f=%.12g |g|=%.6g x=(%.8g %.8g %.8g %.8g %.8g %.8g) evals=%d\n", inner, result, bfgs.f, bfgs.g0norm, x[0], x[1], x[2], x[3], x[4], x[5], evals);
       if (result) break;
       result = bfgs.test_gradient(1e-2);
-    } while (result == kBfgsRunning && inner < o.gicp_max_inner_iterations);
-    if (fn.status) { h->err = "GICP functor evaluation failed"; return fn.status; }
+    } while (result == kBfgsRunning && inner < o.gicp_max_inner_iterations && status == SMHIP_OK);
+    if (status) return;
     const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     apply_state_f32(I4, x, T);                                           // :240-241
     double delta = 0;                                                    // :475-491
@@ -466,12 +532,125 @@ smhip_status gicp_align_slot0(smhip_context* h, const float* guess, float* final
     if (it >= o.gicp_max_iterations || delta < 1) { for (int i = 0; i < 16; ++i) prev[i] = T[i]; break; }   // :500-505
   }
   // final_transformation_ (:511-514)
-  for (int i = 0; i < 16; ++i) final_out[i] = (i % 5 == 0) ? 1.f : 0.f;
+  for (int i = 0; i < 16; ++i) fin[i] = (i % 5 == 0) ? 1.f : 0.f;
   for (int r = 0; r < 3; ++r) {
-    for (int c = 0; c < 3; ++c) { float a = 0; for (int q = 0; q < 3; ++q) a += prev[4 * r + q] * guess[4 * q + c]; final_out[4 * r + c] = a; }
-    final_out[4 * r + 3] = prev[4 * r + 3] + guess[4 * r + 3];
+    for (int c = 0; c < 3; ++c) { float a = 0; for (int q = 0; q < 3; ++q) a += prev[4 * r + q] * guess[4 * q + c]; fin[4 * r + c] = a; }
+    fin[4 * r + 3] = prev[4 * r + 3] + guess[4 * r + 3];
   }
-  if (stats) { stats->gicp_iterations = it; stats->gicp_function_evaluations = G.evals; stats->gicp_correspondences = (int32_t)ncorr; }
+}
+
+void gicp_task_entry(unsigned lo, unsigned hi) {
+  GicpTask* t = reinterpret_cast<GicpTask*>(((uintptr_t)hi << 32) | (uintptr_t)lo);
+  t->body();
+  t->req = GicpTask::kDone;
+  t->yield();                                              // never resumed
+}
+
+// the live tasks (jobs of slots [first, first + K)) advanced in lock-step until each has finished
+smhip_status gicp_run_tasks(smhip_context* h, int first, int K, std::vector<GicpTask>& tasks) {
+  constexpr size_t kStack = 256 * 1024;
+  for (GicpTask& t : tasks) {
+    if (!t.live) continue;
+    t.stack.reset(new char[kStack]);
+    if (getcontext(&t.ctx) != 0) { h->err = "getcontext failed"; return SMHIP_ERR_HIP; }
+    t.ctx.uc_stack.ss_sp = t.stack.get();
+    t.ctx.uc_stack.ss_size = kStack;
+    t.ctx.uc_link = nullptr;
+    const uintptr_t p = reinterpret_cast<uintptr_t>(&t);
+    makecontext(&t.ctx, reinterpret_cast<void (*)()>(gicp_task_entry), 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
+  }
+  std::vector<GicpTask*> corr, fdf;
+  for (;;) {
+    corr.clear(); fdf.clear();
+    for (GicpTask& t : tasks) {
+      if (!t.live) continue;
+      swapcontext(&t.sched, &t.ctx);                       // runs until the job's next request
+      if (t.req == GicpTask::kDone) t.live = false;
+      else (t.req == GicpTask::kCorr ? corr : fdf).push_back(&t);
+    }
+    if (corr.empty() && fdf.empty()) return SMHIP_OK;
+    const smhip_status s = gicp_round(h, first, K, corr, fdf);
+    if (s) return s;                                       // (the unfinished coroutines are dropped with their stacks)
+  }
+}
+
+// GICP of the jobs first .. first + K - 1 whose `run` flag is set: covariances (:391-402), then the lock-step outer loops.
+// guess / fin: float 4x4 row-major per job
+smhip_status gicp_align_jobs(smhip_context* h, int first, int K, const char* run, const float* guess, float* fin, smhip_ndt_gicp_stats* stats) {
+  GicpHost& G = gicp_of(h);
+  const smhip_ndt_gicp_options& o = G.opts;
+  const int k = o.gicp_k_correspondences;
+  if (k < 3 || k > kGicpKMax) { h->err = "gicp_k_correspondences must be in [3, 32]"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  const int sfirst = gicp_scratch_slot(h, first);
+  for (int e = 0; e < K; ++e) {
+    const int ns = h->ns[first + e], nt = h->nt[first + e];
+    if (ns < k || nt < k) { h->err = "GICP: a cloud has fewer points than k_correspondences (gicp_omp_impl.hpp:64-68)"; return SMHIP_ERR_INVALID_ARGUMENT; }
+    if (ns > h->dev.nt_cap) { h->err = "GICP: max_target_points must be >= the down-sampled source size"; return SMHIP_ERR_CAPACITY; }
+  }
+  // ---- covariances: a target's over its job slot's grid, a source's over the scratch slot's (the source as its own target)
+  for (int e = 0; e < K; ++e) {
+    const int ns = h->ns[first + e];
+    hipLaunchKernelGGL(gicp_copy_points, dim3(ceil_div(ns, 256)), dim3(256), 0, h->stream, h->dev.src + (size_t)(first + e) * h->dev.ns_cap,
+                       const_cast<float4*>(h->dev.tgt_p) + (size_t)(sfirst + e) * h->dev.nt_cap, ns);
+    h->ns[sfirst + e] = ns; h->nt[sfirst + e] = ns;
+    touch_target(h, sfirst + e);
+  }
+  const float knn_cell = h->dev.grid_cell;                 // (GicpCell)
+  {
+    GicpSearchMode mode(h);
+    bool kept = false;
+    smhip_status s = gicp_build_grids(h, sfirst, K, &kept);
+    if (s == SMHIP_OK) s = gicp_build_grids(h, first, K, &kept);
+    if (s) return s;
+    if (kept) h->cache_hits++;
+  }
+  {
+    // the targets' covariances depend on the target, k, epsilon and the search cell alone: kept while those are
+    IcpDev dk = h->dev;
+    dk.have_rowbits = 1;                       // built by gicp_build_grids (a ring-search context)
+    GicpKnnBatch L{};
+    int nmax = 0;
+    auto flush = [&]() {
+      if (!L.n) return;
+      // the set's LDS footprint follows k (the default 20 fits 20 entries per thread: 20 KiB per workgroup instead of 32)
+      if (k <= 20) hipLaunchKernelGGL(gicp_knn_cov<20>, dim3(ceil_div(nmax, kGicpKnnThreads), L.n), dim3(kGicpKnnThreads), 0, h->stream, dk, L, k, o.gicp_epsilon);
+      else hipLaunchKernelGGL(gicp_knn_cov<kGicpKMax>, dim3(ceil_div(nmax, kGicpKnnThreads), L.n), dim3(kGicpKnnThreads), 0, h->stream, dk, L, k, o.gicp_epsilon);
+      L.n = 0; nmax = 0;
+    };
+    auto add = [&](int slot, double* cov, int n) {
+      L.slot[L.n] = slot; L.cov[L.n] = cov; ++L.n;
+      nmax = std::max(nmax, n);
+      if (L.n == kGicpKnnJobs) flush();
+    };
+    for (int e = 0; e < K; ++e) {
+      if (!run[e]) continue;
+      GicpJobHost& jh = G.job[first + e];
+      const bool cov_kept = h->target_cache && jh.cov_gen != 0 && jh.cov_gen == h->tgt_gen[first + e] && jh.cov_k == k && jh.cov_eps == o.gicp_epsilon && jh.cov_cell == knn_cell;
+      if (!cov_kept) add(first + e, G.dev.cov_t + (size_t)(first + e) * h->dev.nt_cap * 6, h->nt[first + e]);
+      else h->cache_hits++;
+      add(sfirst + e, G.dev.cov_s + (size_t)(first + e) * h->dev.ns_cap * 6, h->ns[first + e]);
+      jh.cov_gen = h->tgt_gen[first + e]; jh.cov_k = k; jh.cov_eps = o.gicp_epsilon; jh.cov_cell = knn_cell;
+    }
+    flush();
+  }
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));              // the pinned pair inputs are rewritten below
+  // ---- outer loops
+  std::vector<GicpTask> tasks((size_t)K);
+  for (int e = 0; e < K; ++e) {
+    GicpTask& t = tasks[e];
+    t.h = h; t.job = first + e; t.ns = h->ns[first + e]; t.live = run[e] != 0;
+    for (int i = 0; i < 16; ++i) t.guess[i] = guess[16 * e + i];
+  }
+  const smhip_status s = gicp_run_tasks(h, first, K, tasks);
+  if (s) return s;
+  for (int e = 0; e < K; ++e) {
+    if (!run[e]) continue;
+    const GicpTask& t = tasks[e];
+    for (int i = 0; i < 16; ++i) fin[16 * e + i] = t.fin[i];
+    if (stats) { stats[e].gicp_iterations = t.it; stats[e].gicp_function_evaluations = t.evals; stats[e].gicp_correspondences = (int32_t)t.ncorr; }
+    G.evals = t.evals;
+  }
   return SMHIP_OK;
 }
 
@@ -526,75 +705,103 @@ smhip_status smhip_ndt_gicp_set_options(smhip_handle h, const smhip_ndt_gicp_opt
   return SMHIP_OK;
 }
 
-smhip_status smhip_ndt_gicp_set_source_f32(smhip_handle h, const float* xyz, int stride_floats, int n) {
+static smhip_status gicp_check_job(smhip_handle h, int job) {
   if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
   smhip_status s = gicp_ensure(h);
   if (s) return s;
+  if (job < 0 || job >= gicp_of(h).jobs) { h->err = "NdtWithGicp job out of range (a handle runs pair_slots / 2 jobs)"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  return SMHIP_OK;
+}
+
+int smhip_ndt_gicp_jobs(smhip_handle h) { return h ? h->dev.slots / 2 : 0; }
+
+smhip_status smhip_ndt_gicp_set_source_f32_job(smhip_handle h, int job, const float* xyz, int stride_floats, int n) {
+  smhip_status s = gicp_check_job(h, job);
+  if (s) return s;
   GicpHost& g = gicp_of(h);
-  return gicp_upload_raw(h, g.raw_src, xyz, stride_floats, n, h->dev.ns_cap, &g.n_raw_src);
+  return gicp_upload_raw(h, g.raw_src + (size_t)job * h->dev.ns_cap, xyz, stride_floats, n, h->dev.ns_cap, &g.job[job].n_raw_src);
+}
+
+smhip_status smhip_ndt_gicp_set_target_f32_job(smhip_handle h, int job, const float* xyz, int stride_floats, int n) {
+  smhip_status s = gicp_check_job(h, job);
+  if (s) return s;
+  GicpHost& g = gicp_of(h);
+  g.job[job].raw_tgt_gen = ++h->gen_counter;
+  return gicp_upload_raw(h, g.raw_tgt + (size_t)job * h->dev.nt_cap, xyz, stride_floats, n, h->dev.nt_cap, &g.job[job].n_raw_tgt);
+}
+
+smhip_status smhip_ndt_gicp_set_source_f32(smhip_handle h, const float* xyz, int stride_floats, int n) {
+  return smhip_ndt_gicp_set_source_f32_job(h, 0, xyz, stride_floats, n);
 }
 
 smhip_status smhip_ndt_gicp_set_target_f32(smhip_handle h, const float* xyz, int stride_floats, int n) {
-  if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
-  smhip_status s = gicp_ensure(h);
-  if (s) return s;
-  GicpHost& g = gicp_of(h);
-  g.raw_tgt_gen = ++h->gen_counter;
-  return gicp_upload_raw(h, g.raw_tgt, xyz, stride_floats, n, h->dev.nt_cap, &g.n_raw_tgt);
+  return smhip_ndt_gicp_set_target_f32_job(h, 0, xyz, stride_floats, n);
 }
 
-// ndt_gicp.cc:55-81: the (optionally down-sampled) clouds become slot 0's source and target
-static smhip_status ndt_gicp_stage_clouds(smhip_handle h) {
+// ndt_gicp.cc:55-81: the (optionally down-sampled) clouds become the job slot's source and target
+static smhip_status ndt_gicp_stage_clouds(smhip_handle h, int job) {
   GicpHost& g = gicp_of(h);
-  if (g.n_raw_src <= 0 || g.n_raw_tgt <= 0) { h->err = "NdtWithGicp::Align before SetInputSource/SetInputTarget"; return SMHIP_ERR_NOT_READY; }
-  float4* src0 = const_cast<float4*>(h->dev.src);
-  float4* tgt0 = const_cast<float4*>(h->dev.tgt_p);
-  int ms = g.n_raw_src, mt = g.n_raw_tgt;
+  GicpJobHost& jh = g.job[job];
+  if (jh.n_raw_src <= 0 || jh.n_raw_tgt <= 0) { h->err = "NdtWithGicp::Align before SetInputSource/SetInputTarget"; return SMHIP_ERR_NOT_READY; }
+  float4* src0 = const_cast<float4*>(h->dev.src) + (size_t)job * h->dev.ns_cap;
+  float4* tgt0 = const_cast<float4*>(h->dev.tgt_p) + (size_t)job * h->dev.nt_cap;
+  const float4* raw_src = g.raw_src + (size_t)job * h->dev.ns_cap;
+  const float4* raw_tgt = g.raw_tgt + (size_t)job * h->dev.nt_cap;
+  int ms = jh.n_raw_src, mt = jh.n_raw_tgt;
   hipError_t e = hipSuccess;
   const int filt = g.opts.using_voxel_filter ? 1 : 0;
-  const bool keep_target = h->target_cache && g.raw_tgt_gen != 0 && g.staged_raw_gen == g.raw_tgt_gen && g.staged_slot_gen == h->tgt_gen[0] &&
-                           g.staged_filter == filt && (!filt || g.staged_res == g.opts.voxel_resolution);
+  const bool keep_target = h->target_cache && jh.raw_tgt_gen != 0 && jh.staged_raw_gen == jh.raw_tgt_gen && jh.staged_slot_gen == h->tgt_gen[job] &&
+                           jh.staged_filter == filt && (!filt || jh.staged_res == g.opts.voxel_resolution);
   if (filt) {
-    e = prep_approx_voxel_grid(h->prep, h->stream, g.raw_src, g.n_raw_src, g.opts.voxel_resolution, g.ds_tmp, &ms);
+    e = prep_approx_voxel_grid(h->prep, h->stream, raw_src, jh.n_raw_src, g.opts.voxel_resolution, g.ds_tmp, &ms);
     if (e == hipSuccess) e = prep_morton_sort(h->prep, h->stream, g.ds_tmp, ms, src0);
-    if (e == hipSuccess && !keep_target) e = prep_approx_voxel_grid(h->prep, h->stream, g.raw_tgt, g.n_raw_tgt, g.opts.voxel_resolution, tgt0, &mt);
+    if (e == hipSuccess && !keep_target) e = prep_approx_voxel_grid(h->prep, h->stream, raw_tgt, jh.n_raw_tgt, g.opts.voxel_resolution, tgt0, &mt);
   } else {
-    e = prep_morton_sort(h->prep, h->stream, g.raw_src, ms, src0);
-    if (e == hipSuccess && !keep_target) e = hipMemcpyAsync(tgt0, g.raw_tgt, sizeof(float4) * (size_t)mt, hipMemcpyDeviceToDevice, h->stream);
+    e = prep_morton_sort(h->prep, h->stream, raw_src, ms, src0);
+    if (e == hipSuccess && !keep_target) e = hipMemcpyAsync(tgt0, raw_tgt, sizeof(float4) * (size_t)mt, hipMemcpyDeviceToDevice, h->stream);
   }
   if (e != hipSuccess) { h->err = std::string("NdtWithGicp down-sampling: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
-  h->ns[0] = ms; h->has_normals[0] = 0;
-  touch_source(h, 0);
+  h->ns[job] = ms; h->has_normals[job] = 0;
+  touch_source(h, job);
   if (keep_target) {
     h->cache_hits++;
     return SMHIP_OK;
   }
-  h->nt[0] = mt;
-  touch_target(h, 0);
-  g.staged_raw_gen = g.raw_tgt_gen; g.staged_slot_gen = h->tgt_gen[0]; g.staged_filter = filt; g.staged_res = g.opts.voxel_resolution; g.staged_nt = mt;
+  h->nt[job] = mt;
+  touch_target(h, job);
+  jh.staged_raw_gen = jh.raw_tgt_gen; jh.staged_slot_gen = h->tgt_gen[job]; jh.staged_filter = filt; jh.staged_res = g.opts.voxel_resolution; jh.staged_nt = mt;
   return SMHIP_OK;
 }
 
-smhip_status smhip_ndt_gicp_align(smhip_handle h, const double guess[16], double result[16], double* score, smhip_ndt_gicp_stats* stats) {
-  if (!h || !guess || !result) return SMHIP_ERR_INVALID_ARGUMENT;
+// NdtWithGicp::Align of the jobs first .. first + K - 1, each stage over all of them at once
+static smhip_status ndt_gicp_align_jobs(smhip_handle h, int first, int K, const double* guesses, double* results, double* scores, smhip_ndt_gicp_stats* stats) {
   HIPCHK(h, hipSetDevice(h->device));
   smhip_status s = gicp_ensure(h);
   if (s) return s;
   GicpHost& g = gicp_of(h);
-  smhip_ndt_gicp_stats st{};
+  if (first < 0 || K < 1 || first + K > g.jobs) { h->err = "NdtWithGicp jobs out of range (a handle runs pair_slots / 2 jobs)"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  std::vector<smhip_ndt_gicp_stats> st((size_t)K);
+  for (auto& x : st) std::memset(&x, 0, sizeof(x));
   // smhip_set_target_cache(h, 0) = nothing survives from one Align to the next, as in the reference; INSIDE an Align the
   // target's structures are still built once (PCL builds its kd-trees in setInputTarget, not per iteration)
   struct WithinAlign {
     smhip_context* h; decltype(smhip_context::target_cache) keep;
     ~WithinAlign() { h->target_cache = keep; }
   } within{h, h->target_cache};
-  if (!within.keep) { g.staged_raw_gen = 0; g.cov_gen = 0; for (auto& m : ndt_of(h).meta) m.valid = false; h->target_cache = 1; }
-  s = ndt_gicp_stage_clouds(h);
-  if (s) return s;
-  st.n_source = h->ns[0]; st.n_target = h->nt[0];
-  float ndt_guess[16];
-  colmajor_to_rm_f32(guess, ndt_guess);                      // guess.cast<float>(), :80
-  double ndt_score = 0.9;                                    // :81
+  if (!within.keep) {
+    for (int e = 0; e < K; ++e) { g.job[first + e].staged_raw_gen = 0; g.job[first + e].cov_gen = 0; touch_grid(h, first + e, 1); }
+    for (auto& m : ndt_of(h).meta) m.valid = false;
+    h->target_cache = 1;
+  }
+  GicpCell cell(h, g.opts);
+  for (int e = 0; e < K; ++e) {
+    s = ndt_gicp_stage_clouds(h, first + e);
+    if (s) return s;
+    st[e].n_source = h->ns[first + e]; st[e].n_target = h->nt[first + e];
+  }
+  std::vector<float> ndt_guess((size_t)16 * K), fin((size_t)16 * K);
+  std::vector<double> ndt_score((size_t)K, 0.9);             // :81
+  for (int e = 0; e < K; ++e) colmajor_to_rm_f32(guesses + 16 * e, &ndt_guess[(size_t)16 * e]);   // guess.cast<float>(), :80
   if (g.opts.use_ndt) {                                      // :82-90
     NdtHost& n = ndt_of(h);
     const smhip_ndt_options saved = n.opts;
@@ -604,32 +811,53 @@ smhip_status smhip_ndt_gicp_align(smhip_handle h, const double guess[16], double
     no.resolution = g.opts.ndt_resolution; no.step_size = g.opts.ndt_step_size;
     no.transformation_epsilon = g.opts.ndt_transformation_epsilon; no.max_iterations = g.opts.ndt_max_iterations;
     n.opts = no; n.double_math = true;
-    double nres[16];
-    smhip_ndt_stats ns{};
-    s = smhip_ndt_align(h, guess, nres, &ndt_score, &ns);
+    std::vector<double> nres((size_t)16 * K);
+    std::vector<smhip_ndt_stats> ns((size_t)K);
+    for (auto& x : ns) std::memset(&x, 0, sizeof(x));
+    s = ndt_align_slots(h, first, K, guesses, nres.data(), ndt_score.data(), ns.data());
     n.opts = saved; n.double_math = dm;
     if (s) return s;
-    colmajor_to_rm_f32(nres, ndt_guess);                     // ndt_.getFinalTransformation()
-    st.ndt_iterations = ns.iterations;
+    for (int e = 0; e < K; ++e) {
+      colmajor_to_rm_f32(&nres[(size_t)16 * e], &ndt_guess[(size_t)16 * e]);     // ndt_.getFinalTransformation()
+      st[e].ndt_iterations = ns[e].iterations;
+    }
   }
-  st.ndt_score = ndt_score;
-  double icp_score = 10.0;                                   // :92
-  if (ndt_score <= 1.0) {                                    // :94
-    float fin[16];
-    s = gicp_align_slot0(h, ndt_guess, fin, &st);
+  std::vector<char> run((size_t)K, 0);
+  bool any = false;
+  for (int e = 0; e < K; ++e) { st[e].ndt_score = ndt_score[e]; run[e] = ndt_score[e] <= 1.0 ? 1 : 0; any = any || run[e]; }   // :94
+  std::vector<double> fit((size_t)K, 10.0);                  // :92
+  if (any) {
+    s = gicp_align_jobs(h, first, K, run.data(), ndt_guess.data(), fin.data(), st.data());
     if (s) return s;
-    rm_f32_to_colmajor(fin, result);
-    s = fitness_score(h, result, &icp_score);                // gicp_.getFitnessScore(), :101
-    if (s) return s;
-    st.ok = 1;
-  } else {
-    for (int i = 0; i < 16; ++i) result[i] = guess[i];       // :106
-    st.ok = 0;
   }
-  st.gicp_score = icp_score;
-  if (score) *score = std::exp(-icp_score);                  // :103 / :107
-  if (stats) *stats = st;
+  for (int e = 0; e < K; ++e) {
+    if (run[e]) rm_f32_to_colmajor(&fin[(size_t)16 * e], results + 16 * e);
+    else for (int i = 0; i < 16; ++i) results[16 * e + i] = guesses[16 * e + i];   // :106
+  }
+  if (any) {
+    std::vector<double> f2((size_t)K);
+    s = fitness_scores(h, first, K, results, f2.data());    // gicp_.getFitnessScore(), :101
+    if (s) return s;
+    for (int e = 0; e < K; ++e) if (run[e]) fit[e] = f2[e];
+  }
+  for (int e = 0; e < K; ++e) {
+    st[e].ok = run[e] ? 1 : 0;
+    st[e].gicp_score = fit[e];
+    if (scores) scores[e] = std::exp(-fit[e]);               // :103 / :107
+    if (stats) stats[e] = st[e];
+  }
   return SMHIP_OK;
+}
+
+smhip_status smhip_ndt_gicp_align(smhip_handle h, const double guess[16], double result[16], double* score, smhip_ndt_gicp_stats* stats) {
+  if (!h || !guess || !result) return SMHIP_ERR_INVALID_ARGUMENT;
+  return ndt_gicp_align_jobs(h, 0, 1, guess, result, score, stats);
+}
+
+smhip_status smhip_ndt_gicp_align_batch(smhip_handle h, int first_job, int njobs, const double* guesses, double* results, double* scores,
+                                        smhip_ndt_gicp_stats* stats) {
+  if (!h || !guesses || !results) return SMHIP_ERR_INVALID_ARGUMENT;
+  return ndt_gicp_align_jobs(h, first_job, njobs, guesses, results, scores, stats);
 }
 
 // GICP alone on slot 0's clouds as set by smhip_set_source_f32 / smhip_set_target_f32 (parity hook; also what a
@@ -644,7 +872,9 @@ smhip_status smhip_gicp_align(smhip_handle h, const double guess[16], double res
   st.n_source = h->ns[0]; st.n_target = h->nt[0];
   float g32[16], fin[16];
   colmajor_to_rm_f32(guess, g32);
-  s = gicp_align_slot0(h, g32, fin, &st);
+  GicpCell cell(h, gicp_of(h).opts);
+  const char run = 1;
+  s = gicp_align_jobs(h, 0, 1, &run, g32, fin, &st);
   if (s) return s;
   rm_f32_to_colmajor(fin, result);
   double fit = 0;
@@ -663,10 +893,24 @@ smhip_status smhip_gicp_evaluate(smhip_handle h, const double guess[16], const d
   GicpHost& g = gicp_of(h);
   if (!g.allocated || h->ns[0] <= 0) { h->err = "GICP has not run"; return SMHIP_ERR_NOT_READY; }
   HIPCHK(h, hipSetDevice(h->device));
-  GicpFunctor fn{h, {}, h->ns[0]};
-  colmajor_to_rm_f32(guess, fn.base);
-  fn.fdf(x, *f, grad);
-  return fn.status;
+  // one functor evaluation of job 0, outside any run: the "task" is this call
+  GicpTask t;
+  t.h = h; t.job = 0; t.ns = h->ns[0];
+  colmajor_to_rm_f32(guess, t.guess);
+  float T[16];
+  apply_state_f32(t.guess, x, T);
+  for (int i = 0; i < 12; ++i) { t.P.T[i] = T[i]; t.P.B[i] = t.guess[i]; }
+  std::vector<GicpTask*> none, one{&t};
+  const smhip_status s = gicp_round(h, 0, 1, none, one);
+  if (s) return s;
+  const double* o = g.out_pinned;
+  const double m = o[13];
+  *f = o[0] / m;
+  for (int i = 0; i < 3; ++i) grad[i] = o[1 + i] * (2.0 / m);
+  double R[9];
+  for (int i = 0; i < 9; ++i) R[i] = o[4 + i] * (2.0 / m);
+  r_derivative(x, R, grad);
+  return SMHIP_OK;
 }
 
 // parity hooks -----------------------------------------------------------------------------------

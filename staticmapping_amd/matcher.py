@@ -340,9 +340,11 @@ class NdtGicpHip(IcpFastHip):
     plus the PCL parameters the reference fixes in InitWithOptions (:45-53)."""
 
     def __init__(self, device: int = 0, max_source_points: int = 131072, max_target_points: int = 524288,
-                 stream: int | None = None, **options):
-        super().__init__(device=device, pair_slots=2, max_source_points=max_source_points,
+                 stream: int | None = None, jobs: int = 1, **options):
+        # a job = one (source, target) pair with its own kept structures; job j works in pair slot j and slot jobs + j
+        super().__init__(device=device, pair_slots=2 * max(1, jobs), max_source_points=max_source_points,
                          max_target_points=max(max_target_points, max_source_points), stream=stream)
+        self.jobs = max(1, jobs)
         self._gopts = _capi.NdtGicpOptions()
         self._lib.smhip_ndt_gicp_default_options(ctypes.byref(self._gopts))
         if options:
@@ -357,12 +359,13 @@ class NdtGicpHip(IcpFastHip):
         self._check(self._lib.smhip_ndt_gicp_set_options(self._h, ctypes.byref(self._gopts)))
 
     def set_input_source(self, points, slot: int = 0):
+        """`slot` = the job (0 for the single Align)."""
         a = np.ascontiguousarray(np.asarray(points, dtype=np.float32))
-        self._check(self._lib.smhip_ndt_gicp_set_source_f32(self._h, a.ctypes.data_as(_capi.c_float_p), a.shape[1], a.shape[0]))
+        self._check(self._lib.smhip_ndt_gicp_set_source_f32_job(self._h, slot, a.ctypes.data_as(_capi.c_float_p), a.shape[1], a.shape[0]))
 
     def set_input_target(self, points, normals=None, slot: int = 0):
         a = np.ascontiguousarray(np.asarray(points, dtype=np.float32))
-        self._check(self._lib.smhip_ndt_gicp_set_target_f32(self._h, a.ctypes.data_as(_capi.c_float_p), a.shape[1], a.shape[0]))
+        self._check(self._lib.smhip_ndt_gicp_set_target_f32_job(self._h, slot, a.ctypes.data_as(_capi.c_float_p), a.shape[1], a.shape[0]))
 
     def _run(self, fn, guess):
         G = np.eye(4) if guess is None else np.asarray(guess, dtype=np.float64)
@@ -378,6 +381,18 @@ class NdtGicpHip(IcpFastHip):
     def align(self, guess=None):
         self.final_score_, result = self._run(self._lib.smhip_ndt_gicp_align, guess)
         return bool(self.last_gicp_stats["ok"]), result
+
+    def align_batch(self, njobs: int, guesses=None, first_job: int = 0):
+        """njobs NdtWithGicp::Align calls (jobs first_job .. first_job + njobs - 1) advanced in lock-step
+        (smhip_ndt_gicp_align_batch): poses [njobs, 4, 4], scores [njobs], stats (list of dicts) -- the single calls' bits."""
+        g = self._pack_guesses(njobs, guesses)
+        res = np.zeros((njobs, 16))
+        scores = np.zeros(njobs)
+        stats = (_capi.NdtGicpStats * njobs)()
+        self._check(self._lib.smhip_ndt_gicp_align_batch(self._h, first_job, njobs, g.ctypes.data_as(_capi.c_double_p), res.ctypes.data_as(_capi.c_double_p),
+                                                         scores.ctypes.data_as(_capi.c_double_p), stats))
+        self.last_gicp_stats = [{k: getattr(s, k) for k, _ in s._fields_ if k != "reserved"} for s in stats]
+        return res.reshape(njobs, 4, 4).transpose(0, 2, 1).copy(), scores, self.last_gicp_stats
 
     # -- parity-test hooks ---------------------------------------------------------------------
     def gicp_only(self, source, target, guess=None):

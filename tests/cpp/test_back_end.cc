@@ -118,6 +118,24 @@ int main(int argc, char** argv) {
       for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) gicp_pool_equal = gicp_pool_equal && pooled[k].transform_to_next(r, c) == one.transform_to_next(r, c);
     }
   }
+  // ... and the same four pairs as ONE lock-step batch through the jobs of one NdtWithGicp matcher (SubmapPairMatchBatch ->
+  // NdtGicpHip::AlignBatch -> smhip_ndt_gicp_align_batch): every pair's NDT and BFGS evaluations in its own order, the launches
+  // shared -- what four single SubmapPairMatch calls give, bit for bit
+  bool gicp_batch_equal = true;
+  {
+    reg::MatcherOptions gopt; gopt.type = reg::kNdtWithGicp; gopt.accepted_min_score = -1.0f;
+    std::vector<smhip::back_end::SubmapPairJob> gjobs(4);
+    for (int k = 0; k < 4; ++k) { gjobs[k] = jobs[0]; gjobs[k].source_first_frame_pose(0, 3) += 0.03 * k; }
+    auto gicp_matcher = reg::CreateMatcher(gopt, false);
+    auto lock = smhip::back_end::SubmapPairMatchBatch(gopt, gicp_matcher, gjobs);
+    lock = smhip::back_end::SubmapPairMatchBatch(gopt, gicp_matcher, gjobs);              // the handle outlives a batch (targets kept)
+    for (int k = 0; k < 4; ++k) {
+      const auto one = smhip::back_end::SubmapPairMatch(gopt, gjobs[k].source_submap_cloud, gjobs[k].source_first_frame_pose,
+                                                         gjobs[k].target_submap_cloud, gjobs[k].target_first_frame_pose);
+      gicp_batch_equal = gicp_batch_equal && lock[k].match_score == one.match_score && lock[k].accepted == one.accepted;
+      for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) gicp_batch_equal = gicp_batch_equal && lock[k].transform_to_next(r, c) == one.transform_to_next(r, c);
+    }
+  }
   // a loop-closure matcher that outlives its candidates
   reg::IcpPointMatcherHip keep_matcher(settings.device, 1 << 12);            // deliberately too small: must re-size itself
   keep_matcher.InitWithOptions();
@@ -125,8 +143,8 @@ int main(int argc, char** argv) {
   const bool closed2 = smhip::back_end::CloseLoop(tpose, target, spose, source, settings, &edge2, &keep_matcher);
   const bool closed_far2 = smhip::back_end::CloseLoop(tpose, target, far, source, settings, &bad_edge2, &keep_matcher);
 
-  std::printf("{\"pool_equal\": %s, \"ndt_batch_equal\": %s, \"gicp_pool_equal\": %s, \"pool_accepted\": %d, \"closed\": %s, \"edge_score\": %.17g, \"closed_far\": %s, ", pool_equal ? "true" : "false",
-              ndt_batch_equal ? "true" : "false", gicp_pool_equal ? "true" : "false", pool_accepted,
+  std::printf("{\"pool_equal\": %s, \"ndt_batch_equal\": %s, \"gicp_pool_equal\": %s, \"gicp_batch_equal\": %s, \"pool_accepted\": %d, \"closed\": %s, \"edge_score\": %.17g, \"closed_far\": %s, ", pool_equal ? "true" : "false",
+              ndt_batch_equal ? "true" : "false", gicp_pool_equal ? "true" : "false", gicp_batch_equal ? "true" : "false", pool_accepted,
               closed ? "true" : "false", edge.score, closed_far ? "true" : "false");
   PrintMatrix("edge_guess", edge.init_guess);
   PrintMatrix("edge_transform", edge.transform);

@@ -117,6 +117,7 @@ def test_close_loop_and_submap_pair_match(tmp_path, matcher_type):
     assert res["pool_equal"] and res["pool_accepted"] == 6
     assert res["ndt_batch_equal"]              # the same six pairs as one lock-step batch (smhip_ndt_align_batch): the single calls' bits
     assert res["gicp_pool_equal"]              # and four registrators::NdtWithGicp pairs through two matchers
+    assert res["gicp_batch_equal"]             # the same four pairs as one lock-step batch (smhip_ndt_gicp_align_batch): the single calls' bits
     # the two pairs as one batch through a pooled matcher (SubmapPairMatchBatch) = the two single calls
     assert res["batch_accepted"] == [True, False]
     da, dt = sm.se3_error(M("batch0_transform"), M("sub_transform"))

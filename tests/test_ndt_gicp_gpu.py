@@ -221,3 +221,65 @@ def test_results_do_not_depend_on_the_order_inside_grid_cells():
     for R, cs, ct in runs[1:]:
         assert np.array_equal(R, runs[0][0])
         assert np.array_equal(cs, runs[0][1]) and np.array_equal(ct, runs[0][2])
+
+
+def _batch_pairs(n):
+    pairs = []
+    for k in range(n):
+        a, b, T = synth.scan_pair("cfg2", n_points=20000 + 1500 * k, scene_seed=k)
+        G = T.copy(); G[0, 3] += 0.04 * ((k % 3) - 1) - 0.2; G[1, 3] += 0.03
+        pairs.append((b[:, :3].copy(), a[:, :3].copy(), G))          # (source, target, guess)
+    return pairs
+
+
+def test_lock_step_batch_returns_the_single_calls_bits():
+    """smhip_ndt_gicp_align_batch: seven jobs of different sizes advanced in lock-step (one launch per round of functor
+    evaluations / correspondence steps over all live jobs) against the same seven pairs aligned one at a time on a handle
+    of their own.  Every job keeps its own sequence of evaluations and its own summation order, so poses, scores and
+    every counter must be identical -- rebuilt, and again with the targets kept."""
+    pairs = _batch_pairs(7)
+    single = []
+    m1 = sm.NdtGicpHip(max_source_points=65536, max_target_points=65536)
+    for a, b, G in pairs:
+        m1.set_input_source(a); m1.set_input_target(b)
+        ok, R = m1.align(G)
+        single.append((ok, R, m1.get_fitness_score(), dict(m1.last_gicp_stats)))
+    m1.close()
+    mb = sm.NdtGicpHip(max_source_points=65536, max_target_points=65536, jobs=8)
+    for k, (a, b, G) in enumerate(pairs):
+        mb.set_input_source(a, slot=k + 1); mb.set_input_target(b, slot=k + 1)        # jobs 1..7: a batch need not start at job 0
+    for attempt in ("rebuilt", "kept"):
+        R, sc, st = mb.align_batch(7, [p[2] for p in pairs], first_job=1)
+        for k in range(7):
+            ok1, R1, s1, st1 = single[k]
+            assert np.array_equal(R[k], R1), f"{attempt}: job {k} pose differs from the single call's by {np.abs(R[k] - R1).max():.3e}"
+            assert sc[k] == s1
+            for key in ("ok", "n_source", "n_target", "ndt_iterations", "gicp_iterations", "gicp_function_evaluations", "gicp_correspondences", "ndt_score", "gicp_score"):
+                assert st[k][key] == st1[key], (attempt, k, key, st[k][key], st1[key])
+    assert any(s["gicp_iterations"] != st[0]["gicp_iterations"] or s["gicp_function_evaluations"] != st[0]["gicp_function_evaluations"] for s in st), \
+        "the jobs all took the same path: the batch was never out of step"
+    mb.close()
+
+
+def test_batch_with_a_rejected_job_and_job_range_errors():
+    """A job whose NDT stage ends above the fitness gate returns its guess with ok = 0 (ndt_gicp.cc:105-108) while the others run
+    on; jobs outside the handle's range are refused."""
+    pairs = _batch_pairs(3)
+    mb = sm.NdtGicpHip(max_source_points=65536, max_target_points=65536, jobs=3)
+    for k, (a, b, G) in enumerate(pairs):
+        mb.set_input_source(a, slot=k); mb.set_input_target(b, slot=k)
+    far = np.eye(4); far[:3, 3] = [60.0, -45.0, 3.0]
+    guesses = [pairs[0][2], far, pairs[2][2]]
+    R, sc, st = mb.align_batch(3, guesses)
+    assert st[0]["ok"] == 1 and st[2]["ok"] == 1 and st[1]["ok"] == 0
+    assert np.array_equal(R[1], far) and sc[1] == np.exp(-10.0)
+    m1 = sm.NdtGicpHip(max_source_points=65536, max_target_points=65536)
+    m1.set_input_source(pairs[2][0]); m1.set_input_target(pairs[2][1])
+    ok, R2 = m1.align(pairs[2][2])
+    assert np.array_equal(R[2], R2)
+    m1.close()
+    with pytest.raises(Exception):
+        mb.align_batch(2, guesses[:2], first_job=2)
+    with pytest.raises(Exception):
+        mb.set_input_source(pairs[0][0], slot=3)
+    mb.close()

@@ -8,6 +8,9 @@
 //   calib_scatter     per listed query (one in 50 elements, a hashed position): 12-byte row + int read, three dwords written to
 //                     three arrays at that position                                                         -- nn_ball_listed's shape
 //                     (known REQUESTED bytes; what the counters report per query is the granularity the memory system moves)
+//   calib_certify_gather  calib_certify + the two 16-byte gathers of nn_certify_acc (matched point and normal) from the element's
+//                     pair's own 21 700-row tables at a hashed row: the fused certificate pass's memory shape with no arithmetic --
+//                     its duration (tools/traffic_calib.sh, kernel-trace pass) is what the access pattern alone costs
 // Arrays are 256 x 120 000 elements (a 256-pair launch) and far larger than the 256 MiB Infinity Cache taken together.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -20,6 +23,18 @@ __global__ __launch_bounds__(256) void calib_certify(const float* __restrict__ s
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float3 v = *reinterpret_cast<const float3*>(src3 + 3 * i);
     d2[i] = v.x + v.y + v.z + (float)idx[i] + lb[i];
+  }
+}
+__global__ __launch_bounds__(256) void calib_certify_gather(const float* __restrict__ src3, const int* __restrict__ idx, const float* __restrict__ lb,
+                                                            const float4* __restrict__ tq, const float4* __restrict__ tn, float* __restrict__ d2, size_t n) {
+  const int kRows = 21700;                                 // the bench's CalculateNormals target
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float3 v = *reinterpret_cast<const float3*>(src3 + 3 * i);
+    const size_t pair = i / 120000;
+    unsigned z = (unsigned)i * 2654435761u; z ^= z >> 15;
+    const size_t row = pair * kRows + (z + (unsigned)idx[i]) % kRows;
+    const float4 q = tq[row], m = tn[row];
+    d2[i] = v.x * q.x + v.y * q.y + v.z * q.z + m.x + m.y + m.z + lb[i];
   }
 }
 __global__ __launch_bounds__(256) void calib_accumulate(const float* __restrict__ src3, const int* __restrict__ idx, const float* __restrict__ d2in,
@@ -55,7 +70,9 @@ int main() {
   const size_t n = (size_t)256 * 120000;
   float *src3, *lb, *d2, *out;
   int* idx;
-  float4 *a4, *b4;
+  float4 *a4, *b4, *tq, *tn;
+  CK(hipMalloc(&tq, (size_t)256 * 21700 * 16)); CK(hipMalloc(&tn, (size_t)256 * 21700 * 16));
+  CK(hipMemset(tq, 0, (size_t)256 * 21700 * 16)); CK(hipMemset(tn, 0, (size_t)256 * 21700 * 16));
   CK(hipMalloc(&src3, n * 12)); CK(hipMalloc(&idx, n * 4)); CK(hipMalloc(&lb, n * 4)); CK(hipMalloc(&d2, n * 4)); CK(hipMalloc(&out, 256));
   CK(hipMalloc(&a4, n * 16)); CK(hipMalloc(&b4, n * 16));
   CK(hipMemset(src3, 0, n * 12)); CK(hipMemset(idx, 0, n * 4)); CK(hipMemset(lb, 0, n * 4)); CK(hipMemset(d2, 0, n * 4));
@@ -70,10 +87,13 @@ int main() {
     hipLaunchKernelGGL(calib_accumulate, dim3(blocks), dim3(256), 0, 0, src3, idx, lb, out, n);
     hipLaunchKernelGGL(calib_x4, dim3(blocks), dim3(256), 0, 0, a4, b4, n);
     hipLaunchKernelGGL(calib_scatter, dim3(blocks), dim3(256), 0, 0, src3, idx, lb, d2, n, n / 50);
+    hipLaunchKernelGGL(calib_x4, dim3(blocks), dim3(256), 0, 0, a4, b4, n);
+    hipLaunchKernelGGL(calib_certify_gather, dim3(blocks), dim3(256), 0, 0, src3, idx, lb, tq, tn, d2, n);
   }
   CK(hipDeviceSynchronize());
   std::printf("{\"elements\": %zu, \"calib_certify\": {\"read_bytes\": %zu, \"written_bytes\": %zu}, \"calib_accumulate\": {\"read_bytes\": %zu, "
               "\"written_bytes\": 0}, \"calib_x4\": {\"read_bytes\": %zu, \"written_bytes\": %zu}, \"calib_scatter\": {\"queries\": %zu, \"read_bytes\": %zu, "
-              "\"written_bytes\": %zu}}\n", n, n * 20, n * 4, n * 20, n * 16, n * 16, n / 50, (n / 50) * 16, (n / 50) * 12);
+              "\"written_bytes\": %zu}, \"calib_certify_gather\": {\"read_bytes\": %zu, \"written_bytes\": %zu, \"gathered_bytes\": %zu}}\n", n, n * 20, n * 4, n * 20, n * 16, n * 16, n / 50, (n / 50) * 16, (n / 50) * 12,
+              n * 20, n * 4, n * 32);
   return 0;
 }

@@ -10,6 +10,8 @@ hipcc --offload-arch=gfx950 -O3 -o /tmp/traffic_calib $R/tools/traffic_calib.hip
 rm -rf /tmp/calib_f /tmp/calib_w
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/calib_f -- /tmp/traffic_calib > /tmp/calib_known.json 2> /tmp/calib_f.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/calib_w -- /tmp/traffic_calib > /dev/null 2> /tmp/calib_w.log
+rm -rf /tmp/calib_t
+rocprofv3 --kernel-trace --output-format csv -d /tmp/calib_t -- /tmp/traffic_calib > /dev/null 2> /tmp/calib_t.log
 python - "$out" <<'PY'
 import csv, glob, json, sys
 known = json.load(open("/tmp/calib_known.json"))
@@ -19,7 +21,7 @@ def avg(d, name, counter):
     return sum(v) / len(v) if v else 0.0
 res = {"elements": known["elements"], "unit": "counter values are KB (x 1024 bytes)", "kernels": {}}
 for k in ("calib_certify", "calib_accumulate", "calib_x4"):
-    f, w = avg("/tmp/calib_f", k, "FETCH_SIZE"), avg("/tmp/calib_w", k, "WRITE_SIZE")
+    f, w = avg("/tmp/calib_f", k + "(", "FETCH_SIZE"), avg("/tmp/calib_w", k + "(", "WRITE_SIZE")
     rb, wb = known[k]["read_bytes"], known[k]["written_bytes"]
     res["kernels"][k] = {"read_bytes": rb, "written_bytes": wb, "FETCH_SIZE": f, "WRITE_SIZE": w,
                          "fetch_factor": rb / (f * 1024) if f else None, "write_factor": wb / (w * 1024) if w and wb else None}
@@ -31,6 +33,22 @@ res["kernels"]["calib_scatter"] = {"queries": sc["queries"], "requested_read_byt
                                    "FETCH_SIZE": f, "WRITE_SIZE": w,
                                    "fetched_bytes_per_query_at_factor_2": 2.0 * f * 1024 / sc["queries"], "written_bytes_per_query": w * 1024 / sc["queries"],
                                    "note": "a 12-byte row + an int read and three dwords written at a hashed position per query: requested 16 B read / 12 B written"}
+# what the access shapes alone cost: durations of the counter-free pass (4 launches each, the first dropped)
+def dur_us(name):
+    v = sorted((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+               for f in glob.glob("/tmp/calib_t/**/*kernel_trace.csv", recursive=True) for r in csv.DictReader(open(f)) if name + "(" in r["Kernel_Name"])
+    v = [d for _, d in v][1:]
+    return sum(v) / len(v) if v else None
+for k in ("calib_certify", "calib_accumulate", "calib_x4", "calib_certify_gather"):
+    d = dur_us(k)
+    if k == "calib_certify_gather":
+        f, w = avg("/tmp/calib_f", k + "(", "FETCH_SIZE"), avg("/tmp/calib_w", k + "(", "WRITE_SIZE")
+        res["kernels"][k] = {"read_bytes": known[k]["read_bytes"], "written_bytes": known[k]["written_bytes"], "gathered_bytes_l2": known[k]["gathered_bytes"],
+                             "FETCH_SIZE": f, "WRITE_SIZE": w}
+    if d:
+        b = res["kernels"][k]["read_bytes"] + res["kernels"][k]["written_bytes"]
+        res["kernels"][k]["duration_us"] = round(d, 1)
+        res["kernels"][k]["streamed_TB_per_s"] = round(b / d / 1e6, 3)
 res["fetch_factor_stream_12_4_4"] = res["kernels"]["calib_certify"]["fetch_factor"]
 res["write_factor_dword"] = res["kernels"]["calib_certify"]["write_factor"]
 res["fetch_factor_x4"] = res["kernels"]["calib_x4"]["fetch_factor"]

@@ -8,9 +8,11 @@
 //   calib_scatter     per listed query (one in 50 elements, a hashed position): 12-byte row + int read, three dwords written to
 //                     three arrays at that position                                                         -- nn_ball_listed's shape
 //                     (known REQUESTED bytes; what the counters report per query is the granularity the memory system moves)
-//   calib_certify_gather  calib_certify + the two 16-byte gathers of nn_certify_acc (matched point and normal) from the element's
-//                     pair's own 21 700-row tables at a hashed row: the fused certificate pass's memory shape with no arithmetic --
-//                     its duration (tools/traffic_calib.sh, kernel-trace pass) is what the access pattern alone costs
+//   calib_certify_v4  calib_certify with four consecutive elements per lane (the same bytes in 16-byte accesses)
+//   calib_certify_gather  calib_certify + two 16-byte gathers (matched point and normal) from the element's pair's own 21 700-row
+//                     tables at a UNIFORMLY RANDOM row, workgroups striding over all pairs: what the gathers of nn_certify_acc would
+//                     cost without the Morton order of the sources and the pair -> XCD mapping (no L2 locality at all)
+// The durations of the counter-free pass (tools/traffic_calib.sh) are what each access shape alone costs on this GPU.
 // Arrays are 256 x 120 000 elements (a 256-pair launch) and far larger than the 256 MiB Infinity Cache taken together.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -35,6 +37,20 @@ __global__ __launch_bounds__(256) void calib_certify_gather(const float* __restr
     const size_t row = pair * kRows + (z + (unsigned)idx[i]) % kRows;
     const float4 q = tq[row], m = tn[row];
     d2[i] = v.x * q.x + v.y * q.y + v.z * q.z + m.x + m.y + m.z + lb[i];
+  }
+}
+// calib_certify with four consecutive elements per lane: the same bytes in 16-byte accesses (3 + 1 + 1 loads, one store)
+__global__ __launch_bounds__(256) void calib_certify_v4(const float* __restrict__ src3, const int* __restrict__ idx, const float* __restrict__ lb,
+                                                        float* __restrict__ d2, size_t n) {
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(src3)[3 * i], b = reinterpret_cast<const float4*>(src3)[3 * i + 1], c = reinterpret_cast<const float4*>(src3)[3 * i + 2];
+    const int4 j = reinterpret_cast<const int4*>(idx)[i];
+    const float4 l = reinterpret_cast<const float4*>(lb)[i];
+    float4 o;
+    o.x = a.x + a.y + a.z + (float)j.x + l.x; o.y = a.w + b.x + b.y + (float)j.y + l.y;
+    o.z = b.z + b.w + c.x + (float)j.z + l.z; o.w = c.y + c.z + c.w + (float)j.w + l.w;
+    reinterpret_cast<float4*>(d2)[i] = o;
   }
 }
 __global__ __launch_bounds__(256) void calib_accumulate(const float* __restrict__ src3, const int* __restrict__ idx, const float* __restrict__ d2in,
@@ -88,12 +104,14 @@ int main() {
     hipLaunchKernelGGL(calib_x4, dim3(blocks), dim3(256), 0, 0, a4, b4, n);
     hipLaunchKernelGGL(calib_scatter, dim3(blocks), dim3(256), 0, 0, src3, idx, lb, d2, n, n / 50);
     hipLaunchKernelGGL(calib_x4, dim3(blocks), dim3(256), 0, 0, a4, b4, n);
+    hipLaunchKernelGGL(calib_certify_v4, dim3(blocks), dim3(256), 0, 0, src3, idx, lb, d2, n);
+    hipLaunchKernelGGL(calib_x4, dim3(blocks), dim3(256), 0, 0, a4, b4, n);
     hipLaunchKernelGGL(calib_certify_gather, dim3(blocks), dim3(256), 0, 0, src3, idx, lb, tq, tn, d2, n);
   }
   CK(hipDeviceSynchronize());
   std::printf("{\"elements\": %zu, \"calib_certify\": {\"read_bytes\": %zu, \"written_bytes\": %zu}, \"calib_accumulate\": {\"read_bytes\": %zu, "
               "\"written_bytes\": 0}, \"calib_x4\": {\"read_bytes\": %zu, \"written_bytes\": %zu}, \"calib_scatter\": {\"queries\": %zu, \"read_bytes\": %zu, "
-              "\"written_bytes\": %zu}, \"calib_certify_gather\": {\"read_bytes\": %zu, \"written_bytes\": %zu, \"gathered_bytes\": %zu}}\n", n, n * 20, n * 4, n * 20, n * 16, n * 16, n / 50, (n / 50) * 16, (n / 50) * 12,
-              n * 20, n * 4, n * 32);
+              "\"written_bytes\": %zu}, \"calib_certify_gather\": {\"read_bytes\": %zu, \"written_bytes\": %zu, \"gathered_bytes\": %zu}, \"calib_certify_v4\": {\"read_bytes\": %zu, \"written_bytes\": %zu}}\n", n, n * 20, n * 4, n * 20, n * 16, n * 16, n / 50, (n / 50) * 16, (n / 50) * 12,
+              n * 20, n * 4, n * 32, n * 20, n * 4);
   return 0;
 }

@@ -33,14 +33,16 @@ res["kernels"]["calib_scatter"] = {"queries": sc["queries"], "requested_read_byt
                                    "FETCH_SIZE": f, "WRITE_SIZE": w,
                                    "fetched_bytes_per_query_at_factor_2": 2.0 * f * 1024 / sc["queries"], "written_bytes_per_query": w * 1024 / sc["queries"],
                                    "note": "a 12-byte row + an int read and three dwords written at a hashed position per query: requested 16 B read / 12 B written"}
-# what the access shapes alone cost: durations of the counter-free pass (4 launches each, the first dropped)
+# what the access shapes alone cost: the median duration in the counter-free pass
 def dur_us(name):
     v = sorted((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
                for f in glob.glob("/tmp/calib_t/**/*kernel_trace.csv", recursive=True) for r in csv.DictReader(open(f)) if name + "(" in r["Kernel_Name"])
-    v = [d for _, d in v][1:]
-    return sum(v) / len(v) if v else None
-for k in ("calib_certify", "calib_accumulate", "calib_x4", "calib_certify_gather"):
+    v = sorted(d for _, d in v)
+    return v[len(v) // 2] if v else None                     # the median: calib_x4 also runs in between the others, behind different kernels
+for k in ("calib_certify", "calib_accumulate", "calib_x4", "calib_certify_v4", "calib_certify_gather"):
     d = dur_us(k)
+    if k == "calib_certify_v4":
+        res["kernels"][k] = {"read_bytes": known[k]["read_bytes"], "written_bytes": known[k]["written_bytes"]}
     if k == "calib_certify_gather":
         f, w = avg("/tmp/calib_f", k + "(", "FETCH_SIZE"), avg("/tmp/calib_w", k + "(", "WRITE_SIZE")
         res["kernels"][k] = {"read_bytes": known[k]["read_bytes"], "written_bytes": known[k]["written_bytes"], "gathered_bytes_l2": known[k]["gathered_bytes"],

@@ -430,6 +430,7 @@ def main():
                          "alone": {"note": "same kernel on one stream, not sharing the GPU with the other half-batch",
                                    "pairs_per_launch": alone_pairs, "avg_launch_ms": round(alone_ms, 4),
                                    "achieved": round(alone_gbs, 2), "frac": round(alone_gbs / HBM_PEAK_GBS, 5)},
+                         "shape_rate": _shape_rate(),
                          "whole_alignment": {"algorithmic_bytes": alg_bytes,
                                              "achieved_GBs": round(alg_bytes * value / world / 1e9, 2),
                                              "frac": round(alg_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)}},
@@ -662,6 +663,18 @@ def _submap_case(n_scans, n_target, seed, device, n_points=N_POINTS):
     c, s = np.cos(np.deg2rad(1.0)), np.sin(np.deg2rad(1.0))
     G[:3, :3] = T[:3, :3] @ np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
     return np.ascontiguousarray(scans[n_scans][:, :3]), tgt, T, G
+
+
+def _shape_rate():
+    """What the dominant kernel's streaming accesses alone reach on this GPU: a recorded run of tools/traffic_calib.sh (a kernel that
+    reads 12 + 4 + 4 B and writes 4 B per element and computes nothing).  A reference point next to `peak`, not a replacement for it."""
+    try:
+        c = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic_calibration.json")))["kernels"]["calib_certify"]
+        return {"kernel": "calib_certify (tools/traffic_calib.hip)", "achieved": round(1e3 * c["streamed_TB_per_s"], 1), "unit": "GB/s",
+                "measured": "recorded run, profiles/r04_traffic_calibration.json",
+                "note": "HBM rate of a no-arithmetic kernel with nn_certify_acc's streaming accesses (12-byte row + int + float in, one float out)"}
+    except Exception:
+        return None
 
 
 def other_workloads(dev, with_cpu):

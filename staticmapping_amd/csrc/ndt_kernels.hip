@@ -298,12 +298,19 @@ __device__ __forceinline__ void ndt_voxel_stats_one(const NdtDev& d, int v, int 
 // need no registers of their own -- 43 doubles fewer per lane.
 // grid = (workgroups per table, evaluations): evaluation e is pose poses[e] against table devs[active[e]] -- the K Aligns of a
 // batch advance in lock-step on the host and every round's evaluations are ONE launch.
+// A round of at most kNdtArgPoses evaluations (every round of a single Align) carries its poses and tables in the launch's own
+// arguments: no copy to the device before the launch.  Larger rounds read them from device arrays.
+constexpr int kNdtArgPoses = 4;
+struct NdtPoseArgs {
+  int32_t n;
+  int32_t active[kNdtArgPoses];
+  int32_t pad[3];
+  NdtPose p[kNdtArgPoses];
+};
+
 template <typename R, bool ONE>
-__global__ __launch_bounds__(kNdtDerivThreads, ONE ? 2 : 1) void ndt_derivatives(const NdtDev* __restrict__ devs, const NdtPose* __restrict__ poses,
-                                                                                    const int32_t* __restrict__ active) {
+__device__ __forceinline__ void ndt_derivatives_body(const NdtDev& d, const NdtPose& P) {
   constexpr bool kDouble = sizeof(R) == 8;
-  const NdtDev d = devs[active[blockIdx.y]];
-  const NdtPose& P = poses[blockIdx.y];
   const NdtGridInfo* g = d.info;
   double acc[43];
 #pragma unroll
@@ -472,11 +479,23 @@ __global__ __launch_bounds__(kNdtDerivThreads, ONE ? 2 : 1) void ndt_derivatives
     d.partials[(size_t)blockIdx.x * kNdtDerivCols + threadIdx.x] = t;
   }
 }
+template <typename R, bool ONE>
+__global__ __launch_bounds__(kNdtDerivThreads, ONE ? 2 : 1) void ndt_derivatives(const NdtDev* __restrict__ devs, const NdtPose* __restrict__ poses,
+                                                                                    const int32_t* __restrict__ active) {
+  const NdtDev d = devs[active[blockIdx.y]];
+  ndt_derivatives_body<R, ONE>(d, poses[blockIdx.y]);
+}
+template <typename R, bool ONE>
+__global__ __launch_bounds__(kNdtDerivThreads, ONE ? 2 : 1) void ndt_derivatives_args(const NdtDev* __restrict__ devs, const NdtPoseArgs A) {
+  const NdtDev d = devs[A.active[blockIdx.y]];
+  ndt_derivatives_body<R, ONE>(d, A.p[blockIdx.y]);
+}
 
 // 16 thread groups take every 16th block, then one thread per column folds the group sums:
-// a fixed order, so repeated evaluations at the same pose are bitwise identical.
-__global__ __launch_bounds__(16 * 64) void ndt_reduce(const NdtDev* __restrict__ devs, const int32_t* __restrict__ active, int nblocks) {
-  const NdtDev d = devs[active[blockIdx.x]];
+// a fixed order, so repeated evaluations at the same pose are bitwise identical.  The sums also go straight into page-locked
+// host memory (row e of out_host = evaluation e of the round): the host reads them after the stream's synchronise, no copy.
+struct NdtActiveArgs { int32_t slot[kNdtArgPoses]; };
+__device__ __forceinline__ void ndt_reduce_body(const NdtDev& d, int nblocks, double* __restrict__ out_host) {
   __shared__ double s_g[16][kNdtDerivCols];
   const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
   if (c < kNdtDerivCols) {
@@ -489,14 +508,26 @@ __global__ __launch_bounds__(16 * 64) void ndt_reduce(const NdtDev* __restrict__
     double t = 0;
     for (int g = 0; g < 16; ++g) t += s_g[g][threadIdx.x];
     d.out[threadIdx.x] = t;
+    out_host[(size_t)blockIdx.x * kNdtDerivCols + threadIdx.x] = t;
   }
+}
+__global__ __launch_bounds__(16 * 64) void ndt_reduce(const NdtDev* __restrict__ devs, const int32_t* __restrict__ active, int nblocks, double* __restrict__ out_host) {
+  const NdtDev d = devs[active[blockIdx.x]];
+  ndt_reduce_body(d, nblocks, out_host);
+}
+__global__ __launch_bounds__(16 * 64) void ndt_reduce_args(const NdtDev* __restrict__ devs, const NdtActiveArgs A, int nblocks, double* __restrict__ out_host) {
+  const NdtDev d = devs[A.slot[blockIdx.x]];
+  ndt_reduce_body(d, nblocks, out_host);
 }
 
 // mean of the squared NN distances of slot 0 (pcl::Registration::getFitnessScore, ndt.cc:60)
 // grid = (64, pairs): pair slot pair_base + blockIdx.y of the matcher's d2 array ([slots][ns_cap]), ns[blockIdx.y] valid entries
-__global__ __launch_bounds__(256) void fitness_partial(const float* d2_all, size_t ns_cap, int pair_base, const int32_t* ns, double* partials_all) {
+// (the sizes ride in the launch's arguments and the partial sums go straight into page-locked host memory: no copy either way)
+constexpr int kFitnessArgPairs = 64;
+struct FitnessArgs { int32_t ns[kFitnessArgPairs]; };
+__global__ __launch_bounds__(256) void fitness_partial(const float* d2_all, size_t ns_cap, int pair_base, const FitnessArgs A, double* partials_all) {
   const float* d2 = d2_all + (size_t)(pair_base + blockIdx.y) * ns_cap;
-  const int n = ns[blockIdx.y];
+  const int n = A.ns[blockIdx.y];
   double* partials = partials_all + (size_t)blockIdx.y * 128;
   double s = 0, c = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {

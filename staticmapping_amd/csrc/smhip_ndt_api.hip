@@ -279,29 +279,37 @@ void ndt_fill_pose(const NdtHost& n, const double* p, const float* T, bool hess,
 // slot active_host[e]; results in out_pinned[e][0..43] (score, 6-gradient, 6x6 hessian, pair count)
 smhip_status ndt_eval_round(smhip_context* h, int count, int ns_max) {
   NdtHost& n = ndt_of(h);
-  HIPCHK(h, hipMemcpyAsync(n.poses_dev, n.poses_host, sizeof(NdtPose) * count, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(n.active_dev, n.active_host, sizeof(int32_t) * count, hipMemcpyHostToDevice, h->stream));
   // (workgroups per evaluation from the LARGEST source: a smaller cloud's surplus workgroups add zero rows, and the fold of the
   // rows is grouped by workgroup index, so a pair's sums are the bits its single call gives -- up to 524 288 source points)
   const int blocks = std::min(kNdtMaxDerivBlocks, std::max(1, ceil_div(ns_max, kNdtDerivThreads)));
   const bool one = (long long)blocks * kNdtDerivThreads >= ns_max;      // a thread per source point
   const dim3 g(blocks, count);
-  if (n.double_math) {
-    if (one) hipLaunchKernelGGL((ndt_derivatives<double, true>), g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, n.poses_dev, n.active_dev);
-    else hipLaunchKernelGGL((ndt_derivatives<double, false>), g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, n.poses_dev, n.active_dev);
+  if (count <= kNdtArgPoses) {
+    // a small round (every round of a single Align): poses and tables ride in the launches' arguments, the sums come back through
+    // page-locked memory -- no copy either way
+    NdtPoseArgs A{};
+    NdtActiveArgs S{};
+    A.n = count;
+    for (int e = 0; e < count; ++e) { A.active[e] = n.active_host[e]; S.slot[e] = n.active_host[e]; A.p[e] = n.poses_host[e]; }
+    if (n.double_math) {
+      if (one) hipLaunchKernelGGL((ndt_derivatives_args<double, true>), g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, A);
+      else hipLaunchKernelGGL((ndt_derivatives_args<double, false>), g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, A);
+    } else {
+      if (one) hipLaunchKernelGGL((ndt_derivatives_args<float, true>), g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, A);
+      else hipLaunchKernelGGL((ndt_derivatives_args<float, false>), g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, A);
+    }
+    hipLaunchKernelGGL(ndt_reduce_args, dim3(count), dim3(16 * 64), 0, h->stream, n.devs_dev, S, blocks, n.out_pinned);
   } else {
-    if (one) hipLaunchKernelGGL((ndt_derivatives<float, true>), g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, n.poses_dev, n.active_dev);
-    else hipLaunchKernelGGL((ndt_derivatives<float, false>), g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, n.poses_dev, n.active_dev);
-  }
-  hipLaunchKernelGGL(ndt_reduce, dim3(count), dim3(16 * 64), 0, h->stream, n.devs_dev, n.active_dev, blocks);
-  // the evaluations' tables need not be consecutive slots: gather their 44 doubles with one strided copy when they are, else one each
-  bool consecutive = true;
-  for (int e = 1; e < count; ++e) consecutive = consecutive && n.active_host[e] == n.active_host[0] + e;
-  if (consecutive) {
-    HIPCHK(h, hipMemcpyAsync(n.out_pinned, n.out_all + (size_t)n.active_host[0] * kNdtDerivCols, sizeof(double) * kNdtDerivCols * count, hipMemcpyDeviceToHost, h->stream));
-  } else {
-    for (int e = 0; e < count; ++e)
-      HIPCHK(h, hipMemcpyAsync(n.out_pinned + (size_t)e * kNdtDerivCols, n.out_all + (size_t)n.active_host[e] * kNdtDerivCols, sizeof(double) * kNdtDerivCols, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(n.poses_dev, n.poses_host, sizeof(NdtPose) * count, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(n.active_dev, n.active_host, sizeof(int32_t) * count, hipMemcpyHostToDevice, h->stream));
+    if (n.double_math) {
+      if (one) hipLaunchKernelGGL((ndt_derivatives<double, true>), g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, n.poses_dev, n.active_dev);
+      else hipLaunchKernelGGL((ndt_derivatives<double, false>), g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, n.poses_dev, n.active_dev);
+    } else {
+      if (one) hipLaunchKernelGGL((ndt_derivatives<float, true>), g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, n.poses_dev, n.active_dev);
+      else hipLaunchKernelGGL((ndt_derivatives<float, false>), g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, n.poses_dev, n.active_dev);
+    }
+    hipLaunchKernelGGL(ndt_reduce, dim3(count), dim3(16 * 64), 0, h->stream, n.devs_dev, n.active_dev, blocks, n.out_pinned);
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipGetLastError());
@@ -539,13 +547,14 @@ smhip_status fitness_scores(smhip_context* h, int first, int K, const double* T,
   }
   h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was; h->dev.max_ring = ring_was;
   if (s) return s;
-  std::vector<int32_t> nsv(K);
-  for (int k = 0; k < K; ++k) nsv[k] = h->ns[first + k];
-  HIPCHK(h, hipMemcpyAsync(n.ns_dev, nsv.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(fitness_partial, dim3(64, K), dim3(256), 0, h->stream, h->dev.d2, (size_t)h->dev.ns_cap, first, n.ns_dev, n.fit_dev);
+  for (int k0 = 0; k0 < K; k0 += kFitnessArgPairs) {
+    FitnessArgs A{};
+    const int kn = std::min(kFitnessArgPairs, K - k0);
+    for (int k = 0; k < kn; ++k) A.ns[k] = h->ns[first + k0 + k];
+    hipLaunchKernelGGL(fitness_partial, dim3(64, kn), dim3(256), 0, h->stream, h->dev.d2, (size_t)h->dev.ns_cap, first + k0, A, n.fit_pinned + (size_t)128 * k0);
+  }
   HIPCHK(h, hipMemsetAsync(h->dev.hist + (size_t)first * kHistBins, 0, sizeof(uint32_t) * kHistBins * (size_t)K, h->stream));
-  HIPCHK(h, hipMemcpyAsync(n.fit_pinned, n.fit_dev, sizeof(double) * 128 * K, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));      // (nsv is read by the copy above: keep it alive until here)
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   for (int k = 0; k < K; ++k) {
     double ssum = 0, cnt = 0;
     for (int b = 0; b < 64; ++b) { ssum += n.fit_pinned[128 * k + 2 * b]; cnt += n.fit_pinned[128 * k + 2 * b + 1]; }

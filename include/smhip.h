@@ -427,10 +427,12 @@ typedef struct smhip_mrvm_settings {
 } smhip_mrvm_settings;
 typedef struct smhip_mrvm_context* smhip_mrvm_handle;
 void smhip_mrvm_default_settings(smhip_mrvm_settings* s);
-/* table_log2: the open-addressing voxel table holds 2^table_log2 voxels and does not grow (the reference's map does): size it
- * for the whole map -- a 0.1 m map of a KITTI-length drive needs 2^25 or more; past 70 % full every insert leaves a warning in
- * smhip_mrvm_last_error, and an insert that cannot place a voxel returns SMHIP_ERR_CAPACITY from then on (the voxel is lost,
- * the rest of the cloud is applied).  max_cloud_points: the largest cloud one InsertPointCloud may hand over */
+/* table_log2: the open-addressing voxel table STARTS with 2^table_log2 slots and doubles between inserts, like the reference's
+ * map grows: before an insert it is made large enough for the voxels it holds plus one per point of the coming cloud to fill at
+ * most half of it, up to 2^28 slots (smhip_mrvm_set_max_table_log2 lowers that; a slot costs 37 + 20 * max_point_num_in_cell
+ * bytes).  Only a table that can no longer grow (the limit, or the device's memory) reports "> 70 % full" as a warning and, when
+ * a voxel finds no slot, SMHIP_ERR_CAPACITY from then on (the voxel is lost, the rest of the cloud is applied).
+ * max_cloud_points: the largest cloud one InsertPointCloud may hand over */
 smhip_status smhip_mrvm_create(int device, int table_log2, int max_cloud_points, const smhip_mrvm_settings* settings, smhip_mrvm_handle* out);
 smhip_status smhip_mrvm_destroy(smhip_mrvm_handle h);
 const char* smhip_mrvm_last_error(smhip_mrvm_handle h);
@@ -439,10 +441,12 @@ void smhip_mrvm_set_offset_z(smhip_mrvm_handle h, float offset);                
  * stride 5), origin = the sensor position of the frame.  Non-finite points are skipped.  Refused BEFORE the map is touched
  * (status != OK, map unchanged): empty cloud, cloud larger than max_cloud_points, origin not finite or beyond +-2^20 voxels.
  * Applied with a warning (status OK, text in smhip_mrvm_last_error): points beyond +-2^20 voxels are skipped (their number:
- * smhip_mrvm_last_skipped; the flag does not carry over to the next insert), table > 70 % full. */
+ * smhip_mrvm_last_skipped; the flag does not carry over to the next insert), a table > 70 % full that cannot grow. */
 smhip_status smhip_mrvm_insert_f32(smhip_mrvm_handle h, const float* points, int stride_floats, int n, const float origin[3]);
 smhip_status smhip_mrvm_last_skipped(smhip_mrvm_handle h, int* n);
 smhip_status smhip_mrvm_voxel_count(smhip_mrvm_handle h, int* n);
+smhip_status smhip_mrvm_set_max_table_log2(smhip_mrvm_handle h, int max_table_log2);   /* 10..28; default 28 */
+int smhip_mrvm_table_log2(smhip_mrvm_handle h);                                        /* log2 of the table's current size */
 /* OutputToPointCloud(threshold, PointXYZI cloud) without averaging, .cc:133-170: rows x y z intensity of every stored point of
  * every voxel with probability byte >= uint8(threshold * 256), in no particular order (the reference iterates an unordered
  * map).  capacity = 0 only counts. */

@@ -36,7 +36,8 @@ struct PointXYZRGB {                                // pcl::PointXYZRGB's payloa
 class MultiResolutionVoxelMapHip {
  public:
   using InnerCloud = std::vector<data::InnerPointType>;        // data::InnerCloudType::points
-  // table_log2 / max_cloud_points: the device map's capacity (2^table_log2 voxels; the largest cloud of one insert)
+  // table_log2 / max_cloud_points: the voxel table's first size (2^table_log2 slots; it doubles between inserts as the map grows, like
+  // the reference's std::map) and the largest cloud of one insert
   explicit MultiResolutionVoxelMapHip(int device = 0, int table_log2 = 24, int max_cloud_points = 1 << 18)
       : device_(device), table_log2_(table_log2), max_cloud_points_(max_cloud_points) {}
   ~MultiResolutionVoxelMapHip() { if (handle_) smhip_mrvm_destroy(handle_); }

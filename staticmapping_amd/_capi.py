@@ -157,6 +157,8 @@ SIGNATURES = {
     "smhip_mrvm_set_offset_z": (None, [ctypes.c_void_p, ctypes.c_float]),
     "smhip_mrvm_insert_f32": (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int, c_float_p]),
     "smhip_mrvm_voxel_count": (ctypes.c_int, [ctypes.c_void_p, c_int32_p]),
+    "smhip_mrvm_set_max_table_log2": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "smhip_mrvm_table_log2": (ctypes.c_int, [ctypes.c_void_p]),
     "smhip_mrvm_output": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, c_float_p, ctypes.c_int, c_int32_p]),
     "smhip_mrvm_output_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_int, c_float_p, ctypes.c_int, c_int32_p]),
     "smhip_mrvm_last_skipped": (ctypes.c_int, [ctypes.c_void_p, c_int32_p]),

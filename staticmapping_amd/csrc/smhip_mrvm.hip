@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <string>
@@ -81,6 +82,25 @@ __device__ __forceinline__ int find_slot(const MrvmDev& d, unsigned long long ke
     s = (s + 1) & d.tmask;
   }
   return -1;
+}
+
+// Growth: every voxel of the old table into a larger one (between two inserts: the per-insert columns hits / misses / jmin are
+// at rest).  A voxel's content does not depend on its slot, and every reader of the map orders by key, not by slot.
+__global__ __launch_bounds__(256) void mrvm_rehash(MrvmDev o, MrvmDev nw) {
+  const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s > (size_t)o.tmask) return;
+  const unsigned long long key = o.keys[s];
+  if (key == 0ull) return;
+  uint32_t t = hash_key(key) & nw.tmask;
+  for (;;) {                                               // the new table holds at most half as many voxels as slots: ends
+    if (atomicCAS(&nw.keys[t], 0ull, key) == 0ull) break;
+    t = (t + 1) & nw.tmask;
+  }
+  nw.prob[t] = o.prob[s]; nw.max_int[t] = o.max_int[s]; nw.npts[t] = o.npts[s]; nw.created[t] = o.created[s];
+  const int np = min(o.npts[s], o.maxp);
+  const float* from = o.pts + (size_t)s * o.maxp * 5;
+  float* to = nw.pts + (size_t)t * nw.maxp * 5;
+  for (int k = 0; k < 5 * np; ++k) to[k] = from[k];
 }
 
 // per-insert reset: the touched list, the out-of-range flag and count of THIS cloud; "table full" stays (a lost voxel is lost)
@@ -279,7 +299,52 @@ struct smhip_mrvm_context {
   std::vector<void*> allocs;
   std::string err;
   int last_skipped = 0;                 // points of the last insert skipped for their coordinates
+  size_t voxels = 0;                    // voxels in the table after the last insert
+  int max_table_log2 = 28;              // growth stops here (smhip_mrvm_set_max_table_log2)
+  int growths = 0;
 };
+
+// the table's columns for T slots, initialised empty; false (nothing kept) when the device refuses the memory
+static bool mrvm_alloc_table(smhip_mrvm_context* h, size_t T, MrvmDev* d, std::vector<void*>* got) {
+  const size_t P = (size_t)h->set.max_point_num_in_cell;
+  bool ok = true;
+  auto A = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes) == hipSuccess) got->push_back(*p); else ok = false; };
+  A((void**)&d->keys, T * 8); A((void**)&d->prob, T); A((void**)&d->max_int, T * 4); A((void**)&d->npts, T * 4); A((void**)&d->created, T * 4);
+  A((void**)&d->pts, T * P * 5 * 4); A((void**)&d->jmin, T * 4); A((void**)&d->hits, T * 4); A((void**)&d->misses, T * 4); A((void**)&d->touched, T * 4);
+  ok = ok && hipMemsetAsync(d->keys, 0, T * 8, h->stream) == hipSuccess && hipMemsetAsync(d->prob, kUnknown, T, h->stream) == hipSuccess &&
+       hipMemsetAsync(d->max_int, 0, T * 4, h->stream) == hipSuccess && hipMemsetAsync(d->npts, 0, T * 4, h->stream) == hipSuccess &&
+       hipMemsetAsync(d->created, 0, T * 4, h->stream) == hipSuccess && hipMemsetAsync(d->jmin, 0xff, T * 4, h->stream) == hipSuccess &&
+       hipMemsetAsync(d->hits, 0, T * 4, h->stream) == hipSuccess && hipMemsetAsync(d->misses, 0, T * 4, h->stream) == hipSuccess;
+  if (!ok) { for (void* p : *got) (void)hipFree(p); got->clear(); (void)hipGetLastError(); }
+  d->tmask = (uint32_t)(T - 1);
+  return ok;
+}
+
+// The reference's map grows without bound (std::map of voxels); this table doubles until the voxels it holds plus the points of
+// the coming cloud (an insert creates at most one voxel per point) fill at most half of it, up to 2^max_table_log2 slots.
+// Called between inserts.  A refused allocation leaves the old table in place (the insert then reports what it always did).
+static void mrvm_grow_for(smhip_mrvm_context* h, int n) {
+  const size_t need = h->voxels + (size_t)n;
+  if (need * 10 <= h->T * 6) return;
+  size_t T = h->T;
+  const size_t cap = (size_t)1 << h->max_table_log2;
+  while (T < cap && need * 2 > T) T <<= 1;
+  if (T <= h->T) return;
+  MrvmDev nw = h->d;
+  std::vector<void*> got;
+  if (!mrvm_alloc_table(h, T, &nw, &got)) return;
+  hipLaunchKernelGGL(mrvm_rehash, dim3((unsigned)((h->T + 255) / 256)), dim3(256), 0, h->stream, h->d, nw);
+  if (hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) { for (void* p : got) (void)hipFree(p); return; }
+  void* old[10] = {h->d.keys, h->d.prob, h->d.max_int, h->d.npts, h->d.created, h->d.pts, h->d.jmin, h->d.hits, h->d.misses, h->d.touched};
+  for (void* p : old) {
+    (void)hipFree(p);
+    h->allocs.erase(std::remove(h->allocs.begin(), h->allocs.end(), p), h->allocs.end());
+  }
+  for (void* p : got) h->allocs.push_back(p);
+  h->d = nw;
+  h->T = T;
+  h->growths++;
+}
 
 #define MCHK(h, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_); return SMHIP_ERR_HIP; } } while (0)
 
@@ -308,9 +373,8 @@ smhip_status smhip_mrvm_create(int device, int table_log2, int max_cloud_points,
   bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
   auto A = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes) == hipSuccess) h->allocs.push_back(*p); else ok = false; };
   MrvmDev& d = h->d;
-  const size_t T = h->T, N = (size_t)max_cloud_points, P = (size_t)settings->max_point_num_in_cell;
-  A((void**)&d.keys, T * 8); A((void**)&d.prob, T); A((void**)&d.max_int, T * 4); A((void**)&d.npts, T * 4); A((void**)&d.created, T * 4);
-  A((void**)&d.pts, T * P * 5 * 4); A((void**)&d.jmin, T * 4); A((void**)&d.hits, T * 4); A((void**)&d.misses, T * 4); A((void**)&d.touched, T * 4);
+  const size_t T = h->T, N = (size_t)max_cloud_points;
+  { std::vector<void*> got; ok = ok && mrvm_alloc_table(h, T, &d, &got); for (void* p : got) h->allocs.push_back(p); }
   A((void**)&d.counters, 64); A((void**)&h->tables_dev, 2 * kTable); A((void**)&h->cloud_dev, N * 5 * 4); A((void**)&d.endslot, N * 4);
   A((void**)&d.sort_keys[0], N * 8); A((void**)&d.sort_keys[1], N * 8); A((void**)&d.run_start, N * 4); A((void**)&h->scan_out, N * 4);
   if (ok) {
@@ -322,11 +386,7 @@ smhip_status smhip_mrvm_create(int device, int table_log2, int max_cloud_points,
   }
   ok = ok && hipHostMalloc((void**)&h->stage, N * 5 * 4) == hipSuccess && hipHostMalloc((void**)&h->counters_host, 64) == hipSuccess;
   if (ok) {
-    ok = hipMemsetAsync(d.keys, 0, T * 8, h->stream) == hipSuccess && hipMemsetAsync(d.prob, kUnknown, T, h->stream) == hipSuccess &&
-         hipMemsetAsync(d.max_int, 0, T * 4, h->stream) == hipSuccess && hipMemsetAsync(d.npts, 0, T * 4, h->stream) == hipSuccess &&
-         hipMemsetAsync(d.created, 0, T * 4, h->stream) == hipSuccess && hipMemsetAsync(d.jmin, 0xff, T * 4, h->stream) == hipSuccess &&
-         hipMemsetAsync(d.hits, 0, T * 4, h->stream) == hipSuccess && hipMemsetAsync(d.misses, 0, T * 4, h->stream) == hipSuccess &&
-         hipMemsetAsync(d.counters, 0, 64, h->stream) == hipSuccess;
+    ok = hipMemsetAsync(d.counters, 0, 64, h->stream) == hipSuccess;
     // the byte -> byte maps of one hit / one miss, with the reference's expressions: odds_table_ (.cc:41-43), update_prob (:68-72)
     uint8_t tab[2 * kTable];
     const float hit_log_odd = prob_to_odd(h->set.hit_prob), miss_log_odd = prob_to_odd(h->set.miss_prob);
@@ -381,6 +441,7 @@ smhip_status smhip_mrvm_insert_f32(smhip_mrvm_handle h, const float* points, int
   h->last_skipped = 0;
   MCHK(h, hipSetDevice(h->device));
   MCHK(h, hipStreamSynchronize(h->stream));
+  mrvm_grow_for(h, n);                                      // room for the voxels this cloud can add, like the reference's std::map
   for (int i = 0; i < n; ++i) {
     const float* r = points + (size_t)stride_floats * i;
     float* o = h->stage + 5 * (size_t)i;
@@ -409,17 +470,32 @@ smhip_status smhip_mrvm_insert_f32(smhip_mrvm_handle h, const float* points, int
   if (touched > 0) hipLaunchKernelGGL(mrvm_apply, dim3((touched + 255) / 256), b, 0, h->stream, d);
   MCHK(h, hipGetLastError());
   // What is reported after the cloud has been applied.  Only a LOST voxel is an error (sticky: the map is incomplete from then
-  // on -- the reference's map grows without bound, this table does not; size it with table_log2).  Points beyond the coordinate
+  // on -- the table grows between inserts like the reference's map, until max_table_log2 or the device's memory ends it).  Points beyond the coordinate
   // range were skipped, the rest of the cloud is in the map: status OK, the count in smhip_mrvm_last_skipped, the text in
   // smhip_mrvm_last_error.  The same for a table that is getting full.
   h->last_skipped = (int)h->counters_host[5];
+  h->voxels = h->counters_host[1];
   if (h->counters_host[2] & 2u) {
-    h->err = "voxel table full: at least one voxel of this or an earlier cloud was dropped (the rest was applied); create the map with a larger table_log2";
+    h->err = "voxel table full: at least one voxel of this or an earlier cloud was dropped (the rest was applied); the table could not grow "
+             "(smhip_mrvm_set_max_table_log2, or device memory)";
     return SMHIP_ERR_CAPACITY;
   }
   if (h->counters_host[2] & 1u) h->err = "warning: " + std::to_string(h->last_skipped) + " point(s) beyond +-2^20 voxels skipped, the rest of the cloud applied";
-  else if ((size_t)h->counters_host[1] * 10 > h->T * 7) h->err = "warning: voxel table more than 70 % full: create the map with a larger table_log2";
+  else if ((size_t)h->counters_host[1] * 10 > h->T * 7) h->err = "warning: voxel table more than 70 % full and at its largest size (smhip_mrvm_set_max_table_log2)";
   return SMHIP_OK;
+}
+
+smhip_status smhip_mrvm_set_max_table_log2(smhip_mrvm_handle h, int max_table_log2) {
+  if (!h || max_table_log2 < 10 || max_table_log2 > 28) return SMHIP_ERR_INVALID_ARGUMENT;
+  h->max_table_log2 = max_table_log2;
+  return SMHIP_OK;
+}
+
+int smhip_mrvm_table_log2(smhip_mrvm_handle h) {
+  if (!h) return 0;
+  int l = 0;
+  while (((size_t)1 << l) < h->T) ++l;
+  return l;
 }
 
 smhip_status smhip_mrvm_voxel_count(smhip_mrvm_handle h, int* n) {

@@ -11,7 +11,8 @@ from .matcher import SmhipError
 
 
 class MultiResolutionVoxelMapHip:
-    def __init__(self, device: int = 0, table_log2: int = 22, max_cloud_points: int = 262144, **settings):
+    def __init__(self, device: int = 0, table_log2: int = 22, max_cloud_points: int = 262144, max_table_log2: int | None = None, **settings):
+        """table_log2: the table's FIRST size; it doubles between inserts as the map grows, up to 2^max_table_log2 (default 28)."""
         self._lib = _capi.load_library()
         self.settings = _capi.MrvmSettings()
         self._lib.smhip_mrvm_default_settings(ctypes.byref(self.settings))
@@ -26,6 +27,12 @@ class MultiResolutionVoxelMapHip:
             raise SmhipError(st, self._lib.smhip_status_string(st).decode())
         self.last_warning = ""
         self.last_skipped = 0
+        if max_table_log2 is not None:
+            self._check(self._lib.smhip_mrvm_set_max_table_log2(self._h, max_table_log2))
+
+    @property
+    def table_log2(self) -> int:
+        return int(self._lib.smhip_mrvm_table_log2(self._h))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

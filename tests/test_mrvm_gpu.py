@@ -77,7 +77,7 @@ def test_repeated_scan_saturates_and_clears():
 def test_edge_cases():
     import staticmapping_amd as sm
     from oracle import cref
-    dev = sm.MultiResolutionVoxelMapHip(table_log2=12, max_cloud_points=4096)
+    dev = sm.MultiResolutionVoxelMapHip(table_log2=12, max_cloud_points=4096, max_table_log2=12)   # (a table that may not grow)
     ora = cref.Mrvm()
     with pytest.raises(sm.SmhipError):
         dev.insert_point_cloud(np.zeros((0, 5), np.float32), [0, 0, 0])                # "cloud is empty."
@@ -115,6 +115,31 @@ def test_edge_cases():
     with pytest.raises(sm.SmhipError):                                                 # sticky: a voxel was lost
         dev.insert_point_cloud(pts, [0, 0, 0])
     dev.close(); ora.close()
+
+
+def test_table_grows_like_the_reference_map():
+    """The reference's map is a std::map and grows without bound (multi_resolution_voxel_map.h).  A device table that starts far
+    too small (1 024 slots) doubles between inserts; after every cloud the whole map still equals the reference loop's."""
+    import staticmapping_amd as sm
+    from oracle import cref
+    scans = _world_scans(5, 20_000)
+    dev = sm.MultiResolutionVoxelMapHip(table_log2=10, max_cloud_points=20_000)
+    ora = cref.Mrvm()
+    sizes = []
+    for pts, origin in scans:
+        dev.insert_point_cloud(pts, origin); ora.insert(pts, origin)
+        assert dev.last_warning == ""
+        _assert_same_map(dev, ora)
+        sizes.append(dev.table_log2)
+    assert sizes[0] > 10 and sizes[-1] >= sizes[0] and dev.voxel_count() * 2 <= (1 << sizes[-1]) + 20_000, sizes
+    a = dev.output_to_point_cloud(0.6); b = ora.output(0.6)
+    assert np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])
+    # a limit below what the map needs: the old behaviour (warning, then a lost voxel reported from then on)
+    small = sm.MultiResolutionVoxelMapHip(table_log2=10, max_cloud_points=20_000, max_table_log2=11)
+    with pytest.raises(sm.SmhipError):
+        small.insert_point_cloud(scans[0][0], scans[0][1])
+    assert small.table_log2 == 11
+    small.close(); dev.close(); ora.close()
 
 
 def test_cpp_mirror_drives_the_map_like_the_map_builder(tmp_path):

@@ -113,7 +113,10 @@ __device__ __forceinline__ float kd_coord(const float4 p, uint32_t d) { return d
 // the partition pass, which has the point in registers, writes the next level's keys as it scatters.
 // fetch(i) = point i of the cloud as the working orders hold it (.w = i as int bits): the last levels sort (segment, coordinate,
 // index) keys in registers and pick the points up again by index.  n < 2^24 - 1.
-template <int BUCKET, typename Fetch>
+// WIDE: the extents of the inherited box compared as exact double differences (cloud_types.cc works on doubles: two sides whose
+// float difference rounds to the same value are still told apart, as the sort-per-level builder of prep_normals.hip does); the
+// libnabo restatement keeps the float differences it has always used.
+template <int BUCKET, bool WIDE, typename Fetch>
 __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur, float4*& oth, uint32_t*& sid, uint32_t*& sid_o, KdSeg*& seg, KdSeg*& seg_o,
                                                 uint32_t*& kk, uint32_t*& kk_o,
                                                 uint2* nodes, uint32_t* cnt_global, int seg_cap, int node_cap,
@@ -136,8 +139,14 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
         nodes[g.node] = make_uint2(g.first, (g.count << 2) | 3u);
       } else {
         g.split = 1;
-        uint32_t cd = 0; float mv = 0.f;                     // argMax from (0, 0.)
-        for (uint32_t d = 0; d < 3; ++d) { const float e = g.mx[d] - g.mn[d]; if (e > mv) { mv = e; cd = d; } }
+        uint32_t cd = 0;                                     // argMax from (0, 0.)
+        if (WIDE) {
+          double mv = 0.0;
+          for (uint32_t d = 0; d < 3; ++d) { const double e = (double)g.mx[d] - (double)g.mn[d]; if (e > mv) { mv = e; cd = d; } }
+        } else {
+          float mv = 0.f;
+          for (uint32_t d = 0; d < 3; ++d) { const float e = g.mx[d] - g.mn[d]; if (e > mv) { mv = e; cd = d; } }
+        }
         g.dim = cd;
         g.left = g.count - g.count / 2;
         g.prefix = 0; g.k = g.left; g.nless = 0; g.neq = 0; g.vidx = 0;
@@ -379,11 +388,11 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
         if (!g.split) continue;
         const float cut = kd_unkey(g.prefix);
         for (int side = 0; side < 2; ++side) {
-          uint32_t cd = 0; float mv = 0.f;
+          uint32_t cd = 0; float mv = 0.f; double mvw = 0.0;   // (the child's own choice one level on, the same way)
           for (uint32_t d = 0; d < 3; ++d) {
             const float lo = (side == 1 && d == g.dim) ? cut : g.mn[d], hi = (side == 0 && d == g.dim) ? cut : g.mx[d];
-            const float e = hi - lo;
-            if (e > mv) { mv = e; cd = d; }
+            if (WIDE) { const double e = (double)hi - (double)lo; if (e > mvw) { mvw = e; cd = d; } }
+            else { const float e = hi - lo; if (e > mv) { mv = e; cd = d; } }
           }
           if (side == 0) g.ldim = cd; else g.rdim = cd;
         }

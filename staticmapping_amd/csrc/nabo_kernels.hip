@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kKdThreads) void kd_build(IcpDev b, KdDev kd) {
   // ---- libnabo's buildNodes level by level (kd_median_tree.h; bucketSize 8)
   const float4* raw_t = b.tgt_p + to;
   auto fetch = [&](uint32_t i) { const float3 c = centre_point(raw_t[i], mu); return make_float4(c.x, c.y, c.z, __int_as_float((int)i)); };
-  kd_median_build<kKdBucket>(n, fetch, cur, oth, sid, sid_o, seg, seg_o, kk, kk_o, nodes, kd.cnt + (size_t)pair * 2 * kd.seg_cap, kd.seg_cap, kd.node_cap,
+  kd_median_build<kKdBucket, false>(n, fetch, cur, oth, sid, sid_o, seg, seg_o, kk, kk_o, nodes, kd.cnt + (size_t)pair * 2 * kd.seg_cap, kd.seg_cap, kd.node_cap,
                              s_hist, s_w, s_misc, &st->status);
   // ---- final order into tq (+ normals), bucket entries by caller index (a deterministic stand-in for nth_element's
   // unspecified order inside a bucket; it only matters for exactly equidistant entries)

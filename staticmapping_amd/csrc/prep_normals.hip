@@ -139,13 +139,56 @@ __global__ void kd_keys(const float4* raw, int n, const int32_t* order, const in
   keys[pos] = ((unsigned long long)(uint32_t)st << 32) | lowbits;
 }
 
+// ascending sort of a few point indices in place (insertion sort; heap sort for a long run of equal coordinates)
+__device__ void sort_indices(int32_t* a, int n) {
+  if (n <= 24) {
+    for (int i = 1; i < n; ++i) {
+      const int32_t v = a[i];
+      int j = i;
+      while (j > 0 && a[j - 1] > v) { a[j] = a[j - 1]; --j; }
+      a[j] = v;
+    }
+    return;
+  }
+  auto sift = [&](int root, int end) {
+    for (;;) {
+      int c = 2 * root + 1;
+      if (c >= end) return;
+      if (c + 1 < end && a[c + 1] > a[c]) ++c;
+      if (a[root] >= a[c]) return;
+      const int32_t t = a[root]; a[root] = a[c]; a[c] = t;
+      root = c;
+    }
+  };
+  for (int i = n / 2 - 1; i >= 0; --i) sift(i, n);
+  for (int e = n - 1; e > 0; --e) { const int32_t t = a[0]; a[0] = a[e]; a[e] = t; sift(0, e); }
+}
+
 // children of every active node; leaves are appended to the leaf list
-__global__ void kd_split(const float4* raw, const int32_t* order, const KdNode* nodes, KdNode* next, int32_t* counts,
+__global__ void kd_split(const float4* raw, int32_t* order, const KdNode* nodes, KdNode* next, int32_t* counts,
                          int32_t* node_at_next, KdLeaf* leaves) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= counts[0]) return;
   const KdNode nd = nodes[k];
-  const float4 pc = raw[order[nd.start + nd.left]];        // the nth element, :128
+  // Points ON the median value: std::nth_element leaves open which of them go left; the rule of this code base (the forest of
+  // kd_median_tree.h has it too, so a scan's leaves do not depend on the size of the batch it is prepared in) is "the smallest
+  // indices".  The level's stable sort left equal coordinates in the previous level's order: when a run of them straddles the
+  // split position, that run is put in index order.  (Tie-free data never enters the branch.)
+  auto key_at = [&](int pos) {
+    const float4 p = raw[order[pos]];
+    return ordered_bits(nd.dim == 0 ? p.x : (nd.dim == 1 ? p.y : p.z));
+  };
+  const int m = nd.start + nd.left;
+  if (nd.left > 0 && nd.left < nd.count) {
+    const uint32_t km = key_at(m);
+    if (key_at(m - 1) == km) {
+      int a = m - 1, b = m + 1;
+      while (a > nd.start && key_at(a - 1) == km) --a;
+      while (b < nd.start + nd.count && key_at(b) == km) ++b;
+      sort_indices(order + a, b - a);
+    }
+  }
+  const float4 pc = raw[order[m]];                         // the nth element, :128
   const float cut = nd.dim == 0 ? pc.x : (nd.dim == 1 ? pc.y : pc.z);
   KdNode ch[2];
   ch[0].start = nd.start; ch[0].count = nd.left;
@@ -362,7 +405,7 @@ __global__ __launch_bounds__(kKdThreads) void kd_forest_build(const float4* raw,
   }
   __syncthreads();
   auto fetch = [&](uint32_t i) { const float4 p = p0[i]; return make_float4(p.x, p.y, p.z, __int_as_float((int)i)); };
-  kd_median_build<kLeafMax>(n, fetch, cur, oth, sid, sid_o, seg, seg_o, kk, kk_o, nodes, f.cnt + f.seg_off[sc], seg_cap, node_cap, s_hist, s_w, s_misc, status);
+  kd_median_build<kLeafMax, true>(n, fetch, cur, oth, sid, sid_o, seg, seg_o, kk, kk_o, nodes, f.cnt + f.seg_off[sc], seg_cap, node_cap, s_hist, s_w, s_misc, status);
   __syncthreads();
   // the leaves (position ranges of the forest) and the permutation: order[position] = index into raw
   const int nn = (int)s_misc[0];

@@ -128,3 +128,39 @@ def test_large_batch_forest_equals_single_calls_and_the_oracle(cfg2, capsys):
     with capsys.disabled():
         print(f"\n[forest] 32 scans ({sum(len(s) for s in scans)} points) prepared in {dt * 1e3:.2f} ms = {dt * 1e3 / 32:.3f} ms per scan")
     m.close()
+
+
+def test_tied_coordinates_give_the_same_leaves_in_every_batch_size(cfg2):
+    """Real scans carry tied coordinates (KITTI's are quantised), and std::nth_element leaves open which of the points ON a
+    median go left.  Both builders break such ties by point index -- the forest (batches of >= 32 scans) in its select, the
+    sort-per-level form by putting a tie run that straddles a split in index order -- so a scan's target points and normals do
+    not depend on the size of the batch it was prepared in: here scans quantised to 2 cm (thousands of ties per cut) prepared
+    in a batch of 32 against the same scans one at a time, bit for bit."""
+    import staticmapping_amd as sm
+    rng = np.random.default_rng(11)
+    base = cfg2["tgt"]
+    scans = []
+    for k in range(32):
+        n = 15_000 + 700 * k
+        sc = base[rng.choice(len(base), size=n, replace=False)].copy()
+        sc[:, :3] = np.round(sc[:, :3] / 0.02) * 0.02
+        scans.append(np.ascontiguousarray(sc.astype(np.float32)))
+    cap = max(len(s) for s in scans)
+    m = sm.IcpFastHip(pair_slots=64, max_source_points=cap, max_target_points=cap // 4 + 64)
+    for k, sc in enumerate(scans):
+        m.set_input_source(sc, slot=k)
+    Ms = m.prepare_targets_from_sources(list(range(32)), list(range(32, 64)))
+
+    def canon(p, nrm):
+        o = np.lexsort((nrm[:, 2], nrm[:, 1], nrm[:, 0], p[:, 2], p[:, 1], p[:, 0]))
+        return p[o], nrm[o]
+    ties = 0
+    for k in (0, 7, 19, 31):
+        pb, nb = canon(*m.get_target(int(Ms[k]), slot=32 + k))
+        M1 = m.prepare_target_from_source(k, k)                                # the sort-per-level form (one scan)
+        p1, n1 = canon(*m.get_target(M1, slot=k))
+        assert M1 == Ms[k]
+        assert np.array_equal(pb, p1) and np.array_equal(nb, n1), (k, int((pb != p1).any(axis=1).sum()), int((nb != n1).any(axis=1).sum()))
+        ties += len(scans[k]) - len(np.unique(scans[k][:, 0]))
+    assert ties > 10_000                                                       # the scans did carry ties
+    m.close()

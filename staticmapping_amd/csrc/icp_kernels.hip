@@ -2176,10 +2176,10 @@ __device__ __forceinline__ void listed_search_one(const IcpDev& b, const PairSta
     if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
   }
 }
-// lanes per query for a list of `count` entries: as many (a power of two, at most 16) as keep kListedBlocks workgroups busy
-__device__ __forceinline__ int listed_lanes_log2(int count) {
+// lanes per query for a list of `count` entries: as many (a power of two, at most 16) as keep `budget` lanes busy
+__device__ __forceinline__ int listed_lanes_log2(int count, int budget = kListedBlocks * kNnThreads) {
   int L = 1, logL = 0;
-  while (L < 16 && 2 * L * count <= kListedBlocks * kNnThreads) { L *= 2; ++logL; }
+  while (L < 16 && 2 * L * count <= budget) { L *= 2; ++logL; }
   return logL;
 }
 __device__ __forceinline__ void listed_append_hard(const IcpDev& b, PairState* st, size_t so, bool hard, int i, int lane) {
@@ -2262,7 +2262,7 @@ __global__ __launch_bounds__(256) void listed_plan(IcpDev b) {
     if (blockIdx.x == 0) st->listed_ticket = 0;
     dc[nseg0] = (int32_t)total;
     st->deferred_count = total;
-    const int qpb = kNnThreads >> listed_lanes_log2((int)total);
+    const int qpb = kNnThreads >> listed_lanes_log2((int)total, b.listed_lane_budget);
     b.litems[pair] = total ? (total + qpb - 1) / qpb : 0u;
   }
 }
@@ -2342,7 +2342,7 @@ __global__ __launch_bounds__(kNnThreads, 5) void nn_ball_listed_items(IcpDev b) 
       const int32_t* __restrict__ dc = b.dcount + (size_t)pair * b.seg_stride;
       nseg0 = ((st->ns + kNnThreads * kCertifyItems - 1) / (kNnThreads * kCertifyItems)) * (kNnThreads / 64);
       count = dc[nseg0];
-      logL = listed_lanes_log2(count);
+      logL = listed_lanes_log2(count, b.listed_lane_budget);
       for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
       top = 1;
       while (2 * top < nseg0) top *= 2;
@@ -2552,7 +2552,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   const int seg_len0 = chunk / 4;
   // (region 1: one segment per item of the listed search, as long as the item's queries -- listed_plan's cut of the list)
   const int nseg = nseg0 + (fusedm ? (int)b.litems[pair] : 0);
-  const int seg_len1 = kNnThreads >> listed_lanes_log2((int)st->deferred_count);
+  const int seg_len1 = kNnThreads >> listed_lanes_log2((int)st->deferred_count, b.listed_lane_budget);
   const uint32_t* gcount = b.gcount + (size_t)pair * b.seg_stride;
   const float4* ra = b.rec_a + (size_t)pair * 2 * b.bl_stride;
   const int32_t* rj = b.rec_j + (size_t)pair * 2 * b.bl_stride;

@@ -488,6 +488,10 @@ void sync_options(smhip_context* h) {
   h->dev.fused = 0;
   h->dev.band_pad = 0.1f; h->dev.band_gain = 1.5f;              // tuning only: results do not depend on the band, only how often it holds
   { const char* e = std::getenv("SMHIP_BAND_PAD"); if (e && std::atof(e) >= 0.0) h->dev.band_pad = (float)std::atof(e); }
+  // lanes per query of the balanced listed search: measured flat from 1 024 to 8 192 (3.13-3.25 ms per step), slower beyond
+  // (16 384: 3.5, 32 768: 4.2).  At most 32 768: a pair's list is cut into at most budget / 512 items (finalize's segment table)
+  h->dev.listed_lane_budget = 4096;
+  { const char* e = std::getenv("SMHIP_LISTED_LANES"); if (e && std::atoi(e) >= 256) h->dev.listed_lane_budget = std::min(std::atoi(e), 32768); }
   h->dev.listed_grain = 1;
   { const char* e = std::getenv("SMHIP_LISTED_GRAIN"); if (e && std::atoi(e) >= 0) h->dev.listed_grain = std::atoi(e); }
   { const char* e = std::getenv("SMHIP_BAND_GAIN"); if (e && std::atof(e) >= 0.0) h->dev.band_gain = (float)std::atof(e); }

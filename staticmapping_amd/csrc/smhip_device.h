@@ -125,6 +125,7 @@ struct IcpDev {
   int32_t fused;             // 1 = this iteration's launches belong to the fused path (nn_certify_acc + nn_ball_listed_items):
                              //     nn_validate decides spec_ok, accumulate returns at once when it holds, finalize reads either form
   float band_pad;            // half-width of the predicted band in bins, at least (tuning; default 0.1)
+  int32_t listed_lane_budget; // lanes a pair's listed search may spread its queries over (sets the lanes per query of nn_ball_listed_items)
   int32_t listed_grain;      // items a workgroup of nn_ball_listed_items claims at a time (0: equal runs fixed in advance)
   float band_gain;           // ... and this many times the quantile's last move (default 1.5)
   int32_t acc_items;         // points per thread of the accumulate launches of this batch part (finalize folds accordingly)

@@ -66,6 +66,7 @@ struct smhip_context {
   unsigned long long cache_hits = 0;
   PairInput* in_pinned = nullptr;
   PairState* state_pinned = nullptr;
+  float split_share = 0.2f;      // auto split: the first iteration whose median searched share falls below this runs certify + listed search
   float4* stage = nullptr;       // pinned staging for uploads, 2 * max(ns_cap, nt_cap)
   uint32_t* done_pinned = nullptr;
   // split_after = 0: where the batched iterations switch from the fused search to certify + listed search follows the
@@ -492,6 +493,8 @@ void sync_options(smhip_context* h) {
   // (16 384: 3.5, 32 768: 4.2).  At most 32 768: a pair's list is cut into at most budget / 512 items (finalize's segment table)
   h->dev.listed_lane_budget = 4096;
   { const char* e = std::getenv("SMHIP_LISTED_LANES"); if (e && std::atoi(e) >= 256) h->dev.listed_lane_budget = std::min(std::atoi(e), 32768); }
+  h->split_share = 0.2f;
+  { const char* e = std::getenv("SMHIP_SPLIT_SHARE"); if (e && std::atof(e) > 0.0) h->split_share = (float)std::atof(e); }
   h->dev.listed_grain = 1;
   { const char* e = std::getenv("SMHIP_LISTED_GRAIN"); if (e && std::atoi(e) >= 0) h->dev.listed_grain = std::atoi(e); }
   { const char* e = std::getenv("SMHIP_BAND_GAIN"); if (e && std::atof(e) >= 0.0) h->dev.band_gain = (float)std::atof(e); }
@@ -1096,7 +1099,7 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
     for (; k < std::min(h->hist_iters, kSearchHist); ++k) {
       for (int p = 0; p < h->hist_pairs; ++p) share[p] = (float)h->hist_pinned[(size_t)p * kSearchHist + k] / (float)std::max(1, h->ns[h->hist_first + p]);
       std::nth_element(share.begin(), share.begin() + share.size() / 2, share.end());
-      if (share[share.size() / 2] < 0.2f) break;
+      if (share[share.size() / 2] < h->split_share) break;
     }
     h->auto_split = std::max(1, std::min(k, 8));              // 8: from there on the two-launch form won on every workload measured
     h->hist_pairs = 0;

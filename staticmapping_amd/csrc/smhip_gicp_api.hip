@@ -339,14 +339,18 @@ struct GicpSearchMode {
   ~GicpSearchMode() { h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was; h->dev.max_ring = ring_was; h->dev.nn_cutoff2 = cutoff_was; }
 };
 
-// One grid cell for everything an Align searches (the NDT fitness pass, the 20-NN sets, the correspondences, the final fitness):
-// the searches are exact whatever the cell, and a common one means a target's grid is built once per Align instead of three
-// times.  The k-NN search wants cells of a few point spacings -- one shell then holds the 20 neighbours almost everywhere.
+// Which grid cell an Align searches with.  The searches are exact whatever the cell; what differs is their cost: the 20-NN sets
+// want cells of a few point spacings (0.6 m: one shell holds the 20 neighbours almost everywhere), the 1-NN searches (NDT
+// fitness, correspondences, final fitness) the handle's own small cell.  An Align that has to estimate a target's covariances
+// builds that target's grid ONCE, with the k-NN cell, and runs its 1-NN searches on it too (one build instead of three); an
+// Align whose targets all keep their covariances never needs the large cell on a target and keeps the small one (its grid is
+// kept as well).  The scratch slots (a source as its own target) always get the k-NN cell.
+inline float gicp_knn_cell(const smhip_ndt_gicp_options& o) {
+  return o.gicp_search_cell > 0 ? o.gicp_search_cell : 3.0f * (o.using_voxel_filter ? o.voxel_resolution : 0.2f);
+}
 struct GicpCell {
   smhip_context* h; float was;
-  GicpCell(smhip_context* h_, const smhip_ndt_gicp_options& o) : h(h_), was(h_->dev.grid_cell) {
-    h->dev.grid_cell = o.gicp_search_cell > 0 ? o.gicp_search_cell : 3.0f * (o.using_voxel_filter ? o.voxel_resolution : 0.2f);
-  }
+  GicpCell(smhip_context* h_, float cell) : h(h_), was(h_->dev.grid_cell) { h->dev.grid_cell = cell; }
   ~GicpCell() { h->dev.grid_cell = was; }
 };
 
@@ -595,12 +599,13 @@ smhip_status gicp_align_jobs(smhip_context* h, int first, int K, const char* run
     h->ns[sfirst + e] = ns; h->nt[sfirst + e] = ns;
     touch_target(h, sfirst + e);
   }
-  const float knn_cell = h->dev.grid_cell;                 // (GicpCell)
+  const float knn_cell = gicp_knn_cell(o);
   {
     GicpSearchMode mode(h);
     bool kept = false;
-    smhip_status s = gicp_build_grids(h, sfirst, K, &kept);
-    if (s == SMHIP_OK) s = gicp_build_grids(h, first, K, &kept);
+    smhip_status s;
+    { GicpCell scratch_cell(h, knn_cell); s = gicp_build_grids(h, sfirst, K, &kept); }
+    if (s == SMHIP_OK) s = gicp_build_grids(h, first, K, &kept);      // (with the Align's cell: the k-NN one unless every target's covariances are kept)
     if (s) return s;
     if (kept) h->cache_hits++;
   }
@@ -793,7 +798,19 @@ static smhip_status ndt_gicp_align_jobs(smhip_handle h, int first, int K, const 
     for (auto& m : ndt_of(h).meta) m.valid = false;
     h->target_cache = 1;
   }
-  GicpCell cell(h, g.opts);
+  // (see GicpCell) does any job have to estimate its target's covariances in this Align?
+  const float knn_cell = gicp_knn_cell(g.opts);
+  bool all_kept = true;
+  for (int e = 0; e < K; ++e) {
+    const GicpJobHost& jh = g.job[first + e];
+    const int filt = g.opts.using_voxel_filter ? 1 : 0;
+    const bool staged = jh.raw_tgt_gen != 0 && jh.staged_raw_gen == jh.raw_tgt_gen && jh.staged_slot_gen == h->tgt_gen[first + e] &&
+                        jh.staged_filter == filt && (!filt || jh.staged_res == g.opts.voxel_resolution);
+    const bool cov = jh.cov_gen != 0 && jh.cov_gen == h->tgt_gen[first + e] && jh.cov_k == g.opts.gicp_k_correspondences &&
+                     jh.cov_eps == g.opts.gicp_epsilon && jh.cov_cell == knn_cell;
+    all_kept = all_kept && staged && cov;
+  }
+  GicpCell cell(h, all_kept ? h->dev.grid_cell : knn_cell);
   for (int e = 0; e < K; ++e) {
     s = ndt_gicp_stage_clouds(h, first + e);
     if (s) return s;
@@ -872,7 +889,7 @@ smhip_status smhip_gicp_align(smhip_handle h, const double guess[16], double res
   st.n_source = h->ns[0]; st.n_target = h->nt[0];
   float g32[16], fin[16];
   colmajor_to_rm_f32(guess, g32);
-  GicpCell cell(h, gicp_of(h).opts);
+  GicpCell cell(h, gicp_knn_cell(gicp_of(h).opts));
   const char run = 1;
   s = gicp_align_jobs(h, 0, 1, &run, g32, fin, &st);
   if (s) return s;

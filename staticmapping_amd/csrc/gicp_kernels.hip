@@ -34,6 +34,10 @@ struct GicpDev {
   uint32_t* round_done;    // jobs of the running evaluation round whose sums are in host memory
   double* out_host;        // [jobs][kGicpCols] page-locked host memory: the folded sums; behind them ([jobs * kGicpCols]) the round's number
   uint32_t* count;         // [jobs] kept correspondences
+  uint32_t* cov_epoch;     // [jobs][nt_cap] by the target point's position in the job slot's tgt_p array: the job's epoch when its covariance
+                           //                was estimated (target covariances are estimated when first matched, not all up front)
+  int32_t* need_list;      // [jobs][ns_cap] sorted positions of matched target points whose covariance is missing (this correspondence step)
+  uint32_t* need_count;    // [jobs]
   int32_t jobs;            // rows
 };
 
@@ -74,16 +78,12 @@ struct GicpKnnBatch {
   double* cov[kGicpKnnJobs];             // where its covariances go
 };
 
+// the neighbourhood and covariance of target point j0 (its sorted position) of pair slot `pair`; the workgroup's set columns
+// s_d / s_j are the caller's
 template <int KMAX>
-__global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, GicpKnnBatch L, int k, double gicp_epsilon) {
-  __shared__ float s_d[KMAX][kGicpKnnThreads];
-  __shared__ int s_j[KMAX][kGicpKnnThreads];
-  const int pair = L.slot[blockIdx.y];
-  double* cov = L.cov[blockIdx.y];
+__device__ __forceinline__ void gicp_knn_cov_one(const IcpDev& b, int pair, int j0, int k, double gicp_epsilon, double* cov,
+                                                 float (*s_d)[kGicpKnnThreads], int (*s_j)[kGicpKnnThreads]) {
   const PairState* st = &b.state[pair];
-  const int nt = st->nt;
-  const int j0 = blockIdx.x * kGicpKnnThreads + threadIdx.x;
-  if (j0 >= nt) return;
   const int t = threadIdx.x;
   const float4* tq = b.tq + (size_t)pair * b.nt_cap;
   const uint2* words = b.words + (size_t)pair * kMaxGridWords;
@@ -221,6 +221,61 @@ __global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, GicpKn
   const double s = 1.0 - gicp_epsilon;          // U diag(1, 1, eps) U^T = I - (1 - eps) u3 u3^T  (:118-129)
   o[0] = 1.0 - s * u0 * u0; o[1] = -s * u0 * u1; o[2] = -s * u0 * u2;
   o[3] = 1.0 - s * u1 * u1; o[4] = -s * u1 * u2; o[5] = 1.0 - s * u2 * u2;
+}
+
+// every point of the clouds of L (a source through its scratch slot; a whole target: the parity hook)
+template <int KMAX>
+__global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov(IcpDev b, GicpKnnBatch L, int k, double gicp_epsilon) {
+  __shared__ float s_d[KMAX][kGicpKnnThreads];
+  __shared__ int s_j[KMAX][kGicpKnnThreads];
+  const int pair = L.slot[blockIdx.y];
+  const int j0 = blockIdx.x * kGicpKnnThreads + threadIdx.x;
+  if (j0 >= b.state[pair].nt) return;
+  gicp_knn_cov_one<KMAX>(b, pair, j0, k, gicp_epsilon, L.cov[blockIdx.y], s_d, s_j);
+}
+
+// Target covariances on demand.  A GICP run consumes the covariance of a target point only when a source point is matched to it
+// (:449-459) -- some 34 000 of the 574 000 points of the config #5 submap -- so they are estimated when first needed instead of
+// all up front (computeCovariances for the whole target, :391-402: 0.65-1.25 ms per Align): gicp_need lists the matched target
+// points of a correspondence step whose covariance does not carry the job's current epoch (and stamps them), gicp_knn_cov_listed
+// estimates those -- the same function of the same neighbours, so every value that is used is the value the full pass gives.
+struct GicpNeedJob { int32_t job, ns; float thr2; uint32_t epoch; };
+struct GicpNeedBatch {
+  int32_t n, k;
+  double gicp_epsilon;
+  GicpNeedJob j[kGicpLaunchJobs];
+};
+__global__ __launch_bounds__(256) void gicp_need(IcpDev b, GicpDev g, GicpNeedBatch L) {
+  const GicpNeedJob& J = L.j[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t so = (size_t)J.job * b.ns_cap, to = (size_t)J.job * b.nt_cap;
+  bool need = false;
+  int j = -1;
+  if (i < J.ns) {
+    j = b.idx[so + i];
+    if (j >= 0 && b.d2[so + i] < J.thr2) {
+      const int orig = __float_as_int(b.tq[to + j].w);
+      need = atomicExch(&g.cov_epoch[to + orig], J.epoch) != J.epoch;      // the first to ask lists the point
+    }
+  }
+  const unsigned long long m = __ballot(need);
+  if (m) {
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(g.need_count + J.job, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
+    if (need) g.need_list[so + base + __popcll(m & ((1ull << lane) - 1ull))] = j;
+  }
+}
+template <int KMAX>
+__global__ __launch_bounds__(kGicpKnnThreads) void gicp_knn_cov_listed(IcpDev b, GicpDev g, GicpNeedBatch L) {
+  __shared__ float s_d[KMAX][kGicpKnnThreads];
+  __shared__ int s_j[KMAX][kGicpKnnThreads];
+  const GicpNeedJob& J = L.j[blockIdx.y];
+  const uint32_t e = blockIdx.x * kGicpKnnThreads + threadIdx.x;
+  if (e >= g.need_count[J.job]) return;
+  const int j0 = g.need_list[(size_t)J.job * b.ns_cap + e];
+  gicp_knn_cov_one<KMAX>(b, J.job, j0, L.k, L.gicp_epsilon, g.cov_t + (size_t)J.job * b.nt_cap * 6, s_d, s_j);
 }
 
 // per source point: keep the correspondence if d2 < threshold^2 and store (R C1 R^T + C2)^-1 and the raw target point

@@ -28,8 +28,12 @@ struct GicpJobHost {
   unsigned long long staged_raw_gen = 0;    // the raw target the job slot's staged target was made from ...
   unsigned long long staged_slot_gen = 0;   // ... and the slot's tgt_gen right after staging it
   int staged_filter = -1; float staged_res = 0.f; int staged_nt = 0;
-  unsigned long long cov_gen = 0;           // the slot's tgt_gen its cov_t row was estimated from, with these parameters
-  int cov_k = 0; double cov_eps = 0; float cov_cell = 0.f;
+  // target covariances are estimated when a point is first matched (gicp_need / gicp_knn_cov_listed); an entry is valid when its
+  // stamp in cov_epoch equals `epoch`, which moves on whenever the target or the parameters change
+  unsigned long long cov_gen = 0;           // the slot's tgt_gen the current epoch belongs to, with these parameters
+  int cov_k = 0; double cov_eps = 0;
+  uint32_t epoch = 0;
+  bool cov_full = false;                    // every entry was estimated up front (a single Align does that: see gicp_align_jobs)
 };
 
 struct GicpHost {
@@ -70,6 +74,9 @@ smhip_status gicp_ensure(smhip_context* h) {
   A(dev_alloc(h, &g.dev.count, (size_t)J));
   A(dev_alloc(h, &g.dev.ticket, (size_t)J));
   A(dev_alloc(h, &g.dev.round_done, 4));
+  A(dev_alloc(h, &g.dev.cov_epoch, (size_t)J * NT));
+  A(dev_alloc(h, &g.dev.need_list, (size_t)J * NS));
+  A(dev_alloc(h, &g.dev.need_count, (size_t)J));
   A(dev_alloc(h, &g.raw_src, (size_t)J * NS));
   A(dev_alloc(h, &g.raw_tgt, (size_t)J * NT));
   A(dev_alloc(h, &g.ds_tmp, std::max(NS, NT)));
@@ -82,7 +89,8 @@ smhip_status gicp_ensure(smhip_context* h) {
   std::memset(g.out_pinned, 0, sizeof(double) * ((size_t)J * kGicpCols + 1));
   g.dev.out_host = g.out_pinned;                       // (page-locked host memory is device-addressable at the same pointer)
   g.dev.jobs = J;
-  if (hipMemsetAsync(g.dev.ticket, 0, sizeof(uint32_t) * (size_t)J, h->stream) != hipSuccess ||
+  if (hipMemsetAsync(g.dev.cov_epoch, 0, sizeof(uint32_t) * (size_t)J * NT, h->stream) != hipSuccess ||
+      hipMemsetAsync(g.dev.ticket, 0, sizeof(uint32_t) * (size_t)J, h->stream) != hipSuccess ||
       hipMemsetAsync(g.dev.round_done, 0, sizeof(uint32_t) * 4, h->stream) != hipSuccess) { h->err = "hipMemsetAsync failed (GICP)"; return SMHIP_ERR_HIP; }
   g.jobs = J;
   g.job.assign((size_t)J, GicpJobHost{});
@@ -171,6 +179,7 @@ struct GicpFunctor {
 
 // ---- pcl/registration/bfgs.h: BFGS<Functor> (GSL vector_bfgs2, Fletcher's line search) -------------
 enum { kBfgsSuccess = 0, kBfgsNoProgress = 1, kBfgsRunning = -1 };
+constexpr int kGicpLazyMinJobs = 4;          // batches from this size on estimate target covariances on demand
 
 int solve_quadratic(double a, double b, double c, double* x0, double* x1) {     // gsl_poly_solve_quadratic
   if (a == 0) { if (b == 0) return 0; *x0 = -c / b; return 1; }
@@ -339,12 +348,12 @@ struct GicpSearchMode {
   ~GicpSearchMode() { h->dev.sort_cells = sort_was; h->dev.use_ball = ball_was; h->dev.max_ring = ring_was; h->dev.nn_cutoff2 = cutoff_was; }
 };
 
-// Which grid cell an Align searches with.  The searches are exact whatever the cell; what differs is their cost: the 20-NN sets
-// want cells of a few point spacings (0.6 m: one shell holds the 20 neighbours almost everywhere), the 1-NN searches (NDT
-// fitness, correspondences, final fitness) the handle's own small cell.  An Align that has to estimate a target's covariances
-// builds that target's grid ONCE, with the k-NN cell, and runs its 1-NN searches on it too (one build instead of three); an
-// Align whose targets all keep their covariances never needs the large cell on a target and keeps the small one (its grid is
-// kept as well).  The scratch slots (a source as its own target) always get the k-NN cell.
+// Which grid cell an Align searches with.  The searches are exact whatever the cell; what differs is their cost.  A 20-NN
+// neighbourhood wants cells of a few point spacings (0.6 m: one shell holds the 20 neighbours almost everywhere; on the handle's
+// small cell it walks hundreds of grid rows), the 1-NN searches (NDT fitness, correspondences, final fitness) are a third faster
+// on the small cell.  An Align that may have to estimate target covariances builds the target's grid ONCE, with the k-NN cell,
+// and runs its 1-NN searches on it too; an Align whose targets all hold a complete, current set of covariances stays on the
+// small cell (that grid is kept as well).  The scratch slots (a source as its own target) always get the k-NN cell.
 inline float gicp_knn_cell(const smhip_ndt_gicp_options& o) {
   return o.gicp_search_cell > 0 ? o.gicp_search_cell : 3.0f * (o.using_voxel_filter ? o.voxel_resolution : 0.2f);
 }
@@ -426,6 +435,26 @@ smhip_status gicp_round(smhip_context* h, int first, int K, const std::vector<Gi
     HIPCHK(h, hipMemsetAsync(h->dev.hist + (size_t)first * kHistBins, 0, sizeof(uint32_t) * kHistBins * (size_t)K, h->stream));
     h->ev_used = 0;
     HIPCHK(h, hipMemsetAsync(G.dev.count + first, 0, sizeof(uint32_t) * (size_t)K, h->stream));
+    HIPCHK(h, hipMemsetAsync(G.dev.need_count + first, 0, sizeof(uint32_t) * (size_t)K, h->stream));
+    // the covariances of the matched target points that do not have one yet
+    std::vector<const GicpTask*> lazy;
+    for (const GicpTask* t : corr) if (!G.job[t->job].cov_full) lazy.push_back(t);
+    for (size_t c0 = 0; c0 < lazy.size(); c0 += kGicpLaunchJobs) {
+      GicpNeedBatch N{};
+      N.n = (int)std::min<size_t>(kGicpLaunchJobs, lazy.size() - c0);
+      N.k = o.gicp_k_correspondences; N.gicp_epsilon = o.gicp_epsilon;
+      int nmax = 0;
+      for (int e = 0; e < N.n; ++e) {
+        const GicpTask* t = lazy[c0 + e];
+        N.j[e].job = t->job; N.j[e].ns = t->ns; N.j[e].thr2 = thr2; N.j[e].epoch = G.job[t->job].epoch;
+        nmax = std::max(nmax, t->ns);
+      }
+      IcpDev dk = h->dev;
+      dk.have_rowbits = 1;                     // the job slots' grids are ring-search structures
+      hipLaunchKernelGGL(gicp_need, dim3(ceil_div(nmax, 256), N.n), dim3(256), 0, h->stream, h->dev, G.dev, N);
+      if (N.k <= 20) hipLaunchKernelGGL(gicp_knn_cov_listed<20>, dim3(ceil_div(nmax, kGicpKnnThreads), N.n), dim3(kGicpKnnThreads), 0, h->stream, dk, G.dev, N);
+      else hipLaunchKernelGGL(gicp_knn_cov_listed<kGicpKMax>, dim3(ceil_div(nmax, kGicpKnnThreads), N.n), dim3(kGicpKnnThreads), 0, h->stream, dk, G.dev, N);
+    }
     for (size_t c0 = 0; c0 < corr.size(); c0 += kGicpLaunchJobs) {
       GicpCorrBatch L{};
       L.n = (int)std::min<size_t>(kGicpLaunchJobs, corr.size() - c0);
@@ -599,18 +628,16 @@ smhip_status gicp_align_jobs(smhip_context* h, int first, int K, const char* run
     h->ns[sfirst + e] = ns; h->nt[sfirst + e] = ns;
     touch_target(h, sfirst + e);
   }
-  const float knn_cell = gicp_knn_cell(o);
   {
     GicpSearchMode mode(h);
     bool kept = false;
     smhip_status s;
-    { GicpCell scratch_cell(h, knn_cell); s = gicp_build_grids(h, sfirst, K, &kept); }
-    if (s == SMHIP_OK) s = gicp_build_grids(h, first, K, &kept);      // (with the Align's cell: the k-NN one unless every target's covariances are kept)
+    { GicpCell scratch_cell(h, gicp_knn_cell(o)); s = gicp_build_grids(h, sfirst, K, &kept); }
+    if (s == SMHIP_OK) s = gicp_build_grids(h, first, K, &kept);
     if (s) return s;
     if (kept) h->cache_hits++;
   }
   {
-    // the targets' covariances depend on the target, k, epsilon and the search cell alone: kept while those are
     IcpDev dk = h->dev;
     dk.have_rowbits = 1;                       // built by gicp_build_grids (a ring-search context)
     GicpKnnBatch L{};
@@ -622,19 +649,37 @@ smhip_status gicp_align_jobs(smhip_context* h, int first, int K, const char* run
       else hipLaunchKernelGGL(gicp_knn_cov<kGicpKMax>, dim3(ceil_div(nmax, kGicpKnnThreads), L.n), dim3(kGicpKnnThreads), 0, h->stream, dk, L, k, o.gicp_epsilon);
       L.n = 0; nmax = 0;
     };
-    auto add = [&](int slot, double* cov, int n) {
-      L.slot[L.n] = slot; L.cov[L.n] = cov; ++L.n;
-      nmax = std::max(nmax, n);
-      if (L.n == kGicpKnnJobs) flush();
-    };
+    // Target covariances.  A batch estimates them on demand (gicp_need / gicp_knn_cov_listed in the correspondence steps: a
+    // twelfth of the neighbourhoods); a single Align estimates them all up front, as computeCovariances does (:391-402): the
+    // duration of a neighbourhood launch is that of its slowest queries (far-range points with metres to their 20th neighbour),
+    // which a launch over 574 000 points hides no worse than one over 34 000, and a complete set lets the following Aligns on
+    // the kept target skip the step altogether.
+    const bool eager = K < kGicpLazyMinJobs;
     for (int e = 0; e < K; ++e) {
       if (!run[e]) continue;
       GicpJobHost& jh = G.job[first + e];
-      const bool cov_kept = h->target_cache && jh.cov_gen != 0 && jh.cov_gen == h->tgt_gen[first + e] && jh.cov_k == k && jh.cov_eps == o.gicp_epsilon && jh.cov_cell == knn_cell;
-      if (!cov_kept) add(first + e, G.dev.cov_t + (size_t)(first + e) * h->dev.nt_cap * 6, h->nt[first + e]);
-      else h->cache_hits++;
-      add(sfirst + e, G.dev.cov_s + (size_t)(first + e) * h->dev.ns_cap * 6, h->ns[first + e]);
-      jh.cov_gen = h->tgt_gen[first + e]; jh.cov_k = k; jh.cov_eps = o.gicp_epsilon; jh.cov_cell = knn_cell;
+      // a target's covariances depend on the target, k and epsilon alone: the entries estimated so far stay while those do
+      const bool cov_kept = h->target_cache && jh.epoch != 0 && jh.cov_gen == h->tgt_gen[first + e] && jh.cov_k == k && jh.cov_eps == o.gicp_epsilon;
+      if (cov_kept) {
+        h->cache_hits++;
+      } else {
+        jh.cov_full = eager;
+        if (eager) {
+          L.slot[L.n] = first + e; L.cov[L.n] = G.dev.cov_t + (size_t)(first + e) * h->dev.nt_cap * 6; ++L.n;
+          nmax = std::max(nmax, h->nt[first + e]);
+          if (L.n == kGicpKnnJobs) flush();
+        }
+        if (jh.epoch == 0xffffffffu) {         // (4 billion invalidations later: start over)
+          HIPCHK(h, hipMemsetAsync(G.dev.cov_epoch + (size_t)(first + e) * h->dev.nt_cap, 0, sizeof(uint32_t) * (size_t)h->dev.nt_cap, h->stream));
+          jh.epoch = 0;
+        }
+        ++jh.epoch;
+        jh.cov_gen = h->tgt_gen[first + e]; jh.cov_k = k; jh.cov_eps = o.gicp_epsilon;
+      }
+      // the source's covariances: all of them, every Align (every source point is a query)
+      L.slot[L.n] = sfirst + e; L.cov[L.n] = G.dev.cov_s + (size_t)(first + e) * h->dev.ns_cap * 6; ++L.n;
+      nmax = std::max(nmax, h->ns[first + e]);
+      if (L.n == kGicpKnnJobs) flush();
     }
     flush();
   }
@@ -794,23 +839,22 @@ static smhip_status ndt_gicp_align_jobs(smhip_handle h, int first, int K, const 
     ~WithinAlign() { h->target_cache = keep; }
   } within{h, h->target_cache};
   if (!within.keep) {
-    for (int e = 0; e < K; ++e) { g.job[first + e].staged_raw_gen = 0; g.job[first + e].cov_gen = 0; touch_grid(h, first + e, 1); }
+    for (int e = 0; e < K; ++e) { g.job[first + e].staged_raw_gen = 0; g.job[first + e].cov_gen = 0; touch_grid(h, first + e, 1); }   // (cov_gen 0: a new epoch)
     for (auto& m : ndt_of(h).meta) m.valid = false;
     h->target_cache = 1;
   }
-  // (see GicpCell) does any job have to estimate its target's covariances in this Align?
-  const float knn_cell = gicp_knn_cell(g.opts);
-  bool all_kept = true;
+  // (see GicpCell) can any job have to estimate target covariances in this Align?
+  bool all_full = true;
   for (int e = 0; e < K; ++e) {
     const GicpJobHost& jh = g.job[first + e];
     const int filt = g.opts.using_voxel_filter ? 1 : 0;
     const bool staged = jh.raw_tgt_gen != 0 && jh.staged_raw_gen == jh.raw_tgt_gen && jh.staged_slot_gen == h->tgt_gen[first + e] &&
                         jh.staged_filter == filt && (!filt || jh.staged_res == g.opts.voxel_resolution);
-    const bool cov = jh.cov_gen != 0 && jh.cov_gen == h->tgt_gen[first + e] && jh.cov_k == g.opts.gicp_k_correspondences &&
-                     jh.cov_eps == g.opts.gicp_epsilon && jh.cov_cell == knn_cell;
-    all_kept = all_kept && staged && cov;
+    const bool cov = jh.epoch != 0 && jh.cov_full && jh.cov_gen == h->tgt_gen[first + e] && jh.cov_k == g.opts.gicp_k_correspondences &&
+                     jh.cov_eps == g.opts.gicp_epsilon;
+    all_full = all_full && staged && cov;
   }
-  GicpCell cell(h, all_kept ? h->dev.grid_cell : knn_cell);
+  GicpCell cell(h, all_full ? h->dev.grid_cell : gicp_knn_cell(g.opts));
   for (int e = 0; e < K; ++e) {
     s = ndt_gicp_stage_clouds(h, first + e);
     if (s) return s;
@@ -959,6 +1003,24 @@ smhip_status smhip_gicp_get_covariances(smhip_handle h, int which, double* cov, 
   const int m = which == 0 ? h->ns[0] : h->nt[0];
   if (n != m) { h->err = "n must equal the cloud size"; return SMHIP_ERR_INVALID_ARGUMENT; }
   HIPCHK(h, hipSetDevice(h->device));
+  if (which == 1) {
+    // a run estimates a target's covariances only where a source point was matched: the hook asks for all of them, as
+    // computeCovariances would have left them (:391-402) -- the same function over the job slot's grid, every point
+    const smhip_ndt_gicp_options& o = g.opts;
+    GicpSearchMode mode(h);
+    GicpCell cell(h, gicp_knn_cell(o));
+    bool kept = false;
+    smhip_status s = gicp_build_grids(h, 0, 1, &kept);
+    if (s) return s;
+    IcpDev dk = h->dev;
+    dk.have_rowbits = 1;
+    GicpKnnBatch L{};
+    L.n = 1; L.slot[0] = 0; L.cov[0] = g.dev.cov_t;
+    const int k = o.gicp_k_correspondences;
+    if (k <= 20) hipLaunchKernelGGL(gicp_knn_cov<20>, dim3(ceil_div(m, kGicpKnnThreads), 1), dim3(kGicpKnnThreads), 0, h->stream, dk, L, k, o.gicp_epsilon);
+    else hipLaunchKernelGGL(gicp_knn_cov<kGicpKMax>, dim3(ceil_div(m, kGicpKnnThreads), 1), dim3(kGicpKnnThreads), 0, h->stream, dk, L, k, o.gicp_epsilon);
+    HIPCHK(h, hipGetLastError());
+  }
   std::vector<double> c((size_t)m * 6);
   HIPCHK(h, hipMemcpyAsync(c.data(), which == 0 ? g.dev.cov_s : g.dev.cov_t, sizeof(double) * 6 * (size_t)m, hipMemcpyDeviceToHost, h->stream));
   if (which == 1) {                                          // already indexed by the target's array position

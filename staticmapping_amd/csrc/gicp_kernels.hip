@@ -148,20 +148,36 @@ __device__ __forceinline__ void gicp_knn_cov_one(const IcpDev& b, int pair, int 
   // blocks of half-width 0, 1, 2, 4, ... cells around the query's cell; a larger block only visits what the previous one
   // did not (whole rows outside it, the two x extensions of the rows inside it), so sparse regions cost O(log) steps
   const int rmax = max(max(st->nx, st->ny), st->nz);
+  const float row_slack = 2.0e-3f * st->h;       // (points sitting on a cell face, as in the 1-NN searches)
   int rp = -1;                                   // half-width already covered
-  for (int r = 0; ; r = (r == 0 ? 1 : 2 * r)) {
+  for (int r = 0; ; ) {
     const int X0 = max(cx - r, 0), X1 = min(cx + r, st->nx - 1);
     const int Y0 = max(cy - r, 0), Y1 = min(cy + r, st->ny - 1);
     const int Z0 = max(cz - r, 0), Z1 = min(cz + r, st->nz - 1);
     auto visit_row = [&](int z, int y) {
+      // a row farther away than the set's largest distance holds no candidate (strictly farther: a point AT that distance may
+      // still replace a member with a larger index); `worst` only shrinks, so what is skipped now stays irrelevant
+      const float yl = st->origin[1] + (float)y * st->h, zl = st->origin[2] + (float)z * st->h;
+      const float ry = fmaxf(fmaxf(yl - q.y, q.y - (yl + st->h)) - row_slack, 0.f);
+      const float rz = fmaxf(fmaxf(zl - q.z, q.z - (zl + st->h)) - row_slack, 0.f);
+      const float ryz2 = fmaf(ry, ry, rz * rz);
+      if (ryz2 > worst) return;
+      // ... and inside the row only the chord of that ball
+      int xa = X0, xb = X1;
+      if (worst < INFINITY) {
+        const float rx = sqrtf(worst - ryz2) * 1.0001f + row_slack;
+        xa = max(xa, cell_coord(q.x - rx, st->origin[0], st->inv_h));
+        xb = min(xb, cell_coord(q.x + rx, st->origin[0], st->inv_h));
+        if (xa > xb) return;
+      }
       const int rowbase = (z * st->ny + y) * st->wx;
       const bool inner = rp >= 0 && abs(y - cy) <= rp && abs(z - cz) <= rp;
       if (!inner) {
-        scan(rowbase, X0, X1);
+        scan(rowbase, xa, xb);
       } else {
-        const int xl1 = min(cx - rp - 1, st->nx - 1), xr0 = max(cx + rp + 1, 0);
-        if (X0 <= xl1) scan(rowbase, X0, xl1);
-        if (xr0 <= X1) scan(rowbase, xr0, X1);
+        const int xl1 = min(cx - rp - 1, xb), xr0 = max(cx + rp + 1, xa);
+        if (xa <= xl1) scan(rowbase, xa, xl1);
+        if (xr0 <= xb) scan(rowbase, xr0, xb);
       }
     };
     for (int z = Z0; z <= Z1; ++z) {
@@ -175,6 +191,11 @@ __device__ __forceinline__ void gicp_knn_cov_one(const IcpDev& b, int pair, int 
     if (g > 0.f && worst <= g * g) break;
     if (r > rmax) break;
     rp = r;
+    // the next block: once the set is full its largest distance bounds the neighbourhood, and the block that reaches that far
+    // ends the search -- doubling past it (a far-range point with metres to its 20th neighbour: half-width 8 -> 16 -> 32) visits
+    // up to eight times the rows for nothing
+    const int dbl = r == 0 ? 1 : 2 * r;
+    r = worst < INFINITY ? max(r + 1, min(dbl, (int)(sqrtf(worst) * st->inv_h) + 2)) : dbl;
   }
   // covariance of the k neighbours from the RAW coordinates; the products pt.x * pt.y are float products (:95-103)
   // The set's slots are filled in visiting order, which follows the order of the points inside a grid cell: summed slot by

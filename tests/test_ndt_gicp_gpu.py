@@ -283,3 +283,46 @@ def test_batch_with_a_rejected_job_and_job_range_errors():
     with pytest.raises(Exception):
         mb.set_input_source(pairs[0][0], slot=3)
     mb.close()
+
+
+def test_covariance_cache_transitions_between_single_and_batch_calls():
+    """Target covariances are estimated all up front by a single Align and on demand by a batch, and both forms keep what they
+    estimated while the target stays.  Every order of the two on one handle -- single then batch, a target replaced in between,
+    batch then single -- must give what a fresh handle gives for the same pair."""
+    pairs = _batch_pairs(5)
+
+    def fresh(src, tgt, G):
+        m = sm.NdtGicpHip(max_source_points=65536, max_target_points=65536)
+        m.set_input_source(src); m.set_input_target(tgt)
+        ok, R = m.align(G)
+        st = dict(m.last_gicp_stats)
+        m.close()
+        return R, st
+    want = [fresh(*p) for p in pairs[:4]]
+    mb = sm.NdtGicpHip(max_source_points=65536, max_target_points=65536, jobs=4)
+    for k, (a, b, G) in enumerate(pairs[:4]):
+        mb.set_input_source(a, slot=k); mb.set_input_target(b, slot=k)
+    # job 0 alone first (a complete set of covariances), then the batch of four (job 0 keeps its set, the others list what they need)
+    ok, R0 = mb.align(pairs[0][2])
+    assert np.array_equal(R0, want[0][0])
+    R, sc, st = mb.align_batch(4, [p[2] for p in pairs[:4]])
+    for k in range(4):
+        assert np.array_equal(R[k], want[k][0]), k
+        assert st[k]["gicp_function_evaluations"] == want[k][1]["gicp_function_evaluations"]
+    # job 2 gets another target (and source): its epoch moves on, nothing of the old target may be used
+    mb.set_input_source(pairs[4][0], slot=2); mb.set_input_target(pairs[4][1], slot=2)
+    guesses = [pairs[0][2], pairs[1][2], pairs[4][2], pairs[3][2]]
+    R, sc, st = mb.align_batch(4, guesses)
+    w2 = fresh(*pairs[4])
+    assert np.array_equal(R[2], w2[0]) and st[2]["gicp_correspondences"] == w2[1]["gicp_correspondences"]
+    for k in (0, 1, 3):
+        assert np.array_equal(R[k], want[k][0]), k
+    # a batch of two (small batches estimate up front) over jobs whose sets are partial, and with a guess that matches other points
+    G1 = pairs[1][2].copy(); G1[0, 3] += 0.15
+    R, sc, st = mb.align_batch(2, [G1, pairs[4][2]], first_job=1)
+    m1 = sm.NdtGicpHip(max_source_points=65536, max_target_points=65536)
+    m1.set_input_source(pairs[1][0]); m1.set_input_target(pairs[1][1])
+    ok, R1 = m1.align(G1)
+    m1.close()
+    assert np.array_equal(R[0], R1) and np.array_equal(R[1], w2[0])
+    mb.close()

@@ -713,6 +713,8 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
   const float4* __restrict__ tq = b.tq + (size_t)pair * b.nt_cap;
   const float r_need = 0.9f * sqrtf(st->rcap2);     // a hard query's bound must stay well above the quantile
   uint32_t min_lb = 0xffffffffu;
+  uint32_t nabo_failed = 0;                          // NABO: bit `it` = this lane's query of round `it` has to be walked again
+  static_assert(ITEMS <= 32, "one bit per round");
   // two-deep software pipeline: a round's streamed values (point, bound, previous match id) are loaded two rounds ahead and
   // the gather of the previous match one round ahead, so no round waits for a load it has just issued
   int ic = min(base + (int)threadIdx.x, ns - 1);
@@ -779,20 +781,9 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
     }
     const unsigned long long dm = __ballot(fail);
     if (NABO) {
-      // queries to walk again go to one of four lists by the number of buckets their last walk scanned: a wave of the list
-      // walk executes the union of its lanes' walks, so queries of like cost share waves (nabo_kernels.hip, nabo_class)
-      if (dm) {
-        const int cls = fail ? nabo_class(b.nabo_work[so + min(i, ns - 1)]) : -1;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const unsigned long long cm = __ballot(cls == c);
-          if (!cm) continue;                                             // wave-uniform
-          uint32_t basepos = 0;
-          if (lane == 0) basepos = atomicAdd(&st->nabo_count[c], (uint32_t)__popcll(cm));
-          basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);
-          if (cls == c) *nabo_list_slot(b, so, c, basepos + __popcll(cm & ((1ull << lane) - 1ull))) = i;
-        }
-      }
+      // (listed after the loop: an atomic whose result is needed waits for every load issued before it, which would empty the
+      // two-deep pipeline in every round that has a failing certificate -- nearly all of them in the first iterations)
+      if (fail) nabo_failed |= 1u << it;
     } else if (dm) {
       uint32_t basepos = 0;
       if (lane == 0) basepos = atomicAdd(&st->deferred_count, (uint32_t)__popcll(dm));
@@ -805,6 +796,55 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
       if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
       basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);   // lane 0 did the atomic
       if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
+    }
+  }
+  if (NABO && __ballot(nabo_failed != 0u)) {
+    // Queries to walk again go to one of four lists by the number of buckets their last walk scanned: a wave of the list walk
+    // executes the union of its lanes' walks, so queries of like cost share waves (nabo_kernels.hip, nabo_class).  The wave
+    // appends what its ITEMS rounds collected in one go: the classes of its failing queries (their loads all in flight
+    // together), four counts, four atomics, then the entries.
+    unsigned long long cls2 = 0;                                         // two class bits per round
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int i = base + it * kNnThreads + (int)threadIdx.x;
+      const uint32_t w = (nabo_failed >> it) & 1u ? (uint32_t)b.nabo_work[so + min(i, ns - 1)] : 0u;
+      cls2 |= (unsigned long long)nabo_class(w) << (2 * it);
+    }
+    uint32_t tot[4] = {0, 0, 0, 0};
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    auto class_masks = [&](int it, unsigned long long* m) {
+      const bool f = (nabo_failed >> it) & 1u;
+      const uint32_t c = (uint32_t)(cls2 >> (2 * it)) & 3u;
+      const unsigned long long fm = __ballot(f), b0 = __ballot(f && (c & 1u)), b1 = __ballot(f && (c & 2u));
+      m[0] = fm & ~b0 & ~b1; m[1] = fm & b0 & ~b1; m[2] = fm & ~b0 & b1; m[3] = fm & b0 & b1;
+      return fm;
+    };
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      unsigned long long m[4];
+      if (!class_masks(it, m)) continue;                                 // wave-uniform
+#pragma unroll
+      for (int c = 0; c < 4; ++c) tot[c] += (uint32_t)__popcll(m[c]);
+    }
+    uint32_t basepos[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint32_t v = 0;
+      if (lane == 0 && tot[c]) v = atomicAdd(&st->nabo_count[c], tot[c]);
+      basepos[c] = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      unsigned long long m[4];
+      if (!class_masks(it, m)) continue;
+      const uint32_t c = (uint32_t)(cls2 >> (2 * it)) & 3u;
+      if ((nabo_failed >> it) & 1u) {
+        const unsigned long long mine = c == 0 ? m[0] : (c == 1 ? m[1] : (c == 2 ? m[2] : m[3]));
+        const uint32_t bp = c == 0 ? basepos[0] : (c == 1 ? basepos[1] : (c == 2 ? basepos[2] : basepos[3]));
+        *nabo_list_slot(b, so, (int)c, bp + (uint32_t)__popcll(mine & lt)) = base + it * kNnThreads + (int)threadIdx.x;
+      }
+#pragma unroll
+      for (int c2 = 0; c2 < 4; ++c2) basepos[c2] += (uint32_t)__popcll(m[c2]);
     }
   }
 #pragma unroll

@@ -687,6 +687,61 @@ __device__ __forceinline__ int32_t* nabo_list_slot(const IcpDev& b, size_t so, i
   return (c & 1) ? base + (b.ns_cap - 1) - k : base + k;
 }
 
+// SMHIP_NN_NABO: the queries a wave's ITEMS rounds found to walk again (bit `it` of nabo_failed = this lane's query of round
+// `it`) go to one of four lists by the number of buckets their last walk scanned: a wave of the list walk executes the union of
+// its lanes' walks, so queries of like cost share waves (nabo_kernels.hip, nabo_class).  Done once per wave AFTER the streaming
+// loop -- an atomic whose result is needed waits for every load issued before it, which would empty the two-deep pipeline in
+// every round that has a failing certificate (nearly all of them in the first iterations): the classes of the failing queries
+// (their loads all in flight together), four counts, four atomics, then the entries.
+template <int ITEMS>
+__device__ __forceinline__ void nabo_list_append(const IcpDev& b, PairState* st, size_t so, int base, int ns, uint32_t nabo_failed, int lane) {
+  static_assert(ITEMS <= 32, "one bit per round");
+  if (!__ballot(nabo_failed != 0u)) return;
+  unsigned long long cls2 = 0;                                         // two class bits per round
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int i = base + it * kNnThreads + (int)threadIdx.x;
+    const uint32_t w = (nabo_failed >> it) & 1u ? (uint32_t)b.nabo_work[so + min(i, ns - 1)] : 0u;
+    cls2 |= (unsigned long long)nabo_class(w) << (2 * it);
+  }
+  uint32_t tot[4] = {0, 0, 0, 0};
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  auto class_masks = [&](int it, unsigned long long* m) {
+    const bool f = (nabo_failed >> it) & 1u;
+    const uint32_t c = (uint32_t)(cls2 >> (2 * it)) & 3u;
+    const unsigned long long fm = __ballot(f), b0 = __ballot(f && (c & 1u)), b1 = __ballot(f && (c & 2u));
+    m[0] = fm & ~b0 & ~b1; m[1] = fm & b0 & ~b1; m[2] = fm & ~b0 & b1; m[3] = fm & b0 & b1;
+    return fm;
+  };
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    unsigned long long m[4];
+    if (!class_masks(it, m)) continue;                                 // wave-uniform
+#pragma unroll
+    for (int c = 0; c < 4; ++c) tot[c] += (uint32_t)__popcll(m[c]);
+  }
+  uint32_t basepos[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    uint32_t v = 0;
+    if (lane == 0 && tot[c]) v = atomicAdd(&st->nabo_count[c], tot[c]);
+    basepos[c] = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+  }
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    unsigned long long m[4];
+    if (!class_masks(it, m)) continue;
+    const uint32_t c = (uint32_t)(cls2 >> (2 * it)) & 3u;
+    if ((nabo_failed >> it) & 1u) {
+      const unsigned long long mine = c == 0 ? m[0] : (c == 1 ? m[1] : (c == 2 ? m[2] : m[3]));
+      const uint32_t bp = c == 0 ? basepos[0] : (c == 1 ? basepos[1] : (c == 2 ? basepos[2] : basepos[3]));
+      *nabo_list_slot(b, so, (int)c, bp + (uint32_t)__popcll(mine & lt)) = base + it * kNnThreads + (int)threadIdx.x;
+    }
+#pragma unroll
+    for (int c2 = 0; c2 < 4; ++c2) basepos[c2] += (uint32_t)__popcll(m[c2]);
+  }
+}
+
 // Certificate pass (iterations >= 1): no search, five memory operations per query.
 // ITEMS = rounds of 256 queries per workgroup: kBallItems in batches, 1 where that would leave too few workgroups (one pair)
 // NABO = true: the records are traversal certificates of the libnabo walk (nabo_kernels.hip): how far the query may move
@@ -714,7 +769,6 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
   const float r_need = 0.9f * sqrtf(st->rcap2);     // a hard query's bound must stay well above the quantile
   uint32_t min_lb = 0xffffffffu;
   uint32_t nabo_failed = 0;                          // NABO: bit `it` = this lane's query of round `it` has to be walked again
-  static_assert(ITEMS <= 32, "one bit per round");
   // two-deep software pipeline: a round's streamed values (point, bound, previous match id) are loaded two rounds ahead and
   // the gather of the previous match one round ahead, so no round waits for a load it has just issued
   int ic = min(base + (int)threadIdx.x, ns - 1);
@@ -781,9 +835,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
     }
     const unsigned long long dm = __ballot(fail);
     if (NABO) {
-      // (listed after the loop: an atomic whose result is needed waits for every load issued before it, which would empty the
-      // two-deep pipeline in every round that has a failing certificate -- nearly all of them in the first iterations)
-      if (fail) nabo_failed |= 1u << it;
+      if (fail) nabo_failed |= 1u << it;               // (listed after the loop: nabo_list_append)
     } else if (dm) {
       uint32_t basepos = 0;
       if (lane == 0) basepos = atomicAdd(&st->deferred_count, (uint32_t)__popcll(dm));
@@ -798,55 +850,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify(IcpDev b, int nblk) {
       if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
     }
   }
-  if (NABO && __ballot(nabo_failed != 0u)) {
-    // Queries to walk again go to one of four lists by the number of buckets their last walk scanned: a wave of the list walk
-    // executes the union of its lanes' walks, so queries of like cost share waves (nabo_kernels.hip, nabo_class).  The wave
-    // appends what its ITEMS rounds collected in one go: the classes of its failing queries (their loads all in flight
-    // together), four counts, four atomics, then the entries.
-    unsigned long long cls2 = 0;                                         // two class bits per round
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int i = base + it * kNnThreads + (int)threadIdx.x;
-      const uint32_t w = (nabo_failed >> it) & 1u ? (uint32_t)b.nabo_work[so + min(i, ns - 1)] : 0u;
-      cls2 |= (unsigned long long)nabo_class(w) << (2 * it);
-    }
-    uint32_t tot[4] = {0, 0, 0, 0};
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    auto class_masks = [&](int it, unsigned long long* m) {
-      const bool f = (nabo_failed >> it) & 1u;
-      const uint32_t c = (uint32_t)(cls2 >> (2 * it)) & 3u;
-      const unsigned long long fm = __ballot(f), b0 = __ballot(f && (c & 1u)), b1 = __ballot(f && (c & 2u));
-      m[0] = fm & ~b0 & ~b1; m[1] = fm & b0 & ~b1; m[2] = fm & ~b0 & b1; m[3] = fm & b0 & b1;
-      return fm;
-    };
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      unsigned long long m[4];
-      if (!class_masks(it, m)) continue;                                 // wave-uniform
-#pragma unroll
-      for (int c = 0; c < 4; ++c) tot[c] += (uint32_t)__popcll(m[c]);
-    }
-    uint32_t basepos[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      uint32_t v = 0;
-      if (lane == 0 && tot[c]) v = atomicAdd(&st->nabo_count[c], tot[c]);
-      basepos[c] = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
-    }
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      unsigned long long m[4];
-      if (!class_masks(it, m)) continue;
-      const uint32_t c = (uint32_t)(cls2 >> (2 * it)) & 3u;
-      if ((nabo_failed >> it) & 1u) {
-        const unsigned long long mine = c == 0 ? m[0] : (c == 1 ? m[1] : (c == 2 ? m[2] : m[3]));
-        const uint32_t bp = c == 0 ? basepos[0] : (c == 1 ? basepos[1] : (c == 2 ? basepos[2] : basepos[3]));
-        *nabo_list_slot(b, so, (int)c, bp + (uint32_t)__popcll(mine & lt)) = base + it * kNnThreads + (int)threadIdx.x;
-      }
-#pragma unroll
-      for (int c2 = 0; c2 < 4; ++c2) basepos[c2] += (uint32_t)__popcll(m[c2]);
-    }
-  }
+  if (NABO) nabo_list_append<ITEMS>(b, st, so, base, ns, nabo_failed, lane);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) min_lb = min(min_lb, (uint32_t)__shfl_xor((int)min_lb, off, 64));
   if (lane == 0 && min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
@@ -1977,8 +1981,8 @@ __device__ __forceinline__ void emit_record(const IcpDev& b, size_t segbase, int
   wcount += (int)__popcll(bm);
 }
 
-template <int ITEMS>
-__global__ __launch_bounds__(kNnThreads) void nn_certify_acc(IcpDev b, int nblk) {
+template <int ITEMS, bool NABO = false>
+__global__ __launch_bounds__(kNnThreads, NABO ? 4 : 1) void nn_certify_acc(IcpDev b, int nblk) {   // (NABO: 129 registers without the hint, one wave per SIMD less)
   int pair, blk;
   if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
   PairState* st = &b.state[pair];
@@ -2017,6 +2021,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify_acc(IcpDev b, int nblk)
   const size_t recbase = (size_t)pair * 2 * b.bl_stride + (size_t)seg * (64 * ITEMS);
   char* __restrict__ dsegb = reinterpret_cast<char*>(b.dlist + (size_t)pair * b.dl_stride + (size_t)seg * (64 * ITEMS));
   int nrec = 0, ndef = 0;
+  uint32_t nabo_failed = 0;
   double acc[29];
 #pragma unroll
   for (int c = 0; c < 29; ++c) acc[c] = 0.0;
@@ -2055,9 +2060,23 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify_acc(IcpDev b, int nblk)
       transform_point(Mc, s, px, py, pz);
       const float qx = (float)px, qy = (float)py, qz = (float)pz;
       // as nn_certify; |s| by the hardware root (1 ulp: bound_now's slack of 1e-4 of the potential covers a million of those)
-      const float Lp = bound_now(l, pot_at(pot, __builtin_amdgcn_sqrtf(fmaf(s.z, s.z, fmaf(s.y, s.y, s.x * s.x)))));
+      const float Lp = NABO ? 0.f : bound_now(l, pot_at(pot, __builtin_amdgcn_sqrtf(fmaf(s.z, s.z, fmaf(s.y, s.y, s.x * s.x)))));
       fail = true;
-      if (isfinite(qx) && isfinite(qy) && isfinite(qz) && Lp > 0.f) {
+      if (NABO) {
+        // the traversal certificate of the libnabo walk (nn_certify<., true>, with its expression and its |s|): the query keeps
+        // its id -- by the same walk -- and only its distance to that id is recomputed
+        const float Pn = pot_at(pot, norm3(s.x, s.y, s.z));
+        if (isfinite(qx) && isfinite(qy) && isfinite(qz) && l > 0.f && j >= 0 &&
+            l - Pn - 4.0e-7f * (l + Pn) - 1.3e-7f * (fabsf(qx) + fabsf(qy) + fabsf(qz)) > 0.f) {
+          d1 = dist2(t, qx, qy, qz);               // the bucket scan's arithmetic: the bits the walk would produce
+          st_d(i, d1);
+          const int bin = (int)(__float_as_uint(d1) >> kHistShift);
+          atomicAdd(&s_hist[bin], 1u);
+          fail = false;
+          if (bin < band_lo) accumulate_terms_p(px, py, pz, t, n, d1, acc);
+          else band = bin <= band_hi;
+        }
+      } else if (isfinite(qx) && isfinite(qy) && isfinite(qz) && Lp > 0.f) {
         if (l > 0.f && j >= 0) {
           d1 = dist2(t, qx, qy, qz);
           if (d1 < Lp * Lp) {                       // still the unique nearest neighbour: exact, no search
@@ -2078,7 +2097,9 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify_acc(IcpDev b, int nblk)
         }
       }
     }
-    {   // failing certificates: the wave's own segment of dlist, in query order
+    if (NABO) {
+      if (fail) nabo_failed |= 1u << it;             // to the class lists after the loop (nabo_list_append)
+    } else {   // failing certificates: the wave's own segment of dlist, in query order
       const unsigned long long dm = __ballot(fail);
       if (fail) *reinterpret_cast<int*>(dsegb + (uint32_t)(ndef + (int)__popcll(dm & ((1ull << lane) - 1ull))) * 4u) = i;
       ndef += (int)__popcll(dm);
@@ -2101,6 +2122,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_certify_acc(IcpDev b, int nblk)
   if (lane == 0 && min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
   block_reduce29(acc, s_red, s_out);                // (its barriers also order the histogram updates before the flush)
   if (threadIdx.x < 29) b.partials[((size_t)pair * b.part_stride + blk) * kAccCols + threadIdx.x] = s_out[threadIdx.x];
+  if (NABO) nabo_list_append<ITEMS>(b, st, so, base, ns, nabo_failed, lane);      // (after the sums: their 58 registers are free again)
   uint32_t* gh = b.hist + (size_t)pair * kHistBins;
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
     const uint32_t v = s_hist[k];
@@ -2431,6 +2453,104 @@ __global__ __launch_bounds__(kNnThreads, 5) void nn_ball_listed_items(IcpDev b) 
   if (cur >= 0) flush();
 }
 
+// Reference-search mode, fused path: the queries the list walk (nn_nabo<., true>) has just matched again, by the fused pass's
+// rule -- a match below the predicted band is summed, a match inside it becomes a record -- once the histogram is complete and
+// nabo_validate has checked the prediction (the quantile's bin inside the band: this mode's nn_validate; spec_ok also tells
+// `accumulate` to return at once, and finalize which form the iteration's sums have).  kNaboAccBlocks workgroups per pair take
+// equal shares of the four class lists laid end to end; every wave leaves its records in its own segment of region 1 (a wave
+// meets at most ceil(ns / 32) entries and a segment holds bl_stride / 32), the workgroup its sums in row nblk + blk of partials.
+// (the check of the prediction: one workgroup per pair looks at the completed histogram -- a look costs as much as a small
+// workgroup's whole share of the lists, so the kNaboAccBlocks workgroups of accumulate_listed read its verdict instead)
+__global__ __launch_bounds__(kAccThreads) void nabo_validate(IcpDev b) {
+  const int pair = b.pair_base + (int)blockIdx.x;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  __shared__ uint32_t s_w[17];
+  __shared__ uint32_t s_q[4];
+  find_quantile_bin(b.hist + (size_t)pair * kHistBins, b.rho, s_w, s_q);
+  if (threadIdx.x == 0) {
+    const int band_lo = st->band_lo, band_hi = st->band_hi;
+    st->spec_ok = (band_lo > 0 && s_q[2] > 0 && (int)s_q[0] >= band_lo && (int)s_q[0] <= band_hi) ? 1 : 0;
+  }
+}
+__global__ __launch_bounds__(kAccThreads) void accumulate_listed(IcpDev b) {
+  const int pair = b.pair_base + (int)blockIdx.y, blk = (int)blockIdx.x;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  __shared__ double s_red[4][29];
+  __shared__ double s_out[29];
+  const int ns = st->ns;
+  const int nblk0 = (ns + kNnThreads * kCertifyItems - 1) / (kNnThreads * kCertifyItems);
+  const int nseg0 = nblk0 * (kNnThreads / 64);
+  int cls_first[5];
+  cls_first[0] = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) cls_first[c + 1] = cls_first[c] + (int)st->nabo_count[c];
+  const int total = cls_first[4];
+  constexpr int kWaves = kNaboAccBlocks * (kAccThreads / 64);
+  const int lane = threadIdx.x & 63, wave = blk * (kAccThreads / 64) + (int)(threadIdx.x >> 6);
+  const int share = (total + kWaves - 1) / kWaves;
+  const int e0 = wave * share, e1 = min(total, e0 + share);
+  if (blk != 0 && blk * (kAccThreads / 64) * share >= total) {
+    // nothing of the lists falls to this workgroup (the usual case once the pose has settled): empty segments, a zero row --
+    // harmless if the prediction missed
+    if (lane == 0) b.gcount[(size_t)pair * b.seg_stride + nseg0 + wave] = 0u;
+    if (threadIdx.x < 29) b.partials[((size_t)pair * b.part_stride + nblk0 + blk) * kAccCols + threadIdx.x] = 0.0;
+    return;
+  }
+  if (!st->spec_ok) return;                                 // (nabo_validate) no prediction, or a miss: `accumulate` sums the plain way
+  const int band_lo = st->band_lo, band_hi = st->band_hi;
+  const size_t so = (size_t)pair * b.ns_cap, to = (size_t)pair * b.nt_cap;
+  const int seg_len1 = b.bl_stride / kWaves;
+  const size_t segbase = (size_t)pair * 2 * b.bl_stride + (size_t)b.bl_stride + (size_t)wave * seg_len1;
+  double Mc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Mc[k] = st->M[k];
+  double acc[29];
+#pragma unroll
+  for (int c = 0; c < 29; ++c) acc[c] = 0.0;
+  int wcount = 0;
+  auto entry = [&](int e) -> int {                          // the e-th query of the four class lists laid end to end
+    const int c = e < cls_first[1] ? 0 : (e < cls_first[2] ? 1 : (e < cls_first[3] ? 2 : 3));
+    const int f = c == 0 ? cls_first[0] : (c == 1 ? cls_first[1] : (c == 2 ? cls_first[2] : cls_first[3]));
+    return *nabo_list_slot(b, so, c, (uint32_t)(e - f));
+  };
+  constexpr int kU = 2;                                     // entries per lane and round: their dependent loads level by level
+  for (int eb = e0; eb < e1; eb += 64 * kU) {               // wave-uniform
+    int i[kU], jm[kU];
+    float d[kU];
+    float4 s4[kU], q4[kU], n4[kU];
+    bool live[kU], below[kU], rec[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) { live[u] = eb + 64 * u + lane < e1; i[u] = live[u] ? entry(eb + 64 * u + lane) : 0; }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) { d[u] = b.d2[so + i[u]]; jm[u] = b.idx[so + i[u]]; s4[u] = ld_src(b, so + i[u]); }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const uint32_t key = __float_as_uint(d[u]);
+      const int bin = (int)(key >> kHistShift);
+      const bool valid = live[u] && key < 0x7f800000u && jm[u] >= 0;
+      below[u] = valid && bin < band_lo;
+      rec[u] = valid && bin >= band_lo && bin <= band_hi;
+      if (below[u]) { q4[u] = b.tq[to + jm[u]]; n4[u] = b.tn[to + jm[u]]; }
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (below[u]) accumulate_terms(Mc, s4[u], q4[u], n4[u], d[u], acc);
+      const unsigned long long bm = __ballot(rec[u]);
+      if (rec[u]) {
+        const size_t at = segbase + wcount + __popcll(bm & ((1ull << lane) - 1ull));
+        b.rec_a[at] = make_float4(s4[u].x, s4[u].y, s4[u].z, d[u]);
+        b.rec_j[at] = jm[u];
+      }
+      wcount += (int)__popcll(bm);
+    }
+  }
+  if (lane == 0) b.gcount[(size_t)pair * b.seg_stride + nseg0 + wave] = (uint32_t)wcount;
+  block_reduce29(acc, s_red, s_out);
+  if (threadIdx.x < 29) b.partials[((size_t)pair * b.part_stride + nblk0 + blk) * kAccCols + threadIdx.x] = s_out[threadIdx.x];
+}
+
 // ------------------------------------------------------------------------------------------
 // K4: exact quantile, solve, update, convergence
 // ------------------------------------------------------------------------------------------
@@ -2591,8 +2711,12 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   const int nseg0 = nblk * 4;                                   // 4 waves per workgroup in both producers
   const int seg_len0 = chunk / 4;
   // (region 1: one segment per item of the listed search, as long as the item's queries -- listed_plan's cut of the list)
-  const int nseg = nseg0 + (fusedm ? (int)b.litems[pair] : 0);
-  const int seg_len1 = kNnThreads >> listed_lanes_log2((int)st->deferred_count, b.listed_lane_budget);
+  // (reference-search mode: the kNaboAccBlocks x 4 waves of accumulate_listed, which also summed the listed matches below the band)
+  const bool nabof = fusedm && b.fused_nabo;
+  constexpr int kNaboSegs = kNaboAccBlocks * (kAccThreads / 64);
+  const int nseg = nseg0 + (fusedm ? (nabof ? kNaboSegs : (int)b.litems[pair]) : 0);
+  const int seg_len1 = nabof ? b.bl_stride / kNaboSegs : kNnThreads >> listed_lanes_log2((int)st->deferred_count, b.listed_lane_budget);
+  const int nrows = nblk + (nabof ? kNaboAccBlocks : 0);
   const uint32_t* gcount = b.gcount + (size_t)pair * b.seg_stride;
   const float4* ra = b.rec_a + (size_t)pair * 2 * b.bl_stride;
   const int32_t* rj = b.rec_j + (size_t)pair * 2 * b.bl_stride;
@@ -2616,7 +2740,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   double acc[29];
 #pragma unroll
   for (int c = 0; c < 29; ++c) acc[c] = 0.0;
-  if (fusedm && n_valid > 0) {
+  if (fusedm && !nabof && n_valid > 0) {
     // Listed phase: the queries whose certificate failed this iteration (the per-wave segments of dlist the fused pass left,
     // dcount) have exact matches from the listed search now; those below the band are kept whatever the quantile turns out to
     // be inside it -- summed here, eight entries per thread and round with their loads issued level by level.  (Lower-bounded
@@ -2809,7 +2933,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
     const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
     double s = 0;
     const double* part = b.partials + (size_t)pair * b.part_stride * kAccCols + col;
-    for (int k = grp; k < nblk; k += 8) s += part[(size_t)k * kAccCols];
+    for (int k = grp; k < nrows; k += 8) s += part[(size_t)k * kAccCols];
     s_part[grp][col] = s;
   }
   __syncthreads();

@@ -66,6 +66,8 @@ struct smhip_context {
   unsigned long long cache_hits = 0;
   PairInput* in_pinned = nullptr;
   PairState* state_pinned = nullptr;
+  int hist_mode = 0;             // nn_mode of the batch whose searched-query history is waiting in hist_pinned
+  int nabo_fused_from = 6;       // reference-search mode: the first iteration of a batch that runs the fused certificate pass (fused_iteration)
   float split_share = 0.2f;      // auto split: the first iteration whose median searched share falls below this runs certify + listed search
   float4* stage = nullptr;       // pinned staging for uploads, 2 * max(ns_cap, nt_cap)
   uint32_t* done_pinned = nullptr;
@@ -340,16 +342,28 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
         Bracket br(h, 5, st, np);
         if (f.small) {
           hipLaunchKernelGGL((nn_certify<1, true>), dim3(nb1 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nb1);
+        } else if (d.fused) {
+          // certificate pass + the sums below the predicted quantile band in one pass over the source (fused_iteration decides)
+          const int nbc = ceil_div(ns_max, kNnThreads * kCertifyItems);
+          hipLaunchKernelGGL((nn_certify_acc<kCertifyItems, true>), dim3(nbc * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nbc);
         } else {
           const int nbc = ceil_div(ns_max, kNnThreads * kCertifyItems);
           hipLaunchKernelGGL((nn_certify<kCertifyItems, true>), dim3(nbc * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nbc);
         }
       }
-      Bracket br(h, 6, st, np);
-      const int nbl = f.small ? nb1 : h->nabo_listed_blocks;
-      const dim3 gl(nbl * 8 * ceil_div(np, 8));
-      if (shallow) hipLaunchKernelGGL((nn_nabo<1, true, 12>), gl, dim3(kNnThreads), 0, st, d, kd, nbl);
-      else hipLaunchKernelGGL((nn_nabo<1, true, kKdStack>), gl, dim3(kNnThreads), 0, st, d, kd, nbl);
+      {
+        Bracket br(h, 6, st, np);
+        const int nbl = f.small ? nb1 : h->nabo_listed_blocks;
+        const dim3 gl(nbl * 8 * ceil_div(np, 8));
+        if (shallow) hipLaunchKernelGGL((nn_nabo<1, true, 12>), gl, dim3(kNnThreads), 0, st, d, kd, nbl);
+        else hipLaunchKernelGGL((nn_nabo<1, true, kKdStack>), gl, dim3(kNnThreads), 0, st, d, kd, nbl);
+      }
+      if (d.fused) {
+        // the walked queries by the fused pass's rule, and the check of its prediction (this mode's nn_validate)
+        Bracket br(h, 1, st);
+        hipLaunchKernelGGL(nabo_validate, dim3(np), dim3(kAccThreads), 0, st, d);
+        hipLaunchKernelGGL(accumulate_listed, dim3(kNaboAccBlocks, np), dim3(kAccThreads), 0, st, d);
+      }
     } else {
       Bracket br(h, 4, st, np);
       if (f.small) {
@@ -446,6 +460,16 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
 // bound is refined in every iteration anyway (nothing to speculate on) or the cloud has more record segments than finalize indexes.
 bool fused_iteration(const smhip_context* h, const Half& f, int ns_max, int iteration) {
   const IcpDev& d = f.d;
+  if (h->opts.nn_mode == SMHIP_NN_NABO) {
+    // the reference-search form: every certificate iteration of a batch (the walk has no bounds to refine); rows of partials for
+    // the certificate pass's workgroups + accumulate_listed's
+    // ... from the iteration on in which the previous batch's median pair walked fewer than a fifth of its queries again: the walked
+    // queries are summed from their lists (accumulate_listed: scattered reads, ten times a streamed point's bytes), which only
+    // pays once they are few; before that `accumulate` streams every point
+    if (!d.certify || h->opts.no_fused_sums || f.small || iteration < std::max(1, h->nabo_fused_from) || f.np < 16) return false;
+    const int nbc = ceil_div(ns_max, kNnThreads * kCertifyItems);
+    return nbc + kNaboAccBlocks <= d.part_stride && nbc * (kNnThreads / 64) + kNaboAccBlocks * (kAccThreads / 64) <= std::min(kFinalizeMaxSeg, (int)d.seg_stride);
+  }
   if (h->opts.nn_mode != SMHIP_NN_GRID || !d.use_ball || !d.lds_table || !d.certify || h->opts.no_fused_sums || d.exact_all || f.small) return false;
   if (iteration < 1 || iteration < d.split_after || !(h->opts.split_after > 0 || f.np >= 16)) return false;
   if (f.np > kListedMaxPairs) return false;
@@ -486,7 +510,7 @@ void sync_options(smhip_context* h) {
   // radius only moves the point from which the ring search takes over, never the result)
   h->dev.ball_radius = std::min(h->dev.ball_radius, 14.0f * h->dev.grid_cell);
   { const char* e = std::getenv("SMHIP_DEBUG_FLAGS"); h->dev.debug_flags = e ? std::atoi(e) : 0; }
-  h->dev.fused = 0;
+  h->dev.fused = 0; h->dev.fused_nabo = 0;
   h->dev.band_pad = 0.1f; h->dev.band_gain = 1.5f;              // tuning only: results do not depend on the band, only how often it holds
   { const char* e = std::getenv("SMHIP_BAND_PAD"); if (e && std::atof(e) >= 0.0) h->dev.band_pad = (float)std::atof(e); }
   // lanes per query of the balanced listed search: measured flat from 1 024 to 8 192 (3.13-3.25 ms per step), slower beyond
@@ -599,7 +623,8 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   d.slots = pair_slots; d.ns_cap = max_source_points; d.nt_cap = max_target_points;
   d.acc_blocks = ceil_div(max_source_points, kAccThreads * kAccItemsSmall);
   d.acc_items = kAccItemsSmall;
-  d.part_stride = d.acc_blocks;
+  // rows of partials: accumulate's workgroups, or the fused certificate pass's plus accumulate_listed's (reference-search mode)
+  d.part_stride = std::max(d.acc_blocks, ceil_div(max_source_points, kNnThreads * kCertifyItems) + kNaboAccBlocks);
   d.dl_stride = ceil_div(max_source_points, kNnThreads * kCertifyItems) * (kNnThreads * kCertifyItems);
   d.bl_stride = std::max(ceil_div(max_source_points, kAccThreads * kAccItemsBatch) * (kAccThreads * kAccItemsBatch), d.dl_stride);
   // one segment per producing wave: accumulate with short chunks makes the most; the fused path has its certificate pass's waves
@@ -1101,7 +1126,8 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
       std::nth_element(share.begin(), share.begin() + share.size() / 2, share.end());
       if (share[share.size() / 2] < h->split_share) break;
     }
-    h->auto_split = std::max(1, std::min(k, 8));              // 8: from there on the two-launch form won on every workload measured
+    if (h->hist_mode == SMHIP_NN_NABO) h->nabo_fused_from = std::max(1, std::min(k, 12));   // (see fused_iteration)
+    else h->auto_split = std::max(1, std::min(k, 8));         // 8: from there on the two-launch form won on every workload measured
     h->hist_pairs = 0;
   }
   if (h->opts.split_after == 0) h->dev.split_after = h->auto_split;
@@ -1159,6 +1185,7 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
     for (int k = 0; k < nh; ++k) {
       Half& f = halves[k];
       f.d.fused = fused_iteration(h, f, ns_max, it) ? 1 : 0;     // every launch of this iteration and part sees the same flag
+      f.d.fused_nabo = f.d.fused && h->opts.nn_mode == SMHIP_NN_NABO ? 1 : 0;
       s = enqueue_find_closests_half(h, f, ns_max, it);
       if (s) return s;
       {
@@ -1182,7 +1209,9 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
   s = join();
   if (s) return s;
   // (only batches that ran the ball search with certificates say anything about where its two forms cross)
-  if (npairs >= 16 && h->opts.split_after == 0 && h->opts.nn_mode == SMHIP_NN_GRID && h->dev.use_ball && h->dev.certify && h->dev.lds_table) {
+  if (npairs >= 16 && h->dev.certify &&
+      ((h->opts.split_after == 0 && h->opts.nn_mode == SMHIP_NN_GRID && h->dev.use_ball && h->dev.lds_table) || h->opts.nn_mode == SMHIP_NN_NABO)) {
+    h->hist_mode = h->opts.nn_mode;
     HIPCHK(h, hipMemcpyAsync(h->hist_pinned, h->dev.search_hist + (size_t)first * kSearchHist, sizeof(uint32_t) * kSearchHist * (size_t)npairs,
                              hipMemcpyDeviceToHost, h->stream));
     h->hist_first = first; h->hist_pairs = npairs; h->hist_iters = max_it;

@@ -30,6 +30,7 @@ constexpr int kLdsTableCap = 1024;        // u32 entries of the per-workgroup ro
 constexpr int kLdsPointCap = 512;         // target points staged per round (8 KiB)
 constexpr int kLdsRowCap = 256;           // grid rows of the box whose runs are staged (<= workgroup size)
 constexpr int kWideBlocks = 512;         // workgroups (4 waves = 4 queries at a time) per pair of nn_ring_wide
+constexpr int kNaboAccBlocks = 8;         // workgroups per pair of accumulate_listed (reference-search mode, fused path)
 constexpr int kListedMaxPairs = 1024;   // pairs per launch of the balanced listed search (nn_ball_listed_items: its plan sits in LDS)
 constexpr int kListedItemBlocks = 1280;  // its workgroups: 5 per CU (LDS), each takes an equal run of the launch's items
 constexpr int kListedBlocks = 32;        // workgroups per pair of the listed search (nn_ball_listed): it strides over the list
@@ -125,6 +126,7 @@ struct IcpDev {
   int32_t fused;             // 1 = this iteration's launches belong to the fused path (nn_certify_acc + nn_ball_listed_items):
                              //     nn_validate decides spec_ok, accumulate returns at once when it holds, finalize reads either form
   float band_pad;            // half-width of the predicted band in bins, at least (tuning; default 0.1)
+  int32_t fused_nabo;        // the fused path's reference-search form (nn_certify_acc<., true> + nn_nabo + accumulate_listed)
   int32_t listed_lane_budget; // lanes a pair's listed search may spread its queries over (sets the lanes per query of nn_ball_listed_items)
   int32_t listed_grain;      // items a workgroup of nn_ball_listed_items claims at a time (0: equal runs fixed in advance)
   float band_gain;           // ... and this many times the quantile's last move (default 1.5)

@@ -169,16 +169,49 @@ def test_nabo_certificates_change_no_bit(cfg2, guess_name, capsys):
 
 
 def test_nabo_certificates_in_a_batch(velo20k):
-    """The batched launches (20 rounds per certificate workgroup, the strided list walk) against the single-pair ones."""
+    """The batched launches (20 rounds per certificate workgroup, the strided list walk) against the single-pair ones.  (The sums
+    the plain way in both runs: the fused certificate pass adds the same terms in another order -- its own test is below.)"""
     import staticmapping_amd as sm
     guesses = [velo20k["guess"], np.eye(4), velo20k["T"]] * 6
     out = {}
     for name, opts in (("no_certify", dict(no_certify=1)), ("certify", dict())):
         m = sm.IcpFastHip(pair_slots=len(guesses), max_source_points=20000, max_target_points=len(velo20k["q"]), nn_mode=sm.NN_NABO,
-                          max_iteration=15, early_exit=0, **opts)
+                          max_iteration=15, early_exit=0, no_fused_sums=1, **opts)
         for s in range(len(guesses)):
             m.set_input_source(velo20k["src"], slot=s); m.set_input_target(velo20k["q"], velo20k["n"], slot=s)
         R, sc, st = m.align_batch(len(guesses), guesses)
         m.close()
         out[name] = (np.asarray(R).tobytes(), [s["kept"] for s in st])
     assert out["certify"] == out["no_certify"]
+
+
+@pytest.mark.parametrize("rho", [0.7, 0.4])
+def test_fused_sums_in_the_reference_search_mode(velo20k, cfg1, cfg2, rho):
+    """nn_mode NABO with the fused path (nn_certify_acc<., true>: traversal certificates + the sums below the predicted quantile
+    band in one pass; accumulate_listed: the walked queries by the same rule and the check of the prediction) against the same
+    ragged batch with certificate pass and accumulate kept apart: 18 pairs of three sizes, NaN points in some, early exit on --
+    the same iteration counts, kept sets and quantiles, poses to 1e-10."""
+    import staticmapping_amd as sm
+    from staticmapping_amd import synth
+    cases = [cfg2, velo20k, cfg1] * 6
+    cap_s = max(len(c["src"]) for c in cases); cap_t = max(len(c["q"]) for c in cases)
+    guesses = [c.get("guess", np.eye(4)) @ synth.make_pose(t=(0.01 * (k % 3), 0.0, 0.0), rpy_deg=(0, 0, 0.03 * (k % 4))) for k, c in enumerate(cases)]
+    out = {}
+    for name, opts in (("separate", dict(no_fused_sums=1)), ("fused", dict())):
+        m = sm.IcpFastHip(pair_slots=len(cases), max_source_points=cap_s, max_target_points=cap_t, max_iteration=30, early_exit=1,
+                          dist_outlier_ratio=rho, nn_mode=sm.NN_NABO, **opts)
+        for s_, c in enumerate(cases):
+            src = np.array(c["src"], dtype=np.float32, copy=True)
+            if s_ % 5 == 1:
+                src[7, 0] = np.nan; src[100, 2] = np.inf
+            m.set_input_source(src, slot=s_); m.set_input_target(c["q"], c["n"], slot=s_)
+        out[name] = m.align_batch(len(cases), guesses)
+        m.close()
+    Rs, scs, sts = out["separate"]; Rf, scf, stf = out["fused"]
+    for s_ in range(len(cases)):
+        assert stf[s_]["iterations"] == sts[s_]["iterations"] and stf[s_]["kept"] == sts[s_]["kept"] and stf[s_]["limit_d2"] == sts[s_]["limit_d2"], (s_, stf[s_], sts[s_])
+        da, dt = sm.se3_error(Rf[s_], Rs[s_])
+        assert da < 1e-10 and dt < 1e-9, (s_, da, dt)
+        assert abs(scf[s_] - scs[s_]) < 1e-11
+        assert stf[s_]["searched_queries"] == sts[s_]["searched_queries"]
+    assert max(s_["fused_iterations"] for s_ in stf) > 0 and max(s_["fused_iterations"] for s_ in sts) == 0

@@ -93,7 +93,9 @@ typedef struct smhip_icp_options {
                                    Default 0: from split_after on ONE pass does both, summing the matches below a predicted band of
                                    histogram bins around the trimming quantile and leaving the band's members for the exact select
                                    (a missed prediction costs that pair one plain pass).  The same matches, distances and kept set
-                                   either way; the 29 sums are added in a different (fixed) order: poses agree to ~1e-12. */
+                                   either way; the 29 sums are added in a different (fixed) order: poses agree to ~1e-12.
+                                   SMHIP_NN_NABO has the same form (traversal certificates instead of distance bounds), from the
+                                   iteration on in which the previous batch's median pair walked fewer than a fifth of its queries. */
 } smhip_icp_options;
 
 /* Per-call statistics (all optional to read). */

@@ -43,6 +43,14 @@ def test_cpp_mirror_compiles_and_links():
     assert os.path.exists(_build_filters_exe())
 
 
+@pytest.mark.parametrize("name", ["test_back_end", "test_front_end", "test_mrvm", "test_registrator", "test_filters", "test_kitti_scans", "host_dry_run"])
+def test_every_cpp_program_compiles_without_a_gpu(name):
+    """The header-only C++ mirrors (registrator.h, back_end.h, front_end.h, mrvm.h, filters.h, kitti_scans.h) are compiled here
+    through every program of tests/cpp -- the GPU tests build and run them; a header that no longer compiles shows up on the CPU."""
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", name + ".cc")])
+
+
 @pytest.mark.gpu
 def test_cpp_filters_replay_the_reference_tests():
     """tests/cpp/test_filters.cc = the reference's five filter tests + the Factory chain, against include/smhip/filters.h"""

@@ -52,23 +52,16 @@ def algorithmic_bytes_per_alignment(ns: int, nt: int, iters: float = ICP_ITERS, 
     return 24.0 * nt + iters * ns * (12.0 + 8.0 + 24.0 * rho)
 
 
+def _device_id(torch, index: int) -> str:
+    p = torch.cuda.get_device_properties(index)
+    return f"{index}:{getattr(p, 'uuid', '')}:{getattr(p, 'pci_bus_id', '')}:{getattr(p, 'gcnArchName', p.name)}"
+
+
 def build_workload(n_distinct: int, n_points: int, device):
     """`n_distinct` consecutive scan pairs (i, i + 1) of the synthetic drive; scan i prepared as pair i's target by
     the caller-side CalculateNormals (builder/map_builder.cc:286,389)."""
-    import staticmapping_amd as sm
     from staticmapping_amd import synth
-    poses = synth.drive_poses(n_distinct + 2, seed=5, speed=8.0, speed_spread=2.0, yaw_rate_max=0.2, segment_s=1.0)
-    scene = synth.make_drive_scene(poses, seed=5)
-    scans = [synth.velodyne_scan(synth.scene_near(scene, P[:3, 3]), P, seed=500 + k, n_points=n_points, device=device)
-             for k, P in enumerate(poses[1:])]
-    rel = [np.linalg.inv(poses[k]) @ poses[k + 1] for k in range(len(poses) - 1)]     # rel[k]: scan k+1 -> scan k
-    pairs = []
-    for k in range(n_distinct):
-        q, n = sm.calculate_normals(scans[k][:, :3].astype(np.float64))
-        # pair k = (target scan k, source scan k + 1) of `scans`; its true motion is rel[k + 1], the motion one frame
-        # earlier (what a constant-velocity extrapolator predicts) is rel[k]
-        pairs.append(dict(src=scans[k + 1], q=q, n=n, T=rel[k + 1], guess_cv=rel[k], guess_id=np.eye(4)))
-    return pairs
+    return synth.drive_pairs(n_distinct, n_points, device, seed=5)
 
 
 def oracle_pose(w, guess, max_iteration, early_exit, nthreads=1, nn_eps=None):
@@ -135,6 +128,20 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # What the collective library actually saw: an all-reduce of ones over the communicator the poses are gathered on (its result IS
+    # the number of ranks that took part) and every rank's device, so that a multi-GPU line certifies itself.
+    coll = {"backend": None, "ranks_in_all_reduce": 1, "devices": [_device_id(torch, dev_index)]}
+    if dist.is_initialized():
+        ones = torch.ones(1, dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(ones)
+        got = [None] * world
+        dist.all_gather_object(got, (rank, _device_id(torch, dev_index)))
+        coll = {"backend": "gloo (shared-GPU dry run)" if shared_gpu else "nccl (RCCL)", "ranks_in_all_reduce": int(ones.item()),
+                "devices": [d for _, d in sorted(got)]}
+        assert coll["ranks_in_all_reduce"] == world, coll
+        if not shared_gpu:
+            assert len(set(coll["devices"])) == world, f"two ranks on one device: {coll['devices']}"
 
     B = args.pairs
     n_total = B * world
@@ -238,6 +245,12 @@ def main():
         dist.broadcast(t, 0)
         prof_class = int(t.item())
     head = timed_run(head_key, args.steps, args.warmup, profile_nn=prof_class)
+    by_rank = [(rank, prof_class, int(head["split"]))]
+    if world > 1:       # what every rank timed: the same kernel class (broadcast above) and where its library placed the search-form switch
+        got = [None] * world
+        dist.all_gather_object(got, by_rank[0])
+        by_rank = sorted(got)
+        assert len({c for _, c, _ in by_rank}) == 1, by_rank
     assert int(head["it"].min()) == ICP_ITERS == int(head["it"].max()), "a pair did not run exactly 20 iterations"
     elapsed, value, nn_prof = head["elapsed"], head["value"], head["prof"]
     h_rot, h_t, h_med = truth_errors(head["T"])
@@ -278,11 +291,16 @@ def main():
             # the reference's own search semantics: libnabo's tree + epsilon = 3.16 approximate knn on the device (nn_mode NABO)
             m.set_options(nn_mode=sm.NN_NABO, nn_epsilon=3.16)
             nb = timed_run("guess_cv", fs, fw)
+            if rank == 0:                        # where this mode's step goes: events around every launch of one untimed step
+                m.enable_profile(True)
+                m.enqueue_batch(B, nb["guesses"]); m.fetch_batch(B)
+                nb["prof_all"] = m.get_profile()
+                m.enable_profile(False)
             m.set_options(nn_mode=1 if args.nn_mode == "grid" else 0)
             n_rot, n_t, n_med = truth_errors(nb["T"])
             figures["reference_search_eps3.16"] = dict(value=round(nb["value"], 2), iterations=ICP_ITERS, searched_queries_per_alignment=searched(nb["stats"]),
                                                        worst_trans_err_vs_truth_m=n_t, median_trans_err_vs_truth_m=n_med, T=nb["T"], guess_key="guess_cv",
-                                                       max_iteration=ICP_ITERS, early_exit=False, nn_eps=3.16)
+                                                       max_iteration=ICP_ITERS, early_exit=False, nn_eps=3.16, prof_all=nb.get("prof_all"))
             figures["early_exit"] = dict(value=round(ee["value"], 2), iterations=float(ee["it"].mean()), iterations_max=int(ee["it"].max()),
                                          searched_queries_per_alignment=searched(ee["stats"]), split_after=ee["split"], worst_trans_err_vs_truth_m=e_t,
                                          median_trans_err_vs_truth_m=e_med, T=ee["T"], guess_key="guess_cv", max_iteration=100, early_exit=True)
@@ -318,6 +336,9 @@ def main():
             n_l = max(1, launches)
             avg_ms = ms / n_l
             pairs = int(round(pairs_sum / n_l))
+            if bytes_per_point is None:          # a kernel that handles a varying PART of the points: no per-launch byte figure, no fraction
+                return dict(total_ms=ms, launches=launches, avg_launch_ms=avg_ms, pairs_per_launch=pairs, bytes_per_point=None,
+                            bytes_per_launch=None, achieved=None)
             by = pairs * ns * bytes_per_point
             return dict(total_ms=ms, launches=launches, avg_launch_ms=avg_ms, pairs_per_launch=pairs, bytes_per_point=bytes_per_point,
                         bytes_per_launch=by, achieved=by / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0)
@@ -337,11 +358,13 @@ def main():
             if p["launches_nn_certify"] > 0:
                 kf[cert_name] = kernel_figures(p, p["ms_nn_certify"], p["launches_nn_certify"], p["pairs_nn_certify"], cert_bytes)
             if p["launches_nn_listed"] > 0:
-                kf["nn_ball_listed"] = kernel_figures(p, p["ms_nn_listed"], p["launches_nn_listed"], p["pairs_nn_listed"], 20.0)
+                # (the listed search finishes the ~2 % of the queries whose certificate failed: priced with the whole of FindClosests' 20 B/pt
+                # it read "51 % of the roofline"; it has no fraction of its own -- find_closests_per_iteration prices the iteration's search as a whole)
+                kf["nn_ball_listed"] = kernel_figures(p, p["ms_nn_listed"], p["launches_nn_listed"], p["pairs_nn_listed"], None)
             if p["launches_error_elements"] > 0:
                 # (fused path: most of these launches are the early-exit form, so the average says nothing about the kernel;
                 # the entry is kept for the time it takes per step)
-                kf["accumulate"] = kernel_figures(p, p["ms_error_elements"], p["launches_error_elements"], p["pairs_error_elements"], 24.0 * RHO)
+                kf["accumulate"] = kernel_figures(p, p["ms_error_elements"], p["launches_error_elements"], p["pairs_error_elements"], None if fused_on else 24.0 * RHO)
                 if fused_on:
                     kf["accumulate"]["mostly_early_exit_launches"] = True
             # FindClosests of one iteration as a whole: every launch that belongs to it, 20 B per source point once
@@ -364,13 +387,14 @@ def main():
         kf_timed, _ = all_kernels(nn_prof)
         kf_all, fc = all_kernels(prof)
         kf = {k: dict(kf_timed[k], timed=True) if k in kf_timed else dict(v, timed=False) for k, v in kf_all.items()}
-        dom = max((k for k in kf_timed if not kf_timed[k].get("mostly_early_exit_launches")), key=lambda k: kf_timed[k]["total_ms"])
+        cands = [k for k in kf_timed if kf_timed[k]["achieved"] is not None] or [k for k in kf if kf[k]["achieved"] is not None]
+        dom = max(cands, key=lambda k: kf[k]["total_ms"])
         nn_ms, pairs_per_launch, nn_bytes, achieved = (kf[dom][k] for k in ("avg_launch_ms", "pairs_per_launch", "bytes_per_launch", "achieved"))
         kf_alone, _ = all_kernels(alone)
         alone_f = kf_alone.get(dom, dict(avg_launch_ms=0.0, pairs_per_launch=0, achieved=0.0))
         alone_ms, alone_pairs, alone_gbs = alone_f["avg_launch_ms"], alone_f["pairs_per_launch"], alone_f["achieved"]
 
-        def traffic_of(kernel, pairs):
+        def traffic_of(kernel, pairs, scattered=False):
             """HBM bytes per launch from the committed counter passes (profiles/traffic_<kernel>.json: FETCH_SIZE / WRITE_SIZE passes
             of the same batch, corrected with the factors calibrated on known-byte kernels of the same access shape)."""
             tj = os.path.join(ROOT, "profiles", f"traffic_{kernel}.json")
@@ -379,7 +403,10 @@ def main():
             try:
                 tdat = json.load(open(tj))
                 if tdat.get("nn_mode") == args.nn_mode and tdat.get("source_points") in (None, ns):
-                    return int(tdat["hbm_bytes_per_launch"] * pairs / tdat["pairs_per_launch"])   # per point, so it scales with the pairs
+                    # scattered 32-64 B sectors (the listed search): the counters at factor 1, as the scatter calibration found
+                    # (profiles/r04_traffic_calibration.json calib_scatter); streaming shapes: FETCH_SIZE x 2
+                    key = "hbm_bytes_per_launch_uncorrected" if scattered and "hbm_bytes_per_launch_uncorrected" in tdat else "hbm_bytes_per_launch"
+                    return int(tdat[key] * pairs / tdat["pairs_per_launch"])   # per point, so it scales with the pairs
             except Exception:
                 pass
             return None
@@ -398,7 +425,9 @@ def main():
                        "pairs_per_gpu": B, "global_pairs_per_step": n_total, "distinct_pairs": D, "source_points": ns,
                        "target_points_mean": int(nt_mean), "iterations": ICP_ITERS, "nn_mode": args.nn_mode,
                        "grid_cell_m": args.cell, "guess": args.headline, "split_after": head["split"],
-                       "parallelism": f"pairs round-robin over {world} GPU(s), one RCCL gather of poses"},
+                       "parallelism": f"pairs round-robin over {world} GPU(s), one RCCL gather of poses",
+                       "rccl_ranks": coll["ranks_in_all_reduce"], "collective_backend": coll["backend"], "rank_devices": coll["devices"],
+                       "split_after_by_rank": [sp for _, _, sp in by_rank], "profiled_class_by_rank": [c for _, c, _ in by_rank]},
             "roofline": {"bound": "hbm", "kernel": dom,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -407,8 +436,10 @@ def main():
                          "ms_per_step_by_kernel": {k: round(v["total_ms"] / (args.steps if v["timed"] else 1), 3) for k, v in kf.items()},
                          "kernels": {k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "pairs_per_launch": v["pairs_per_launch"],
                                          "launches": v["launches"], "in_timed_region": v["timed"], "algorithmic_bytes_per_point": v["bytes_per_point"],
-                                         "algorithmic_bytes_per_launch": v["bytes_per_launch"], "achieved": round(v["achieved"], 2),
-                                         "frac": round(v["achieved"] / HBM_PEAK_GBS, 5), "traffic": traffic_of(k, v["pairs_per_launch"]),
+                                         "algorithmic_bytes_per_launch": v["bytes_per_launch"],
+                                         "achieved": None if v["achieved"] is None else round(v["achieved"], 2),
+                                         "frac": None if v["achieved"] is None else round(v["achieved"] / HBM_PEAK_GBS, 5),
+                                         "traffic": traffic_of(k, v["pairs_per_launch"], scattered=(k == "nn_ball_listed")),
                                          **({"mostly_early_exit_launches": True} if v.get("mostly_early_exit_launches") else {})}
                                      for k, v in kf.items()},
                          "fused_certificate_pass": {"on": bool(fused_on), "iterations_carried_mean": float(np.mean([s_["fused_iterations"] for s_ in head["stats"]])),
@@ -430,6 +461,7 @@ def main():
                          "alone": {"note": "same kernel on one stream, not sharing the GPU with the other half-batch",
                                    "pairs_per_launch": alone_pairs, "avg_launch_ms": round(alone_ms, 4),
                                    "achieved": round(alone_gbs, 2), "frac": round(alone_gbs / HBM_PEAK_GBS, 5)},
+                         "reference_search": _reference_search_roofline(figures.get("reference_search_eps3.16"), ns, nt_mean, B, world),
                          "shape_rate": _shape_rate(),
                          "whole_alignment": {"algorithmic_bytes": alg_bytes,
                                              "achieved_GBs": round(alg_bytes * value / world / 1e9, 2),
@@ -444,7 +476,7 @@ def main():
             out["parity"].update(par)
             if world == 1:
                 out["cpu_baseline"] = cpu
-        out["figures"] = {k: {kk: vv for kk, vv in f.items() if kk not in ("T", "guess_key", "max_iteration", "early_exit", "nn_eps")}
+        out["figures"] = {k: {kk: vv for kk, vv in f.items() if kk not in ("T", "guess_key", "max_iteration", "early_exit", "nn_eps", "prof_all")}
                           for k, f in figures.items()}
         for k, f in out["figures"].items():      # the same whole-alignment roofline for every figure (its own iteration count)
             by = algorithmic_bytes_per_alignment(ns, nt_mean, iters=float(f["iterations"]))
@@ -466,6 +498,32 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def _reference_search_roofline(f, ns, nt_mean, pairs_per_gpu, world):
+    """The reference's own search semantics (nn_mode NABO) against the same roofline: the whole alignment, and the kernel class the
+    step spends the most time in (events around every launch of one untimed step).  Classes: the full walk of iteration 0
+    (nn_nabo<4, false>, every query: 20 B/pt), the certificate pass (nn_certify<., true> / nn_certify_acc<., true>: 20 B/pt, + 24 rho
+    where it also sums), the list walk of the queries whose traversal certificate failed (nn_nabo<1, true>: priced with FindClosests'
+    20 B for every query it walks, from the per-alignment count of walked queries), accumulate."""
+    if not f or not f.get("prof_all"):
+        return None
+    p = f["prof_all"]
+    by = algorithmic_bytes_per_alignment(ns, nt_mean)
+    walked = max(0.0, f["searched_queries_per_alignment"] - ns)           # iterations >= 1 (iteration 0 walks every query)
+    cls = {"nn_nabo_full_walk": (p["ms_nn_main"], 20.0 * ns * p["pairs_nn_main"]),          # (pairs_*: pairs covered, summed over the class's launches)
+           "nn_certify": (p["ms_nn_certify"], 20.0 * ns * p["pairs_nn_certify"]),
+           "nn_nabo_list_walk": (p["ms_nn_listed"], 20.0 * walked * pairs_per_gpu),
+           "accumulate": (p["ms_error_elements"], None)}
+    dom = max(cls, key=lambda k: cls[k][0])
+    ms, bytes_step = cls[dom]
+    ach = None if bytes_step is None or ms <= 0 else bytes_step / (ms * 1e-3) / 1e9
+    return {"value": f["value"], "unit": "alignments/s", "whole_alignment_frac": round(by * f["value"] / world / 1e9 / HBM_PEAK_GBS, 5),
+            "kernel": dom, "kernel_ms_per_step": round(ms, 3), "kernel_bytes_per_step": bytes_step,
+            "achieved": None if ach is None else round(ach, 2), "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 5),
+            "walked_queries_per_alignment_after_iteration_0": walked,
+            "ms_per_step_by_class": {k: round(v[0], 3) for k, v in cls.items()} | {"refine_validate": round(p["ms_nn_refine"], 3), "finalize": round(p["ms_solve"], 3), "kd_build_and_grid": round(p["ms_prepare"], 3)},
+            "note": "nn_mode NABO: libnabo's tree + epsilon = 3.16 search on the device (icp_fast.cc:174, 464-467); one untimed step with HIP events around every launch"}
 
 
 def cpu_baseline_and_parity(work, figures, head, head_key, n_cpu, world):
@@ -500,11 +558,14 @@ def cpu_baseline_and_parity(work, figures, head, head_key, n_cpu, world):
         wr = wt = 0.0
         it_ok = True
         sub = list(range(0, D, max(1, D // 8)))[:8]
+        if f.get("nn_eps"):                      # the reference's own search: the figure inside north_star's tolerance of the reference -- 64 pairs
+            sub = list(range(min(D, 64)))
         if f["guess_key"] == "mixed":            # pairs of both kinds: even global index = extrapolated guess, odd = identity
             sub = [min(D - 1, d + (k % 2)) for k, d in enumerate(sub)]
+        many = cref.usable_cores() if len(sub) > 8 else 1
         for d in sub:
             gkey = ("guess_cv" if d % 2 == 0 else "guess_id") if f["guess_key"] == "mixed" else f["guess_key"]
-            ref = oracle_pose(work[d], work[d][gkey], f["max_iteration"], f["early_exit"], nn_eps=f.get("nn_eps"))
+            ref = oracle_pose(work[d], work[d][gkey], f["max_iteration"], f["early_exit"], nthreads=many, nn_eps=f.get("nn_eps"))
             da, dt = sm.se3_error(f["T"][d], ref["result"])
             wr, wt = max(wr, da), max(wt, dt)
         f["worst_rot_vs_oracle_rad"], f["worst_trans_vs_oracle_m"], f["pairs_checked_vs_oracle"] = wr, wt, len(sub)

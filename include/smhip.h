@@ -456,8 +456,9 @@ smhip_status smhip_mrvm_output(smhip_mrvm_handle h, float threshold, float* xyzi
 /* Both OutputToPointCloud overloads with MrvmSettings::output_average, .cc:125-216.  flags: SMHIP_MRVM_AVERAGE = one row per
  * voxel, the float mean of its stored points (summed in their order, divided by float(size)); its 4th column is the voxel's max
  * intensity, or 0 without use_max_intensity (the reference never assigns it).  SMHIP_MRVM_RGB = the PointXYZRGB overload: the
- * 4th column holds the bits of the packed colour r << 16 | g << 8 | b with r = g = b = min(255, uint32(max_intensity * 1.4))
- * (pcl::PointXYZRGB's `rgb` float). */
+ * 4th column holds the bits of the packed colour a << 24 | r << 16 | g << 8 | b with r = g = b = min(255, uint32(max_intensity * 1.4))
+ * and a = 255 (pcl::PointXYZRGB's `rgb` float; the reference assigns r, g, b only, so the alpha byte is what the PCL >= 1.8
+ * constructor puts there). */
 #define SMHIP_MRVM_AVERAGE 1
 #define SMHIP_MRVM_RGB 2
 smhip_status smhip_mrvm_output_ex(smhip_mrvm_handle h, float threshold, int flags, float* rows, int capacity, int* n_out);

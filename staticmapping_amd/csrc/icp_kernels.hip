@@ -2761,7 +2761,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
     constexpr int kL = 8;
     for (int e0 = threadIdx.x; e0 < nl; e0 += kL * 256) {
       int sg[kL], ii[kL], jj[kL];
-      float dd[kL], ll[kL];
+      float dd[kL];
       float4 s4[kL], q4[kL], n4[kL];
 #pragma unroll
       for (int k = 0; k < kL; ++k) sg[k] = 0;
@@ -2775,13 +2775,15 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
 #pragma unroll
       for (int k = 0; k < kL; ++k) ii[k] = dl[(size_t)sg[k] * (64 * kCertifyItems) + (min(e0 + 256 * k, nl - 1) - (int)s_off[sg[k]])];
 #pragma unroll
-      for (int k = 0; k < kL; ++k) { s4[k] = ld_src(b, so + ii[k]); jj[k] = b.idx[so + ii[k]]; dd[k] = b.d2[so + ii[k]]; ll[k] = b.lb[so + ii[k]]; }
+      for (int k = 0; k < kL; ++k) { s4[k] = ld_src(b, so + ii[k]); jj[k] = b.idx[so + ii[k]]; dd[k] = b.d2[so + ii[k]]; }
 #pragma unroll
       for (int k = 0; k < kL; ++k) { q4[k] = b.tq[to + max(jj[k], 0)]; n4[k] = b.tn[to + max(jj[k], 0)]; }
 #pragma unroll
       for (int k = 0; k < kL; ++k) {
         const uint32_t key = __float_as_uint(dd[k]);
-        if (e0 + 256 * k < nl && ll[k] > 0.f && jj[k] >= 0 && key < 0x7f800000u && (int)(key >> kHistShift) < band_lo)
+        // (a lower-bounded entry's d2 is its bound, whose bin nn_validate found above the quantile's, so above band_lo; an exact match
+        // with a coincident runner-up carries the bound 0 and is summed like any other, as `accumulate` does)
+        if (e0 + 256 * k < nl && jj[k] >= 0 && key < 0x7f800000u && (int)(key >> kHistShift) < band_lo)
           accumulate_terms(st->M, s4[k], q4[k], n4[k], dd[k], acc);
       }
     }

@@ -474,7 +474,7 @@ bool fused_iteration(const smhip_context* h, const Half& f, int ns_max, int iter
   if (iteration < 1 || iteration < d.split_after || !(h->opts.split_after > 0 || f.np >= 16)) return false;
   if (f.np > kListedMaxPairs) return false;
   // finalize's segment table: the certificate pass's waves + the listed search's items of a list nn_validate accepts
-  return ceil_div(ns_max, kNnThreads * kCertifyItems) * (kNnThreads / 64) + ceil_div(kFusedListedMax, kNnThreads) <= kFinalizeMaxSeg;
+  return ceil_div(ns_max, kNnThreads * kCertifyItems) * (kNnThreads / 64) + kListedMaxItems <= std::min(kFinalizeMaxSeg, (int)d.seg_stride);
 }
 
 smhip_status fill_inputs(smhip_context* h, int np, const double* guesses, int* ns_max, int* nt_max, int first = 0) {
@@ -514,9 +514,10 @@ void sync_options(smhip_context* h) {
   h->dev.band_pad = 0.1f; h->dev.band_gain = 1.5f;              // tuning only: results do not depend on the band, only how often it holds
   { const char* e = std::getenv("SMHIP_BAND_PAD"); if (e && std::atof(e) >= 0.0) h->dev.band_pad = (float)std::atof(e); }
   // lanes per query of the balanced listed search: measured flat from 1 024 to 8 192 (3.13-3.25 ms per step), slower beyond
-  // (16 384: 3.5, 32 768: 4.2).  At most 32 768: a pair's list is cut into at most budget / 512 items (finalize's segment table)
+  // (16 384: 3.5, 32 768: 4.2).  At most kListedLaneBudgetMax: a pair's list is cut into at most budget / 256 + 1 items
+  // (kListedMaxItems: finalize's segment table and the handle's seg_stride are sized for that)
   h->dev.listed_lane_budget = 4096;
-  { const char* e = std::getenv("SMHIP_LISTED_LANES"); if (e && std::atoi(e) >= 256) h->dev.listed_lane_budget = std::min(std::atoi(e), 32768); }
+  { const char* e = std::getenv("SMHIP_LISTED_LANES"); if (e && std::atoi(e) >= 256) h->dev.listed_lane_budget = std::min(std::atoi(e), kListedLaneBudgetMax); }
   h->split_share = 0.2f;
   { const char* e = std::getenv("SMHIP_SPLIT_SHARE"); if (e && std::atof(e) > 0.0) h->split_share = (float)std::atof(e); }
   h->dev.listed_grain = 1;
@@ -630,7 +631,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   // one segment per producing wave: accumulate with short chunks makes the most; the fused path has its certificate pass's waves
   // plus the listed search's
   d.seg_stride = std::max(d.acc_blocks * (kAccThreads / 64),
-                          ceil_div(max_source_points, kNnThreads * kCertifyItems) * (kNnThreads / 64) + kListedBlocks * (kNnThreads / 64));
+                          ceil_div(max_source_points, kNnThreads * kCertifyItems) * (kNnThreads / 64) + std::max(kListedBlocks * (kNnThreads / 64), kListedMaxItems) + 1);
   const size_t B = pair_slots, NS = max_source_points, NT = max_target_points;
   smhip_status s = SMHIP_OK;
   auto A = [&](smhip_status r) { if (s == SMHIP_OK) s = r; };

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void mrvm_update_counts(MrvmDev d, int n, cons
 }
 
 // OutputToPointCloud, :125-216.  flags bit 0 = settings_.output_average (one row per voxel: the float sums of the stored points in
-// their order, divided by float(size)), bit 1 = the PointXYZRGB overload (4th column = the bits of (g << 16 | g << 8 | g) with
+// their order, divided by float(size)), bit 1 = the PointXYZRGB overload (4th column = the bits of (255 << 24 | g << 16 | g << 8 | g) with
 // g = min(255, uint32(max_intensity * 1.4)), :181-186), else PointXYZI (4th column = the voxel's max intensity when
 // use_max_intensity, else the point's own -- 0 for an averaged point, whose intensity is never assigned, :148-151)
 __global__ __launch_bounds__(256) void mrvm_output(MrvmDev d, uint8_t thr, int use_max, int flags, float* xyzi, int capacity) {
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void mrvm_output(MrvmDev d, uint8_t thr, int u
     uint32_t g = (uint32_t)d.max_int[s];
     g = (uint32_t)((double)g * 1.4);                                          // intensity *= 1.4 on a uint32_t
     if (g > 255u) g = 255u;
-    grey = __uint_as_float((g << 16) | (g << 8) | g);
+    grey = __uint_as_float(0xff000000u | (g << 16) | (g << 8) | g);            // a = 255: what pcl::PointXYZRGB's constructor (PCL >= 1.8) leaves in the byte the reference never assigns
   }
   const uint32_t base = atomicAdd(&d.counters[3], average ? 1u : (uint32_t)c);
   if (average) {
@@ -300,6 +300,7 @@ struct smhip_mrvm_context {
   std::string err;
   int last_skipped = 0;                 // points of the last insert skipped for their coordinates
   size_t voxels = 0;                    // voxels in the table after the last insert
+  bool voxels_stale = false;            // an insert was started and did not reach the point where `voxels` is refreshed
   int max_table_log2 = 28;              // growth stops here (smhip_mrvm_set_max_table_log2)
   int growths = 0;
 };
@@ -441,6 +442,11 @@ smhip_status smhip_mrvm_insert_f32(smhip_mrvm_handle h, const float* points, int
   h->last_skipped = 0;
   MCHK(h, hipSetDevice(h->device));
   MCHK(h, hipStreamSynchronize(h->stream));
+  if (h->voxels_stale) {                                    // the previous insert ended early: its voxels are in the table, not in `voxels`
+    MCHK(h, hipMemcpy(h->counters_host, h->d.counters, 16, hipMemcpyDeviceToHost));
+    h->voxels = h->counters_host[1];
+  }
+  h->voxels_stale = true;
   mrvm_grow_for(h, n);                                      // room for the voxels this cloud can add, like the reference's std::map
   for (int i = 0; i < n; ++i) {
     const float* r = points + (size_t)stride_floats * i;
@@ -475,6 +481,7 @@ smhip_status smhip_mrvm_insert_f32(smhip_mrvm_handle h, const float* points, int
   // smhip_mrvm_last_error.  The same for a table that is getting full.
   h->last_skipped = (int)h->counters_host[5];
   h->voxels = h->counters_host[1];
+  h->voxels_stale = false;
   if (h->counters_host[2] & 2u) {
     h->err = "voxel table full: at least one voxel of this or an earlier cloud was dropped (the rest was applied); the table could not grow "
              "(smhip_mrvm_set_max_table_log2, or device memory)";
@@ -486,7 +493,9 @@ smhip_status smhip_mrvm_insert_f32(smhip_mrvm_handle h, const float* points, int
 }
 
 smhip_status smhip_mrvm_set_max_table_log2(smhip_mrvm_handle h, int max_table_log2) {
-  if (!h || max_table_log2 < 10 || max_table_log2 > 28) return SMHIP_ERR_INVALID_ARGUMENT;
+  if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
+  if (max_table_log2 < 10 || max_table_log2 > 28) { h->err = "max_table_log2 must be in 10..28"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  h->err.clear();
   h->max_table_log2 = max_table_log2;
   return SMHIP_OK;
 }
@@ -499,7 +508,8 @@ int smhip_mrvm_table_log2(smhip_mrvm_handle h) {
 }
 
 smhip_status smhip_mrvm_voxel_count(smhip_mrvm_handle h, int* n) {
-  if (!h || !n) return SMHIP_ERR_INVALID_ARGUMENT;
+  if (!h || !n) { if (h) h->err = "null output pointer"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  h->err.clear();
   MCHK(h, hipSetDevice(h->device));
   MCHK(h, hipMemcpyAsync(h->counters_host, h->d.counters, 16, hipMemcpyDeviceToHost, h->stream));
   MCHK(h, hipStreamSynchronize(h->stream));
@@ -508,7 +518,9 @@ smhip_status smhip_mrvm_voxel_count(smhip_mrvm_handle h, int* n) {
 }
 
 smhip_status smhip_mrvm_output_ex(smhip_mrvm_handle h, float threshold, int flags, float* rows, int capacity, int* n_out) {
-  if (!h || !n_out || (capacity > 0 && !rows) || (flags & ~3)) return SMHIP_ERR_INVALID_ARGUMENT;
+  if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
+  if (!n_out || (capacity > 0 && !rows) || (flags & ~3)) { h->err = "output: null pointer or unknown flag"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  h->err.clear();                                           // (an insert's warning text does not outlive the next call)
   MCHK(h, hipSetDevice(h->device));
   float* dev = nullptr;
   if (capacity > 0) MCHK(h, hipMalloc((void**)&dev, sizeof(float) * 4 * (size_t)capacity));
@@ -537,7 +549,9 @@ smhip_status smhip_mrvm_last_skipped(smhip_mrvm_handle h, int* n) {
 }
 
 smhip_status smhip_mrvm_dump(smhip_mrvm_handle h, int32_t* keys3, uint8_t* prob, int32_t* max_intensity, int32_t* npoints, float* points5, int capacity, int* n_out) {
-  if (!h || !n_out || capacity < 1 || !keys3 || !prob || !max_intensity || !npoints || !points5) return SMHIP_ERR_INVALID_ARGUMENT;
+  if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
+  if (!n_out || capacity < 1 || !keys3 || !prob || !max_intensity || !npoints || !points5) { h->err = "dump: null pointer or no capacity"; return SMHIP_ERR_INVALID_ARGUMENT; }
+  h->err.clear();
   MCHK(h, hipSetDevice(h->device));
   const size_t C = (size_t)capacity, P = (size_t)h->d.maxp;
   int32_t *dk = nullptr, *dm = nullptr, *dn = nullptr; uint8_t* dp = nullptr; float* dq = nullptr;

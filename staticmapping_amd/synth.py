@@ -323,3 +323,23 @@ def three_planes_pair(n_points: int = 5000, seed: int = 1, sigma: float = 0.01):
     src = src_in_tgt @ Ti[:3, :3].T + Ti[:3, 3]
     f = lambda p: np.concatenate([p, np.zeros((p.shape[0], 1))], axis=1).astype(np.float32)
     return f(tgt), f(src), T_true
+
+
+def drive_pairs(n_pairs: int, n_points: int = 120_000, device=None, seed: int = 5):
+    """`n_pairs` consecutive scan pairs (i, i + 1) of the synthetic drive (SURVEY.md 8(d) cfg 4: 10 Hz, speed 6-10 m/s, yaw rate
+    +-0.2 rad/s); scan i prepared as pair i's target by the caller-side CalculateNormals (builder/map_builder.cc:286, 389).
+    Each entry: src (the 120 k-point scan i + 1), q / n (target points / normals of scan i), T (true motion), guess_cv (the motion
+    one frame earlier: what a constant-velocity extrapolator supplies, map_builder.cc:302-308), guess_id (identity)."""
+    from .matcher import calculate_normals
+    poses = drive_poses(n_pairs + 2, seed=seed, speed=8.0, speed_spread=2.0, yaw_rate_max=0.2, segment_s=1.0)
+    scene = make_drive_scene(poses, seed=seed)
+    scans = [velodyne_scan(scene_near(scene, P[:3, 3]), P, seed=500 + k, n_points=n_points, device=device)
+             for k, P in enumerate(poses[1:])]
+    rel = [np.linalg.inv(poses[k]) @ poses[k + 1] for k in range(len(poses) - 1)]     # rel[k]: scan k+1 -> scan k
+    pairs = []
+    for k in range(n_pairs):
+        q, n = calculate_normals(scans[k][:, :3].astype(np.float64))
+        # pair k = (target scan k, source scan k + 1) of `scans`; its true motion is rel[k + 1], the motion one frame
+        # earlier (what a constant-velocity extrapolator predicts) is rel[k]
+        pairs.append(dict(src=scans[k + 1], q=q, n=n, T=rel[k + 1], guess_cv=rel[k], guess_id=np.eye(4)))
+    return pairs

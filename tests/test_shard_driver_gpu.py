@@ -116,3 +116,6 @@ def test_bench_runs_its_multi_rank_sequence_to_the_end(tmp_path):
     assert d["parity"]["worst_trans_err_vs_truth_m"] < 0.05
     assert "cpu_baseline" not in d                           # the CPU legs are a one-GPU report
     assert set(d["figures"]) >= {"extrapolated_guess", "identity_guess", "reference_search_eps3.16", "early_exit"}
+    # the line certifies what the collective library saw: an all-reduce of ones over the communicator counted both ranks
+    assert d["config"]["rccl_ranks"] == 2 and len(d["config"]["rank_devices"]) == 2 and len(d["config"]["split_after_by_rank"]) == 2
+    assert len(set(d["config"]["profiled_class_by_rank"])) == 1

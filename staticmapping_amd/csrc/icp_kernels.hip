@@ -1237,6 +1237,283 @@ __global__ __launch_bounds__(kNnThreads, 5) void nn_ball_lds(IcpDev b, int nblk)
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// nn_ball_wave: the search of the iterations in which (nearly) every query searches, one WAVE per 64 Morton-consecutive
+// queries, every candidate broadcast to the whole wave.
+//
+// nn_ball_lds gives every query its own walk over the rows of its ball: ~50 vector instructions of bookkeeping per row
+// visited and a candidate loop whose trip count is the wave's longest run, per row -- a wave pays the sum over row steps of
+// the maxima.  Counted on the bench scans (64 consecutive queries, 0.3 m balls, 0.25 m cells): a lane has 35 candidates in 6
+// occupied rows of its own, the wave executes ~54 candidate steps + 7.5 row steps + staging and compaction, ~1 900 vector
+// instructions per 64 queries in all (SQ_INSTS_VALU).  The bounding box of the wave's balls holds 110 target points (median
+// 89) in 11 occupied rows of 49.  So here the WAVE walks that box once: lane r looks up the run of row r (two dependent loads
+// for all rows at a time instead of per row and query), the runs' points are copied -- coalesced, every lane a point -- into
+// the wave's own LDS strip as PAIRS {x0 x1 y0 y1 | z0 z1 j0 j1}, and all 64 lanes test pair after pair from two broadcast
+// reads with packed fp32 arithmetic: 6 v_pk instructions for two squared distances + 4 per candidate for (nearest, runner-
+// up, position) = 7 vector instructions per candidate, no per-query bookkeeping, no divergence, no workgroup barrier -- the
+// four waves of a workgroup only share the histogram.  (First built with the candidates fetched by SCALAR loads into SGPR
+// operands -- no LDS at all: 2 x slower than nn_ball_lds; the scalar cache serves a few loads at a time and every wave sat
+// waiting for it.)
+//
+// Same results as the per-query walks: candidates are met in ascending sorted position (rows in (z, y) order, a row's run in
+// x order), so the tie rule holds; a point outside a query's own cube is farther than its radius, so it neither becomes the
+// match of an exact query nor lowers min(runner-up, radius).  Only the SEED a lower-bounded query keeps (the nearest point
+// seen, all of them beyond the radius) can be another point -- it only sizes a later search.
+__device__ __forceinline__ void listed_append_hard(const IcpDev& b, PairState* st, size_t so, bool hard, int i, int lane);
+constexpr int kWaveBoxRows = 1024;        // grid rows of a wave's box it walks cooperatively; beyond: every lane walks its own ball
+constexpr int kWaveCand = 256;            // candidates a wave stages per pass (4 KiB of LDS per wave)
+
+// one query's own walk, lookups from global memory (nn_ball's loop): the fallback for a wave whose queries are far apart
+__device__ __forceinline__ void lane_ball_search(const uint2* __restrict__ words, const uint32_t* __restrict__ cstart, const float4* __restrict__ tq,
+                                                 float ox, float oy, float oz, float h, int ny, int wx, float qx, float qy, float qz, float R2,
+                                                 int x0, int x1, int y0, int y1, int z0, int z1, Best& best) {
+  const float slack = 2.0e-3f * h;
+  for (int z = z0; z <= z1; ++z) {
+    const float zl = oz + (float)z * h;
+    const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + h)) - slack, 0.f);
+    for (int y = y0; y <= y1; ++y) {
+      const float yl = oy + (float)y * h;
+      const float dy = fmaxf(fmaxf(yl - qy, qy - (yl + h)) - slack, 0.f);
+      if (fmaf(dy, dy, dz * dz) > R2) continue;            // the row lies outside the ball
+      uint32_t sb, se;
+      row_slots(words, (z * ny + y) * wx, x0, x1, sb, se);
+      if (se > sb) {
+        const uint32_t j0 = cstart[sb], j1 = cstart[se];
+        for (uint32_t j = j0; j < j1; ++j) test_ascending_ru(tq[j], (int)j, qx, qy, qz, best);
+      }
+    }
+  }
+}
+// a staged pair against the lane's query: dist2's expression on both halves at once (v_pk_add / mul / fma_f32), then the
+// sweep's update for the first and the second (ascending positions: strict "<")
+__device__ __forceinline__ void test_pair_ru(const float4 a, const float4 c, float qx, float qy, float qz, Best& best) {
+  const f32x2 dx = (f32x2){qx, qx} - (f32x2){a.x, a.y};
+  const f32x2 dy = (f32x2){qy, qy} - (f32x2){a.z, a.w};
+  const f32x2 dz = (f32x2){qz, qz} - (f32x2){c.x, c.y};
+  f32x2 d = dx * dx;
+  d = __builtin_elementwise_fma(dy, dy, d);
+  d = __builtin_elementwise_fma(dz, dz, d);
+  best.s2 = __builtin_amdgcn_fmed3f(d.x, best.d2, best.s2);
+  if (d.x < best.d2) { best.d2 = d.x; best.j = __float_as_int(c.z); }
+  best.s2 = __builtin_amdgcn_fmed3f(d.y, best.d2, best.s2);
+  if (d.y < best.d2) { best.d2 = d.y; best.j = __float_as_int(c.w); }
+}
+
+template <int ITEMS, bool FIRST>
+__global__ __launch_bounds__(kNnThreads) void nn_ball_wave(IcpDev b, int nblk) {
+  int pair, blk;
+  if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  const int ns = st->ns;
+  const int base0 = blk * (kNnThreads * ITEMS);
+  if (base0 >= ns) return;
+  double Mc[12];                         // read before the first store: scalar loads, held in SGPRs (see nn_ball_lds)
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Mc[k] = st->M[k];
+  const Pot pot = {(float)st->pot_a, (float)st->pot_b, (float)st->step_a, (float)st->step_b};
+  const float Mtx = (float)Mc[3], Mty = (float)Mc[7], Mtz = (float)Mc[11];
+  __shared__ uint32_t s_hist[kHistBins];
+  __shared__ float4 s_cand[kNnThreads / 64][kWaveCand];          // per wave: kWaveCand / 2 pairs of two float4
+  __shared__ uint32_t s_roff[kNnThreads / 64][64];               // per wave: candidates before row r of the current 64 rows
+  __shared__ uint32_t s_rbase[kNnThreads / 64][64];              //           sorted position of the row's first point, less that
+  __shared__ uint32_t s_nsearch;
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+  if (threadIdx.x == 0) s_nsearch = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4* cand = s_cand[wave];
+  uint32_t* roff = s_roff[wave];
+  uint32_t* rbase = s_rbase[wave];
+  const size_t so = (size_t)pair * b.ns_cap;
+  const uint2* __restrict__ words = b.words + (size_t)pair * kMaxGridWords;
+  const uint32_t* __restrict__ cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
+  const float4* __restrict__ tq = b.tq + (size_t)pair * b.nt_cap;
+  const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
+  const float h = st->h, inv_h = st->inv_h;
+  const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
+  const float r2cap = st->rcap2;
+  const float r_need = 0.9f * sqrtf(r2cap);
+  const bool have_prev = !FIRST && st->iter > 0;
+  const bool certify = have_prev && b.certify;
+  uint32_t min_lb = 0xffffffffu;
+  uint32_t nsearch = 0;
+
+  int i = base0 + threadIdx.x;
+  float4 s_cur = make_float4(0, 0, 0, 0);
+  int jp_cur = -1;
+  float l_cur = 0.f;
+  if (i < ns) {
+    s_cur = ld_src(b, so + i);
+    if (have_prev) { jp_cur = b.idx[so + i]; if (certify) l_cur = ld_lb(b, so + i); }
+  }
+  for (int it = 0; it < ITEMS; ++it) {
+    const int base = base0 + it * kNnThreads;
+    if (base >= ns) break;                               // block-uniform
+    i = base + threadIdx.x;
+    const int i_next = i + kNnThreads;                   // the next round's streamed values, a round ahead
+    float4 s_next = make_float4(0, 0, 0, 0);
+    int jp_next = -1;
+    float l_next = 0.f;
+    if (it + 1 < ITEMS && i_next < ns) {
+      s_next = ld_src(b, so + i_next);
+      if (have_prev) { jp_next = b.idx[so + i_next]; if (certify) l_next = ld_lb(b, so + i_next); }
+    }
+    // ---- every lane: query, previous match, certificate (as nn_ball_lds's phase C)
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    bool valid = false;
+    if (i < ns) {
+      double px, py, pz;
+      transform_point(Mc, s_cur, px, py, pz);
+      qx = (float)px; qy = (float)py; qz = (float)pz;
+      valid = isfinite(qx) && isfinite(qy) && isfinite(qz);
+    }
+    const bool has_jp = valid && jp_cur >= 0;
+    float dub2 = INFINITY;
+    if (has_jp) dub2 = dist2(tq[jp_cur], qx, qy, qz);
+    bool need_search = valid, hard = false;
+    if (i < ns && !valid) {                                // NaN / inf input: no match
+      b.d2[so + i] = INFINITY; b.idx[so + i] = -1; st_lb(b, so + i, 0.f);
+    }
+    float R2 = r2cap;
+    if (!FIRST) {
+      const float sn = __builtin_amdgcn_sqrtf(fmaf(s_cur.z, s_cur.z, fmaf(s_cur.y, s_cur.y, s_cur.x * s_cur.x)));
+      const float delta = have_prev ? fmaf(pot.sa, sn, pot.sb) : 0.03f;
+      if (certify && valid) {
+        const float Lp = bound_now(l_cur, pot_at(pot, sn));
+        if (Lp > 0.f) {
+          if (l_cur > 0.f && has_jp && dub2 < Lp * Lp) {     // still the unique nearest neighbour: exact, no search
+            b.d2[so + i] = dub2;
+            atomicAdd(&s_hist[__float_as_uint(dub2) >> kHistShift], 1u);
+            need_search = false;
+          } else if (l_cur < 0.f && Lp >= r_need) {          // still provably beyond the trimming radius
+            const float lb2 = Lp * Lp;
+            b.d2[so + i] = lb2;
+            atomicAdd(&s_hist[__float_as_uint(lb2) >> kHistShift], 1u);
+            min_lb = min(min_lb, __float_as_uint(lb2));
+            hard = true;
+            need_search = false;
+          }
+        }
+      }
+      if (has_jp) R2 = search_radius2(r2cap, dub2, search_margin(delta));
+      listed_append_hard(b, st, so, hard, i, lane);          // lower-bounded lanes keep their place in the hard list
+    }
+    const unsigned long long sm = __ballot(need_search);
+    if (sm) {                                              // wave-uniform
+      nsearch += (uint32_t)__popcll(sm);
+      int x0 = 1, x1 = 0, y0 = 1, y1 = 0, z0 = 1, z1 = 0;
+      if (need_search) {
+        const float Rs = __builtin_amdgcn_sqrtf(R2) * 1.0001f + 1.0e-3f * h;
+        x0 = max(cell_coord(qx - Rs, ox, inv_h), 0); x1 = min(cell_coord(qx + Rs, ox, inv_h), nx - 1);
+        y0 = max(cell_coord(qy - Rs, oy, inv_h), 0); y1 = min(cell_coord(qy + Rs, oy, inv_h), ny - 1);
+        z0 = max(cell_coord(qz - Rs, oz, inv_h), 0); z1 = min(cell_coord(qz + Rs, oz, inv_h), nz - 1);
+      }
+      const bool inbox = need_search && x0 <= x1 && y0 <= y1 && z0 <= z1;
+      const int big = 0x3fffffff;
+      const int X0 = wave_min_i(inbox ? x0 : big), X1 = wave_max_i(inbox ? x1 : -big);
+      const int Y0 = wave_min_i(inbox ? y0 : big), Y1 = wave_max_i(inbox ? y1 : -big);
+      const int Z0 = wave_min_i(inbox ? z0 : big), Z1 = wave_max_i(inbox ? z1 : -big);
+      Best best = {INFINITY, -1, INFINITY};
+      if (X0 <= X1) {                                      // some ball meets the grid
+        const int nyl = Y1 - Y0 + 1;
+        const long long nrows_ll = (long long)nyl * (Z1 - Z0 + 1);
+        if (nrows_ll <= kWaveBoxRows) {
+          const int nrows = (int)nrows_ll;
+          const float inv_nyl = 1.0f / (float)nyl;
+          for (int r0 = 0; r0 < nrows; r0 += 64) {         // 64 rows of the box at a time, one per lane
+            const int r = r0 + lane;
+            uint32_t j0 = 0, len = 0;
+            if (r < nrows) {
+              const int zz = (int)(((float)r + 0.5f) * inv_nyl);     // r / nyl (r < 1024: exact via float)
+              const int y = Y0 + (r - zz * nyl), z = Z0 + zz;
+              uint32_t sb, se;
+              row_slots(words, (z * ny + y) * wx, X0, X1, sb, se);
+              if (se > sb) { j0 = cstart[sb]; len = cstart[se] - j0; }
+            }
+            const uint32_t incl = wave_incl_scan(len, lane);
+            const int N = __builtin_amdgcn_readlane((int)incl, 63);
+            if (N == 0) continue;                          // wave-uniform
+            roff[lane] = incl - len;
+            rbase[lane] = j0 - (incl - len);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int p0 = 0; p0 < N; p0 += kWaveCand) {    // the rows' points in ascending sorted position, kWaveCand per pass
+              const int cnt = min(kWaveCand, N - p0);
+              // copy: flat candidate k of the 64 rows sits in the last row whose offset is <= k (empty rows share their successor's)
+#pragma unroll
+              for (int m = 0; m < kWaveCand / 64; ++m) {
+                if (64 * m >= cnt) break;                  // wave-uniform
+                const int c = lane + 64 * m;
+                const uint32_t k = (uint32_t)(p0 + min(c, cnt - 1));
+                int rho = 0;
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) rho = roff[min(rho + step, 63)] <= k && rho + step < 64 ? rho + step : rho;
+                const uint32_t j = rbase[rho] + k;
+                const float4 t = tq[j];
+                if (c < cnt) {
+                  float* o = reinterpret_cast<float*>(cand + 2 * (c >> 1)) + (c & 1);
+                  o[0] = t.x; o[2] = t.y; o[4] = t.z; o[6] = __int_as_float((int)j);
+                }
+              }
+              if ((cnt & 1) && lane == 0) {                // an odd pass: the last pair's second half is a point at infinity
+                float* o = reinterpret_cast<float*>(cand + 2 * (cnt >> 1)) + 1;
+                o[0] = 3.0e38f; o[2] = 0.f; o[4] = 0.f; o[6] = __int_as_float(-1);
+              }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              const int npair = (cnt + 1) >> 1;
+#pragma unroll 4
+              for (int pp = 0; pp < npair; ++pp) test_pair_ru(cand[2 * pp], cand[2 * pp + 1], qx, qy, qz, best);
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+        } else if (inbox) {
+          lane_ball_search(words, cstart, tq, ox, oy, oz, h, ny, wx, qx, qy, qz, R2, x0, x1, y0, y1, z0, z1, best);
+        }
+      }
+      bool hard2 = false;
+      if (need_search) {
+        float d2out, lbout;
+        int jout;
+        if (best.d2 <= R2) {                  // exact: everything within sqrt(R2) was seen
+          d2out = best.d2;
+          jout = best.j;
+          lbout = __builtin_amdgcn_sqrtf(fminf(best.s2, R2));  // every other point is at least this far
+        } else {                              // certified lower bound
+          d2out = R2;
+          jout = best.j >= 0 ? best.j : jp_cur;
+          lbout = -__builtin_amdgcn_sqrtf(R2);
+          hard2 = true;
+          min_lb = min(min_lb, __float_as_uint(R2));
+        }
+        b.d2[so + i] = d2out;
+        b.idx[so + i] = jout;
+        {   // |s| as nn_ball_lds's search lanes take it (from the moved point: M is rigid), so that the record has the same bits
+          const float ux = qx - Mtx, uy = qy - Mty, uz = qz - Mtz;
+          st_lb(b, so + i, with_pot(lbout, pot_at(pot, __builtin_amdgcn_sqrtf(fmaf(uz, uz, fmaf(uy, uy, ux * ux))))));
+        }
+        const uint32_t key = __float_as_uint(d2out);
+        if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
+      }
+      listed_append_hard(b, st, so, hard2, i, lane);
+    }
+    s_cur = s_next; jp_cur = jp_next; l_cur = l_next;
+  }
+  if (lane == 0 && nsearch) atomicAdd(&s_nsearch, nsearch);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) min_lb = min(min_lb, (uint32_t)__shfl_xor((int)min_lb, off, 64));
+  if (lane == 0 && min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_nsearch) atomicAdd(&st->deferred_count, s_nsearch);      // statistics only
+  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
+    const uint32_t v = s_hist[k];
+    if (v) atomicAdd(&gh[k], v);
+  }
+}
+
 // a run of the sorted target tested with the explicit tie rule, four independent loads in flight per lane (one load per
 // trip left every candidate a full memory latency: 400 us for the first ring of 120 k queries against a dense submap)
 __device__ __forceinline__ void sweep_run_any(const float4* __restrict__ tq, uint32_t j0, uint32_t j1,
@@ -1870,23 +2147,13 @@ __device__ __forceinline__ void block_reduce29(double* acc, double (*s_red)[29],
   __syncthreads();
 }
 
+// One block (kAccThreads * ITEMS source points) of a pair's ErrorElements / ComputePointToPlane sums with the quantile's bin known:
+// row `blk` of partials, the bin's members as records in the block's four wave segments.
 template <int ITEMS>
-__global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
-  int pair, blk;
-  if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
-  PairState* st = &b.state[pair];
-  if (st->done) return;
-  if (b.fused && st->spec_ok) return;    // the fused certificate pass + the listed search's epilogue already hold this iteration's sums
+__device__ __forceinline__ void accumulate_block(const IcpDev& b, PairState* st, int pair, int blk, const double* Mc,
+                                                 uint32_t* s_w, uint32_t* s_q, double (*s_red)[29], double* s_out) {
   const int ns = st->ns;
   const int base = blk * (kAccThreads * ITEMS);
-  if (base >= ns) return;
-  double Mc[12];                         // read before the first store: scalar loads, held in SGPRs (see nn_ball_lds)
-#pragma unroll
-  for (int k = 0; k < 12; ++k) Mc[k] = st->M[k];
-  __shared__ uint32_t s_w[17];
-  __shared__ uint32_t s_q[4];
-  __shared__ double s_red[4][29];
-  __shared__ double s_out[29];
   find_quantile_bin(b.hist + (size_t)pair * kHistBins, b.rho, s_w, s_q);
   const uint32_t qbin = s_q[0];
   double acc[29];
@@ -1951,6 +2218,24 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
   if ((threadIdx.x & 63) == 0) b.gcount[(size_t)pair * b.seg_stride + seg] = (uint32_t)wcount;
   block_reduce29(acc, s_red, s_out);
   if (threadIdx.x < 29) b.partials[((size_t)pair * b.part_stride + blk) * kAccCols + threadIdx.x] = s_out[threadIdx.x];
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
+  int pair, blk;
+  if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  if (b.fused && st->spec_ok) return;    // the fused certificate pass + the listed search's epilogue already hold this iteration's sums
+  if (blk * (kAccThreads * ITEMS) >= st->ns) return;
+  double Mc[12];                         // read before the first store: scalar loads, held in SGPRs (see nn_ball_lds)
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Mc[k] = st->M[k];
+  __shared__ uint32_t s_w[17];
+  __shared__ uint32_t s_q[4];
+  __shared__ double s_red[4][29];
+  __shared__ double s_out[29];
+  accumulate_block<ITEMS>(b, st, pair, blk, Mc, s_w, s_q, s_red, s_out);
 }
 
 
@@ -2456,6 +2741,115 @@ __global__ __launch_bounds__(kNnThreads, 5) void nn_ball_listed_items(IcpDev b) 
   if (cur >= 0) flush();
 }
 
+// Fused iterations: the sums the certificate pass could not make, as ONE launch of a fixed grid of kSumsBlocks workgroups.
+//  * A pair whose prediction held (spec_ok): the queries whose certificate failed this iteration (the per-wave segments of dlist the
+//    fused pass left, dcount) have exact matches from the listed search now; those below the band are kept whatever the quantile
+//    turns out to be inside it -- summed here, kListedSumChunk entries per work item, four per thread and round with their loads
+//    issued level by level, into row nblk + item of partials.  (Lower-bounded ones lie above the quantile: nn_validate checked that,
+//    or the iteration would not be in this form; an exact match with a coincident runner-up carries the bound 0 and is summed like
+//    any other, as `accumulate` does.)  This was a phase of finalize -- one workgroup per pair walking 2 500 to 16 000 entries.
+//  * A pair whose prediction missed: the plain `accumulate` of its every block (accumulate_block).  This was a standing launch of
+//    `accumulate` per iteration, 3 840 workgroups of which all but a few pairs' returned at once.
+// Workgroup id & 7 = XCD: it takes work of the pairs whose index in the launch has that residue, like xcd_block.
+__device__ __forceinline__ void listed_sums_block(const IcpDev& b, PairState* st, int pair, int item, uint32_t* s_off, double (*s_red)[29], double* s_out) {
+  const int ns = st->ns;
+  const int nblk = (ns + kNnThreads * kCertifyItems - 1) / (kNnThreads * kCertifyItems);
+  const int nseg0 = nblk * (kNnThreads / 64);
+  const int32_t* dc = b.dcount + (size_t)pair * b.seg_stride;      // (listed_plan: entries before each segment, the total behind them)
+  const int32_t* dl = b.dlist + (size_t)pair * b.dl_stride;
+  int top = 1;
+  while (2 * top < nseg0) top *= 2;
+  for (int x = threadIdx.x; x < 2 * top; x += kAccThreads) s_off[x] = x < nseg0 ? (uint32_t)dc[x] : 0xffffffffu;
+  const int nl = dc[nseg0];
+  __syncthreads();
+  const int band_lo = st->band_lo;
+  const size_t so = (size_t)pair * b.ns_cap, to = (size_t)pair * b.nt_cap;
+  double acc[29];
+#pragma unroll
+  for (int c = 0; c < 29; ++c) acc[c] = 0.0;
+  // (a work item is long -- 16 entries per thread -- because it ends with a 29-column block reduction that costs as much as 8 entries
+  // per thread; four entries per thread and round)
+  constexpr int kL = 4;
+  const int e_end = min(nl, (item + 1) * kListedSumChunk);
+  for (int e0 = item * kListedSumChunk + (int)threadIdx.x; e0 < e_end; e0 += kL * kAccThreads) {
+    int sg[kL], ii[kL], jj[kL];
+    float dd[kL];
+    float4 s4[kL], q4[kL], n4[kL];
+#pragma unroll
+    for (int k = 0; k < kL; ++k) sg[k] = 0;
+    for (int step = top; step > 0; step >>= 1) {
+#pragma unroll
+      for (int k = 0; k < kL; ++k) {
+        const int cand = sg[k] + step;
+        sg[k] = s_off[cand] <= (uint32_t)min(e0 + kAccThreads * k, e_end - 1) ? cand : sg[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kL; ++k) ii[k] = dl[(size_t)sg[k] * (64 * kCertifyItems) + (min(e0 + kAccThreads * k, e_end - 1) - (int)s_off[sg[k]])];
+#pragma unroll
+    for (int k = 0; k < kL; ++k) { s4[k] = ld_src(b, so + ii[k]); jj[k] = b.idx[so + ii[k]]; dd[k] = b.d2[so + ii[k]]; }
+#pragma unroll
+    for (int k = 0; k < kL; ++k) { q4[k] = b.tq[to + max(jj[k], 0)]; n4[k] = b.tn[to + max(jj[k], 0)]; }
+#pragma unroll
+    for (int k = 0; k < kL; ++k) {
+      const uint32_t key = __float_as_uint(dd[k]);
+      if (e0 + kAccThreads * k < e_end && jj[k] >= 0 && key < 0x7f800000u && (int)(key >> kHistShift) < band_lo)
+        accumulate_terms(st->M, s4[k], q4[k], n4[k], dd[k], acc);
+    }
+  }
+  block_reduce29(acc, s_red, s_out);
+  if (threadIdx.x < 29) b.partials[((size_t)pair * b.part_stride + nblk + item) * kAccCols + threadIdx.x] = s_out[threadIdx.x];
+}
+
+// ITEMS = points per thread of a missed pair's blocks (IcpDev::sums_items).  A block is a chain of dependent rounds and the launch
+// lasts as long as its longest workgroup, so once only a few pairs miss (the band predictions hold from the third fused iteration
+// on) the blocks are the short ones: an 8 192-point block takes ~40 us with the GPU nearly empty, a 2 048-point one ~12.  While most
+// pairs still miss (no prediction yet, or a band of more than three bins) the long ones: a block's 29-column reduction and quantile
+// look-up cost as much as 8 points per thread.
+template <int ITEMS>
+__global__ __launch_bounds__(kAccThreads) void iteration_sums(IcpDev b) {
+  __shared__ uint32_t s_w[17];
+  __shared__ uint32_t s_q[4];
+  __shared__ double s_red[4][29];
+  __shared__ double s_out[29];
+  __shared__ uint32_t s_plan[kListedMaxPairs / 8 + 1];       // work items before the k-th pair of this XCD
+  __shared__ uint32_t s_off[2 * kFinalizeMaxSeg];
+  const int x = (int)blockIdx.x & 7, lw = (int)blockIdx.x >> 3, nlw = (int)gridDim.x >> 3;
+  const int npx = (b.npairs - x + 7) >> 3;                    // this XCD's pairs: x, x + 8, ... of the launch (<= kListedMaxPairs / 8)
+  {
+    uint32_t mine = 0;
+    if ((int)threadIdx.x < npx) {
+      const PairState* st = &b.state[b.pair_base + (int)threadIdx.x * 8 + x];
+      if (!st->done) {
+        if (st->spec_ok) mine = (st->deferred_count + (uint32_t)kListedSumChunk - 1u) / (uint32_t)kListedSumChunk;
+        else mine = (uint32_t)((st->ns + kAccThreads * ITEMS - 1) / (kAccThreads * ITEMS));
+      }
+    }
+    uint32_t total;
+    const uint32_t o = block_excl_scan(mine, s_w, &total);
+    if ((int)threadIdx.x < npx) s_plan[threadIdx.x] = o;
+    if (threadIdx.x == 0) s_plan[npx] = total;
+    __syncthreads();
+  }
+  const int nitems = (int)s_plan[npx];
+  int lo = 0;
+  for (int item = lw; item < nitems; item += nlw) {           // workgroup-uniform
+    while (s_plan[lo + 1] <= (uint32_t)item) ++lo;
+    const int pair = b.pair_base + lo * 8 + x;
+    PairState* st = &b.state[pair];
+    const int k = item - (int)s_plan[lo];
+    if (st->spec_ok) {
+      listed_sums_block(b, st, pair, k, s_off, s_red, s_out);
+    } else {
+      double Mc[12];
+#pragma unroll
+      for (int c = 0; c < 12; ++c) Mc[c] = st->M[c];
+      accumulate_block<ITEMS>(b, st, pair, k, Mc, s_w, s_q, s_red, s_out);
+    }
+    __syncthreads();
+  }
+}
+
 // Reference-search mode, fused path: the queries the list walk (nn_nabo<., true>) has just matched again, by the fused pass's
 // rule -- a match below the predicted band is summed, a match inside it becomes a record -- once the histogram is complete and
 // nabo_validate has checked the prediction (the quantile's bin inside the band: this mode's nn_validate; spec_ok also tells
@@ -2704,12 +3098,13 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   // partials hold the sums below that bin, its waves' segments the bin's members.  Fused (b.fused and nn_validate's spec_ok):
   // the certificate pass summed its certified matches below a PREDICTED band of bins that does contain the quantile's -- rows
   // [0, nblk) -- and left records of the band's members; the listed search left records of the band's members among the
-  // matches it found, and those of its matches that lie below the band are summed here (the listed phase below).  Either
+  // matches it found, and those of its matches that lie below the band were summed by iteration_sums (rows behind nblk).  Either
   // way a record carries all finalize needs (source point, d2, match), the records' order is fixed by the data alone, and
   // what is added from them is every record at or below the exact quantile: the band's lower bins entirely, the quantile's
   // bin up to the selected value.
   const bool fusedm = b.fused && st->spec_ok;
-  const int chunk = fusedm ? kNnThreads * kCertifyItems : kAccThreads * b.acc_items;
+  // (a fused iteration's missed pairs were summed by iteration_sums in short blocks, whatever the batch's accumulate launches use)
+  const int chunk = fusedm ? kNnThreads * kCertifyItems : kAccThreads * ((b.fused && !b.fused_nabo) ? b.sums_items : b.acc_items);
   const int nblk = (ns + chunk - 1) / chunk;
   const int nseg0 = nblk * 4;                                   // 4 waves per workgroup in both producers
   const int seg_len0 = chunk / 4;
@@ -2719,7 +3114,9 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   constexpr int kNaboSegs = kNaboAccBlocks * (kAccThreads / 64);
   const int nseg = nseg0 + (fusedm ? (nabof ? kNaboSegs : (int)b.litems[pair]) : 0);
   const int seg_len1 = nabof ? b.bl_stride / kNaboSegs : kNnThreads >> listed_lanes_log2((int)st->deferred_count, b.listed_lane_budget);
-  const int nrows = nblk + (nabof ? kNaboAccBlocks : 0);
+  // rows of partials behind the certificate pass's: reference-search mode: accumulate_listed's workgroups; else the listed matches
+  // below the band, summed by iteration_sums kListedSumChunk entries per row (deferred_count = the length of the pair's list)
+  const int nrows = nblk + (fusedm ? (nabof ? kNaboAccBlocks : (int)((st->deferred_count + (uint32_t)kListedSumChunk - 1u) / (uint32_t)kListedSumChunk)) : 0);
   const uint32_t* gcount = b.gcount + (size_t)pair * b.seg_stride;
   const float4* ra = b.rec_a + (size_t)pair * 2 * b.bl_stride;
   const int32_t* rj = b.rec_j + (size_t)pair * 2 * b.bl_stride;
@@ -2743,52 +3140,6 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   double acc[29];
 #pragma unroll
   for (int c = 0; c < 29; ++c) acc[c] = 0.0;
-  if (fusedm && !nabof && n_valid > 0) {
-    // Listed phase: the queries whose certificate failed this iteration (the per-wave segments of dlist the fused pass left,
-    // dcount) have exact matches from the listed search now; those below the band are kept whatever the quantile turns out to
-    // be inside it -- summed here, eight entries per thread and round with their loads issued level by level.  (Lower-bounded
-    // ones lie above the quantile: nn_validate checked that, or the iteration would not be in this form.)
-    const int32_t* dc = b.dcount + (size_t)pair * b.seg_stride;      // (listed_plan: entries before each segment, the total behind them)
-    const int32_t* dl = b.dlist + (size_t)pair * b.dl_stride;
-    int top = 1;
-    while (2 * top < nseg0) top *= 2;
-    for (int x = threadIdx.x; x < 2 * top; x += 256) s_off[x] = x < nseg0 ? (uint32_t)dc[x] : 0xffffffffu;
-    const uint32_t total = (uint32_t)dc[nseg0];
-    __syncthreads();
-    const int nl = (int)total;
-    const int band_lo = st->band_lo;
-    const size_t so = (size_t)pair * b.ns_cap, to = (size_t)pair * b.nt_cap;
-    constexpr int kL = 8;
-    for (int e0 = threadIdx.x; e0 < nl; e0 += kL * 256) {
-      int sg[kL], ii[kL], jj[kL];
-      float dd[kL];
-      float4 s4[kL], q4[kL], n4[kL];
-#pragma unroll
-      for (int k = 0; k < kL; ++k) sg[k] = 0;
-      for (int step = top; step > 0; step >>= 1) {
-#pragma unroll
-        for (int k = 0; k < kL; ++k) {
-          const int cand = sg[k] + step;
-          sg[k] = s_off[cand] <= (uint32_t)min(e0 + 256 * k, nl - 1) ? cand : sg[k];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < kL; ++k) ii[k] = dl[(size_t)sg[k] * (64 * kCertifyItems) + (min(e0 + 256 * k, nl - 1) - (int)s_off[sg[k]])];
-#pragma unroll
-      for (int k = 0; k < kL; ++k) { s4[k] = ld_src(b, so + ii[k]); jj[k] = b.idx[so + ii[k]]; dd[k] = b.d2[so + ii[k]]; }
-#pragma unroll
-      for (int k = 0; k < kL; ++k) { q4[k] = b.tq[to + max(jj[k], 0)]; n4[k] = b.tn[to + max(jj[k], 0)]; }
-#pragma unroll
-      for (int k = 0; k < kL; ++k) {
-        const uint32_t key = __float_as_uint(dd[k]);
-        // (a lower-bounded entry's d2 is its bound, whose bin nn_validate found above the quantile's, so above band_lo; an exact match
-        // with a coincident runner-up carries the bound 0 and is summed like any other, as `accumulate` does)
-        if (e0 + 256 * k < nl && jj[k] >= 0 && key < 0x7f800000u && (int)(key >> kHistShift) < band_lo)
-          accumulate_terms(st->M, s4[k], q4[k], n4[k], dd[k], acc);
-      }
-    }
-    __syncthreads();                                       // s_off is reused for the record segments below
-  }
   SMHIP_FPH();
   uint32_t limit_key = 0;
   int nb = 0;

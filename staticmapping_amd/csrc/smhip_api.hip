@@ -69,6 +69,10 @@ struct smhip_context {
   int hist_mode = 0;             // nn_mode of the batch whose searched-query history is waiting in hist_pinned
   int nabo_fused_from = 6;       // reference-search mode: the first iteration of a batch that runs the fused certificate pass (fused_iteration)
   float split_share = 0.2f;      // auto split: the first iteration whose median searched share falls below this runs certify + listed search
+  int sums_blocks = kSumsBlocks;  // workgroups of iteration_sums (SMHIP_SUMS_BLOCKS)
+  int sums_long_for = 3;         // fused iterations of a batch whose missed pairs iteration_sums cuts into long blocks (SMHIP_SUMS_LONG_FOR)
+  int wave_search = 0;           // batches: the every-query-searches iterations through nn_ball_lds (0, default: 5-25 % faster on the bench scans)
+                                 // or nn_ball_wave (1; SMHIP_WAVE_SEARCH=1) -- same results
   float4* stage = nullptr;       // pinned staging for uploads, 2 * max(ns_cap, nt_cap)
   uint32_t* done_pinned = nullptr;
   // split_after = 0: where the batched iterations switch from the fused search to certify + listed search follows the
@@ -187,6 +191,7 @@ struct Half {
   hipStream_t stream;
   int np;
   bool small = false;      // few workgroups per launch: use the single-round NN / short-chunk accumulate variants
+  int first_fused = -1;    // the first iteration of this Align that ran the fused path
 };
 
 // the ICP iteration kernels stream the 12-byte copy of the sources: repacked here (main stream, the PairInput rows already
@@ -392,6 +397,10 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
         if (f.small) {
           const int nb1 = ceil_div(ns_max, kNnThreads);
           hipLaunchKernelGGL(nn_ball_lds<1>, dim3(nb1 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nb1);
+        } else if (h->wave_search) {
+          // a wave per 64 queries walks the box of its balls once, candidates from SGPRs (nn_ball_wave)
+          if (iteration == 0) hipLaunchKernelGGL((nn_ball_wave<kBallItems, true>), gx, dim3(kNnThreads), 0, st, d, nblk);
+          else hipLaunchKernelGGL((nn_ball_wave<kBallItems, false>), gx, dim3(kNnThreads), 0, st, d, nblk);
         } else {
           hipLaunchKernelGGL(nn_ball_lds<kBallItems>, gx, dim3(kNnThreads), 0, st, d, nblk);
         }
@@ -520,6 +529,12 @@ void sync_options(smhip_context* h) {
   { const char* e = std::getenv("SMHIP_LISTED_LANES"); if (e && std::atoi(e) >= 256) h->dev.listed_lane_budget = std::min(std::atoi(e), kListedLaneBudgetMax); }
   h->split_share = 0.2f;
   { const char* e = std::getenv("SMHIP_SPLIT_SHARE"); if (e && std::atof(e) > 0.0) h->split_share = (float)std::atof(e); }
+  h->sums_long_for = 3;
+  { const char* e = std::getenv("SMHIP_SUMS_LONG_FOR"); if (e) h->sums_long_for = std::atoi(e); }
+  h->wave_search = 0;
+  { const char* e = std::getenv("SMHIP_WAVE_SEARCH"); if (e) h->wave_search = std::atoi(e); }
+  h->sums_blocks = kSumsBlocks;
+  { const char* e = std::getenv("SMHIP_SUMS_BLOCKS"); if (e && std::atoi(e) >= 8) h->sums_blocks = (std::min(std::atoi(e), 65536) / 8) * 8; }
   h->dev.listed_grain = 1;
   { const char* e = std::getenv("SMHIP_LISTED_GRAIN"); if (e && std::atoi(e) >= 0) h->dev.listed_grain = std::atoi(e); }
   { const char* e = std::getenv("SMHIP_BAND_GAIN"); if (e && std::atof(e) >= 0.0) h->dev.band_gain = (float)std::atof(e); }
@@ -625,7 +640,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   d.acc_blocks = ceil_div(max_source_points, kAccThreads * kAccItemsSmall);
   d.acc_items = kAccItemsSmall;
   // rows of partials: accumulate's workgroups, or the fused certificate pass's plus accumulate_listed's (reference-search mode)
-  d.part_stride = std::max(d.acc_blocks, ceil_div(max_source_points, kNnThreads * kCertifyItems) + kNaboAccBlocks);
+  d.part_stride = std::max(d.acc_blocks, ceil_div(max_source_points, kNnThreads * kCertifyItems) + std::max(kNaboAccBlocks, kFusedListedMax / kListedSumChunk));
   d.dl_stride = ceil_div(max_source_points, kNnThreads * kCertifyItems) * (kNnThreads * kCertifyItems);
   d.bl_stride = std::max(ceil_div(max_source_points, kAccThreads * kAccItemsBatch) * (kAccThreads * kAccItemsBatch), d.dl_stride);
   // one segment per producing wave: accumulate with short chunks makes the most; the fused path has its certificate pass's waves
@@ -641,7 +656,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, const_cast<float**>(&d.src3), B * NS * 3));
   A(dev_alloc(h, const_cast<float4**>(&d.tgt_p), B * NT));
   A(dev_alloc(h, const_cast<float4**>(&d.tgt_n), B * NT));
-  A(dev_alloc(h, &d.tq, B * NT));
+  A(dev_alloc(h, &d.tq, B * NT + 8));        // (+ 8: nn_ball_wave's scalar loads read up to seven rows past a run's end)
   A(dev_alloc(h, &d.tn, B * NT));
   A(dev_alloc(h, &d.tcell, B * NT));
   A(dev_alloc(h, &d.tslot, B * NT));
@@ -1187,12 +1202,26 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
       Half& f = halves[k];
       f.d.fused = fused_iteration(h, f, ns_max, it) ? 1 : 0;     // every launch of this iteration and part sees the same flag
       f.d.fused_nabo = f.d.fused && h->opts.nn_mode == SMHIP_NN_NABO ? 1 : 0;
+      if (f.d.fused && !f.d.fused_nabo) {
+        // A band needs two quantiles: the iteration after the first has none, so no pair's sums can come from the fused pass -- the
+        // plain accumulate launch for all of them (fused = 0 for the sums only would change what finalize expects: keep the flag,
+        // it reads spec_ok = 0).  The next `sums_long_for` fused iterations most predictions still miss (the quantile moves by more
+        // than a bin): long blocks; after that short ones (iteration_sums).
+        f.first_fused = f.first_fused < 0 ? it : f.first_fused;
+        f.d.sums_items = (it - f.first_fused < h->sums_long_for && f.d.acc_items == kAccItemsBatch) ? kAccItemsBatch : kAccItemsSmall;
+        if (it < 2) f.d.sums_items = f.d.acc_items;
+      }
       s = enqueue_find_closests_half(h, f, ns_max, it);
       if (s) return s;
       {
         Bracket br(h, 2, f.stream, f.np);
         const int nblk = ceil_div(ns_max, kAccThreads * f.d.acc_items);
-        if (f.d.acc_items == kAccItemsBatch) hipLaunchKernelGGL(accumulate<kAccItemsBatch>, dim3(nblk * 8 * ceil_div(f.np, 8)), dim3(kAccThreads), 0, f.stream, f.d, nblk);
+        if (f.d.fused && !f.d.fused_nabo && it >= 2) {
+          // fused iteration: only the pairs whose prediction missed need `accumulate`, the others the sums of their listed matches --
+          // one fixed grid that takes both kinds of work (iteration_sums) instead of nblk workgroups per pair that look at a flag
+          if (f.d.sums_items == kAccItemsBatch) hipLaunchKernelGGL(iteration_sums<kAccItemsBatch>, dim3(h->sums_blocks), dim3(kAccThreads), 0, f.stream, f.d);
+          else hipLaunchKernelGGL(iteration_sums<kAccItemsSmall>, dim3(h->sums_blocks), dim3(kAccThreads), 0, f.stream, f.d);
+        } else if (f.d.acc_items == kAccItemsBatch) hipLaunchKernelGGL(accumulate<kAccItemsBatch>, dim3(nblk * 8 * ceil_div(f.np, 8)), dim3(kAccThreads), 0, f.stream, f.d, nblk);
         else hipLaunchKernelGGL(accumulate<kAccItemsSmall>, dim3(nblk * 8 * ceil_div(f.np, 8)), dim3(kAccThreads), 0, f.stream, f.d, nblk);
       }
       { Bracket br(h, 3, f.stream); hipLaunchKernelGGL(finalize, dim3(f.np), dim3(256), 0, f.stream, f.d); }

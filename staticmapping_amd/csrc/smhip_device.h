@@ -41,6 +41,8 @@ constexpr int kFusedListedMax = 16384;   // fused path: with more failing certif
 // most work items listed_plan can cut a pair's list into (= record segments of region 1 finalize has to index): a list of `count`
 // entries searched with L lanes each (L * count <= the budget, or L = 1) makes ceil(count * L / 256) items
 constexpr int kListedMaxItems = (kFusedListedMax / kNnThreads > kListedLaneBudgetMax / kNnThreads ? kFusedListedMax / kNnThreads : kListedLaneBudgetMax / kNnThreads) + 1;
+constexpr int kListedSumChunk = 4096;    // fused path: listed queries per work item of iteration_sums (a row of partials each: at most kFusedListedMax / this)
+constexpr int kSumsBlocks = 768;         // its workgroups (a multiple of 8; 3 per CU: 164 VGPRs)
 constexpr int kCertifyItems = 20;        // rounds per workgroup of the certificate pass: its per-workgroup costs (histogram zero + flush, pipeline fill) are
                                          // large next to a round's -- 8: 80, 12: 57, 16: 57, 20: 49, 24: 48, 28: 52, 32: 53 us per 64 pairs (120 k points)
 
@@ -135,6 +137,7 @@ struct IcpDev {
   int32_t listed_grain;      // items a workgroup of nn_ball_listed_items claims at a time (0: equal runs fixed in advance)
   float band_gain;           // ... and this many times the quantile's last move (default 1.5)
   int32_t acc_items;         // points per thread of the accumulate launches of this batch part (finalize folds accordingly)
+  int32_t sums_items;        // fused iterations: points per thread of the blocks iteration_sums cuts a missed pair into (this launch)
   PairState* state;
   const PairInput* in;
   const float4* src;         // [slots][ns_cap] raw source xyz, w = caller index bits (uploads, the prep / filter / NDT / GICP kernels)

@@ -589,3 +589,49 @@ def test_fused_sums_in_a_ragged_batch(smhip, velo20k, cfg1, cfg2, rho):
         assert abs(scf[s_] - scs[s_]) < 1e-11
     if rho < 1.0:
         assert max(s_["fused_iterations"] for s_ in stf) > 0                 # the fused form did carry iterations
+
+
+@pytest.mark.parametrize("iters", [1, 6])
+def test_wave_search_equals_the_per_query_walks(smhip, velo20k, cfg1, cfg2, iters, monkeypatch):
+    """nn_ball_wave (a wave walks the box of its 64 queries' balls once, candidates from SGPRs) against nn_ball_lds (every query
+    walks its own ball, lookups staged in LDS): a ragged batch of 18 pairs from good, poor and exact guesses, NaN points in some,
+    every iteration through the search kernel (split_after = -1).  The same distances bit for bit, the same match wherever the
+    match is exact (a lower-bounded query only keeps a seed, which may be another point), the same kept sets, quantiles and
+    poses (icp_fast.cc:169-180, 484-523)."""
+    sm = smhip
+    from staticmapping_amd import synth
+    cases = [cfg2, velo20k, cfg1] * 6
+    cap_s = max(len(c["src"]) for c in cases); cap_t = max(len(c["q"]) for c in cases)
+    guesses = []
+    for k, c in enumerate(cases):
+        g = [c.get("guess", np.eye(4)), np.eye(4), c["T"]][(k // 3) % 3]
+        guesses.append(g @ synth.make_pose(t=(0.01 * (k % 3), 0.0, 0.0), rpy_deg=(0, 0, 0.03 * (k % 4))))
+    out = {}
+    for name, env in (("lds", "0"), ("wave", "1")):
+        monkeypatch.setenv("SMHIP_WAVE_SEARCH", env)
+        m = sm.IcpFastHip(pair_slots=len(cases), max_source_points=cap_s, max_target_points=cap_t, max_iteration=iters, early_exit=0, split_after=-1)
+        for s_, c in enumerate(cases):
+            src = np.array(c["src"], dtype=np.float32, copy=True)
+            if s_ % 5 == 1:
+                src[7, 0] = np.nan; src[100, 2] = np.inf
+            m.set_input_source(src, slot=s_); m.set_input_target(c["q"], c["n"], slot=s_)
+        R, sc, st = m.align_batch(len(cases), guesses)
+        matches = [m.get_matches(len(c["src"]), slot=s_) for s_, c in enumerate(cases)]
+        m.close()
+        out[name] = (R, sc, st, matches)
+    monkeypatch.delenv("SMHIP_WAVE_SEARCH")
+    Rl, scl, stl, ml = out["lds"]; Rw, scw, stw, mw = out["wave"]
+    for s_ in range(len(cases)):
+        assert stw[s_]["iterations"] == stl[s_]["iterations"] == iters
+        assert stw[s_]["kept"] == stl[s_]["kept"] and stw[s_]["limit_d2"] == stl[s_]["limit_d2"], (s_, stw[s_], stl[s_])
+        assert Rw[s_].tobytes() == Rl[s_].tobytes() and scw[s_] == scl[s_], s_
+        (il, dl), (iw, dw) = ml[s_], mw[s_]
+        # a lower-bounded query (nothing within the radius searched: its d2 is that radius squared, above the quantile) keeps a SEED,
+        # which may be another point, and with it the radius of its next search: everything at or below the quantile is identical
+        lim = stl[s_]["limit_d2"]
+        kl, kw = dl <= lim, dw <= lim
+        assert np.array_equal(kl, kw), s_
+        assert dl[kl].tobytes() == dw[kl].tobytes() and il[kl].tobytes() == iw[kl].tobytes(), s_
+        if iters == 1:                                       # one search from the same state: the same bits everywhere but the seeds
+            assert dl.tobytes() == dw.tobytes(), (s_, int((dl != dw).sum()))
+        assert (il != iw).mean() < 0.3

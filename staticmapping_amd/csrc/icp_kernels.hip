@@ -440,6 +440,32 @@ __device__ __forceinline__ float4 ld_src(const IcpDev& b, size_t k) {
 }
 __device__ __forceinline__ float ld_lb(const IcpDev& b, size_t k) { return b.lb[k]; }
 __device__ __forceinline__ void st_lb(const IcpDev& b, size_t k, float v) { b.lb[k] = v; }
+// The 4-byte shadow of (match, bound): bits [14:0] the match (0x7fff: none), [31:15] the bound as a 17-bit float -- sign, 4 exponent
+// bits (2^-10 .. 2^3 m; 0 = the value zero, below a millimetre: "unknown"), 12 mantissa bits TRUNCATED, so its magnitude is never
+// above the recorded one (a smaller bound certifies less, never wrongly) and at most 2^-13 below it.  (An IEEE half -- 10 mantissa
+// bits -- made 0.8 % more certificates fail, those of far points, whose records carry metres of motion potential and whose
+// searches are the long ones: the listed search took 17 % longer.)
+__device__ __forceinline__ uint32_t pack_match(int j, float lbv) {
+  const uint32_t u = __float_as_uint(lbv), a0 = u & 0x7fffffffu;
+  uint32_t code = 0;
+  if (a0 >= 0x3a800000u) {                                   // >= 2^-10
+    const uint32_t a = min(a0, 0x417ff800u);                 // < 16
+    code = ((u >> 31) << 16) | (((a >> 23) - 116u) << 12) | ((a >> 11) & 0xfffu);
+  }
+  return (code << 15) | (uint32_t)(j < 0 || j >= 0x7fff ? 0x7fff : j);
+}
+__device__ __forceinline__ float shadow_bound(uint32_t m) {
+  const uint32_t e = (m >> 27) & 0xfu;
+  const uint32_t bits = ((m >> 31) << 31) | ((e + 116u) << 23) | (((m >> 15) & 0xfffu) << 11);
+  return e ? __uint_as_float(bits) : 0.f;
+}
+__device__ __forceinline__ int shadow_match(uint32_t m) { const int j = (int)(m & 0x7fffu); return j == 0x7fff ? -1 : j; }
+// a query's match and certificate bound: the two arrays every kernel reads, and their 4-byte shadow (IcpDev::mb)
+__device__ __forceinline__ void st_match(const IcpDev& b, size_t k, int j, float lbv) {
+  b.idx[k] = j;
+  b.lb[k] = lbv;
+  b.mb[k] = pack_match(j, lbv);
+}
 // certificate bounds are stored with the pair's motion potential at the time of the search added (PairState::pot_a / pot_b)
 struct Pot { float a, b, sa, sb; };
 __device__ __forceinline__ float norm3(float x, float y, float z) { return sqrtf(fmaf(z, z, fmaf(y, y, x * x))); }
@@ -648,8 +674,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball(IcpDev b, int nblk) {
         }
       }
       b.d2[so + i] = d2out;
-      b.idx[so + i] = jout;
-      st_lb(b, so + i, with_pot(lbout, pot_at(pot, norm3(s4.x, s4.y, s4.z))));
+      st_match(b, so + i, jout, with_pot(lbout, pot_at(pot, norm3(s4.x, s4.y, s4.z))));
       const uint32_t key = __float_as_uint(d2out);
       if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
     }
@@ -998,7 +1023,7 @@ __global__ __launch_bounds__(kNnThreads, 5) void nn_ball_lds(IcpDev b, int nblk)
     if (has_jp) dub2 = dist2(tq[jp_cur], qx, qy, qz);
     bool need_search = valid, hard = false;
     if (i < ns && !valid) {                                // NaN / inf input: no match
-      b.d2[so + i] = INFINITY; b.idx[so + i] = -1; st_lb(b, so + i, 0.f);
+      b.d2[so + i] = INFINITY; st_match(b, so + i, -1, 0.f);
     }
     // (|s| and the other roots of this kernel by the hardware instruction, 1 ulp: each feeds a bound that bound_now / the cell
     // block take with 1e-5 .. 1e-4 of relative slack; the IEEE sequence is ~13 instructions a root in a kernel bound by their issue)
@@ -1197,11 +1222,10 @@ __global__ __launch_bounds__(kNnThreads, 5) void nn_ball_lds(IcpDev b, int nblk)
       }
       SMHIP_PHASE(5);    // search
       b.d2[so + gi] = d2out;
-      b.idx[so + gi] = jout;
       // |s| of the query from its transformed position: M is rigid, so |s| = |q - t|
       {
         const float ux = qx - Mtx, uy = qy - Mty, uz = qz - Mtz;
-        st_lb(b, so + gi, with_pot(lbout, pot_at(pot, __builtin_amdgcn_sqrtf(fmaf(uz, uz, fmaf(uy, uy, ux * ux))))));
+        st_match(b, so + gi, jout, with_pot(lbout, pot_at(pot, __builtin_amdgcn_sqrtf(fmaf(uz, uz, fmaf(uy, uy, ux * ux))))));
       }
       const uint32_t key = __float_as_uint(d2out);
       if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
@@ -1373,7 +1397,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball_wave(IcpDev b, int nblk) {
     if (has_jp) dub2 = dist2(tq[jp_cur], qx, qy, qz);
     bool need_search = valid, hard = false;
     if (i < ns && !valid) {                                // NaN / inf input: no match
-      b.d2[so + i] = INFINITY; b.idx[so + i] = -1; st_lb(b, so + i, 0.f);
+      b.d2[so + i] = INFINITY; st_match(b, so + i, -1, 0.f);
     }
     float R2 = r2cap;
     if (!FIRST) {
@@ -1489,10 +1513,9 @@ __global__ __launch_bounds__(kNnThreads) void nn_ball_wave(IcpDev b, int nblk) {
           min_lb = min(min_lb, __float_as_uint(R2));
         }
         b.d2[so + i] = d2out;
-        b.idx[so + i] = jout;
         {   // |s| as nn_ball_lds's search lanes take it (from the moved point: M is rigid), so that the record has the same bits
           const float ux = qx - Mtx, uy = qy - Mty, uz = qz - Mtz;
-          st_lb(b, so + i, with_pot(lbout, pot_at(pot, __builtin_amdgcn_sqrtf(fmaf(uz, uz, fmaf(uy, uy, ux * ux))))));
+          st_match(b, so + i, jout, with_pot(lbout, pot_at(pot, __builtin_amdgcn_sqrtf(fmaf(uz, uz, fmaf(uy, uy, ux * ux))))));
         }
         const uint32_t key = __float_as_uint(d2out);
         if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
@@ -1607,8 +1630,7 @@ __device__ __forceinline__ void ring_body(const IcpDev& b, PairState* st, int pa
       }
     }
     b.d2[so + i] = best.d2;
-    b.idx[so + i] = best.j;
-    st_lb(b, so + i, 0.f);                 // exact match, but no runner-up information: searched again next time
+    st_match(b, so + i, best.j, 0.f);      // exact match, but no runner-up information: searched again next time
     if (resolved) {
       const uint32_t key = __float_as_uint(best.d2);
       if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
@@ -1759,8 +1781,7 @@ __global__ __launch_bounds__(kNnThreads) void nn_ring_coop(IcpDev b) {
     }
     if (live && sub == 0) {
       b.d2[so + i] = best.d2;
-      b.idx[so + i] = best.j;
-      st_lb(b, so + i, 0.f);
+      st_match(b, so + i, best.j, 0.f);
       if (resolved) {
         const uint32_t key = __float_as_uint(best.d2);
         if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
@@ -1975,8 +1996,7 @@ __device__ __forceinline__ void fallback_body(const IcpDev& b, PairState* st, in
     const unsigned long long key = __hip_atomic_load(&b.ukeys[so + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t dbits = (uint32_t)(key >> 32);
     b.d2[so + i] = __uint_as_float(dbits);
-    b.idx[so + i] = (int)(uint32_t)(key & 0xffffffffu);
-    st_lb(b, so + i, 0.f);
+    st_match(b, so + i, (int)(uint32_t)(key & 0xffffffffu), 0.f);
     if (dbits < 0x7f800000u) atomicAdd(&b.hist[(size_t)pair * kHistBins + (dbits >> kHistShift)], 1u);
   }
   if (threadIdx.x == 0) st->fallback_ticket = 0;
@@ -2269,7 +2289,10 @@ __device__ __forceinline__ void emit_record(const IcpDev& b, size_t segbase, int
   wcount += (int)__popcll(bm);
 }
 
-template <int ITEMS, bool NABO = false>
+// SHADOW = true: the bound and the match come from their 4-byte shadow (IcpDev::mb): 16 streamed bytes per point in instead of 20
+// (launches whose targets all have fewer than 32 767 points).  The shadow's bound is never larger than the recorded one, so a few
+// more certificates fail and are searched -- the matches, distances and kept set are the same.
+template <int ITEMS, bool NABO = false, bool SHADOW = false>
 __global__ __launch_bounds__(kNnThreads, NABO ? 4 : 1) void nn_certify_acc(IcpDev b, int nblk) {   // (NABO: 129 registers without the hint, one wave per SIMD less)
   int pair, blk;
   if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
@@ -2297,10 +2320,12 @@ __global__ __launch_bounds__(kNnThreads, NABO ? 4 : 1) void nn_certify_acc(IcpDe
   const char* __restrict__ srcb = reinterpret_cast<const char*>(b.src3 + 3 * so);
   const char* __restrict__ lbb = reinterpret_cast<const char*>(b.lb + so);
   const char* __restrict__ idxb = reinterpret_cast<const char*>(b.idx + so);
+  const char* __restrict__ mbb = reinterpret_cast<const char*>(b.mb + so);
   char* __restrict__ d2b = reinterpret_cast<char*>(b.d2 + so);
   auto ld_s = [&](int k) { const float3 v = *reinterpret_cast<const float3*>(srcb + (uint32_t)k * 12u); return make_float4(v.x, v.y, v.z, 0.f); };
   auto ld_l = [&](int k) { return *reinterpret_cast<const float*>(lbb + (uint32_t)k * 4u); };
   auto ld_j = [&](int k) { return *reinterpret_cast<const int*>(idxb + (uint32_t)k * 4u); };
+  auto ld_m = [&](int k) { return *reinterpret_cast<const uint32_t*>(mbb + (uint32_t)k * 4u); };
   auto ld_t = [&](const char* base, int j) { const float3 v = *reinterpret_cast<const float3*>(base + (uint32_t)max(j, 0) * 16u); return make_float4(v.x, v.y, v.z, 0.f); };
   auto st_d = [&](int k, float v) { *reinterpret_cast<float*>(d2b + (uint32_t)k * 4u) = v; };
   const float r_need = 0.9f * sqrtf(st->rcap2);     // a hard query's bound must stay well above the quantile
@@ -2317,12 +2342,15 @@ __global__ __launch_bounds__(kNnThreads, NABO ? 4 : 1) void nn_certify_acc(IcpDe
   // gathers of the previous match and its normal one round ahead (for every lane: seven in ten use both)
   int ic = min(base + (int)threadIdx.x, ns - 1);
   float4 s_1 = ld_s(ic);
-  float l_1 = ld_l(ic);
-  int j_1 = ld_j(ic);
+  float l_1, l_2;
+  int j_1, j_2;
+  uint32_t m_2 = 0;                                  // SHADOW: a round's packed (bound, match), unpacked when it becomes round 1
+  if (SHADOW) { const uint32_t m = ld_m(ic); l_1 = shadow_bound(m); j_1 = shadow_match(m); }
+  else { l_1 = ld_l(ic); j_1 = ld_j(ic); }
   ic = min(base + kNnThreads + (int)threadIdx.x, ns - 1);
   float4 s_2 = ld_s(ic);
-  float l_2 = ld_l(ic);
-  int j_2 = ld_j(ic);
+  if (SHADOW) { m_2 = ld_m(ic); l_2 = 0.f; j_2 = 0; }
+  else { l_2 = ld_l(ic); j_2 = ld_j(ic); }
   const bool summing = band_lo > 0;                 // no prediction: the normals are not needed, the pass only certifies
   float4 t_1 = ld_t(tqb, j_1);
   float4 n_1 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2334,13 +2362,15 @@ __global__ __launch_bounds__(kNnThreads, NABO ? 4 : 1) void nn_certify_acc(IcpDe
     const float l = l_1;
     const int j = j_1;
     const float4 t = t_1, n = n_1;
-    s_1 = s_2; l_1 = l_2; j_1 = j_2;
+    s_1 = s_2;
+    if (SHADOW) { l_1 = shadow_bound(m_2); j_1 = shadow_match(m_2); }
+    else { l_1 = l_2; j_1 = j_2; }
     if (it + 1 < ITEMS) { t_1 = ld_t(tqb, j_1); if (summing) n_1 = ld_t(tnb, j_1); }
     if (it + 2 < ITEMS) {
       ic = min(i + 2 * kNnThreads, ns - 1);
       s_2 = ld_s(ic);
-      l_2 = ld_l(ic);
-      j_2 = ld_j(ic);
+      if (SHADOW) m_2 = ld_m(ic);
+      else { l_2 = ld_l(ic); j_2 = ld_j(ic); }
     }
     float d1 = 0.f;
     if (i < ns) {
@@ -2520,8 +2550,7 @@ __device__ __forceinline__ void listed_search_one(const IcpDev& b, const PairSta
       }
     }
     b.d2[so + i] = d2out;
-    b.idx[so + i] = jout;
-    st_lb(b, so + i, with_pot(lbout, pot_at(c.pot, norm3(s4.x, s4.y, s4.z))));
+    st_match(b, so + i, jout, with_pot(lbout, pot_at(c.pot, norm3(s4.x, s4.y, s4.z))));
     const uint32_t key = __float_as_uint(d2out);
     if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
   }

@@ -71,6 +71,7 @@ struct smhip_context {
   float split_share = 0.2f;      // auto split: the first iteration whose median searched share falls below this runs certify + listed search
   int sums_blocks = kSumsBlocks;  // workgroups of iteration_sums (SMHIP_SUMS_BLOCKS)
   int sums_long_for = 3;         // fused iterations of a batch whose missed pairs iteration_sums cuts into long blocks (SMHIP_SUMS_LONG_FOR)
+  int use_shadow = 1;            // fused certificate pass reads the 4-byte shadow of (bound, match) where every target is small enough (SMHIP_SHADOW)
   int wave_search = 0;           // batches: the every-query-searches iterations through nn_ball_lds (0, default: 5-25 % faster on the bench scans)
                                  // or nn_ball_wave (1; SMHIP_WAVE_SEARCH=1) -- same results
   float4* stage = nullptr;       // pinned staging for uploads, 2 * max(ns_cap, nt_cap)
@@ -413,7 +414,11 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
           if (d.fused) {
             // certificate pass + the sums below the predicted quantile band in one pass over the source (fused_iteration decides)
             const int nbc = ceil_div(ns_max, kNnThreads * kCertifyItems);
-            hipLaunchKernelGGL(nn_certify_acc<kCertifyItems>, dim3(nbc * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nbc);
+            // (every target of the launch below 32 767 points: the 4-byte shadow of bound + match instead of the two arrays)
+            if (h->use_shadow && nt_max_of(h, d.pair_base, np) < 0x7fff)
+              hipLaunchKernelGGL((nn_certify_acc<kCertifyItems, false, true>), dim3(nbc * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nbc);
+            else
+              hipLaunchKernelGGL(nn_certify_acc<kCertifyItems>, dim3(nbc * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nbc);
           } else if (f.small) {
             const int nb1 = ceil_div(ns_max, kNnThreads);
             hipLaunchKernelGGL(nn_certify<1>, dim3(nb1 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nb1);
@@ -531,6 +536,8 @@ void sync_options(smhip_context* h) {
   { const char* e = std::getenv("SMHIP_SPLIT_SHARE"); if (e && std::atof(e) > 0.0) h->split_share = (float)std::atof(e); }
   h->sums_long_for = 3;
   { const char* e = std::getenv("SMHIP_SUMS_LONG_FOR"); if (e) h->sums_long_for = std::atoi(e); }
+  h->use_shadow = 1;
+  { const char* e = std::getenv("SMHIP_SHADOW"); if (e) h->use_shadow = std::atoi(e); }
   h->wave_search = 0;
   { const char* e = std::getenv("SMHIP_WAVE_SEARCH"); if (e) h->wave_search = std::atoi(e); }
   h->sums_blocks = kSumsBlocks;
@@ -670,6 +677,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, &d.lb, B * NS));
   A(dev_alloc(h, &d.search_hist, B * kSearchHist));
   A(dev_alloc(h, &d.idx, B * NS));
+  A(dev_alloc(h, &d.mb, B * NS));
   A(dev_alloc(h, &d.hist, B * kHistBins));
   A(dev_alloc(h, &d.dlist, B * (size_t)d.dl_stride));
   A(dev_alloc(h, &d.hlist, B * NS));

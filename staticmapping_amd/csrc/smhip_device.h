@@ -160,6 +160,10 @@ struct IcpDev {
                              //                 < 0: no exact match, EVERY target point is at least -lb away; 0: unknown
   float* d2;                 // [slots][ns_cap]
   int32_t* idx;              // [slots][ns_cap] index into tq/tn (sorted order)
+  uint32_t* mb;              // [slots][ns_cap] the 4-byte shadow of (idx, lb) the fused certificate pass streams instead of the two: 15 bits of
+                             //                 match (0x7fff: none) + the bound as a 17-bit float whose magnitude is rounded TOWARDS ZERO (a smaller
+                             //                 bound certifies less, never wrongly).  Every writer of idx / lb writes it (st_match); it is read only
+                             //                 by launches whose targets all have fewer than 32 767 points
   uint32_t* hist;            // [slots][kHistBins]
   int32_t* dlist;            // [slots][ns_cap] deferred queries (searched by nn_ball_listed)
   int32_t* hlist;            // [slots][ns_cap] queries the tile phase could not certify (ring search)

@@ -45,8 +45,8 @@ struct smhip_context {
   // a batch is split into up to kMaxParts parts on separate streams so that the latency-bound kernels of one part
   // (finalize, validate, grid build) hide behind the NN / accumulate kernels of the others
   static constexpr int kMaxParts = 4;
-  hipStream_t side[kMaxParts - 1] = {nullptr, nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[kMaxParts - 1] = {nullptr, nullptr, nullptr};
+  hipStream_t side[kMaxParts - 1] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxParts - 1] = {};
   int n_side = 0;
   IcpDev dev{};
   KdDev kd{};                    // SMHIP_NN_NABO: tree arrays, allocated on first use
@@ -1203,36 +1203,46 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
     halves[k].d.acc_items = (halves[k].np * ceil_div(ns_max, kAccThreads * kAccItemsBatch) >= 768 ||
                              ceil_div(ns_max, kAccThreads * kAccItemsSmall) * (kAccThreads / 64) > kFinalizeMaxSeg) ? kAccItemsBatch : kAccItemsSmall;
   }
-  if (!cached_one) for (int k = 0; k < nh; ++k) { s = enqueue_grid_build(h, halves[k], nt_max); if (s) return s; }
   const int max_it = h->dev.max_iteration;
+  // one iteration of one part: FindClosests, the sums, finalize
+  auto enqueue_iteration = [&](Half& f, int it) -> smhip_status {
+    f.d.fused = fused_iteration(h, f, ns_max, it) ? 1 : 0;     // every launch of this iteration and part sees the same flag
+    f.d.fused_nabo = f.d.fused && h->opts.nn_mode == SMHIP_NN_NABO ? 1 : 0;
+    if (f.d.fused && !f.d.fused_nabo) {
+      // A band needs two quantiles: the iteration after the first has none, so no pair's sums can come from the fused pass -- the
+      // plain accumulate launch for all of them (fused = 0 for the sums only would change what finalize expects: keep the flag,
+      // it reads spec_ok = 0).  The next `sums_long_for` fused iterations most predictions still miss (the quantile moves by more
+      // than a bin): long blocks; after that short ones (iteration_sums).
+      f.first_fused = f.first_fused < 0 ? it : f.first_fused;
+      f.d.sums_items = (it - f.first_fused < h->sums_long_for && f.d.acc_items == kAccItemsBatch) ? kAccItemsBatch : kAccItemsSmall;
+      if (it < 2) f.d.sums_items = f.d.acc_items;
+    }
+    smhip_status r = enqueue_find_closests_half(h, f, ns_max, it);
+    if (r) return r;
+    {
+      Bracket br(h, 2, f.stream, f.np);
+      const int nblk = ceil_div(ns_max, kAccThreads * f.d.acc_items);
+      if (f.d.fused && !f.d.fused_nabo && it >= 2) {
+        // fused iteration: only the pairs whose prediction missed need `accumulate`, the others the sums of their listed matches --
+        // one fixed grid that takes both kinds of work (iteration_sums) instead of nblk workgroups per pair that look at a flag
+        if (f.d.sums_items == kAccItemsBatch) hipLaunchKernelGGL(iteration_sums<kAccItemsBatch>, dim3(h->sums_blocks), dim3(kAccThreads), 0, f.stream, f.d);
+        else hipLaunchKernelGGL(iteration_sums<kAccItemsSmall>, dim3(h->sums_blocks), dim3(kAccThreads), 0, f.stream, f.d);
+      } else if (f.d.acc_items == kAccItemsBatch) hipLaunchKernelGGL(accumulate<kAccItemsBatch>, dim3(nblk * 8 * ceil_div(f.np, 8)), dim3(kAccThreads), 0, f.stream, f.d, nblk);
+      else hipLaunchKernelGGL(accumulate<kAccItemsSmall>, dim3(nblk * 8 * ceil_div(f.np, 8)), dim3(kAccThreads), 0, f.stream, f.d, nblk);
+    }
+    { Bracket br(h, 3, f.stream); hipLaunchKernelGGL(finalize, dim3(f.np), dim3(256), 0, f.stream, f.d); }
+    return SMHIP_OK;
+  };
+  // (The parts march in lock-step.  Tried in round 5: part k + 1 started two to five iterations behind part k, so that one part's
+  // searching iterations -- bound by vector-instruction issue -- would run beside another's streaming ones -- bound by HBM: no gain
+  // with 2, 3, 4 or 8 parts (24.0 / 23.9 / 23.5 / 18.7 k alignments/s against 24.4 k in lock-step).  Side by side the two kernels
+  // split the registers: the certificate pass needs all of its waves to keep ~10 MB in flight, the search all of its to fill the
+  // SIMDs, and each runs as much slower as the other gains.)
+  if (!cached_one) for (int k = 0; k < nh; ++k) { s = enqueue_grid_build(h, halves[k], nt_max); if (s) return s; }
   for (int it = 0; it < max_it; ++it) {
     for (int k = 0; k < nh; ++k) {
-      Half& f = halves[k];
-      f.d.fused = fused_iteration(h, f, ns_max, it) ? 1 : 0;     // every launch of this iteration and part sees the same flag
-      f.d.fused_nabo = f.d.fused && h->opts.nn_mode == SMHIP_NN_NABO ? 1 : 0;
-      if (f.d.fused && !f.d.fused_nabo) {
-        // A band needs two quantiles: the iteration after the first has none, so no pair's sums can come from the fused pass -- the
-        // plain accumulate launch for all of them (fused = 0 for the sums only would change what finalize expects: keep the flag,
-        // it reads spec_ok = 0).  The next `sums_long_for` fused iterations most predictions still miss (the quantile moves by more
-        // than a bin): long blocks; after that short ones (iteration_sums).
-        f.first_fused = f.first_fused < 0 ? it : f.first_fused;
-        f.d.sums_items = (it - f.first_fused < h->sums_long_for && f.d.acc_items == kAccItemsBatch) ? kAccItemsBatch : kAccItemsSmall;
-        if (it < 2) f.d.sums_items = f.d.acc_items;
-      }
-      s = enqueue_find_closests_half(h, f, ns_max, it);
+      s = enqueue_iteration(halves[k], it);
       if (s) return s;
-      {
-        Bracket br(h, 2, f.stream, f.np);
-        const int nblk = ceil_div(ns_max, kAccThreads * f.d.acc_items);
-        if (f.d.fused && !f.d.fused_nabo && it >= 2) {
-          // fused iteration: only the pairs whose prediction missed need `accumulate`, the others the sums of their listed matches --
-          // one fixed grid that takes both kinds of work (iteration_sums) instead of nblk workgroups per pair that look at a flag
-          if (f.d.sums_items == kAccItemsBatch) hipLaunchKernelGGL(iteration_sums<kAccItemsBatch>, dim3(h->sums_blocks), dim3(kAccThreads), 0, f.stream, f.d);
-          else hipLaunchKernelGGL(iteration_sums<kAccItemsSmall>, dim3(h->sums_blocks), dim3(kAccThreads), 0, f.stream, f.d);
-        } else if (f.d.acc_items == kAccItemsBatch) hipLaunchKernelGGL(accumulate<kAccItemsBatch>, dim3(nblk * 8 * ceil_div(f.np, 8)), dim3(kAccThreads), 0, f.stream, f.d, nblk);
-        else hipLaunchKernelGGL(accumulate<kAccItemsSmall>, dim3(nblk * 8 * ceil_div(f.np, 8)), dim3(kAccThreads), 0, f.stream, f.d, nblk);
-      }
-      { Bracket br(h, 3, f.stream); hipLaunchKernelGGL(finalize, dim3(f.np), dim3(256), 0, f.stream, f.d); }
     }
     if (h->dev.early_exit && (it + 1) % h->opts.check_every == 0 && it + 1 < max_it) {
       s = join();

@@ -1,7 +1,7 @@
 // icp_kernels.hip -- hand-written gfx950 kernels for the IcpFast hot path.
 //
 // Kernel inventory (SURVEY.md §2b ids in brackets; reference lines are in /root/reference):
-//   tgt_reduce / grid_setup / grid_mark / grid_rank / grid_count / grid_cscan / grid_scatter
+//   tgt_reduce / grid_setup / grid_mark / grid_rank / grid_count / grid_cscan / grid_scatter_idx / grid_place
 //        target centring (icp_fast.cc:457-463) + the search structure that replaces the
 //        libnabo kd-tree rebuilt on every Align (icp_fast.cc:464-467)
 //   nn_grid, nn_brute   [K1]  ApplyTransform + FindClosests      (icp_fast.cc:486-493, 169-180)
@@ -352,38 +352,37 @@ __global__ __launch_bounds__(1024) void grid_cscan(IcpDev b) {
   if (threadIdx.x == 0) cs[n] = total;
 }
 
-__global__ __launch_bounds__(256) void grid_scatter(IcpDev b) {
+// The cell-sorted target in two steps.  grid_count dealt every point a place in its cell in the order the atomics happened to
+// arrive; positions must not depend on that (the tie rule of every search is "smallest sorted position").  Step 1 leaves only the
+// point's INDEX at that place (perm: the tcell array, free once the points are counted); step 2 ranks every point among the
+// indices of its cell's run -- a handful of 4-byte reads -- and writes the 32 bytes of point + normal once, at their final
+// place: cells in linear order, a cell's points by caller index.  (Before: the 32 bytes scattered in arrival order, then one
+// thread per cell insertion-sorting them in global memory -- as long as grid_mark for nothing but a few swaps.)
+__global__ __launch_bounds__(256) void grid_scatter_idx(IcpDev b) {
   const int pair = b.pair_base + blockIdx.y;
   const PairState* st = &b.state[pair];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= st->nt) return;
   const size_t o = (size_t)pair * b.nt_cap;
-  const float3 c = centre_point(b.tgt_p[o + j], st->mu);
-  const uint32_t pos = b.cstart[(size_t)pair * (b.nt_cap + 1) + b.tslot[o + j]] + b.tord[o + j];
-  b.tq[o + pos] = make_float4(c.x, c.y, c.z, __int_as_float(j));
-  float4 n = b.tgt_n[o + j];
-  n.w = 0.f;
-  b.tn[o + pos] = n;
+  b.tcell[o + b.cstart[(size_t)pair * (b.nt_cap + 1) + b.tslot[o + j]] + b.tord[o + j]] = (uint32_t)j;
 }
-
-// One thread per occupied cell: order the cell's points by original index so that sorted
-// positions (and with them the NN tie rule) do not depend on the atomic order of grid_count.
-__global__ __launch_bounds__(256) void grid_sort_cells(IcpDev b) {
+__global__ __launch_bounds__(256) void grid_place(IcpDev b) {
   const int pair = b.pair_base + blockIdx.y;
   const PairState* st = &b.state[pair];
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= st->nocc) return;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= st->nt) return;
+  const size_t o = (size_t)pair * b.nt_cap;
   const uint32_t* cs = b.cstart + (size_t)pair * (b.nt_cap + 1);
-  const uint32_t j0 = cs[c], j1 = cs[c + 1];
-  float4* tq = b.tq + (size_t)pair * b.nt_cap;
-  float4* tn = b.tn + (size_t)pair * b.nt_cap;
-  for (uint32_t a = j0 + 1; a < j1; ++a) {       // insertion sort; cells hold a handful of points
-    const float4 kq = tq[a], kn = tn[a];
-    const int key = __float_as_int(kq.w);
-    uint32_t p = a;
-    while (p > j0 && __float_as_int(tq[p - 1].w) > key) { tq[p] = tq[p - 1]; tn[p] = tn[p - 1]; --p; }
-    tq[p] = kq; tn[p] = kn;
-  }
+  const uint32_t slot = b.tslot[o + j];
+  const uint32_t c0 = cs[slot], c1 = cs[slot + 1];
+  const float4 p = b.tgt_p[o + j];
+  float4 n = b.tgt_n[o + j];
+  uint32_t rank = 0;
+  for (uint32_t k = c0; k < c1; ++k) rank += b.tcell[o + k] < (uint32_t)j ? 1u : 0u;
+  const float3 c = centre_point(p, st->mu);
+  b.tq[o + c0 + rank] = make_float4(c.x, c.y, c.z, __int_as_float(j));
+  n.w = 0.f;
+  b.tn[o + c0 + rank] = n;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -391,7 +390,7 @@ __global__ __launch_bounds__(256) void grid_sort_cells(IcpDev b) {
 // ------------------------------------------------------------------------------------------
 // Tie rule everywhere: among equidistant targets the smallest SORTED position j wins.  Positions
 // are deterministic (cells in linear order, points inside a cell ordered by original index, see
-// grid_sort_cells), so brute force, tile search, ring search and fallback agree bit for bit.
+// grid_place), so brute force, tile search, ring search and fallback agree bit for bit.
 struct Best { float d2; int j; float s2; };   // nearest (squared distance, position) and runner-up squared distance
 
 __device__ __forceinline__ float dist2(const float4 t, float qx, float qy, float qz) {

@@ -1,2 +1,2 @@
-bash tools/r05_trace.sh r05t4 "one:no_overlap=1" cv "nn_ball_listed_items iteration_sums"
-bash tools/r05_quick.sh r05k "tests/test_icp_gpu.py tests/test_fused_batch_oracle_gpu.py tests/test_properties_gpu.py" "two:;one:no_overlap=1"
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r05o_pytest_gpu.txt 2>&1; echo "rc=$?" >> gpurun_out/r05o_pytest_gpu.txt; grep -v amdgpu.ids gpurun_out/r05o_pytest_gpu.txt | tail -4
+bash tools/r05_quick.sh r05o none "two:;one:no_overlap=1" "cv id"

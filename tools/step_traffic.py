@@ -27,7 +27,7 @@ steps = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 workload = sys.argv[5] if len(sys.argv) > 5 else "tools/profile_target.py B=512 reps=1: 512 copies of the cfg2 120 k-point pair, guess 0.6 m off, 20 iterations, two 256-pair halves on two streams"
 rows = {}
 for k in sorted(set(fetch) | set(write)):
-    if not any(t in k for t in ("nn_", "listed_plan", "accumulate", "finalize", "grid_", "tgt_reduce", "reset_scratch", "pack_source", "pose_setup")):
+    if not any(t in k for t in ("nn_", "listed_plan", "accumulate", "iteration_sums", "finalize", "grid_", "tgt_reduce", "reset_scratch", "pack_source", "pose_setup")):
         continue
     nf, f = fetch.get(k, [0, 0.0]); nw, w = write.get(k, [0, 0.0])
     rows[k] = {"launches": max(nf, nw) / steps, "fetch_kb": round(f / steps), "write_kb": round(w / steps), "bytes": int((ff * f + wf * w) * 1024 / steps)}

@@ -358,6 +358,21 @@ __global__ __launch_bounds__(1024) void grid_cscan(IcpDev b) {
 // indices of its cell's run -- a handful of 4-byte reads -- and writes the 32 bytes of point + normal once, at their final
 // place: cells in linear order, a cell's points by caller index.  (Before: the 32 bytes scattered in arrival order, then one
 // thread per cell insertion-sorting them in global memory -- as long as grid_mark for nothing but a few swaps.)
+// (sort_cells = 0 -- the NDT fitness pass, the GICP neighbourhoods: their searches carry the tie rule on the caller index explicitly,
+// so a cell's points may stand in arrival order: one scatter, no ranking.  Their targets are dense -- tens of points per cell.)
+__global__ __launch_bounds__(256) void grid_scatter(IcpDev b) {
+  const int pair = b.pair_base + blockIdx.y;
+  const PairState* st = &b.state[pair];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= st->nt) return;
+  const size_t o = (size_t)pair * b.nt_cap;
+  const float3 c = centre_point(b.tgt_p[o + j], st->mu);
+  const uint32_t pos = b.cstart[(size_t)pair * (b.nt_cap + 1) + b.tslot[o + j]] + b.tord[o + j];
+  b.tq[o + pos] = make_float4(c.x, c.y, c.z, __int_as_float(j));
+  float4 n = b.tgt_n[o + j];
+  n.w = 0.f;
+  b.tn[o + pos] = n;
+}
 __global__ __launch_bounds__(256) void grid_scatter_idx(IcpDev b) {
   const int pair = b.pair_base + blockIdx.y;
   const PairState* st = &b.state[pair];

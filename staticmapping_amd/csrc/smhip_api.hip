@@ -262,8 +262,12 @@ smhip_status enqueue_grid_build(smhip_context* h, const Half& f, int nt_max) {
   hipLaunchKernelGGL(grid_rank, dim3(std::max(1, std::min(16, 64 / np)), np), dim3(1024), 0, f.stream, d);   // segments per pair when pairs are few
   hipLaunchKernelGGL(grid_count, gpts, dim3(256), 0, f.stream, d);
   hipLaunchKernelGGL(grid_cscan, dim3(np), dim3(1024), 0, f.stream, d);
-  hipLaunchKernelGGL(grid_scatter_idx, gpts, dim3(256), 0, f.stream, d);
-  hipLaunchKernelGGL(grid_place, gpts, dim3(256), 0, f.stream, d);
+  if (d.sort_cells) {
+    hipLaunchKernelGGL(grid_scatter_idx, gpts, dim3(256), 0, f.stream, d);
+    hipLaunchKernelGGL(grid_place, gpts, dim3(256), 0, f.stream, d);
+  } else {
+    hipLaunchKernelGGL(grid_scatter, gpts, dim3(256), 0, f.stream, d);
+  }
   HIPCHK(h, hipGetLastError());
   for (int p = d.pair_base; p < d.pair_base + np; ++p) {
     h->grid_gen[p] = h->tgt_gen[p]; h->grid_cell_built[p] = d.grid_cell; h->grid_sorted[p] = d.sort_cells; h->grid_rows[p] = d.have_rowbits;

@@ -943,7 +943,9 @@ __device__ __forceinline__ void sweep_run(const float4* __restrict__ tq, uint32_
 #else
 #define SMHIP_PHASE(k) do { } while (0)
 #endif
-template <int ITEMS>
+// FIRST = the launch of iteration 0 (the host knows): no previous match, no certificate, one radius for every query -- the loads,
+// the gather of the previous match and the certificate arithmetic drop out at compile time.
+template <int ITEMS, bool FIRST = false>
 __global__ __launch_bounds__(kNnThreads, 5) void nn_ball_lds(IcpDev b, int nblk) {
   int pair, blk;
   if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
@@ -993,7 +995,7 @@ __global__ __launch_bounds__(kNnThreads, 5) void nn_ball_lds(IcpDev b, int nblk)
   const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx, nw = st->nw;
   const float r2cap = st->rcap2;
   const float r_need = 0.9f * sqrtf(r2cap);
-  const bool have_prev = st->iter > 0;
+  const bool have_prev = !FIRST && st->iter > 0;
   const bool certify = have_prev && b.certify;
   uint32_t min_lb = 0xffffffffu;
 

@@ -318,6 +318,9 @@ int RunRank(const Args& a, int rank, int world, int device) {
 }  // namespace
 
 int main(int argc, char** argv) {
+  // the library splits a batch over up to four streams and RCCL brings its own: more hardware queues than the runtime's default 4, or
+  // two of them share a queue and run one after the other (as bench.py does; must be set before the runtime starts)
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   Args a = Parse(argc, argv);
   if (a.id_file.empty()) a.id_file = "/tmp/smhip_shard_id_" + std::to_string(a.rank >= 0 ? static_cast<long>(getppid()) : static_cast<long>(getpid()));
   if (a.rank >= 0) {                                                     // one rank of a launched group

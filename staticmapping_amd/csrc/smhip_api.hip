@@ -406,6 +406,8 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
           // a wave per 64 queries walks the box of its balls once, candidates from SGPRs (nn_ball_wave)
           if (iteration == 0) hipLaunchKernelGGL((nn_ball_wave<kBallItems, true>), gx, dim3(kNnThreads), 0, st, d, nblk);
           else hipLaunchKernelGGL((nn_ball_wave<kBallItems, false>), gx, dim3(kNnThreads), 0, st, d, nblk);
+        } else if (iteration == 0) {
+          hipLaunchKernelGGL((nn_ball_lds<kBallItems, true>), gx, dim3(kNnThreads), 0, st, d, nblk);
         } else {
           hipLaunchKernelGGL(nn_ball_lds<kBallItems>, gx, dim3(kNnThreads), 0, st, d, nblk);
         }
@@ -1167,7 +1169,9 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
   // Split the batch over several streams: the latency-bound launches of one part (finalize, validate, grid
   // build, near-empty refinement kernels) overlap the throughput-bound NN / accumulate of the others.
   // Parts are multiples of 8 pairs (the XCD mapping) and at least 16 pairs each.
-  int want = h->opts.no_overlap ? 1 : (h->opts.overlap_streams > 0 ? h->opts.overlap_streams : 2);
+  // (default: parts of at least 64 pairs, two to four of them -- measured on 512-pair batches with the fixed-grid tail kernels of
+  // round 5: 2 / 3 / 4 parts = 25.3 / 25.9 / 26.0 k alignments/s, identity guesses 15.3 / 15.8 / 15.7 k, mixed 17.4 / 18.1 / 18.4 k)
+  int want = h->opts.no_overlap ? 1 : (h->opts.overlap_streams > 0 ? h->opts.overlap_streams : std::max(2, std::min(4, npairs / 64)));
   want = std::min(want, smhip_context::kMaxParts);
   if (want > 1 && npairs >= 32) ensure_side_streams(h, want - 1);
   want = std::min(want, 1 + h->n_side);

@@ -1169,9 +1169,10 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
   // Split the batch over several streams: the latency-bound launches of one part (finalize, validate, grid
   // build, near-empty refinement kernels) overlap the throughput-bound NN / accumulate of the others.
   // Parts are multiples of 8 pairs (the XCD mapping) and at least 16 pairs each.
-  // (default: parts of at least 64 pairs, two to four of them -- measured on 512-pair batches with the fixed-grid tail kernels of
-  // round 5: 2 / 3 / 4 parts = 25.3 / 25.9 / 26.0 k alignments/s, identity guesses 15.3 / 15.8 / 15.7 k, mixed 17.4 / 18.1 / 18.4 k)
-  int want = h->opts.no_overlap ? 1 : (h->opts.overlap_streams > 0 ? h->opts.overlap_streams : std::max(2, std::min(4, npairs / 64)));
+  // (default two.  Measured on 512-pair batches with the fixed-grid tail kernels of round 5: 2 / 3 / 4 parts = 25.3 / 25.9 / 26.0 k
+  // alignments/s, identity guesses 15.3 / 15.8 / 15.7 k, mixed 17.4 / 18.1 / 18.4 k -- overlap_streams = 4 is worth 1.5-5 % there; the
+  // sequence driver's 256-pair batches lose 12 % with four parts of 64 pairs, so the default stays where every batch size is served)
+  int want = h->opts.no_overlap ? 1 : (h->opts.overlap_streams > 0 ? h->opts.overlap_streams : 2);
   want = std::min(want, smhip_context::kMaxParts);
   if (want > 1 && npairs >= 32) ensure_side_streams(h, want - 1);
   want = std::min(want, 1 + h->n_side);

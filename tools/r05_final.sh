@@ -14,12 +14,21 @@ echo "default bench.py run: $((SECONDS - t0)) s wall" > "$out/bench_wall.txt"
 timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python bench.py --no-cpu-baseline --no-end-to-end --no-other > "$out/bench_line_traced.json" 2> "$out/trace.err" < /dev/null
 f=$(find "$out/trace" -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" "$out/bench_kernel_stats.csv"
-# trace averages over the launches of the timed region only: 4 untimed steps first, then 5 timed steps; per step 4 launches of
-# nn_ball_lds and accumulate (iterations 0-1 x 2 halves), 36 of nn_certify_acc / listed_plan / nn_ball_listed_items / nn_refine_one /
-# iteration_sums, 40 of finalize
+# trace averages over the launches of the timed region only: 4 untimed steps first, then 5 timed steps; a 512-pair step runs as
+# P parts (default 2 of 256 pairs), so per step 2 P launches of nn_ball_lds and accumulate (iterations 0-1), 18 P of nn_certify_acc /
+# listed_plan / nn_ball_listed_items / nn_refine_one / iteration_sums, 20 P of finalize, P of every grid kernel
+P=${PARTS:-2}
 : > "$out/timed_region_trace_average.txt"
-for spec in "nn_certify_acc 144 180" "nn_ball_lds 16 20" "nn_ball_listed_items 144 180" "listed_plan 144 180" "nn_refine_one 144 180" "iteration_sums 144 180" "finalize 160 200" "accumulate 16 20" "grid_mark 8 10" "grid_rank 8 10" "grid_count 8 10" "grid_place 8 10"; do
-  python tools/trace_tail_average.py "$out/trace" $spec >> "$out/timed_region_trace_average.txt" 2>&1
+echo "# rocprofv3 --kernel-trace of bench.py: the launches of the 5 timed steps ($P parts of $((512 / P)) pairs per step)" >> "$out/timed_region_trace_average.txt"
+for k in nn_certify_acc nn_ball_listed_items listed_plan nn_refine_one iteration_sums; do
+  python tools/trace_tail_average.py "$out/trace" $k $((4 * 18 * P)) $((5 * 18 * P)) >> "$out/timed_region_trace_average.txt" 2>&1
+done
+for k in nn_ball_lds accumulate; do
+  python tools/trace_tail_average.py "$out/trace" $k $((4 * 2 * P)) $((5 * 2 * P)) >> "$out/timed_region_trace_average.txt" 2>&1
+done
+python tools/trace_tail_average.py "$out/trace" finalize $((4 * 20 * P)) $((5 * 20 * P)) >> "$out/timed_region_trace_average.txt" 2>&1
+for k in grid_mark grid_rank grid_count grid_place; do
+  python tools/trace_tail_average.py "$out/trace" $k $((4 * P)) $((5 * P)) >> "$out/timed_region_trace_average.txt" 2>&1
 done
 rm -rf "$out/trace"
 # FETCH_SIZE / WRITE_SIZE passes over the bench workload (512 distinct pairs) through tools/fused_probe.py

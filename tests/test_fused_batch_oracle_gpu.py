@@ -139,3 +139,32 @@ def test_fused_sums_with_coincident_duplicated_targets():
         assert abs(scf[s] - scs[s]) < 1e-12
         # the doubled points' exact copies are listed in every iteration after the first
         assert stf[s]["searched_queries"] >= len(src) + 10 * 6 * n_dup
+
+
+def test_fused_path_with_odd_sizes_and_pair_counts(velo20k):
+    """The fixed-grid kernels of the fused iteration (iteration_sums: work items per XCD from a plan over the launch's pairs; the
+    listed search's tickets) with a pair count that is no multiple of 8 and source sizes around every block boundary (one certificate
+    block = 5 120 points, one short accumulate block = 2 048, one long = 8 192): fused against separate passes -- the same kept
+    sets and quantiles, poses to 1e-10 (icp_fast.cc:484-523)."""
+    import staticmapping_amd as sm
+    from staticmapping_amd import synth
+    sizes = [20000, 5120, 5121, 2048, 2049, 8192, 8193, 10240, 1000, 19999, 4097, 16384, 12345, 6000, 5119, 15361, 20000, 777, 10241]
+    src0 = np.asarray(velo20k["src"], dtype=np.float32)
+    out = {}
+    for name, opts in (("separate", dict(no_fused_sums=1)), ("fused", dict())):
+        m = sm.IcpFastHip(pair_slots=len(sizes), max_source_points=max(sizes), max_target_points=len(velo20k["q"]), max_iteration=15, early_exit=0,
+                          split_after=1, **opts)
+        for s_, n_ in enumerate(sizes):
+            pick = np.sort(np.random.default_rng(100 + s_).choice(len(src0), size=n_, replace=False))
+            m.set_input_source(src0[pick], slot=s_); m.set_input_target(velo20k["q"], velo20k["n"], slot=s_)
+        g = [velo20k["guess"] @ synth.make_pose(t=(0.01 * (k % 3), 0.005 * (k % 2), 0.0), rpy_deg=(0, 0, 0.02 * (k % 5))) for k in range(len(sizes))]
+        out[name] = m.align_batch(len(sizes), g)
+        m.close()
+    Rs, scs, sts = out["separate"]; Rf, scf, stf = out["fused"]
+    assert max(s["fused_iterations"] for s in stf) > 0 and max(s["fused_iterations"] for s in sts) == 0
+    for s_ in range(len(sizes)):
+        assert stf[s_]["iterations"] == sts[s_]["iterations"] == 15
+        assert stf[s_]["kept"] == sts[s_]["kept"] and stf[s_]["limit_d2"] == sts[s_]["limit_d2"], (s_, sizes[s_], stf[s_], sts[s_])
+        da, dt = sm.se3_error(Rf[s_], Rs[s_])
+        assert da < 1e-10 and dt < 1e-9, (s_, sizes[s_], da, dt)
+        assert abs(scf[s_] - scs[s_]) < 1e-11

@@ -2287,12 +2287,12 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
 // target point and distance in registers anyway, sums the certified matches below the band on the spot, drops those above
 // it, and leaves the band's members as records (source point, distance, match id) for finalize to select among.  The queries
 // whose certificate fails go to the wave's own segment of dlist; the listed search (nn_ball_listed_items) finds their matches
-// and records those inside the band, finalize sums those below it.  nn_validate then checks the prediction against the
+// and records those inside the band, iteration_sums adds those below it.  nn_validate then checks the prediction against the
 // completed histogram (PairState::spec_ok); a miss costs one plain `accumulate` for that pair.  No atomics with a return value
 // inside the loop (the lists are per-wave segments, counted in SGPRs), so the two-deep load pipeline never drains.
 // NABO = true, the reference-search form: the traversal certificates of the libnabo walk instead of the distance bounds, the
 // failing queries to the walk's four class lists (once per wave, after the loop), and after the walk nabo_validate +
-// accumulate_listed in the roles of nn_validate and of finalize's listed phase.
+// accumulate_listed in the roles of nn_validate and of iteration_sums' listed matches.
 // Exactness: the same matches, the same distances, the same kept set as the separate passes; only the order in which the
 // 29 sums are added differs (1e-16 relative), and it is a fixed order -- the result is reproducible bit for bit.
 __device__ __forceinline__ void emit_record(const IcpDev& b, size_t segbase, int& wcount, bool band, const float4 s, float d, int j) {
@@ -2669,7 +2669,7 @@ __global__ __launch_bounds__(kNnThreads, 6) void nn_ball_listed(IcpDev b, int nb
 // ITEMS of one pass each (kNnThreads >> logL consecutive entries, logL from the list's length); nn_ball_listed_items is a
 // fixed grid of workgroups that takes the items of ALL pairs of the launch in turn.  A match found here whose distance falls
 // in the predicted quantile band becomes a record in its item's segment of region 1 (compacted inside the workgroup, in list
-// order); the matches below the band are summed by finalize, which walks the list once more.
+// order); the matches below the band are summed by iteration_sums, which walks the list once more.
 __global__ __launch_bounds__(256) void listed_plan(IcpDev b) {
   const int pair = b.pair_base + blockIdx.x;
   PairState* st = &b.state[pair];

@@ -403,7 +403,7 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
           const int nb1 = ceil_div(ns_max, kNnThreads);
           hipLaunchKernelGGL(nn_ball_lds<1>, dim3(nb1 * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nb1);
         } else if (h->wave_search) {
-          // a wave per 64 queries walks the box of its balls once, candidates from SGPRs (nn_ball_wave)
+          // a wave per 64 queries walks the box of its balls once, candidates broadcast from the wave's LDS strip (nn_ball_wave)
           if (iteration == 0) hipLaunchKernelGGL((nn_ball_wave<kBallItems, true>), gx, dim3(kNnThreads), 0, st, d, nblk);
           else hipLaunchKernelGGL((nn_ball_wave<kBallItems, false>), gx, dim3(kNnThreads), 0, st, d, nblk);
         } else if (iteration == 0) {
@@ -669,7 +669,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, const_cast<float**>(&d.src3), B * NS * 3));
   A(dev_alloc(h, const_cast<float4**>(&d.tgt_p), B * NT));
   A(dev_alloc(h, const_cast<float4**>(&d.tgt_n), B * NT));
-  A(dev_alloc(h, &d.tq, B * NT + 8));        // (+ 8: nn_ball_wave's scalar loads read up to seven rows past a run's end)
+  A(dev_alloc(h, &d.tq, B * NT));
   A(dev_alloc(h, &d.tn, B * NT));
   A(dev_alloc(h, &d.tcell, B * NT));
   A(dev_alloc(h, &d.tslot, B * NT));
@@ -1223,7 +1223,9 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
       // it reads spec_ok = 0).  The next `sums_long_for` fused iterations most predictions still miss (the quantile moves by more
       // than a bin): long blocks; after that short ones (iteration_sums).
       f.first_fused = f.first_fused < 0 ? it : f.first_fused;
-      f.d.sums_items = (it - f.first_fused < h->sums_long_for && f.d.acc_items == kAccItemsBatch) ? kAccItemsBatch : kAccItemsSmall;
+      // (short blocks only while their record segments -- four per block -- fit finalize's table: clouds of up to a million points)
+      const bool short_fits = ceil_div(ns_max, kAccThreads * kAccItemsSmall) * (kAccThreads / 64) <= kFinalizeMaxSeg;
+      f.d.sums_items = (f.d.acc_items == kAccItemsBatch && (it - f.first_fused < h->sums_long_for || !short_fits)) ? kAccItemsBatch : kAccItemsSmall;
       if (it < 2) f.d.sums_items = f.d.acc_items;
     }
     smhip_status r = enqueue_find_closests_half(h, f, ns_max, it);

@@ -37,7 +37,8 @@ constexpr int kListedBlocks = 32;        // workgroups per pair of the listed se
 constexpr int kBallItems = 2;            // rounds of 256 queries per workgroup in nn_ball_lds / nn_ball (prefetch across rounds; 2 measured best: 4 = +8 %, 1 = +5 %)
 constexpr int kListedLaneBudgetMax = 32768;   // largest lane budget of the balanced listed search (SMHIP_LISTED_LANES; default 4096)
 constexpr int kFusedListedMax = 16384;   // fused path: with more failing certificates than this in a pair and iteration the sums are left to `accumulate`
-                                         // (finalize, one workgroup per pair, walks the listed queries: 16 rounds of 4 per thread at most)
+                                         // (their listed matches below the band are summed kListedSumChunk entries per work item of iteration_sums,
+                                         // a row of partials each)
 // most work items listed_plan can cut a pair's list into (= record segments of region 1 finalize has to index): a list of `count`
 // entries searched with L lanes each (L * count <= the budget, or L = 1) makes ceil(count * L / 256) items
 constexpr int kListedMaxItems = (kFusedListedMax / kNnThreads > kListedLaneBudgetMax / kNnThreads ? kFusedListedMax / kNnThreads : kListedLaneBudgetMax / kNnThreads) + 1;

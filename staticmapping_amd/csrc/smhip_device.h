@@ -44,8 +44,10 @@ constexpr int kFusedListedMax = 16384;   // fused path: with more failing certif
 constexpr int kListedMaxItems = (kFusedListedMax / kNnThreads > kListedLaneBudgetMax / kNnThreads ? kFusedListedMax / kNnThreads : kListedLaneBudgetMax / kNnThreads) + 1;
 constexpr int kListedSumChunk = 4096;    // fused path: listed queries per work item of iteration_sums (a row of partials each: at most kFusedListedMax / this)
 constexpr int kSumsBlocks = 768;         // its workgroups (a multiple of 8; 3 per CU: 164 VGPRs)
-constexpr int kCertifyItems = 20;        // rounds per workgroup of the certificate pass: its per-workgroup costs (histogram zero + flush, pipeline fill) are
-                                         // large next to a round's -- 8: 80, 12: 57, 16: 57, 20: 49, 24: 48, 28: 52, 32: 53 us per 64 pairs (120 k points)
+constexpr int kCertifyItems = 32;        // rounds per workgroup of the certificate pass: its per-workgroup costs (histogram zero + flush, pipeline fill, the
+                                         // fused pass's 29-column reduction) are large next to a round's.  The plain pass (round 3): 8: 80, 12: 57, 16: 57,
+                                         // 20: 49, 24: 48, 28: 52, 32: 53 us per 64 pairs (120 k points); the fused pass with the shadow (round 5), per
+                                         // 512-pair step: 16: 8.41, 20: 8.21, 32: 7.97, 40: 7.98 ms (at most 32: one bit per round in nabo_list_append)
 
 // Per-pair device state.  Everything an iteration needs and everything the host reads back.
 struct PairState {

@@ -144,7 +144,7 @@ def test_fused_sums_with_coincident_duplicated_targets():
 def test_fused_path_with_odd_sizes_and_pair_counts(velo20k):
     """The fixed-grid kernels of the fused iteration (iteration_sums: work items per XCD from a plan over the launch's pairs; the
     listed search's tickets) with a pair count that is no multiple of 8 and source sizes around every block boundary (one certificate
-    block = 5 120 points, one short accumulate block = 2 048, one long = 8 192): fused against separate passes -- the same kept
+    block = 8 192 points, one short accumulate block = 2 048, one long = 8 192; 5 120 was the certificate block until the re-tune): fused against separate passes -- the same kept
     sets and quantiles, poses to 1e-10 (icp_fast.cc:484-523)."""
     import staticmapping_amd as sm
     from staticmapping_amd import synth

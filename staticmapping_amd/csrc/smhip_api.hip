@@ -533,10 +533,11 @@ void sync_options(smhip_context* h) {
   h->dev.fused = 0; h->dev.fused_nabo = 0;
   h->dev.band_pad = 0.1f; h->dev.band_gain = 1.5f;              // tuning only: results do not depend on the band, only how often it holds
   { const char* e = std::getenv("SMHIP_BAND_PAD"); if (e && std::atof(e) >= 0.0) h->dev.band_pad = (float)std::atof(e); }
-  // lanes per query of the balanced listed search: measured flat from 1 024 to 8 192 (3.13-3.25 ms per step), slower beyond
-  // (16 384: 3.5, 32 768: 4.2).  At most kListedLaneBudgetMax: a pair's list is cut into at most budget / 256 + 1 items
+  // lanes per query of the balanced listed search: round 4 measured it flat from 1 024 to 8 192 (3.13-3.25 ms per step), slower beyond
+  // (16 384: 3.5, 32 768: 4.2); with the level-by-level row walk of round 5: 512 / 1 024 / 2 048 / 4 096 = +2.6 / +3.1 / +0.6 / 0 % alignments/s
+  // on the bench batch together with 2 048 sums workgroups (one lane walks a short ball's few rows at no loss now).  At most kListedLaneBudgetMax: a pair's list is cut into at most budget / 256 + 1 items
   // (kListedMaxItems: finalize's segment table and the handle's seg_stride are sized for that)
-  h->dev.listed_lane_budget = 4096;
+  h->dev.listed_lane_budget = 1024;
   { const char* e = std::getenv("SMHIP_LISTED_LANES"); if (e && std::atoi(e) >= 256) h->dev.listed_lane_budget = std::min(std::atoi(e), kListedLaneBudgetMax); }
   h->split_share = 0.2f;
   { const char* e = std::getenv("SMHIP_SPLIT_SHARE"); if (e && std::atof(e) > 0.0) h->split_share = (float)std::atof(e); }

@@ -43,7 +43,8 @@ constexpr int kFusedListedMax = 16384;   // fused path: with more failing certif
 // entries searched with L lanes each (L * count <= the budget, or L = 1) makes ceil(count * L / 256) items
 constexpr int kListedMaxItems = (kFusedListedMax / kNnThreads > kListedLaneBudgetMax / kNnThreads ? kFusedListedMax / kNnThreads : kListedLaneBudgetMax / kNnThreads) + 1;
 constexpr int kListedSumChunk = 4096;    // fused path: listed queries per work item of iteration_sums (a row of partials each: at most kFusedListedMax / this)
-constexpr int kSumsBlocks = 768;         // its workgroups (a multiple of 8; 3 per CU: 164 VGPRs)
+constexpr int kSumsBlocks = 2048;        // its workgroups (a multiple of 8).  768 (three per CU at 164 VGPRs: all resident) / 1 536 / 2 048 / 3 072: 25.5 / 26.3 / 26.0 /
+                                         // 25.8 k alignments/s on the bench batch, 17.8 / 18.2 / 18.5 / 18.5 k mixed: short items, so a second round of workgroups balances them
 constexpr int kCertifyItems = 32;        // rounds per workgroup of the certificate pass: its per-workgroup costs (histogram zero + flush, pipeline fill, the
                                          // fused pass's 29-column reduction) are large next to a round's.  The plain pass (round 3): 8: 80, 12: 57, 16: 57,
                                          // 20: 49, 24: 48, 28: 52, 32: 53 us per 64 pairs (120 k points); the fused pass with the shadow (round 5), per

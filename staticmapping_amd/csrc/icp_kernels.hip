@@ -11,6 +11,7 @@
 //                       CheckConvergence, score                  (icp_fast.cc:204-254, 306-323, 377-405, 513-523)
 //
 // Everything here is HBM/L2-bound gather, scan and reduction work: wave64 shuffles + LDS, no MFMA.
+#include <type_traits>
 #include "smhip_device.h"
 #include "kd_median_tree.h"
 
@@ -469,9 +470,9 @@ __device__ __forceinline__ uint32_t pack_match(int j, float lbv) {
   return (code << 15) | (uint32_t)(j < 0 || j >= 0x7fff ? 0x7fff : j);
 }
 __device__ __forceinline__ float shadow_bound(uint32_t m) {
-  const uint32_t e = (m >> 27) & 0xfu;
-  const uint32_t bits = ((m >> 31) << 31) | ((e + 116u) << 23) | (((m >> 15) & 0xfffu) << 11);
-  return e ? __uint_as_float(bits) : 0.f;
+  // [31] sign, [30:27] exponent - 116 (0: no bound), [26:15] the mantissa's top twelve bits: exponent and mantissa move down as one field
+  const uint32_t bits = (((m & 0x7fff8000u) >> 4) + 0x3a000000u) | (m & 0x80000000u);
+  return (m & 0x78000000u) ? __uint_as_float(bits) : 0.f;
 }
 __device__ __forceinline__ int shadow_match(uint32_t m) { const int j = (int)(m & 0x7fffu); return j == 0x7fff ? -1 : j; }
 // a query's match and certificate bound: the two arrays every kernel reads, and their 4-byte shadow (IcpDev::mb)
@@ -2116,10 +2117,15 @@ __global__ __launch_bounds__(kNnThreads) void nn_refine_one(IcpDev b) {
   fallback_body(b, st, pair, 0, 1, s_t, &s_last);
 }
 
-// J = [p x n ; n], r = (p - q) . n ; acc += upper(J J^T), J r, sqrt(d2), 1     (icp_fast.cc:182-202, 256-303)
+// J = [p x n ; n], r = (p - q) . n ; acc += upper(J J^T), J r, 1     (icp_fast.cc:182-202, 256-303)
 // p = the source point already moved (transform_point).  Every producer of sums -- accumulate, the fused certificate pass, the
-// listed search's epilogue, finalize -- goes through this one function: a match contributes the same 29 doubles wherever it is met.
-__device__ __forceinline__ void accumulate_terms_p(double px, double py, double pz, const float4 q4, const float4 n4, float d2v, double* acc) {
+// listed search's epilogue, finalize -- goes through this one function: a match contributes the same 28 doubles wherever it is met.
+// Column 27 stays zero: the reference forms the sum of the kept distances' roots only in the iteration it leaves the loop with
+// (icp_fast.cc:516-522), and so does the device -- final_score, one pass over the last iteration's distances -- instead of a root,
+// a reciprocal and a Newton step per point and iteration (12 of the certificate pass's ~170 vector instructions per round).
+// COUNT = false: the caller counts the kept matches itself (a wave's kept lanes by one scalar popcount instead of an f64 add per lane).
+template <bool COUNT = true>
+__device__ __forceinline__ void accumulate_terms_p(double px, double py, double pz, const float4 q4, const float4 n4, double* acc) {
   const double nx = n4.x, ny = n4.y, nz = n4.z;
   double J[6];
   J[0] = py * nz - pz * ny;
@@ -2134,20 +2140,12 @@ __device__ __forceinline__ void accumulate_terms_p(double px, double py, double 
     for (int e = a; e < 6; ++e) acc[c++] += J[a] * J[e];
 #pragma unroll
   for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;     // b = -sum(J r): sign applied at solve time
-  {
-    // sqrt(d2) in double without the f64 sqrt sequence (a sixth of this kernel's vector instructions): the f32 root and one
-    // Newton step in f64, s + (d2 - s^2) / (2 s), good to ~1e-14 relative
-    const float sf = __builtin_amdgcn_sqrtf(d2v);
-    double sd = (double)sf;
-    if (sf > 0.f) sd = fma(fma(-sd, sd, (double)d2v), (double)__builtin_amdgcn_rcpf(sf + sf), sd);
-    acc[27] += sd;
-  }
-  acc[28] += 1.0;
+  if (COUNT) acc[28] += 1.0;
 }
-__device__ __forceinline__ void accumulate_terms(const double* M, const float4 s4, const float4 q4, const float4 n4, float d2v, double* acc) {
+__device__ __forceinline__ void accumulate_terms(const double* M, const float4 s4, const float4 q4, const float4 n4, double* acc) {
   double px, py, pz;
   transform_point(M, s4, px, py, pz);
-  accumulate_terms_p(px, py, pz, q4, n4, d2v, acc);
+  accumulate_terms_p(px, py, pz, q4, n4, acc);
 }
 // Block reduction of kAccCols-3 = 29 doubles; thread 0 ends up with the totals in acc[].
 // v of the lanes a DPP control reads from, 0.0 where the control has no source lane or the row is masked off
@@ -2236,7 +2234,7 @@ __device__ __forceinline__ void accumulate_block(const IcpDev& b, PairState* st,
       const uint32_t key = __float_as_uint(d);
       if (key < 0x7f800000u) {
         const uint32_t bin = key >> kHistShift;
-        if (bin < qbin) accumulate_terms(Mc, s4, q4, n4, d, acc);
+        if (bin < qbin) accumulate_terms(Mc, s4, q4, n4, acc);
         else boundary = bin == qbin;
       }
     }
@@ -2295,12 +2293,19 @@ __global__ __launch_bounds__(kAccThreads) void accumulate(IcpDev b, int nblk) {
 // accumulate_listed in the roles of nn_validate and of iteration_sums' listed matches.
 // Exactness: the same matches, the same distances, the same kept set as the separate passes; only the order in which the
 // 29 sums are added differs (1e-16 relative), and it is a fixed order -- the result is reproducible bit for bit.
-__device__ __forceinline__ void emit_record(const IcpDev& b, size_t segbase, int& wcount, bool band, const float4 s, float d, int j) {
-  const unsigned long long bm = __ballot(band);
+// number of set bits of `mask` below this lane (v_mbcnt_lo / _hi: two instructions, no lane mask to build and AND)
+__device__ __forceinline__ uint32_t rank_below(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// segbase: wave-uniform (the stores take the scalar base + 32-bit lane offset form)
+// bm: the wave's ballot of `band`
+__device__ __forceinline__ void emit_record(const IcpDev& b, size_t segbase, int& wcount, bool band, unsigned long long bm, const float4 s, float d, int j) {
   if (band) {
-    const size_t at = segbase + wcount + __popcll(bm & ((1ull << (threadIdx.x & 63)) - 1ull));
-    b.rec_a[at] = make_float4(s.x, s.y, s.z, d);
-    b.rec_j[at] = j;
+    const uint32_t k = rank_below(bm);
+    char* __restrict__ ra = reinterpret_cast<char*>(b.rec_a + segbase + wcount);
+    char* __restrict__ rj = reinterpret_cast<char*>(b.rec_j + segbase + wcount);
+    *reinterpret_cast<float4*>(ra + k * 16u) = make_float4(s.x, s.y, s.z, d);
+    *reinterpret_cast<int32_t*>(rj + k * 4u) = j;
   }
   wcount += (int)__popcll(bm);
 }
@@ -2320,6 +2325,9 @@ __global__ __launch_bounds__(kNnThreads, NABO ? 4 : 1) void nn_certify_acc(IcpDe
   double Mc[12];                         // read before the first store: scalar loads, held in SGPRs (see nn_ball_lds)
 #pragma unroll
   for (int k = 0; k < 12; ++k) Mc[k] = st->M[k];
+  // ... but the translation in VGPRs: fma(M[2], z, M[3]) with both M's in SGPRs is a move into a VGPR pair + v_fmac per coordinate
+  // and point (one scalar operand per instruction); with the addend in a VGPR it is the one v_fma_f64
+  asm volatile("" : "+v"(Mc[3]), "+v"(Mc[7]), "+v"(Mc[11]));
   const Pot pot = {(float)st->pot_a, (float)st->pot_b, 0.f, 0.f};
   const int band_lo = st->band_lo, band_hi = st->band_hi;      // band_lo = 0, band_hi = -1: no prediction, nothing summed or recorded
   __shared__ uint32_t s_hist[kHistBins];
@@ -2338,7 +2346,7 @@ __global__ __launch_bounds__(kNnThreads, NABO ? 4 : 1) void nn_certify_acc(IcpDe
   const char* __restrict__ idxb = reinterpret_cast<const char*>(b.idx + so);
   const char* __restrict__ mbb = reinterpret_cast<const char*>(b.mb + so);
   char* __restrict__ d2b = reinterpret_cast<char*>(b.d2 + so);
-  auto ld_s = [&](int k) { const float3 v = *reinterpret_cast<const float3*>(srcb + (uint32_t)k * 12u); return make_float4(v.x, v.y, v.z, 0.f); };
+  auto ld_s = [&](int k) { const float3 v = *reinterpret_cast<const float3*>(srcb + __umul24((uint32_t)k, 12u)); return make_float4(v.x, v.y, v.z, 0.f); };   // (k < 2^24; the 32-bit multiply is a quarter-rate instruction)
   auto ld_l = [&](int k) { return *reinterpret_cast<const float*>(lbb + (uint32_t)k * 4u); };
   auto ld_j = [&](int k) { return *reinterpret_cast<const int*>(idxb + (uint32_t)k * 4u); };
   auto ld_m = [&](int k) { return *reinterpret_cast<const uint32_t*>(mbb + (uint32_t)k * 4u); };
@@ -2346,10 +2354,11 @@ __global__ __launch_bounds__(kNnThreads, NABO ? 4 : 1) void nn_certify_acc(IcpDe
   auto st_d = [&](int k, float v) { *reinterpret_cast<float*>(d2b + (uint32_t)k * 4u) = v; };
   const float r_need = 0.9f * sqrtf(st->rcap2);     // a hard query's bound must stay well above the quantile
   uint32_t min_lb = 0xffffffffu;
-  const int seg = blk * (kNnThreads / 64) + (int)(threadIdx.x >> 6);               // this wave's segments: 64 * ITEMS slots each
+  // this wave's segments: 64 * ITEMS slots each (the wave's number read into an SGPR: the segment bases below are scalars)
+  const int seg = blk * (kNnThreads / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const size_t recbase = (size_t)pair * 2 * b.bl_stride + (size_t)seg * (64 * ITEMS);
   char* __restrict__ dsegb = reinterpret_cast<char*>(b.dlist + (size_t)pair * b.dl_stride + (size_t)seg * (64 * ITEMS));
-  int nrec = 0, ndef = 0;
+  int nrec = 0, ndef = 0, nkept = 0;
   uint32_t nabo_failed = 0;
   double acc[29];
 #pragma unroll
@@ -2367,11 +2376,13 @@ __global__ __launch_bounds__(kNnThreads, NABO ? 4 : 1) void nn_certify_acc(IcpDe
   float4 s_2 = ld_s(ic);
   if (SHADOW) { m_2 = ld_m(ic); l_2 = 0.f; j_2 = 0; }
   else { l_2 = ld_l(ic); j_2 = ld_j(ic); }
-  const bool summing = band_lo > 0;                 // no prediction: the normals are not needed, the pass only certifies
   float4 t_1 = ld_t(tqb, j_1);
-  float4 n_1 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (summing) n_1 = ld_t(tnb, j_1);
-  for (int it = 0; it < ITEMS; ++it) {
+  float4 n_1 = ld_t(tnb, j_1);
+  // One round of 256 points.  GATHER / STREAM: whether the round still issues the gathers of the next round and the stream loads of
+  // the round after it -- compile-time flags (the last two rounds are written out after the loop), so that inside the loop the
+  // pipeline registers are plainly overwritten: as run-time conditions every guarded load kept its old value alive and cost a
+  // register copy per round.
+  auto round = [&](const int it, auto GATHER, auto STREAM) {
     const int i = base + it * kNnThreads + threadIdx.x;
     bool hard = false, fail = false, band = false;
     const float4 s = s_1;
@@ -2381,22 +2392,24 @@ __global__ __launch_bounds__(kNnThreads, NABO ? 4 : 1) void nn_certify_acc(IcpDe
     s_1 = s_2;
     if (SHADOW) { l_1 = shadow_bound(m_2); j_1 = shadow_match(m_2); }
     else { l_1 = l_2; j_1 = j_2; }
-    if (it + 1 < ITEMS) { t_1 = ld_t(tqb, j_1); if (summing) n_1 = ld_t(tnb, j_1); }
-    if (it + 2 < ITEMS) {
+    // (the normals are gathered in the one iteration without a prediction too: a branch around the load costs its register copies
+    // in every other)
+    if (GATHER.value) { t_1 = ld_t(tqb, j_1); n_1 = ld_t(tnb, j_1); }
+    if (STREAM.value) {
       ic = min(i + 2 * kNnThreads, ns - 1);
       s_2 = ld_s(ic);
       if (SHADOW) m_2 = ld_m(ic);
       else { l_2 = ld_l(ic); j_2 = ld_j(ic); }
     }
     float d1 = 0.f;
-    if (i < ns) {
-      double px, py, pz;
-      transform_point(Mc, s, px, py, pz);
-      const float qx = (float)px, qy = (float)py, qz = (float)pz;
-      // as nn_certify; |s| by the hardware root (1 ulp: bound_now's slack of 1e-4 of the potential covers a million of those)
-      const float Lp = NABO ? 0.f : bound_now(l, pot_at(pot, __builtin_amdgcn_sqrtf(fmaf(s.z, s.z, fmaf(s.y, s.y, s.x * s.x)))));
-      fail = true;
-      if (NABO) {
+    unsigned long long m_fail = 0, m_band = 0, m_hard = 0;    // the wave's ballots of fail / band / hard
+    if (NABO) {
+      bool keep = false;
+      if (i < ns) {
+        double px, py, pz;
+        transform_point(Mc, s, px, py, pz);
+        const float qx = (float)px, qy = (float)py, qz = (float)pz;
+        fail = true;
         // the traversal certificate of the libnabo walk (nn_certify<., true>, with its expression and its |s|): the query keeps
         // its id -- by the same walk -- and only its distance to that id is recomputed
         const float Pn = pot_at(pot, norm3(s.x, s.y, s.z));
@@ -2407,46 +2420,73 @@ __global__ __launch_bounds__(kNnThreads, NABO ? 4 : 1) void nn_certify_acc(IcpDe
           const int bin = (int)(__float_as_uint(d1) >> kHistShift);
           atomicAdd(&s_hist[bin], 1u);
           fail = false;
-          if (bin < band_lo) accumulate_terms_p(px, py, pz, t, n, d1, acc);
+          if (bin < band_lo) { accumulate_terms_p<false>(px, py, pz, t, n, acc); keep = true; }
           else band = bin <= band_hi;
         }
-      } else if (isfinite(qx) && isfinite(qy) && isfinite(qz) && Lp > 0.f) {
-        if (l > 0.f && j >= 0) {
-          d1 = dist2(t, qx, qy, qz);
-          if (d1 < Lp * Lp) {                       // still the unique nearest neighbour: exact, no search
-            st_d(i, d1);
-            const int bin = (int)(__float_as_uint(d1) >> kHistShift);
-            atomicAdd(&s_hist[bin], 1u);
-            fail = false;
-            if (bin < band_lo) accumulate_terms_p(px, py, pz, t, n, d1, acc);      // below every bin the quantile can fall in: kept
-            else band = bin <= band_hi;                                            // the quantile decides: finalize
-          }
-        } else if (l < 0.f && Lp >= r_need) {       // still provably farther than the trimming radius
-          const float lb2 = Lp * Lp;
-          st_d(i, lb2);
-          atomicAdd(&s_hist[__float_as_uint(lb2) >> kHistShift], 1u);
-          min_lb = min(min_lb, __float_as_uint(lb2));
-          hard = true;
-          fail = false;
-        }
+      }
+      nkept += (int)__popcll(__ballot(keep));        // (counted where the whole wave is: an update inside the branches would be per lane)
+    } else {
+      // Every predicate of the round as a WAVE MASK: the ballots of the single compares (a compare's own scalar result) combined
+      // by scalar ANDs, over values all lanes have (the loads are clamped to the pair's last point); a lane's own predicate is
+      // its bit of the mask (inverse ballot: no instruction).  As nested branches each of fail / band / hard was a boolean carried
+      // through the branches in a VGPR and compared again for its ballot, and the kept count an add per lane.
+      const auto B = [](bool p) { return (unsigned long long)__builtin_amdgcn_ballot_w64(p); };
+      const auto P = [](unsigned long long m) { return (bool)__builtin_amdgcn_inverse_ballot_w64(m); };
+      double px, py, pz;
+      transform_point(Mc, s, px, py, pz);
+      const float qx = (float)px, qy = (float)py, qz = (float)pz;
+      // as nn_certify; |s| by the hardware root (1 ulp: bound_now's slack of 1e-4 of the potential covers a million of those)
+      const float Lp = bound_now(l, pot_at(pot, __builtin_amdgcn_sqrtf(fmaf(s.z, s.z, fmaf(s.y, s.y, s.x * s.x)))));
+      const unsigned long long m_inr = B(i < ns);
+      const unsigned long long m_pos = m_inr & B(Lp > 0.f);
+      const unsigned long long m_has = B(l > 0.f) & B(j >= 0);
+      d1 = dist2(t, qx, qy, qz);
+      // still the unique nearest neighbour: exact, no search.  (A query with a non-finite coordinate has a non-finite d1: the
+      // compare fails, as the explicit test did.)
+      const unsigned long long m_ok = m_pos & m_has & B(d1 < Lp * Lp);
+      // still provably farther than the trimming radius.  All three coordinates finite <=> 0 * qx + 0 * qy + 0 * qz == 0 (inf and NaN
+      // give NaN): four instructions; isfinite is a class compare whose ballot costs a select and a compare more, per coordinate
+      const float zq = fmaf(qz, 0.f, fmaf(qy, 0.f, qx * 0.f));
+      m_hard = m_pos & B(zq == 0.f) & ~m_has & B(l < 0.f) & B(Lp >= r_need);
+      m_fail = m_inr & ~(m_ok | m_hard);
+      const int bin = (int)(__float_as_uint(d1) >> kHistShift);
+      const unsigned long long m_keep = m_ok & B(bin < band_lo);          // below every bin the quantile can fall in: kept
+      m_band = m_ok & ~m_keep & B(bin <= band_hi);                        // the quantile decides: finalize
+      nkept += (int)__popcll(m_keep);                                     // (a scalar count, no f64 add per lane)
+      fail = P(m_fail); band = P(m_band); hard = P(m_hard);
+      if (P(m_ok)) {
+        st_d(i, d1);
+        atomicAdd(&s_hist[bin], 1u);
+      }
+      if (P(m_keep)) accumulate_terms_p<false>(px, py, pz, t, n, acc);
+      if (hard) {
+        const float lb2 = Lp * Lp;
+        st_d(i, lb2);
+        atomicAdd(&s_hist[__float_as_uint(lb2) >> kHistShift], 1u);
+        min_lb = min(min_lb, __float_as_uint(lb2));
       }
     }
     if (NABO) {
       if (fail) nabo_failed |= 1u << it;             // to the class lists after the loop (nabo_list_append)
+      m_band = __ballot(band);
     } else {   // failing certificates: the wave's own segment of dlist, in query order
-      const unsigned long long dm = __ballot(fail);
-      if (fail) *reinterpret_cast<int*>(dsegb + (uint32_t)(ndef + (int)__popcll(dm & ((1ull << lane) - 1ull))) * 4u) = i;
-      ndef += (int)__popcll(dm);
+      if (fail) *reinterpret_cast<int*>(dsegb + ((uint32_t)ndef + rank_below(m_fail)) * 4u) = i;
+      ndef += (int)__popcll(m_fail);
     }
-    emit_record(b, recbase, nrec, band, s, d1, j);
-    const unsigned long long hm = __ballot(hard);
+    emit_record(b, recbase, nrec, band, m_band, s, d1, j);
+    const unsigned long long hm = m_hard;
     if (hm) {                                       // rare: lower-bounded queries keep their global list
       uint32_t basepos = 0;
       if (lane == 0) basepos = atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
       basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);   // lane 0 did the atomic
       if (hard) b.hlist[so + basepos + __popcll(hm & ((1ull << lane) - 1ull))] = i;
     }
-  }
+  };
+  static_assert(ITEMS >= 2, "the pipeline's last two rounds are written out");
+#pragma unroll 2
+  for (int it = 0; it < ITEMS - 2; ++it) round(it, std::true_type{}, std::true_type{});
+  round(ITEMS - 2, std::true_type{}, std::false_type{});
+  round(ITEMS - 1, std::false_type{}, std::false_type{});
   if (lane == 0) {
     b.gcount[(size_t)pair * b.seg_stride + seg] = (uint32_t)nrec;
     b.dcount[(size_t)pair * b.seg_stride + seg] = ndef;
@@ -2454,6 +2494,7 @@ __global__ __launch_bounds__(kNnThreads, NABO ? 4 : 1) void nn_certify_acc(IcpDe
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) min_lb = min(min_lb, (uint32_t)__shfl_xor((int)min_lb, off, 64));
   if (lane == 0 && min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
+  if (lane == 0) acc[28] = (double)nkept;           // the wave's kept matches (counted in an SGPR)
   block_reduce29(acc, s_red, s_out);                // (its barriers also order the histogram updates before the flush)
   if (threadIdx.x < 29) b.partials[((size_t)pair * b.part_stride + blk) * kAccCols + threadIdx.x] = s_out[threadIdx.x];
   if (NABO) nabo_list_append<ITEMS>(b, st, so, base, ns, nabo_failed, lane);      // (after the sums: their 58 registers are free again)
@@ -2877,7 +2918,7 @@ __device__ __forceinline__ void listed_sums_block(const IcpDev& b, PairState* st
     for (int k = 0; k < kL; ++k) {
       const uint32_t key = __float_as_uint(dd[k]);
       if (e0 + kAccThreads * k < e_end && jj[k] >= 0 && key < 0x7f800000u && (int)(key >> kHistShift) < band_lo)
-        accumulate_terms(st->M, s4[k], q4[k], n4[k], dd[k], acc);
+        accumulate_terms(st->M, s4[k], q4[k], n4[k], acc);
     }
   }
   block_reduce29(acc, s_red, s_out);
@@ -3016,7 +3057,7 @@ __global__ __launch_bounds__(kAccThreads) void accumulate_listed(IcpDev b) {
     }
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
-      if (below[u]) accumulate_terms(Mc, s4[u], q4[u], n4[u], d[u], acc);
+      if (below[u]) accumulate_terms(Mc, s4[u], q4[u], n4[u], acc);
       const unsigned long long bm = __ballot(rec[u]);
       if (rec[u]) {
         const size_t at = segbase + wcount + __popcll(bm & ((1ull << lane) - 1ull));
@@ -3351,7 +3392,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
         for (int k = 0; k < kW; ++k) { q4[k] = b.tq[to + jj[k]]; n4[k] = b.tn[to + jj[k]]; }
 #pragma unroll
         for (int k = 0; k < kW; ++k)
-          if (use[k]) accumulate_terms(st->M, s4[k], q4[k], n4[k], s4[k].w, acc);
+          if (use[k]) accumulate_terms(st->M, s4[k], q4[k], n4[k], acc);
       }
     } else {
       for (int e = threadIdx.x; e < nb; e += blockDim.x) {
@@ -3359,7 +3400,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
         const float4 a = ra[at];
         if (__float_as_uint(a.w) <= limit_key) {
           const int j = max(rj[at], 0);
-          accumulate_terms(st->M, a, b.tq[to + j], b.tn[to + j], a.w, acc);
+          accumulate_terms(st->M, a, b.tq[to + j], b.tn[to + j], acc);
         }
       }
     }
@@ -3527,7 +3568,7 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
     converged = (rd / 4 < 1e-3) && (td / 4 < 1e-2);
   }
   if (converged || it >= b.max_iteration) {                                   // :516-522
-    st->score = exp(-s_tot[27] / kept);
+    // (the score of this iteration's kept matches, :518-521, is formed by final_score once the batch has left its loop)
     // result = T_mean * T_iter * T_mean^-1 * guess  (:527), written column-major
     double Tm[16] = {1, 0, 0, st->mu[0], 0, 1, 0, st->mu[1], 0, 0, 1, st->mu[2], 0, 0, 0, 1};
     double Rm[16];
@@ -3544,6 +3585,47 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
            (fstamp[5] - fstamp[4]) * 0.01, (fstamp[6] - fstamp[5]) * 0.01, (tend - fstamp[6]) * 0.01, (tend - fstamp[0]) * 0.01);
   }
 #endif
+}
+
+// The score of the iteration an alignment left the loop with (icp_fast.cc:516-522: exp(-mean distance of that iteration's kept
+// matches), formed there and nowhere else): one pass over the pair's distances of that iteration -- `d2` keeps them once the pair is
+// done (every kernel returns on PairState::done) -- with the weights of :497-498, d2 <= limit (finalize's limit_key: keys order like
+// the floats; a lower-bounded query's entry is its bound, which nn_validate keeps above the quantile).  kScoreParts workgroups per
+// pair, each over a fixed range of the pair's points, leave their sums in PairState::score_part; score_fold (the next launch: no
+// fences, no tickets) adds them in order.  The partition and every order of addition are fixed by ns alone.
+__global__ __launch_bounds__(kAccThreads) void final_score(IcpDev b) {
+  const int pair = b.pair_base + (int)(blockIdx.x / kScoreParts), part = (int)(blockIdx.x % kScoreParts);
+  PairState* st = &b.state[pair];
+  __shared__ double s_w4[kAccThreads / 64];
+  double s = 0.0;
+  if (st->done && st->status == 0) {                      // (no match: finalize left score = 0, score_fold keeps it)
+    const int ns = st->ns;
+    const int len = ((ns + kScoreParts * kAccThreads - 1) / (kScoreParts * kAccThreads)) * kAccThreads;   // points per part: whole rounds
+    const int lo = part * len, hi = min(ns, lo + len);
+    const uint32_t limit_key = st->limit_key;
+    const float* __restrict__ d2 = b.d2 + (size_t)pair * b.ns_cap;
+    for (int i0 = lo + (int)threadIdx.x; i0 < hi; i0 += 8 * kAccThreads) {
+      float d[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d[k] = d2[min(i0 + k * kAccThreads, hi - 1)];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i0 + k * kAccThreads < hi && __float_as_uint(d[k]) <= limit_key) s += sqrt((double)d[k]);
+    }
+  }
+  s = wave_sum_to_last(s);
+  if ((threadIdx.x & 63) == 63) s_w4[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) st->score_part[part] = ((s_w4[0] + s_w4[1]) + s_w4[2]) + s_w4[3];
+}
+__global__ void score_fold(IcpDev b, int npairs) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= npairs) return;
+  PairState* st = &b.state[b.pair_base + k];
+  if (!st->done || st->status != 0 || st->kept < 1) return;
+  double tot = 0.0;
+  for (int p = 0; p < kScoreParts; ++p) tot += st->score_part[p];
+  st->score = exp(-tot / (double)st->kept);
 }
 
 // Slot-to-slot copy of the uploaded clouds (benchmark replication).

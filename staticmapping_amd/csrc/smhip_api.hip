@@ -1266,6 +1266,13 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
       if (s) return s;
     }
   }
+  // the score of the iteration every pair left the loop with (icp_fast.cc:516-522), from that iteration's distances
+  for (int k = 0; k < nh; ++k) {
+    Half& f = halves[k];
+    Bracket br(h, 3, f.stream);
+    hipLaunchKernelGGL(final_score, dim3(f.np * kScoreParts), dim3(kAccThreads), 0, f.stream, f.d);
+    hipLaunchKernelGGL(score_fold, dim3(ceil_div(f.np, 256)), dim3(256), 0, f.stream, f.d, f.np);
+  }
   s = join();
   if (s) return s;
   // (only batches that ran the ball search with certificates say anything about where its two forms cross)

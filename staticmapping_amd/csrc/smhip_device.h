@@ -20,7 +20,8 @@ constexpr int kAccItemsBatch = 32;
 constexpr int kFinalizeKeyCap = 8192;     // band records whose keys finalize keeps in LDS between its radix-select passes
 constexpr int kFinalizeMaxSeg = 2048;     // record segments (one per producing wave) per pair finalize can index: 4 Mi source points at 32 per
                                           // accumulate thread; the fused path (20 per thread + the listed search's 128 waves) up to 2.4 Mi points
-constexpr int kAccCols = 32;             // 21 (A upper) + 6 (b) + 1 (sum sqrt d2) + 1 (count) padded to 32
+constexpr int kScoreParts = 16;          // workgroups per pair of final_score
+constexpr int kAccCols = 32;             // 21 (A upper) + 6 (b) + 1 (unused: the score is formed once, by final_score) + 1 (count) padded to 32
 constexpr int kMaxGridWords = 1 << 18;   // 32-cell words per pair (8 Mi cells)
 constexpr int kMaxRowWords = (kMaxGridWords >> 5) + 2;   // 32-row words of the row-occupancy bitmap (rows = ny * nz <= kMaxGridWords), + slack for two-word reads
 constexpr int kTgtReduceBlocks = 32;     // partial blocks for the target mean / bbox
@@ -110,6 +111,7 @@ struct PairState {
   uint32_t pad2_;
 
   // outputs
+  double score_part[kScoreParts];   // final_score: the sums of sqrt(d2) over the kept matches of the pair's kScoreParts point ranges
   double score;
   double result[16];     // column-major (Eigen layout)
 };

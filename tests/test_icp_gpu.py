@@ -635,3 +635,38 @@ def test_wave_search_equals_the_per_query_walks(smhip, velo20k, cfg1, cfg2, iter
         if iters == 1:                                       # one search from the same state: the same bits everywhere but the seeds
             assert dl.tobytes() == dw.tobytes(), (s_, int((dl != dw).sum()))
         assert (il != iw).mean() < 0.3
+
+
+def test_fused_pass_without_the_shadow_word(smhip, velo20k, cfg1, cfg2, monkeypatch):
+    """The fused certificate pass streams the 4-byte shadow of (match, bound) when every target of the launch has fewer than 32 767
+    points, and the two arrays themselves otherwise (nn_certify_acc<., false, false>: targets of the size of a submap).  None of the
+    fixtures has such a target, so SMHIP_SHADOW=0 sends the same ragged batch through that form: the shadow's bound is the
+    recorded one rounded towards zero -- a few more certificates fail and are searched -- and everything else must come out the
+    same: iteration counts, kept sets, quantiles, poses to 1e-10 (icp_fast.cc:484-523)."""
+    sm = smhip
+    from staticmapping_amd import synth
+    cases = [cfg2, velo20k, cfg1] * 6
+    cap_s = max(len(c["src"]) for c in cases); cap_t = max(len(c["q"]) for c in cases)
+    guesses = [c.get("guess", np.eye(4)) @ synth.make_pose(t=(0.01 * (k % 3), 0.0, 0.0), rpy_deg=(0, 0, 0.03 * (k % 4))) for k, c in enumerate(cases)]
+    out = {}
+    for name, env in (("shadow", "1"), ("arrays", "0")):
+        monkeypatch.setenv("SMHIP_SHADOW", env)
+        m = sm.IcpFastHip(pair_slots=len(cases), max_source_points=cap_s, max_target_points=cap_t, max_iteration=12, early_exit=0, split_after=1)
+        for s_, c in enumerate(cases):
+            src = np.array(c["src"], dtype=np.float32, copy=True)
+            if s_ % 5 == 1:
+                src[7, 0] = np.nan; src[100, 2] = np.inf
+            m.set_input_source(src, slot=s_); m.set_input_target(c["q"], c["n"], slot=s_)
+        out[name] = m.align_batch(len(cases), guesses)
+        m.close()
+    monkeypatch.delenv("SMHIP_SHADOW")
+    Ra, sca, sta = out["arrays"]; Rs, scs, sts = out["shadow"]
+    assert max(s_["fused_iterations"] for s_ in sta) > 0 and max(s_["fused_iterations"] for s_ in sts) > 0
+    for s_ in range(len(cases)):
+        assert sta[s_]["iterations"] == sts[s_]["iterations"] == 12
+        assert sta[s_]["kept"] == sts[s_]["kept"] and sta[s_]["limit_d2"] == sts[s_]["limit_d2"], (s_, sta[s_], sts[s_])
+        da, dt = sm.se3_error(Ra[s_], Rs[s_])
+        assert da < 1e-10 and dt < 1e-9, (s_, da, dt)
+        assert abs(sca[s_] - scs[s_]) < 1e-11
+    # the rounded bound can only fail more certificates
+    assert sum(s_["searched_queries"] for s_ in sts) >= sum(s_["searched_queries"] for s_ in sta)

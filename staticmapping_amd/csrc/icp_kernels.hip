@@ -3241,6 +3241,18 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   // rows of partials behind the certificate pass's: reference-search mode: accumulate_listed's workgroups; else the listed matches
   // below the band, summed by iteration_sums kListedSumChunk entries per row (deferred_count = the length of the pair's list)
   const int nrows = nblk + (fusedm ? (nabof ? kNaboAccBlocks : (int)((st->deferred_count + (uint32_t)kListedSumChunk - 1u) / (uint32_t)kListedSumChunk)) : 0);
+  // the rows of `partials` this thread folds at the end (every 8th from its group's first): loaded now, so that their latency runs
+  // under the select phases instead of behind the last barrier (rows beyond the first 64 are read there)
+  constexpr int kPrefRows = 8;
+  double pref[kPrefRows];
+  {
+    const double* part = b.partials + (size_t)pair * b.part_stride * kAccCols + (threadIdx.x & 31);
+#pragma unroll
+    for (int u = 0; u < kPrefRows; ++u) {
+      const int k = (int)(threadIdx.x >> 5) + 8 * u;
+      pref[u] = k < nrows ? part[(size_t)k * kAccCols] : 0.0;
+    }
+  }
   const uint32_t* gcount = b.gcount + (size_t)pair * b.seg_stride;
   const float4* ra = b.rec_a + (size_t)pair * 2 * b.bl_stride;
   const int32_t* rj = b.rec_j + (size_t)pair * 2 * b.bl_stride;
@@ -3363,9 +3375,10 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
     // record of a lower bin of the band is below the limit whatever its low bits.)
     const size_t to = (size_t)pair * b.nt_cap;
     if (flat) {
-      // eight records per thread and round, their loads issued level by level (the record, then the matched target point +
-      // normal) instead of one record after the other
-      constexpr int kW = 8;
+      // ten records per thread and round, their loads issued level by level (the record, then the matched target point +
+      // normal) instead of one record after the other.  (Ten: one pair's quantile bin holds ~2 100 records, and with eight
+      // the 30 left over cost a second round -- two more memory levels -- of the 28 us this kernel takes for one pair.)
+      constexpr int kW = 10;
       for (int e0 = threadIdx.x; e0 < nb; e0 += kW * 256) {
         bool use[kW];
         uint32_t pos[kW];
@@ -3413,7 +3426,9 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
     const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
     double s = 0;
     const double* part = b.partials + (size_t)pair * b.part_stride * kAccCols + col;
-    for (int k = grp; k < nrows; k += 8) s += part[(size_t)k * kAccCols];
+#pragma unroll
+    for (int u = 0; u < kPrefRows; ++u) if (grp + 8 * u < nrows) s += pref[u];       // (the same rows in the same order)
+    for (int k = grp + 8 * kPrefRows; k < nrows; k += 8) s += part[(size_t)k * kAccCols];
     s_part[grp][col] = s;
   }
   __syncthreads();

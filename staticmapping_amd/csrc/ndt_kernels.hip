@@ -4,9 +4,9 @@
 //   ndt_voxel_*      VoxelGridCovariance::applyFilter   pclomp/voxel_grid_covariance_omp_impl.hpp:49-370
 //   ndt_derivatives  computeDerivatives + computePointDerivatives + updateDerivatives
 //                                                       pclomp/ndt_omp_impl.hpp:180-284, 397-438, 483-535
-//   ndt_reduce       the per-thread partial fold        pclomp/ndt_omp_impl.hpp:272-281
-// The Newton / More-Thuente driver (ndt_omp_impl.hpp:81-171, 757-916) is 6-vector host code in
-// smhip_ndt_api.hip.  As in the reference the per-neighbour math is float and the accumulation double.
+//   ndt_ctl_step     the fold of the partial sums (:272-281) + the Newton / More-Thuente driver
+//                                                       pclomp/ndt_omp_impl.hpp:81-171, 757-916
+// As in the reference the per-neighbour math is float and the accumulation double.
 #pragma once
 #include "smhip_device.h"
 
@@ -14,8 +14,6 @@ namespace smhip {
 
 constexpr int kNdtMaxWords = 1 << 20;        // 32 voxels per word: up to 32 Mi voxels in the dense box
 constexpr int kNdtDerivThreads = 256;
-constexpr int kNdtDerivCols = 44;            // score + 6 gradient + 36 hessian + pair count
-constexpr int kNdtMaxDerivBlocks = 2048;
 
 struct NdtVoxel {          // 64 B record of one searchable voxel (n >= min_points)
   double mean[3];          // Leaf::mean_  (double)
@@ -51,8 +49,8 @@ struct NdtDev {
   float4* vpts;            // [nt] points sorted by voxel
   NdtVoxel* vox;           // [nt] one record per occupied voxel
   double* icovd;           // [nt][6] Leaf::icov_ in double: xx xy xz yy yz zz (stock PCL path reads these)
-  double* partials;        // [kNdtMaxDerivBlocks][kNdtDerivCols]
-  double* out;             // [kNdtDerivCols]
+  double* partials;        // [ceil(ns_cap / 256)][kNdtCols]
+  double* out;             // [kNdtOutCols]
   int32_t key_off;         // where this table's (voxel code, point) pairs start in the batch's sort arrays
   int32_t pad_;
 };
@@ -293,231 +291,767 @@ __device__ __forceinline__ void ndt_voxel_stats_one(const NdtDev& d, int v, int 
 // R = float restates pclomp (ndt_omp_impl.hpp: Matrix<float,4,6> math); R = double restates stock
 // pcl::NormalDistributionsTransform (PCL 1.8.1 ndt.hpp: the same formulas on Vector3d / Matrix3d), which
 // registrators/ndt_gicp.cc:38-41,84-89 uses.
-// ONE = the grid has a thread for every source point (always, up to 524 288 points): the per-point sums of the reference
-// (score_pt, g_pt, h_pt: summed per point first, then added to the totals) are then the thread's totals themselves and
-// need no registers of their own -- 43 doubles fewer per lane.
-// grid = (workgroups per table, evaluations): evaluation e is pose poses[e] against table devs[active[e]] -- the K Aligns of a
-// batch advance in lock-step on the host and every round's evaluations are ONE launch.
-// A round of at most kNdtArgPoses evaluations (every round of a single Align) carries its poses and tables in the launch's own
-// arguments: no copy to the device before the launch.  Larger rounds read them from device arrays.
-constexpr int kNdtArgPoses = 4;
-struct NdtPoseArgs {
-  int32_t n;
-  int32_t active[kNdtArgPoses];
-  int32_t pad[3];
-  NdtPose p[kNdtArgPoses];
+//
+// Shape of the kernel.  A wave owns 64 source points (four granules of 16 Morton-consecutive points taken a quarter of the cloud
+// apart, so every wave gets the cloud's average neighbour count); its four phases meet no other wave until the final fold.
+//   A  (a lane per POINT): transform, the occupancy words of the nine (z, y) rows around its voxel (a row's three cells lie in
+//      at most two words: 18 loads in flight), one (point, voxel slot) entry per OCCUPIED neighbour voxel appended to the wave's
+//      list in LDS (order: point, then the reference's z, y, x neighbour order).
+//   B1 (a lane per ENTRY): the entries the reference's radiusSearch would return -- voxel in the centroid kd-tree, centroid within
+//      resolution_ of the point (:235; KDTREE mode == the 27-stencil filtered by centroid distance) -- kept, compacted in place;
+//      a dense submap has 8-10 occupied voxels around a point of which 3 pass.  16-byte gathers (centroid + n), four in flight.
+//   B2 (a lane per POINT again, over its kept voxels): the 48-byte rest of the voxel record (the hash-probed gather), then only what
+//      depends on the voxel: x' = x_trans - mean, v = C x', e = d1 d2 exp(-d2/2 x'.v) with the reference's validity rule
+//      (:497-508), and the four sums  S0 = sum score_inc,  sv = sum e v,  SC = sum e C,  W = sum e v v^T.
+//   C  (a lane per POINT): updateDerivatives' (:511-529) gradient and Hessian terms are linear in those sums --
+//         g = J^T sv,   H = J^T (SC - d2 W) J + [sv . H_ij],   J = [I | A(point)] (computePointDerivatives, :397-438)
+//      -- so the Jacobian / Hessian algebra runs once per point instead of once per (point, voxel) pair: the same real numbers
+//      as the reference's per-pair float evaluation, associated differently (and the Hessian's upper triangle only: H(i, j)
+//      and H(j, i) are one real number whose two float evaluations in the reference differ by rounding; the control kernel mirrors it).
+//   fold: the 32 columns of a wave with v_permlane32_swap / v_permlane16_swap (two columns per instruction pair: after the swap
+//      one add forms lanes l + l+32 of column k in the low half and of column k+16 in the high half), then DPP row rotations --
+//      170 instructions instead of 44 columns x 6 DPP steps -- then the workgroup's four waves through LDS.
+// Arithmetic: per-voxel and per-point math in R (float as pclomp, double as stock PCL), a point's few terms summed in R, every
+// sum beyond the point in double.  (The reference adds each float term to double sums at once; summing a point's three or so
+// float terms in float first is the same order of rounding as the terms' own arithmetic, and nothing grows with the cloud.)
+// A list longer than the LDS window (kCap entries: more than 16 occupied neighbours per point on average) is worked off in
+// windows.  Every order is fixed by the data alone, so an evaluation is bit-reproducible, alone or in a batch.
+constexpr int kNdtCols = 32;               // a row of partials: score, 6 gradient, 21 Hessian (upper triangle, row-major), pair count, 3 zeros
+constexpr int kNdtOutCols = 44;            // a folded evaluation: score + 6 gradient + 36 Hessian (mirrored) + pair count
+
+// sum of v over lanes {l, l + 32} of column a (result in lanes 0..31) and of column b (lanes 32..63)
+__device__ __forceinline__ double swap32_add(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// the same across the rows of 16 lanes: rows 0 and 2 get column a (rows 0+1, 2+3), rows 1 and 3 column b
+__device__ __forceinline__ double swap16_add(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_row(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// 32 columns per lane -> column sums over the wave: on return lane 16 r (r = 0..3) holds in acc[k], k = 0..7, the wave's sum of
+// column k + 8 r
+__device__ __forceinline__ void wave_fold32(double* acc) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = swap32_add(acc[k], acc[k + 16]);      // lanes 0..31: column k, lanes 32..63: column k + 16
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = swap16_add(acc[k], acc[k + 8]);        // rows 0..3: columns k, k + 8, k + 16, k + 24
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    acc[k] += dpp_row<0x128>(acc[k]);      // row_ror 8, 4, 2, 1: every lane of a row ends with the row's sum
+    acc[k] += dpp_row<0x124>(acc[k]);
+    acc[k] += dpp_row<0x122>(acc[k]);
+    acc[k] += dpp_row<0x121>(acc[k]);
+  }
+}
+
+// (pointers read from a table are generic to the compiler -- flat loads, which also wait on the LDS counter; these are global)
+template <typename T> using gptr = const T __attribute__((address_space(1)))*;
+template <typename T> __device__ __forceinline__ gptr<T> as_global(const T* p) { return (gptr<T>)p; }
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// A wave's LDS: its 64 transformed points, one window of its entry list, a kept-voxel count per point
+constexpr int kNdtPairCap = 1024;                   // entries per window and wave
+struct NdtDerivShared {
+  float4 t[kNdtDerivThreads];
+  uint32_t pair[kNdtDerivThreads / 64][kNdtPairCap];            // point (6 bits) << 24 | voxel slot (24 bits)
+  uint32_t cnt[kNdtDerivThreads];
+  double red[kNdtDerivThreads / 64][kNdtCols];
 };
 
-template <typename R, bool ONE>
-__device__ __forceinline__ void ndt_derivatives_body(const NdtDev& d, const NdtPose& P) {
+struct VoxRaw { u32x4 a, b, c; };          // the first three 16-byte quarters of an NdtVoxel: mean[0..1] | mean[2], icov[0..1] | icov[2..5]  (the fourth: centroid, n)
+__device__ __forceinline__ VoxRaw load_voxel_raw(const NdtVoxel* base, uint32_t slot) {
+  const gptr<u32x4> q = (gptr<u32x4>)(base + slot);
+  VoxRaw v;
+  v.a = q[0]; v.b = q[1]; v.c = q[2];
+  return v;
+}
+
+// inclusive prefix sum over the wave (DPP: inside rows of 16 lanes, then the row totals carried across)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);     // row_shr 1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);     // row_shr 2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);     // row_shr 4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);     // row_shr 8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast 15 into rows 1, 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast 31 into rows 2, 3
+  return v;
+}
+
+// The granule assignment depends on the slot's own point count only (never on the batch a launch carries), so an evaluation's
+// sums have one order.
+template <typename R, bool HESS>
+__device__ __forceinline__ void ndt_derivatives_body(const NdtDev& d, const NdtPose& P, double* __restrict__ row_out, NdtDerivShared& sh) {
   constexpr bool kDouble = sizeof(R) == 8;
+  constexpr int kCap = kNdtPairCap;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4* const s_t = sh.t + 64 * wave;
+  uint32_t* const s_pair = sh.pair[wave];
+  uint32_t* const s_cnt = sh.cnt + 64 * wave;
+  const gptr<u32x2> words = (gptr<u32x2>)d.words;
+  const gptr<double> icovd = as_global(d.icovd);
   const NdtGridInfo* g = d.info;
-  double acc[43];
-#pragma unroll
-  for (int k = 0; k < 43; ++k) acc[k] = 0.0;
-  double pairs = 0;
-  __shared__ uint32_t s_nb[27][kNdtDerivThreads];          // per-thread list of occupied neighbour voxels (slots)
+  const int div0 = g->div_b[0], div1 = g->div_b[1], div2 = g->div_b[2], wx = g->wx;
+  const float inv = g->inv;
+  const float mb0 = (float)g->min_b[0], mb1 = (float)g->min_b[1], mb2 = (float)g->min_b[2];
   const R gd2 = kDouble ? (R)P.d2d : (R)P.d2;
-  for (int i = blockIdx.x * kNdtDerivThreads + threadIdx.x; i < d.ns; i += gridDim.x * kNdtDerivThreads) {
-    const float4 s = d.src[i];
-    if (!(isfinite(s.x) && isfinite(s.y) && isfinite(s.z))) continue;
+  double accd[kNdtCols];
+#pragma unroll
+  for (int k = 0; k < kNdtCols; ++k) accd[k] = 0.0;
+#ifdef NDT_TIMING
+  unsigned long long tm[6];
+  tm[0] = tm[1] = tm[2] = tm[3] = tm[4] = wall_clock64();
+  const unsigned long long cyc0 = __builtin_readcyclecounter();
+#define NDT_STAMP(k) tm[k] = wall_clock64()
+#else
+#define NDT_STAMP(k)
+#endif
+  const int nwaves_own = (d.ns + 63) >> 6;                   // waves the slot's own source needs
+  const int gw = blockIdx.x * (kNdtDerivThreads / 64) + wave;
+  if (gw < nwaves_own) {
+    // ---- phase A: the point
+    const int i = (lane & 15) + 16 * (gw + (lane >> 4) * nwaves_own);
+    bool live = i < d.ns;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) { const f32x4 v = ((gptr<f32x4>)d.src)[i]; s = make_float4(v.x, v.y, v.z, v.w); }
+    live = live && isfinite(s.x) && isfinite(s.y) && isfinite(s.z);
     // pcl::transformPointCloud with the float final_transformation_
     const float tx = P.T[0] * s.x + P.T[1] * s.y + P.T[2] * s.z + P.T[3];
     const float ty = P.T[4] * s.x + P.T[5] * s.y + P.T[6] * s.z + P.T[7];
     const float tz = P.T[8] * s.x + P.T[9] * s.y + P.T[10] * s.z + P.T[11];
-    // voxel of the transformed point; KDTREE radius search == 27-stencil filtered by centroid distance
-    const int c0 = (int)(floorf(tx * g->inv) - (float)g->min_b[0]);
-    const int c1 = (int)(floorf(ty * g->inv) - (float)g->min_b[1]);
-    const int c2 = (int)(floorf(tz * g->inv) - (float)g->min_b[2]);
-    // point gradient (4x6 float): identity + 8 angular entries, :397-412
-    R pg[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-      pg[r] = kDouble ? (R)(P.j_angd[r][0] * (double)s.x + P.j_angd[r][1] * (double)s.y + P.j_angd[r][2] * (double)s.z)
-                      : (R)(P.j_ang[r][0] * s.x + P.j_ang[r][1] * s.y + P.j_ang[r][2] * s.z);
-    R ph[15];
-    if (P.compute_hessian) {
-#pragma unroll
-      for (int r = 0; r < 15; ++r)                                                                             // :416
-        ph[r] = kDouble ? (R)(P.h_angd[r][0] * (double)s.x + P.h_angd[r][1] * (double)s.y + P.h_angd[r][2] * (double)s.z)
-                        : (R)(P.h_ang[r][0] * s.x + P.h_ang[r][1] * s.y + P.h_ang[r][2] * s.z);
+    int c0 = 0, c1 = 0, c2 = 0;
+    if (live) {
+      c0 = (int)(floorf(tx * inv) - mb0); c1 = (int)(floorf(ty * inv) - mb1); c2 = (int)(floorf(tz * inv) - mb2);
+      // (far outside the box every row test below fails; keep the row arithmetic inside int range)
+      live = !g->status && c0 >= -1 && c0 <= div0 && c1 >= -1 && c1 <= div1 && c2 >= -1 && c2 <= div2;
     }
-    double pt_sums[ONE ? 1 : 43];
-    double* const pt = ONE ? acc : pt_sums;                 // [0] score, [1..6] gradient, [7..42] hessian of this point
-    if (!ONE) {
-#pragma unroll
-      for (int k = 0; k < 43; ++k) pt_sums[ONE ? 0 : k] = 0.0;
-    }
-    // The occupied voxels among the 27 neighbours, in the z, y, x order of the reference's loop.  The occupancy words of the
-    // nine (z, y) rows are loaded together (a row's three cells lie in at most two words) and the slots parked in LDS; the
-    // loop below then visits only the occupied neighbours (3.3 on average) instead of waiting for a word lookup per cell.
-    int nnb = 0;
-    {
-      const int div0 = g->div_b[0], div1 = g->div_b[1], div2 = g->div_b[2];
-      const int xa = min(max(c0 - 1, 0), div0 - 1), xb = min(max(c0 + 1, 0), div0 - 1);
+    s_t[lane] = make_float4(tx, ty, tz, 0.f);
+    s_cnt[lane] = 0u;
+    const int xa = min(max(c0 - 1, 0), div0 - 1), xb = min(max(c0 + 1, 0), div0 - 1);
+    uint32_t off = 0, total = 0;
+    // the point's sums over its voxels
+    R S0 = 0, sv0 = 0, sv1 = 0, sv2 = 0, SCxx = 0, SCxy = 0, SCxz = 0, SCyy = 0, SCyz = 0, SCzz = 0, Wxx = 0, Wxy = 0, Wxz = 0, Wyy = 0, Wyz = 0, Wzz = 0;
+    uint32_t npairs_lane = 0;
+    const double tdx = (double)tx, tdy = (double)ty, tdz = (double)tz;
+    NDT_STAMP(1);
+    for (uint32_t wbase = 0; wbase == 0 || wbase < total; wbase += kCap) {
+      // the occupancy words of the nine rows (re-read for every further window of a crowded wave: L2 hits)
       uint2 wa[9], wb[9];
-      bool rowok[9];
+      uint32_t rowok = 0;
+      int c1w = c1, c2w = c2;
+      asm volatile("" : "+v"(c1w), "+v"(c2w));            // (keeps the 18 row addresses out of registers across phase B)
 #pragma unroll
       for (int r = 0; r < 9; ++r) {
-        const int z = c2 + r / 3 - 1, y = c1 + r % 3 - 1;
-        rowok[r] = z >= 0 && z < div2 && y >= 0 && y < div1;
-        const int rowbase = rowok[r] ? (z * div1 + y) * g->wx : 0;
-        wa[r] = d.words[rowbase + (xa >> 5)];
-        wb[r] = d.words[rowbase + (xb >> 5)];
+        const int z = c2w + r / 3 - 1, y = c1w + r % 3 - 1;
+        const bool ok = live && z >= 0 && z < div2 && y >= 0 && y < div1;
+        rowok |= ok ? 1u << r : 0u;
+        const int rowbase = ok ? (z * div1 + y) * wx : 0;
+        { const u32x2 v = words[rowbase + (xa >> 5)]; wa[r] = make_uint2(v.x, v.y); }
+        { const u32x2 v = words[rowbase + (xb >> 5)]; wb[r] = make_uint2(v.x, v.y); }
       }
+      if (wbase == 0) {
+        uint32_t nnb = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r)
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int x = c0 + dx;
+            const uint2 wd = (x >> 5) == (xa >> 5) ? wa[r] : wb[r];
+            nnb += (((rowok >> r) & 1u) && x >= 0 && x < div0 && ((wd.x >> (x & 31)) & 1u)) ? 1u : 0u;
+          }
+        NDT_STAMP(2);
+        const uint32_t incl = wave_incl_scan_u32(nnb);
+        off = incl - nnb;
+        total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (the wave's earlier reads of its window are done)
+      uint32_t k = off - wbase;                            // position in this window (wraps below it: the unsigned compare drops those)
 #pragma unroll
       for (int r = 0; r < 9; ++r)
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
           const int x = c0 + dx;
-          if (!rowok[r] || x < 0 || x >= div0) continue;
           const uint2 wd = (x >> 5) == (xa >> 5) ? wa[r] : wb[r];
-          if (!((wd.x >> (x & 31)) & 1u)) continue;
-          s_nb[nnb++][threadIdx.x] = wd.y + __popc(wd.x & ((1u << (x & 31)) - 1u));
-        }
-    }
-    // (float arithmetic: the next neighbour's record is fetched while this one is processed; the double variant has no
-    // registers to spare for that)
-    uint32_t slot_next = nnb > 0 ? s_nb[0][threadIdx.x] : 0u;
-    NdtVoxel vx_next;
-    if (!kDouble && nnb > 0) vx_next = d.vox[slot_next];
-    for (int kn = 0; kn < nnb; ++kn) {
-      {
-        {
-          const uint32_t slot = slot_next;
-          NdtVoxel vx;
-          if (kDouble) vx = d.vox[slot]; else vx = vx_next;
-          if (kn + 1 < nnb) {
-            slot_next = s_nb[kn + 1][threadIdx.x];
-            if (!kDouble) vx_next = d.vox[slot_next];
-          }
-          if (vx.n >= 0 && vx.n < d.min_points) continue;            // not in the centroid kd-tree
-          const float ex = tx - vx.centroid[0], ey = ty - vx.centroid[1], ez = tz - vx.centroid[2];
-          if (ex * ex + ey * ey + ez * ez > P.res2) continue;        // radiusSearch(x_trans, resolution_), :235
-          pairs += 1.0;
-          // x_trans - mean in double, then float (:253, :490)
-          const R u0 = (R)((double)tx - vx.mean[0]), u1 = (R)((double)ty - vx.mean[1]), u2 = (R)((double)tz - vx.mean[2]);
-          R cxx, cxy, cxz, cyy, cyz, czz;
-          if (kDouble) {
-            const double* ic = d.icovd + (size_t)slot * 6;
-            cxx = (R)ic[0]; cxy = (R)ic[1]; cxz = (R)ic[2]; cyy = (R)ic[3]; cyz = (R)ic[4]; czz = (R)ic[5];
-          } else {
-            cxx = vx.icov[0]; cxy = vx.icov[1]; cxz = vx.icov[2]; cyy = vx.icov[3]; cyz = vx.icov[4]; czz = vx.icov[5];
-          }
-          // x_trans4 * c_inv4
-          const R v0 = u0 * cxx + u1 * cxy + u2 * cxz;
-          const R v1 = u0 * cxy + u1 * cyy + u2 * cyz;
-          const R v2 = u0 * cxz + u1 * cyz + u2 * czz;
-          const R q = u0 * v0 + u1 * v1 + u2 * v2;
-          R e = kDouble ? (R)exp(-(double)gd2 * (double)q / 2) : (R)expf(-(float)gd2 * (float)q * 0.5f);   // :497
-          const R score_inc = (R)(-P.d1d * (double)e);               // :499
-          e = gd2 * e;                                               // :501
-          if (e > (R)1 || e < (R)0 || e != e) continue;              // :504-505
-          e = (R)(P.d1d * (double)e);                                // :508
-          pt[0] += (double)score_inc;
-          // columns of c_inv4 * point_gradient4: col 0..2 = columns of C; col 3..5 from the angular entries
-          // J col3 = (0, pg0, pg1), col4 = (pg2, pg3, pg4), col5 = (pg5, pg6, pg7)
-          R CJ[6][3];
-          CJ[0][0] = cxx; CJ[0][1] = cxy; CJ[0][2] = cxz;
-          CJ[1][0] = cxy; CJ[1][1] = cyy; CJ[1][2] = cyz;
-          CJ[2][0] = cxz; CJ[2][1] = cyz; CJ[2][2] = czz;
-          CJ[3][0] = cxy * pg[0] + cxz * pg[1]; CJ[3][1] = cyy * pg[0] + cyz * pg[1]; CJ[3][2] = cyz * pg[0] + czz * pg[1];
-          CJ[4][0] = cxx * pg[2] + cxy * pg[3] + cxz * pg[4]; CJ[4][1] = cxy * pg[2] + cyy * pg[3] + cyz * pg[4]; CJ[4][2] = cxz * pg[2] + cyz * pg[3] + czz * pg[4];
-          CJ[5][0] = cxx * pg[5] + cxy * pg[6] + cxz * pg[7]; CJ[5][1] = cxy * pg[5] + cyy * pg[6] + cyz * pg[7]; CJ[5][2] = cxz * pg[5] + cyz * pg[6] + czz * pg[7];
-          R xCJ[6];
-#pragma unroll
-          for (int c = 0; c < 6; ++c) xCJ[c] = u0 * CJ[c][0] + u1 * CJ[c][1] + u2 * CJ[c][2];     // :511
-#pragma unroll
-          for (int c = 0; c < 6; ++c) pt[1 + c] += (double)(e * xCJ[c]);                              // :513
-          if (P.compute_hessian) {
-            // J columns as 3-vectors
-            R Jc[6][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, pg[0], pg[1]}, {pg[2], pg[3], pg[4]}, {pg[5], pg[6], pg[7]}};
-            // x_trans4_x_c_inv4 . point_hessian block (i, j): only i, j in 3..5 are non-zero, :418-437
-            // a=(0,ph0,ph1) b=(0,ph2,ph3) c=(0,ph4,ph5) d=(ph6,ph7,ph8) e=(ph9,ph10,ph11) f=(ph12,ph13,ph14)
-            const R ha = v1 * ph[0] + v2 * ph[1], hb = v1 * ph[2] + v2 * ph[3], hc = v1 * ph[4] + v2 * ph[5];
-            const R hd = v0 * ph[6] + v1 * ph[7] + v2 * ph[8], he = v0 * ph[9] + v1 * ph[10] + v2 * ph[11];
-            const R hf = v0 * ph[12] + v1 * ph[13] + v2 * ph[14];
-            const R xH[3][3] = {{ha, hb, hc}, {hb, hd, he}, {hc, he, hf}};     // [i-3][j-3]
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-              for (int c = 0; c < 6; ++c) {
-                // point_gradient4.col(j) . (c_inv4 * point_gradient4.col(i))  -> (j, i) entry, :517, :529
-                const R jcj = Jc[c][0] * CJ[a][0] + Jc[c][1] * CJ[a][1] + Jc[c][2] * CJ[a][2];
-                const R hh = (a >= 3 && c >= 3) ? xH[a - 3][c - 3] : (R)0;
-                pt[7 + 6 * a + c] += (double)(e * (-gd2 * xCJ[a] * xCJ[c] + hh + jcj));               // :527-529
-              }
+          if (((rowok >> r) & 1u) && x >= 0 && x < div0 && ((wd.x >> (x & 31)) & 1u)) {
+            if (k < (uint32_t)kCap) s_pair[k] = ((uint32_t)lane << 24) | (wd.y + __popc(wd.x & ((1u << (x & 31)) - 1u)));
+            ++k;
           }
         }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the window is written: LDS is in order inside a wave
+      NDT_STAMP(3);
+      // ---- phase B1: a lane per entry; keep what radiusSearch returns, compacting the window in place and counting per point
+      const uint32_t nwin = min((uint32_t)kCap, total - wbase);
+      uint32_t kept = 0;                                   // wave-uniform
+      for (uint32_t q0 = 0; q0 < nwin; q0 += 256) {
+        uint32_t prs[4];
+        u32x4 cen[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t q = q0 + 64 * u + lane;
+          prs[u] = 0; cen[u] = u32x4{0, 0, 0, 0};
+          if (q < nwin) { prs[u] = s_pair[q]; cen[u] = ((gptr<u32x4>)(d.vox + (prs[u] & 0xffffffu)))[3]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t q = q0 + 64 * u + lane;
+          const float4 tp = s_t[prs[u] >> 24];
+          const int vn_pts = (int)cen[u].w;
+          const float ex = tp.x - __uint_as_float(cen[u].x), ey = tp.y - __uint_as_float(cen[u].y), ez = tp.z - __uint_as_float(cen[u].z);
+          const bool pass = q < nwin && !(vn_pts >= 0 && vn_pts < d.min_points) && !(ex * ex + ey * ey + ez * ez > P.res2);
+          const unsigned long long mask = __ballot(pass);
+          const uint32_t pos = kept + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+          if (pass) { s_pair[pos] = prs[u]; atomicAdd(&s_cnt[prs[u] >> 24], 1u); }
+          kept += (uint32_t)__popcll(mask);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // ---- phase B2: a lane per point over its kept voxels (they follow one another in the compacted window); the next record is
+      // on its way while this one is worked on
+      const uint32_t mine = s_cnt[lane];
+      s_cnt[lane] = 0u;
+      const uint32_t first = wave_incl_scan_u32(mine) - mine;
+      npairs_lane += mine;
+      VoxRaw vn;
+      vn.a = vn.b = vn.c = u32x4{0, 0, 0, 0};
+      uint32_t slot_next = 0;
+      if (mine) { slot_next = s_pair[first] & 0xffffffu; vn = load_voxel_raw(d.vox, slot_next); }
+      for (uint32_t jn = 0; jn < mine; ++jn) {
+        const VoxRaw vr = vn;
+        const uint32_t slot = slot_next;
+        if (jn + 1 < mine) { slot_next = s_pair[first + jn + 1] & 0xffffffu; vn = load_voxel_raw(d.vox, slot_next); }
+        // x_trans - mean in double, then R (:253, :490)
+        const R u0 = (R)(tdx - __hiloint2double((int)vr.a.y, (int)vr.a.x));
+        const R u1 = (R)(tdy - __hiloint2double((int)vr.a.w, (int)vr.a.z));
+        const R u2 = (R)(tdz - __hiloint2double((int)vr.b.y, (int)vr.b.x));
+        R cxx, cxy, cxz, cyy, cyz, czz;
+        if (kDouble) {
+          const gptr<double> ic = icovd + (size_t)slot * 6;
+          cxx = (R)ic[0]; cxy = (R)ic[1]; cxz = (R)ic[2]; cyy = (R)ic[3]; cyz = (R)ic[4]; czz = (R)ic[5];
+        } else {
+          cxx = __uint_as_float(vr.b.z); cxy = __uint_as_float(vr.b.w); cxz = __uint_as_float(vr.c.x);
+          cyy = __uint_as_float(vr.c.y); cyz = __uint_as_float(vr.c.z); czz = __uint_as_float(vr.c.w);
+        }
+        // x_trans4 * c_inv4
+        const R v0 = u0 * cxx + u1 * cxy + u2 * cxz;
+        const R v1 = u0 * cxy + u1 * cyy + u2 * cyz;
+        const R v2 = u0 * cxz + u1 * cyz + u2 * czz;
+        const R qq = u0 * v0 + u1 * v1 + u2 * v2;
+        const R e0 = kDouble ? (R)exp(-(double)gd2 * (double)qq / 2) : (R)expf(-(float)gd2 * (float)qq * 0.5f);   // :497
+        const R e1 = gd2 * e0;                                     // :501
+        // :504-505: a term whose e_x_cov_x is out of range (or NaN) adds nothing, not even its score -- here by a factor of zero
+        const bool good = !(e1 > (R)1 || e1 < (R)0 || e1 != e1);
+        S0 += good ? (R)(-P.d1d * (double)e0) : (R)0;                              // :499
+        const R e = good ? (R)(P.d1d * (double)e1) : (R)0;                          // :508
+        const R ev0 = e * v0, ev1 = e * v1, ev2 = e * v2;
+        sv0 += ev0; sv1 += ev1; sv2 += ev2;
+        SCxx += e * cxx; SCxy += e * cxy; SCxz += e * cxz; SCyy += e * cyy; SCyz += e * cyz; SCzz += e * czz;
+        if (HESS) { Wxx += ev0 * v0; Wxy += ev0 * v1; Wxz += ev0 * v2; Wyy += ev1 * v1; Wyz += ev1 * v2; Wzz += ev2 * v2; }
       }
     }
-    if (!ONE) {
-      acc[0] += pt[0];
+    NDT_STAMP(4);
+    // ---- phase C: the point's terms.  J = [I | a3 a4 a5], a3 = (0, pg0, pg1), a4 = (pg2, pg3, pg4), a5 = (pg5, pg6, pg7) (:397-412)
+    R pg[8];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) acc[1 + c] += pt[1 + c];
-      if (P.compute_hessian) {
+    for (int r = 0; r < 8; ++r)
+      pg[r] = kDouble ? (R)(P.j_angd[r][0] * (double)s.x + P.j_angd[r][1] * (double)s.y + P.j_angd[r][2] * (double)s.z)
+                      : (R)(P.j_ang[r][0] * s.x + P.j_ang[r][1] * s.y + P.j_ang[r][2] * s.z);
+    accd[0] = (double)S0;
+    // score_gradient += e (x' C) J, :511-513
+    accd[1] = (double)sv0; accd[2] = (double)sv1; accd[3] = (double)sv2;
+    accd[4] = (double)(sv1 * pg[0] + sv2 * pg[1]);
+    accd[5] = (double)(sv0 * pg[2] + sv1 * pg[3] + sv2 * pg[4]);
+    accd[6] = (double)(sv0 * pg[5] + sv1 * pg[6] + sv2 * pg[7]);
+    if (HESS) {
+      R ph[15];
 #pragma unroll
-        for (int k = 0; k < 36; ++k) acc[7 + k] += pt[7 + k];
-      }
+      for (int r = 0; r < 15; ++r)                                                                             // :416
+        ph[r] = kDouble ? (R)(P.h_angd[r][0] * (double)s.x + P.h_angd[r][1] * (double)s.y + P.h_angd[r][2] * (double)s.z)
+                        : (R)(P.h_ang[r][0] * s.x + P.h_ang[r][1] * s.y + P.h_ang[r][2] * s.z);
+      // hessian(i, j) += e (-d2 (x'CJ_i)(x'CJ_j) + x'C H_ij + J_j C J_i) summed over the point's voxels = J^T M J + [sv . H_ij],
+      // M = SC - d2 W (:527-529)
+      const R Mxx = SCxx - gd2 * Wxx, Mxy = SCxy - gd2 * Wxy, Mxz = SCxz - gd2 * Wxz, Myy = SCyy - gd2 * Wyy, Myz = SCyz - gd2 * Wyz, Mzz = SCzz - gd2 * Wzz;
+      // M a3, M a4, M a5
+      const R k30 = Mxy * pg[0] + Mxz * pg[1], k31 = Myy * pg[0] + Myz * pg[1], k32 = Myz * pg[0] + Mzz * pg[1];
+      const R k40 = Mxx * pg[2] + Mxy * pg[3] + Mxz * pg[4], k41 = Mxy * pg[2] + Myy * pg[3] + Myz * pg[4], k42 = Mxz * pg[2] + Myz * pg[3] + Mzz * pg[4];
+      const R k50 = Mxx * pg[5] + Mxy * pg[6] + Mxz * pg[7], k51 = Mxy * pg[5] + Myy * pg[6] + Myz * pg[7], k52 = Mxz * pg[5] + Myz * pg[6] + Mzz * pg[7];
+      // sv . (a b c / b d e / c e f), a = (0, ph0, ph1) b = (0, ph2, ph3) c = (0, ph4, ph5) d = (ph6, ph7, ph8) e = (ph9, ph10, ph11) f = (ph12, ph13, ph14) (:418-437)
+      const R ha = sv1 * ph[0] + sv2 * ph[1], hb = sv1 * ph[2] + sv2 * ph[3], hc = sv1 * ph[4] + sv2 * ph[5];
+      const R hd = sv0 * ph[6] + sv1 * ph[7] + sv2 * ph[8], he = sv0 * ph[9] + sv1 * ph[10] + sv2 * ph[11];
+      const R hf = sv0 * ph[12] + sv1 * ph[13] + sv2 * ph[14];
+      accd[7] = (double)Mxx; accd[8] = (double)Mxy; accd[9] = (double)Mxz; accd[10] = (double)k30; accd[11] = (double)k40; accd[12] = (double)k50;
+      accd[13] = (double)Myy; accd[14] = (double)Myz; accd[15] = (double)k31; accd[16] = (double)k41; accd[17] = (double)k51;
+      accd[18] = (double)Mzz; accd[19] = (double)k32; accd[20] = (double)k42; accd[21] = (double)k52;
+      accd[22] = (double)(pg[0] * k31 + pg[1] * k32 + ha);
+      accd[23] = (double)(pg[2] * k30 + pg[3] * k31 + pg[4] * k32 + hb);
+      accd[24] = (double)(pg[5] * k30 + pg[6] * k31 + pg[7] * k32 + hc);
+      accd[25] = (double)(pg[2] * k40 + pg[3] * k41 + pg[4] * k42 + hd);
+      accd[26] = (double)(pg[5] * k40 + pg[6] * k41 + pg[7] * k42 + he);
+      accd[27] = (double)(pg[5] * k50 + pg[6] * k51 + pg[7] * k52 + hf);
     }
+    accd[28] = (double)npairs_lane;
   }
-  // block reduction -> partials
-  __shared__ double s_red[kNdtDerivThreads / 64][kNdtDerivCols];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // ---- fold: columns over the wave, then over the workgroup's four waves (the only point where its waves meet)
+  wave_fold32(accd);
+  double (*const s_red)[kNdtCols] = sh.red;
+  if ((lane & 15) == 0) {
 #pragma unroll
-  for (int k = 0; k < 43; ++k) acc[k] = wave_sum_to_last(acc[k]);      // DPP row operations, total in lane 63
-  pairs = wave_sum_to_last(pairs);
-  if (lane == 63) {
-#pragma unroll
-    for (int k = 0; k < 43; ++k) s_red[wave][k] = acc[k];
-    s_red[wave][43] = pairs;
+    for (int k = 0; k < 8; ++k) s_red[wave][k + 8 * (lane >> 4)] = accd[k];
   }
   __syncthreads();
-  if (threadIdx.x < kNdtDerivCols) {
-    double t = 0;
-    for (int w = 0; w < kNdtDerivThreads / 64; ++w) t += s_red[w][threadIdx.x];
-    d.partials[(size_t)blockIdx.x * kNdtDerivCols + threadIdx.x] = t;
+  if (threadIdx.x < kNdtCols) row_out[threadIdx.x] = ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
+#ifdef NDT_TIMING
+  // tuning build only: the workgroup's phase stamps (10 ns ticks) in the row's three unused columns
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    tm[5] = wall_clock64();
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(row_out);
+    w[29] = tm[0];
+    w[30] = ((tm[1] - tm[0]) & 0xffff) | (((tm[2] - tm[0]) & 0xffff) << 16) | (((tm[3] - tm[0]) & 0xffff) << 32) | (((tm[4] - tm[0]) & 0xffff) << 48);
+    w[31] = (tm[5] - tm[0]) | ((__builtin_readcyclecounter() - cyc0) << 32);
   }
-}
-template <typename R, bool ONE>
-__global__ __launch_bounds__(kNdtDerivThreads, ONE ? 2 : 1) void ndt_derivatives(const NdtDev* __restrict__ devs, const NdtPose* __restrict__ poses,
-                                                                                    const int32_t* __restrict__ active) {
-  const NdtDev d = devs[active[blockIdx.y]];
-  ndt_derivatives_body<R, ONE>(d, poses[blockIdx.y]);
-}
-template <typename R, bool ONE>
-__global__ __launch_bounds__(kNdtDerivThreads, ONE ? 2 : 1) void ndt_derivatives_args(const NdtDev* __restrict__ devs, const NdtPoseArgs A) {
-  const NdtDev d = devs[A.active[blockIdx.y]];
-  ndt_derivatives_body<R, ONE>(d, A.p[blockIdx.y]);
+#endif
 }
 
-// 16 thread groups take every 16th block, then one thread per column folds the group sums:
-// a fixed order, so repeated evaluations at the same pose are bitwise identical.  The sums also go straight into page-locked
-// host memory (row e of out_host = evaluation e of the round): the host reads them after the stream's synchronise, no copy.
-struct NdtActiveArgs { int32_t slot[kNdtArgPoses]; };
-__device__ __forceinline__ void ndt_reduce_body(const NdtDev& d, int nblocks, double* __restrict__ out_host) {
-  __shared__ double s_g[16][kNdtDerivCols];
-  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  if (c < kNdtDerivCols) {
+// ------------------------------------------------------------------------------------------
+// The Newton / More-Thuente driver on the device
+// ------------------------------------------------------------------------------------------
+// computeTransformation (ndt_omp_impl.hpp:81-171) and computeStepLengthMT (:757-916) are sequential 6-vector code around
+// computeDerivatives calls.  Each Align is a state machine (NdtCtl) that asks for one evaluation at a time: INIT (:119) -> per
+// Newton iteration TRIAL (:809-813) -> MT (the line-search loop's evaluations, :870-878) -> HESS (:912-913, only after a line
+// search that looped) -> next iteration.  One round = ndt_derivatives_ctl (every running job's evaluation, grid.y = job) +
+// ndt_ctl_step (a workgroup per job: fold of the job's rows in a fixed order, the 6x6 solve, the line-search decision, the next
+// pose with its angular derivative tables).  The host only enqueues rounds; it never sees a score or a gradient.
+//
+// Provenance note: update_interval_mt / trial_value_mt / the ndt_ctl_* transitions follow pclomp/ndt_omp_impl.hpp:633-916 branch
+// for branch (same variable roles: a_l, f_l, g_l, a_u, phi_0, d_psi_t, open_interval ...), including the reference's quirk that
+// `interval_converged` is computed from the UN-updated interval: the iteration and derivative-call counts the parity tests
+// assert depend on that control flow.  Nothing in it is data-parallel; everything it drives is this repository's own code.
+struct NdtCtlOpts {
+  double step_size, trans_eps;       // computeStepLengthMT's step_max; transformation_epsilon_
+  double d1, d2;                     // gauss_d1_, gauss_d2_ (:86-93)
+  float res2;                        // resolution^2
+  int32_t max_iterations;
+  int32_t double_math;               // stock pcl::NormalDistributionsTransform arithmetic (NdtWithGicp): fill the double tables
+  int32_t pad_;
+};
+
+enum NdtPhase : int32_t { kNdtInit = 0, kNdtTrial = 1, kNdtMt = 2, kNdtHess = 3, kNdtDone = 4, kNdtEvalOnly = 5 };
+
+struct NdtCtl {
+  int32_t phase, slot, it, deriv_calls;
+  int32_t interval_converged, open_interval, step_iterations, done_round;
+  double p[6], x_t[6], dir[6], eval_p[6];
+  double sc, g[6], H[36], last_pairs;
+  // computeStepLengthMT's locals
+  double phi_0, d_phi_0, a_t, a_l, a_u, f_l, g_l, f_u, g_u, phi_t, d_phi_t, psi_t, d_psi_t, step_max, step_min;
+  float Tf[16];                      // the pose matrix of the last evaluation asked for = final_transformation_ at the end
+  NdtPose pose;                      // the evaluation wanted next
+};
+
+struct NdtResult {                   // written to page-locked host memory by the step that ends a job
+  float Tf[16];
+  double sc, last_pairs;
+  int32_t it, deriv_calls, done_round, pad_;
+};
+
+constexpr double kMtMu = 1.e-4, kMtNu = 0.9;
+
+__host__ __device__ inline double psi_mt(double a, double f_a, double f_0, double g_0, double mu) { return f_a - f_0 - mu * g_0 * a; }     // ndt_omp.h auxilaryFunction_PsiMT
+__host__ __device__ inline double dpsi_mt(double g_a, double g_0, double mu) { return g_a - mu * g_0; }
+
+__host__ __device__ inline bool update_interval_mt(double& a_l, double& f_l, double& g_l, double& a_u, double& f_u, double& g_u, double a_t, double f_t, double g_t) {   // :633-670
+  if (f_t > f_l) { a_u = a_t; f_u = f_t; g_u = g_t; return false; }
+  else if (g_t * (a_l - a_t) > 0) { a_l = a_t; f_l = f_t; g_l = g_t; return false; }
+  else if (g_t * (a_l - a_t) < 0) { a_u = a_l; f_u = f_l; g_u = g_l; a_l = a_t; f_l = f_t; g_l = g_t; return false; }
+  return true;
+}
+
+__host__ __device__ inline double trial_value_mt(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t) {   // :674-753
+  if (f_t > f_l) {
+    const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    const double w = sqrt(z * z - g_t * g_l);
+    const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    const double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+    return fabs(a_c - a_l) < fabs(a_q - a_l) ? a_c : 0.5 * (a_q + a_c);
+  } else if (g_t * g_l < 0) {
+    const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    const double w = sqrt(z * z - g_t * g_l);
+    const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    return fabs(a_c - a_t) >= fabs(a_s - a_t) ? a_c : a_s;
+  } else if (fabs(g_t) <= fabs(g_l)) {
+    const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    const double w = sqrt(z * z - g_t * g_l);
+    const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    const double nxt = fabs(a_c - a_t) < fabs(a_s - a_t) ? a_c : a_s;
+    return a_t > a_l ? fmin(a_t + 0.66 * (a_u - a_t), nxt) : fmax(a_t + 0.66 * (a_u - a_t), nxt);
+  }
+  const double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u;
+  const double w = sqrt(z * z - g_t * g_u);
+  return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+}
+
+// Eigen::JacobiSVD<Matrix6d>(H, FullU | FullV).solve(b) (:127-129) = the pseudo-inverse applied to b.  For a matrix of full
+// numerical rank that is H^-1 b, formed here by Gaussian elimination with partial pivoting (a few hundred dependent
+// instructions on one lane; a Jacobi SVD is several thousand, on the critical path of every round).  When the pivots span more
+// than ten decades the one-sided Jacobi SVD below decides which directions count, with JacobiSVD's threshold.
+__host__ __device__ __noinline__ void svd_solve6(const double* H /*row-major*/, const double* b, double* x) {
+  double A[36], V[36];
+  for (int i = 0; i < 36; ++i) { A[i] = H[i]; V[i] = (i % 7 == 0) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    bool rotated = false;
+    for (int p = 0; p < 6; ++p)
+      for (int q = p + 1; q < 6; ++q) {
+        double app = 0, aqq = 0, apq = 0;
+        for (int k = 0; k < 6; ++k) { app += A[6 * k + p] * A[6 * k + p]; aqq += A[6 * k + q] * A[6 * k + q]; apq += A[6 * k + p] * A[6 * k + q]; }
+        if (fabs(apq) <= 1e-300 || fabs(apq) <= 1e-16 * sqrt(app * aqq)) continue;
+        rotated = true;
+        const double zeta = (aqq - app) / (2.0 * apq);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int k = 0; k < 6; ++k) {
+          const double ap = A[6 * k + p], aq = A[6 * k + q];
+          A[6 * k + p] = c * ap - s * aq; A[6 * k + q] = s * ap + c * aq;
+          const double vp = V[6 * k + p], vq = V[6 * k + q];
+          V[6 * k + p] = c * vp - s * vq; V[6 * k + q] = s * vp + c * vq;
+        }
+      }
+    if (!rotated) break;
+  }
+  double sig[6], smax = 0;
+  for (int j = 0; j < 6; ++j) { double s = 0; for (int k = 0; k < 6; ++k) s += A[6 * k + j] * A[6 * k + j]; sig[j] = sqrt(s); smax = fmax(smax, sig[j]); }
+  const double thr = 2.220446049250313e-16 * 6 * smax;
+  for (int i = 0; i < 6; ++i) x[i] = 0;
+  for (int j = 0; j < 6; ++j) {
+    if (!(sig[j] > thr)) continue;
+    double ub = 0;                                   // u_j . b with u_j = A[:, j] / sig_j
+    for (int k = 0; k < 6; ++k) ub += A[6 * k + j] * b[k];
+    ub /= sig[j] * sig[j];
+    for (int i = 0; i < 6; ++i) x[i] += V[6 * i + j] * ub;
+  }
+}
+
+__host__ __device__ inline void ndt_solve6(const double* H /*row-major*/, const double* b, double* x) {
+  double A[6][7];
+  for (int i = 0; i < 6; ++i) { for (int j = 0; j < 6; ++j) A[i][j] = H[6 * i + j]; A[i][6] = b[i]; }
+  double pmin = 1.7976931348623157e308, pmax = 0;
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    int piv = c;
+    double best = fabs(A[c][c]);
+#pragma unroll
+    for (int r = c + 1; r < 6; ++r) { const double v = fabs(A[r][c]); if (v > best) { best = v; piv = r; } }
+    if (!(best > 0) || !(best < 1.7976931348623157e308)) { ok = false; break; }
+    pmin = fmin(pmin, best); pmax = fmax(pmax, best);
+#pragma unroll
+    for (int r = c + 1; r < 6; ++r)
+      if (r == piv) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) { const double t = A[c][j]; A[c][j] = A[r][j]; A[r][j] = t; }
+      }
+    const double ip = 1.0 / A[c][c];
+#pragma unroll
+    for (int r = c + 1; r < 6; ++r) {
+      const double f = A[r][c] * ip;
+#pragma unroll
+      for (int j = c + 1; j < 7; ++j) A[r][j] -= f * A[c][j];
+    }
+  }
+  if (!ok || !(pmin > 1e-10 * pmax)) { svd_solve6(H, b, x); return; }
+#pragma unroll
+  for (int r = 5; r >= 0; --r) {
+    double sacc = A[r][6];
+#pragma unroll
+    for (int j = r + 1; j < 6; ++j) sacc -= A[r][j] * x[j];
+    x[r] = sacc / A[r][r];
+  }
+}
+
+// ---- the transitions (one lane).  They end by asking for an evaluation at j.eval_p (phase kNdtTrial / kNdtMt: a new pose matrix
+// is due; kNdtHess: the same pose once more, Hessian only) or with kNdtDone.
+__host__ __device__ inline void ndt_ctl_request(NdtCtl& j, const double* x, bool hess, int32_t ph) {
+  for (int i = 0; i < 6; ++i) j.eval_p[i] = x[i];
+  j.pose.compute_hessian = hess ? 1 : 0;
+  j.phase = ph;
+}
+
+__host__ __device__ __noinline__ void ndt_ctl_newton(NdtCtl& j, const NdtCtlOpts& o);
+
+__host__ __device__ inline void ndt_ctl_finish_iteration(NdtCtl& j, const NdtCtlOpts& o) {
+  const double dp_norm = j.a_t;                                                    // :142
+  for (int i = 0; i < 6; ++i) j.p[i] += j.dir[i] * dp_norm;                        // :143, :152
+  const bool converged = j.it > o.max_iterations || (j.it && fabs(dp_norm) < o.trans_eps);   // :158-162
+  j.it++;                                                                          // :164
+  if (converged) { j.phase = kNdtDone; return; }
+  ndt_ctl_newton(j, o);
+}
+
+// the line-search loop's head (:867): another trial value, the closing Hessian, or the end of the iteration
+__host__ __device__ inline void ndt_ctl_mt_continue(NdtCtl& j, const NdtCtlOpts& o) {
+  if (!j.interval_converged && j.step_iterations < 10 && !(j.psi_t <= 0 && j.d_phi_t <= -kMtNu * j.d_phi_0)) {
+    j.a_t = j.open_interval ? trial_value_mt(j.a_l, j.f_l, j.g_l, j.a_u, j.f_u, j.g_u, j.a_t, j.psi_t, j.d_psi_t)
+                            : trial_value_mt(j.a_l, j.f_l, j.g_l, j.a_u, j.f_u, j.g_u, j.a_t, j.phi_t, j.d_phi_t);
+    j.a_t = fmax(fmin(j.a_t, j.step_max), j.step_min);
+    for (int i = 0; i < 6; ++i) j.x_t[i] = j.p[i] + j.dir[i] * j.a_t;
+    ndt_ctl_request(j, j.x_t, false, kNdtMt);
+    return;
+  }
+  if (j.step_iterations) { ndt_ctl_request(j, j.x_t, true, kNdtHess); return; }       // :912-913
+  ndt_ctl_finish_iteration(j, o);
+}
+
+// one Newton iteration up to its first evaluation (:121-141, :757-813)
+__host__ __device__ __noinline__ void ndt_ctl_newton(NdtCtl& j, const NdtCtlOpts& o) {
+  for (;;) {
+    double mg[6], dp[6];
+    for (int i = 0; i < 6; ++i) mg[i] = -j.g[i];
+    ndt_solve6(j.H, mg, dp);                                                           // :127-129
+    double dp_norm = 0;
+    for (int i = 0; i < 6; ++i) dp_norm += dp[i] * dp[i];
+    dp_norm = sqrt(dp_norm);
+    if (dp_norm == 0 || dp_norm != dp_norm) { j.phase = kNdtDone; return; }        // :134-139
+    for (int i = 0; i < 6; ++i) j.dir[i] = dp[i] / dp_norm;                        // :141
+    // ---- computeStepLengthMT(p, dir, dp_norm, step_size, trans_eps / 2, ...) :757-916
+    const double step_init = dp_norm;
+    j.step_max = o.step_size; j.step_min = o.trans_eps / 2;
+    j.phi_0 = -j.sc;
+    j.d_phi_0 = 0;
+    for (int i = 0; i < 6; ++i) j.d_phi_0 -= j.g[i] * j.dir[i];
+    j.a_t = 0;
+    bool skip = false;
+    if (j.d_phi_0 >= 0) {
+      if (j.d_phi_0 == 0) skip = true;
+      else { j.d_phi_0 *= -1; for (int i = 0; i < 6; ++i) j.dir[i] = -j.dir[i]; }
+    }
+    if (!skip) {
+      j.a_l = 0; j.a_u = 0;
+      j.f_l = psi_mt(j.a_l, j.phi_0, j.phi_0, j.d_phi_0, kMtMu); j.g_l = dpsi_mt(j.d_phi_0, j.d_phi_0, kMtMu);
+      j.f_u = j.f_l; j.g_u = j.g_l;
+      j.interval_converged = (j.step_max - j.step_min) > 0 ? 1 : 0;                // :795 (sic: the loop never runs with the wrapper's settings)
+      j.open_interval = 1;
+      j.step_iterations = 0;
+      j.a_t = fmax(fmin(step_init, j.step_max), j.step_min);
+      for (int i = 0; i < 6; ++i) j.x_t[i] = j.p[i] + j.dir[i] * j.a_t;
+      ndt_ctl_request(j, j.x_t, true, kNdtTrial);                                  // :803-813
+      return;
+    }
+    // d_phi_0 == 0: no step; the iteration ends where it began
+    const bool converged = j.it > o.max_iterations || (j.it && fabs(j.a_t) < o.trans_eps);
+    j.it++;
+    if (converged) { j.phase = kNdtDone; return; }
+  }
+}
+
+// the evaluation the job asked for has come back: out = score, gradient, hessian (36), pair count
+__host__ __device__ inline void ndt_ctl_result(NdtCtl& j, const double* out, const NdtCtlOpts& o) {
+  j.deriv_calls++;
+  j.last_pairs = out[43];
+  switch (j.phase) {
+    case kNdtInit:
+      j.sc = out[0];
+      for (int i = 0; i < 6; ++i) j.g[i] = out[1 + i];
+      for (int i = 0; i < 36; ++i) j.H[i] = out[7 + i];
+      ndt_ctl_newton(j, o);
+      break;
+    case kNdtTrial:
+      j.sc = out[0];
+      for (int i = 0; i < 6; ++i) j.g[i] = out[1 + i];
+      for (int i = 0; i < 36; ++i) j.H[i] = out[7 + i];
+      j.phi_t = -j.sc; j.d_phi_t = 0;
+      for (int i = 0; i < 6; ++i) j.d_phi_t -= j.g[i] * j.dir[i];
+      j.psi_t = psi_mt(j.a_t, j.phi_t, j.phi_0, j.d_phi_0, kMtMu); j.d_psi_t = dpsi_mt(j.d_phi_t, j.d_phi_0, kMtMu);
+      ndt_ctl_mt_continue(j, o);
+      break;
+    case kNdtMt:
+      j.sc = out[0];
+      for (int i = 0; i < 6; ++i) j.g[i] = out[1 + i];                             // (no Hessian in the loop, :872)
+      j.phi_t = -j.sc; j.d_phi_t = 0;
+      for (int i = 0; i < 6; ++i) j.d_phi_t -= j.g[i] * j.dir[i];
+      j.psi_t = psi_mt(j.a_t, j.phi_t, j.phi_0, j.d_phi_0, kMtMu); j.d_psi_t = dpsi_mt(j.d_phi_t, j.d_phi_0, kMtMu);
+      if (j.open_interval && (j.psi_t <= 0 && j.d_psi_t >= 0)) {
+        j.open_interval = 0;
+        j.f_l = j.f_l + j.phi_0 - kMtMu * j.d_phi_0 * j.a_l; j.g_l = j.g_l + kMtMu * j.d_phi_0;
+        j.f_u = j.f_u + j.phi_0 - kMtMu * j.d_phi_0 * j.a_u; j.g_u = j.g_u + kMtMu * j.d_phi_0;
+      }
+      j.interval_converged = (j.open_interval ? update_interval_mt(j.a_l, j.f_l, j.g_l, j.a_u, j.f_u, j.g_u, j.a_t, j.psi_t, j.d_psi_t)
+                                              : update_interval_mt(j.a_l, j.f_l, j.g_l, j.a_u, j.f_u, j.g_u, j.a_t, j.phi_t, j.d_phi_t)) ? 1 : 0;
+      j.step_iterations++;
+      ndt_ctl_mt_continue(j, o);
+      break;
+    case kNdtHess:
+      for (int i = 0; i < 36; ++i) j.H[i] = out[7 + i];                            // the Hessian alone: score and gradient stay the loop's last
+      ndt_ctl_finish_iteration(j, o);
+      break;
+    default:
+      break;
+  }
+}
+
+// computeAngleDerivatives (:288-393) from the sines / cosines of p[3..5] (with the reference's small-angle rule applied by the caller)
+__host__ __device__ inline void ndt_angle_tables(double cx, double sx, double cy, double sy, double cz, double sz, bool dbl, NdtPose& P) {
+  const double j[8][3] = {
+      {(-sx * sz + cx * sy * cz), (-sx * cz - cx * sy * sz), (-cx * cy)}, {(cx * sz + sx * sy * cz), (cx * cz - sx * sy * sz), (-sx * cy)},
+      {(-sy * cz), sy * sz, cy}, {sx * cy * cz, (-sx * cy * sz), sx * sy}, {(-cx * cy * cz), cx * cy * sz, (-cx * sy)},
+      {(-cy * sz), (-cy * cz), 0}, {(cx * cz - sx * sy * sz), (-cx * sz - sx * sy * cz), 0}, {(sx * cz + cx * sy * sz), (cx * sy * cz - sx * sz), 0}};
+  const double hh[15][3] = {
+      {(-cx * sz - sx * sy * cz), (-cx * cz + sx * sy * sz), sx * cy}, {(-sx * sz + cx * sy * cz), (-cx * sy * sz - sx * cz), (-cx * cy)},
+      {(cx * cy * cz), (-cx * cy * sz), (cx * sy)}, {(sx * cy * cz), (-sx * cy * sz), (sx * sy)},
+      {(-sx * cz - cx * sy * sz), (sx * sz - cx * sy * cz), 0}, {(cx * cz - sx * sy * sz), (-sx * sy * cz - cx * sz), 0},
+      {(-cy * cz), (cy * sz), (sy)}, {(-sx * sy * cz), (sx * sy * sz), (sx * cy)}, {(cx * sy * cz), (-cx * sy * sz), (-cx * cy)},
+      {(sy * sz), (sy * cz), 0}, {(-sx * cy * sz), (-sx * cy * cz), 0}, {(cx * cy * sz), (cx * cy * cz), 0},
+      {(-cy * cz), (cy * sz), 0}, {(-cx * sz - sx * sy * cz), (-cx * cz + sx * sy * sz), 0}, {(-sx * sz + cx * sy * cz), (-cx * sy * sz - sx * cz), 0}};
+  if (dbl) {
+    for (int r = 0; r < 8; ++r) for (int c = 0; c < 3; ++c) P.j_angd[r][c] = j[r][c];
+    for (int r = 0; r < 15; ++r) for (int c = 0; c < 3; ++c) P.h_angd[r][c] = hh[r][c];
+  } else {
+    for (int r = 0; r < 8; ++r) for (int c = 0; c < 3; ++c) P.j_ang[r][c] = (float)j[r][c];
+    for (int r = 0; r < 15; ++r) for (int c = 0; c < 3; ++c) P.h_ang[r][c] = (float)hh[r][c];
+  }
+}
+
+// Translation(p0..2) * AngleAxis(p3, X) * AngleAxis(p4, Y) * AngleAxis(p5, Z), all float (:146-149, :803-806), from the float
+// cosines / sines of the float-rounded angles
+__host__ __device__ inline void ndt_pose_matrix_f32(const double* p, float ca, float sa, float cb, float sb, float cc, float sc, float* T /*row-major 4x4*/) {
+  const float Rx[9] = {1, 0, 0, 0, ca, -sa, 0, sa, ca};
+  const float Ry[9] = {cb, 0, sb, 0, 1, 0, -sb, 0, cb};
+  const float Rz[9] = {cc, -sc, 0, sc, cc, 0, 0, 0, 1};
+  float M[9], R[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { float s = 0; for (int k = 0; k < 3; ++k) s += Rx[3 * i + k] * Ry[3 * k + j]; M[3 * i + j] = s; }
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { float s = 0; for (int k = 0; k < 3; ++k) s += M[3 * i + k] * Rz[3 * k + j]; R[3 * i + j] = s; }
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) T[4 * i + j] = R[3 * i + j]; T[4 * i + 3] = (float)p[i]; }
+  T[12] = T[13] = T[14] = 0.f; T[15] = 1.f;
+}
+
+// grid = (workgroups per source, jobs): job blockIdx.y evaluates its pose against the table of its slot; a finished job's
+// workgroups leave at once
+template <typename R>
+__global__ __launch_bounds__(kNdtDerivThreads, sizeof(R) == 4 ? 4 : 3) void ndt_derivatives_ctl(const NdtDev* __restrict__ devs, const NdtCtl* __restrict__ ctl) {
+  const NdtCtl& c = ctl[blockIdx.y];
+  if (c.phase == kNdtDone) return;
+  const NdtDev d = devs[c.slot];
+  __shared__ NdtDerivShared sh;
+  if (c.pose.compute_hessian) ndt_derivatives_body<R, true>(d, c.pose, d.partials + (size_t)blockIdx.x * kNdtCols, sh);
+  else ndt_derivatives_body<R, false>(d, c.pose, d.partials + (size_t)blockIdx.x * kNdtCols, sh);
+}
+
+// A workgroup per job: the fold of the job's rows (16 thread groups take every 16th row, then one thread per column adds the group
+// sums: a fixed order, so an evaluation is bit-reproducible whatever else the launch holds), the state machine's step, the next
+// pose.  flags[job] (page-locked) = (round + 1) << 8 | phase tells the host how far the job is; a job that ends leaves its result
+// in res[job] (page-locked) and the final transformation, as doubles, in the pair input block of its slot -- where the fitness
+// pass (pcl::Registration::getFitnessScore, ndt.cc:60) takes its pose from.
+constexpr int kNdtStepThreads = 512;
+__global__ __launch_bounds__(kNdtStepThreads) void ndt_ctl_step(const NdtDev* __restrict__ devs, NdtCtl* __restrict__ ctl, int nblocks, const NdtCtlOpts o, int round,
+                                                      PairInput* __restrict__ in, uint32_t* __restrict__ flags, NdtResult* __restrict__ res, double* __restrict__ out_host) {
+  static_assert(sizeof(NdtCtl) % 8 == 0, "NdtCtl is copied as 8-byte words");
+  NdtCtl* const jg = ctl + blockIdx.x;
+  if (jg->phase == kNdtDone) return;
+  // the job's state in LDS while the step runs: the sequential code below indexes its vectors in loops (private arrays would go
+  // to scratch memory)
+  __shared__ NdtCtl j;
+  constexpr int kGroups = kNdtStepThreads / 32;
+  __shared__ double s_g[kGroups][kNdtCols];
+  __shared__ double s_out[kNdtOutCols];
+  __shared__ double s_trig[12];
+  __shared__ int s_new_pose;
+  {
+    const unsigned long long* srcw = reinterpret_cast<const unsigned long long*>(jg);
+    unsigned long long* dstw = reinterpret_cast<unsigned long long*>(&j);
+    for (int k = threadIdx.x; k < (int)(sizeof(NdtCtl) / 8); k += blockDim.x) dstw[k] = srcw[k];
+  }
+  const NdtDev d = devs[jg->slot];
+  const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  {
     double t = 0;
-    for (int k = grp; k < nblocks; k += 16) t += d.partials[(size_t)k * kNdtDerivCols + c];
+    int k = grp;
+    for (; k + 7 * kGroups < nblocks; k += 8 * kGroups) {            // eight loads in flight; added in row order
+      double a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = d.partials[(size_t)(k + u * kGroups) * kNdtCols + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += a[u];
+    }
+    for (; k < nblocks; k += kGroups) t += d.partials[(size_t)k * kNdtCols + c];
     s_g[grp][c] = t;
   }
   __syncthreads();
-  if (threadIdx.x < kNdtDerivCols) {
+  if (threadIdx.x < kNdtCols) {
     double t = 0;
-    for (int g = 0; g < 16; ++g) t += s_g[g][threadIdx.x];
-    d.out[threadIdx.x] = t;
-    out_host[(size_t)blockIdx.x * kNdtDerivCols + threadIdx.x] = t;
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) t += s_g[g][threadIdx.x];
+    s_g[0][threadIdx.x] = t;                               // (thread c reads column c of every group before it overwrites group 0's)
   }
-}
-__global__ __launch_bounds__(16 * 64) void ndt_reduce(const NdtDev* __restrict__ devs, const int32_t* __restrict__ active, int nblocks, double* __restrict__ out_host) {
-  const NdtDev d = devs[active[blockIdx.x]];
-  ndt_reduce_body(d, nblocks, out_host);
-}
-__global__ __launch_bounds__(16 * 64) void ndt_reduce_args(const NdtDev* __restrict__ devs, const NdtActiveArgs A, int nblocks, double* __restrict__ out_host) {
-  const NdtDev d = devs[A.slot[blockIdx.x]];
-  ndt_reduce_body(d, nblocks, out_host);
+  __syncthreads();
+  if (threadIdx.x < kNdtOutCols) {
+    // score, gradient, the Hessian mirrored from its upper triangle, pair count
+    const int k = threadIdx.x;
+    double v;
+    if (k < 7) v = s_g[0][k];
+    else if (k == 43) v = s_g[0][28];
+    else {
+      int a = (k - 7) / 6, b = (k - 7) % 6;
+      if (a > b) { const int t = a; a = b; b = t; }
+      v = s_g[0][7 + a * 6 - a * (a - 1) / 2 + (b - a)];
+    }
+    s_out[k] = v;
+    d.out[k] = v;
+    if (out_host) out_host[(size_t)blockIdx.x * kNdtOutCols + k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (j.phase == kNdtEvalOnly) { j.deriv_calls++; j.last_pairs = s_out[43]; j.phase = kNdtDone; }
+    else ndt_ctl_result(j, s_out, o);
+    s_new_pose = j.phase != kNdtDone;
+  }
+  __syncthreads();
+  if (s_new_pose) {
+    // the cosines / sines of the next pose: lanes 0..2 those of the float-rounded angles (the float pose matrix), lanes 3..5
+    // those of the angles themselves (the angular derivative tables, with the reference's |angle| < 1e-4 rule, :290-324)
+    if (threadIdx.x < 6) {
+      const double ang = j.eval_p[3 + threadIdx.x % 3];
+      double sn, cs;
+      if (threadIdx.x < 3) { sincos((double)(float)ang, &sn, &cs); sn = (double)(float)sn; cs = (double)(float)cs; }
+      else if (fabs(ang) < 10e-5) { sn = 0.0; cs = 1.0; }
+      else sincos(ang, &sn, &cs);
+      s_trig[2 * threadIdx.x] = cs; s_trig[2 * threadIdx.x + 1] = sn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (j.phase == kNdtTrial || j.phase == kNdtMt)
+        ndt_pose_matrix_f32(j.eval_p, (float)s_trig[0], (float)s_trig[1], (float)s_trig[2], (float)s_trig[3], (float)s_trig[4], (float)s_trig[5], j.Tf);
+      for (int i = 0; i < 12; ++i) j.pose.T[i] = j.Tf[i];
+    }
+    if (threadIdx.x == 64) ndt_angle_tables(s_trig[6], s_trig[7], s_trig[8], s_trig[9], s_trig[10], s_trig[11], o.double_math != 0, j.pose);
+  } else if (threadIdx.x == 0) {
+    j.done_round = round;
+    NdtResult& r = res[blockIdx.x];
+    for (int i = 0; i < 16; ++i) r.Tf[i] = j.Tf[i];
+    r.sc = j.sc; r.last_pairs = j.last_pairs; r.it = j.it; r.deriv_calls = j.deriv_calls; r.done_round = round;
+    PairInput& pi = in[j.slot];
+    for (int i = 0; i < 16; ++i) pi.guess[i] = (double)j.Tf[i];      // getFinalTransformation().cast<double>() (ndt.cc:61), row-major
+  }
+  __syncthreads();
+  {
+    const unsigned long long* srcw = reinterpret_cast<const unsigned long long*>(&j);
+    unsigned long long* dstw = reinterpret_cast<unsigned long long*>(jg);
+    for (int k = threadIdx.x; k < (int)(sizeof(NdtCtl) / 8); k += blockDim.x) dstw[k] = srcw[k];
+  }
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    flags[blockIdx.x] = ((uint32_t)(round + 1) << 8) | (uint32_t)j.phase;
+  }
 }
 
 // mean of the squared NN distances of slot 0 (pcl::Registration::getFitnessScore, ndt.cc:60)

@@ -22,7 +22,7 @@ struct NdtVoxel {          // 64 B record of one searchable voxel (n >= min_poin
   int32_t n;               // nr_points; -1 = eigen check failed (stays searchable with icov = 0)
 };
 
-struct NdtGridInfo {       // written by ndt_voxel_setup
+struct NdtGridInfo {       // written by ndt_voxel_setup and the build kernels after it
   int32_t min_b[3];
   int32_t div_b[3];
   int32_t wx;              // words per x row
@@ -31,7 +31,35 @@ struct NdtGridInfo {       // written by ndt_voxel_setup
   int32_t status;          // 0 ok, 7 = voxel box larger than the bit grid
   float inv;               // inverse leaf size (float, as PCL)
   float res;
+  int32_t nvalid;          // target points inside the box (finite)
+  int32_t nsub;            // (unused)
+  int32_t nbig;            // voxels with more than kNdtBigVoxel points
+  uint32_t nlist;          // fitness search: queries the first pass left to the second / the second to the sweep
+  uint32_t nleft;
+  float marg;              // what the float rounding of p * inv can move a point across a lattice plane, in cells
+  int32_t pad_[2];
 };
+
+// The fine levels of the table.  Every voxel is cut into 4 x 4 x 4 mid cells and each of those into 4 x 4 x 4 fine cells (1/16 of a
+// voxel: 6.25 cm at the reference's 1 m; coordinates from the fractional part of p * inv), and a voxel's points lie sorted by
+// mid cell, then fine cell ((z * 4 + y) * 4 + x), then caller index -- so a voxel, a mid cell, a fine cell and an x-row of fine cells are
+// each ONE run of vpts.  The NDT statistics do not care (any fixed order of a voxel's points serves); the exact 1-NN search of the
+// fitness score finds a mid cell through an open-addressing hash table (key: voxel code | mid cell coordinates) whose entry
+// carries the cell's run, the occupancy mask of its 64 fine cells and, through fpos[start + rank], where each occupied fine cell
+// begins.  Neighbouring queries probe the same few entries: the table is read through the caches, not at random.
+struct alignas(32) NdtCell {
+  unsigned long long key;  // ~0 = empty
+  uint32_t start, end;     // the mid cell's points: vpts[start, end)
+  unsigned long long fmask;
+  unsigned long long pad_;
+};
+__device__ __forceinline__ uint32_t ndt_cell_hash(unsigned long long key, int log2cap) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - log2cap)); }
+__device__ __forceinline__ unsigned long long ndt_mid_key(uint32_t code, int mz, int my, int mx) {
+  return ((unsigned long long)code << 6) | (unsigned long long)((mz << 4) | (my << 2) | mx);
+}
+
+constexpr int kNdtBoxBlocks = 128;           // workgroups per target of the bounding-box pass
+constexpr int kNdtBigVoxel = 2048;           // voxels with more points get a whole 1024-thread workgroup for their sums
 
 // One voxel table (one pair slot's target).  The kernels take a device ARRAY of these and pick theirs by block index: a batch
 // of K Aligns builds its K tables and evaluates its K derivative sets in single launches (grid.y = pair).
@@ -42,16 +70,24 @@ struct NdtDev {
   const float4* tgt;       // raw target points
   const float4* src;       // raw source points (Morton order)
   NdtGridInfo* info;
-  const double* tpart;     // [kTgtReduceBlocks][16] from tgt_reduce
+  float* bbox;             // [kNdtBoxBlocks][8] min xyz, max xyz of a stripe of the target
   uint32_t* bits;          // [kNdtMaxWords]
   uint2* words;            // [kNdtMaxWords]
   uint32_t* vstart;        // [nt + 1]
-  float4* vpts;            // [nt] points sorted by voxel
+  float4* vpts;            // [nt] points sorted by voxel, mid cell, fine cell, caller index (w)
   NdtVoxel* vox;           // [nt] one record per occupied voxel
+  NdtCell* cells;          // [1 << log2cells] hash table of the occupied mid cells
+  uint32_t* fpos;          // [nt] fpos[start of a mid cell + r] = where its r-th occupied fine cell begins
+  uint32_t* big;           // [nt / kNdtBigVoxel + 1] the crowded voxels
+  uint32_t* qlist;         // [ns] fitness search: queries the first pass hands to the second
+  uint32_t* qleft;         // [ns] ... and the second to the sweep
   double* icovd;           // [nt][6] Leaf::icov_ in double: xx xy xz yy yz zz (stock PCL path reads these)
   double* partials;        // [ceil(ns_cap / 256)][kNdtCols]
   double* out;             // [kNdtOutCols]
-  int32_t key_off;         // where this table's (voxel code, point) pairs start in the batch's sort arrays
+  float* fit_d2;           // [ns] squared distance to the nearest target point (fitness search)
+  int32_t key_off;         // where this table's (key, point) pairs start in the batch's sort arrays
+  int32_t key_bits;        // bits of slot << 12 | mid cell << 6 | fine cell in a sort key (the table number sits above them)
+  int32_t log2cells;       // size of `cells`: at least two entries per target point (never more than half full)
   int32_t pad_;
 };
 
@@ -70,30 +106,55 @@ struct NdtPose {           // per derivative evaluation
 // ------------------------------------------------------------------------------------------
 // voxel grid build
 // ------------------------------------------------------------------------------------------
+// bbox -> setup -> mark (occupancy bit per voxel) -> rank (popcount dictionary: bit -> slot) -> keys (slot | mid cell | fine cell)
+// -> ONE radix sort of every table's (key, point) pairs -> heads (points gathered into sorted order, voxel starts, the cells' runs
+// opened in the hash table) -> tails (the runs closed, list of crowded voxels) -> stats / stats_big (the Leaf of every voxel).
+__global__ __launch_bounds__(256) void ndt_bbox(const NdtDev* __restrict__ devs) {
+  const NdtDev d = devs[blockIdx.y];
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < d.nt; j += gridDim.x * blockDim.x) {
+    const float4 p = d.tgt[j];
+    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+  }
+  __shared__ float s_mn[4][3], s_mx[4][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = 0; c < 3; ++c) { mn[c] = wave_min(mn[c]); mx[c] = wave_max(mx[c]); }
+  if (lane == 0) for (int c = 0; c < 3; ++c) { s_mn[wave][c] = mn[c]; s_mx[wave][c] = mx[c]; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int c = threadIdx.x;
+    d.bbox[8 * blockIdx.x + c] = fminf(fminf(s_mn[0][c], s_mn[1][c]), fminf(s_mn[2][c], s_mn[3][c]));
+    d.bbox[8 * blockIdx.x + 4 + c] = fmaxf(fmaxf(s_mx[0][c], s_mx[1][c]), fmaxf(s_mx[2][c], s_mx[3][c]));
+  }
+}
+
 __global__ void ndt_voxel_setup(const NdtDev* __restrict__ devs, float leaf) {
-  if (threadIdx.x != 0) return;
   const NdtDev d = devs[blockIdx.x];
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int k = 0; k < kTgtReduceBlocks; ++k)
-    for (int c = 0; c < 3; ++c) {
-      mn[c] = fminf(mn[c], (float)d.tpart[16 * k + 3 + c]);
-      mx[c] = fmaxf(mx[c], (float)d.tpart[16 * k + 6 + c]);
-    }
+  for (int k = threadIdx.x; k < kNdtBoxBlocks; k += 64)
+    for (int c = 0; c < 3; ++c) { mn[c] = fminf(mn[c], d.bbox[8 * k + c]); mx[c] = fmaxf(mx[c], d.bbox[8 * k + 4 + c]); }
+  for (int c = 0; c < 3; ++c) { mn[c] = wave_min(mn[c]); mx[c] = wave_max(mx[c]); }
+  if (threadIdx.x != 0) return;
   NdtGridInfo* g = d.info;
   const float inv = 1.0f / leaf;                                   // inverse_leaf_size_
   g->inv = inv; g->res = leaf;
   double vox = 1;
+  float amax = 0.f;
   for (int c = 0; c < 3; ++c) {
     g->min_b[c] = (int)floorf(mn[c] * inv);                        // :87-92
     const int max_b = (int)floorf(mx[c] * inv);
     g->div_b[c] = max_b - g->min_b[c] + 1;                         // :95
     vox *= (double)g->div_b[c];
+    amax = fmaxf(amax, fmaxf(fabsf(mn[c] * inv), fabsf(mx[c] * inv)));
   }
   g->wx = (g->div_b[0] + 31) >> 5;
   const double nw = (double)g->wx * g->div_b[1] * g->div_b[2];
   g->status = (nw > (double)kNdtMaxWords || !(vox > 0)) ? 7 : 0;
   g->nw = g->status ? 0 : (int)nw;
-  g->nocc = 0;
+  g->nocc = 0; g->nvalid = 0; g->nsub = 0; g->nbig = 0; g->nlist = 0; g->nleft = 0;
+  // p * inv is one float rounding: a lattice plane can be off by 2^-24 |p * inv| for a target point and as much for a query
+  g->marg = 4.0f * 5.9604645e-08f * (amax + 2.0f);
 }
 
 __device__ __forceinline__ bool ndt_voxel_of(const NdtGridInfo* g, float x, float y, float z, int& i0, int& i1, int& i2) {
@@ -102,6 +163,48 @@ __device__ __forceinline__ bool ndt_voxel_of(const NdtGridInfo* g, float x, floa
   i1 = (int)(floorf(y * g->inv) - (float)g->min_b[1]);
   i2 = (int)(floorf(z * g->inv) - (float)g->min_b[2]);
   return i0 >= 0 && i1 >= 0 && i2 >= 0 && i0 < g->div_b[0] && i1 < g->div_b[1] && i2 < g->div_b[2];
+}
+// the fine coordinate of a point inside its voxel: floor(16 frac(p * inv)) per axis -- exact float operations on the one rounded
+// product; its upper two bits are the mid cell's coordinate, the lower two the fine cell's inside the mid cell
+__device__ __forceinline__ int ndt_fine_axis(float p, float inv) {
+  const float ps = p * inv;
+  return min(15, (int)((ps - floorf(ps)) * 16.0f));
+}
+__device__ __forceinline__ uint32_t ndt_voxel_code(const NdtGridInfo* g, const float4 p) {     // word << 5 | bit, or ~0
+  int i0, i1, i2;
+  if (g->status || !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) || !ndt_voxel_of(g, p.x, p.y, p.z, i0, i1, i2)) return 0xffffffffu;   // :209-213
+  return ((uint32_t)((i2 * g->div_b[1] + i1) * g->wx + (i0 >> 5)) << 5) | (uint32_t)(i0 & 31);
+}
+
+// A workgroup's 256 points fall into a handful of voxels (a submap's points arrive ring by ring; 500 k of them fill a few thousand
+// 1 m voxels): the distinct codes are collected in a small LDS set first, and only those go to the bit grid -- one global atomicOr per
+// (workgroup, voxel) instead of one per point, which queued up on the few hundred words a dense target occupies.
+__global__ __launch_bounds__(256) void ndt_voxel_mark(const NdtDev* __restrict__ devs) {
+  const NdtDev d = devs[blockIdx.y];
+  constexpr int kSet = 128;
+  __shared__ uint32_t s_set[kSet];
+  if (threadIdx.x < kSet) s_set[threadIdx.x] = 0xffffffffu;
+  __syncthreads();
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t code = 0xffffffffu;
+  if (j < d.nt) code = ndt_voxel_code(d.info, d.tgt[j]);
+  const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)0xfffffffeu, (int)code, 0x138, 0xf, 0xf, false);   // wave_shr 1; lane 0 keeps the fill
+  if (code != 0xffffffffu && code != prev) {
+    // a run's first point: into the set, or straight to the grid when its probe window is taken by other codes
+    uint32_t hpos = (code * 0x9E3779B1u) >> 25;
+    bool placed = false;
+    for (int t = 0; t < 8 && !placed; ++t) {
+      const uint32_t was = atomicCAS(&s_set[hpos], 0xffffffffu, code);
+      placed = was == 0xffffffffu || was == code;
+      hpos = (hpos + 1u) & (kSet - 1);
+    }
+    if (!placed) atomicOr(&d.bits[code >> 5], 1u << (code & 31));
+  }
+  __syncthreads();
+  if (threadIdx.x < kSet) {
+    const uint32_t c = s_set[threadIdx.x];
+    if (c != 0xffffffffu) atomicOr(&d.bits[c >> 5], 1u << (c & 31));
+  }
 }
 
 // one 1024-thread block: words = {bits, exclusive rank}; nocc
@@ -127,58 +230,116 @@ __global__ __launch_bounds__(1024) void ndt_voxel_rank(const NdtDev* __restrict_
   if (threadIdx.x == 0) g->nocc = (int)carry;
 }
 
-// ---- sort-based build: (voxel code, point) pairs radix-sorted by the caller, then one pass marks the
-// first point of every voxel (one atomicOr per VOXEL instead of one per point: 500 k points fall into a few
-// thousand 1 m voxels) and one pass, after ndt_voxel_rank, records the voxel starts and gathers the points.
-// (key = table << 33 | code: ONE radix sort orders the (voxel, point) pairs of every table of the batch, each table's run where
-// its key_off says)
-constexpr unsigned long long kNdtCodeMask = (1ull << 33) - 1ull;
+// key = table << key_bits | slot << 12 | mid cell << 6 | fine cell; points outside the box (or not finite) get the table's largest key and sort last
 __global__ __launch_bounds__(256) void ndt_voxel_keys64(const NdtDev* __restrict__ devs, unsigned long long* keys, int32_t* vals) {
   const NdtDev d = devs[blockIdx.y];
   const NdtGridInfo* g = d.info;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= d.nt) return;
-  unsigned long long code = 0xffffffffull;                          // non-finite / out-of-box points sort last (:209-213)
-  if (!g->status) {
-    const float4 p = d.tgt[j];
-    int i0, i1, i2;
-    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && ndt_voxel_of(g, p.x, p.y, p.z, i0, i1, i2))
-      code = ((unsigned long long)((i2 * g->div_b[1] + i1) * g->wx + (i0 >> 5)) << 5) | (unsigned long long)(i0 & 31);
+  const float4 p = d.tgt[j];
+  const uint32_t code = ndt_voxel_code(g, p);
+  unsigned long long low = (1ull << d.key_bits) - 1ull;
+  if (code != 0xffffffffu) {
+    const uint2 wd = d.words[code >> 5];
+    const uint32_t slot = wd.y + __popc(wd.x & ((1u << (code & 31)) - 1u));
+    const int fx = ndt_fine_axis(p.x, g->inv), fy = ndt_fine_axis(p.y, g->inv), fz = ndt_fine_axis(p.z, g->inv);
+    const uint32_t mid = (uint32_t)((((fz >> 2) * 4 + (fy >> 2)) * 4 + (fx >> 2)));
+    const uint32_t fin = (uint32_t)((((fz & 3) * 4 + (fy & 3)) * 4 + (fx & 3)));
+    low = ((unsigned long long)slot << 12) | (mid << 6) | fin;
   }
-  keys[d.key_off + j] = ((unsigned long long)blockIdx.y << 33) | code;
+  keys[d.key_off + j] = ((unsigned long long)blockIdx.y << d.key_bits) | low;
   vals[d.key_off + j] = j;
 }
 
-__global__ __launch_bounds__(256) void ndt_voxel_heads(const NdtDev* __restrict__ devs, const unsigned long long* keys) {
+// open-addressing insert / find of a cell's entry (linear probing; the table is never more than 2/3 full)
+__device__ __forceinline__ NdtCell* ndt_cell_insert(const NdtDev& d, unsigned long long key) {
+  const uint32_t maskc = (1u << d.log2cells) - 1u;
+  uint32_t hpos = ndt_cell_hash(key, d.log2cells);
+  for (;;) {
+    const unsigned long long was = atomicCAS(&d.cells[hpos].key, ~0ull, key);
+    if (was == ~0ull || was == key) return d.cells + hpos;
+    hpos = (hpos + 1u) & maskc;
+  }
+}
+__device__ __forceinline__ const NdtCell* ndt_cell_find(const NdtDev& d, unsigned long long key) {
+  const uint32_t maskc = (1u << d.log2cells) - 1u;
+  uint32_t hpos = ndt_cell_hash(key, d.log2cells);
+  for (;;) {
+    const unsigned long long k = d.cells[hpos].key;
+    if (k == key) return d.cells + hpos;
+    if (k == ~0ull) return nullptr;
+    hpos = (hpos + 1u) & maskc;
+  }
+}
+__global__ __launch_bounds__(256) void ndt_cells_clear(const NdtDev* __restrict__ devs) {
   const NdtDev d = devs[blockIdx.y];
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= d.nt) return;
-  keys += d.key_off;
-  const unsigned long long c = keys[s] & kNdtCodeMask;
-  if (c == 0xffffffffull) return;
-  if (s == 0 || (keys[s - 1] & kNdtCodeMask) != c) atomicOr(&d.bits[(uint32_t)(c >> 5)], 1u << (uint32_t)(c & 31));
+  const size_t n = (size_t)1 << d.log2cells;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+    NdtCell e;
+    e.key = ~0ull; e.start = 0u; e.end = 0u; e.fmask = 0ull; e.pad_ = 0ull;
+    d.cells[k] = e;
+  }
 }
 
-__global__ __launch_bounds__(256) void ndt_voxel_starts(const NdtDev* __restrict__ devs, const unsigned long long* keys, const int32_t* vals) {
+// the key of a sorted point's mid cell and the number of its fine cell inside it, from the point itself
+__device__ __forceinline__ unsigned long long ndt_point_cell(const NdtGridInfo* g, const float4 p, int& fine) {
+  const uint32_t code = ndt_voxel_code(g, p);
+  const int fx = ndt_fine_axis(p.x, g->inv), fy = ndt_fine_axis(p.y, g->inv), fz = ndt_fine_axis(p.z, g->inv);
+  fine = ((fz & 3) * 4 + (fy & 3)) * 4 + (fx & 3);
+  return ndt_mid_key(code, fz >> 2, fy >> 2, fx >> 2);
+}
+
+// sorted order: gather the points, voxel starts; the first point of every fine cell sets its bit in its mid cell's entry (made by
+// whoever comes first), the first point of a mid cell the entry's start
+__global__ __launch_bounds__(256) void ndt_voxel_heads(const NdtDev* __restrict__ devs, const unsigned long long* keys, const int32_t* vals) {
   const NdtDev d = devs[blockIdx.y];
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= d.nt) return;
   keys += d.key_off; vals += d.key_off;
-  const unsigned long long c = keys[s] & kNdtCodeMask;
-  const bool valid = c != 0xffffffffull;
+  const unsigned long long lowmask = (1ull << d.key_bits) - 1ull;
+  const unsigned long long k = keys[s] & lowmask;
+  const bool valid = k != lowmask;
   if (valid) {
     const int j = vals[s];
     float4 p = d.tgt[j];
     p.w = __int_as_float(j);
     d.vpts[s] = p;
-    if (s == 0 || (keys[s - 1] & kNdtCodeMask) != c) {
-      const uint2 wd = d.words[(uint32_t)(c >> 5)];
-      d.vstart[wd.y + __popc(wd.x & ((1u << (uint32_t)(c & 31)) - 1u))] = (uint32_t)s;
+    const unsigned long long kp = s ? (keys[s - 1] & lowmask) : ~0ull;
+    if (kp != k) {
+      int fine;
+      NdtCell* e = ndt_cell_insert(d, ndt_point_cell(d.info, p, fine));
+      atomicOr(&e->fmask, 1ull << fine);
+      if (s == 0 || (kp >> 6) != (k >> 6)) e->start = (uint32_t)s;
+      if (s == 0 || (kp >> 12) != (k >> 12)) d.vstart[(uint32_t)(k >> 12)] = (uint32_t)s;
     }
   }
   // one past the last valid point closes the last voxel
-  if (valid && (s == d.nt - 1 || (keys[s + 1] & kNdtCodeMask) == 0xffffffffull)) d.vstart[d.info->nocc] = (uint32_t)s + 1u;
-  if (s == 0 && !valid) d.vstart[0] = 0u;
+  if (valid && (s == d.nt - 1 || (keys[s + 1] & lowmask) == lowmask)) { d.vstart[d.info->nocc] = (uint32_t)s + 1u; d.info->nvalid = s + 1; }
+  if (s == 0 && !valid) { d.vstart[0] = 0u; d.info->nvalid = 0; }
+}
+
+// the entries' masks and starts stand: the first point of every fine cell records where the cell begins, the last point of a mid cell
+// closes its run; the crowded voxels are listed
+__global__ __launch_bounds__(256) void ndt_voxel_tails(const NdtDev* __restrict__ devs, const unsigned long long* keys) {
+  const NdtDev d = devs[blockIdx.y];
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.nt) return;
+  keys += d.key_off;
+  const unsigned long long lowmask = (1ull << d.key_bits) - 1ull;
+  const unsigned long long k = keys[s] & lowmask;
+  if (k == lowmask) return;
+  const unsigned long long kp = s ? (keys[s - 1] & lowmask) : ~0ull;
+  const unsigned long long kn = s + 1 < d.nt ? (keys[s + 1] & lowmask) : lowmask;
+  const bool head = kp != k, mid_tail = (kn >> 6) != (k >> 6);
+  if (!head && !mid_tail) return;
+  int fine;
+  NdtCell* e = ndt_cell_insert(d, ndt_point_cell(d.info, d.vpts[s], fine));
+  if (head) d.fpos[e->start + (uint32_t)__popcll(e->fmask & ((1ull << fine) - 1ull))] = (uint32_t)s;
+  if (mid_tail) e->end = (uint32_t)s + 1u;
+  if ((kn >> 12) != (k >> 12)) {
+    const uint32_t v = (uint32_t)(k >> 12);
+    if ((uint32_t)s + 1u - d.vstart[v] > (uint32_t)kNdtBigVoxel) d.big[atomicAdd((uint32_t*)&d.info->nbig, 1u)] = v;
+  }
 }
 
 __device__ void jacobi_eig3(double* A, double* V, double* w) {     // symmetric 3x3, cyclic Jacobi
@@ -208,40 +369,77 @@ __device__ void jacobi_eig3(double* A, double* V, double* w) {     // symmetric 
       }
 }
 
-// One wave per occupied voxel: sums over its points, then lane 0 finishes the Leaf (:282-367).
-__device__ __forceinline__ void ndt_voxel_stats_one(const NdtDev& d, int v, int lane);
+// One wave per occupied voxel: sums over its points, then lane 0 finishes the Leaf (:282-367).  A crowded voxel (a 1 m cell
+// of a dense submap next to the sensor holds 10 000+ points, and the launch lasted as long as the one wave that owned it) is
+// left to ndt_voxel_stats_big: a whole 1024-thread workgroup.  Which kernel sums a voxel follows from its size alone.
+__device__ __forceinline__ void ndt_voxel_finish(const NdtDev& d, int v, const double* s, const float* cs);
+struct NdtVoxelSums { double s[9]; float cs[3]; };
+__device__ __forceinline__ void ndt_voxel_add(NdtVoxelSums& a, const float4 p) {
+  const double x = p.x, y = p.y, z = p.z;
+  a.s[0] += x; a.s[1] += y; a.s[2] += z;                                 // leaf.mean_ += pt3d, :233
+  a.s[3] += x * x; a.s[4] += x * y; a.s[5] += x * z; a.s[6] += y * y; a.s[7] += y * z; a.s[8] += z * z;   // leaf.cov_ += pt pt^T, :235
+  a.cs[0] += p.x; a.cs[1] += p.y; a.cs[2] += p.z;                        // float centroid, :241
+}
+// a thread's share of the points [j0, j1): every `stride`-th from j0 + first, four loads in flight, added in the plain loop's order
+__device__ __forceinline__ void ndt_voxel_walk(NdtVoxelSums& a, const float4* __restrict__ vpts, uint32_t j0, uint32_t j1, uint32_t first, uint32_t stride) {
+  uint32_t j = j0 + first;
+  for (; j + 3 * stride < j1; j += 4 * stride) {
+    const float4 p0 = vpts[j], p1 = vpts[j + stride], p2 = vpts[j + 2 * stride], p3 = vpts[j + 3 * stride];
+    ndt_voxel_add(a, p0); ndt_voxel_add(a, p1); ndt_voxel_add(a, p2); ndt_voxel_add(a, p3);
+  }
+  for (; j < j1; j += stride) ndt_voxel_add(a, vpts[j]);
+}
 __global__ __launch_bounds__(256) void ndt_voxel_stats(const NdtDev* __restrict__ devs) {
   const NdtDev d = devs[blockIdx.y];
   const int lane = threadIdx.x & 63;
   // (the host does not know nocc: a grid sized by the point count is millions of empty workgroups for a batch of dense
   // submaps -- 4.9 ms of dispatch for 64 x 500 k points -- so a bounded grid strides over the occupied voxels instead)
   const int nocc = d.info->nocc;
-  for (int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); v < nocc; v += gridDim.x * (blockDim.x >> 6)) ndt_voxel_stats_one(d, v, lane);
-}
-__device__ __forceinline__ void ndt_voxel_stats_one(const NdtDev& d, int v, int lane) {
-  const uint32_t j0 = d.vstart[v], j1 = d.vstart[v + 1];
-  double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  float cs[3] = {0, 0, 0};
-  auto add = [&](const float4 p) {
-    const double x = p.x, y = p.y, z = p.z;
-    s[0] += x; s[1] += y; s[2] += z;                                 // leaf.mean_ += pt3d, :233
-    s[3] += x * x; s[4] += x * y; s[5] += x * z; s[6] += y * y; s[7] += y * z; s[8] += z * z;   // leaf.cov_ += pt pt^T, :235
-    cs[0] += p.x; cs[1] += p.y; cs[2] += p.z;                        // float centroid, :241
-  };
-  // four loads in flight per lane, added in the order of the plain loop (a 1 m voxel of a dense submap holds thousands of points,
-  // and with one load per trip the wave that owns it waited a memory latency per 64 of them)
-  uint32_t j = j0 + lane;
-  for (; j + 192 < j1; j += 256) {
-    const float4 p0 = d.vpts[j], p1 = d.vpts[j + 64], p2 = d.vpts[j + 128], p3 = d.vpts[j + 192];
-    add(p0); add(p1); add(p2); add(p3);
+  for (int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); v < nocc; v += gridDim.x * (blockDim.x >> 6)) {
+    const uint32_t j0 = d.vstart[v], j1 = d.vstart[v + 1];
+    if (j1 - j0 > (uint32_t)kNdtBigVoxel) continue;
+    NdtVoxelSums a{};
+    ndt_voxel_walk(a, d.vpts, j0, j1, lane, 64);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a.s[k] = wave_sum(a.s[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      for (int off = 32; off > 0; off >>= 1) a.cs[k] += __shfl_down(a.cs[k], off, 64);
+    if (lane == 0) ndt_voxel_finish(d, v, a.s, a.cs);
   }
-  for (; j < j1; j += 64) add(d.vpts[j]);
+}
+__global__ __launch_bounds__(1024) void ndt_voxel_stats_big(const NdtDev* __restrict__ devs) {
+  const NdtDev d = devs[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ double s_s[16][9];
+  __shared__ float s_c[16][3];
+  const int nbig = d.info->nbig;
+  for (int k = blockIdx.x; k < nbig; k += gridDim.x) {
+    const int v = (int)d.big[k];
+    const uint32_t j0 = d.vstart[v], j1 = d.vstart[v + 1];
+    NdtVoxelSums a{};
+    ndt_voxel_walk(a, d.vpts, j0, j1, threadIdx.x, 1024);
 #pragma unroll
-  for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
+    for (int c = 0; c < 9; ++c) a.s[c] = wave_sum(a.s[c]);
 #pragma unroll
-  for (int k = 0; k < 3; ++k)
-    for (int off = 32; off > 0; off >>= 1) cs[k] += __shfl_down(cs[k], off, 64);
-  if (lane != 0) return;
+    for (int c = 0; c < 3; ++c)
+      for (int off = 32; off > 0; off >>= 1) a.cs[c] += __shfl_down(a.cs[c], off, 64);
+    if (lane == 0) {
+      for (int c = 0; c < 9; ++c) s_s[wave][c] = a.s[c];
+      for (int c = 0; c < 3; ++c) s_c[wave][c] = a.cs[c];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t[9]; float tc[3];
+      for (int c = 0; c < 9; ++c) { double r = 0; for (int w = 0; w < 16; ++w) r += s_s[w][c]; t[c] = r; }
+      for (int c = 0; c < 3; ++c) { float r = 0; for (int w = 0; w < 16; ++w) r += s_c[w][c]; tc[c] = r; }
+      ndt_voxel_finish(d, v, t, tc);
+    }
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ void ndt_voxel_finish(const NdtDev& d, int v, const double* s, const float* cs) {
+  const uint32_t j0 = d.vstart[v], j1 = d.vstart[v + 1];
   NdtVoxel& o = d.vox[v];
   const int n = (int)(j1 - j0);
   const double nn = n;
@@ -1054,14 +1252,221 @@ __global__ __launch_bounds__(kNdtStepThreads) void ndt_ctl_step(const NdtDev* __
   }
 }
 
-// mean of the squared NN distances of slot 0 (pcl::Registration::getFitnessScore, ndt.cc:60)
-// grid = (64, pairs): pair slot pair_base + blockIdx.y of the matcher's d2 array ([slots][ns_cap]), ns[blockIdx.y] valid entries
-// (the sizes ride in the launch's arguments and the partial sums go straight into page-locked host memory: no copy either way)
-constexpr int kFitnessArgPairs = 64;
-struct FitnessArgs { int32_t ns[kFitnessArgPairs]; };
-__global__ __launch_bounds__(256) void fitness_partial(const float* d2_all, size_t ns_cap, int pair_base, const FitnessArgs A, double* partials_all) {
-  const float* d2 = d2_all + (size_t)(pair_base + blockIdx.y) * ns_cap;
-  const int n = A.ns[blockIdx.y];
+// ------------------------------------------------------------------------------------------
+// fitness score: exact 1-NN distances over the table's own points
+// ------------------------------------------------------------------------------------------
+// pcl::Registration::getFitnessScore (ndt.cc:60, ndt_gicp.cc:88,101): the source moved by the float final transformation, the
+// squared distance of every point to its nearest target point, their mean.  The target's points already lie sorted by voxel, mid
+// cell and fine cell, so the table IS the search structure -- no second grid is built over the raw target.
+//   ndt_fit_near  a lane per query: the 3 x 3 x 3 fine cells (1/16 voxel) around it, 27 independent hash probes (nine in flight at
+//                 a time), then the runs of the cells that exist.  A point outside that cube is at least a fine cell away, so a best
+//                 distance below that is the answer -- for most of a scan that lies on its submap.
+//   ndt_fit_wide  a wave per query the first pass could not settle: the 3 x 3 x 3 mid cells (1/4 voxel) around it, a lane per cell,
+//                 the wave walks the runs together; then shells of voxels around the query's own (a lane looks one voxel up through the
+//                 occupancy dictionary; a voxel farther than the best so far is skipped); after shell R everything unseen is at
+//                 least R + (distance to the own voxel's wall) away.
+//   ndt_fit_sweep a workgroup per query with nothing within kNdtFitMaxRing voxels: all points.
+// The lattice is exact in the scaled coordinate fl(p * inv) (floor and the fractional part of a float are exact operations); `marg`
+// covers that one rounding on both sides.  Distances: float, as FLANN's L2 functor.
+constexpr int kNdtFitMaxRing = 6;
+constexpr int kNdtFitWideBlocks = 1024;
+constexpr int kNdtFitSweepBlocks = 256;
+
+struct NdtQuery { float t[3]; int iv[3]; int c16[3]; float f[3]; bool finite; };
+__device__ __forceinline__ NdtQuery ndt_fit_query(const NdtDev& d, const PairInput& in, int i) {
+  const NdtGridInfo* g = d.info;
+  const float4 s = d.src[i];
+  NdtQuery q;
+  q.finite = isfinite(s.x) && isfinite(s.y) && isfinite(s.z);
+  // transformPointCloud(*input_, input_transformed, final_transformation_): the float 4x4
+  const double* G = in.guess;
+  q.t[0] = (float)G[0] * s.x + (float)G[1] * s.y + (float)G[2] * s.z + (float)G[3];
+  q.t[1] = (float)G[4] * s.x + (float)G[5] * s.y + (float)G[6] * s.z + (float)G[7];
+  q.t[2] = (float)G[8] * s.x + (float)G[9] * s.y + (float)G[10] * s.z + (float)G[11];
+  q.finite = q.finite && isfinite(q.t[0]) && isfinite(q.t[1]) && isfinite(q.t[2]);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float ps = q.t[c] * g->inv, fl = floorf(ps);
+    // (clamped far outside the box: every voxel test fails there anyway, and the int arithmetic stays in range)
+    q.iv[c] = (int)fminf(fmaxf(fl - (float)g->min_b[c], -1.0e6f), 1.0e6f);
+    q.f[c] = ps - fl;
+    q.c16[c] = min(15, (int)(q.f[c] * 16.0f));
+  }
+  return q;
+}
+__device__ __forceinline__ float ndt_d2(const float4 p, const float* t) {
+  const float dx = p.x - t[0], dy = p.y - t[1], dz = p.z - t[2];
+  return dx * dx + dy * dy + dz * dz;
+}
+
+__global__ __launch_bounds__(256) void ndt_fit_near(const NdtDev* __restrict__ devs, const PairInput* __restrict__ in, int first_slot) {
+  const int slot = first_slot + blockIdx.y;
+  const NdtDev d = devs[slot];
+  NdtGridInfo* g = d.info;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool have = i < d.ns;
+  NdtQuery q{};
+  if (have) q = ndt_fit_query(d, in[slot], i);
+  float best = INFINITY;
+  if (have && q.finite && !g->status) {
+    const int div0 = g->div_b[0], div1 = g->div_b[1], div2 = g->div_b[2], wx = g->wx;
+    // the cube in fine coordinates, and the (at most 2 x 2 x 2) mid cells it touches
+    int gf[3], mlo[3], mhi[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { gf[c] = q.iv[c] * 16 + q.c16[c]; mlo[c] = (gf[c] - 1) >> 2; mhi[c] = (gf[c] + 1) >> 2; }
+    for (int mz = mlo[2]; mz <= mhi[2]; ++mz) {
+      const int vz = mz >> 2;
+      if (vz < 0 || vz >= div2) continue;
+      const int az = max(gf[2] - 1, 4 * mz) - 4 * mz, bz = min(gf[2] + 1, 4 * mz + 3) - 4 * mz;
+      for (int my = mlo[1]; my <= mhi[1]; ++my) {
+        const int vy = my >> 2;
+        if (vy < 0 || vy >= div1) continue;
+        const int ay = max(gf[1] - 1, 4 * my) - 4 * my, by = min(gf[1] + 1, 4 * my + 3) - 4 * my;
+        for (int mx = mlo[0]; mx <= mhi[0]; ++mx) {
+          const int vx = mx >> 2;
+          if (vx < 0 || vx >= div0) continue;
+          const uint32_t code = ((uint32_t)((vz * div1 + vy) * wx + (vx >> 5)) << 5) | (uint32_t)(vx & 31);
+          const NdtCell* e = ndt_cell_find(d, ndt_mid_key(code, mz & 3, my & 3, mx & 3));
+          if (!e) continue;
+          const unsigned long long fm = e->fmask;
+          const uint32_t a = e->start, b = e->end, nf = (uint32_t)__popcll(fm);
+          const int ax = max(gf[0] - 1, 4 * mx) - 4 * mx, bx = min(gf[0] + 1, 4 * mx + 3) - 4 * mx;
+          for (int fz = az; fz <= bz; ++fz)
+            for (int fy = ay; fy <= by; ++fy) {
+              const int row = (fz * 4 + fy) * 4;
+              const uint32_t lo = (uint32_t)__popcll(fm & ((1ull << (row + ax)) - 1ull));
+              const uint32_t hi = (uint32_t)__popcll(fm & ((2ull << (row + bx)) - 1ull));
+              if (hi == lo) continue;
+              const uint32_t j0 = d.fpos[a + lo], j1 = hi == nf ? b : d.fpos[a + hi];
+              for (uint32_t j = j0; j < j1; ++j) best = fminf(best, ndt_d2(d.vpts[j], q.t));
+            }
+        }
+      }
+    }
+  }
+  if (have) d.fit_d2[i] = best;
+  // anything outside the cube is at least a fine cell away
+  const float bound = (0.0625f - g->marg) * g->res * 0.999999f;
+  const bool open = have && q.finite && !(best <= bound * bound);
+  // the open queries of the workgroup take one stretch of the list (one returning atomic per workgroup: one per query queued up
+  // on the counter for 18 ns each)
+  __shared__ uint32_t s_w[17];
+  __shared__ uint32_t s_base;
+  uint32_t total;
+  const uint32_t off = block_excl_scan(open ? 1u : 0u, s_w, &total);
+  if (threadIdx.x == 0) s_base = total ? atomicAdd(&g->nlist, total) : 0u;
+  __syncthreads();
+  if (open) d.qlist[s_base + off] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void ndt_fit_wide(const NdtDev* __restrict__ devs, const PairInput* __restrict__ in, int first_slot) {
+  const int slot = first_slot + blockIdx.y;
+  const NdtDev d = devs[slot];
+  NdtGridInfo* g = d.info;
+  const int lane = threadIdx.x & 63;
+  const uint32_t nlist = g->nlist;
+  const int div0 = g->div_b[0], div1 = g->div_b[1], div2 = g->div_b[2];
+  for (uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < nlist; k += gridDim.x * (blockDim.x >> 6)) {
+    const int i = (int)d.qlist[k];
+    const NdtQuery q = ndt_fit_query(d, in[slot], i);
+    float best = d.fit_d2[i];                                // what the cube held (or infinity)
+    const float wall = fminf(fminf(fminf(q.f[0], 1.f - q.f[0]), fminf(q.f[1], 1.f - q.f[1])), fminf(q.f[2], 1.f - q.f[2]));
+    bool settled = false;
+    if (!g->status) {
+      {
+        // the 27 mid cells around the query's own: a lane per cell, their runs walked by the whole wave
+        uint32_t j0 = 0, j1 = 0;
+        if (lane < 27) {
+          const int m0 = q.iv[0] * 4 + (q.c16[0] >> 2) + lane % 3 - 1, m1 = q.iv[1] * 4 + (q.c16[1] >> 2) + (lane / 3) % 3 - 1, m2 = q.iv[2] * 4 + (q.c16[2] >> 2) + lane / 9 - 1;
+          const int vx = m0 >> 2, vy = m1 >> 2, vz = m2 >> 2;
+          if (vx >= 0 && vx < div0 && vy >= 0 && vy < div1 && vz >= 0 && vz < div2) {
+            const uint32_t code = ((uint32_t)((vz * div1 + vy) * g->wx + (vx >> 5)) << 5) | (uint32_t)(vx & 31);
+            const NdtCell* e = ndt_cell_find(d, ndt_mid_key(code, m2 & 3, m1 & 3, m0 & 3));
+            if (e) { j0 = e->start; j1 = e->end; }
+          }
+        }
+        unsigned long long live = __ballot(j1 > j0);
+        while (live) {
+          const int l = __ffsll((long long)live) - 1;
+          live &= live - 1ull;
+          const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)j0, l), b = (uint32_t)__builtin_amdgcn_readlane((int)j1, l);
+          for (uint32_t j = a + lane; j < b; j += 64) best = fminf(best, ndt_d2(d.vpts[j], q.t));
+        }
+        best = wave_min(best);
+        best = __shfl(best, 0, 64);
+        const float bound = (0.25f - g->marg) * g->res * 0.999999f;
+        settled = best <= bound * bound;
+      }
+      for (int R = 0; R <= kNdtFitMaxRing && !settled; ++R) {
+        const int side = 2 * R + 1, cells = side * side * side;
+        for (int c0 = 0; c0 < cells; c0 += 64) {
+          // a lane per voxel of the shell: its run of points, if it is occupied and not farther than the best so far
+          uint32_t j0 = 0, j1 = 0;
+          const int c = c0 + lane;
+          if (c < cells) {
+            const int dx = c % side - R, dy = (c / side) % side - R, dz = c / (side * side) - R;
+            const int vx = q.iv[0] + dx, vy = q.iv[1] + dy, vz = q.iv[2] + dz;
+            if (max(abs(dx), max(abs(dy), abs(dz))) == R && vx >= 0 && vx < div0 && vy >= 0 && vy < div1 && vz >= 0 && vz < div2) {
+              // distance from the query to the voxel's box, in voxels
+              const float gx = dx > 0 ? (float)dx - q.f[0] : (dx < 0 ? q.f[0] - (float)(dx + 1) : 0.f);
+              const float gy = dy > 0 ? (float)dy - q.f[1] : (dy < 0 ? q.f[1] - (float)(dy + 1) : 0.f);
+              const float gz = dz > 0 ? (float)dz - q.f[2] : (dz < 0 ? q.f[2] - (float)(dz + 1) : 0.f);
+              const float gap = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz) - g->marg, 0.f) * g->res * 0.999999f;
+              if (gap * gap <= best) {
+                const uint2 wd = d.words[(vz * div1 + vy) * g->wx + (vx >> 5)];
+                if ((wd.x >> (vx & 31)) & 1u) {
+                  const uint32_t v = wd.y + __popc(wd.x & ((1u << (vx & 31)) - 1u));
+                  j0 = d.vstart[v]; j1 = d.vstart[v + 1];
+                }
+              }
+            }
+          }
+          unsigned long long live = __ballot(j1 > j0);
+          while (live) {
+            const int l = __ffsll((long long)live) - 1;
+            live &= live - 1ull;
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)j0, l), b = (uint32_t)__builtin_amdgcn_readlane((int)j1, l);
+            for (uint32_t j = a + lane; j < b; j += 64) best = fminf(best, ndt_d2(d.vpts[j], q.t));
+          }
+        }
+        best = wave_min(best);
+        best = __shfl(best, 0, 64);
+        const float bound = fmaxf((float)R + wall - g->marg, 0.f) * g->res * 0.999999f;
+        settled = best <= bound * bound;
+      }
+    }
+    if (lane == 0) {
+      if (settled) d.fit_d2[i] = best;
+      else { d.fit_d2[i] = best; d.qleft[atomicAdd(&g->nleft, 1u)] = (uint32_t)i; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ndt_fit_sweep(const NdtDev* __restrict__ devs, const PairInput* __restrict__ in, int first_slot) {
+  const int slot = first_slot + blockIdx.y;
+  const NdtDev d = devs[slot];
+  const NdtGridInfo* g = d.info;
+  const uint32_t nleft = g->nleft;
+  __shared__ float s_m[4];
+  for (uint32_t k = blockIdx.x; k < nleft; k += gridDim.x) {
+    const int i = (int)d.qleft[k];
+    const NdtQuery q = ndt_fit_query(d, in[slot], i);
+    float best = d.fit_d2[i];
+    for (int j = threadIdx.x; j < g->nvalid; j += blockDim.x) best = fminf(best, ndt_d2(d.vpts[j], q.t));
+    best = wave_min(best);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) d.fit_d2[i] = fminf(fminf(s_m[0], s_m[1]), fminf(s_m[2], s_m[3]));
+    __syncthreads();
+  }
+}
+
+// mean of the squared NN distances (pcl::Registration::getFitnessScore, ndt.cc:60): grid = (64, slots); the partial sums go
+// straight into page-locked host memory (row first_slot-relative): no copy
+__global__ __launch_bounds__(256) void fitness_partial(const NdtDev* __restrict__ devs, int first_slot, double* partials_all) {
+  const NdtDev d = devs[first_slot + blockIdx.y];
+  const float* d2 = d.fit_d2;
+  const int n = d.ns;
   double* partials = partials_all + (size_t)blockIdx.y * 128;
   double s = 0, c = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -1076,6 +1481,12 @@ __global__ __launch_bounds__(256) void fitness_partial(const float* d2_all, size
     partials[2 * blockIdx.x] = s_s[0] + s_s[1] + s_s[2] + s_s[3];
     partials[2 * blockIdx.x + 1] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
   }
+}
+
+// the fitness search's counters of slots [first, first + n) back to zero (every search starts from empty lists)
+__global__ void ndt_fit_reset(const NdtDev* __restrict__ devs, int first_slot, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) { NdtGridInfo* g = devs[first_slot + k].info; g->nlist = 0u; g->nleft = 0u; }
 }
 
 }  // namespace smhip

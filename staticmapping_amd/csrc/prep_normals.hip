@@ -466,7 +466,11 @@ PrepWorkspace* prep_create(int max_points) {
     size_t bytes = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                     (const int32_t*)nullptr, (int32_t*)nullptr, (unsigned)max_points, 0, 64, (hipStream_t)0);
-    w->sort_bytes = bytes + 256;
+    size_t bytes1 = 0;        // prep_sort_pairs' one-sweep configuration
+    using OneSweep = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 32768>;
+    (void)rocprim::radix_sort_pairs<OneSweep>(nullptr, bytes1, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                              (const int32_t*)nullptr, (int32_t*)nullptr, (unsigned)max_points, 0, 64, (hipStream_t)0);
+    w->sort_bytes = std::max(bytes, bytes1) + 256;
     A(&w->sort_tmp, w->sort_bytes);
   }
   if (ok && hipHostMalloc((void**)&w->host_pinned, (size_t)4 * (8 + 6 * kMaxScans + 16)) != hipSuccess) ok = false;
@@ -559,7 +563,10 @@ int32_t* prep_values(PrepWorkspace* w, int which) { return w->order[which & 1]; 
 hipError_t prep_sort_pairs(PrepWorkspace* w, hipStream_t st, int n, int end_bit) {
   if (!w || n <= 0 || n > w->cap) return hipErrorInvalidValue;
   size_t bytes = w->sort_bytes;
-  return rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[0], w->order[1], (unsigned)n, 0, (unsigned)end_bit, st);
+  // (rocPRIM sorts up to a million items by merging: ~18 launches for one 500 k-point target, against one histogram pass + one
+  // launch per 8 key bits of its one-sweep radix sort -- and the caller passes as few bits as its keys can have)
+  using OneSweep = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 32768>;
+  return rocprim::radix_sort_pairs<OneSweep>(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[0], w->order[1], (unsigned)n, 0, (unsigned)end_bit, st);
 }
 
 // Morton (Z-order) permutation of a cloud on the device: out[k] = raw[perm[k]], w = perm[k].

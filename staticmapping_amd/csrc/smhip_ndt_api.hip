@@ -29,6 +29,13 @@ struct NdtHost {
   uint32_t* vstart_all = nullptr;     // [cap][nt_cap + 1]
   float4* vpts_all = nullptr;         // [cap][nt_cap]
   NdtVoxel* vox_all = nullptr;
+  NdtCell* cells_all = nullptr;       // [cap][cells_cap] hash tables of the mid cells
+  size_t cells_cap = 0;               // entries per slot: the power of two >= 2 nt_cap
+  uint32_t* fpos_all = nullptr;       // [cap][nt_cap]
+  uint32_t* big_all = nullptr;        // [cap][nt_cap / kNdtBigVoxel + 1]
+  uint32_t* qlist_all = nullptr;      // [cap][2][ns_cap]
+  float* bbox_all = nullptr;          // [cap][kNdtBoxBlocks][8]
+  float* fit_d2_all = nullptr;        // [cap][ns_cap]
   double* icovd_all = nullptr;        // [cap][nt_cap][6]
   double* partials_all = nullptr;     // [cap][rows][kNdtCols], rows = a workgroup of ndt_derivatives_ctl per 256 source points
   int rows = 0;
@@ -107,7 +114,11 @@ smhip_status ndt_ensure(smhip_context* h, int need = 1) {
     if (ok && hipHostMalloc(&v, count * sizeof(**p)) == hipSuccess) { n.host_allocs.push_back(v); *p = reinterpret_cast<decltype(*p)>(v); } else ok = false;
   };
   D(&n.devs_dev, K); D(&n.info_all, K); D(&n.bits_all, K * kNdtMaxWords); D(&n.words_all, K * kNdtMaxWords);
+  const size_t NS = h->dev.ns_cap, NBIG = NT / kNdtBigVoxel + 1;
   D(&n.vstart_all, K * (NT + 1)); D(&n.vpts_all, K * NT); D(&n.vox_all, K * NT); D(&n.icovd_all, K * NT * 6);
+  n.cells_cap = 1; while (n.cells_cap < 2 * NT) n.cells_cap <<= 1;
+  D(&n.cells_all, K * n.cells_cap); D(&n.fpos_all, K * NT); D(&n.big_all, K * NBIG); D(&n.qlist_all, K * 2 * NS); D(&n.bbox_all, K * (size_t)kNdtBoxBlocks * 8);
+  D(&n.fit_d2_all, K * NS);
   n.rows = ceil_div(h->dev.ns_cap, kNdtDerivThreads);
   D(&n.partials_all, K * (size_t)n.rows * kNdtCols); D(&n.out_all, K * kNdtOutCols);
   D(&n.ctl_dev, K); D(&n.vkey, NT);
@@ -123,7 +134,9 @@ smhip_status ndt_ensure(smhip_context* h, int need = 1) {
     d.info = n.info_all + k; d.bits = n.bits_all + k * kNdtMaxWords; d.words = n.words_all + k * kNdtMaxWords;
     d.vstart = n.vstart_all + k * (NT + 1); d.vpts = n.vpts_all + k * NT; d.vox = n.vox_all + k * NT; d.icovd = n.icovd_all + k * NT * 6;
     d.partials = n.partials_all + k * (size_t)n.rows * kNdtCols; d.out = n.out_all + k * kNdtOutCols;
-    d.tgt = h->dev.tgt_p + k * NT; d.src = h->dev.src + k * (size_t)h->dev.ns_cap; d.tpart = h->dev.tpart + k * kTgtReduceBlocks * 16;
+    d.tgt = h->dev.tgt_p + k * NT; d.src = h->dev.src + k * NS;
+    d.cells = n.cells_all + k * n.cells_cap; d.fpos = n.fpos_all + k * NT; d.big = n.big_all + k * NBIG;
+    d.qlist = n.qlist_all + k * 2 * NS; d.qleft = d.qlist + NS; d.bbox = n.bbox_all + k * (size_t)kNdtBoxBlocks * 8; d.fit_d2 = n.fit_d2_all + k * NS;
   }
   return SMHIP_OK;
 }
@@ -147,13 +160,18 @@ bool ndt_table_current(const smhip_context* h, const NdtHost& n, int slot) {
 // per-slot sizes / options into the device array the kernels index (a copy only when something changed since the last one)
 smhip_status ndt_push_devs(smhip_context* h, int first, int K) {
   NdtHost& n = ndt_of(h);
-  int off = 0;
+  int off = 0, nt_max = 0;
   bool same = true;
+  for (int k = first; k < first + K; ++k) nt_max = std::max(nt_max, h->nt[k]);
+  int sbits = 1;
+  while ((1ll << sbits) <= (long long)nt_max) ++sbits;        // slots < nt_max < 2^sbits: the all-ones key below never names a voxel
   for (int k = first; k < first + K; ++k) {
     NdtDev& d = n.devs_host[k];
     d.nt = h->nt[k]; d.ns = h->ns[k];
     d.min_points = n.opts.min_points_per_voxel; d.eig_mult = n.opts.min_covar_eigvalue_mult;
     d.key_off = off; off += d.nt;
+    d.key_bits = sbits + 12;
+    d.log2cells = 2; while ((1ll << d.log2cells) < 2ll * d.nt) ++d.log2cells;      // (never above cells_cap: nt <= nt_cap)
     same = same && std::memcmp(&d, &n.devs_sent[k], sizeof(NdtDev)) == 0;
   }
   if (same) return SMHIP_OK;
@@ -185,24 +203,26 @@ smhip_status ndt_enqueue_grids(smhip_context* h, int first, int K) {
   int nt_max = 0, nt_sum = 0;
   for (int k = first; k < first + K; ++k) { nt_max = std::max(nt_max, h->nt[k]); nt_sum += h->nt[k]; n.meta[k].valid = false; }
   HIPCHK(h, hipMemsetAsync(n.bits_all + (size_t)first * kNdtMaxWords, 0, sizeof(uint32_t) * (size_t)kNdtMaxWords * K, h->stream));
-  IcpDev rd = h->dev; rd.npairs = K; rd.pair_base = first;
+  // the cell tables start empty (key ~0; the mask bits are cleared by the fill kernel below), each over the part its target's size makes it use
+  hipLaunchKernelGGL(ndt_cells_clear, dim3(std::max(64, 4096 / K), K), dim3(256), 0, h->stream, n.devs_dev + first);
   const NdtDev* devs = n.devs_dev + first;
   const int gb = ceil_div(nt_max, 256);
-  hipLaunchKernelGGL(tgt_reduce, dim3(kTgtReduceBlocks, K), dim3(256), 0, h->stream, rd);
+  hipLaunchKernelGGL(ndt_bbox, dim3(kNdtBoxBlocks, K), dim3(256), 0, h->stream, devs);
   hipLaunchKernelGGL(ndt_voxel_setup, dim3(K), dim3(64), 0, h->stream, devs, n.opts.resolution);
-  // (voxel code, point) pairs sorted with the rocPRIM radix sort of the workspace; the voxel's slot is the rank of its bit,
-  // which is also its position among the sorted unique codes, so the sorted points ARE vpts
+  hipLaunchKernelGGL(ndt_voxel_mark, dim3(gb, K), dim3(256), 0, h->stream, devs);
+  hipLaunchKernelGGL(ndt_voxel_rank, dim3(K), dim3(1024), 0, h->stream, devs);
+  // (slot << 6 | sub-cell, point) pairs sorted with the rocPRIM radix sort of the workspace: as few key bits as the largest
+  // target of the batch can need.  The sorted points ARE vpts
   hipLaunchKernelGGL(ndt_voxel_keys64, dim3(gb, K), dim3(256), 0, h->stream, devs, prep_keys(n.prep, 0), prep_values(n.prep, 0));
   int kbits = 0;
   while ((1 << kbits) < K) ++kbits;
-  const hipError_t e = prep_sort_pairs(n.prep, h->stream, nt_sum, 33 + kbits);
+  const hipError_t e = prep_sort_pairs(n.prep, h->stream, nt_sum, n.devs_host[first].key_bits + kbits);
   if (e != hipSuccess) { h->err = std::string("NDT voxel sort: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
-  hipLaunchKernelGGL(ndt_voxel_heads, dim3(gb, K), dim3(256), 0, h->stream, devs, prep_keys(n.prep, 1));
-  hipLaunchKernelGGL(ndt_voxel_rank, dim3(K), dim3(1024), 0, h->stream, devs);
-  hipLaunchKernelGGL(ndt_voxel_starts, dim3(gb, K), dim3(256), 0, h->stream, devs, prep_keys(n.prep, 1), prep_values(n.prep, 1));
-  // one wave per occupied voxel; nocc <= nt
+  hipLaunchKernelGGL(ndt_voxel_heads, dim3(gb, K), dim3(256), 0, h->stream, devs, prep_keys(n.prep, 1), prep_values(n.prep, 1));
+  hipLaunchKernelGGL(ndt_voxel_tails, dim3(gb, K), dim3(256), 0, h->stream, devs, prep_keys(n.prep, 1));
+  // one wave per occupied voxel (nocc <= nt), a workgroup per crowded one
   hipLaunchKernelGGL(ndt_voxel_stats, dim3(std::min(ceil_div(nt_max, 4), std::max(64, 8192 / K)), K), dim3(256), 0, h->stream, devs);
-  HIPCHK(h, hipMemcpyAsync(n.info_pinned + first, n.info_all + first, sizeof(NdtGridInfo) * K, hipMemcpyDeviceToHost, h->stream));
+  hipLaunchKernelGGL(ndt_voxel_stats_big, dim3(std::max(8, 256 / K), K), dim3(1024), 0, h->stream, devs);
   HIPCHK(h, hipGetLastError());
   return SMHIP_OK;
 }
@@ -221,6 +241,7 @@ smhip_status ndt_build_grids(smhip_context* h, int first, int K) {      // build
   smhip_status s = ndt_push_inputs(h, first, K, nullptr);
   if (s == SMHIP_OK) s = ndt_enqueue_grids(h, first, K);
   if (s) return s;
+  HIPCHK(h, hipMemcpyAsync(ndt_of(h).info_pinned + first, ndt_of(h).info_all + first, sizeof(NdtGridInfo) * K, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return ndt_tables_built(h, first, K);
 }
@@ -277,54 +298,16 @@ void ndt_enqueue_round(smhip_context* h, int first, int K, int blocks, const Ndt
 // target (ndt.cc:60, ndt_gicp.cc:88,101), for slots [first, first + K) in one pass.  In two parts: the search structure over the
 // raw targets (independent of the pose: enqueued before the rounds), and the search itself with the pose that stands in the
 // slots' pair input rows on the device.
-struct FitnessSaved { int sort_cells, use_ball, max_ring; };
-FitnessSaved fitness_settings(smhip_context* h) {
-  // distances only: no tie-order requirement (skip the per-cell sort) and no previous match to seed a
-  // ball search -> plain exact ring search (r = 1 certifies almost every query against a dense submap)
-  const FitnessSaved w{h->dev.sort_cells, h->dev.use_ball, h->dev.max_ring};
-  h->dev.sort_cells = 0; h->dev.use_ball = 0;
-  h->dev.max_ring = std::max(w.max_ring, 32);      // wide rings are cheap with the row-occupancy bitmap; fewer queries reach the brute-force sweep
-  return w;
-}
-void fitness_restore(smhip_context* h, const FitnessSaved& w) { h->dev.sort_cells = w.sort_cells; h->dev.use_ball = w.use_ball; h->dev.max_ring = w.max_ring; }
-
-smhip_status fitness_enqueue_structure(smhip_context* h, int first, int K) {
-  int nt_max = 0;
-  for (int k = first; k < first + K; ++k) nt_max = std::max(nt_max, h->nt[k]);
-  const FitnessSaved w = fitness_settings(h);
-  bool cached = true;
-  for (int k = first; k < first + K; ++k) cached = cached && grid_cached(h, k);
-  smhip_status s = SMHIP_OK;
-  if (cached) {
-    s = ensure_packed(h, first, K);
-    h->cache_hits++;
-  } else {
-    touch_grid(h, first, K);
-    hipLaunchKernelGGL(reset_scratch, dim3(std::min(4096, 256 * K)), dim3(256), 0, h->stream, h->dev, first, K);
-    s = ensure_packed(h, first, K);
-    if (s == SMHIP_OK) s = enqueue_grid_build(h, whole_batch(h, K, first), nt_max);
-  }
-  fitness_restore(h, w);
-  return s;
-}
-
 smhip_status fitness_enqueue_search(smhip_context* h, int first, int K) {
   NdtHost& n = ndt_of(h);
   int ns_max = 0;
   for (int k = first; k < first + K; ++k) ns_max = std::max(ns_max, h->ns[k]);
-  const FitnessSaved w = fitness_settings(h);
-  const Half f = whole_batch(h, K, first);
-  hipLaunchKernelGGL(reset_scratch_light, dim3(std::min(1024, 8 * K)), dim3(256), 0, h->stream, f.d, first, K);
-  hipLaunchKernelGGL(pose_setup, dim3(ceil_div(K, 64)), dim3(64), 0, h->stream, f.d, K);
-  smhip_status s = enqueue_find_closests_half(h, f, ns_max, 0);
-  fitness_restore(h, w);
-  if (s) return s;
-  for (int k0 = 0; k0 < K; k0 += kFitnessArgPairs) {
-    FitnessArgs A{};
-    const int kn = std::min(kFitnessArgPairs, K - k0);
-    for (int k = 0; k < kn; ++k) A.ns[k] = h->ns[first + k0 + k];
-    hipLaunchKernelGGL(fitness_partial, dim3(64, kn), dim3(256), 0, h->stream, h->dev.d2, (size_t)h->dev.ns_cap, first + k0, A, n.fit_pinned + (size_t)128 * k0);
-  }
+  PairInput* in = const_cast<PairInput*>(h->dev.in);
+  hipLaunchKernelGGL(ndt_fit_reset, dim3(ceil_div(K, 64)), dim3(64), 0, h->stream, n.devs_dev, first, K);
+  hipLaunchKernelGGL(ndt_fit_near, dim3(ceil_div(ns_max, 256), K), dim3(256), 0, h->stream, n.devs_dev, in, first);
+  hipLaunchKernelGGL(ndt_fit_wide, dim3(std::max(8, kNdtFitWideBlocks / K), K), dim3(256), 0, h->stream, n.devs_dev, in, first);
+  hipLaunchKernelGGL(ndt_fit_sweep, dim3(std::max(4, kNdtFitSweepBlocks / K), K), dim3(256), 0, h->stream, n.devs_dev, in, first);
+  hipLaunchKernelGGL(fitness_partial, dim3(64, K), dim3(256), 0, h->stream, n.devs_dev, first, n.fit_pinned);
   HIPCHK(h, hipGetLastError());
   return SMHIP_OK;
 }
@@ -345,11 +328,20 @@ smhip_status fitness_scores(smhip_context* h, int first, int K, const double* T,
   for (int k = first; k < first + K; ++k)
     if (h->ns[k] <= 0 || h->nt[k] <= 0) { h->err = "fitness score before SetInputSource/SetInputTarget"; return SMHIP_ERR_NOT_READY; }
   smhip_status s = ndt_ensure(h, first + K);
-  if (s == SMHIP_OK) s = ndt_push_inputs(h, first, K, T);
-  if (s == SMHIP_OK) s = fitness_enqueue_structure(h, first, K);
+  if (s) return s;
+  NdtHost& n = ndt_of(h);
+  s = ndt_push_inputs(h, first, K, T);
+  if (s) return s;
+  // the search structure is the slots' voxel tables: built here unless they are current
+  bool current = true;
+  for (int k = first; k < first + K; ++k) current = current && ndt_table_current(h, n, k);
+  if (current) s = ndt_push_devs(h, first, K);
+  else s = ndt_enqueue_grids(h, first, K);
   if (s == SMHIP_OK) s = fitness_enqueue_search(h, first, K);
   if (s) return s;
+  if (!current) HIPCHK(h, hipMemcpyAsync(n.info_pinned + first, n.info_all + first, sizeof(NdtGridInfo) * K, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (!current) { s = ndt_tables_built(h, first, K); if (s) return s; }
   fitness_collect(h, K, out);
   return SMHIP_OK;
 }
@@ -378,8 +370,6 @@ smhip_status ndt_align_slots(smhip_context* h, int first, int K, const double* g
     s = ndt_enqueue_grids(h, first, K);
     if (s) return s;
   }
-  s = fitness_enqueue_structure(h, first, K);
-  if (s) return s;
   const NdtCtlOpts o = ndt_ctl_opts(n);
   int ns_max = 0;
   for (int k = first; k < first + K; ++k) ns_max = std::max(ns_max, h->ns[k]);
@@ -399,6 +389,7 @@ smhip_status ndt_align_slots(smhip_context* h, int first, int K, const double* g
     for (; rounds < want; ++rounds) ndt_enqueue_round(h, first, K, blocks, o, rounds, nullptr);
     s = fitness_enqueue_search(h, first, K);       // speculative: valid if every job has ended by now
     if (s) return s;
+    HIPCHK(h, hipMemcpyAsync(n.info_pinned + first, n.info_all + first, sizeof(NdtGridInfo) * K, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     n.last_submissions++;

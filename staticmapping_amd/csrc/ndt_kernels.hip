@@ -79,6 +79,8 @@ struct NdtDev {
   NdtCell* cells;          // [1 << log2cells] hash table of the occupied mid cells
   uint32_t* fpos;          // [nt] fpos[start of a mid cell + r] = where its r-th occupied fine cell begins
   uint32_t* big;           // [nt / kNdtBigVoxel + 1] the crowded voxels
+  double* vsum;            // [nt][12] a voxel's raw sums (x y z, xx xy xz yy yz zz, float centroid sums) between the summing and the finishing pass
+  float4* vbox;            // [nt] lower corner of every occupied voxel in scaled coordinates (p * inv): the far search prunes by boxes
   uint32_t* qlist;         // [ns] fitness search: queries the first pass hands to the second
   uint32_t* qleft;         // [ns] ... and the second to the sweep
   double* icovd;           // [nt][6] Leaf::icov_ in double: xx xy xz yy yz zz (stock PCL path reads these)
@@ -176,35 +178,30 @@ __device__ __forceinline__ uint32_t ndt_voxel_code(const NdtGridInfo* g, const f
   return ((uint32_t)((i2 * g->div_b[1] + i1) * g->wx + (i0 >> 5)) << 5) | (uint32_t)(i0 & 31);
 }
 
-// A workgroup's 256 points fall into a handful of voxels (a submap's points arrive ring by ring; 500 k of them fill a few thousand
-// 1 m voxels): the distinct codes are collected in a small LDS set first, and only those go to the bit grid -- one global atomicOr per
-// (workgroup, voxel) instead of one per point, which queued up on the few hundred words a dense target occupies.
-__global__ __launch_bounds__(256) void ndt_voxel_mark(const NdtDev* __restrict__ devs) {
+// 500 k points of a submap fill a few thousand voxels -- a dozen cache lines of the bit grid -- and one atomicOr per point queues
+// up on them (a look at the word first is no better: device-scope loads of the same few lines queue up just the same; and the points
+// arrive interleaved over the 64 rings, so neighbours in the array are no neighbours in space and nothing combines inside a wave).
+// A workgroup of 1024 points holds ~100 distinct voxels: each point enters its code into an LDS set, and only the one that finds
+// its place empty sends the atomicOr -- a tenth of the traffic on the hot lines.
+constexpr int kNdtMarkThreads = 1024;
+__global__ __launch_bounds__(kNdtMarkThreads) void ndt_voxel_mark(const NdtDev* __restrict__ devs) {
   const NdtDev d = devs[blockIdx.y];
-  constexpr int kSet = 128;
+  constexpr int kSet = 1024;
   __shared__ uint32_t s_set[kSet];
-  if (threadIdx.x < kSet) s_set[threadIdx.x] = 0xffffffffu;
+  s_set[threadIdx.x] = 0xffffffffu;
   __syncthreads();
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t code = 0xffffffffu;
-  if (j < d.nt) code = ndt_voxel_code(d.info, d.tgt[j]);
-  const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)0xfffffffeu, (int)code, 0x138, 0xf, 0xf, false);   // wave_shr 1; lane 0 keeps the fill
-  if (code != 0xffffffffu && code != prev) {
-    // a run's first point: into the set, or straight to the grid when its probe window is taken by other codes
-    uint32_t hpos = (code * 0x9E3779B1u) >> 25;
-    bool placed = false;
-    for (int t = 0; t < 8 && !placed; ++t) {
-      const uint32_t was = atomicCAS(&s_set[hpos], 0xffffffffu, code);
-      placed = was == 0xffffffffu || was == code;
-      hpos = (hpos + 1u) & (kSet - 1);
-    }
-    if (!placed) atomicOr(&d.bits[code >> 5], 1u << (code & 31));
+  if (j >= d.nt) return;
+  const uint32_t code = ndt_voxel_code(d.info, d.tgt[j]);
+  if (code == 0xffffffffu) return;
+  uint32_t hpos = (code * 0x9E3779B1u) >> 22;
+  for (int t = 0; t < 16; ++t) {
+    const uint32_t was = atomicCAS(&s_set[hpos], 0xffffffffu, code);
+    if (was == code) return;                               // another point of the workgroup speaks for this voxel
+    if (was == 0xffffffffu) break;
+    hpos = (hpos + 1u) & (kSet - 1);
   }
-  __syncthreads();
-  if (threadIdx.x < kSet) {
-    const uint32_t c = s_set[threadIdx.x];
-    if (c != 0xffffffffu) atomicOr(&d.bits[c >> 5], 1u << (c & 31));
-  }
+  atomicOr(&d.bits[code >> 5], 1u << (code & 31));         // first of its voxel here (or no room in its probe window)
 }
 
 // one 1024-thread block: words = {bits, exclusive rank}; nocc
@@ -289,8 +286,10 @@ __device__ __forceinline__ unsigned long long ndt_point_cell(const NdtGridInfo* 
   return ndt_mid_key(code, fz >> 2, fy >> 2, fx >> 2);
 }
 
-// sorted order: gather the points, voxel starts; the first point of every fine cell sets its bit in its mid cell's entry (made by
-// whoever comes first), the first point of a mid cell the entry's start
+// sorted order: every thread gathers its point; the first point of a mid cell walks the cell's run of keys (ten points on average),
+// collects the occupancy mask of its fine cells and where each begins, and enters the cell into the hash table; the first point of a
+// voxel records the voxel's start and box.  (One table insert per mid cell: with one per fine cell -- every second point of a
+// submap -- the inserts and their mask updates were the build's second largest cost.)
 __global__ __launch_bounds__(256) void ndt_voxel_heads(const NdtDev* __restrict__ devs, const unsigned long long* keys, const int32_t* vals) {
   const NdtDev d = devs[blockIdx.y];
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -305,41 +304,36 @@ __global__ __launch_bounds__(256) void ndt_voxel_heads(const NdtDev* __restrict_
     p.w = __int_as_float(j);
     d.vpts[s] = p;
     const unsigned long long kp = s ? (keys[s - 1] & lowmask) : ~0ull;
-    if (kp != k) {
+    if (s == 0 || (kp >> 6) != (k >> 6)) {
+      // the mid cell's run: keys[s ...] while the upper bits stay
+      unsigned long long fm = 0ull, prev = ~0ull;
+      uint32_t nf = 0, t = (uint32_t)s;
+      bool more = true;
+      while (more) {
+        unsigned long long kk[4];                          // four keys in flight
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kk[u] = (t + u < (uint32_t)d.nt) ? (keys[t + u] & lowmask) : lowmask;
+        const uint32_t t0 = t;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (more && (kk[u] >> 6) == (k >> 6)) {
+            if (kk[u] != prev) { fm |= 1ull << (uint32_t)(kk[u] & 63); d.fpos[(uint32_t)s + nf] = t0 + u; ++nf; prev = kk[u]; }
+            t = t0 + u + 1;
+          } else more = false;
+        }
+      }
       int fine;
       NdtCell* e = ndt_cell_insert(d, ndt_point_cell(d.info, p, fine));
-      atomicOr(&e->fmask, 1ull << fine);
-      if (s == 0 || (kp >> 6) != (k >> 6)) e->start = (uint32_t)s;
-      if (s == 0 || (kp >> 12) != (k >> 12)) d.vstart[(uint32_t)(k >> 12)] = (uint32_t)s;
+      e->start = (uint32_t)s; e->end = t; e->fmask = fm;
+      if (s == 0 || (kp >> 12) != (k >> 12)) {
+        d.vstart[(uint32_t)(k >> 12)] = (uint32_t)s;
+        d.vbox[(uint32_t)(k >> 12)] = make_float4(floorf(p.x * d.info->inv), floorf(p.y * d.info->inv), floorf(p.z * d.info->inv), 0.f);
+      }
     }
   }
   // one past the last valid point closes the last voxel
   if (valid && (s == d.nt - 1 || (keys[s + 1] & lowmask) == lowmask)) { d.vstart[d.info->nocc] = (uint32_t)s + 1u; d.info->nvalid = s + 1; }
   if (s == 0 && !valid) { d.vstart[0] = 0u; d.info->nvalid = 0; }
-}
-
-// the entries' masks and starts stand: the first point of every fine cell records where the cell begins, the last point of a mid cell
-// closes its run; the crowded voxels are listed
-__global__ __launch_bounds__(256) void ndt_voxel_tails(const NdtDev* __restrict__ devs, const unsigned long long* keys) {
-  const NdtDev d = devs[blockIdx.y];
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= d.nt) return;
-  keys += d.key_off;
-  const unsigned long long lowmask = (1ull << d.key_bits) - 1ull;
-  const unsigned long long k = keys[s] & lowmask;
-  if (k == lowmask) return;
-  const unsigned long long kp = s ? (keys[s - 1] & lowmask) : ~0ull;
-  const unsigned long long kn = s + 1 < d.nt ? (keys[s + 1] & lowmask) : lowmask;
-  const bool head = kp != k, mid_tail = (kn >> 6) != (k >> 6);
-  if (!head && !mid_tail) return;
-  int fine;
-  NdtCell* e = ndt_cell_insert(d, ndt_point_cell(d.info, d.vpts[s], fine));
-  if (head) d.fpos[e->start + (uint32_t)__popcll(e->fmask & ((1ull << fine) - 1ull))] = (uint32_t)s;
-  if (mid_tail) e->end = (uint32_t)s + 1u;
-  if ((kn >> 12) != (k >> 12)) {
-    const uint32_t v = (uint32_t)(k >> 12);
-    if ((uint32_t)s + 1u - d.vstart[v] > (uint32_t)kNdtBigVoxel) d.big[atomicAdd((uint32_t*)&d.info->nbig, 1u)] = v;
-  }
 }
 
 __device__ void jacobi_eig3(double* A, double* V, double* w) {     // symmetric 3x3, cyclic Jacobi
@@ -372,7 +366,6 @@ __device__ void jacobi_eig3(double* A, double* V, double* w) {     // symmetric 
 // One wave per occupied voxel: sums over its points, then lane 0 finishes the Leaf (:282-367).  A crowded voxel (a 1 m cell
 // of a dense submap next to the sensor holds 10 000+ points, and the launch lasted as long as the one wave that owned it) is
 // left to ndt_voxel_stats_big: a whole 1024-thread workgroup.  Which kernel sums a voxel follows from its size alone.
-__device__ __forceinline__ void ndt_voxel_finish(const NdtDev& d, int v, const double* s, const float* cs);
 struct NdtVoxelSums { double s[9]; float cs[3]; };
 __device__ __forceinline__ void ndt_voxel_add(NdtVoxelSums& a, const float4 p) {
   const double x = p.x, y = p.y, z = p.z;
@@ -389,6 +382,11 @@ __device__ __forceinline__ void ndt_voxel_walk(NdtVoxelSums& a, const float4* __
   }
   for (; j < j1; j += stride) ndt_voxel_add(a, vpts[j]);
 }
+__device__ __forceinline__ void ndt_voxel_store_sums(const NdtDev& d, int v, const double* s, const float* cs) {
+  double* o = d.vsum + (size_t)v * 12;
+  for (int k = 0; k < 9; ++k) o[k] = s[k];
+  for (int k = 0; k < 3; ++k) o[9 + k] = (double)cs[k];                // (a float's double is exact)
+}
 __global__ __launch_bounds__(256) void ndt_voxel_stats(const NdtDev* __restrict__ devs) {
   const NdtDev d = devs[blockIdx.y];
   const int lane = threadIdx.x & 63;
@@ -397,7 +395,10 @@ __global__ __launch_bounds__(256) void ndt_voxel_stats(const NdtDev* __restrict_
   const int nocc = d.info->nocc;
   for (int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); v < nocc; v += gridDim.x * (blockDim.x >> 6)) {
     const uint32_t j0 = d.vstart[v], j1 = d.vstart[v + 1];
-    if (j1 - j0 > (uint32_t)kNdtBigVoxel) continue;
+    if (j1 - j0 > (uint32_t)kNdtBigVoxel) {
+      if (lane == 0) d.big[atomicAdd((uint32_t*)&d.info->nbig, 1u)] = (uint32_t)v;
+      continue;
+    }
     NdtVoxelSums a{};
     ndt_voxel_walk(a, d.vpts, j0, j1, lane, 64);
 #pragma unroll
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(256) void ndt_voxel_stats(const NdtDev* __restrict_
 #pragma unroll
     for (int k = 0; k < 3; ++k)
       for (int off = 32; off > 0; off >>= 1) a.cs[k] += __shfl_down(a.cs[k], off, 64);
-    if (lane == 0) ndt_voxel_finish(d, v, a.s, a.cs);
+    if (lane == 0) ndt_voxel_store_sums(d, v, a.s, a.cs);
   }
 }
 __global__ __launch_bounds__(1024) void ndt_voxel_stats_big(const NdtDev* __restrict__ devs) {
@@ -433,9 +434,23 @@ __global__ __launch_bounds__(1024) void ndt_voxel_stats_big(const NdtDev* __rest
       double t[9]; float tc[3];
       for (int c = 0; c < 9; ++c) { double r = 0; for (int w = 0; w < 16; ++w) r += s_s[w][c]; t[c] = r; }
       for (int c = 0; c < 3; ++c) { float r = 0; for (int w = 0; w < 16; ++w) r += s_c[w][c]; tc[c] = r; }
-      ndt_voxel_finish(d, v, t, tc);
+      ndt_voxel_store_sums(d, v, t, tc);
     }
     __syncthreads();
+  }
+}
+// a thread per voxel finishes its Leaf from the sums (:282-367): with a wave per voxel this serial tail -- a Jacobi
+// eigen-decomposition in double on one lane -- was most of the summing kernel's time
+__device__ __forceinline__ void ndt_voxel_finish(const NdtDev& d, int v, const double* s, const float* cs);
+__global__ __launch_bounds__(64) void ndt_voxel_leaves(const NdtDev* __restrict__ devs) {
+  const NdtDev d = devs[blockIdx.y];
+  const int nocc = d.info->nocc;
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nocc; v += gridDim.x * blockDim.x) {
+    const double* in = d.vsum + (size_t)v * 12;
+    double s[9]; float cs[3];
+    for (int k = 0; k < 9; ++k) s[k] = in[k];
+    for (int k = 0; k < 3; ++k) cs[k] = (float)in[9 + k];
+    ndt_voxel_finish(d, v, s, cs);
   }
 }
 __device__ __forceinline__ void ndt_voxel_finish(const NdtDev& d, int v, const double* s, const float* cs) {
@@ -1261,16 +1276,17 @@ __global__ __launch_bounds__(kNdtStepThreads) void ndt_ctl_step(const NdtDev* __
 //   ndt_fit_near  a lane per query: the 3 x 3 x 3 fine cells (1/16 voxel) around it, 27 independent hash probes (nine in flight at
 //                 a time), then the runs of the cells that exist.  A point outside that cube is at least a fine cell away, so a best
 //                 distance below that is the answer -- for most of a scan that lies on its submap.
-//   ndt_fit_wide  a wave per query the first pass could not settle: the 3 x 3 x 3 mid cells (1/4 voxel) around it, a lane per cell,
-//                 the wave walks the runs together; then shells of voxels around the query's own (a lane looks one voxel up through the
-//                 occupancy dictionary; a voxel farther than the best so far is skipped); after shell R everything unseen is at
-//                 least R + (distance to the own voxel's wall) away.
-//   ndt_fit_sweep a workgroup per query with nothing within kNdtFitMaxRing voxels: all points.
+//   ndt_fit_mid   sixteen lanes per query the first pass could not settle: shells of mid cells (1/4 voxel) around the query's own, a
+//                 lane per cell (hash probe, skipped when the cell's box is farther than the best so far), its run walked by that
+//                 lane; after shell R everything unseen is at least R quarter-voxels + (distance to the own mid cell's wall) away.
+//   ndt_fit_far   a wave per query with nothing within kNdtFitMidRings quarter-voxels (a scan's far points, ahead of what the submap
+//                 covers): over the occupied voxels' boxes -- the smallest farthest-corner distance bounds the answer from above
+//                 (every listed voxel holds a point), then only the voxels whose nearest corner is within that bound are walked.
 // The lattice is exact in the scaled coordinate fl(p * inv) (floor and the fractional part of a float are exact operations); `marg`
 // covers that one rounding on both sides.  Distances: float, as FLANN's L2 functor.
-constexpr int kNdtFitMaxRing = 6;
-constexpr int kNdtFitWideBlocks = 1024;
-constexpr int kNdtFitSweepBlocks = 256;
+constexpr int kNdtFitMidRings = 3;          // shells of mid cells the second pass walks: settles everything within 3/4 voxel
+constexpr int kNdtFitMidBlocks = 8192;
+constexpr int kNdtFitFarBlocks = 4096;
 
 struct NdtQuery { float t[3]; int iv[3]; int c16[3]; float f[3]; bool finite; };
 __device__ __forceinline__ NdtQuery ndt_fit_query(const NdtDev& d, const PairInput& in, int i) {
@@ -1298,6 +1314,16 @@ __device__ __forceinline__ float ndt_d2(const float4 p, const float* t) {
   const float dx = p.x - t[0], dy = p.y - t[1], dz = p.z - t[2];
   return dx * dx + dy * dy + dz * dz;
 }
+// one lane over a run of points: four loads in flight (a lane that waits for every point in turn pays a memory latency per point;
+// the clamped repeats at the run's end change no minimum)
+__device__ __forceinline__ float ndt_scan_run(const float4* __restrict__ vpts, uint32_t j0, uint32_t j1, const float* t, float best) {
+  for (uint32_t j = j0; j < j1; j += 4) {
+    const uint32_t last = j1 - 1u;
+    const float4 p0 = vpts[j], p1 = vpts[min(j + 1u, last)], p2 = vpts[min(j + 2u, last)], p3 = vpts[min(j + 3u, last)];
+    best = fminf(fminf(best, ndt_d2(p0, t)), fminf(ndt_d2(p1, t), fminf(ndt_d2(p2, t), ndt_d2(p3, t))));
+  }
+  return best;
+}
 
 __global__ __launch_bounds__(256) void ndt_fit_near(const NdtDev* __restrict__ devs, const PairInput* __restrict__ in, int first_slot) {
   const int slot = first_slot + blockIdx.y;
@@ -1310,38 +1336,58 @@ __global__ __launch_bounds__(256) void ndt_fit_near(const NdtDev* __restrict__ d
   float best = INFINITY;
   if (have && q.finite && !g->status) {
     const int div0 = g->div_b[0], div1 = g->div_b[1], div2 = g->div_b[2], wx = g->wx;
-    // the cube in fine coordinates, and the (at most 2 x 2 x 2) mid cells it touches
+    // the cube in fine coordinates, and the (at most 2 x 2 x 2) mid cells it touches: their first probes go out together
     int gf[3], mlo[3], mhi[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) { gf[c] = q.iv[c] * 16 + q.c16[c]; mlo[c] = (gf[c] - 1) >> 2; mhi[c] = (gf[c] + 1) >> 2; }
-    for (int mz = mlo[2]; mz <= mhi[2]; ++mz) {
-      const int vz = mz >> 2;
-      if (vz < 0 || vz >= div2) continue;
+    const uint32_t maskc = (1u << d.log2cells) - 1u;
+    const gptr<u32x4> cells = (gptr<u32x4>)d.cells;          // an entry = two 16-byte quarters: key, start, end | fmask
+    unsigned long long key[8];
+    uint32_t hp[8];
+    u32x4 e0[8], e1[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int mz = mlo[2] + (c >> 2), my = mlo[1] + ((c >> 1) & 1), mx = mlo[0] + (c & 1);
+      const int vz = mz >> 2, vy = my >> 2, vx = mx >> 2;
+      const bool want = mz <= mhi[2] && my <= mhi[1] && mx <= mhi[0] && vz >= 0 && vz < div2 && vy >= 0 && vy < div1 && vx >= 0 && vx < div0;
+      const uint32_t code = ((uint32_t)((vz * div1 + vy) * wx + (vx >> 5)) << 5) | (uint32_t)(vx & 31);
+      key[c] = want ? ndt_mid_key(code, mz & 3, my & 3, mx & 3) : ~0ull;
+      hp[c] = ndt_cell_hash(key[c], d.log2cells);
+      e0[c] = cells[2 * hp[c]]; e1[c] = cells[2 * hp[c] + 1];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (key[c] == ~0ull) continue;
+      u32x4 a0 = e0[c], a1 = e1[c];
+      uint32_t hpos = hp[c];
+      for (;;) {                                             // (linear probing: the first probe is the entry nearly always)
+        const unsigned long long kk = ((unsigned long long)a0.y << 32) | a0.x;
+        if (kk == key[c] || kk == ~0ull) break;
+        hpos = (hpos + 1u) & maskc;
+        a0 = cells[2 * hpos]; a1 = cells[2 * hpos + 1];
+      }
+      if ((((unsigned long long)a0.y << 32) | a0.x) != key[c]) continue;
+      const unsigned long long fm = ((unsigned long long)a1.y << 32) | a1.x;
+      const uint32_t a = a0.z, b = a0.w, nf = (uint32_t)__popcll(fm);
+      const int mz = mlo[2] + (c >> 2), my = mlo[1] + ((c >> 1) & 1), mx = mlo[0] + (c & 1);
       const int az = max(gf[2] - 1, 4 * mz) - 4 * mz, bz = min(gf[2] + 1, 4 * mz + 3) - 4 * mz;
-      for (int my = mlo[1]; my <= mhi[1]; ++my) {
-        const int vy = my >> 2;
-        if (vy < 0 || vy >= div1) continue;
-        const int ay = max(gf[1] - 1, 4 * my) - 4 * my, by = min(gf[1] + 1, 4 * my + 3) - 4 * my;
-        for (int mx = mlo[0]; mx <= mhi[0]; ++mx) {
-          const int vx = mx >> 2;
-          if (vx < 0 || vx >= div0) continue;
-          const uint32_t code = ((uint32_t)((vz * div1 + vy) * wx + (vx >> 5)) << 5) | (uint32_t)(vx & 31);
-          const NdtCell* e = ndt_cell_find(d, ndt_mid_key(code, mz & 3, my & 3, mx & 3));
-          if (!e) continue;
-          const unsigned long long fm = e->fmask;
-          const uint32_t a = e->start, b = e->end, nf = (uint32_t)__popcll(fm);
-          const int ax = max(gf[0] - 1, 4 * mx) - 4 * mx, bx = min(gf[0] + 1, 4 * mx + 3) - 4 * mx;
-          for (int fz = az; fz <= bz; ++fz)
-            for (int fy = ay; fy <= by; ++fy) {
-              const int row = (fz * 4 + fy) * 4;
-              const uint32_t lo = (uint32_t)__popcll(fm & ((1ull << (row + ax)) - 1ull));
-              const uint32_t hi = (uint32_t)__popcll(fm & ((2ull << (row + bx)) - 1ull));
-              if (hi == lo) continue;
-              const uint32_t j0 = d.fpos[a + lo], j1 = hi == nf ? b : d.fpos[a + hi];
-              for (uint32_t j = j0; j < j1; ++j) best = fminf(best, ndt_d2(d.vpts[j], q.t));
-            }
+      const int ay = max(gf[1] - 1, 4 * my) - 4 * my, by = min(gf[1] + 1, 4 * my + 3) - 4 * my;
+      const int ax = max(gf[0] - 1, 4 * mx) - 4 * mx, bx = min(gf[0] + 1, 4 * mx + 3) - 4 * mx;
+      // the cube's rows inside this mid cell (a row's fine cells are one run): all their bounds first, then the points
+      uint32_t r0[9], r1[9];
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const int fz = az + r / 3, fy = ay + r % 3;
+        r0[r] = 0u; r1[r] = 0u;
+        if (fz <= bz && fy <= by) {
+          const int row = (fz * 4 + fy) * 4;
+          const uint32_t lo = (uint32_t)__popcll(fm & ((1ull << (row + ax)) - 1ull));
+          const uint32_t hi = (uint32_t)__popcll(fm & ((2ull << (row + bx)) - 1ull));
+          if (hi != lo) { r0[r] = d.fpos[a + lo]; r1[r] = hi == nf ? b : d.fpos[a + hi]; }
         }
       }
+#pragma unroll
+      for (int r = 0; r < 9; ++r) best = ndt_scan_run(d.vpts, r0[r], r1[r], q.t, best);
     }
   }
   if (have) d.fit_d2[i] = best;
@@ -1359,105 +1405,106 @@ __global__ __launch_bounds__(256) void ndt_fit_near(const NdtDev* __restrict__ d
   if (open) d.qlist[s_base + off] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(256) void ndt_fit_wide(const NdtDev* __restrict__ devs, const PairInput* __restrict__ in, int first_slot) {
+template <int CTRL>
+__device__ __forceinline__ float dpp_rowf(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); }
+__device__ __forceinline__ float row_min16(float v) {        // min over the lane's row of 16, in every lane of the row
+  v = fminf(v, dpp_rowf<0x128>(v));       // row_ror 8, 4, 2, 1
+  v = fminf(v, dpp_rowf<0x124>(v));
+  v = fminf(v, dpp_rowf<0x122>(v));
+  v = fminf(v, dpp_rowf<0x121>(v));
+  return v;
+}
+
+__global__ __launch_bounds__(256) void ndt_fit_mid(const NdtDev* __restrict__ devs, const PairInput* __restrict__ in, int first_slot) {
   const int slot = first_slot + blockIdx.y;
   const NdtDev d = devs[slot];
   NdtGridInfo* g = d.info;
-  const int lane = threadIdx.x & 63;
+  const int l16 = threadIdx.x & 15;
   const uint32_t nlist = g->nlist;
   const int div0 = g->div_b[0], div1 = g->div_b[1], div2 = g->div_b[2];
-  for (uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < nlist; k += gridDim.x * (blockDim.x >> 6)) {
+  const uint32_t rows = gridDim.x * (blockDim.x >> 4);
+  // (whole rows loop together: the row-wide reductions need every lane of a row in the loop)
+  for (uint32_t k = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); k < nlist; k += rows) {
     const int i = (int)d.qlist[k];
     const NdtQuery q = ndt_fit_query(d, in[slot], i);
-    float best = d.fit_d2[i];                                // what the cube held (or infinity)
-    const float wall = fminf(fminf(fminf(q.f[0], 1.f - q.f[0]), fminf(q.f[1], 1.f - q.f[1])), fminf(q.f[2], 1.f - q.f[2]));
+    float best = d.fit_d2[i];                                // what the fine cube held (or infinity)
     bool settled = false;
     if (!g->status) {
-      {
-        // the 27 mid cells around the query's own: a lane per cell, their runs walked by the whole wave
-        uint32_t j0 = 0, j1 = 0;
-        if (lane < 27) {
-          const int m0 = q.iv[0] * 4 + (q.c16[0] >> 2) + lane % 3 - 1, m1 = q.iv[1] * 4 + (q.c16[1] >> 2) + (lane / 3) % 3 - 1, m2 = q.iv[2] * 4 + (q.c16[2] >> 2) + lane / 9 - 1;
-          const int vx = m0 >> 2, vy = m1 >> 2, vz = m2 >> 2;
-          if (vx >= 0 && vx < div0 && vy >= 0 && vy < div1 && vz >= 0 && vz < div2) {
-            const uint32_t code = ((uint32_t)((vz * div1 + vy) * g->wx + (vx >> 5)) << 5) | (uint32_t)(vx & 31);
-            const NdtCell* e = ndt_cell_find(d, ndt_mid_key(code, m2 & 3, m1 & 3, m0 & 3));
-            if (e) { j0 = e->start; j1 = e->end; }
-          }
-        }
-        unsigned long long live = __ballot(j1 > j0);
-        while (live) {
-          const int l = __ffsll((long long)live) - 1;
-          live &= live - 1ull;
-          const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)j0, l), b = (uint32_t)__builtin_amdgcn_readlane((int)j1, l);
-          for (uint32_t j = a + lane; j < b; j += 64) best = fminf(best, ndt_d2(d.vpts[j], q.t));
-        }
-        best = wave_min(best);
-        best = __shfl(best, 0, 64);
-        const float bound = (0.25f - g->marg) * g->res * 0.999999f;
-        settled = best <= bound * bound;
-      }
-      for (int R = 0; R <= kNdtFitMaxRing && !settled; ++R) {
+      int gm[3];
+      float fm[3];                                           // position inside the own mid cell, in voxels: [0, 0.25)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { gm[c] = q.iv[c] * 4 + (q.c16[c] >> 2); fm[c] = q.f[c] - 0.25f * (float)(q.c16[c] >> 2); }
+      const float wall = fminf(fminf(fminf(fm[0], 0.25f - fm[0]), fminf(fm[1], 0.25f - fm[1])), fminf(fm[2], 0.25f - fm[2]));
+      for (int R = 1; R <= kNdtFitMidRings && !settled; ++R) {
         const int side = 2 * R + 1, cells = side * side * side;
-        for (int c0 = 0; c0 < cells; c0 += 64) {
-          // a lane per voxel of the shell: its run of points, if it is occupied and not farther than the best so far
-          uint32_t j0 = 0, j1 = 0;
-          const int c = c0 + lane;
-          if (c < cells) {
-            const int dx = c % side - R, dy = (c / side) % side - R, dz = c / (side * side) - R;
-            const int vx = q.iv[0] + dx, vy = q.iv[1] + dy, vz = q.iv[2] + dz;
-            if (max(abs(dx), max(abs(dy), abs(dz))) == R && vx >= 0 && vx < div0 && vy >= 0 && vy < div1 && vz >= 0 && vz < div2) {
-              // distance from the query to the voxel's box, in voxels
-              const float gx = dx > 0 ? (float)dx - q.f[0] : (dx < 0 ? q.f[0] - (float)(dx + 1) : 0.f);
-              const float gy = dy > 0 ? (float)dy - q.f[1] : (dy < 0 ? q.f[1] - (float)(dy + 1) : 0.f);
-              const float gz = dz > 0 ? (float)dz - q.f[2] : (dz < 0 ? q.f[2] - (float)(dz + 1) : 0.f);
-              const float gap = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz) - g->marg, 0.f) * g->res * 0.999999f;
-              if (gap * gap <= best) {
-                const uint2 wd = d.words[(vz * div1 + vy) * g->wx + (vx >> 5)];
-                if ((wd.x >> (vx & 31)) & 1u) {
-                  const uint32_t v = wd.y + __popc(wd.x & ((1u << (vx & 31)) - 1u));
-                  j0 = d.vstart[v]; j1 = d.vstart[v + 1];
-                }
-              }
-            }
-          }
-          unsigned long long live = __ballot(j1 > j0);
-          while (live) {
-            const int l = __ffsll((long long)live) - 1;
-            live &= live - 1ull;
-            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)j0, l), b = (uint32_t)__builtin_amdgcn_readlane((int)j1, l);
-            for (uint32_t j = a + lane; j < b; j += 64) best = fminf(best, ndt_d2(d.vpts[j], q.t));
-          }
+        for (int c = l16; c < cells; c += 16) {
+          const int dx = c % side - R, dy = (c / side) % side - R, dz = c / (side * side) - R;
+          if (R > 1 && max(abs(dx), max(abs(dy), abs(dz))) < R) continue;      // seen in an earlier shell (shell 1 is the whole cube)
+          const int m0 = gm[0] + dx, m1 = gm[1] + dy, m2 = gm[2] + dz;
+          const int vx = m0 >> 2, vy = m1 >> 2, vz = m2 >> 2;
+          if (vx < 0 || vx >= div0 || vy < 0 || vy >= div1 || vz < 0 || vz >= div2) continue;
+          // distance from the query to the cell's box, in voxels
+          const float gx = dx > 0 ? 0.25f * (float)dx - fm[0] : (dx < 0 ? fm[0] - 0.25f * (float)(dx + 1) : 0.f);
+          const float gy = dy > 0 ? 0.25f * (float)dy - fm[1] : (dy < 0 ? fm[1] - 0.25f * (float)(dy + 1) : 0.f);
+          const float gz = dz > 0 ? 0.25f * (float)dz - fm[2] : (dz < 0 ? fm[2] - 0.25f * (float)(dz + 1) : 0.f);
+          const float gap = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz) - g->marg, 0.f) * g->res * 0.999999f;
+          if (gap * gap > best) continue;
+          const uint32_t code = ((uint32_t)((vz * div1 + vy) * g->wx + (vx >> 5)) << 5) | (uint32_t)(vx & 31);
+          const NdtCell* e = ndt_cell_find(d, ndt_mid_key(code, m2 & 3, m1 & 3, m0 & 3));
+          if (!e) continue;
+          best = ndt_scan_run(d.vpts, e->start, e->end, q.t, best);
         }
-        best = wave_min(best);
-        best = __shfl(best, 0, 64);
-        const float bound = fmaxf((float)R + wall - g->marg, 0.f) * g->res * 0.999999f;
+        best = row_min16(best);
+        const float bound = fmaxf(0.25f * (float)R + wall - g->marg, 0.f) * g->res * 0.999999f;
         settled = best <= bound * bound;
       }
     }
-    if (lane == 0) {
-      if (settled) d.fit_d2[i] = best;
-      else { d.fit_d2[i] = best; d.qleft[atomicAdd(&g->nleft, 1u)] = (uint32_t)i; }
+    if (l16 == 0) {
+      d.fit_d2[i] = best;
+      if (!settled) d.qleft[atomicAdd(&g->nleft, 1u)] = (uint32_t)i;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void ndt_fit_sweep(const NdtDev* __restrict__ devs, const PairInput* __restrict__ in, int first_slot) {
+__global__ __launch_bounds__(256) void ndt_fit_far(const NdtDev* __restrict__ devs, const PairInput* __restrict__ in, int first_slot) {
   const int slot = first_slot + blockIdx.y;
   const NdtDev d = devs[slot];
   const NdtGridInfo* g = d.info;
+  const int lane = threadIdx.x & 63;
   const uint32_t nleft = g->nleft;
-  __shared__ float s_m[4];
-  for (uint32_t k = blockIdx.x; k < nleft; k += gridDim.x) {
+  const int nocc = g->nocc;
+  for (uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < nleft; k += gridDim.x * (blockDim.x >> 6)) {
     const int i = (int)d.qleft[k];
     const NdtQuery q = ndt_fit_query(d, in[slot], i);
-    float best = d.fit_d2[i];
-    for (int j = threadIdx.x; j < g->nvalid; j += blockDim.x) best = fminf(best, ndt_d2(d.vpts[j], q.t));
+    const float qs0 = q.t[0] * g->inv, qs1 = q.t[1] * g->inv, qs2 = q.t[2] * g->inv;     // the query in scaled coordinates
+    // an upper bound in voxels: the best so far, and the farthest corner of the nearest boxes
+    float up = sqrtf(d.fit_d2[i]) / g->res * 1.000001f + g->marg;
+    for (int v = lane; v < nocc; v += 64) {
+      const float4 c = d.vbox[v];
+      const float fx = fmaxf(fabsf(qs0 - c.x), fabsf(qs0 - c.x - 1.f)), fy = fmaxf(fabsf(qs1 - c.y), fabsf(qs1 - c.y - 1.f)), fz = fmaxf(fabsf(qs2 - c.z), fabsf(qs2 - c.z - 1.f));
+      up = fminf(up, sqrtf(fx * fx + fy * fy + fz * fz) + g->marg);
+    }
+    up = wave_min(up);
+    up = __shfl(up, 0, 64);
+    float best = INFINITY;
+    for (int v0 = 0; v0 < nocc; v0 += 64) {
+      const int v = v0 + lane;
+      bool near = false;
+      if (v < nocc) {
+        const float4 c = d.vbox[v];
+        const float nx = fmaxf(fmaxf(c.x - qs0, qs0 - c.x - 1.f), 0.f), ny = fmaxf(fmaxf(c.y - qs1, qs1 - c.y - 1.f), 0.f), nz = fmaxf(fmaxf(c.z - qs2, qs2 - c.z - 1.f), 0.f);
+        near = sqrtf(nx * nx + ny * ny + nz * nz) - g->marg <= up;
+      }
+      unsigned long long live = __ballot(near);
+      while (live) {
+        const int l = __ffsll((long long)live) - 1;
+        live &= live - 1ull;
+        const uint32_t a = d.vstart[v0 + l], b = d.vstart[v0 + l + 1];
+        for (uint32_t j = a + lane; j < b; j += 64) best = fminf(best, ndt_d2(d.vpts[j], q.t));
+      }
+    }
     best = wave_min(best);
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = best;
-    __syncthreads();
-    if (threadIdx.x == 0) d.fit_d2[i] = fminf(fminf(s_m[0], s_m[1]), fminf(s_m[2], s_m[3]));
-    __syncthreads();
+    if (lane == 0) d.fit_d2[i] = fminf(best, d.fit_d2[i]);
   }
 }
 

@@ -32,6 +32,8 @@ struct NdtHost {
   NdtCell* cells_all = nullptr;       // [cap][cells_cap] hash tables of the mid cells
   size_t cells_cap = 0;               // entries per slot: the power of two >= 2 nt_cap
   uint32_t* fpos_all = nullptr;       // [cap][nt_cap]
+  float4* vbox_all = nullptr;         // [cap][nt_cap]
+  double* vsum_all = nullptr;         // [cap][nt_cap][12]
   uint32_t* big_all = nullptr;        // [cap][nt_cap / kNdtBigVoxel + 1]
   uint32_t* qlist_all = nullptr;      // [cap][2][ns_cap]
   float* bbox_all = nullptr;          // [cap][kNdtBoxBlocks][8]
@@ -117,7 +119,7 @@ smhip_status ndt_ensure(smhip_context* h, int need = 1) {
   const size_t NS = h->dev.ns_cap, NBIG = NT / kNdtBigVoxel + 1;
   D(&n.vstart_all, K * (NT + 1)); D(&n.vpts_all, K * NT); D(&n.vox_all, K * NT); D(&n.icovd_all, K * NT * 6);
   n.cells_cap = 1; while (n.cells_cap < 2 * NT) n.cells_cap <<= 1;
-  D(&n.cells_all, K * n.cells_cap); D(&n.fpos_all, K * NT); D(&n.big_all, K * NBIG); D(&n.qlist_all, K * 2 * NS); D(&n.bbox_all, K * (size_t)kNdtBoxBlocks * 8);
+  D(&n.cells_all, K * n.cells_cap); D(&n.fpos_all, K * NT); D(&n.vbox_all, K * NT); D(&n.vsum_all, K * NT * 12); D(&n.big_all, K * NBIG); D(&n.qlist_all, K * 2 * NS); D(&n.bbox_all, K * (size_t)kNdtBoxBlocks * 8);
   D(&n.fit_d2_all, K * NS);
   n.rows = ceil_div(h->dev.ns_cap, kNdtDerivThreads);
   D(&n.partials_all, K * (size_t)n.rows * kNdtCols); D(&n.out_all, K * kNdtOutCols);
@@ -135,7 +137,7 @@ smhip_status ndt_ensure(smhip_context* h, int need = 1) {
     d.vstart = n.vstart_all + k * (NT + 1); d.vpts = n.vpts_all + k * NT; d.vox = n.vox_all + k * NT; d.icovd = n.icovd_all + k * NT * 6;
     d.partials = n.partials_all + k * (size_t)n.rows * kNdtCols; d.out = n.out_all + k * kNdtOutCols;
     d.tgt = h->dev.tgt_p + k * NT; d.src = h->dev.src + k * NS;
-    d.cells = n.cells_all + k * n.cells_cap; d.fpos = n.fpos_all + k * NT; d.big = n.big_all + k * NBIG;
+    d.cells = n.cells_all + k * n.cells_cap; d.fpos = n.fpos_all + k * NT; d.vbox = n.vbox_all + k * NT; d.vsum = n.vsum_all + k * NT * 12; d.big = n.big_all + k * NBIG;
     d.qlist = n.qlist_all + k * 2 * NS; d.qleft = d.qlist + NS; d.bbox = n.bbox_all + k * (size_t)kNdtBoxBlocks * 8; d.fit_d2 = n.fit_d2_all + k * NS;
   }
   return SMHIP_OK;
@@ -209,7 +211,7 @@ smhip_status ndt_enqueue_grids(smhip_context* h, int first, int K) {
   const int gb = ceil_div(nt_max, 256);
   hipLaunchKernelGGL(ndt_bbox, dim3(kNdtBoxBlocks, K), dim3(256), 0, h->stream, devs);
   hipLaunchKernelGGL(ndt_voxel_setup, dim3(K), dim3(64), 0, h->stream, devs, n.opts.resolution);
-  hipLaunchKernelGGL(ndt_voxel_mark, dim3(gb, K), dim3(256), 0, h->stream, devs);
+  hipLaunchKernelGGL(ndt_voxel_mark, dim3(ceil_div(nt_max, kNdtMarkThreads), K), dim3(kNdtMarkThreads), 0, h->stream, devs);
   hipLaunchKernelGGL(ndt_voxel_rank, dim3(K), dim3(1024), 0, h->stream, devs);
   // (slot << 6 | sub-cell, point) pairs sorted with the rocPRIM radix sort of the workspace: as few key bits as the largest
   // target of the batch can need.  The sorted points ARE vpts
@@ -219,10 +221,10 @@ smhip_status ndt_enqueue_grids(smhip_context* h, int first, int K) {
   const hipError_t e = prep_sort_pairs(n.prep, h->stream, nt_sum, n.devs_host[first].key_bits + kbits);
   if (e != hipSuccess) { h->err = std::string("NDT voxel sort: ") + hipGetErrorString(e); return SMHIP_ERR_HIP; }
   hipLaunchKernelGGL(ndt_voxel_heads, dim3(gb, K), dim3(256), 0, h->stream, devs, prep_keys(n.prep, 1), prep_values(n.prep, 1));
-  hipLaunchKernelGGL(ndt_voxel_tails, dim3(gb, K), dim3(256), 0, h->stream, devs, prep_keys(n.prep, 1));
   // one wave per occupied voxel (nocc <= nt), a workgroup per crowded one
   hipLaunchKernelGGL(ndt_voxel_stats, dim3(std::min(ceil_div(nt_max, 4), std::max(64, 8192 / K)), K), dim3(256), 0, h->stream, devs);
   hipLaunchKernelGGL(ndt_voxel_stats_big, dim3(std::max(8, 256 / K), K), dim3(1024), 0, h->stream, devs);
+  hipLaunchKernelGGL(ndt_voxel_leaves, dim3(std::min(ceil_div(nt_max, 64), std::max(32, 2048 / K)), K), dim3(64), 0, h->stream, devs);
   HIPCHK(h, hipGetLastError());
   return SMHIP_OK;
 }
@@ -305,8 +307,8 @@ smhip_status fitness_enqueue_search(smhip_context* h, int first, int K) {
   PairInput* in = const_cast<PairInput*>(h->dev.in);
   hipLaunchKernelGGL(ndt_fit_reset, dim3(ceil_div(K, 64)), dim3(64), 0, h->stream, n.devs_dev, first, K);
   hipLaunchKernelGGL(ndt_fit_near, dim3(ceil_div(ns_max, 256), K), dim3(256), 0, h->stream, n.devs_dev, in, first);
-  hipLaunchKernelGGL(ndt_fit_wide, dim3(std::max(8, kNdtFitWideBlocks / K), K), dim3(256), 0, h->stream, n.devs_dev, in, first);
-  hipLaunchKernelGGL(ndt_fit_sweep, dim3(std::max(4, kNdtFitSweepBlocks / K), K), dim3(256), 0, h->stream, n.devs_dev, in, first);
+  hipLaunchKernelGGL(ndt_fit_mid, dim3(std::max(64, kNdtFitMidBlocks / K), K), dim3(256), 0, h->stream, n.devs_dev, in, first);
+  hipLaunchKernelGGL(ndt_fit_far, dim3(std::max(64, kNdtFitFarBlocks / K), K), dim3(256), 0, h->stream, n.devs_dev, in, first);
   hipLaunchKernelGGL(fitness_partial, dim3(64, K), dim3(256), 0, h->stream, n.devs_dev, first, n.fit_pinned);
   HIPCHK(h, hipGetLastError());
   return SMHIP_OK;
@@ -400,6 +402,11 @@ smhip_status ndt_align_slots(smhip_context* h, int first, int K, const double* g
     want = std::min(round_cap, rounds + 2);
   }
   if (!current) { s = ndt_tables_built(h, first, K); if (s) return s; }
+  if (std::getenv("SMHIP_NDT_DEBUG"))
+    for (int k = 0; k < std::min(K, 8); ++k) {
+      const NdtGridInfo& gi = n.info_pinned[first + k];
+      std::fprintf(stderr, "ndt job %d: ns %d nt %d voxels %d big %d; fitness: %u queries past the fine cube, %u past the mid shells\n", k, h->ns[first + k], h->nt[first + k], gi.nocc, gi.nbig, gi.nlist, gi.nleft);
+    }
   int needed = 1;
   for (int k = 0; k < K; ++k) needed = std::max(needed, n.res_pinned[first + k].done_round + 1);
   n.predicted_rounds = needed;

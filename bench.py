@@ -402,6 +402,9 @@ def main():
                 return None
             try:
                 tdat = json.load(open(tj))
+                # (a record that names its source files is only used while they are what it was measured on)
+                if tdat.get("source_files") and tdat.get("source_sha") != _source_sha(tdat["source_files"]):
+                    return None
                 if tdat.get("nn_mode") == args.nn_mode and tdat.get("source_points") in (None, ns):
                     # scattered 32-64 B sectors (the listed search): the counters at factor 1, as the scatter calibration found
                     # (profiles/r04_traffic_calibration.json calib_scatter); streaming shapes: FETCH_SIZE x 2
@@ -726,6 +729,30 @@ def _submap_case(n_scans, n_target, seed, device, n_points=N_POINTS):
     return np.ascontiguousarray(scans[n_scans][:, :3]), tgt, T, G
 
 
+def _source_sha(files):
+    """sha256 over the named kernel sources (relative to the repository): what a recorded counter pass is dated with"""
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in sorted(files):
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()
+
+
+def _kernel_traffic(kernel, units):
+    """HBM bytes per launch of `kernel` from its recorded counter passes (profiles/traffic_<kernel>.json: separate FETCH_SIZE and
+    WRITE_SIZE passes), scaled to `units` of work per launch -- or None when the record is missing or was taken from other source
+    than the tree holds now (the record carries the sha256 of the kernel's source files)."""
+    tj = os.path.join(ROOT, "profiles", f"traffic_{kernel}.json")
+    try:
+        d = json.load(open(tj))
+        if not d.get("source_files") or d.get("source_sha") != _source_sha(d["source_files"]):
+            return None
+        return int(d["hbm_bytes_per_launch"] * units / d["units_per_launch"])
+    except Exception:
+        return None
+
+
 def _shape_rate():
     """What the dominant kernel's streaming accesses alone reach on this GPU: a recorded run of tools/traffic_calib.sh (a kernel that
     reads 12 + 4 + 4 B and writes 4 B per element and computes nothing).  A reference point next to `peak`, not a replacement for it."""
@@ -765,16 +792,26 @@ def other_workloads(dev, with_cpu):
         ns, nt_, V, C = len(src), len(tgt), st["voxels"], st["derivative_calls"]
         mbar = st["pairs_last"] / ns
         b_ndt = 12.0 * nt_ + 40.0 * V + C * ns * (12.0 + 36.0 * mbar) + 12.0 * ns + 4.0 * ns     # SURVEY §8(d) B_ndt
+        # the path's dominant kernel by itself: computeDerivatives (ndt_derivatives_ctl), HIP events around back-to-back launches on
+        # the matcher's stream at the pose the Align ended with; its algorithmic bytes = B_ndt's per-call term N_s (12 + 36 m)
+        ms_k, pairs_k = m.time_derivatives(npairs=1, launches=50)
+        b_call = 12.0 * ns + 36.0 * pairs_k
         entry = {"workload": "BASELINE config #3: registrators::Ndt, 120k-pt scan vs 500k-pt submap (5 merged scans), 1.0 m voxels, "
-                             "guess = truth perturbed by 0.3 m / 1 deg; includes the per-Align cloud upload the reference's conversion corresponds to? no: clouds resident",
+                             "guess = truth perturbed by 0.3 m / 1 deg, clouds resident",
                  "value": round(1.0 / dt, 2), "unit": "alignments/s", "ms_per_alignment": round(dt * 1e3, 3),
                  "iterations": st["iterations"], "derivative_calls": C, "voxels": V, "mean_neighbours": round(mbar, 3),
-                 "roofline": {"bound": "hbm", "achieved": round(b_ndt / dt / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(b_ndt / dt / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": b_ndt,
-                              "note": "whole Align (voxel build + C computeDerivatives + fitness pass), SURVEY §8(d) B_ndt with measured V, C, m"},
+                 "roofline": {"bound": "hbm", "kernel": "ndt_derivatives_ctl", "achieved": round(b_call / ms_k / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(b_call / ms_k / 1e6 / HBM_PEAK_GBS, 5), "bytes_per_launch": b_call, "avg_launch_ms": round(ms_k, 5),
+                              "launches_timed": 50, "pairs_per_launch": pairs_k,
+                              "traffic": _kernel_traffic("ndt_derivatives_ctl", 1),
+                              "note": "one evaluation of one pair (469 workgroups: the launch is as long as a workgroup lives, not bandwidth); "
+                                      "the batch of 64 below is the kernel under load",
+                              "whole_alignment": {"achieved": round(b_ndt / dt / 1e9, 2), "frac": round(b_ndt / dt / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": b_ndt,
+                                                  "note": "whole Align (voxel table build + C computeDerivatives + fitness pass), SURVEY §8(d) B_ndt with measured V, C, m"}},
+                 "submission": "one per Align: table build, the rounds of the device-resident Newton / More-Thuente driver, fitness pass; one synchronise",
                  "trans_err_vs_truth_m": sm.se3_error(R, T)[1],
                  "target_kept": {"value": round(1.0 / dt_kept, 2), "ms_per_alignment": round(dt_kept * 1e3, 3),
-                                 "note": "voxel table + fitness search structure kept across Aligns on an unchanged target "
+                                 "note": "voxel table (which is also the fitness search structure) kept across Aligns on an unchanged target "
                                          "(smhip_set_target_cache, default on); identical result"}}
         entry["workload"] = ("BASELINE config #3: registrators::Ndt, 120k-pt scan vs 500k-pt submap (5 merged scans), 1.0 m voxels, "
                              "guess = truth perturbed by 0.3 m / 1 deg, clouds resident")
@@ -835,14 +872,19 @@ def other_workloads(dev, with_cpu):
             dtb_kept, Rb_kept, _ = time_batch()
             calls = float(np.sum([s_["derivative_calls"] for s_ in stb]))
             b_batch = K * (12.0 * nt_ + 40.0 * V + 16.0 * ns) + calls * ns * (12.0 + 36.0 * mbar)       # SURVEY §8(d) B_ndt, summed over the pairs
+            ms_kb, pairs_kb = mb.time_derivatives(npairs=K, launches=20)
+            b_call_b = 12.0 * ns * K + 36.0 * pairs_kb
             entry["batch64"] = {"value": round(K / dtb, 2), "unit": "alignments/s", "pairs": K, "ms_per_batch": round(dtb * 1e3, 3),
                                 "identical_to_single": bool(np.array_equal(Rb[0], R)), "iterations_min_max": [int(min(s_["iterations"] for s_ in stb)), int(max(s_["iterations"] for s_ in stb))],
                                 "derivative_calls_total": int(calls),
-                                "roofline": {"bound": "hbm", "achieved": round(b_batch / dtb / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": round(b_batch / dtb / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": b_batch},
+                                "roofline": {"bound": "hbm", "kernel": "ndt_derivatives_ctl", "achieved": round(b_call_b / ms_kb / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": round(b_call_b / ms_kb / 1e6 / HBM_PEAK_GBS, 5), "bytes_per_launch": b_call_b, "avg_launch_ms": round(ms_kb, 5),
+                                             "launches_timed": 20, "pairs_per_launch": pairs_kb, "evaluations_per_launch": K,
+                                             "traffic": _kernel_traffic("ndt_derivatives_ctl", K),
+                                             "whole_batch": {"achieved": round(b_batch / dtb / 1e9, 2), "frac": round(b_batch / dtb / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": b_batch}},
                                 "target_kept": {"value": round(K / dtb_kept, 2), "ms_per_batch": round(dtb_kept * 1e3, 3), "identical_result": bool(np.array_equal(Rb, Rb_kept))},
-                                "note": "smhip_ndt_align_batch: lock-step state machines, one ndt_derivatives launch per round over all running pairs "
-                                        "(pclomp/ndt_omp_impl.hpp:81-171, 757-916; builder/map_builder.cc:399-446, 655); value = everything rebuilt per Align"}
+                                "note": "smhip_ndt_align_batch: device-resident state machines, one ndt_derivatives_ctl + one ndt_ctl_step launch per round over all running "
+                                        "pairs, one submission per batch (pclomp/ndt_omp_impl.hpp:81-171, 757-916; builder/map_builder.cc:399-446, 655); value = everything rebuilt per Align"}
             mb.close()
         except Exception as e:
             entry["batch64"] = {"error": repr(e)}

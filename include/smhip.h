@@ -295,9 +295,10 @@ smhip_status smhip_ndt_align(smhip_handle h, const double guess[16], double resu
 /* npairs independent Ndt::Align calls -- pair slots first_slot .. first_slot + npairs - 1, clouds set with smhip_set_source_f32 /
  * smhip_set_target_f32 on those slots -- advanced in lock-step: the back end runs up to six SubmapPairMatch tasks at once with
  * whichever matcher is configured (builder/map_builder.cc:399-446, 655).  Every pair's Newton / More-Thuente state machine
- * (pclomp/ndt_omp_impl.hpp:81-171, 757-916) asks for the evaluations the reference would make, in the reference's order; each
- * round's computeDerivatives calls of all pairs still running are ONE launch and one read-back, the voxel tables are built in
- * one pass and the fitness scores in another.  Results are the single calls' bit for bit (sources up to 524 288 points).
+ * (pclomp/ndt_omp_impl.hpp:81-171, 757-916) lives in device memory and asks for the evaluations the reference would make, in the
+ * reference's order; a round = one computeDerivatives launch over all pairs still running + one control launch (fold, 6x6 solve,
+ * line-search decision, next pose), the voxel tables are built in one pass and the fitness scores in another: the whole batch is one
+ * submission and one synchronise.  Results are the single calls' bit for bit.
  * guesses / results: npairs column-major 4x4; scores / stats: npairs entries (may be NULL). */
 smhip_status smhip_ndt_align_batch(smhip_handle h, int first_slot, int npairs, const double* guesses, double* results,
                                    double* scores, smhip_ndt_stats* stats);
@@ -310,6 +311,12 @@ smhip_status smhip_ndt_get_voxels(smhip_handle h, int capacity, int32_t* keys, i
 smhip_status smhip_get_target_f32(smhip_handle h, int slot, float* xyz, float* normals, int n);
 smhip_status smhip_ndt_compute_derivatives(smhip_handle h, const double pose6[6], int compute_hessian,
                                            double* score, double grad[6], double hess[36]);
+/* measurement hook: `launches` back-to-back computeDerivatives launches (with Hessian) over slots first_slot .. + npairs - 1 at the
+ * poses their last Align ended with, HIP events around them on the handle's stream: *ms_per_launch = the average duration of
+ * the kernel, *pairs_per_launch = the (point, voxel) pairs one launch works through (for its algorithmic bytes).  The slots'
+ * voxel tables must be current (an Align with the target cache on, or smhip_ndt_build_voxels for slot 0). */
+smhip_status smhip_ndt_time_derivatives(smhip_handle h, int first_slot, int npairs, int launches, double* ms_per_launch,
+                                        double* pairs_per_launch);
 
 /* ---- registrators::NdtWithGicp (ndt_gicp.cc:28-112) ------------------------------------------
  * ApproximateVoxelGrid (0.2 m) on both clouds -> stock pcl NDT -> stock pcl GICP; PCL is not vendored by the

@@ -131,6 +131,7 @@ SIGNATURES = {
     "smhip_ndt_build_voxels": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
     "smhip_ndt_get_voxels": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int32_p, c_int32_p, c_double_p, c_float_p, c_float_p]),
     "smhip_ndt_compute_derivatives": (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_int, c_double_p, c_double_p, c_double_p]),
+    "smhip_ndt_time_derivatives": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p]),
     "smhip_ndt_gicp_default_options": (None, [ctypes.POINTER(NdtGicpOptions)]),
     "smhip_ndt_gicp_set_options": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(NdtGicpOptions)]),
     "smhip_ndt_gicp_set_source_f32": (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int]),

@@ -268,9 +268,13 @@ __device__ __forceinline__ const NdtCell* ndt_cell_find(const NdtDev& d, unsigne
     hpos = (hpos + 1u) & maskc;
   }
 }
+// the table starts empty: the mid cells' hash table over the part this target's size makes it use, and the words of the bit grid
+// its box covers (known since ndt_voxel_setup)
 __global__ __launch_bounds__(256) void ndt_cells_clear(const NdtDev* __restrict__ devs) {
   const NdtDev d = devs[blockIdx.y];
   const size_t n = (size_t)1 << d.log2cells;
+  const int nw = d.info->nw;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nw; k += gridDim.x * blockDim.x) d.bits[k] = 0u;
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
     NdtCell e;
     e.key = ~0ull; e.start = 0u; e.end = 0u; e.fmask = 0ull; e.pad_ = 0ull;
@@ -1331,6 +1335,7 @@ __global__ __launch_bounds__(256) void ndt_fit_near(const NdtDev* __restrict__ d
   NdtGridInfo* g = d.info;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool have = i < d.ns;
+  __shared__ uint4 s_ent[8][256];
   NdtQuery q{};
   if (have) q = ndt_fit_query(d, in[slot], i);
   float best = INFINITY;
@@ -1355,40 +1360,43 @@ __global__ __launch_bounds__(256) void ndt_fit_near(const NdtDev* __restrict__ d
       hp[c] = ndt_cell_hash(key[c], d.log2cells);
       e0[c] = cells[2 * hp[c]]; e1[c] = cells[2 * hp[c] + 1];
     }
+    // the entries found, parked in LDS: the cube's rows below pick theirs by index
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      if (key[c] == ~0ull) continue;
-      u32x4 a0 = e0[c], a1 = e1[c];
-      uint32_t hpos = hp[c];
-      for (;;) {                                             // (linear probing: the first probe is the entry nearly always)
-        const unsigned long long kk = ((unsigned long long)a0.y << 32) | a0.x;
-        if (kk == key[c] || kk == ~0ull) break;
-        hpos = (hpos + 1u) & maskc;
-        a0 = cells[2 * hpos]; a1 = cells[2 * hpos + 1];
-      }
-      if ((((unsigned long long)a0.y << 32) | a0.x) != key[c]) continue;
-      const unsigned long long fm = ((unsigned long long)a1.y << 32) | a1.x;
-      const uint32_t a = a0.z, b = a0.w, nf = (uint32_t)__popcll(fm);
-      const int mz = mlo[2] + (c >> 2), my = mlo[1] + ((c >> 1) & 1), mx = mlo[0] + (c & 1);
-      const int az = max(gf[2] - 1, 4 * mz) - 4 * mz, bz = min(gf[2] + 1, 4 * mz + 3) - 4 * mz;
-      const int ay = max(gf[1] - 1, 4 * my) - 4 * my, by = min(gf[1] + 1, 4 * my + 3) - 4 * my;
-      const int ax = max(gf[0] - 1, 4 * mx) - 4 * mx, bx = min(gf[0] + 1, 4 * mx + 3) - 4 * mx;
-      // the cube's rows inside this mid cell (a row's fine cells are one run): all their bounds first, then the points
-      uint32_t r0[9], r1[9];
-#pragma unroll
-      for (int r = 0; r < 9; ++r) {
-        const int fz = az + r / 3, fy = ay + r % 3;
-        r0[r] = 0u; r1[r] = 0u;
-        if (fz <= bz && fy <= by) {
-          const int row = (fz * 4 + fy) * 4;
-          const uint32_t lo = (uint32_t)__popcll(fm & ((1ull << (row + ax)) - 1ull));
-          const uint32_t hi = (uint32_t)__popcll(fm & ((2ull << (row + bx)) - 1ull));
-          if (hi != lo) { r0[r] = d.fpos[a + lo]; r1[r] = hi == nf ? b : d.fpos[a + hi]; }
+      uint4 found = make_uint4(0u, 0u, 0u, 0u);              // start, end, fine mask: an absent cell has an empty mask
+      if (key[c] != ~0ull) {
+        u32x4 a0 = e0[c], a1 = e1[c];
+        uint32_t hpos = hp[c];
+        for (;;) {                                           // (linear probing: the first probe is the entry nearly always)
+          const unsigned long long kk = ((unsigned long long)a0.y << 32) | a0.x;
+          if (kk == key[c] || kk == ~0ull) break;
+          hpos = (hpos + 1u) & maskc;
+          a0 = cells[2 * hpos]; a1 = cells[2 * hpos + 1];
         }
+        if ((((unsigned long long)a0.y << 32) | a0.x) == key[c]) found = make_uint4(a0.z, a0.w, a1.x, a1.y);
       }
-#pragma unroll
-      for (int r = 0; r < 9; ++r) best = ndt_scan_run(d.vpts, r0[r], r1[r], q.t, best);
+      s_ent[c][threadIdx.x] = found;
     }
+    // the cube's nine (z, y) rows of fine cells, each cut at most once by a mid cell's wall along x: a piece inside one mid cell is
+    // one run of points.  All bounds first (their loads go out together), then the points.
+    uint32_t r0[18], r1[18];
+#pragma unroll
+    for (int r = 0; r < 18; ++r) {
+      const int fz = gf[2] + (r / 6) - 1, fy = gf[1] + ((r / 2) % 3) - 1, xs = r & 1;
+      const int mz = fz >> 2, my = fy >> 2, mx = mlo[0] + xs;
+      r0[r] = 0u; r1[r] = 0u;
+      if (mx <= mhi[0]) {
+        const uint4 en = s_ent[((mz - mlo[2]) << 2) | ((my - mlo[1]) << 1) | xs][threadIdx.x];
+        const unsigned long long fm = ((unsigned long long)en.w << 32) | en.z;
+        const int ax = max(gf[0] - 1, 4 * mx) - 4 * mx, bx = min(gf[0] + 1, 4 * mx + 3) - 4 * mx;
+        const int row = ((fz & 3) * 4 + (fy & 3)) * 4;
+        const uint32_t lo = (uint32_t)__popcll(fm & ((1ull << (row + ax)) - 1ull));
+        const uint32_t hi = (uint32_t)__popcll(fm & ((2ull << (row + bx)) - 1ull));
+        if (hi != lo) { r0[r] = d.fpos[en.x + lo]; r1[r] = hi == (uint32_t)__popcll(fm) ? en.y : d.fpos[en.x + hi]; }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 18; ++r) best = ndt_scan_run(d.vpts, r0[r], r1[r], q.t, best);
   }
   if (have) d.fit_d2[i] = best;
   // anything outside the cube is at least a fine cell away
@@ -1470,24 +1478,29 @@ __global__ __launch_bounds__(256) void ndt_fit_far(const NdtDev* __restrict__ de
   const int slot = first_slot + blockIdx.y;
   const NdtDev d = devs[slot];
   const NdtGridInfo* g = d.info;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t nleft = g->nleft;
   const int nocc = g->nocc;
-  for (uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < nleft; k += gridDim.x * (blockDim.x >> 6)) {
+  __shared__ float s_m[4];
+  // a workgroup per query (there are few of them, and each looks at every occupied voxel's box twice)
+  for (uint32_t k = blockIdx.x; k < nleft; k += gridDim.x) {
     const int i = (int)d.qleft[k];
     const NdtQuery q = ndt_fit_query(d, in[slot], i);
     const float qs0 = q.t[0] * g->inv, qs1 = q.t[1] * g->inv, qs2 = q.t[2] * g->inv;     // the query in scaled coordinates
     // an upper bound in voxels: the best so far, and the farthest corner of the nearest boxes
     float up = sqrtf(d.fit_d2[i]) / g->res * 1.000001f + g->marg;
-    for (int v = lane; v < nocc; v += 64) {
+    for (int v = threadIdx.x; v < nocc; v += blockDim.x) {
       const float4 c = d.vbox[v];
       const float fx = fmaxf(fabsf(qs0 - c.x), fabsf(qs0 - c.x - 1.f)), fy = fmaxf(fabsf(qs1 - c.y), fabsf(qs1 - c.y - 1.f)), fz = fmaxf(fabsf(qs2 - c.z), fabsf(qs2 - c.z - 1.f));
       up = fminf(up, sqrtf(fx * fx + fy * fy + fz * fz) + g->marg);
     }
     up = wave_min(up);
-    up = __shfl(up, 0, 64);
+    if (lane == 0) s_m[wave] = up;
+    __syncthreads();
+    up = fminf(fminf(s_m[0], s_m[1]), fminf(s_m[2], s_m[3]));
+    __syncthreads();
     float best = INFINITY;
-    for (int v0 = 0; v0 < nocc; v0 += 64) {
+    for (int v0 = 64 * wave; v0 < nocc; v0 += 256) {       // a wave takes 64 voxels at a time and walks the near ones' points together
       const int v = v0 + lane;
       bool near = false;
       if (v < nocc) {
@@ -1504,7 +1517,10 @@ __global__ __launch_bounds__(256) void ndt_fit_far(const NdtDev* __restrict__ de
       }
     }
     best = wave_min(best);
-    if (lane == 0) d.fit_d2[i] = fminf(best, d.fit_d2[i]);
+    if (lane == 0) s_m[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) d.fit_d2[i] = fminf(fminf(fminf(s_m[0], s_m[1]), fminf(s_m[2], s_m[3])), d.fit_d2[i]);
+    __syncthreads();
   }
 }
 

@@ -204,13 +204,11 @@ smhip_status ndt_enqueue_grids(smhip_context* h, int first, int K) {
   if (s) return s;
   int nt_max = 0, nt_sum = 0;
   for (int k = first; k < first + K; ++k) { nt_max = std::max(nt_max, h->nt[k]); nt_sum += h->nt[k]; n.meta[k].valid = false; }
-  HIPCHK(h, hipMemsetAsync(n.bits_all + (size_t)first * kNdtMaxWords, 0, sizeof(uint32_t) * (size_t)kNdtMaxWords * K, h->stream));
-  // the cell tables start empty (key ~0; the mask bits are cleared by the fill kernel below), each over the part its target's size makes it use
-  hipLaunchKernelGGL(ndt_cells_clear, dim3(std::max(64, 4096 / K), K), dim3(256), 0, h->stream, n.devs_dev + first);
   const NdtDev* devs = n.devs_dev + first;
   const int gb = ceil_div(nt_max, 256);
   hipLaunchKernelGGL(ndt_bbox, dim3(kNdtBoxBlocks, K), dim3(256), 0, h->stream, devs);
   hipLaunchKernelGGL(ndt_voxel_setup, dim3(K), dim3(64), 0, h->stream, devs, n.opts.resolution);
+  hipLaunchKernelGGL(ndt_cells_clear, dim3(std::max(64, 4096 / K), K), dim3(256), 0, h->stream, devs);
   hipLaunchKernelGGL(ndt_voxel_mark, dim3(ceil_div(nt_max, kNdtMarkThreads), K), dim3(kNdtMarkThreads), 0, h->stream, devs);
   hipLaunchKernelGGL(ndt_voxel_rank, dim3(K), dim3(1024), 0, h->stream, devs);
   // (slot << 6 | sub-cell, point) pairs sorted with the rocPRIM radix sort of the workspace: as few key bits as the largest
@@ -532,6 +530,50 @@ smhip_status smhip_ndt_compute_derivatives(smhip_handle h, const double pose6[6]
   for (int i = 0; i < 36; ++i) hess[i] = compute_hessian ? n.out_pinned[7 + i] : 0.0;
   n.last_pairs = n.out_pinned[43];
   n.deriv_calls++;
+  return SMHIP_OK;
+}
+
+smhip_status smhip_ndt_time_derivatives(smhip_handle h, int first_slot, int npairs, int launches, double* ms_per_launch, double* pairs_per_launch) {
+  if (!h || !ms_per_launch || npairs < 1 || launches < 1 || first_slot < 0 || first_slot + npairs > h->dev.slots) return SMHIP_ERR_INVALID_ARGUMENT;
+  NdtHost& n = ndt_of(h);
+  if (n.cap < first_slot + npairs) { h->err = "no NDT tables for these slots"; return SMHIP_ERR_NOT_READY; }
+  for (int k = first_slot; k < first_slot + npairs; ++k)
+    if (!n.meta[k].valid || h->ns[k] <= 0) { h->err = "voxel table / source of a slot missing"; return SMHIP_ERR_NOT_READY; }
+  HIPCHK(h, hipSetDevice(h->device));
+  smhip_status s = ndt_push_devs(h, first_slot, npairs);
+  if (s) return s;
+  // jobs that stay in the 'evaluation wanted' state (no control launch runs): every launch does the same work
+  const NdtCtlOpts o = ndt_ctl_opts(n);
+  int ns_max = 0;
+  for (int k = 0; k < npairs; ++k) {
+    double G[16];
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) G[4 * c + r] = (double)n.res_pinned[first_slot + k].Tf[4 * r + c];
+    ndt_ctl_start(n, o, n.ctl_host[first_slot + k], first_slot + k, G, nullptr, kNdtTrial);
+    ns_max = std::max(ns_max, h->ns[first_slot + k]);
+  }
+  HIPCHK(h, hipMemcpyAsync(n.ctl_dev + first_slot, n.ctl_host + first_slot, sizeof(NdtCtl) * npairs, hipMemcpyHostToDevice, h->stream));
+  const dim3 g(std::max(1, ceil_div(ns_max, kNdtDerivThreads)), npairs);
+  hipEvent_t a, b;
+  HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b));
+  auto launch = [&]() {
+    if (n.double_math) hipLaunchKernelGGL(ndt_derivatives_ctl<double>, g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, n.ctl_dev + first_slot);
+    else hipLaunchKernelGGL(ndt_derivatives_ctl<float>, g, dim3(kNdtDerivThreads), 0, h->stream, n.devs_dev, n.ctl_dev + first_slot);
+  };
+  launch();                                                  // warm
+  HIPCHK(h, hipEventRecord(a, h->stream));
+  for (int r = 0; r < launches; ++r) launch();
+  HIPCHK(h, hipEventRecord(b, h->stream));
+  // the pair count of these evaluations: one control round on top (it ends the jobs' EvalOnly lives and leaves the sums)
+  for (int k = 0; k < npairs; ++k) n.ctl_host[first_slot + k].phase = kNdtEvalOnly;
+  HIPCHK(h, hipMemcpyAsync(n.ctl_dev + first_slot, n.ctl_host + first_slot, sizeof(NdtCtl) * npairs, hipMemcpyHostToDevice, h->stream));
+  ndt_enqueue_round(h, first_slot, npairs, (int)g.x, o, 0, n.out_pinned);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipGetLastError());
+  float ms = 0;
+  HIPCHK(h, hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  *ms_per_launch = (double)ms / launches;
+  if (pairs_per_launch) { double p = 0; for (int k = 0; k < npairs; ++k) p += n.out_pinned[(size_t)k * kNdtOutCols + 43]; *pairs_per_launch = p; }
   return SMHIP_OK;
 }
 

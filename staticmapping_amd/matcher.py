@@ -331,6 +331,14 @@ class NdtHip(IcpFastHip):
                                                             H.ctypes.data_as(_capi.c_double_p)))
         return score.value, g, H.reshape(6, 6)
 
+    def time_derivatives(self, npairs: int = 1, launches: int = 20, first_slot: int = 0):
+        """HIP-event time of back-to-back computeDerivatives launches over the slots' last poses (smhip_ndt_time_derivatives):
+        (ms per launch, (point, voxel) pairs per launch)."""
+        ms = np.zeros(1); pairs = np.zeros(1)
+        self._check(self._lib.smhip_ndt_time_derivatives(self._h, first_slot, npairs, launches, ms.ctypes.data_as(_capi.c_double_p),
+                                                         pairs.ctypes.data_as(_capi.c_double_p)))
+        return float(ms[0]), float(pairs[0])
+
 
 class NdtGicpHip(IcpFastHip):
     """registrators::NdtWithGicp on the GPU: mirrors NdtWithGicp::Align

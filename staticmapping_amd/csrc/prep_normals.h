@@ -33,6 +33,10 @@ hipError_t prep_sample_morton(PrepWorkspace* w, hipStream_t st, const float4* in
 // pcl::ApproximateVoxelGrid (leaf x leaf x leaf) of `raw` (n points, arrival order = array order) into `out`
 // (room for n entries; out[k].w = k).  Blocks until *m_host (number of centroids) is known.
 hipError_t prep_approx_voxel_grid(PrepWorkspace* w, hipStream_t st, const float4* raw, int n, float leaf, float4* out, int* m_host);
+// The same for S clouds at once (S <= 64; the workspace must hold sum(n) points): cloud c = raw[c][0 .. n[c]) (device pointers) into
+// out[c] (room for n[c] entries), m_host[c] centroids; per cloud exactly prep_approx_voxel_grid's output.  One synchronise for the batch.
+hipError_t prep_approx_voxel_grid_batch(PrepWorkspace* w, hipStream_t st, int S, const float4* const* raw, const int* n, float leaf,
+                                        float4* const* out, int* m_host);
 // Generic use of the workspace's radix sort by other builders (the NDT voxel grid): fill prep_keys(w, 0) / prep_values(w, 0)
 // with n (key, value) pairs, call prep_sort_pairs, read the sorted pairs from prep_keys(w, 1) / prep_values(w, 1).
 unsigned long long* prep_keys(PrepWorkspace* w, int which);

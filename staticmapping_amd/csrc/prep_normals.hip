@@ -807,7 +807,8 @@ hipError_t prep_approx_voxel_grid(PrepWorkspace* w, hipStream_t st, const float4
   const int gp = (n + 255) / 256;
   hipLaunchKernelGGL(avg_keys, dim3(gp), dim3(256), 0, st, raw, n, inv, w->keys[0], w->order[0]);
   size_t bytes = w->sort_bytes;
-  PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[0], w->order[1], (unsigned)n, 0, 41, st));
+  // (the pairs start in arrival order and the sort is stable: the nine bits of the history entry are all it has to look at)
+  PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[0], w->order[1], (unsigned)n, 32, 41, st));
   hipLaunchKernelGGL(avg_heads, dim3(gp), dim3(256), 0, st, raw, w->order[1], n, inv, w->seg[0]);
   size_t sbytes = w->sort_bytes;
   PCHK(rocprim::inclusive_scan(w->sort_tmp, sbytes, w->seg[0], w->seg[1], (size_t)n, rocprim::plus<int32_t>(), st));
@@ -822,6 +823,119 @@ hipError_t prep_approx_voxel_grid(PrepWorkspace* w, hipStream_t st, const float4
   PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[0], w->node_at[1], (unsigned)R, 0, 33, st));
   hipLaunchKernelGGL(avg_emit, dim3((R + 255) / 256), dim3(256), 0, st, w->avg_cent, w->node_at[1], w->counts, out);
   *m_host = R;
+  return hipGetLastError();
+}
+
+// ---- S clouds at once: one key pass, ONE stable sort on (cloud, history entry), one scan, one flush, one sort of the runs by
+// (cloud, emission time), one emit; the counts come back with a single synchronise.  Per cloud the output is exactly
+// prep_approx_voxel_grid's.  The workspace must hold sum(n) points; S <= kAvgMaxClouds.
+namespace {
+constexpr int kAvgMaxClouds = 64;
+struct AvgClouds {
+  int32_t S;
+  int32_t prefix[kAvgMaxClouds + 1];         // positions of the clouds in the batch
+  const float4* raw[kAvgMaxClouds];
+  float4* out[kAvgMaxClouds];
+};
+__device__ __forceinline__ int avg_cloud_of(const AvgClouds& cl, int g) {
+  int c = 0;
+  while (c + 1 < cl.S && g >= cl.prefix[c + 1]) ++c;
+  return c;
+}
+__global__ void avg_keys_b(const AvgClouds cl, int N, float inv, unsigned long long* keys, int32_t* idx) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= N) return;
+  const int c = avg_cloud_of(cl, g);
+  int ix, iy, iz; uint32_t hsh;
+  avg_voxel(cl.raw[c][g - cl.prefix[c]], inv, ix, iy, iz, hsh);
+  keys[g] = ((unsigned long long)c << 9) | hsh;
+  idx[g] = g;
+}
+__global__ void avg_heads_b(const AvgClouds cl, const int32_t* idx, int N, float inv, int32_t* head) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= N) return;
+  const int g = idx[s], c = avg_cloud_of(cl, g);
+  int ax, ay, az, bx, by, bz; uint32_t ha, hb;
+  avg_voxel(cl.raw[c][g - cl.prefix[c]], inv, ax, ay, az, ha);
+  int hd = 1;
+  if (s > cl.prefix[c]) {                                     // (a cloud's points fill the sorted positions [prefix[c], prefix[c + 1]))
+    const int gp = idx[s - 1];
+    avg_voxel(cl.raw[c][gp - cl.prefix[c]], inv, bx, by, bz, hb);
+    hd = (ha != hb || ax != bx || ay != by || az != bz) ? 1 : 0;
+  }
+  head[s] = hd;
+}
+__global__ void avg_run_starts_b(const AvgClouds cl, const int32_t* head, const int32_t* incl, int N, int32_t* run_start, int32_t* runp) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= N) return;
+  if (head[s]) run_start[incl[s] - 1] = s;
+  if (s <= cl.S) runp[s] = s < cl.S ? incl[cl.prefix[s]] - 1 : incl[N - 1];      // first run of every cloud, and the total
+}
+__global__ void avg_flush_b(const AvgClouds cl, const int32_t* idx, const int32_t* run_start, const int32_t* runp, int N, float inv,
+                            float4* cent, unsigned long long* when, int32_t* rid) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int R = runp[cl.S];
+  if (r >= R) return;
+  const int a = run_start[r], b = (r + 1 < R) ? run_start[r + 1] : N;
+  const int c = avg_cloud_of(cl, idx[a]);
+  const float4* raw = cl.raw[c];
+  const int base = cl.prefix[c], nc = cl.prefix[c + 1] - base;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int s = a; s < b; ++s) { const float4 p = raw[idx[s] - base]; sx += p.x; sy += p.y; sz += p.z; }   // hhe->centroid += scratch
+  const float cnt = (float)(b - a);
+  cent[r] = make_float4(sx / cnt, sy / cnt, sz / cnt, 0.f);                                           // flush: centroid /= count
+  int ix, iy, iz; uint32_t h0, h1 = 0xffffffffu;
+  avg_voxel(raw[idx[a] - base], inv, ix, iy, iz, h0);
+  if (b < cl.prefix[c + 1]) avg_voxel(raw[idx[b] - base], inv, ix, iy, iz, h1);
+  const unsigned long long w = (h1 == h0) ? (unsigned long long)(uint32_t)(idx[b] - base) : (unsigned long long)nc + h0;
+  when[r] = ((unsigned long long)c << 33) | w;
+  rid[r] = r;
+}
+__global__ void avg_emit_b(const AvgClouds cl, const float4* cent, const int32_t* rid_sorted, const int32_t* runp) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= runp[cl.S]) return;
+  int c = 0;
+  while (c + 1 < cl.S && k >= runp[c + 1]) ++c;
+  float4 v = cent[rid_sorted[k]];
+  v.w = __int_as_float(k - runp[c]);
+  cl.out[c][k - runp[c]] = v;
+}
+}  // namespace
+
+hipError_t prep_approx_voxel_grid_batch(PrepWorkspace* w, hipStream_t st, int S, const float4* const* raw, const int* n, float leaf, float4* const* out, int* m_host) {
+  if (!w || S <= 0 || S > kAvgMaxClouds || !(leaf > 0.f)) return hipErrorInvalidValue;
+  AvgClouds cl{};
+  cl.S = S;
+  long long total = 0;
+  for (int c = 0; c < S; ++c) {
+    if (n[c] <= 0) return hipErrorInvalidValue;
+    cl.prefix[c] = (int32_t)total; cl.raw[c] = raw[c]; cl.out[c] = out[c];
+    total += n[c];
+  }
+  cl.prefix[S] = (int32_t)total;
+  if (total > w->cap) return hipErrorInvalidValue;
+  if (!w->avg_cent && hipMalloc((void**)&w->avg_cent, sizeof(float4) * (size_t)w->cap) != hipSuccess) return hipErrorOutOfMemory;
+  const float inv = 1.0f / leaf;
+  const int N = (int)total, gp = (N + 255) / 256;
+  int cbits = 0;
+  while ((1 << cbits) < S) ++cbits;
+  hipLaunchKernelGGL(avg_keys_b, dim3(gp), dim3(256), 0, st, cl, N, inv, w->keys[0], w->order[0]);
+  size_t bytes = w->sort_bytes;
+  PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[0], w->order[1], (unsigned)N, 0, (unsigned)(9 + cbits), st));
+  hipLaunchKernelGGL(avg_heads_b, dim3(gp), dim3(256), 0, st, cl, w->order[1], N, inv, w->seg[0]);
+  size_t sbytes = w->sort_bytes;
+  PCHK(rocprim::inclusive_scan(w->sort_tmp, sbytes, w->seg[0], w->seg[1], (size_t)N, rocprim::plus<int32_t>(), st));
+  int32_t* runp = w->scan_meta;                               // [S + 1] (kAvgMaxClouds + 1 <= 3 * kMaxScans + 8)
+  hipLaunchKernelGGL(avg_run_starts_b, dim3(gp), dim3(256), 0, st, cl, w->seg[0], w->seg[1], N, w->node_at[0], runp);
+  hipLaunchKernelGGL(avg_flush_b, dim3(gp), dim3(256), 0, st, cl, w->order[1], w->node_at[0], runp, N, inv, w->avg_cent, w->keys[0], w->order[0]);
+  PCHK(hipMemcpyAsync(w->host_pinned, runp, sizeof(int32_t) * (S + 1), hipMemcpyDeviceToHost, st));
+  PCHK(hipStreamSynchronize(st));
+  const int R = w->host_pinned[S];
+  if (R <= 0 || R > N) return hipErrorUnknown;
+  bytes = w->sort_bytes;
+  PCHK(rocprim::radix_sort_pairs(w->sort_tmp, bytes, w->keys[0], w->keys[1], w->order[0], w->node_at[1], (unsigned)R, 0, (unsigned)(33 + cbits), st));
+  hipLaunchKernelGGL(avg_emit_b, dim3((R + 255) / 256), dim3(256), 0, st, cl, w->avg_cent, w->node_at[1], runp);
+  for (int c = 0; c < S; ++c) m_host[c] = w->host_pinned[c + 1] - w->host_pinned[c];
   return hipGetLastError();
 }
 

@@ -1522,6 +1522,7 @@ extern "C" void smhip_internal_free_gicp(smhip_context* h) {
   GicpHost& g = h->gicp->g;
   if (g.out_pinned) (void)hipHostFree(g.out_pinned);
   if (g.count_pinned) (void)hipHostFree(g.count_pinned);
+  if (g.prep_avg) prep_destroy(g.prep_avg);
   delete h->gicp;
   h->gicp = nullptr;
 }

@@ -45,6 +45,8 @@ struct GicpHost {
   float4* raw_src = nullptr;          // [jobs][ns_cap] as handed over
   float4* raw_tgt = nullptr;          // [jobs][nt_cap]
   float4* ds_tmp = nullptr;           // [max(ns_cap, nt_cap)] filter output before the Morton ordering
+  float4* ds_src = nullptr;           // [jobs][ns_cap] the same for every job's source at once (batched staging; allocated on first use)
+  PrepWorkspace* prep_avg = nullptr;  // workspace of the batched voxel filter: every job's raw source + target at once (allocated on first use)
   double* out_pinned = nullptr;       // [jobs][kGicpCols] doubles, then the finished round's number
   uint32_t* count_pinned = nullptr;   // [jobs]
   int evals = 0;                      // functor evaluations of the last single-job run (parity hooks)
@@ -823,6 +825,58 @@ static smhip_status ndt_gicp_stage_clouds(smhip_handle h, int job) {
   return SMHIP_OK;
 }
 
+// the same for jobs first .. first + K - 1 at once when the voxel filter is on: ONE ApproximateVoxelGrid pass over every cloud that
+// has to be filtered (all sources, and the targets that are not kept), one Morton ordering of the down-sampled sources, one
+// synchronise -- instead of two sorts, a scan and a synchronise per cloud
+static smhip_status ndt_gicp_stage_clouds_batch(smhip_handle h, int first, int K) {
+  GicpHost& g = gicp_of(h);
+  const size_t NS = h->dev.ns_cap, NT = h->dev.nt_cap;
+  if (!g.prep_avg) {
+    const size_t cap = (size_t)g.jobs * (NS + NT);
+    if (cap > (size_t)0x7fffffff) { h->err = "NdtWithGicp: the handle's clouds together exceed the batched filter's 2^31 points"; return SMHIP_ERR_CAPACITY; }
+    g.prep_avg = prep_create((int)cap);
+    if (!g.prep_avg) { h->err = "NdtWithGicp: batched filter workspace allocation failed"; return SMHIP_ERR_HIP; }
+  }
+  if (!g.ds_src) { smhip_status s0 = dev_alloc(h, &g.ds_src, (size_t)g.jobs * NS); if (s0) return s0; }
+  std::vector<const float4*> raw;
+  std::vector<float4*> out;
+  std::vector<int> n, owner;                        // owner: job e's source = 2 e, target = 2 e + 1
+  std::vector<char> keep((size_t)K, 0);
+  for (int e = 0; e < K; ++e) {
+    const int job = first + e;
+    GicpJobHost& jh = g.job[job];
+    if (jh.n_raw_src <= 0 || jh.n_raw_tgt <= 0) { h->err = "NdtWithGicp::Align before SetInputSource/SetInputTarget"; return SMHIP_ERR_NOT_READY; }
+    keep[e] = h->target_cache && jh.raw_tgt_gen != 0 && jh.staged_raw_gen == jh.raw_tgt_gen && jh.staged_slot_gen == h->tgt_gen[job] &&
+              jh.staged_filter == 1 && jh.staged_res == g.opts.voxel_resolution;
+    raw.push_back(g.raw_src + (size_t)job * NS); out.push_back(g.ds_src + (size_t)job * NS); n.push_back(jh.n_raw_src); owner.push_back(2 * e);
+    if (!keep[e]) {
+      raw.push_back(g.raw_tgt + (size_t)job * NT); out.push_back(const_cast<float4*>(h->dev.tgt_p) + (size_t)job * NT); n.push_back(jh.n_raw_tgt); owner.push_back(2 * e + 1);
+    }
+  }
+  std::vector<int> m(raw.size());
+  hipError_t er = prep_approx_voxel_grid_batch(g.prep_avg, h->stream, (int)raw.size(), raw.data(), n.data(), g.opts.voxel_resolution, out.data(), m.data());
+  if (er != hipSuccess) { h->err = std::string("NdtWithGicp down-sampling: ") + hipGetErrorString(er); return SMHIP_ERR_HIP; }
+  std::vector<int> stage_off((size_t)K), ms((size_t)K);
+  std::vector<long long> out_off((size_t)K);
+  for (size_t c = 0; c < raw.size(); ++c) {
+    const int e = owner[c] >> 1, job = first + e;
+    if (owner[c] & 1) {
+      GicpJobHost& jh = g.job[job];
+      h->nt[job] = m[c];
+      touch_target(h, job);
+      jh.staged_raw_gen = jh.raw_tgt_gen; jh.staged_slot_gen = h->tgt_gen[job]; jh.staged_filter = 1; jh.staged_res = g.opts.voxel_resolution; jh.staged_nt = m[c];
+    } else {
+      ms[e] = m[c]; stage_off[e] = (int)((size_t)job * NS); out_off[e] = (long long)((size_t)job * NS);
+      h->ns[job] = m[c]; h->has_normals[job] = 0;
+      touch_source(h, job);
+    }
+  }
+  for (int e = 0; e < K; ++e) if (keep[e]) h->cache_hits++;
+  er = prep_morton_sort_batch(g.prep_avg, h->stream, g.ds_src, K, stage_off.data(), ms.data(), out_off.data(), const_cast<float4*>(h->dev.src));
+  if (er != hipSuccess) { h->err = std::string("NdtWithGicp source ordering: ") + hipGetErrorString(er); return SMHIP_ERR_HIP; }
+  return SMHIP_OK;
+}
+
 // NdtWithGicp::Align of the jobs first .. first + K - 1, each stage over all of them at once
 static smhip_status ndt_gicp_align_jobs(smhip_handle h, int first, int K, const double* guesses, double* results, double* scores, smhip_ndt_gicp_stats* stats) {
   HIPCHK(h, hipSetDevice(h->device));
@@ -855,11 +909,16 @@ static smhip_status ndt_gicp_align_jobs(smhip_handle h, int first, int K, const 
     all_full = all_full && staged && cov;
   }
   GicpCell cell(h, all_full ? h->dev.grid_cell : gicp_knn_cell(g.opts));
-  for (int e = 0; e < K; ++e) {
-    s = ndt_gicp_stage_clouds(h, first + e);
+  if (g.opts.using_voxel_filter && K > 1) {
+    s = ndt_gicp_stage_clouds_batch(h, first, K);
     if (s) return s;
-    st[e].n_source = h->ns[first + e]; st[e].n_target = h->nt[first + e];
+  } else {
+    for (int e = 0; e < K; ++e) {
+      s = ndt_gicp_stage_clouds(h, first + e);
+      if (s) return s;
+    }
   }
+  for (int e = 0; e < K; ++e) { st[e].n_source = h->ns[first + e]; st[e].n_target = h->nt[first + e]; }
   std::vector<float> ndt_guess((size_t)16 * K), fin((size_t)16 * K);
   std::vector<double> ndt_score((size_t)K, 0.9);             // :81
   for (int e = 0; e < K; ++e) colmajor_to_rm_f32(guesses + 16 * e, &ndt_guess[(size_t)16 * e]);   // guess.cast<float>(), :80

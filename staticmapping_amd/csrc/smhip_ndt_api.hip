@@ -385,26 +385,38 @@ smhip_status ndt_align_slots(smhip_context* h, int first, int K, const double* g
   const int round_cap = (std::max(0, o.max_iterations) + 2) * 12 + 2;
   int rounds = 0, want = std::max(1, std::min(n.predicted_rounds, round_cap));
   n.last_submissions = 0;
-  for (;;) {
+  for (bool speculate = true;; speculate = false) {
     for (; rounds < want; ++rounds) ndt_enqueue_round(h, first, K, blocks, o, rounds, nullptr);
-    s = fitness_enqueue_search(h, first, K);       // speculative: valid if every job has ended by now
-    if (s) return s;
+    // the fitness pass behind the predicted rounds: valid if every job has ended by then (a handle's Aligns are alike: it nearly
+    // always has).  After a wrong prediction: rounds only, twice as many each time, and the fitness pass once the flags say done
+    if (speculate) { s = fitness_enqueue_search(h, first, K); if (s) return s; }
     HIPCHK(h, hipMemcpyAsync(n.info_pinned + first, n.info_all + first, sizeof(NdtGridInfo) * K, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     n.last_submissions++;
     bool all_done = true;
     for (int k = 0; k < K; ++k) all_done = all_done && (n.flags_pinned[first + k] & 0xffu) == (uint32_t)kNdtDone;
-    if (all_done) break;
+    if (all_done) {
+      if (!speculate) {
+        s = fitness_enqueue_search(h, first, K);
+        if (s) return s;
+        HIPCHK(h, hipMemcpyAsync(n.info_pinned + first, n.info_all + first, sizeof(NdtGridInfo) * K, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        n.last_submissions++;
+      }
+      break;
+    }
     if (rounds >= round_cap) { h->err = "NDT: a job did not end within the reference's own iteration bounds"; return SMHIP_ERR_HIP; }
-    want = std::min(round_cap, rounds + 2);
+    want = std::min(round_cap, 2 * rounds);
   }
   if (!current) { s = ndt_tables_built(h, first, K); if (s) return s; }
-  if (std::getenv("SMHIP_NDT_DEBUG"))
+  if (std::getenv("SMHIP_NDT_DEBUG")) {
+    std::fprintf(stderr, "ndt align of %d job(s): %d rounds enqueued, %d submissions, predicted %d\n", K, rounds, n.last_submissions, n.predicted_rounds);
     for (int k = 0; k < std::min(K, 8); ++k) {
       const NdtGridInfo& gi = n.info_pinned[first + k];
       std::fprintf(stderr, "ndt job %d: ns %d nt %d voxels %d big %d; fitness: %u queries past the fine cube, %u past the mid shells\n", k, h->ns[first + k], h->nt[first + k], gi.nocc, gi.nbig, gi.nlist, gi.nleft);
     }
+  }
   int needed = 1;
   for (int k = 0; k < K; ++k) needed = std::max(needed, n.res_pinned[first + k].done_round + 1);
   n.predicted_rounds = needed;

@@ -74,3 +74,54 @@ def test_exact_search_vs_reference_eps_search_whole_align(name, n_points, capsys
     assert 1e-6 < da < 2e-3 and 1e-4 < dt < 2e-2
     if name == "cfg2":
         assert et < at                       # the exact search lands closer to the known motion
+
+
+def test_restatements_on_ties_and_duplicates_hypothesis():
+    """Property test of the two libnabo restatements where a k-d tree's arbitrary choices show: duplicated points, coordinates on a
+    coarse lattice (many equal split values and equal distances), queries that coincide with targets, clouds of 1-40 points (bucket
+    size 8: trees of depth 0-3).  libnabo's own answer is not defined there -- which of two points at the same distance wins follows
+    from the order std::nth_element leaves equal keys in (kdtree_opencl / kdtree_cpu build, 1.0.7) -- so the two restatements may name
+    different points; what each must keep: the distance it reports is the distance to the point it names, at eps = 0 that distance is
+    the exact minimum, and for every eps it is within libnabo's (1 + eps) contract.  The same inputs jittered (no ties left): id,
+    squared distance and visited-leaf count agree exactly."""
+    from hypothesis import given, settings, strategies as st
+
+    coord = st.integers(min_value=-6, max_value=6).map(lambda v: v * 0.25)
+    point = st.tuples(coord, coord, coord)
+    differ = [0, 0]
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(point, min_size=1, max_size=40), st.lists(point, min_size=1, max_size=12), st.sampled_from([0.0, 0.5, 3.16]),
+           st.integers(min_value=0, max_value=3), st.integers(min_value=0, max_value=2 ** 31 - 1))
+    def check(tp, qp, eps, dup, seed):
+        tgt = np.array(tp, dtype=np.float64)
+        if dup:
+            tgt = np.concatenate([tgt, tgt[:: max(1, 4 - dup)]])           # exact duplicates of some of the points
+        qry = np.concatenate([np.array(qp, dtype=np.float64), tgt[:2]])   # and queries that sit on targets
+        for jitter in (False, True):
+            t, q = tgt, qry
+            if jitter:
+                rng = np.random.default_rng(seed)
+                t = tgt + rng.uniform(-0.05, 0.05, tgt.shape); q = qry + rng.uniform(-0.05, 0.05, qry.shape)
+            tree = nabo.NaboTree(t)
+            ids_c, d2_c, leaves_c = cref.nn_nabo(t, q, eps)
+            brute = ((q[:, None, :] - t[None, :, :]) ** 2).sum(axis=2)
+            leaves_py = 0
+            for k, qq in enumerate(q):
+                j, d2, lv = tree.knn1(qq, eps)
+                leaves_py += lv
+                for jj, dd in ((j, d2), (int(ids_c[k]), float(d2_c[k]))):
+                    assert dd == brute[k, jj]                                       # the reported distance is the named point's
+                    assert np.sqrt(dd) <= (1.0 + eps) * np.sqrt(brute[k].min()) + 1e-12
+                    if eps == 0.0:
+                        assert dd == brute[k].min()
+                if jitter:
+                    assert j == ids_c[k] and d2 == d2_c[k], (eps, k, j, ids_c[k])
+                else:
+                    differ[0] += int(j != ids_c[k]); differ[1] += 1
+            if jitter:
+                assert leaves_py == leaves_c
+
+    check()
+    assert differ[1] > 0
+    print(f"\n[nabo ties] the restatements named different (equally far or equally admissible) points for {differ[0]} of {differ[1]} tied queries")

@@ -82,7 +82,10 @@ typedef struct smhip_icp_options {
   int32_t no_lds_table;         /* 1: voxel lookups from global memory (nn_ball) instead of LDS row tables (nn_ball_lds) */
   int32_t no_overlap;           /* 1: keep a batch on one stream (default 0: a batch is split into parts of >= 16 pairs on
                                    separate streams so one part's latency-bound launches hide behind the others' NN) */
-  int32_t overlap_streams;      /* number of such parts, 1..4; 0 = default (2; 4 is 1.5-5 % faster on 512-pair batches, slower on 256-pair ones) */
+  int32_t overlap_streams;      /* number of such parts, 1..4; 0 = default (2; 4 is 1.5-5 % faster on 512-pair batches, slower on 256-pair ones).
+                                 * More than 2 parts (or RCCL beside the matcher) need more hardware queues than the runtime's default 4, or two
+                                 * parts share a queue and run one after the other: export GPU_MAX_HW_QUEUES=8 before the process's first HIP
+                                 * call (smhip_shard and bench.py do) */
   int32_t split_after;          /* batches: iterations >= this run the certificate pass and the search of the failing queries as two
                                    launches instead of the fused kernel (pays once few certificates fail).  0 = automatic: 2 for a
                                    handle's first batch, then the first iteration in which the median pair of the PREVIOUS batch

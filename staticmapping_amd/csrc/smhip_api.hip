@@ -420,8 +420,10 @@ smhip_status enqueue_find_closests_half(smhip_context* h, const Half& f, int ns_
           if (d.fused) {
             // certificate pass + the sums below the predicted quantile band in one pass over the source (fused_iteration decides)
             const int nbc = ceil_div(ns_max, kNnThreads * kCertifyItems);
-            // (every target of the launch below 32 767 points: the 4-byte shadow of bound + match instead of the two arrays)
-            if (h->use_shadow && nt_max_of(h, d.pair_base, np) < 0x7fff)
+            // (every target of the launch below 32 767 points: the 4-byte shadow of bound + match instead of the two arrays.  Only behind
+            // the LDS-table ball search, whose kernels -- with the listed search and the refinement kernels -- write the shadow with every
+            // match (st_match); nn_ring_wide, nn_brute and nn_nabo set idx / lb alone and never run in such an Align)
+            if (h->use_shadow && d.lds_table && nt_max_of(h, d.pair_base, np) < 0x7fff)
               hipLaunchKernelGGL((nn_certify_acc<kCertifyItems, false, true>), dim3(nbc * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nbc);
             else
               hipLaunchKernelGGL(nn_certify_acc<kCertifyItems>, dim3(nbc * 8 * ceil_div(np, 8)), dim3(kNnThreads), 0, st, d, nbc);

@@ -19,7 +19,8 @@ constexpr int kAccItemsSmall = 8;
 constexpr int kAccItemsBatch = 32;
 constexpr int kFinalizeKeyCap = 8192;     // band records whose keys finalize keeps in LDS between its radix-select passes
 constexpr int kFinalizeMaxSeg = 2048;     // record segments (one per producing wave) per pair finalize can index: 4 Mi source points at 32 per
-                                          // accumulate thread; the fused path (20 per thread + the listed search's 128 waves) up to 2.4 Mi points
+                                          // accumulate thread; the fused path (kCertifyItems = 32 per thread, four segments per workgroup, + the listed search's
+                                          // kListedMaxItems = 129 items: fused_iteration() checks the sum) up to (2048 - 129) / 4 workgroups of 8 192 = 3.9 Mi points
 constexpr int kScoreParts = 16;          // workgroups per pair of final_score
 constexpr int kAccCols = 32;             // 21 (A upper) + 6 (b) + 1 (unused: the score is formed once, by final_score) + 1 (count) padded to 32
 constexpr int kMaxGridWords = 1 << 18;   // 32-cell words per pair (8 Mi cells)
@@ -36,7 +37,7 @@ constexpr int kListedMaxPairs = 1024;   // pairs per launch of the balanced list
 constexpr int kListedItemBlocks = 1280;  // its workgroups: 5 per CU (LDS), each takes an equal run of the launch's items
 constexpr int kListedBlocks = 32;        // workgroups per pair of the listed search (nn_ball_listed): it strides over the list
 constexpr int kBallItems = 2;            // rounds of 256 queries per workgroup in nn_ball_lds / nn_ball (prefetch across rounds; 2 measured best: 4 = +8 %, 1 = +5 %)
-constexpr int kListedLaneBudgetMax = 32768;   // largest lane budget of the balanced listed search (SMHIP_LISTED_LANES; default 4096)
+constexpr int kListedLaneBudgetMax = 32768;   // largest lane budget of the balanced listed search (SMHIP_LISTED_LANES; default 1024, sync_options)
 constexpr int kFusedListedMax = 16384;   // fused path: with more failing certificates than this in a pair and iteration the sums are left to `accumulate`
                                          // (their listed matches below the band are summed kListedSumChunk entries per work item of iteration_sums,
                                          // a row of partials each)

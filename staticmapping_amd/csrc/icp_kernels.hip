@@ -107,7 +107,7 @@ __global__ void pose_setup(IcpDev b, int npairs) {
   for (int i = 0; i < 16; ++i) st->guess[i] = in->guess[i];
   if (st->grid_invalid) {                 // the kept "structure" is grid_setup's placeholder for a non-finite target: fail again
     for (int i = 0; i < 16; ++i) st->result[(i % 4) * 4 + i / 4] = st->guess[i];
-    st->iter = 0; st->score = 0; st->kept = 0; st->searched_total = 0; st->fallback_total = 0; st->hard_total = 0; st->refine_total = 0;
+    st->iter = 0; st->score = 0; st->score_mismatch = 0; st->kept = 0; st->searched_total = 0; st->fallback_total = 0; st->hard_total = 0; st->refine_total = 0;
     st->status = 1; st->done = 1;
     atomicAdd(b.done_count, 1u);
     return;
@@ -125,7 +125,7 @@ __global__ void pose_setup(IcpDev b, int npairs) {
   for (int c = 0; c < 4; ++c) st->nabo_count[c] = 0;
   st->pot_a = 0; st->pot_b = 0; st->step_a = 0; st->step_b = 0;
   st->rcap2 = b.ball_radius * b.ball_radius;
-  st->kept = 0; st->limit_key = 0; st->score = 0;
+  st->kept = 0; st->limit_key = 0; st->score = 0; st->score_mismatch = 0;
   st->band_lo = 0; st->band_hi = -1; st->spec_ok = 0; st->spec_hits = 0;
 }
 // per-Align scratch that is not part of the search structure: histogram + finished-pairs counter
@@ -169,7 +169,7 @@ __global__ void grid_setup(IcpDev b, int npairs) {
     st->nx = st->ny = st->nz = 1; st->wx = 1; st->nw = 1; st->nocc = 0;
     for (int i = 0; i < 16; ++i) { st->T_iter[i] = (i % 5 == 0) ? 1.0 : 0.0; st->G[i] = st->guess[i]; st->result[(i % 4) * 4 + i / 4] = st->guess[i]; }
     for (int i = 0; i < 12; ++i) { st->M[i] = st->guess[i]; st->M_prev[i] = st->guess[i]; }
-    st->n_hist = 1; st->iter = 0; st->score = 0; st->kept = 0; st->limit_key = 0;
+    st->n_hist = 1; st->iter = 0; st->score = 0; st->score_mismatch = 0; st->kept = 0; st->limit_key = 0;
     st->unresolved_count = 0; st->fallback_ticket = 0; st->fallback_total = 0; st->hard_count = 0; st->hard_total = 0;
     st->min_lb_key = 0xffffffffu; st->refine = 0; st->refine_total = 0; st->deferred_count = 0; st->searched_total = 0;
   for (int c = 0; c < 4; ++c) st->nabo_count[c] = 0;
@@ -212,7 +212,7 @@ __global__ void grid_setup(IcpDev b, int npairs) {
   for (int c = 0; c < 4; ++c) st->nabo_count[c] = 0;
   st->pot_a = 0; st->pot_b = 0; st->step_a = 0; st->step_b = 0;
   st->rcap2 = b.ball_radius * b.ball_radius;
-  st->kept = 0; st->limit_key = 0; st->score = 0; st->nocc = 0;
+  st->kept = 0; st->limit_key = 0; st->score = 0; st->score_mismatch = 0; st->nocc = 0;
   st->band_lo = 0; st->band_hi = -1; st->spec_ok = 0; st->spec_hits = 0;
 }
 
@@ -3612,7 +3612,9 @@ __global__ __launch_bounds__(kAccThreads) void final_score(IcpDev b) {
   const int pair = b.pair_base + (int)(blockIdx.x / kScoreParts), part = (int)(blockIdx.x % kScoreParts);
   PairState* st = &b.state[pair];
   __shared__ double s_w4[kAccThreads / 64];
+  __shared__ uint32_t s_c4[kAccThreads / 64];
   double s = 0.0;
+  uint32_t cnt = 0;
   if (st->done && st->status == 0) {                      // (no match: finalize left score = 0, score_fold keeps it)
     const int ns = st->ns;
     const int len = ((ns + kScoreParts * kAccThreads - 1) / (kScoreParts * kAccThreads)) * kAccThreads;   // points per part: whole rounds
@@ -3625,13 +3627,18 @@ __global__ __launch_bounds__(kAccThreads) void final_score(IcpDev b) {
       for (int k = 0; k < 8; ++k) d[k] = d2[min(i0 + k * kAccThreads, hi - 1)];
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        if (i0 + k * kAccThreads < hi && __float_as_uint(d[k]) <= limit_key) s += sqrt((double)d[k]);
+        if (i0 + k * kAccThreads < hi && __float_as_uint(d[k]) <= limit_key) { s += sqrt((double)d[k]); ++cnt; }
     }
   }
   s = wave_sum_to_last(s);
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
   if ((threadIdx.x & 63) == 63) s_w4[threadIdx.x >> 6] = s;
+  if ((threadIdx.x & 63) == 0) s_c4[threadIdx.x >> 6] = cnt;
   __syncthreads();
-  if (threadIdx.x == 0) st->score_part[part] = ((s_w4[0] + s_w4[1]) + s_w4[2]) + s_w4[3];
+  if (threadIdx.x == 0) {
+    st->score_part[part] = ((s_w4[0] + s_w4[1]) + s_w4[2]) + s_w4[3];
+    st->score_cnt[part] = ((s_c4[0] + s_c4[1]) + s_c4[2]) + s_c4[3];
+  }
 }
 __global__ void score_fold(IcpDev b, int npairs) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3639,8 +3646,12 @@ __global__ void score_fold(IcpDev b, int npairs) {
   PairState* st = &b.state[b.pair_base + k];
   if (!st->done || st->status != 0 || st->kept < 1) return;
   double tot = 0.0;
-  for (int p = 0; p < kScoreParts; ++p) tot += st->score_part[p];
-  st->score = exp(-tot / (double)st->kept);
+  uint32_t n = 0;
+  for (int p = 0; p < kScoreParts; ++p) { tot += st->score_part[p]; n += st->score_cnt[p]; }
+  // the mean over the matches that were summed: finalize's kept count is the same number whenever the distances of the last
+  // iteration stand untouched (every iteration kernel returns on `done`); a difference is flagged, not divided away
+  st->score_mismatch = n != (uint32_t)st->kept ? 1u : 0u;
+  st->score = n ? exp(-tot / (double)n) : 0.0;
 }
 
 // Slot-to-slot copy of the uploaded clouds (benchmark replication).

@@ -1320,6 +1320,9 @@ static smhip_status fetch_range(smhip_handle h, int first, int npairs, double* r
       h->err = st.status == SMHIP_ERR_INVALID_ARGUMENT ? "pair failed: target cloud has NaN / Inf coordinates" : "pair failed: no finite correspondence";
     }
     if (!st.done && worst == SMHIP_OK) { worst = SMHIP_ERR_HIP; h->err = "pair did not finish (internal)"; }
+    if (st.done && st.status == SMHIP_OK && st.score_mismatch && worst == SMHIP_OK) {
+      worst = SMHIP_ERR_HIP; h->err = "score: the matches summed are not the matches finalize kept (internal)";
+    }
   }
   return worst;
 }

@@ -113,6 +113,9 @@ struct PairState {
 
   // outputs
   double score_part[kScoreParts];   // final_score: the sums of sqrt(d2) over the kept matches of the pair's kScoreParts point ranges
+  uint32_t score_cnt[kScoreParts];  // ... and how many matches each range summed (score_fold divides by their total)
+  uint32_t score_mismatch;          // 1 = that total differed from finalize's kept count (never expected; tests look at it)
+  uint32_t pad_score_;
   double score;
   double result[16];     // column-major (Eigen layout)
 };

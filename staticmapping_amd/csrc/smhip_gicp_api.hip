@@ -909,7 +909,7 @@ static smhip_status ndt_gicp_align_jobs(smhip_handle h, int first, int K, const 
     all_full = all_full && staged && cov;
   }
   GicpCell cell(h, all_full ? h->dev.grid_cell : gicp_knn_cell(g.opts));
-  if (g.opts.using_voxel_filter && K > 1) {
+  if (g.opts.using_voxel_filter) {
     s = ndt_gicp_stage_clouds_batch(h, first, K);
     if (s) return s;
   } else {

@@ -19,7 +19,7 @@ class IcpOptions(ctypes.Structure):
                 ("use_ball", ctypes.c_int32), ("exact_matches", ctypes.c_int32), ("ball_radius", ctypes.c_float),
                 ("ball_cap_factor", ctypes.c_float), ("no_certify", ctypes.c_int32), ("no_lds_table", ctypes.c_int32),
                 ("no_overlap", ctypes.c_int32), ("overlap_streams", ctypes.c_int32),
-                ("split_after", ctypes.c_int32), ("nn_epsilon", ctypes.c_float), ("no_fused_sums", ctypes.c_int32)]
+                ("split_after", ctypes.c_int32), ("nn_epsilon", ctypes.c_float), ("no_fused_sums", ctypes.c_int32), ("no_single_kernel", ctypes.c_int32)]
 
 
 class IcpStats(ctypes.Structure):

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libsmhip.so")
 SHARD_EXE = os.path.join(LIB_DIR, "smhip_shard")          # C++ sharded sequence driver (RCCL gather), csrc/shard_driver.cc
 
 HIP_SOURCES = ["smhip_api.hip", "prep_normals.hip", "cloud_filters.hip", "smhip_mrvm.hip", "host_cloud.cc"]            # translation units (each may #include kernel files)
-HIP_DEPS = ["icp_kernels.hip", "nabo_kernels.hip", "kd_median_tree.h", "smhip_device.h", "host_cloud.cc", "prep_normals.h", "ndt_kernels.hip", "smhip_ndt_api.hip",
+HIP_DEPS = ["icp_kernels.hip", "icp_one.hip", "nabo_kernels.hip", "kd_median_tree.h", "smhip_device.h", "host_cloud.cc", "prep_normals.h", "ndt_kernels.hip", "smhip_ndt_api.hip",
             "gicp_kernels.hip", "smhip_gicp_api.hip", "smhip_filter_api.hip", "cloud_filters.h",
             os.path.join("..", "..", "include", "smhip.h")]
 

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void reset_scratch(IcpDev b, int first, int np
   for (size_t k = tid; k < (size_t)kHistBins * npairs; k += nth) hh[k] = 0;
   for (size_t k = tid; k < (size_t)kSearchHist * npairs; k += nth) b.search_hist[(size_t)kSearchHist * first + k] = 0;
   if (tid == 0) *b.done_count = 0;
+  for (size_t k = tid; k < (size_t)kOneSyncWords; k += nth) b.one_sync[k] = 0;
 }
 
 // The per-Align part of grid_setup alone (pose chain, loop state), for a pair whose target -- and with it the mean, the
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(256) void reset_scratch_light(IcpDev b, int first, 
   for (size_t k = tid; k < (size_t)kHistBins * npairs; k += nth) hh[k] = 0;
   for (size_t k = tid; k < (size_t)kSearchHist * npairs; k += nth) b.search_hist[(size_t)kSearchHist * first + k] = 0;
   if (tid == 0) *b.done_count = 0;
+  for (size_t k = tid; k < (size_t)kOneSyncWords; k += nth) b.one_sync[k] = 0;
 }
 
 __global__ void grid_setup(IcpDev b, int npairs) {
@@ -946,32 +948,23 @@ __device__ __forceinline__ void sweep_run(const float4* __restrict__ tq, uint32_
 #endif
 // FIRST = the launch of iteration 0 (the host knows): no previous match, no certificate, one radius for every query -- the loads,
 // the gather of the previous match and the certificate arithmetic drop out at compile time.
-template <int ITEMS, bool FIRST = false>
-__global__ __launch_bounds__(kNnThreads, 5) void nn_ball_lds(IcpDev b, int nblk) {
-  int pair, blk;
-  if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
-  PairState* st = &b.state[pair];
-  if (st->done) return;
-  const int ns = st->ns;
-  const int base0 = blk * (kNnThreads * ITEMS);
-  if (base0 >= ns) return;
-  // The two transforms are read HERE, before the kernel's first store: the compiler then knows nothing has clobbered them,
-  // loads them through the scalar cache into SGPRs once, and the rounds below transform from registers.  Read inside the
-  // loop (behind the rounds' global stores) each lane fetched the same 2 x 96 bytes with six 16-byte vector loads per
-  // transform and round.
-  double Mc[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) Mc[k] = st->M[k];
+// The rounds of one workgroup: ITEMS rounds of 256 queries from source index base0 on.  `st` is the pair's state in global memory
+// (the counters the rounds add to); `ls` is where the rounds READ the pair's pose-dependent state from -- the same object for the
+// kernel below, the workgroup's own LDS copy for the single-pair persistent kernel (icp_one.hip), whose iterations never
+// write the state back between rounds.  Mc = ls->M, already in registers.  Distances go to s_hist (the caller zeroes and flushes it).
+template <int ITEMS, bool FIRST>
+__device__ __forceinline__ void ball_lds_rounds(const IcpDev& b, PairState* st, const PairState* ls, int pair, int base0, const double* Mc,
+                                                uint32_t* s_hist, uint32_t& min_lb) {
+  const int ns = ls->ns;
   // the pair's motion potential (PairState::pot_a / pot_b) and the last iteration's step norms: how far a query can have moved
   // since its bound was recorded / in this iteration, from |s| alone -- no second transform
-  const Pot pot = {(float)st->pot_a, (float)st->pot_b, (float)st->step_a, (float)st->step_b};
+  const Pot pot = {(float)ls->pot_a, (float)ls->pot_b, (float)ls->step_a, (float)ls->step_b};
   const float Mtx = (float)Mc[3], Mty = (float)Mc[7], Mtz = (float)Mc[11];
 #if SMHIP_PHASE_TIMING
   const bool timing = (b.debug_flags & 16) != 0;
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = timing ? __builtin_readcyclecounter() : 0ull;
 #endif
-  __shared__ uint32_t s_hist[kHistBins];
   __shared__ uint32_t s_tab[kLdsTableCap];
   __shared__ float4 s_pts[kLdsPointCap];
   __shared__ uint32_t s_roff[kLdsRowCap + 1];
@@ -982,7 +975,6 @@ __global__ __launch_bounds__(kNnThreads, 5) void nn_ball_lds(IcpDev b, int nblk)
   __shared__ uint32_t s_nsearch[2];
   __shared__ uint32_t s_w[17];
   __shared__ int s_box[2][6];
-  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
   if (threadIdx.x < 6) { s_box[0][threadIdx.x] = threadIdx.x < 3 ? 0x3fffffff : -0x3fffffff; s_box[1][threadIdx.x] = s_box[0][threadIdx.x]; }
   if (threadIdx.x < 2) s_nsearch[threadIdx.x] = 0;
   __syncthreads();
@@ -991,14 +983,13 @@ __global__ __launch_bounds__(kNnThreads, 5) void nn_ball_lds(IcpDev b, int nblk)
   const uint2* __restrict__ words = b.words + (size_t)pair * kMaxGridWords;
   const uint32_t* __restrict__ cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
   const float4* __restrict__ tq = b.tq + (size_t)pair * b.nt_cap;
-  const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
-  const float h = st->h, inv_h = st->inv_h;
-  const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx, nw = st->nw;
-  const float r2cap = st->rcap2;
+  const float ox = ls->origin[0], oy = ls->origin[1], oz = ls->origin[2];
+  const float h = ls->h, inv_h = ls->inv_h;
+  const int nx = ls->nx, ny = ls->ny, nz = ls->nz, wx = ls->wx, nw = ls->nw;
+  const float r2cap = ls->rcap2;
   const float r_need = 0.9f * sqrtf(r2cap);
-  const bool have_prev = !FIRST && st->iter > 0;
+  const bool have_prev = !FIRST && ls->iter > 0;
   const bool certify = have_prev && b.certify;
-  uint32_t min_lb = 0xffffffffu;
 
   // level 1 of round 0
   int i = base0 + threadIdx.x;
@@ -1137,7 +1128,7 @@ __global__ __launch_bounds__(kNnThreads, 5) void nn_ball_lds(IcpDev b, int nblk)
         const int zz = (int)(((float)r + 0.5f) * inv_nyl);
         const int y = Y0 + (r - zz * nyl), z = Z0 + zz;
         const int widx = (z * ny + y) * wx + (x >> 5);
-        uint32_t val = (uint32_t)st->nt;
+        uint32_t val = (uint32_t)ls->nt;
         if (widx < nw) {
           const uint2 wd = words[widx];
           val = cstart[wd.y + __popc(wd.x & ((1u << (x & 31)) - 1u))];
@@ -1259,23 +1250,47 @@ __global__ __launch_bounds__(kNnThreads, 5) void nn_ball_lds(IcpDev b, int nblk)
     s_cur = s_next; jp_cur = jp_next; l_cur = l_next;
     SMHIP_PHASE(6);      // stores + hard list
   }
-  // statistics: queries searched by this block are counted through deferred_count
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) min_lb = min(min_lb, (uint32_t)__shfl_xor((int)min_lb, off, 64));
-  if (lane == 0 && min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
-  __syncthreads();
-  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
-  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
-    const uint32_t v = s_hist[k];
-    if (v) atomicAdd(&gh[k], v);
-  }
-  SMHIP_PHASE(7);        // epilogue: histogram flush
 #if SMHIP_PHASE_TIMING
   if (timing && lane == 0) {
     unsigned long long* tc = reinterpret_cast<unsigned long long*>(b.tpart);
     for (int k = 0; k < 8; ++k) atomicAdd(&tc[k], tacc[k]);
   }
 #endif
+}
+
+// the smallest lower bound a workgroup recorded -> PairState::min_lb_key; its histogram -> the pair's
+__device__ __forceinline__ void flush_min_lb_and_hist(const IcpDev& b, PairState* st, int pair, uint32_t min_lb, const uint32_t* s_hist) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) min_lb = min(min_lb, (uint32_t)__shfl_xor((int)min_lb, off, 64));
+  if ((threadIdx.x & 63) == 0 && min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
+  __syncthreads();
+  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
+    const uint32_t v = s_hist[k];
+    if (v) atomicAdd(&gh[k], v);
+  }
+}
+
+template <int ITEMS, bool FIRST = false>
+__global__ __launch_bounds__(kNnThreads, 5) void nn_ball_lds(IcpDev b, int nblk) {
+  int pair, blk;
+  if (!xcd_block(nblk, b.npairs, b.pair_base, pair, blk)) return;
+  PairState* st = &b.state[pair];
+  if (st->done) return;
+  const int base0 = blk * (kNnThreads * ITEMS);
+  if (base0 >= st->ns) return;
+  // The transform is read HERE, before the kernel's first store: the compiler then knows nothing has clobbered it,
+  // loads it through the scalar cache into SGPRs once, and the rounds below transform from registers.  Read inside the
+  // loop (behind the rounds' global stores) each lane fetched the same 96 bytes with six 16-byte vector loads per round.
+  double Mc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Mc[k] = st->M[k];
+  __shared__ uint32_t s_hist[kHistBins];
+  for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;   // (visible to the rounds after their first barrier)
+  uint32_t min_lb = 0xffffffffu;
+  ball_lds_rounds<ITEMS, FIRST>(b, st, st, pair, base0, Mc, s_hist, min_lb);
+  // statistics: queries searched by this block are counted through deferred_count
+  flush_min_lb_and_hist(b, st, pair, min_lb, s_hist);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1587,6 +1602,47 @@ __device__ __forceinline__ bool ring_irrelevant(const IcpDev& b, float g, float 
   return b.nn_cutoff2 > 0.f && g * g >= b.nn_cutoff2 && best_d2 >= b.nn_cutoff2;
 }
 
+// One query's exact ring search: rings r = 1, 2, 4, ... <= max_ring of cells around the query's cell, cells covered by an earlier
+// ring skipped.  Returns false when the rings end without a guarantee (the brute-force fallback's case).  `st`: where the grid
+// geometry is read from (the pair's state, or a workgroup's LDS copy of it).
+__device__ __forceinline__ bool ring_search_query(const IcpDev& b, const PairState* st, int pair, float qx, float qy, float qz, Best& best) {
+  bool resolved = true;
+  if (isfinite(qx) && isfinite(qy) && isfinite(qz)) {
+    const uint2* words = b.words + (size_t)pair * kMaxGridWords;
+    const uint32_t* cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
+    const float4* tq = b.tq + (size_t)pair * b.nt_cap;
+    const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
+    const float inv_h = st->inv_h;
+    const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
+    const int cx = cell_coord(qx, ox, inv_h), cy = cell_coord(qy, oy, inv_h), cz = cell_coord(qz, oz, inv_h);
+    int rp = 0;           // radius already covered
+    resolved = false;
+    for (int r = 1; r <= b.max_ring; r *= 2) {
+      const int x0 = max(cx - r, 0), x1 = min(cx + r, nx - 1);
+      const int y0 = max(cy - r, 0), y1 = min(cy + r, ny - 1);
+      const int z0 = max(cz - r, 0), z1 = min(cz + r, nz - 1);
+      if (x0 <= x1 && y0 <= y1 && z0 <= z1) {
+        for (int z = z0; z <= z1; ++z)
+          for (int y = y0; y <= y1; ++y) {
+            const int rowbase = (z * ny + y) * wx;
+            const bool inner = rp > 0 && abs(y - cy) <= rp && abs(z - cz) <= rp;
+            if (!inner) {
+              search_row(words, cstart, tq, rowbase, x0, x1, qx, qy, qz, best);
+            } else {
+              const int xl1 = min(cx - rp - 1, nx - 1), xr0 = max(cx + rp + 1, 0);
+              if (x0 <= xl1) search_row(words, cstart, tq, rowbase, x0, xl1, qx, qy, qz, best);
+              if (xr0 <= x1) search_row(words, cstart, tq, rowbase, xr0, x1, qx, qy, qz, best);
+            }
+          }
+      }
+      const float g = block_guarantee(st, qx, qy, qz, cx - r, cx + r, cy - r, cy + r, cz - r, cz + r);
+      if (g == INFINITY || (g > 0.f && (best.d2 <= g * g || ring_irrelevant(b, g, best.d2)))) { resolved = true; break; }
+      rp = r;
+    }
+  }
+  return resolved;
+}
+
 // Phase B -- exact per-query ring search.  HARD = true: refinement of the lower-bounded queries of
 // nn_ball, run only when nn_validate found that the quantile may reach one of the bounds (or when
 // every match must be exact); HARD = false: over every source point (nn_ball skipped).
@@ -1612,40 +1668,7 @@ __device__ __forceinline__ void ring_body(const IcpDev& b, PairState* st, int pa
     transform_point(st->M, ld_src(b, so + i), px, py, pz);
     const float qx = (float)px, qy = (float)py, qz = (float)pz;
     Best best = {INFINITY, -1, INFINITY};
-    bool resolved = true;
-    if (isfinite(qx) && isfinite(qy) && isfinite(qz)) {
-      const uint2* words = b.words + (size_t)pair * kMaxGridWords;
-      const uint32_t* cstart = b.cstart + (size_t)pair * (b.nt_cap + 1);
-      const float4* tq = b.tq + (size_t)pair * b.nt_cap;
-      const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
-      const float inv_h = st->inv_h;
-      const int nx = st->nx, ny = st->ny, nz = st->nz, wx = st->wx;
-      const int cx = cell_coord(qx, ox, inv_h), cy = cell_coord(qy, oy, inv_h), cz = cell_coord(qz, oz, inv_h);
-      int rp = 0;           // radius already covered
-      resolved = false;
-      for (int r = 1; r <= b.max_ring; r *= 2) {
-        const int x0 = max(cx - r, 0), x1 = min(cx + r, nx - 1);
-        const int y0 = max(cy - r, 0), y1 = min(cy + r, ny - 1);
-        const int z0 = max(cz - r, 0), z1 = min(cz + r, nz - 1);
-        if (x0 <= x1 && y0 <= y1 && z0 <= z1) {
-          for (int z = z0; z <= z1; ++z)
-            for (int y = y0; y <= y1; ++y) {
-              const int rowbase = (z * ny + y) * wx;
-              const bool inner = rp > 0 && abs(y - cy) <= rp && abs(z - cz) <= rp;
-              if (!inner) {
-                search_row(words, cstart, tq, rowbase, x0, x1, qx, qy, qz, best);
-              } else {
-                const int xl1 = min(cx - rp - 1, nx - 1), xr0 = max(cx + rp + 1, 0);
-                if (x0 <= xl1) search_row(words, cstart, tq, rowbase, x0, xl1, qx, qy, qz, best);
-                if (xr0 <= x1) search_row(words, cstart, tq, rowbase, xr0, x1, qx, qy, qz, best);
-              }
-            }
-        }
-        const float g = block_guarantee(st, qx, qy, qz, cx - r, cx + r, cy - r, cy + r, cz - r, cz + r);
-        if (g == INFINITY || (g > 0.f && (best.d2 <= g * g || ring_irrelevant(b, g, best.d2)))) { resolved = true; break; }
-        rp = r;
-      }
-    }
+    const bool resolved = ring_search_query(b, st, pair, qx, qy, qz, best);
     b.d2[so + i] = best.d2;
     st_match(b, so + i, best.j, 0.f);      // exact match, but no runner-up information: searched again next time
     if (resolved) {
@@ -2043,12 +2066,14 @@ __device__ __forceinline__ int quantile_rank(uint32_t n_valid, float rho) {
 // Finds the level-1 histogram bin holding the rank-k element.  All threads of a 256-thread block
 // call it; results land in shared memory: s_out[0] = bin, s_out[1] = #elements below the bin,
 // s_out[2] = n_valid, s_out[3] = k.
-__device__ __forceinline__ void find_quantile_bin(const uint32_t* __restrict__ gh, float rho, uint32_t* s_w, uint32_t* s_out) {
+// Finds the level-1 histogram bin holding the rank-k element, from the counts of the eight bins each thread owns.  All threads of a
+// 256-thread block call it; results land in shared memory: s_out[0] = bin, s_out[1] = #elements below the bin, s_out[2] = n_valid,
+// s_out[3] = k.
+__device__ __forceinline__ void find_quantile_bin_counts(const uint32_t* c, float rho, uint32_t* s_w, uint32_t* s_out) {
   constexpr int per = kHistBins / 256;
-  uint32_t c[per];
   uint32_t sum = 0;
 #pragma unroll
-  for (int k = 0; k < per; ++k) { c[k] = gh[threadIdx.x * per + k]; sum += c[k]; }
+  for (int k = 0; k < per; ++k) sum += c[k];
   uint32_t total;
   const uint32_t excl = block_excl_scan(sum, s_w, &total);
   if (threadIdx.x == 0) { s_out[0] = 0xffffffffu; s_out[1] = 0; s_out[2] = total; s_out[3] = 0; }
@@ -2065,6 +2090,13 @@ __device__ __forceinline__ void find_quantile_bin(const uint32_t* __restrict__ g
     }
   }
   __syncthreads();
+}
+__device__ __forceinline__ void find_quantile_bin(const uint32_t* __restrict__ gh, float rho, uint32_t* s_w, uint32_t* s_out) {
+  constexpr int per = kHistBins / 256;
+  uint32_t c[per];
+#pragma unroll
+  for (int k = 0; k < per; ++k) c[k] = gh[threadIdx.x * per + k];
+  find_quantile_bin_counts(c, rho, s_w, s_out);
 }
 
 // One block per pair, between nn_ball and the refinement kernels: does the quantile stay below
@@ -3181,6 +3213,175 @@ __device__ double quat_angular_distance(const double* a, const double* c) {
   return 2.0 * atan2(sqrt(x * x + y * y + z * z), fabs(w));
 }
 
+// The serial end of an iteration, on ONE thread: the iteration's counters folded into the totals, the next search radius and
+// quantile band, the 6x6 solve, the pose update with its motion potential, CheckConvergence and -- when the loop ends -- the result
+// (icp_fast.cc:204-254, 306-323, 377-405, 506-528).  `st` is the state it reads and writes: the pair's in global memory for the
+// `finalize` kernel; a workgroup's own LDS copy in the single-pair persistent kernel (icp_one.hip), where every workgroup runs
+// this same tail on the same sums and only one of them (`publish`) touches what lies outside the state.  Returns the number of
+// queries whose certificate failed in this iteration.
+// (B: IcpDev, or TailOpts -- the handful of its fields the tail reads -- where the tail is a call, not inlined: icp_one.hip)
+struct TailOpts {
+  float cap_factor, ball_radius, band_gain, band_pad;
+  int32_t fused, early_exit, max_iteration;
+  uint32_t* search_hist;
+  uint32_t* done_count;
+};
+template <class B>
+__device__ __forceinline__ uint32_t finalize_tail(const B& b, PairState* st, int pair, const double* s_tot, uint32_t n_valid, uint32_t limit_key,
+                                                  bool fusedm, int ns, bool publish) {
+  st->fallback_total += st->unresolved_count;
+  st->unresolved_count = 0;
+  st->hard_total += st->hard_count;
+  st->hard_count = 0;
+  {
+    const uint32_t walked = st->nabo_count[0] + st->nabo_count[1] + st->nabo_count[2] + st->nabo_count[3];   // SMHIP_NN_NABO's lists
+    // (iteration 0 searches every query in every mode, whatever part of it went through a list)
+    const uint32_t searched = st->iter == 0 ? (uint32_t)ns : (walked ? walked : (st->deferred_count ? st->deferred_count : (uint32_t)ns));
+    st->searched_total += searched;
+    if (publish && st->iter < kSearchHist) b.search_hist[(size_t)pair * kSearchHist + st->iter] = searched;
+    for (int c = 0; c < 4; ++c) st->nabo_count[c] = 0;
+  }
+  const uint32_t n_listed = st->deferred_count;          // queries whose certificate failed in this iteration
+  st->deferred_count = 0;
+  st->min_lb_key = 0xffffffffu;
+  st->refine = 0;
+  {   // next search radius: cap_factor x the quantile distance, clamped to [0.05 m, ball_radius]
+    const float lim = sqrtf(__uint_as_float(limit_key));
+    float rc = fminf(fmaxf(b.cap_factor * lim, 0.05f), b.ball_radius);
+    if (!(n_valid > 0)) rc = b.ball_radius;
+    st->rcap2 = rc * rc;
+  }
+  {   // fused path: the band of histogram bins the NEXT iteration's quantile is expected in -- this quantile +- max(band_pad bins,
+      // band_gain x its last move).  No previous quantile, a quantile in bin 0 or a band of more than three bins: no prediction
+      // (the certificate pass then only certifies and `accumulate` sums).
+    const uint32_t prev = st->limit_key;
+    int lo = 0, hi = -1;
+    if (n_valid > 0 && prev != 0u && limit_key != 0u) {
+      const double x = (double)limit_key;
+      const double w = fmax((double)b.band_gain * fabs(x - (double)prev), (double)b.band_pad * 1048576.0);
+      const double l = x - w, u = x + w;
+      if (l >= 1048576.0 && u < 2139095040.0) { lo = (int)((uint32_t)l >> kHistShift); hi = (int)((uint32_t)u >> kHistShift); }
+      if (hi - lo > 2) { lo = 0; hi = -1; }
+      // many certificates still fail (the pose still moves): the next iteration will list as many, which finalize would have to
+      // walk -- no prediction, the certificate pass only certifies and `accumulate` sums
+      if (b.fused && n_listed > (uint32_t)kFusedListedMax) { lo = 0; hi = -1; }
+    }
+    st->band_lo = lo; st->band_hi = hi;
+    if (fusedm) st->spec_hits += 1;
+    st->spec_ok = 0;
+  }
+  st->limit_key = limit_key;
+  const double kept = s_tot[28];
+  st->kept = (int)kept;
+  if (n_valid == 0 || kept < 1.0) {       // icp_fast.cc:81 CHECK(!values.empty()) / :113 "no point to minimize"
+    st->status = 6;                        // SMHIP_ERR_NO_MATCH
+    st->done = 1;
+    for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) st->result[4 * c + r] = st->guess[4 * r + c];
+    st->score = 0;
+    if (publish) atomicAdd(b.done_count, 1u);
+    return n_listed;
+  }
+  double A[36], rhs[6], x[6];
+  {
+    int c = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int e = a; e < 6; ++e) { A[6 * a + e] = s_tot[c]; A[6 * e + a] = s_tot[c]; ++c; }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) rhs[a] = -s_tot[21 + a];                       // b = -(wF * dot), :302
+  }
+  solve6(A, rhs, x);                                                          // :304
+  // transform = AngleAxis(|x[0:3]|, x[0:3] / |x[0:3]|), translation = x[3:6]    :306-312
+  double dT[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  {
+    const double ang = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    const double ax = x[0] / ang, ay = x[1] / ang, az = x[2] / ang;
+    const double c = cos(ang), s = sin(ang), v = 1.0 - c;
+    double R[9] = {c + v * ax * ax, v * ax * ay - s * az, v * ax * az + s * ay,
+                   v * ax * ay + s * az, c + v * ay * ay, v * ay * az - s * ax,
+                   v * ax * az - s * ay, v * ay * az + s * ax, c + v * az * az};
+    bool has_nan = false;
+    for (int i = 0; i < 9; ++i) has_nan |= isnan(R[i]);
+    for (int i = 0; i < 3; ++i) has_nan |= isnan(x[3 + i]);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) dT[4 * i + j] = has_nan ? ((i == j) ? 1.0 : 0.0) : R[3 * i + j];   // :315-321
+    dT[3] = x[3]; dT[7] = x[4]; dT[11] = x[5];
+  }
+  double Tn[16];
+  mat4_mul_rm(dT, st->T_iter, Tn);                                            // :506-510
+  for (int i = 0; i < 16; ++i) st->T_iter[i] = Tn[i];
+  double Mn[16];
+  mat4_mul_rm(Tn, st->G, Mn);
+  {   // motion potential: this step's ||dR|| and |dt| (what bounds |M_new s - M_old s| <= ||dR|| |s| + |dt|), and their running sums.
+      // ||dR|| is the SPECTRAL norm of the 3x3 difference (the largest singular value: what |dR s| <= ||dR|| |s| needs), from the
+      // closed-form largest eigenvalue of dR^T dR with 1e-6 of slack and never more than the Frobenius norm; for the difference of
+      // two rotations the Frobenius norm is sqrt(2) times larger, and with it sqrt(2) times the certified motion of far points.
+    double D[9], fa = 0, fb = 0;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) { D[3 * r + c] = Mn[4 * r + c] - st->M[4 * r + c]; fa += D[3 * r + c] * D[3 * r + c]; }
+      const double d = Mn[4 * r + 3] - st->M[4 * r + 3];
+      fb += d * d;
+    }
+    double S[6];                                           // D^T D: xx xy xz yy yz zz
+    S[0] = D[0] * D[0] + D[3] * D[3] + D[6] * D[6]; S[1] = D[0] * D[1] + D[3] * D[4] + D[6] * D[7]; S[2] = D[0] * D[2] + D[3] * D[5] + D[6] * D[8];
+    S[3] = D[1] * D[1] + D[4] * D[4] + D[7] * D[7]; S[4] = D[1] * D[2] + D[4] * D[5] + D[7] * D[8]; S[5] = D[2] * D[2] + D[5] * D[5] + D[8] * D[8];
+    double lam = fa;                                       // trace = squared Frobenius norm >= the largest eigenvalue
+    {
+      const double q = (S[0] + S[3] + S[5]) / 3.0;
+      const double p1 = S[1] * S[1] + S[2] * S[2] + S[4] * S[4];
+      const double p2 = (S[0] - q) * (S[0] - q) + (S[3] - q) * (S[3] - q) + (S[5] - q) * (S[5] - q) + 2.0 * p1;
+      if (p2 > 0.0 && isfinite(p2)) {
+        const double p = sqrt(p2 / 6.0), ip = 1.0 / p;
+        const double b0 = (S[0] - q) * ip, b3 = (S[3] - q) * ip, b5 = (S[5] - q) * ip, b1 = S[1] * ip, b2 = S[2] * ip, b4 = S[4] * ip;
+        double r = 0.5 * (b0 * (b3 * b5 - b4 * b4) - b1 * (b1 * b5 - b4 * b2) + b2 * (b1 * b4 - b3 * b2));
+        r = fmin(1.0, fmax(-1.0, r));
+        const double est = (q + 2.0 * p * cos(acos(r) / 3.0)) * (1.0 + 2e-6) + 1e-300;
+        if (isfinite(est) && est > 0.0) lam = fmin(lam, est);
+      } else if (p2 == 0.0) {
+        lam = fmin(lam, q * (1.0 + 2e-6));
+      }
+    }
+    st->step_a = sqrt(lam) * (1.0 + 1e-9); st->step_b = sqrt(fb) * (1.0 + 1e-9);
+    st->pot_a += st->step_a; st->pot_b += st->step_b;
+  }
+  for (int i = 0; i < 12; ++i) { st->M_prev[i] = st->M[i]; st->M[i] = Mn[i]; }
+  const int it = ++st->iter;                                                  // :513
+  // history ring (latest at n_hist-1, at most 5 kept)
+  int nh = st->n_hist;
+  if (nh == 5) {
+    for (int k = 0; k < 4; ++k) {
+      for (int c = 0; c < 4; ++c) st->quat[k][c] = st->quat[k + 1][c];
+      for (int c = 0; c < 3; ++c) st->trans[k][c] = st->trans[k + 1][c];
+    }
+    nh = 4;
+  }
+  quat_from_rot(Tn, st->quat[nh]);
+  st->trans[nh][0] = Tn[3]; st->trans[nh][1] = Tn[7]; st->trans[nh][2] = Tn[11];
+  st->n_hist = ++nh;
+  bool converged = false;
+  if (b.early_exit && nh > 4) {                                               // :377-405 (kSmoothLength = 4)
+    double rd = 0, td = 0;
+    for (int k = nh - 1; k >= nh - 4; --k) {
+      rd += fabs(quat_angular_distance(st->quat[k], st->quat[k - 1]));
+      const double dx = st->trans[k][0] - st->trans[k - 1][0], dy = st->trans[k][1] - st->trans[k - 1][1], dz = st->trans[k][2] - st->trans[k - 1][2];
+      td += sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    converged = (rd / 4 < 1e-3) && (td / 4 < 1e-2);
+  }
+  if (converged || it >= b.max_iteration) {                                   // :516-522
+    // (the score of this iteration's kept matches, :518-521, is formed by final_score once the batch has left its loop)
+    // result = T_mean * T_iter * T_mean^-1 * guess  (:527), written column-major
+    double Tm[16] = {1, 0, 0, st->mu[0], 0, 1, 0, st->mu[1], 0, 0, 1, st->mu[2], 0, 0, 0, 1};
+    double Rm[16];
+    mat4_mul_rm(Tm, Mn, Rm);
+    for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) st->result[4 * c + r] = Rm[4 * r + c];
+    st->done = 1;
+    if (publish) atomicAdd(b.done_count, 1u);
+  }
+  return n_listed;
+}
+
 __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   const int pair = b.pair_base + blockIdx.x;
   PairState* st = &b.state[pair];
@@ -3442,156 +3643,8 @@ __global__ __launch_bounds__(256) void finalize(IcpDev b) {
   __syncthreads();
   if (threadIdx.x != 0) return;
   SMHIP_FPH();
-  st->fallback_total += st->unresolved_count;
-  st->unresolved_count = 0;
-  st->hard_total += st->hard_count;
-  st->hard_count = 0;
-  {
-    const uint32_t walked = st->nabo_count[0] + st->nabo_count[1] + st->nabo_count[2] + st->nabo_count[3];   // SMHIP_NN_NABO's lists
-    // (iteration 0 searches every query in every mode, whatever part of it went through a list)
-    const uint32_t searched = st->iter == 0 ? (uint32_t)ns : (walked ? walked : (st->deferred_count ? st->deferred_count : (uint32_t)ns));
-    st->searched_total += searched;
-    if (st->iter < kSearchHist) b.search_hist[(size_t)pair * kSearchHist + st->iter] = searched;
-    for (int c = 0; c < 4; ++c) st->nabo_count[c] = 0;
-  }
-  const uint32_t n_listed = st->deferred_count;          // queries whose certificate failed in this iteration
-  st->deferred_count = 0;
-  st->min_lb_key = 0xffffffffu;
-  st->refine = 0;
-  {   // next search radius: cap_factor x the quantile distance, clamped to [0.05 m, ball_radius]
-    const float lim = sqrtf(__uint_as_float(limit_key));
-    float rc = fminf(fmaxf(b.cap_factor * lim, 0.05f), b.ball_radius);
-    if (!(n_valid > 0)) rc = b.ball_radius;
-    st->rcap2 = rc * rc;
-  }
-  {   // fused path: the band of histogram bins the NEXT iteration's quantile is expected in -- this quantile +- max(band_pad bins,
-      // band_gain x its last move).  No previous quantile, a quantile in bin 0 or a band of more than three bins: no prediction
-      // (the certificate pass then only certifies and `accumulate` sums).
-    const uint32_t prev = st->limit_key;
-    int lo = 0, hi = -1;
-    if (n_valid > 0 && prev != 0u && limit_key != 0u) {
-      const double x = (double)limit_key;
-      const double w = fmax((double)b.band_gain * fabs(x - (double)prev), (double)b.band_pad * 1048576.0);
-      const double l = x - w, u = x + w;
-      if (l >= 1048576.0 && u < 2139095040.0) { lo = (int)((uint32_t)l >> kHistShift); hi = (int)((uint32_t)u >> kHistShift); }
-      if (hi - lo > 2) { lo = 0; hi = -1; }
-      // many certificates still fail (the pose still moves): the next iteration will list as many, which finalize would have to
-      // walk -- no prediction, the certificate pass only certifies and `accumulate` sums
-      if (b.fused && n_listed > (uint32_t)kFusedListedMax) { lo = 0; hi = -1; }
-    }
-    st->band_lo = lo; st->band_hi = hi;
-    if (fusedm) st->spec_hits += 1;
-    st->spec_ok = 0;
-  }
-  st->limit_key = limit_key;
-  const double kept = s_tot[28];
-  st->kept = (int)kept;
-  if (n_valid == 0 || kept < 1.0) {       // icp_fast.cc:81 CHECK(!values.empty()) / :113 "no point to minimize"
-    st->status = 6;                        // SMHIP_ERR_NO_MATCH
-    st->done = 1;
-    for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) st->result[4 * c + r] = st->guess[4 * r + c];
-    st->score = 0;
-    atomicAdd(b.done_count, 1u);
-    return;
-  }
-  double A[36], rhs[6], x[6];
-  {
-    int c = 0;
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int e = a; e < 6; ++e) { A[6 * a + e] = s_tot[c]; A[6 * e + a] = s_tot[c]; ++c; }
-#pragma unroll
-    for (int a = 0; a < 6; ++a) rhs[a] = -s_tot[21 + a];                       // b = -(wF * dot), :302
-  }
-  solve6(A, rhs, x);                                                          // :304
-  // transform = AngleAxis(|x[0:3]|, x[0:3] / |x[0:3]|), translation = x[3:6]    :306-312
-  double dT[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-  {
-    const double ang = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-    const double ax = x[0] / ang, ay = x[1] / ang, az = x[2] / ang;
-    const double c = cos(ang), s = sin(ang), v = 1.0 - c;
-    double R[9] = {c + v * ax * ax, v * ax * ay - s * az, v * ax * az + s * ay,
-                   v * ax * ay + s * az, c + v * ay * ay, v * ay * az - s * ax,
-                   v * ax * az - s * ay, v * ay * az + s * ax, c + v * az * az};
-    bool has_nan = false;
-    for (int i = 0; i < 9; ++i) has_nan |= isnan(R[i]);
-    for (int i = 0; i < 3; ++i) has_nan |= isnan(x[3 + i]);
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) dT[4 * i + j] = has_nan ? ((i == j) ? 1.0 : 0.0) : R[3 * i + j];   // :315-321
-    dT[3] = x[3]; dT[7] = x[4]; dT[11] = x[5];
-  }
-  double Tn[16];
-  mat4_mul_rm(dT, st->T_iter, Tn);                                            // :506-510
-  for (int i = 0; i < 16; ++i) st->T_iter[i] = Tn[i];
-  double Mn[16];
-  mat4_mul_rm(Tn, st->G, Mn);
-  {   // motion potential: this step's ||dR|| and |dt| (what bounds |M_new s - M_old s| <= ||dR|| |s| + |dt|), and their running sums.
-      // ||dR|| is the SPECTRAL norm of the 3x3 difference (the largest singular value: what |dR s| <= ||dR|| |s| needs), from the
-      // closed-form largest eigenvalue of dR^T dR with 1e-6 of slack and never more than the Frobenius norm; for the difference of
-      // two rotations the Frobenius norm is sqrt(2) times larger, and with it sqrt(2) times the certified motion of far points.
-    double D[9], fa = 0, fb = 0;
-    for (int r = 0; r < 3; ++r) {
-      for (int c = 0; c < 3; ++c) { D[3 * r + c] = Mn[4 * r + c] - st->M[4 * r + c]; fa += D[3 * r + c] * D[3 * r + c]; }
-      const double d = Mn[4 * r + 3] - st->M[4 * r + 3];
-      fb += d * d;
-    }
-    double S[6];                                           // D^T D: xx xy xz yy yz zz
-    S[0] = D[0] * D[0] + D[3] * D[3] + D[6] * D[6]; S[1] = D[0] * D[1] + D[3] * D[4] + D[6] * D[7]; S[2] = D[0] * D[2] + D[3] * D[5] + D[6] * D[8];
-    S[3] = D[1] * D[1] + D[4] * D[4] + D[7] * D[7]; S[4] = D[1] * D[2] + D[4] * D[5] + D[7] * D[8]; S[5] = D[2] * D[2] + D[5] * D[5] + D[8] * D[8];
-    double lam = fa;                                       // trace = squared Frobenius norm >= the largest eigenvalue
-    {
-      const double q = (S[0] + S[3] + S[5]) / 3.0;
-      const double p1 = S[1] * S[1] + S[2] * S[2] + S[4] * S[4];
-      const double p2 = (S[0] - q) * (S[0] - q) + (S[3] - q) * (S[3] - q) + (S[5] - q) * (S[5] - q) + 2.0 * p1;
-      if (p2 > 0.0 && isfinite(p2)) {
-        const double p = sqrt(p2 / 6.0), ip = 1.0 / p;
-        const double b0 = (S[0] - q) * ip, b3 = (S[3] - q) * ip, b5 = (S[5] - q) * ip, b1 = S[1] * ip, b2 = S[2] * ip, b4 = S[4] * ip;
-        double r = 0.5 * (b0 * (b3 * b5 - b4 * b4) - b1 * (b1 * b5 - b4 * b2) + b2 * (b1 * b4 - b3 * b2));
-        r = fmin(1.0, fmax(-1.0, r));
-        const double est = (q + 2.0 * p * cos(acos(r) / 3.0)) * (1.0 + 2e-6) + 1e-300;
-        if (isfinite(est) && est > 0.0) lam = fmin(lam, est);
-      } else if (p2 == 0.0) {
-        lam = fmin(lam, q * (1.0 + 2e-6));
-      }
-    }
-    st->step_a = sqrt(lam) * (1.0 + 1e-9); st->step_b = sqrt(fb) * (1.0 + 1e-9);
-    st->pot_a += st->step_a; st->pot_b += st->step_b;
-  }
-  for (int i = 0; i < 12; ++i) { st->M_prev[i] = st->M[i]; st->M[i] = Mn[i]; }
-  const int it = ++st->iter;                                                  // :513
-  // history ring (latest at n_hist-1, at most 5 kept)
-  int nh = st->n_hist;
-  if (nh == 5) {
-    for (int k = 0; k < 4; ++k) {
-      for (int c = 0; c < 4; ++c) st->quat[k][c] = st->quat[k + 1][c];
-      for (int c = 0; c < 3; ++c) st->trans[k][c] = st->trans[k + 1][c];
-    }
-    nh = 4;
-  }
-  quat_from_rot(Tn, st->quat[nh]);
-  st->trans[nh][0] = Tn[3]; st->trans[nh][1] = Tn[7]; st->trans[nh][2] = Tn[11];
-  st->n_hist = ++nh;
-  bool converged = false;
-  if (b.early_exit && nh > 4) {                                               // :377-405 (kSmoothLength = 4)
-    double rd = 0, td = 0;
-    for (int k = nh - 1; k >= nh - 4; --k) {
-      rd += fabs(quat_angular_distance(st->quat[k], st->quat[k - 1]));
-      const double dx = st->trans[k][0] - st->trans[k - 1][0], dy = st->trans[k][1] - st->trans[k - 1][1], dz = st->trans[k][2] - st->trans[k - 1][2];
-      td += sqrt(dx * dx + dy * dy + dz * dz);
-    }
-    converged = (rd / 4 < 1e-3) && (td / 4 < 1e-2);
-  }
-  if (converged || it >= b.max_iteration) {                                   // :516-522
-    // (the score of this iteration's kept matches, :518-521, is formed by final_score once the batch has left its loop)
-    // result = T_mean * T_iter * T_mean^-1 * guess  (:527), written column-major
-    double Tm[16] = {1, 0, 0, st->mu[0], 0, 1, 0, st->mu[1], 0, 0, 1, st->mu[2], 0, 0, 0, 1};
-    double Rm[16];
-    mat4_mul_rm(Tm, Mn, Rm);
-    for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) st->result[4 * c + r] = Rm[4 * r + c];
-    st->done = 1;
-    atomicAdd(b.done_count, 1u);
-  }
+  const uint32_t n_listed = finalize_tail(b, st, pair, s_tot, n_valid, limit_key, fusedm, ns, true);
+  (void)n_listed;
 #if SMHIP_PHASE_TIMING
   if (ftime && (wall_clock64() - fstamp[0]) > 6000ull) {
     const unsigned long long tend = wall_clock64();

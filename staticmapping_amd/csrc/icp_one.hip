@@ -1,0 +1,475 @@
+// icp_one.hip -- the single-pair IcpFast::Align as ONE cooperative launch.
+//
+// The reference's front end aligns one scan against one key frame at a time (builder/map_builder.cc:317-333; sequential by
+// :302-307, 379-392), so the call that matters there is a single `Align`, and on the device a single Align is latency, not
+// bandwidth: 120 000 source points are 2.4 MB, the target 0.7 MB.  As separate launches an iteration is four of them (search,
+// refinement check, sums, finalize: 37 + 5 + 11 + 28 us, profiles/r05_single_pair_kernel_stats.txt) with one workgroup doing the
+// whole of `finalize`.  Here the whole loop of icp_fast.cc:484-523 is one kernel whose workgroups stay resident (cooperative
+// launch: the grid is sized to what the device holds at once) and meet at grid barriers; everything a workgroup can compute from
+// what all of them published it computes itself instead of waiting for one workgroup to do it and a barrier to hand it round:
+//
+//   S   every workgroup: the rounds of nn_ball_lds it owns (certificate, LDS-staged ball search of the failing queries), its
+//       histogram added to the pair's                                                                    -- barrier 1 --
+//   V   every workgroup: the quantile's bin from the pair's histogram, the check of the lower bounds against it (nn_validate);
+//       in the rare iteration that must refine bounds: every workgroup refines its own queries' (ring search, then a sweep of the
+//       target for what the rings leave open), one more barrier, the bin again
+//   A   every workgroup: the sums of its points below the bin; the keys of its points inside the bin appended to the pair's key
+//       list (ONE returning atomic per workgroup), the points themselves remembered in LDS                -- barrier 2 --
+//   F1  every workgroup: the exact rank inside the bin by radix select over the key list (~2 000 keys: the whole list sits in
+//       LDS) -- the same list in every workgroup, in whatever order it was appended: the selected VALUE does not depend on it --
+//       then its own in-bin points at or below the limit added to its sums; its row of 29 sums published   -- barrier 3 --
+//   F2  every workgroup: the rows folded in a fixed order, the 6x6 solve, the pose update, CheckConvergence (finalize_tail) on
+//       its OWN copy of the pair's state in LDS.  Identical inputs, identical instruction sequence: identical new pose in every
+//       workgroup, no barrier before the next iteration's S.  Workgroup 0 alone writes the state back to global memory.
+//
+// Matches, distances, histogram, quantile and kept set are those of the separate kernels bit for bit (the same bodies:
+// ball_lds_rounds, find_quantile_bin, ring_body, fallback_body, accumulate_terms, finalize_tail); the 29 sums are added in a
+// different -- fixed -- order, so poses agree to ~1e-15 and a run is reproducible bit for bit.
+//
+// Coherence without cache-wide fences.  The eight XCDs' L2s are not coherent with each other, and an agent-scope release /
+// acquire pair is a write-back plus an invalidate of a whole L2 by every wave: as first built -- fences at every barrier -- a
+// barrier of 472 workgroups cost 45-65 us and every load behind it missed (6.8 ms per Align).  Instead every word that crosses
+// workgroups is named: it is written with agent-scope (write-through) stores or atomics and read with agent-scope loads, a wave
+// waits for its own such stores to complete (s_waitcnt) before its workgroup arrives at the barrier, and nothing else is flushed
+// or invalidated.  A workgroup's matches, distances and bounds (written in S, read in A and F1 by the SAME workgroup: one CU,
+// one L1, one L2) and the read-only target stay in the caches.  The rows of sums -- 472 x 232 bytes read by every workgroup --
+// go to a FRESH address range each iteration (IcpDev::one_rows, 16 MiB): a line nobody has read since the kernel began is in no
+// L2, so plain loads are safe and each XCD fetches the rows once for its 59 workgroups (when the range wraps, an acquire fence).
+// The rare refinement of lower bounds is done by the queries' owners for the same reason (the separate launches spread the list
+// of lower-bounded queries over all workgroups, which then write other workgroups' matches).
+// Barrier: one returning arrival per workgroup on a monotonic counter; the last arrival publishes the epoch in a second word, the
+// others spin on that word (not on the counter the arrivals queue on).
+#include <cstddef>
+#include "smhip_device.h"
+
+namespace smhip {
+
+__device__ __forceinline__ uint32_t ld_dev(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// IcpDev::one_sync, in 128-byte lines (32 words): [0] arrivals of the groups' last workgroups, [32] length of the key list,
+// [64 + 32 g] arrivals of group g's workgroups, [320 + 32 g] the last completed epoch as group g polls it.  Group = blockIdx % 8
+// (the dispatcher's XCD round-robin); measured (tools/grid_barrier_probe.hip, 472 workgroups): every arrival on one counter
+// 6.2 us per barrier -- same-address atomics complete one every ~13 ns --, two levels 2.1 us.
+constexpr int kOneGroups = 8;
+__device__ __forceinline__ void one_arrive_and_wait(uint32_t* sync, uint32_t epoch, uint32_t G, bool group_last) {
+  const uint32_t g = blockIdx.x & (kOneGroups - 1);
+  if (group_last) {
+    const uint32_t old = __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == epoch * kOneGroups)
+      for (int k = 0; k < kOneGroups; ++k) st_dev(&sync[320 + 32 * k], epoch);
+  }
+  while (ld_dev(&sync[320 + 32 * g]) < epoch) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void one_grid_sync(uint32_t* sync, uint32_t& epoch, uint32_t G) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // this wave's write-through stores and atomics have completed
+  __syncthreads();
+  ++epoch;
+  if (threadIdx.x == 0) {
+    const uint32_t g = blockIdx.x & (kOneGroups - 1);
+    const uint32_t old = __hip_atomic_fetch_add(&sync[64 + 32 * g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    one_arrive_and_wait(sync, epoch, G, old + 1u == epoch * (G / kOneGroups));
+  }
+  __syncthreads();
+}
+// The barrier behind the rows of sums, with the first level of their fold inside it: the last workgroup of a group to arrive adds
+// the group's rows -- in the order of their workgroups, whoever arrives last -- and publishes the group's row before it arrives
+// for the group.  (Every workgroup reading all 472 rows would pull 57 MB through the fabric per iteration.)
+__device__ __forceinline__ void one_grid_sync_fold(uint32_t* sync, uint32_t& epoch, uint32_t G, const double* rows, double* grows,
+                                                  double (*s_part)[32], uint32_t* s_flag) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  ++epoch;
+  const uint32_t g = blockIdx.x & (kOneGroups - 1);
+  if (threadIdx.x == 0) {
+    const uint32_t old = __hip_atomic_fetch_add(&sync[64 + 32 * g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_flag = old + 1u == epoch * (G / kOneGroups) ? 1u : 0u;
+  }
+  __syncthreads();
+  const bool last = *s_flag != 0u;
+  if (last) {
+    const int col = threadIdx.x & 31, sub = threadIdx.x >> 5;
+    double s = 0;
+#pragma unroll 8
+    for (uint32_t w = g + kOneGroups * sub; w < G; w += kOneGroups * 8)
+      s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(rows + (size_t)w * kAccCols + col), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    s_part[sub][col] = s;
+    __syncthreads();
+    if (threadIdx.x < 29) {
+      double t = 0;
+      for (int k = 0; k < 8; ++k) t += s_part[k][threadIdx.x];
+      st_dev(&grows[(size_t)g * kAccCols + threadIdx.x], t);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) one_arrive_and_wait(sync, epoch, G, last);
+  __syncthreads();
+}
+__device__ __forceinline__ double uniform_f64(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// the serial tail as a CALL: inlined, its few hundred live doubles (the 6x6 factorisation, the pose chain) set the register
+// allocation of the whole kernel -- 256 VGPRs and 89 spilled ones in the loops every thread runs
+__device__ __noinline__ void one_tail(TailOpts o, PairState* ls, int pair, const double* s_tot, uint32_t n_valid, uint32_t limit_key, int ns, bool publish) {
+  (void)finalize_tail(o, ls, pair, s_tot, n_valid, limit_key, false, ns, publish);
+}
+
+#if SMHIP_PHASE_TIMING
+#define SMHIP_OPH(k) do { if (otime) { const unsigned long long now_ = wall_clock64(); oacc[k] += now_ - oprev; oprev = now_; } } while (0)
+#else
+#define SMHIP_OPH(k) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b) {
+  const int pair = b.pair_base;
+  const uint32_t G = gridDim.x;
+  PairState* st = &b.state[pair];
+  __shared__ PairState ls;
+  __shared__ uint32_t s_hist[kHistBins];
+  __shared__ uint32_t s_w[17];
+  __shared__ uint32_t s_q[4];
+  __shared__ uint32_t s_h[1024];
+  __shared__ uint32_t s_sel[2];
+  __shared__ double s_red[4][29];
+  __shared__ double s_tot[29];
+  __shared__ double s_part[8][32];
+  __shared__ uint32_t s_keys[kFinalizeKeyCap];           // the key list (F1); the refinement's target tile (V)
+  __shared__ int s_rec[kNnThreads / 64][64 * kOneMaxRounds];
+  __shared__ uint32_t s_wc[kNnThreads / 64];
+  __shared__ uint32_t s_misc[8];
+  static_assert(sizeof(float4) * kBruteTile <= sizeof(uint32_t) * kFinalizeKeyCap, "the fallback's tile aliases the key list");
+  {
+    const uint32_t* g = reinterpret_cast<const uint32_t*>(st);
+    uint32_t* l = reinterpret_cast<uint32_t*>(&ls);
+    for (int k = threadIdx.x; k < (int)(sizeof(PairState) / 4); k += kNnThreads) l[k] = g[k];
+  }
+  __syncthreads();
+  if (ls.done) return;                                   // (pose_setup: a target without a search structure) -- every workgroup alike
+  const int ns = ls.ns;
+  const int nrounds = (ns + kNnThreads - 1) / kNnThreads;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t so = (size_t)pair * b.ns_cap, to = (size_t)pair * b.nt_cap;
+  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
+  uint32_t* sync = b.one_sync;
+  uint32_t* gkeys = reinterpret_cast<uint32_t*>(b.rec_j + (size_t)pair * 2 * b.bl_stride);
+  double* rows = b.one_rows;                              // [G][kAccCols] the workgroups' rows of sums
+  double* grows = b.one_rows + (size_t)kOneMaxBlocks * kAccCols;   // [kOneGroups][kAccCols] the groups'
+  uint32_t target = 0;
+  // The pair's histogram is never cleared inside the launch: every workgroup remembers the eight words it owns as it last read them
+  // and takes the difference (a store that clears a word other workgroups add to would have to be ordered against their atomics)
+  uint32_t hprev[kHistBins / kNnThreads];
+#pragma unroll
+  for (int k = 0; k < kHistBins / kNnThreads; ++k) hprev[k] = 0u;
+#if SMHIP_PHASE_TIMING
+  const bool otime = (b.debug_flags & 64) && threadIdx.x == 0 && blockIdx.x == 0;
+  unsigned long long oacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long oprev = otime ? wall_clock64() : 0ull;
+#endif
+  for (;;) {
+    // ---------------- S: FindClosests (icp_fast.cc:486-493)
+    double Mc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Mc[k] = uniform_f64(ls.M[k]);
+    for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+    uint32_t min_lb = 0xffffffffu;
+    for (int r = blockIdx.x; r < nrounds; r += (int)G) ball_lds_rounds<1, false>(b, st, &ls, pair, r * kNnThreads, Mc, s_hist, min_lb);
+    flush_min_lb_and_hist(b, st, pair, min_lb, s_hist);
+    SMHIP_OPH(0);
+    one_grid_sync(sync, target, G);
+    SMHIP_OPH(1);
+    // ---------------- V: the quantile's bin; do the lower bounds stand above it?  (nn_validate)
+    uint32_t hraw[kHistBins / kNnThreads], hcnt[kHistBins / kNnThreads];
+#pragma unroll
+    for (int k = 0; k < kHistBins / kNnThreads; ++k) hraw[k] = ld_dev(&gh[threadIdx.x * (kHistBins / kNnThreads) + k]);
+#pragma unroll
+    for (int k = 0; k < kHistBins / kNnThreads; ++k) hcnt[k] = hraw[k] - hprev[k];
+    find_quantile_bin_counts(hcnt, b.rho, s_w, s_q);
+    if (threadIdx.x == 0) {
+      ls.hard_count = ld_dev(&st->hard_count);
+      ls.min_lb_key = ld_dev(&st->min_lb_key);
+      ls.deferred_count = ld_dev(&st->deferred_count);
+      ls.unresolved_count = 0;
+      const bool any = ls.hard_count > 0;
+      const bool below = (ls.min_lb_key >> kHistShift) <= s_q[0];
+      const bool refine = any && (b.exact_all || below || s_q[2] == 0);
+      if (refine) ls.refine_total += 1;
+      s_misc[0] = refine ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_misc[0]) {
+      // The bounds are refined to matches (nn_ring<true> + nn_fallback) by their OWNERS: every workgroup walks the rings for the
+      // lower-bounded queries among its own points (a stored bound < 0 marks them) and sweeps the whole target for those the rings
+      // leave open -- nothing but the histogram and a counter crosses workgroups.  Then one more barrier and the quantile again.
+      for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+      if (threadIdx.x == 0) s_misc[6] = 0;
+      __syncthreads();
+      float4* s_t = reinterpret_cast<float4*>(s_keys);
+      const float4* __restrict__ tq = b.tq + to;
+      const int nt = ls.nt;
+      for (int r = blockIdx.x; r < nrounds; r += (int)G) {
+        const int i = r * kNnThreads + (int)threadIdx.x;
+        const bool hardq = i < ns && b.lb[so + i] < 0.f;
+        bool open = false;
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+        Best best = {INFINITY, -1, INFINITY};
+        if (hardq) {
+          const uint32_t old = __float_as_uint(b.d2[so + i]);           // the bound leaves the histogram
+          if (old < 0x7f800000u) atomicSub(&gh[old >> kHistShift], 1u);
+          double px, py, pz;
+          transform_point(Mc, ld_src(b, so + i), px, py, pz);
+          qx = (float)px; qy = (float)py; qz = (float)pz;
+          open = !ring_search_query(b, &ls, pair, qx, qy, qz, best);
+        }
+        if (__syncthreads_or(open ? 1 : 0)) {                            // workgroup-uniform
+          if (open) best = {INFINITY, -1, INFINITY};
+          for (int base = 0; base < nt; base += kBruteTile) {
+            const int m = min(kBruteTile, nt - base);
+            __syncthreads();
+            for (int k = threadIdx.x; k < m; k += kNnThreads) s_t[k] = tq[base + k];
+            __syncthreads();
+            if (open)
+#pragma unroll 8
+              for (int k = 0; k < m; ++k) test_ascending(s_t[k], base + k, qx, qy, qz, best);
+          }
+          __syncthreads();
+          const unsigned long long om = __ballot(open);
+          if (lane == 0 && om) atomicAdd(&s_misc[6], (uint32_t)__popcll(om));
+        }
+        if (hardq) {
+          b.d2[so + i] = best.d2;
+          st_match(b, so + i, best.j, 0.f);                              // exact match, no runner-up information: searched again next time
+          const uint32_t key = __float_as_uint(best.d2);
+          if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0 && s_misc[6]) atomicAdd(&st->unresolved_count, s_misc[6]);
+      for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
+        const uint32_t v = s_hist[k];
+        if (v) atomicAdd(&gh[k], v);
+      }
+      one_grid_sync(sync, target, G);
+#pragma unroll
+      for (int k = 0; k < kHistBins / kNnThreads; ++k) hraw[k] = ld_dev(&gh[threadIdx.x * (kHistBins / kNnThreads) + k]);
+#pragma unroll
+      for (int k = 0; k < kHistBins / kNnThreads; ++k) hcnt[k] = hraw[k] - hprev[k];
+      find_quantile_bin_counts(hcnt, b.rho, s_w, s_q);
+      if (threadIdx.x == 0) ls.unresolved_count = ld_dev(&st->unresolved_count);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < kHistBins / kNnThreads; ++k) hprev[k] = hraw[k];
+    const uint32_t qbin = s_q[0], below = s_q[1], n_valid = s_q[2], krank = s_q[3];
+    SMHIP_OPH(2);
+    // ---------------- A: ErrorElements + ComputePointToPlane below the bin (icp_fast.cc:100-166, 256-303); the bin's members listed
+    double acc[29];
+#pragma unroll
+    for (int c = 0; c < 29; ++c) acc[c] = 0.0;
+    int wcount = 0;                                      // this wave's in-bin points so far (wave-uniform)
+    if (n_valid > 0) {
+      for (int r = blockIdx.x; r < nrounds; r += (int)G) {
+        const int i = r * kNnThreads + (int)threadIdx.x;
+        bool boundary = false;
+        if (i < ns) {
+          const float d = b.d2[so + i];
+          const int j = b.idx[so + i];
+          const float4 s4 = ld_src(b, so + i);
+          const uint32_t key = __float_as_uint(d);
+          if (key < 0x7f800000u) {
+            const uint32_t bin = key >> kHistShift;
+            if (bin < qbin) accumulate_terms(Mc, s4, b.tq[to + max(j, 0)], b.tn[to + max(j, 0)], acc);
+            else boundary = bin == qbin;
+          }
+        }
+        const unsigned long long bm = __ballot(boundary);
+        if (boundary) s_rec[wave][wcount + (int)rank_below(bm)] = i;
+        wcount += (int)__popcll(bm);
+      }
+    }
+    if (lane == 0) s_wc[wave] = (uint32_t)wcount;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t total = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+      s_misc[1] = total ? __hip_atomic_fetch_add(&sync[32], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    }
+    __syncthreads();
+    {
+      uint32_t base = s_misc[1];
+      for (int w = 0; w < wave; ++w) base += s_wc[w];
+      for (int k = lane; k < wcount; k += 64) st_dev(&gkeys[base + k], __float_as_uint(b.d2[so + s_rec[wave][k]]));
+    }
+    // this lane's in-bin point (the wave's first 64): everything F1 needs of it, fetched on this side of the barrier
+    float pd = INFINITY;
+    float4 ps = make_float4(0, 0, 0, 0), pq = ps, pn = ps;
+    if (lane < wcount) {
+      const int i = s_rec[wave][lane];
+      pd = b.d2[so + i];
+      const int j = max(b.idx[so + i], 0);
+      ps = ld_src(b, so + i); pq = b.tq[to + j]; pn = b.tn[to + j];
+    }
+    SMHIP_OPH(3);
+    one_grid_sync(sync, target, G);
+    SMHIP_OPH(4);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      // every workgroup has read this iteration's counters: cleared for the next iteration's S -- by exchanges whose old values
+      // have come back before this workgroup arrives at the next barrier (a plain store's completion says less about where it
+      // stands against another XCD's atomics on the same word)
+      uint32_t o = __hip_atomic_exchange(&st->hard_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      o |= __hip_atomic_exchange(&st->deferred_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      o |= __hip_atomic_exchange(&st->unresolved_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      o |= __hip_atomic_exchange(&st->fallback_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      o |= __hip_atomic_exchange(&st->min_lb_key, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_misc[4] = o;
+    }
+    // ---------------- F1: the exact quantile (icp_fast.cc:65-90), then the bin's members at or below it
+    uint32_t limit_key = 0;
+    if (n_valid > 0) {
+      const int nb = (int)ld_dev(&sync[32]);
+      const bool flat = nb <= kFinalizeKeyCap;
+      if (flat) {
+        for (int e0 = 0; e0 < nb; e0 += 8 * kNnThreads) {          // eight loads in flight per thread: one pair's ~2 000 keys in one round
+          uint32_t kk[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) kk[u] = ld_dev(&gkeys[min(e0 + u * kNnThreads + (int)threadIdx.x, nb - 1)]);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) if (e0 + u * kNnThreads + (int)threadIdx.x < nb) s_keys[e0 + u * kNnThreads + threadIdx.x] = kk[u];
+        }
+      }
+      // radix select on the low 20 key bits (every listed key is of the quantile's bin): two passes of ten bits
+      uint32_t rank = krank - below;
+      uint32_t prefix = 0, mask = 0;
+      for (int pass = 0; pass < 2; ++pass) {
+        const int shift = pass == 0 ? 10 : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s_h[threadIdx.x + u * kNnThreads] = 0;
+        __syncthreads();                                            // (pass 0: also the keys staged above)
+        for (int e = threadIdx.x; e < nb; e += kNnThreads) {
+          const uint32_t key = (flat ? s_keys[e] : ld_dev(&gkeys[e])) & 0xfffffu;
+          if ((key & mask) == prefix) atomicAdd(&s_h[(key >> shift) & 1023u], 1u);
+        }
+        __syncthreads();
+        {
+          uint32_t c[4], v = 0;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { c[u] = s_h[threadIdx.x * 4 + u]; v += c[u]; }
+          uint32_t tot;
+          const uint32_t excl = block_excl_scan(v, s_w, &tot);
+          if (v > 0 && excl <= rank && rank < excl + v) {           // exactly one thread (0 <= rank < the count of keys under the prefix)
+            uint32_t run = excl;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (rank < run + c[u]) { s_sel[0] = threadIdx.x * 4 + u; s_sel[1] = run; break; }
+              run += c[u];
+            }
+          }
+        }
+        __syncthreads();
+        prefix |= s_sel[0] << shift;
+        mask |= 1023u << shift;
+        rank -= s_sel[1];
+      }
+      limit_key = (qbin << kHistShift) | prefix;
+      // weights = (d2 <= limit)  (icp_fast.cc:497-498): this wave's in-bin points, in the order it met them (the first 64 of them
+      // were fetched before the barrier)
+      if (lane < wcount && __float_as_uint(pd) <= limit_key) accumulate_terms(Mc, ps, pq, pn, acc);
+      for (int k = lane + 64; k < wcount; k += 64) {
+        const int i = s_rec[wave][k];
+        const float d = b.d2[so + i];
+        if (__float_as_uint(d) <= limit_key) {
+          const int j = max(b.idx[so + i], 0);
+          accumulate_terms(Mc, ld_src(b, so + i), b.tq[to + j], b.tn[to + j], acc);
+        }
+      }
+    }
+    block_reduce29(acc, s_red, s_tot);
+    if (threadIdx.x < 29) st_dev(&rows[(size_t)blockIdx.x * kAccCols + threadIdx.x], s_tot[threadIdx.x]);
+    SMHIP_OPH(5);
+    one_grid_sync_fold(sync, target, G, rows, grows, s_part, &s_misc[3]);
+    SMHIP_OPH(6);
+    if (blockIdx.x == 0 && threadIdx.x == 0)        // (read by everyone before the barrier; appended to again behind the next one)
+      s_misc[5] = __hip_atomic_exchange(&sync[32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---------------- F2: the groups' rows added in order; solve, pose update, convergence -- in every workgroup
+    if (threadIdx.x < 29) {
+      double s = 0;
+      for (int k = 0; k < kOneGroups; ++k)
+        s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(grows + (size_t)k * kAccCols + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      s_tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+    SMHIP_OPH(7);
+    if (threadIdx.x == 0) {
+      const TailOpts o = {b.cap_factor, b.ball_radius, b.band_gain, b.band_pad, 0, b.early_exit, b.max_iteration, b.search_hist, b.done_count};
+      one_tail(o, &ls, pair, s_tot, n_valid, limit_key, ns, blockIdx.x == 0);
+    }
+    __syncthreads();
+    SMHIP_OPH(8);
+    if (blockIdx.x == 0) {
+      // the state back to global memory (the refinement bodies, the host and the next Align's kernels read it there) -- all of it
+      // but the counters the other workgroups' next S may already be adding to
+      const uint32_t* l = reinterpret_cast<const uint32_t*>(&ls);
+      uint32_t* g = reinterpret_cast<uint32_t*>(st);
+      for (int k = threadIdx.x; k < (int)(sizeof(PairState) / 4); k += kNnThreads) {
+        const size_t o = (size_t)k * 4;
+        const bool live = o == offsetof(PairState, hard_count) || o == offsetof(PairState, deferred_count) || o == offsetof(PairState, unresolved_count) ||
+                          o == offsetof(PairState, min_lb_key) || o == offsetof(PairState, fallback_ticket);
+        if (!live) g[k] = l[k];
+      }
+    }
+    if (ls.done) break;
+  }
+  // ---------------- the score of the iteration the loop ended with: exp(-mean distance of its kept matches) (icp_fast.cc:516-522)
+  if (ls.status != 0) return;
+  {
+    const uint32_t limit_key = ls.limit_key;
+    double s = 0.0;
+    uint32_t cnt = 0;
+    for (int r = blockIdx.x; r < nrounds; r += (int)G) {
+      const int i = r * kNnThreads + (int)threadIdx.x;
+      if (i < ns) {
+        const float d = b.d2[so + i];
+        if (__float_as_uint(d) <= limit_key) { s += sqrt((double)d); ++cnt; }
+      }
+    }
+    s = wave_sum_to_last(s);
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if (lane == 63) s_red[wave][0] = s;
+    if (lane == 0) s_wc[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x < 29) {
+      double v = 0.0;
+      if (threadIdx.x == 0) v = ((s_red[0][0] + s_red[1][0]) + s_red[2][0]) + s_red[3][0];
+      if (threadIdx.x == 1) v = (double)(((s_wc[0] + s_wc[1]) + s_wc[2]) + s_wc[3]);
+      st_dev(&rows[(size_t)blockIdx.x * kAccCols + threadIdx.x], v);
+    }
+    one_grid_sync_fold(sync, target, G, rows, grows, s_part, &s_misc[3]);
+    if (blockIdx.x != 0) return;
+    if (threadIdx.x < 2) {
+      double t = 0;
+      for (int k = 0; k < kOneGroups; ++k)
+        t += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(grows + (size_t)k * kAccCols + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      s_part[0][threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double tot = s_part[0][0], n = s_part[0][1];
+      st->score_mismatch = (uint32_t)n != (uint32_t)ls.kept ? 1u : 0u;
+      st->score = n > 0 ? exp(-tot / n) : 0.0;
+    }
+  }
+#if SMHIP_PHASE_TIMING
+  if (otime) {
+    unsigned long long tot = 0;
+    for (int k = 0; k < 12; ++k) tot += oacc[k];
+    printf("[icp_one] iterations %d grid %u us per iteration: S %.1f bar1 %.1f V %.1f A %.1f bar2 %.1f F1 %.1f bar3 %.1f fold %.1f tail %.1f | total %.1f us\n", ls.iter, G,
+           oacc[0] * 0.01 / ls.iter, oacc[1] * 0.01 / ls.iter, oacc[2] * 0.01 / ls.iter, oacc[3] * 0.01 / ls.iter, oacc[4] * 0.01 / ls.iter,
+           oacc[5] * 0.01 / ls.iter, oacc[6] * 0.01 / ls.iter, oacc[7] * 0.01 / ls.iter, oacc[8] * 0.01 / ls.iter, tot * 0.01);
+  }
+#endif
+}
+
+}  // namespace smhip

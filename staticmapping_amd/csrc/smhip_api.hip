@@ -7,6 +7,7 @@
 // the device; the host only enqueues launches and, when early exit is on, polls one word
 // every `check_every` iterations.
 #include "icp_kernels.hip"
+#include "icp_one.hip"
 #include "nabo_kernels.hip"
 
 #include <hip/hip_runtime.h>
@@ -72,6 +73,10 @@ struct smhip_context {
   int sums_blocks = kSumsBlocks;  // workgroups of iteration_sums (SMHIP_SUMS_BLOCKS)
   int sums_long_for = 3;         // fused iterations of a batch whose missed pairs iteration_sums cuts into long blocks (SMHIP_SUMS_LONG_FOR)
   int use_shadow = 1;            // fused certificate pass reads the 4-byte shadow of (bound, match) where every target is small enough (SMHIP_SHADOW)
+  int one_blocks = 0;            // workgroups of the single-pair persistent kernel the device holds at once (0: not available)
+  int one_used = 0;              // the last single-pair enqueue went through it
+  int one_enabled = 1;           // SMHIP_ONE_PAIR=0: single pairs through the separate launches (measurement aid)
+  int one_blocks_want = 0;       // SMHIP_ONE_BLOCKS: its grid (tuning; 0 = as many as a round each needs, at most what is resident)
   int wave_search = 0;           // batches: the every-query-searches iterations through nn_ball_lds (0, default: 5-25 % faster on the bench scans)
                                  // or nn_ball_wave (1; SMHIP_WAVE_SEARCH=1) -- same results
   float4* stage = nullptr;       // pinned staging for uploads, 2 * max(ns_cap, nt_cap)
@@ -549,6 +554,9 @@ void sync_options(smhip_context* h) {
   { const char* e = std::getenv("SMHIP_SHADOW"); if (e) h->use_shadow = std::atoi(e); }
   h->wave_search = 0;
   { const char* e = std::getenv("SMHIP_WAVE_SEARCH"); if (e) h->wave_search = std::atoi(e); }
+  h->one_enabled = 1; h->one_blocks_want = 0;
+  { const char* e = std::getenv("SMHIP_ONE_PAIR"); if (e) h->one_enabled = std::atoi(e); }
+  { const char* e = std::getenv("SMHIP_ONE_BLOCKS"); if (e) h->one_blocks_want = std::atoi(e); }
   h->sums_blocks = kSumsBlocks;
   { const char* e = std::getenv("SMHIP_SUMS_BLOCKS"); if (e && std::atoi(e) >= 8) h->sums_blocks = (std::min(std::atoi(e), 65536) / 8) * 8; }
   h->dev.listed_grain = 1;
@@ -700,6 +708,8 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, &d.partials, B * (size_t)d.part_stride * kAccCols));
   A(dev_alloc(h, &d.tpart, B * kTgtReduceBlocks * 16));
   A(dev_alloc(h, &d.done_count, 4));
+  A(dev_alloc(h, &d.one_sync, (size_t)kOneSyncWords));
+  A(dev_alloc(h, &d.one_rows, (size_t)(kOneMaxBlocks + 8) * kAccCols));
   A(dev_alloc(h, &h->ids_dev, NS));
   A(dev_alloc(h, &h->d2_dev, NS));
   if (s == SMHIP_OK) {
@@ -712,6 +722,15 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
         hipHostMalloc(reinterpret_cast<void**>(&h->ids_pinned), NS * sizeof(int32_t)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&h->d2_pinned), NS * sizeof(float)) != hipSuccess)
       s = SMHIP_ERR_HIP;
+  }
+  if (s == SMHIP_OK) {
+    // the single-pair persistent kernel meets at grid barriers: its grid is what the device holds at once (cooperative launch)
+    int per_cu = 0, coop = 0;
+    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) == hipSuccess && coop &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, icp_one, kNnThreads, 0) == hipSuccess && per_cu > 0)
+      h->one_blocks = (std::min(per_cu * prop.multiProcessorCount, kOneMaxBlocks) / 8) * 8;
+    (void)hipGetLastError();
+    if (hipMemsetAsync(d.one_sync, 0, sizeof(uint32_t) * kOneSyncWords, h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
   }
   if (s == SMHIP_OK && hipMemsetAsync(d.state, 0, B * sizeof(PairState), h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
   if (s == SMHIP_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
@@ -1216,6 +1235,25 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
                              ceil_div(ns_max, kAccThreads * kAccItemsSmall) * (kAccThreads / 64) > kFinalizeMaxSeg) ? kAccItemsBatch : kAccItemsSmall;
   }
   const int max_it = h->dev.max_iteration;
+  // One pair (the front end's call, map_builder.cc:317-333): the whole loop and the score as ONE cooperative launch whose workgroups
+  // meet at grid barriers (icp_one.hip) -- the same matches, distances and kept sets as the launches below.
+  h->one_used = 0;
+  if (npairs == 1 && h->one_blocks > 0 && !h->opts.no_single_kernel && h->one_enabled && h->opts.nn_mode == SMHIP_NN_GRID && h->dev.use_ball &&
+      h->dev.lds_table && h->dev.certify && !h->dev.exact_all && h->profile == 0) {
+    const int nrounds = ceil_div(ns_max, kNnThreads);
+    int G = std::min(h->one_blocks, h->one_blocks_want > 0 ? std::max(8, (h->one_blocks_want / 8) * 8) : h->one_blocks);
+    G = std::min(G, ((nrounds + 7) / 8) * 8);
+    if (ceil_div(nrounds, G) <= kOneMaxRounds) {
+      if (!cached_one) { s = enqueue_grid_build(h, halves[0], nt_max); if (s) return s; }
+      IcpDev d1 = halves[0].d;
+      d1.fused = 0; d1.fused_nabo = 0;
+      void* args[] = {&d1};
+      HIPCHK(h, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(icp_one), dim3(G), dim3(kNnThreads), args, 0, h->stream));
+      h->one_used = 1;
+      h->last_npairs = npairs;
+      return SMHIP_OK;
+    }
+  }
   // one iteration of one part: FindClosests, the sums, finalize
   auto enqueue_iteration = [&](Half& f, int it) -> smhip_status {
     f.d.fused = fused_iteration(h, f, ns_max, it) ? 1 : 0;     // every launch of this iteration and part sees the same flag

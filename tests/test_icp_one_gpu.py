@@ -1,0 +1,145 @@
+"""The single-pair Align as one cooperative launch (csrc/icp_one.hip) against the separate launches per iteration
+(no_single_kernel = 1) and against the oracle: the front end's call shape, builder/map_builder.cc:317-333 -> icp_fast.cc:455-529.
+Matches, distances, histogram, quantile and kept set are the same bits in both forms; the normal-equation sums are added in a
+different fixed order, so poses agree to rounding, and a run is reproducible bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROT_TOL = 1e-4      # rad, BASELINE.json north_star
+TRANS_TOL = 1e-3    # m
+
+
+@pytest.fixture(scope="module")
+def smhip():
+    import staticmapping_amd as sm
+    from staticmapping_amd import _capi
+    lib = _capi.load_library()
+    assert lib.smhip_device_count() >= 1, "no gfx950 device visible"
+    return sm
+
+
+def _run(sm, c, guess, repeats=1, **opts):
+    m = sm.IcpFastHip(max_source_points=len(c["src"]), max_target_points=len(c["q"]), **opts)
+    m.set_input_source(c["src"])
+    m.set_input_target(c["q"], c["n"])
+    _, R = m.align(guess)
+    out = (R.copy(), m.get_fitness_score(), dict(m.last_stats[0]))
+    for rep in range(repeats):                             # target structures kept; every run the same bits
+        _, R2 = m.align(guess)
+        assert np.array_equal(R, R2) and m.get_fitness_score() == out[1] and dict(m.last_stats[0]) == out[2], f"Align {rep + 2} differs from the first"
+    m.close()
+    return out
+
+
+def _same_alignment(sm, a, b, what):
+    """The two forms add the normal equations in different orders: poses differ in their last bits (1e-15), so a borderline
+    certificate or a distance's last float bit may fall the other way -- the counts of searched queries may differ by a few, the
+    quantile by an ulp.  Everything else is equal."""
+    Ra, sa, ta = a
+    Rb, sb, tb = b
+    for k in ("iterations", "status", "refined_iterations", "fallback_queries"):
+        assert ta[k] == tb[k], (what, k, ta[k], tb[k])
+    assert abs(ta["kept"] - tb["kept"]) <= 2, (what, ta["kept"], tb["kept"])
+    assert abs(ta["limit_d2"] - tb["limit_d2"]) <= 1e-6 * abs(tb["limit_d2"]), (what, ta["limit_d2"], tb["limit_d2"])
+    for k in ("hard_queries", "searched_queries"):
+        assert abs(ta[k] - tb[k]) <= 0.01 * max(ta[k], tb[k]) + 2, (what, k, ta[k], tb[k])
+    da, dt = sm.se3_error(Ra, Rb)
+    assert da < 1e-11 and dt < 1e-11, (what, da, dt)
+    assert abs(sa - sb) <= 1e-12 * max(1.0, abs(sa)), (what, sa, sb)
+
+
+@pytest.mark.parametrize("fixture_name", ["cfg1", "velo20k", "cfg2"])
+@pytest.mark.parametrize("early_exit", [0, 1])
+def test_one_launch_equals_the_separate_launches(request, smhip, fixture_name, early_exit):
+    c = request.getfixturevalue(fixture_name)
+    guess = c.get("guess", np.eye(4))
+    opts = dict(max_iteration=20 if not early_exit else 100, early_exit=early_exit)
+    one = _run(smhip, c, guess, **opts)
+    sep = _run(smhip, c, guess, no_single_kernel=1, **opts)
+    _same_alignment(smhip, one, sep, fixture_name)
+
+
+def test_one_launch_against_the_oracle_full_size(smhip, cfg2):
+    from oracle import cref
+    c = cfg2
+    R, score, st = _run(smhip, c, c["guess"], max_iteration=20, early_exit=0)
+    ref = cref.icp_fast_align(c["src"][:, :3].astype(np.float64), c["q"], c["n"], guess=c["guess"], max_iteration=20, early_exit=False)
+    da, dt = smhip.se3_error(R, ref["result"])
+    assert da < ROT_TOL and dt < TRANS_TOL, (da, dt)
+    assert st["iterations"] == ref["iterations"] == 20
+    assert abs(score - ref["score"]) < 1e-4
+
+
+def test_poor_guess_refines_bounds_in_both_forms(smhip, velo20k):
+    """A search radius that the first iterations' quantile exceeds: the lower bounds must be refined to matches (ring search +
+    fallback, shared by all workgroups of the one launch)."""
+    c = velo20k
+    opts = dict(max_iteration=12, early_exit=0, ball_radius=0.1, grid_cell=0.5)
+    one = _run(smhip, c, c["guess"], **opts)
+    sep = _run(smhip, c, c["guess"], no_single_kernel=1, **opts)
+    assert one[2]["refined_iterations"] > 0
+    _same_alignment(smhip, one, sep, "refine")
+
+
+def test_far_source_goes_through_the_fallback_in_both_forms(smhip, velo20k):
+    from staticmapping_amd import synth
+    c = velo20k
+    guess = synth.make_pose(t=(40.0, 0.0, 0.0))            # most queries far outside the target's box
+    opts = dict(max_iteration=6, early_exit=0, grid_max_ring=1)
+    one = _run(smhip, c, guess, **opts)
+    sep = _run(smhip, c, guess, no_single_kernel=1, **opts)
+    _same_alignment(smhip, one, sep, "far")
+
+
+@pytest.mark.parametrize("n", [1, 63, 256, 257, 300, 513, 1000, 4097])
+def test_ragged_sizes(smhip, cfg1, n):
+    c = dict(cfg1)
+    c["src"] = cfg1["src"][:n]
+    opts = dict(max_iteration=8, early_exit=0)
+    one = _run(smhip, c, np.eye(4), repeats=25, **opts)    # (a handful of workgroups, most of them idle: the tightest timing the barriers see)
+    sep = _run(smhip, c, np.eye(4), no_single_kernel=1, **opts)
+    _same_alignment(smhip, one, sep, f"n={n}")
+
+
+def test_several_rounds_per_workgroup(smhip, velo20k, monkeypatch):
+    """A grid of 16 workgroups for 20 000 points: five rounds of 256 points each (the form large clouds take)."""
+    c = velo20k
+    opts = dict(max_iteration=15, early_exit=0)
+    sep = _run(smhip, c, c["guess"], no_single_kernel=1, **opts)
+    full = _run(smhip, c, c["guess"], **opts)
+    monkeypatch.setenv("SMHIP_ONE_BLOCKS", "16")
+    few = _run(smhip, c, c["guess"], **opts)
+    monkeypatch.delenv("SMHIP_ONE_BLOCKS")
+    _same_alignment(smhip, few, sep, "16 workgroups")
+    _same_alignment(smhip, full, sep, "full grid")
+
+
+def test_too_many_rounds_take_the_separate_launches(smhip, cfg2, monkeypatch):
+    """120 000 points over 8 workgroups would be 59 rounds each: the handle falls back to the launches per iteration (same result)."""
+    c = cfg2
+    opts = dict(max_iteration=5, early_exit=0)
+    sep = _run(smhip, c, c["guess"], no_single_kernel=1, **opts)
+    monkeypatch.setenv("SMHIP_ONE_BLOCKS", "8")
+    few = _run(smhip, c, c["guess"], **opts)
+    monkeypatch.delenv("SMHIP_ONE_BLOCKS")
+    for k in ("iterations", "kept", "limit_d2", "searched_queries"):
+        assert few[2][k] == sep[2][k]
+    assert np.array_equal(few[0], sep[0])
+
+
+def test_identical_clouds_and_no_match_cases(smhip, cfg1):
+    """The NaN rule (identical clouds -> identity, icp_fast.cc:315-321) and the no-correspondence status through the one launch."""
+    c = cfg1
+    m = smhip.IcpFastHip(max_source_points=len(c["q"]), max_target_points=len(c["q"]), max_iteration=5, early_exit=0)
+    m.set_input_source(c["q"]); m.set_input_target(c["q"], c["n"])
+    _, R = m.align(np.eye(4))
+    assert np.allclose(R, np.eye(4), atol=1e-5) and m.get_fitness_score() > 0.999
+    m.close()
+    m = smhip.IcpFastHip(max_source_points=8, max_target_points=len(c["q"]), max_iteration=5, early_exit=0)
+    m.set_input_source(np.full((8, 3), np.nan)); m.set_input_target(c["q"], c["n"])
+    with pytest.raises(smhip.SmhipError):
+        m.align(np.eye(4))
+    assert m.last_stats[0]["status"] != 0
+    m.close()

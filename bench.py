@@ -637,9 +637,14 @@ def single_pair_latency(w, device):
     out["ms_20_iterations_rebuild_every_align"] = timed()
     m.set_target_cache(True)
     out["ms_20_iterations_target_kept"] = timed()
+    out["fused_iterations_of_20"] = int(m.last_stats[0]["fused_iterations"])
     m.set_options(max_iteration=100, early_exit=1)
     out["ms_early_exit_target_kept"] = timed()
     out["iterations_early_exit"] = int(m.last_stats[0]["iterations"])
+    # the same Align as separate launches per iteration (round 5's form): what the one cooperative launch (csrc/icp_one.hip) replaced
+    m.set_options(max_iteration=ICP_ITERS, early_exit=0, no_single_kernel=1)
+    out["ms_20_iterations_target_kept_separate_launches"] = timed()
+    out["form"] = "one cooperative launch per Align: the whole loop of icp_fast.cc:484-523 + the score, workgroups resident, grid barriers (csrc/icp_one.hip)"
     m.close()
     return out
 

@@ -1259,16 +1259,22 @@ __device__ __forceinline__ void ball_lds_rounds(const IcpDev& b, PairState* st, 
 }
 
 // the smallest lower bound a workgroup recorded -> PairState::min_lb_key; its histogram -> the pair's
-__device__ __forceinline__ void flush_min_lb_and_hist(const IcpDev& b, PairState* st, int pair, uint32_t min_lb, const uint32_t* s_hist) {
+__device__ __forceinline__ void flush_min_lb(PairState* st, uint32_t min_lb) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) min_lb = min(min_lb, (uint32_t)__shfl_xor((int)min_lb, off, 64));
   if ((threadIdx.x & 63) == 0 && min_lb != 0xffffffffu) atomicMin(&st->min_lb_key, min_lb);
+}
+__device__ __forceinline__ void flush_hist(const IcpDev& b, int pair, const uint32_t* s_hist) {
   __syncthreads();
   uint32_t* gh = b.hist + (size_t)pair * kHistBins;
   for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
     const uint32_t v = s_hist[k];
     if (v) atomicAdd(&gh[k], v);
   }
+}
+__device__ __forceinline__ void flush_min_lb_and_hist(const IcpDev& b, PairState* st, int pair, uint32_t min_lb, const uint32_t* s_hist) {
+  flush_min_lb(st, min_lb);
+  flush_hist(b, pair, s_hist);
 }
 
 template <int ITEMS, bool FIRST = false>

@@ -75,6 +75,42 @@ __device__ __forceinline__ void one_grid_sync(uint32_t* sync, uint32_t& epoch, u
   }
   __syncthreads();
 }
+// The barrier with five counts riding on it (the fused form: how many distances in all, below the predicted band, in each of its
+// bins): integers, so atomics add them in any order to the same totals.  Two levels like the arrivals: a workgroup adds its counts
+// to its group's line, the group's last arrival moves the line's contents (exchanged for zero) to the top line, which is never
+// cleared -- every workgroup remembers what it last read there (cprev, threads 0..4) and takes the difference.
+// sync[576 + 32 g + t]: group g's counts, sync[832 + t]: the totals.
+__device__ __forceinline__ void one_grid_sync_counts(uint32_t* sync, uint32_t& epoch, uint32_t G, const uint32_t* s_cnt, uint32_t* s_out, uint32_t& cprev,
+                                                    uint32_t* s_flag) {
+  const uint32_t g = blockIdx.x & (kOneGroups - 1);
+  uint32_t sink = 0;
+  if (threadIdx.x < 5 && s_cnt[threadIdx.x]) sink = __hip_atomic_fetch_add(&sync[576 + 32 * g + threadIdx.x], s_cnt[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" :: "v"(sink) : "memory");      // (the old values have come back: the additions are done)
+  __syncthreads();
+  ++epoch;
+  if (threadIdx.x == 0) {
+    const uint32_t old = __hip_atomic_fetch_add(&sync[64 + 32 * g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_flag = old + 1u == epoch * (G / kOneGroups) ? 1u : 0u;
+  }
+  __syncthreads();
+  const bool last = *s_flag != 0u;
+  if (last) {
+    if (threadIdx.x < 5) {
+      const uint32_t v = __hip_atomic_exchange(&sync[576 + 32 * g + threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sink = v ? __hip_atomic_fetch_add(&sync[832 + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" :: "v"(sink) : "memory");
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) one_arrive_and_wait(sync, epoch, G, last);
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    const uint32_t cur = ld_dev(&sync[832 + threadIdx.x]);
+    s_out[threadIdx.x] = cur - cprev;
+    cprev = cur;
+  }
+  __syncthreads();
+}
 // The barrier behind the rows of sums, with the first level of their fold inside it: the last workgroup of a group to arrive adds
 // the group's rows -- in the order of their workgroups, whoever arrives last -- and publishes the group's row before it arrives
 // for the group.  (Every workgroup reading all 472 rows would pull 57 MB through the fabric per iteration.)
@@ -98,7 +134,7 @@ __device__ __forceinline__ void one_grid_sync_fold(uint32_t* sync, uint32_t& epo
       s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(rows + (size_t)w * kAccCols + col), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     s_part[sub][col] = s;
     __syncthreads();
-    if (threadIdx.x < 29) {
+    if (threadIdx.x < kAccCols) {
       double t = 0;
       for (int k = 0; k < 8; ++k) t += s_part[k][threadIdx.x];
       st_dev(&grows[(size_t)g * kAccCols + threadIdx.x], t);
@@ -119,7 +155,10 @@ __device__ __noinline__ void one_tail(TailOpts o, PairState* ls, int pair, const
   (void)finalize_tail(o, ls, pair, s_tot, n_valid, limit_key, false, ns, publish);
 }
 
-#if SMHIP_PHASE_TIMING
+#ifndef SMHIP_ONE_TIMING
+#define SMHIP_ONE_TIMING 0
+#endif
+#if SMHIP_ONE_TIMING
 #define SMHIP_OPH(k) do { if (otime) { const unsigned long long now_ = wall_clock64(); oacc[k] += now_ - oprev; oprev = now_; } } while (0)
 #else
 #define SMHIP_OPH(k) do { } while (0)
@@ -136,9 +175,10 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b) {
   __shared__ uint32_t s_h[1024];
   __shared__ uint32_t s_sel[2];
   __shared__ double s_red[4][29];
-  __shared__ double s_tot[29];
+  __shared__ double s_tot[kAccCols];
+  __shared__ uint32_t s_cnt[16];                         // the fused form's five counts of this workgroup, [8..12] the pair's
   __shared__ double s_part[8][32];
-  __shared__ uint32_t s_keys[kFinalizeKeyCap];           // the key list (F1); the refinement's target tile (V)
+  __shared__ uint32_t s_keys[kFinalizeKeyCap];           // the key list (select); the refinement's target tile (V)
   __shared__ int s_rec[kNnThreads / 64][64 * kOneMaxRounds];
   __shared__ uint32_t s_wc[kNnThreads / 64];
   __shared__ uint32_t s_misc[8];
@@ -165,131 +205,42 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b) {
   uint32_t hprev[kHistBins / kNnThreads];
 #pragma unroll
   for (int k = 0; k < kHistBins / kNnThreads; ++k) hprev[k] = 0u;
-#if SMHIP_PHASE_TIMING
+#if SMHIP_ONE_TIMING
   const bool otime = (b.debug_flags & 64) && threadIdx.x == 0 && blockIdx.x == 0;
-  unsigned long long oacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long oacc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long oprev = otime ? wall_clock64() : 0ull;
 #endif
-  for (;;) {
-    // ---------------- S: FindClosests (icp_fast.cc:486-493)
-    double Mc[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Mc[k] = uniform_f64(ls.M[k]);
-    for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
-    uint32_t min_lb = 0xffffffffu;
-    for (int r = blockIdx.x; r < nrounds; r += (int)G) ball_lds_rounds<1, false>(b, st, &ls, pair, r * kNnThreads, Mc, s_hist, min_lb);
-    flush_min_lb_and_hist(b, st, pair, min_lb, s_hist);
-    SMHIP_OPH(0);
-    one_grid_sync(sync, target, G);
-    SMHIP_OPH(1);
-    // ---------------- V: the quantile's bin; do the lower bounds stand above it?  (nn_validate)
-    uint32_t hraw[kHistBins / kNnThreads], hcnt[kHistBins / kNnThreads];
-#pragma unroll
-    for (int k = 0; k < kHistBins / kNnThreads; ++k) hraw[k] = ld_dev(&gh[threadIdx.x * (kHistBins / kNnThreads) + k]);
-#pragma unroll
-    for (int k = 0; k < kHistBins / kNnThreads; ++k) hcnt[k] = hraw[k] - hprev[k];
-    find_quantile_bin_counts(hcnt, b.rho, s_w, s_q);
-    if (threadIdx.x == 0) {
-      ls.hard_count = ld_dev(&st->hard_count);
-      ls.min_lb_key = ld_dev(&st->min_lb_key);
-      ls.deferred_count = ld_dev(&st->deferred_count);
-      ls.unresolved_count = 0;
-      const bool any = ls.hard_count > 0;
-      const bool below = (ls.min_lb_key >> kHistShift) <= s_q[0];
-      const bool refine = any && (b.exact_all || below || s_q[2] == 0);
-      if (refine) ls.refine_total += 1;
-      s_misc[0] = refine ? 1u : 0u;
-    }
-    __syncthreads();
-    if (s_misc[0]) {
-      // The bounds are refined to matches (nn_ring<true> + nn_fallback) by their OWNERS: every workgroup walks the rings for the
-      // lower-bounded queries among its own points (a stored bound < 0 marks them) and sweeps the whole target for those the rings
-      // leave open -- nothing but the histogram and a counter crosses workgroups.  Then one more barrier and the quantile again.
-      for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
-      if (threadIdx.x == 0) s_misc[6] = 0;
-      __syncthreads();
-      float4* s_t = reinterpret_cast<float4*>(s_keys);
-      const float4* __restrict__ tq = b.tq + to;
-      const int nt = ls.nt;
-      for (int r = blockIdx.x; r < nrounds; r += (int)G) {
-        const int i = r * kNnThreads + (int)threadIdx.x;
-        const bool hardq = i < ns && b.lb[so + i] < 0.f;
-        bool open = false;
-        float qx = 0.f, qy = 0.f, qz = 0.f;
-        Best best = {INFINITY, -1, INFINITY};
-        if (hardq) {
-          const uint32_t old = __float_as_uint(b.d2[so + i]);           // the bound leaves the histogram
-          if (old < 0x7f800000u) atomicSub(&gh[old >> kHistShift], 1u);
-          double px, py, pz;
-          transform_point(Mc, ld_src(b, so + i), px, py, pz);
-          qx = (float)px; qy = (float)py; qz = (float)pz;
-          open = !ring_search_query(b, &ls, pair, qx, qy, qz, best);
-        }
-        if (__syncthreads_or(open ? 1 : 0)) {                            // workgroup-uniform
-          if (open) best = {INFINITY, -1, INFINITY};
-          for (int base = 0; base < nt; base += kBruteTile) {
-            const int m = min(kBruteTile, nt - base);
-            __syncthreads();
-            for (int k = threadIdx.x; k < m; k += kNnThreads) s_t[k] = tq[base + k];
-            __syncthreads();
-            if (open)
-#pragma unroll 8
-              for (int k = 0; k < m; ++k) test_ascending(s_t[k], base + k, qx, qy, qz, best);
-          }
-          __syncthreads();
-          const unsigned long long om = __ballot(open);
-          if (lane == 0 && om) atomicAdd(&s_misc[6], (uint32_t)__popcll(om));
-        }
-        if (hardq) {
-          b.d2[so + i] = best.d2;
-          st_match(b, so + i, best.j, 0.f);                              // exact match, no runner-up information: searched again next time
-          const uint32_t key = __float_as_uint(best.d2);
-          if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
-        }
-      }
-      __syncthreads();
-      if (threadIdx.x == 0 && s_misc[6]) atomicAdd(&st->unresolved_count, s_misc[6]);
-      for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
-        const uint32_t v = s_hist[k];
-        if (v) atomicAdd(&gh[k], v);
-      }
-      one_grid_sync(sync, target, G);
-#pragma unroll
-      for (int k = 0; k < kHistBins / kNnThreads; ++k) hraw[k] = ld_dev(&gh[threadIdx.x * (kHistBins / kNnThreads) + k]);
-#pragma unroll
-      for (int k = 0; k < kHistBins / kNnThreads; ++k) hcnt[k] = hraw[k] - hprev[k];
-      find_quantile_bin_counts(hcnt, b.rho, s_w, s_q);
-      if (threadIdx.x == 0) ls.unresolved_count = ld_dev(&st->unresolved_count);
-      __syncthreads();
-    }
-#pragma unroll
-    for (int k = 0; k < kHistBins / kNnThreads; ++k) hprev[k] = hraw[k];
-    const uint32_t qbin = s_q[0], below = s_q[1], n_valid = s_q[2], krank = s_q[3];
-    SMHIP_OPH(2);
-    // ---------------- A: ErrorElements + ComputePointToPlane below the bin (icp_fast.cc:100-166, 256-303); the bin's members listed
-    double acc[29];
+  uint32_t cprev = 0;                                    // (threads 0..4) the pair's cumulative counts as last read
+  double Mc[12];
+  double acc[29];
+  int wcount = 0;                                        // this wave's listed points so far (wave-uniform)
+  float pd = INFINITY;                                   // this lane's listed point (the wave's first 64): fetched ahead of the barrier
+  float4 ps = make_float4(0, 0, 0, 0), pq = ps, pn = ps;
+
+  // ErrorElements + ComputePointToPlane (icp_fast.cc:100-166, 256-303) of this workgroup's points whose distance lies below
+  // histogram bin `lo`, into acc; its points of bins [lo, hi] listed: remembered in LDS, their keys appended to the pair's key list
+  // (ONE returning atomic per workgroup), the first 64 of each wave fetched whole.
+  auto collect = [&](uint32_t lo, uint32_t hi) {
 #pragma unroll
     for (int c = 0; c < 29; ++c) acc[c] = 0.0;
-    int wcount = 0;                                      // this wave's in-bin points so far (wave-uniform)
-    if (n_valid > 0) {
-      for (int r = blockIdx.x; r < nrounds; r += (int)G) {
-        const int i = r * kNnThreads + (int)threadIdx.x;
-        bool boundary = false;
-        if (i < ns) {
-          const float d = b.d2[so + i];
-          const int j = b.idx[so + i];
-          const float4 s4 = ld_src(b, so + i);
-          const uint32_t key = __float_as_uint(d);
-          if (key < 0x7f800000u) {
-            const uint32_t bin = key >> kHistShift;
-            if (bin < qbin) accumulate_terms(Mc, s4, b.tq[to + max(j, 0)], b.tn[to + max(j, 0)], acc);
-            else boundary = bin == qbin;
-          }
+    wcount = 0;
+    for (int r = blockIdx.x; r < nrounds; r += (int)G) {
+      const int i = r * kNnThreads + (int)threadIdx.x;
+      bool listed = false;
+      if (i < ns) {
+        const float d = b.d2[so + i];
+        const int j = b.idx[so + i];
+        const float4 s4 = ld_src(b, so + i);
+        const uint32_t key = __float_as_uint(d);
+        if (key < 0x7f800000u) {
+          const uint32_t bin = key >> kHistShift;
+          if (bin < lo) accumulate_terms(Mc, s4, b.tq[to + max(j, 0)], b.tn[to + max(j, 0)], acc);
+          else listed = bin <= hi;
         }
-        const unsigned long long bm = __ballot(boundary);
-        if (boundary) s_rec[wave][wcount + (int)rank_below(bm)] = i;
-        wcount += (int)__popcll(bm);
       }
+      const unsigned long long bm = __ballot(listed);
+      if (listed) s_rec[wave][wcount + (int)rank_below(bm)] = i;
+      wcount += (int)__popcll(bm);
     }
     if (lane == 0) s_wc[wave] = (uint32_t)wcount;
     __syncthreads();
@@ -298,27 +249,100 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b) {
       s_misc[1] = total ? __hip_atomic_fetch_add(&sync[32], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     }
     __syncthreads();
-    {
-      uint32_t base = s_misc[1];
-      for (int w = 0; w < wave; ++w) base += s_wc[w];
-      for (int k = lane; k < wcount; k += 64) st_dev(&gkeys[base + k], __float_as_uint(b.d2[so + s_rec[wave][k]]));
-    }
-    // this lane's in-bin point (the wave's first 64): everything F1 needs of it, fetched on this side of the barrier
-    float pd = INFINITY;
-    float4 ps = make_float4(0, 0, 0, 0), pq = ps, pn = ps;
+    uint32_t base = s_misc[1];
+    for (int w = 0; w < wave; ++w) base += s_wc[w];
+    for (int k = lane; k < wcount; k += 64) st_dev(&gkeys[base + k], __float_as_uint(b.d2[so + s_rec[wave][k]]));
+    pd = INFINITY;
     if (lane < wcount) {
       const int i = s_rec[wave][lane];
       pd = b.d2[so + i];
       const int j = max(b.idx[so + i], 0);
       ps = ld_src(b, so + i); pq = b.tq[to + j]; pn = b.tn[to + j];
     }
-    SMHIP_OPH(3);
-    one_grid_sync(sync, target, G);
-    SMHIP_OPH(4);
+  };
+  // The exact quantile (icp_fast.cc:65-90): the rank-th smallest key of bin qbin in the pair's key list, by radix select over the
+  // list as every workgroup reads it (the order it was appended in does not matter to the VALUE); then this workgroup's listed
+  // points at or below it added to acc -- weights = (d2 <= limit), icp_fast.cc:497-498 -- in the order the waves met them.
+  auto select_and_add = [&](uint32_t qbin, uint32_t rank) -> uint32_t {
+    const int nb = (int)ld_dev(&sync[32]);
+    const bool flat = nb <= kFinalizeKeyCap;
+    if (flat) {
+      for (int e0 = 0; e0 < nb; e0 += 8 * kNnThreads) {          // eight loads in flight per thread: one pair's ~2 000 keys in one round
+        uint32_t kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) kk[u] = ld_dev(&gkeys[min(e0 + u * kNnThreads + (int)threadIdx.x, nb - 1)]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (e0 + u * kNnThreads + (int)threadIdx.x < nb) s_keys[e0 + u * kNnThreads + threadIdx.x] = kk[u];
+      }
+    }
+    SMHIP_OPH(6);
+    uint32_t prefix = 0, mask = 0;
+    for (int pass = 0; pass < 2; ++pass) {                         // the low 20 key bits, ten at a time
+      const int shift = pass == 0 ? 10 : 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s_h[threadIdx.x + u * kNnThreads] = 0;
+      __syncthreads();                                            // (pass 0: also the keys staged above)
+      for (int e = threadIdx.x; e < nb; e += kNnThreads) {
+        const uint32_t full = flat ? s_keys[e] : ld_dev(&gkeys[e]);
+        const uint32_t key = full & 0xfffffu;
+        if ((full >> kHistShift) == qbin && (key & mask) == prefix) atomicAdd(&s_h[(key >> shift) & 1023u], 1u);
+      }
+      __syncthreads();
+      {
+        uint32_t c[4], v = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { c[u] = s_h[threadIdx.x * 4 + u]; v += c[u]; }
+        uint32_t tot;
+        const uint32_t excl = block_excl_scan(v, s_w, &tot);
+        if (v > 0 && excl <= rank && rank < excl + v) {           // exactly one thread (0 <= rank < the count of keys under the prefix)
+          uint32_t run = excl;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (rank < run + c[u]) { s_sel[0] = threadIdx.x * 4 + u; s_sel[1] = run; break; }
+            run += c[u];
+          }
+        }
+      }
+      __syncthreads();
+      prefix |= s_sel[0] << shift;
+      mask |= 1023u << shift;
+      rank -= s_sel[1];
+    }
+    const uint32_t limit_key = (qbin << kHistShift) | prefix;
+    SMHIP_OPH(7);
+    if (lane < wcount && __float_as_uint(pd) <= limit_key) accumulate_terms(Mc, ps, pq, pn, acc);
+    for (int k = lane + 64; k < wcount; k += 64) {
+      const int i = s_rec[wave][k];
+      const float d = b.d2[so + i];
+      if (__float_as_uint(d) <= limit_key) {
+        const int j = max(b.idx[so + i], 0);
+        accumulate_terms(Mc, ld_src(b, so + i), b.tq[to + j], b.tn[to + j], acc);
+      }
+    }
+    SMHIP_OPH(8);
+    return limit_key;
+  };
+  // this workgroup's row of sums published, the barrier with the groups' fold inside, the groups' rows added in order into dst
+  auto publish_and_fold = [&](double* dst, int ncols) {
+    block_reduce29(acc, s_red, dst);
+    if (threadIdx.x < ncols) st_dev(&rows[(size_t)blockIdx.x * kAccCols + threadIdx.x], dst[threadIdx.x]);
+    SMHIP_OPH(9);
+    one_grid_sync_fold(sync, target, G, rows, grows, s_part, &s_misc[3]);
+    SMHIP_OPH(10);
+    if (threadIdx.x < kAccCols) {
+      double s = 0;
+      for (int k = 0; k < kOneGroups; ++k)
+        s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(grows + (size_t)k * kAccCols + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      dst[threadIdx.x] = s;
+    }
+    __syncthreads();
+    SMHIP_OPH(11);
+  };
+  // this iteration's counters, as every workgroup has read them, cleared for the next iteration's S: by exchanges, whose old
+  // values have come back before this workgroup arrives at the next barrier (a plain store's completion says less about where
+  // it stands against another XCD's atomics on the same word)
+  auto clear_counters = [&]() {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-      // every workgroup has read this iteration's counters: cleared for the next iteration's S -- by exchanges whose old values
-      // have come back before this workgroup arrives at the next barrier (a plain store's completion says less about where it
-      // stands against another XCD's atomics on the same word)
       uint32_t o = __hip_atomic_exchange(&st->hard_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       o |= __hip_atomic_exchange(&st->deferred_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       o |= __hip_atomic_exchange(&st->unresolved_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -326,91 +350,197 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b) {
       o |= __hip_atomic_exchange(&st->min_lb_key, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_misc[4] = o;
     }
-    // ---------------- F1: the exact quantile (icp_fast.cc:65-90), then the bin's members at or below it
-    uint32_t limit_key = 0;
-    if (n_valid > 0) {
-      const int nb = (int)ld_dev(&sync[32]);
-      const bool flat = nb <= kFinalizeKeyCap;
-      if (flat) {
-        for (int e0 = 0; e0 < nb; e0 += 8 * kNnThreads) {          // eight loads in flight per thread: one pair's ~2 000 keys in one round
-          uint32_t kk[8];
+  };
+  auto clear_key_list = [&]() {
+    if (blockIdx.x == 0 && threadIdx.x == 0) s_misc[5] = __hip_atomic_exchange(&sync[32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto read_counters = [&]() {                                    // thread 0
+    ls.hard_count = ld_dev(&st->hard_count);
+    ls.min_lb_key = ld_dev(&st->min_lb_key);
+    ls.deferred_count = ld_dev(&st->deferred_count);
+    ls.unresolved_count = 0;
+  };
+
+  for (;;) {
+    // ---------------- S: FindClosests (icp_fast.cc:486-493)
 #pragma unroll
-          for (int u = 0; u < 8; ++u) kk[u] = ld_dev(&gkeys[min(e0 + u * kNnThreads + (int)threadIdx.x, nb - 1)]);
+    for (int k = 0; k < 12; ++k) Mc[k] = uniform_f64(ls.M[k]);
+    for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+    uint32_t min_lb = 0xffffffffu;
+    for (int r = blockIdx.x; r < nrounds; r += (int)G) ball_lds_rounds<1, false>(b, st, &ls, pair, r * kNnThreads, Mc, s_hist, min_lb);
+    flush_min_lb(st, min_lb);
+    SMHIP_OPH(0);
+    uint32_t n_valid = 0, limit_key = 0;
+    bool have_sums = false;
+    // ---------------- the fused form: finalize_tail predicted the histogram bins this iteration's quantile can fall in
+    // ([band_lo, band_hi], at most three; band_lo = 0: no prediction).  Then no histogram crosses workgroups at all: the sums below
+    // the band stay in registers, the band's members are listed, and five counts from the workgroup's own LDS histogram -- all
+    // distances, those below the band, those in each of its bins -- ride on the barrier.  The totals say whether the quantile's bin
+    // did land in the band (and no lower bound needs refining): if so the exact select over the band's keys and ONE row of sums
+    // finish the iteration with TWO barriers; if not, the iteration is done again the plain way below.  (The plain way's cost is its histogram:
+    // ~200 atomics per workgroup on words all 472 workgroups add to -- same-address atomics complete one every ~13 ns.)
+    const uint32_t blo = (uint32_t)ls.band_lo, bhi = (uint32_t)ls.band_hi;
+    if (ls.band_lo > 0 && !(b.debug_flags & 128)) {
+      __syncthreads();
+      collect(blo, bhi);
+      SMHIP_OPH(4);
+      {   // this workgroup's counts from its own histogram: all distances, those below the band (at most 2 048 each: one scan for both)
+        uint32_t v = 0;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) if (e0 + u * kNnThreads + (int)threadIdx.x < nb) s_keys[e0 + u * kNnThreads + threadIdx.x] = kk[u];
+        for (int u = 0; u < kHistBins / kNnThreads; ++u) {
+          const uint32_t bin = threadIdx.x * (kHistBins / kNnThreads) + u, c = s_hist[bin];
+          v += c + (bin < blo ? c << 16 : 0u);
         }
+        uint32_t tot;
+        (void)block_excl_scan(v, s_w, &tot);
+        if (threadIdx.x < 5) s_cnt[threadIdx.x] = threadIdx.x == 0 ? (tot & 0xffffu) : (threadIdx.x == 1 ? tot >> 16 : (blo + (threadIdx.x - 2) <= bhi ? s_hist[blo + (threadIdx.x - 2)] : 0u));
       }
-      // radix select on the low 20 key bits (every listed key is of the quantile's bin): two passes of ten bits
-      uint32_t rank = krank - below;
-      uint32_t prefix = 0, mask = 0;
-      for (int pass = 0; pass < 2; ++pass) {
-        const int shift = pass == 0 ? 10 : 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) s_h[threadIdx.x + u * kNnThreads] = 0;
-        __syncthreads();                                            // (pass 0: also the keys staged above)
-        for (int e = threadIdx.x; e < nb; e += kNnThreads) {
-          const uint32_t key = (flat ? s_keys[e] : ld_dev(&gkeys[e])) & 0xfffffu;
-          if ((key & mask) == prefix) atomicAdd(&s_h[(key >> shift) & 1023u], 1u);
-        }
-        __syncthreads();
-        {
-          uint32_t c[4], v = 0;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { c[u] = s_h[threadIdx.x * 4 + u]; v += c[u]; }
-          uint32_t tot;
-          const uint32_t excl = block_excl_scan(v, s_w, &tot);
-          if (v > 0 && excl <= rank && rank < excl + v) {           // exactly one thread (0 <= rank < the count of keys under the prefix)
-            uint32_t run = excl;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              if (rank < run + c[u]) { s_sel[0] = threadIdx.x * 4 + u; s_sel[1] = run; break; }
-              run += c[u];
+      SMHIP_OPH(9);
+      one_grid_sync_counts(sync, target, G, s_cnt, s_cnt + 8, cprev, &s_misc[3]);
+      SMHIP_OPH(10);
+      if (threadIdx.x == 0) {
+        read_counters();
+        const uint32_t nv = s_cnt[8], below = s_cnt[9];
+        uint32_t hit = 0, qb = 0, rank = 0;
+        if (nv > 0) {
+          const uint32_t k = (uint32_t)quantile_rank(nv, b.rho);
+          uint32_t run = below;
+          if (k >= below)
+            for (uint32_t c = 0; blo + c <= bhi; ++c) {
+              const uint32_t n = s_cnt[10 + c];
+              if (k < run + n) { hit = 1; qb = blo + c; rank = k - run; break; }
+              run += n;
             }
+        }
+        // (nn_validate) a lower bound sharing the quantile's bin is not provably above it
+        if (hit && ls.hard_count > 0 && (b.exact_all || (ls.min_lb_key >> kHistShift) <= qb)) hit = 0;
+        s_q[0] = qb; s_q[1] = rank; s_q[2] = nv; s_q[3] = hit;
+      }
+      __syncthreads();
+      SMHIP_OPH(3);
+      if (s_q[3]) {
+        n_valid = s_q[2];
+        limit_key = select_and_add(s_q[0], s_q[1]);               // acc: the sums below the band + the band's members at or below the exact quantile
+        publish_and_fold(s_tot, 29);
+        if (threadIdx.x == 0) ls.spec_hits += 1;
+        clear_counters();
+        clear_key_list();
+        have_sums = true;
+      } else {
+        clear_key_list();                                          // (nobody reads the list on a miss; the plain way appends behind its first barrier)
+      }
+    }
+    if (!have_sums) {
+      // ---------------- the plain form: the pair's histogram, the quantile's bin, the sums below it, the exact select inside it
+      flush_hist(b, pair, s_hist);
+      SMHIP_OPH(1);
+      one_grid_sync(sync, target, G);
+      SMHIP_OPH(2);
+      // V: the quantile's bin; do the lower bounds stand above it?  (nn_validate)
+      uint32_t hraw[kHistBins / kNnThreads], hcnt[kHistBins / kNnThreads];
+#pragma unroll
+      for (int k = 0; k < kHistBins / kNnThreads; ++k) hraw[k] = ld_dev(&gh[threadIdx.x * (kHistBins / kNnThreads) + k]);
+#pragma unroll
+      for (int k = 0; k < kHistBins / kNnThreads; ++k) hcnt[k] = hraw[k] - hprev[k];
+      find_quantile_bin_counts(hcnt, b.rho, s_w, s_q);
+      if (threadIdx.x == 0) {
+        read_counters();
+        const bool any = ls.hard_count > 0;
+        const bool below = (ls.min_lb_key >> kHistShift) <= s_q[0];
+        const bool refine = any && (b.exact_all || below || s_q[2] == 0);
+        if (refine) ls.refine_total += 1;
+        s_misc[0] = refine ? 1u : 0u;
+      }
+      __syncthreads();
+      if (s_misc[0]) {
+        // The bounds are refined to matches (nn_ring<true> + nn_fallback) by their OWNERS: every workgroup walks the rings for the
+        // lower-bounded queries among its own points (a stored bound < 0 marks them) and sweeps the whole target for those the rings
+        // leave open -- nothing but the histogram and a counter crosses workgroups.  Then one more barrier and the quantile again.
+        for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
+        if (threadIdx.x == 0) s_misc[6] = 0;
+        __syncthreads();
+        float4* s_t = reinterpret_cast<float4*>(s_keys);
+        const float4* __restrict__ tq = b.tq + to;
+        const int nt = ls.nt;
+        for (int r = blockIdx.x; r < nrounds; r += (int)G) {
+          const int i = r * kNnThreads + (int)threadIdx.x;
+          const bool hardq = i < ns && b.lb[so + i] < 0.f;
+          bool open = false;
+          float qx = 0.f, qy = 0.f, qz = 0.f;
+          Best best = {INFINITY, -1, INFINITY};
+          if (hardq) {
+            const uint32_t old = __float_as_uint(b.d2[so + i]);           // the bound leaves the histogram
+            if (old < 0x7f800000u) atomicSub(&gh[old >> kHistShift], 1u);
+            double px, py, pz;
+            transform_point(Mc, ld_src(b, so + i), px, py, pz);
+            qx = (float)px; qy = (float)py; qz = (float)pz;
+            open = !ring_search_query(b, &ls, pair, qx, qy, qz, best);
+          }
+          if (__syncthreads_or(open ? 1 : 0)) {                            // workgroup-uniform
+            if (open) best = {INFINITY, -1, INFINITY};
+            for (int base = 0; base < nt; base += kBruteTile) {
+              const int m = min(kBruteTile, nt - base);
+              __syncthreads();
+              for (int k = threadIdx.x; k < m; k += kNnThreads) s_t[k] = tq[base + k];
+              __syncthreads();
+              if (open)
+#pragma unroll 8
+                for (int k = 0; k < m; ++k) test_ascending(s_t[k], base + k, qx, qy, qz, best);
+            }
+            __syncthreads();
+            const unsigned long long om = __ballot(open);
+            if (lane == 0 && om) atomicAdd(&s_misc[6], (uint32_t)__popcll(om));
+          }
+          if (hardq) {
+            b.d2[so + i] = best.d2;
+            st_match(b, so + i, best.j, 0.f);                              // exact match, no runner-up information: searched again next time
+            const uint32_t key = __float_as_uint(best.d2);
+            if (key < 0x7f800000u) atomicAdd(&s_hist[key >> kHistShift], 1u);
           }
         }
         __syncthreads();
-        prefix |= s_sel[0] << shift;
-        mask |= 1023u << shift;
-        rank -= s_sel[1];
+        if (threadIdx.x == 0 && s_misc[6]) atomicAdd(&st->unresolved_count, s_misc[6]);
+        flush_hist(b, pair, s_hist);
+        one_grid_sync(sync, target, G);
+#pragma unroll
+        for (int k = 0; k < kHistBins / kNnThreads; ++k) hraw[k] = ld_dev(&gh[threadIdx.x * (kHistBins / kNnThreads) + k]);
+#pragma unroll
+        for (int k = 0; k < kHistBins / kNnThreads; ++k) hcnt[k] = hraw[k] - hprev[k];
+        find_quantile_bin_counts(hcnt, b.rho, s_w, s_q);
+        if (threadIdx.x == 0) ls.unresolved_count = ld_dev(&st->unresolved_count);
+        __syncthreads();
       }
-      limit_key = (qbin << kHistShift) | prefix;
-      // weights = (d2 <= limit)  (icp_fast.cc:497-498): this wave's in-bin points, in the order it met them (the first 64 of them
-      // were fetched before the barrier)
-      if (lane < wcount && __float_as_uint(pd) <= limit_key) accumulate_terms(Mc, ps, pq, pn, acc);
-      for (int k = lane + 64; k < wcount; k += 64) {
-        const int i = s_rec[wave][k];
-        const float d = b.d2[so + i];
-        if (__float_as_uint(d) <= limit_key) {
-          const int j = max(b.idx[so + i], 0);
-          accumulate_terms(Mc, ld_src(b, so + i), b.tq[to + j], b.tn[to + j], acc);
-        }
+#pragma unroll
+      for (int k = 0; k < kHistBins / kNnThreads; ++k) hprev[k] = hraw[k];
+      const uint32_t qbin = s_q[0], below = s_q[1], krank = s_q[3];
+      n_valid = s_q[2];
+      SMHIP_OPH(3);
+      // A: the sums below the bin, the bin's members listed
+      if (n_valid > 0) collect(qbin, qbin);
+      else {
+#pragma unroll
+        for (int c = 0; c < 29; ++c) acc[c] = 0.0;
+        wcount = 0;
       }
+      SMHIP_OPH(4);
+      one_grid_sync(sync, target, G);
+      SMHIP_OPH(5);
+      clear_counters();
+      // F1: the exact quantile, the bin's members at or below it; F2: the rows
+      if (n_valid > 0) limit_key = select_and_add(qbin, krank - below);
+      publish_and_fold(s_tot, 29);
+      clear_key_list();
     }
-    block_reduce29(acc, s_red, s_tot);
-    if (threadIdx.x < 29) st_dev(&rows[(size_t)blockIdx.x * kAccCols + threadIdx.x], s_tot[threadIdx.x]);
-    SMHIP_OPH(5);
-    one_grid_sync_fold(sync, target, G, rows, grows, s_part, &s_misc[3]);
-    SMHIP_OPH(6);
-    if (blockIdx.x == 0 && threadIdx.x == 0)        // (read by everyone before the barrier; appended to again behind the next one)
-      s_misc[5] = __hip_atomic_exchange(&sync[32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // ---------------- F2: the groups' rows added in order; solve, pose update, convergence -- in every workgroup
-    if (threadIdx.x < 29) {
-      double s = 0;
-      for (int k = 0; k < kOneGroups; ++k)
-        s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(grows + (size_t)k * kAccCols + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      s_tot[threadIdx.x] = s;
-    }
-    __syncthreads();
-    SMHIP_OPH(7);
+    // ---------------- solve, pose update, convergence -- in every workgroup, on its own copy of the state
     if (threadIdx.x == 0) {
       const TailOpts o = {b.cap_factor, b.ball_radius, b.band_gain, b.band_pad, 0, b.early_exit, b.max_iteration, b.search_hist, b.done_count};
       one_tail(o, &ls, pair, s_tot, n_valid, limit_key, ns, blockIdx.x == 0);
     }
     __syncthreads();
-    SMHIP_OPH(8);
+    SMHIP_OPH(12);
     if (blockIdx.x == 0) {
-      // the state back to global memory (the refinement bodies, the host and the next Align's kernels read it there) -- all of it
-      // but the counters the other workgroups' next S may already be adding to
+      // the state back to global memory (the host and the next Align's kernels read it there) -- all of it but the counters the
+      // other workgroups' next S may already be adding to
       const uint32_t* l = reinterpret_cast<const uint32_t*>(&ls);
       uint32_t* g = reinterpret_cast<uint32_t*>(st);
       for (int k = threadIdx.x; k < (int)(sizeof(PairState) / 4); k += kNnThreads) {
@@ -461,13 +591,14 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b) {
       st->score = n > 0 ? exp(-tot / n) : 0.0;
     }
   }
-#if SMHIP_PHASE_TIMING
+#if SMHIP_ONE_TIMING
   if (otime) {
     unsigned long long tot = 0;
-    for (int k = 0; k < 12; ++k) tot += oacc[k];
-    printf("[icp_one] iterations %d grid %u us per iteration: S %.1f bar1 %.1f V %.1f A %.1f bar2 %.1f F1 %.1f bar3 %.1f fold %.1f tail %.1f | total %.1f us\n", ls.iter, G,
-           oacc[0] * 0.01 / ls.iter, oacc[1] * 0.01 / ls.iter, oacc[2] * 0.01 / ls.iter, oacc[3] * 0.01 / ls.iter, oacc[4] * 0.01 / ls.iter,
-           oacc[5] * 0.01 / ls.iter, oacc[6] * 0.01 / ls.iter, oacc[7] * 0.01 / ls.iter, oacc[8] * 0.01 / ls.iter, tot * 0.01);
+    for (int k = 0; k < 13; ++k) tot += oacc[k];
+    const double u = 0.01 / ls.iter;
+    printf("[icp_one] iterations %d grid %u us per iteration: S %.1f flush %.1f bar1 %.1f V %.1f A %.1f bar2 %.1f F1 (keys %.1f select %.1f records %.1f reduce %.1f) bar3 %.1f fold %.1f tail %.1f | total %.1f us\n",
+           ls.iter, G, oacc[0] * u, oacc[1] * u, oacc[2] * u, oacc[3] * u, oacc[4] * u, oacc[5] * u, oacc[6] * u, oacc[7] * u, oacc[8] * u, oacc[9] * u, oacc[10] * u,
+           oacc[11] * u, oacc[12] * u, tot * 0.01);
   }
 #endif
 }

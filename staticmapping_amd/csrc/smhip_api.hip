@@ -1241,8 +1241,11 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
   if (npairs == 1 && h->one_blocks > 0 && !h->opts.no_single_kernel && h->one_enabled && h->opts.nn_mode == SMHIP_NN_GRID && h->dev.use_ball &&
       h->dev.lds_table && h->dev.certify && !h->dev.exact_all && h->profile == 0) {
     const int nrounds = ceil_div(ns_max, kNnThreads);
-    int G = std::min(h->one_blocks, h->one_blocks_want > 0 ? std::max(8, (h->one_blocks_want / 8) * 8) : h->one_blocks);
-    G = std::min(G, ((nrounds + 7) / 8) * 8);
+    // two rounds of 256 points per workgroup (measured on 120 000 points, 20 iterations, target kept: 472 workgroups of one round
+    // 1.15-1.18 ms, 320: 1.11-1.15, 240: 1.06-1.11, 160: 1.04-1.13 -- a barrier waits for the slowest workgroup, and two rounds
+    // even out what one round's few searching queries cost); a multiple of 8: the barrier's groups
+    int G = h->one_blocks_want > 0 ? std::max(8, (h->one_blocks_want / 8) * 8) : ((ceil_div(nrounds, 2) + 7) / 8) * 8;
+    G = std::min(std::min(G, h->one_blocks), ((nrounds + 7) / 8) * 8);
     if (ceil_div(nrounds, G) <= kOneMaxRounds) {
       if (!cached_one) { s = enqueue_grid_build(h, halves[0], nt_max); if (s) return s; }
       IcpDev d1 = halves[0].d;

@@ -118,8 +118,9 @@ def test_align_is_identical_across_search_variants(seed, n, yaw, tx, rho):
     ref = None
     for opts in (dict(), dict(no_certify=1), dict(no_lds_table=1), dict(split_after=1), dict(split_after=3, no_lds_table=1),
                  dict(use_ball=0), dict(nn_mode=0), dict(ball_radius=0.05)):
+        # (as separate launches per iteration: the search variants share every sum's order there)
         m = sm.IcpFastHip(max_source_points=len(src), max_target_points=len(q), max_iteration=25, early_exit=1,
-                          dist_outlier_ratio=rho, **opts)
+                          dist_outlier_ratio=rho, no_single_kernel=1, **opts)
         m.set_input_source(src); m.set_input_target(q, nr)
         ok, R = m.align(guess)
         st_ = m.last_stats[0]
@@ -127,7 +128,19 @@ def test_align_is_identical_across_search_variants(seed, n, yaw, tx, rho):
         key = (R.tobytes(), st_["iterations"], st_["kept"], st_["limit_d2"])
         if ref is None:
             ref = key
+            R_ref = R
         assert key == ref, (opts, st_)
+    # the same Align as ONE cooperative launch (csrc/icp_one.hip): the same matches and kept sets, the sums in another fixed order
+    m = sm.IcpFastHip(max_source_points=len(src), max_target_points=len(q), max_iteration=25, early_exit=1, dist_outlier_ratio=rho)
+    m.set_input_source(src); m.set_input_target(q, nr)
+    ok, R = m.align(guess)
+    st_ = m.last_stats[0]
+    ok2, R2 = m.align(guess)
+    m.close()
+    assert R.tobytes() == R2.tobytes()
+    assert st_["iterations"] == ref[1] and abs(st_["kept"] - ref[2]) <= 2, (st_, ref[1:])
+    da, dt = sm.se3_error(R, R_ref)
+    assert da < 1e-10 and dt < 1e-10, (da, dt)
 
 
 @settings(max_examples=max(6, _N // 4), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
@@ -152,7 +165,7 @@ def test_certificates_change_no_bit_far_from_the_origin_and_from_poor_guesses(se
     ref = None
     for opts in (dict(), dict(no_certify=1), dict(split_after=1), dict(no_lds_table=1), dict(use_ball=0)):
         m = sm.IcpFastHip(max_source_points=len(src), max_target_points=len(q), max_iteration=25, early_exit=1,
-                          dist_outlier_ratio=rho, **opts)
+                          dist_outlier_ratio=rho, no_single_kernel=1, **opts)
         m.set_input_source(src); m.set_input_target(q, nr)
         ok, R = m.align(guess)
         st_ = m.last_stats[0]
@@ -161,4 +174,14 @@ def test_certificates_change_no_bit_far_from_the_origin_and_from_poor_guesses(se
         key = (R.tobytes(), st_["iterations"], st_["kept"], st_["limit_d2"], st_["status"])
         if ref is None:
             ref = key
+            R_ref = R
         assert key == ref, (opts, st_)
+    # ... and as ONE cooperative launch (the bounds refined by the queries' owners there): same kept sets, sums in another order
+    m = sm.IcpFastHip(max_source_points=len(src), max_target_points=len(q), max_iteration=25, early_exit=1, dist_outlier_ratio=rho)
+    m.set_input_source(src); m.set_input_target(q, nr)
+    ok, R = m.align(guess)
+    st_ = m.last_stats[0]
+    m.close()
+    assert st_["iterations"] == ref[1] and abs(st_["kept"] - ref[2]) <= 2 and st_["status"] == ref[4], (st_, ref[1:])
+    da, dt = sm.se3_error(R, R_ref)
+    assert da < 1e-9 and dt < 1e-9, (da, dt)

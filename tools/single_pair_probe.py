@@ -19,7 +19,7 @@ for cache in (False, True):
     t = time.time(); reps = 20
     for _ in range(reps): ok, R = m.align(guess)
     dt = (time.time() - t) / reps
-    print(f"single pair, 20 iterations, target_cache={int(cache)}: {dt*1e3:.3f} ms per Align  err={sm.se3_error(R, T)}")
+    print(f"single pair, 20 iterations, target_cache={int(cache)}: {dt*1e3:.3f} ms per Align  err={sm.se3_error(R, T)}  fused iterations {m.last_stats[0]['fused_iterations']} searched {m.last_stats[0]['searched_queries']}")
 m.set_options(max_iteration=100, early_exit=1)
 m.align(guess)
 t = time.time()

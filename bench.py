@@ -402,8 +402,8 @@ def main():
                 return None
             try:
                 tdat = json.load(open(tj))
-                # (a record that names its source files is only used while they are what it was measured on)
-                if tdat.get("source_files") and tdat.get("source_sha") != _source_sha(tdat["source_files"]):
+                # (a record is only used while the kernel sources it names are what it was measured on; one that names none is undated)
+                if not tdat.get("source_files") or tdat.get("source_sha") != _source_sha(tdat["source_files"]):
                     return None
                 if tdat.get("nn_mode") == args.nn_mode and tdat.get("source_points") in (None, ns):
                     # scattered 32-64 B sectors (the listed search): the counters at factor 1, as the scatter calibration found

@@ -51,27 +51,30 @@ __device__ __forceinline__ void st_dev(double* p, double v) {
 }
 
 // IcpDev::one_sync, in 128-byte lines (32 words): [0] arrivals of the groups' last workgroups, [32] length of the key list,
-// [64 + 32 g] arrivals of group g's workgroups, [320 + 32 g] the last completed epoch as group g polls it.  Group = blockIdx % 8
-// (the dispatcher's XCD round-robin); measured (tools/grid_barrier_probe.hip, 472 workgroups): every arrival on one counter
+// [kSyncArrive + 32 g] arrivals of group g's workgroups, [kSyncFlag + 32 g] the last completed epoch as group g polls it.  Group =
+// blockIdx % NG; measured (tools/grid_barrier_probe.hip, 472 workgroups): every arrival on one counter
 // 6.2 us per barrier -- same-address atomics complete one every ~13 ns --, two levels 2.1 us.
-constexpr int kOneGroups = 8;
-__device__ __forceinline__ void one_arrive_and_wait(uint32_t* sync, uint32_t epoch, uint32_t G, bool group_last) {
-  const uint32_t g = blockIdx.x & (kOneGroups - 1);
+constexpr int kOneMaxGroups = 32;
+constexpr int kSyncArrive = 64, kSyncFlag = kSyncArrive + 32 * kOneMaxGroups, kSyncCount = kSyncFlag + 32 * kOneMaxGroups, kSyncTotal = kSyncCount + 32 * kOneMaxGroups;
+static_assert(kSyncTotal + 32 <= kOneSyncWords, "IcpDev::one_sync holds the barrier's lines");
+struct OneGrid { uint32_t G, NG; };       // workgroups, groups (a power of two that divides G)
+__device__ __forceinline__ void one_arrive_and_wait(uint32_t* sync, uint32_t epoch, OneGrid og, bool group_last) {
+  const uint32_t g = blockIdx.x & (og.NG - 1);
   if (group_last) {
     const uint32_t old = __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1u == epoch * kOneGroups)
-      for (int k = 0; k < kOneGroups; ++k) st_dev(&sync[320 + 32 * k], epoch);
+    if (old + 1u == epoch * og.NG)
+      for (uint32_t k = 0; k < og.NG; ++k) st_dev(&sync[kSyncFlag + 32 * k], epoch);
   }
-  while (ld_dev(&sync[320 + 32 * g]) < epoch) __builtin_amdgcn_s_sleep(1);
+  while (ld_dev(&sync[kSyncFlag + 32 * g]) < epoch) __builtin_amdgcn_s_sleep(1);
 }
-__device__ __forceinline__ void one_grid_sync(uint32_t* sync, uint32_t& epoch, uint32_t G) {
+__device__ __forceinline__ void one_grid_sync(uint32_t* sync, uint32_t& epoch, OneGrid og) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // this wave's write-through stores and atomics have completed
   __syncthreads();
   ++epoch;
   if (threadIdx.x == 0) {
-    const uint32_t g = blockIdx.x & (kOneGroups - 1);
-    const uint32_t old = __hip_atomic_fetch_add(&sync[64 + 32 * g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    one_arrive_and_wait(sync, epoch, G, old + 1u == epoch * (G / kOneGroups));
+    const uint32_t g = blockIdx.x & (og.NG - 1);
+    const uint32_t old = __hip_atomic_fetch_add(&sync[kSyncArrive + 32 * g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    one_arrive_and_wait(sync, epoch, og, old + 1u == epoch * (og.G / og.NG));
   }
   __syncthreads();
 }
@@ -79,33 +82,34 @@ __device__ __forceinline__ void one_grid_sync(uint32_t* sync, uint32_t& epoch, u
 // bins): integers, so atomics add them in any order to the same totals.  Two levels like the arrivals: a workgroup adds its counts
 // to its group's line, the group's last arrival moves the line's contents (exchanged for zero) to the top line, which is never
 // cleared -- every workgroup remembers what it last read there (cprev, threads 0..4) and takes the difference.
-// sync[576 + 32 g + t]: group g's counts, sync[832 + t]: the totals.
-__device__ __forceinline__ void one_grid_sync_counts(uint32_t* sync, uint32_t& epoch, uint32_t G, const uint32_t* s_cnt, uint32_t* s_out, uint32_t& cprev,
+// sync[kSyncCount + 32 g + t]: group g's counts, sync[kSyncTotal + t]: the totals.
+__device__ __forceinline__ void one_grid_sync_counts(uint32_t* sync, uint32_t& epoch, OneGrid og, const uint32_t* s_cnt, uint32_t* s_out, uint32_t& cprev,
                                                     uint32_t* s_flag) {
-  const uint32_t g = blockIdx.x & (kOneGroups - 1);
+  const uint32_t G = og.G;
+  const uint32_t g = blockIdx.x & (og.NG - 1);
   uint32_t sink = 0;
-  if (threadIdx.x < 5 && s_cnt[threadIdx.x]) sink = __hip_atomic_fetch_add(&sync[576 + 32 * g + threadIdx.x], s_cnt[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x < 5 && s_cnt[threadIdx.x]) sink = __hip_atomic_fetch_add(&sync[kSyncCount + 32 * g + threadIdx.x], s_cnt[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" :: "v"(sink) : "memory");      // (the old values have come back: the additions are done)
   __syncthreads();
   ++epoch;
   if (threadIdx.x == 0) {
-    const uint32_t old = __hip_atomic_fetch_add(&sync[64 + 32 * g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *s_flag = old + 1u == epoch * (G / kOneGroups) ? 1u : 0u;
+    const uint32_t old = __hip_atomic_fetch_add(&sync[kSyncArrive + 32 * g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_flag = old + 1u == epoch * (G / og.NG) ? 1u : 0u;
   }
   __syncthreads();
   const bool last = *s_flag != 0u;
   if (last) {
     if (threadIdx.x < 5) {
-      const uint32_t v = __hip_atomic_exchange(&sync[576 + 32 * g + threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sink = v ? __hip_atomic_fetch_add(&sync[832 + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      const uint32_t v = __hip_atomic_exchange(&sync[kSyncCount + 32 * g + threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sink = v ? __hip_atomic_fetch_add(&sync[kSyncTotal + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" :: "v"(sink) : "memory");
     __syncthreads();
   }
-  if (threadIdx.x == 0) one_arrive_and_wait(sync, epoch, G, last);
+  if (threadIdx.x == 0) one_arrive_and_wait(sync, epoch, og, last);
   __syncthreads();
   if (threadIdx.x < 5) {
-    const uint32_t cur = ld_dev(&sync[832 + threadIdx.x]);
+    const uint32_t cur = ld_dev(&sync[kSyncTotal + threadIdx.x]);
     s_out[threadIdx.x] = cur - cprev;
     cprev = cur;
   }
@@ -114,15 +118,16 @@ __device__ __forceinline__ void one_grid_sync_counts(uint32_t* sync, uint32_t& e
 // The barrier behind the rows of sums, with the first level of their fold inside it: the last workgroup of a group to arrive adds
 // the group's rows -- in the order of their workgroups, whoever arrives last -- and publishes the group's row before it arrives
 // for the group.  (Every workgroup reading all 472 rows would pull 57 MB through the fabric per iteration.)
-__device__ __forceinline__ void one_grid_sync_fold(uint32_t* sync, uint32_t& epoch, uint32_t G, const double* rows, double* grows,
+__device__ __forceinline__ void one_grid_sync_fold(uint32_t* sync, uint32_t& epoch, OneGrid og, const double* rows, double* grows,
                                                   double (*s_part)[32], uint32_t* s_flag) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   ++epoch;
-  const uint32_t g = blockIdx.x & (kOneGroups - 1);
+  const uint32_t G = og.G;
+  const uint32_t g = blockIdx.x & (og.NG - 1);
   if (threadIdx.x == 0) {
-    const uint32_t old = __hip_atomic_fetch_add(&sync[64 + 32 * g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *s_flag = old + 1u == epoch * (G / kOneGroups) ? 1u : 0u;
+    const uint32_t old = __hip_atomic_fetch_add(&sync[kSyncArrive + 32 * g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_flag = old + 1u == epoch * (G / og.NG) ? 1u : 0u;
   }
   __syncthreads();
   const bool last = *s_flag != 0u;
@@ -130,7 +135,7 @@ __device__ __forceinline__ void one_grid_sync_fold(uint32_t* sync, uint32_t& epo
     const int col = threadIdx.x & 31, sub = threadIdx.x >> 5;
     double s = 0;
 #pragma unroll 8
-    for (uint32_t w = g + kOneGroups * sub; w < G; w += kOneGroups * 8)
+    for (uint32_t w = g + og.NG * sub; w < G; w += og.NG * 8)
       s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(rows + (size_t)w * kAccCols + col), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     s_part[sub][col] = s;
     __syncthreads();
@@ -142,7 +147,7 @@ __device__ __forceinline__ void one_grid_sync_fold(uint32_t* sync, uint32_t& epo
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  if (threadIdx.x == 0) one_arrive_and_wait(sync, epoch, G, last);
+  if (threadIdx.x == 0) one_arrive_and_wait(sync, epoch, og, last);
   __syncthreads();
 }
 __device__ __forceinline__ double uniform_f64(double v) {
@@ -164,9 +169,10 @@ __device__ __noinline__ void one_tail(TailOpts o, PairState* ls, int pair, const
 #define SMHIP_OPH(k) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b) {
+__global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
   const int pair = b.pair_base;
   const uint32_t G = gridDim.x;
+  const OneGrid og = {G, (uint32_t)groups};
   PairState* st = &b.state[pair];
   __shared__ PairState ls;
   __shared__ uint32_t s_hist[kHistBins];
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b) {
   uint32_t* sync = b.one_sync;
   uint32_t* gkeys = reinterpret_cast<uint32_t*>(b.rec_j + (size_t)pair * 2 * b.bl_stride);
   double* rows = b.one_rows;                              // [G][kAccCols] the workgroups' rows of sums
-  double* grows = b.one_rows + (size_t)kOneMaxBlocks * kAccCols;   // [kOneGroups][kAccCols] the groups'
+  double* grows = b.one_rows + (size_t)kOneMaxBlocks * kAccCols;   // [groups][kAccCols] the groups'
   uint32_t target = 0;
   // The pair's histogram is never cleared inside the launch: every workgroup remembers the eight words it owns as it last read them
   // and takes the difference (a store that clears a word other workgroups add to would have to be ordered against their atomics)
@@ -327,11 +333,11 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b) {
     block_reduce29(acc, s_red, dst);
     if (threadIdx.x < ncols) st_dev(&rows[(size_t)blockIdx.x * kAccCols + threadIdx.x], dst[threadIdx.x]);
     SMHIP_OPH(9);
-    one_grid_sync_fold(sync, target, G, rows, grows, s_part, &s_misc[3]);
+    one_grid_sync_fold(sync, target, og, rows, grows, s_part, &s_misc[3]);
     SMHIP_OPH(10);
     if (threadIdx.x < kAccCols) {
       double s = 0;
-      for (int k = 0; k < kOneGroups; ++k)
+      for (uint32_t k = 0; k < og.NG; ++k)
         s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(grows + (size_t)k * kAccCols + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       dst[threadIdx.x] = s;
     }
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b) {
         if (threadIdx.x < 5) s_cnt[threadIdx.x] = threadIdx.x == 0 ? (tot & 0xffffu) : (threadIdx.x == 1 ? tot >> 16 : (blo + (threadIdx.x - 2) <= bhi ? s_hist[blo + (threadIdx.x - 2)] : 0u));
       }
       SMHIP_OPH(9);
-      one_grid_sync_counts(sync, target, G, s_cnt, s_cnt + 8, cprev, &s_misc[3]);
+      one_grid_sync_counts(sync, target, og, s_cnt, s_cnt + 8, cprev, &s_misc[3]);
       SMHIP_OPH(10);
       if (threadIdx.x == 0) {
         read_counters();
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b) {
       // ---------------- the plain form: the pair's histogram, the quantile's bin, the sums below it, the exact select inside it
       flush_hist(b, pair, s_hist);
       SMHIP_OPH(1);
-      one_grid_sync(sync, target, G);
+      one_grid_sync(sync, target, og);
       SMHIP_OPH(2);
       // V: the quantile's bin; do the lower bounds stand above it?  (nn_validate)
       uint32_t hraw[kHistBins / kNnThreads], hcnt[kHistBins / kNnThreads];
@@ -501,7 +507,7 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b) {
         __syncthreads();
         if (threadIdx.x == 0 && s_misc[6]) atomicAdd(&st->unresolved_count, s_misc[6]);
         flush_hist(b, pair, s_hist);
-        one_grid_sync(sync, target, G);
+        one_grid_sync(sync, target, og);
 #pragma unroll
         for (int k = 0; k < kHistBins / kNnThreads; ++k) hraw[k] = ld_dev(&gh[threadIdx.x * (kHistBins / kNnThreads) + k]);
 #pragma unroll
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b) {
         wcount = 0;
       }
       SMHIP_OPH(4);
-      one_grid_sync(sync, target, G);
+      one_grid_sync(sync, target, og);
       SMHIP_OPH(5);
       clear_counters();
       // F1: the exact quantile, the bin's members at or below it; F2: the rows
@@ -576,11 +582,11 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b) {
       if (threadIdx.x == 1) v = (double)(((s_wc[0] + s_wc[1]) + s_wc[2]) + s_wc[3]);
       st_dev(&rows[(size_t)blockIdx.x * kAccCols + threadIdx.x], v);
     }
-    one_grid_sync_fold(sync, target, G, rows, grows, s_part, &s_misc[3]);
+    one_grid_sync_fold(sync, target, og, rows, grows, s_part, &s_misc[3]);
     if (blockIdx.x != 0) return;
     if (threadIdx.x < 2) {
       double t = 0;
-      for (int k = 0; k < kOneGroups; ++k)
+      for (uint32_t k = 0; k < og.NG; ++k)
         t += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(grows + (size_t)k * kAccCols + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       s_part[0][threadIdx.x] = t;
     }

@@ -76,6 +76,7 @@ struct smhip_context {
   int one_blocks = 0;            // workgroups of the single-pair persistent kernel the device holds at once (0: not available)
   int one_used = 0;              // the last single-pair enqueue went through it
   int one_enabled = 1;           // SMHIP_ONE_PAIR=0: single pairs through the separate launches (measurement aid)
+  int one_groups_want = 0;       // SMHIP_ONE_GROUPS: groups of its barrier (tuning)
   int one_blocks_want = 0;       // SMHIP_ONE_BLOCKS: its grid (tuning; 0 = as many as a round each needs, at most what is resident)
   int wave_search = 0;           // batches: the every-query-searches iterations through nn_ball_lds (0, default: 5-25 % faster on the bench scans)
                                  // or nn_ball_wave (1; SMHIP_WAVE_SEARCH=1) -- same results
@@ -557,6 +558,8 @@ void sync_options(smhip_context* h) {
   h->one_enabled = 1; h->one_blocks_want = 0;
   { const char* e = std::getenv("SMHIP_ONE_PAIR"); if (e) h->one_enabled = std::atoi(e); }
   { const char* e = std::getenv("SMHIP_ONE_BLOCKS"); if (e) h->one_blocks_want = std::atoi(e); }
+  h->one_groups_want = 0;
+  { const char* e = std::getenv("SMHIP_ONE_GROUPS"); if (e) h->one_groups_want = std::atoi(e); }
   h->sums_blocks = kSumsBlocks;
   { const char* e = std::getenv("SMHIP_SUMS_BLOCKS"); if (e && std::atoi(e) >= 8) h->sums_blocks = (std::min(std::atoi(e), 65536) / 8) * 8; }
   h->dev.listed_grain = 1;
@@ -709,7 +712,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, &d.tpart, B * kTgtReduceBlocks * 16));
   A(dev_alloc(h, &d.done_count, 4));
   A(dev_alloc(h, &d.one_sync, (size_t)kOneSyncWords));
-  A(dev_alloc(h, &d.one_rows, (size_t)(kOneMaxBlocks + 8) * kAccCols));
+  A(dev_alloc(h, &d.one_rows, (size_t)(kOneMaxBlocks + 32) * kAccCols));
   A(dev_alloc(h, &h->ids_dev, NS));
   A(dev_alloc(h, &h->d2_dev, NS));
   if (s == SMHIP_OK) {
@@ -728,7 +731,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
     int per_cu = 0, coop = 0;
     if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) == hipSuccess && coop &&
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, icp_one, kNnThreads, 0) == hipSuccess && per_cu > 0)
-      h->one_blocks = (std::min(per_cu * prop.multiProcessorCount, kOneMaxBlocks) / 8) * 8;
+      h->one_blocks = (std::min(per_cu * prop.multiProcessorCount, kOneMaxBlocks) / 32) * 32;
     (void)hipGetLastError();
     if (hipMemsetAsync(d.one_sync, 0, sizeof(uint32_t) * kOneSyncWords, h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
   }
@@ -1235,6 +1238,7 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
                              ceil_div(ns_max, kAccThreads * kAccItemsSmall) * (kAccThreads / 64) > kFinalizeMaxSeg) ? kAccItemsBatch : kAccItemsSmall;
   }
   const int max_it = h->dev.max_iteration;
+  bool grid_built = false;
   // One pair (the front end's call, map_builder.cc:317-333): the whole loop and the score as ONE cooperative launch whose workgroups
   // meet at grid barriers (icp_one.hip) -- the same matches, distances and kept sets as the launches below.
   h->one_used = 0;
@@ -1245,16 +1249,28 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
     // 1.15-1.18 ms, 320: 1.11-1.15, 240: 1.06-1.11, 160: 1.04-1.13 -- a barrier waits for the slowest workgroup, and two rounds
     // even out what one round's few searching queries cost); a multiple of 8: the barrier's groups
     int G = h->one_blocks_want > 0 ? std::max(8, (h->one_blocks_want / 8) * 8) : ((ceil_div(nrounds, 2) + 7) / 8) * 8;
-    G = std::min(std::min(G, h->one_blocks), ((nrounds + 7) / 8) * 8);
+    G = std::min(G, ((nrounds + 7) / 8) * 8);
+    if (G >= 64) G = ((G + 31) / 32) * 32;                 // (whole groups of the barrier; workgroups beyond the rounds only take part in the barriers)
+    G = std::min(G, h->one_blocks);
     if (ceil_div(nrounds, G) <= kOneMaxRounds) {
       if (!cached_one) { s = enqueue_grid_build(h, halves[0], nt_max); if (s) return s; }
+      grid_built = true;
       IcpDev d1 = halves[0].d;
       d1.fused = 0; d1.fused_nabo = 0;
-      void* args[] = {&d1};
-      HIPCHK(h, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(icp_one), dim3(G), dim3(kNnThreads), args, 0, h->stream));
-      h->one_used = 1;
-      h->last_npairs = npairs;
-      return SMHIP_OK;
+      // the barrier's groups: 8 (measured on 256 / 480 workgroups: 8 or 16 groups equal, 32 groups 7 % slower -- the barriers wait for
+      // the slowest workgroup, not for their own atomics; SMHIP_ONE_GROUPS overrides)
+      int groups = 8;
+      if (h->one_groups_want > 0 && (h->one_groups_want & (h->one_groups_want - 1)) == 0 && h->one_groups_want <= 32 && G % h->one_groups_want == 0) groups = h->one_groups_want;
+      void* args[] = {&d1, &groups};
+      if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(icp_one), dim3(G), dim3(kNnThreads), args, 0, h->stream) == hipSuccess) {
+        h->one_used = 1;
+        h->last_npairs = npairs;
+        return SMHIP_OK;
+      }
+      // the runtime refused the cooperative launch (it cannot place the grid): not an error of the Align -- the same iterations as
+      // separate launches below, and no further attempts on this handle
+      (void)hipGetLastError();
+      h->one_blocks = 0;
     }
   }
   // one iteration of one part: FindClosests, the sums, finalize
@@ -1293,7 +1309,7 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
   // with 2, 3, 4 or 8 parts (24.0 / 23.9 / 23.5 / 18.7 k alignments/s against 24.4 k in lock-step).  Side by side the two kernels
   // split the registers: the certificate pass needs all of its waves to keep ~10 MB in flight, the search all of its to fill the
   // SIMDs, and each runs as much slower as the other gains.)
-  if (!cached_one) for (int k = 0; k < nh; ++k) { s = enqueue_grid_build(h, halves[k], nt_max); if (s) return s; }
+  if (!cached_one && !grid_built) for (int k = 0; k < nh; ++k) { s = enqueue_grid_build(h, halves[k], nt_max); if (s) return s; }
   for (int it = 0; it < max_it; ++it) {
     for (int k = 0; k < nh; ++k) {
       s = enqueue_iteration(halves[k], it);

@@ -4,7 +4,7 @@ known-byte kernels of the same access shape (tools/traffic_calib.sh -> profiles/
 per kernel instead of the bracket the guide's 16 B/lane rule left (MI355X_MICROARCH.md, HBM section).
 Usage: traffic_json.py <fetch dir> <write dir> <kernel substring> <pairs per launch> <source points> <algorithmic B/pt>
                        <implementation B/pt> [calibration.json] [json name of the kernel]"""
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, sys
 
 
 def avg(d, name, counter):
@@ -27,8 +27,15 @@ if calib_path and os.path.exists(calib_path):
         ff, wf = float(c["fetch_factor_stream_12_4_4"]), float(c["write_factor_dword"])
         src = (f"{os.path.basename(calib_path)}: true bytes / (counter x 1024) of a known-byte kernel reading a 12-byte row + int + float and "
                f"writing one float per element (the shape of nn_certify / accumulate): FETCH_SIZE x {ff:.4f}, WRITE_SIZE x {wf:.4f}")
+# the record is dated with the kernel sources it was measured on: bench.py uses it only while they are unchanged
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SOURCES = ["staticmapping_amd/csrc/icp_kernels.hip", "staticmapping_amd/csrc/smhip_device.h"]
+_h = hashlib.sha256()
+for _f in sorted(SOURCES):
+    with open(os.path.join(ROOT, _f), "rb") as _fh:
+        _h.update(_fh.read())
 print(json.dumps({
-    "kernel": sys.argv[9] if len(sys.argv) > 9 else kernel, "pairs_per_launch": pairs, "nn_mode": "grid", "source_points": ns,
+    "kernel": sys.argv[9] if len(sys.argv) > 9 else kernel, "source_files": SOURCES, "source_sha": _h.hexdigest(), "pairs_per_launch": pairs, "nn_mode": "grid", "source_points": ns,
     "fetch_size_kb_per_launch": round(fetch), "write_size_kb_per_launch": round(write), "launches_averaged": [nf, nw],
     "fetch_factor": ff, "write_factor": wf, "factors_from": src,
     "hbm_bytes_per_launch": int((ff * fetch + wf * write) * 1024),
@@ -36,7 +43,7 @@ print(json.dumps({
     "algorithmic_bytes_per_launch": int(alg * pairs * ns),
     "compulsory_bytes_of_this_implementation": int(impl * pairs * ns),
     "ratio_to_algorithmic": round((ff * fetch + wf * write) * 1024 / max(1.0, alg * pairs * ns), 4),
-    "how": "tools/round_profile.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE and a separate --pmc WRITE_SIZE pass of "
-           "tools/profile_target.py B=512 reps=1 (two 256-pair halves on two streams), averaged over the kernel's launches; "
+    "how": "tools/r06_final.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE and a separate --pmc WRITE_SIZE pass of "
+           "tools/fused_probe.py pairs=512 distinct=512 (the bench workload, two 256-pair halves on two streams), averaged over the kernel's launches; "
            "bytes = (fetch_factor * FETCH_SIZE + write_factor * WRITE_SIZE) * 1024 (the counters are in KB)",
 }, indent=1))

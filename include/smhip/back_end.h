@@ -190,6 +190,11 @@ class SubmapMatcherPool {
     for (int k = 0; k < std::max(1, concurrency); ++k) {
       auto m = registrator::CreateMatcher(options, false);
       SMHIP_CHECK(m != nullptr, "CreateMatcher returned null");
+      // members of a pool align at the same time: IcpFast's single-pair cooperative launch would queue them one behind the other
+      if (concurrency > 1 && options.type == registrator::kFastIcp) {
+        m->InitWithXml("<param name=\"single_launch\"> 0 </param>");
+        m->InitWithOptions();
+      }
       matchers_.push_back(m);
     }
   }

@@ -291,6 +291,10 @@ class IcpFastHip : public Interface {
     SMHIP_REG_REGISTRATOR_INNER_OPTION("nn_epsilon", OptionItemDataType::kFloat32, options_.nn_epsilon);
     SMHIP_REG_REGISTRATOR_INNER_OPTION("grid_cell", OptionItemDataType::kFloat32, options_.grid_cell);
     SMHIP_REG_REGISTRATOR_INNER_OPTION("exact_matches", OptionItemDataType::kBool, options_.exact_matches);
+    // true (default): a single Align is ONE cooperative launch (csrc/icp_one.hip) -- the front end's one-pair-at-a-time call.  Matchers
+    // that align at the same time from several threads (the back end's pool of six) set it false: cooperative launches of several
+    // handles run one after the other on the device's cooperative queue (six threads: 583 Aligns/s against 781 as separate launches).
+    SMHIP_REG_REGISTRATOR_INNER_OPTION("single_launch", OptionItemDataType::kBool, options_.single_launch);
   }
 
   void InitWithOptions() override { EnsureHandle(0, 0, true, true); }
@@ -444,6 +448,7 @@ class IcpFastHip : public Interface {
     o.nn_epsilon = options_.nn_epsilon;
     o.grid_cell = options_.grid_cell;
     o.exact_matches = options_.exact_matches ? 1 : 0;
+    o.no_single_kernel = options_.single_launch ? 0 : 1;
     return Ok(smhip_icp_set_options(h, &o), "smhip_icp_set_options");
   }
   // Handle with room for ns / nt points (0 = whatever it has).  After a re-creation the clouds the old handle held
@@ -472,6 +477,7 @@ class IcpFastHip : public Interface {
     float nn_epsilon = 3.16f;                // icp_fast.cc:174
     float grid_cell = 0.25f;
     bool exact_matches = false;
+    bool single_launch = true;
   } options_;
   int32_t device_ = 0;
   int32_t max_points_;

@@ -143,3 +143,31 @@ def test_identical_clouds_and_no_match_cases(smhip, cfg1):
         m.align(np.eye(4))
     assert m.last_stats[0]["status"] != 0
     m.close()
+
+
+def test_six_matchers_align_at_once(smhip, cfg2):
+    """Six host threads, a matcher each, single 120 k-point Aligns at the same time (the back end's pool, builder/map_builder.cc:399-446,
+    655): six grids of 256 resident workgroups do not fit the device together -- the cooperative launches must queue, not deadlock, and
+    every result must be the single-threaded run's bits."""
+    import threading
+    c = cfg2
+    opts = dict(max_iteration=20, early_exit=0)
+    ref = _run(smhip, c, c["guess"], **opts)[0]
+    err = []
+
+    def work(k):
+        try:
+            m = smhip.IcpFastHip(max_source_points=len(c["src"]), max_target_points=len(c["q"]), **opts)
+            m.set_input_source(c["src"]); m.set_input_target(c["q"], c["n"])
+            for _ in range(5):
+                if not np.array_equal(m.align(c["guess"])[1], ref):
+                    err.append((k, "differs"))
+            m.close()
+        except Exception as e:      # noqa: BLE001
+            err.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    for t in threads: t.start()
+    for t in threads: t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a matcher did not return"
+    assert not err, err

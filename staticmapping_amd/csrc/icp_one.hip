@@ -369,12 +369,97 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
 
   for (;;) {
     // ---------------- S: FindClosests (icp_fast.cc:486-493)
+#if SMHIP_ONE_TIMING
+    const unsigned long long s_t0 = wall_clock64();
+#endif
 #pragma unroll
     for (int k = 0; k < 12; ++k) Mc[k] = uniform_f64(ls.M[k]);
     for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
     uint32_t min_lb = 0xffffffffu;
-    for (int r = blockIdx.x; r < nrounds; r += (int)G) ball_lds_rounds<1, false>(b, st, &ls, pair, r * kNnThreads, Mc, s_hist, min_lb);
+    if (ls.iter == 0 || (b.debug_flags & 256)) {
+      // every query searches: the rounds of nn_ball_lds (the workgroup's queries walk the rows of their balls from LDS tables)
+      for (int r = blockIdx.x; r < nrounds; r += (int)G) ball_lds_rounds<1, false>(b, st, &ls, pair, r * kNnThreads, Mc, s_hist, min_lb);
+    } else {
+      // Later iterations: the certificate for every query (nn_certify), then the few whose certificate fails (6 % of them in a
+      // settled iteration: ~30 of a workgroup's 512) searched with as many lanes each as the workgroup has to spare (the listed
+      // search, listed_search_one: a lane takes every L-th row of the query's ball, the lanes' results merged with the sweep's tie
+      // rule) -- where nn_ball_lds gives a failing query ONE lane and walks the workgroup through its staging barriers for it
+      // (8 us per round against 3).  The same matches either way (every search here is exact); the recorded bounds differ in
+      // their search radius, as they do between the two forms of the batched path.
+      int* s_fail = &s_rec[0][0];                            // (collect's list: not in use during S)
+      if (threadIdx.x == 0) s_misc[7] = 0;
+      __syncthreads();
+      const Pot pot = {(float)ls.pot_a, (float)ls.pot_b, 0.f, 0.f};
+      const float r_need = 0.9f * sqrtf(ls.rcap2);
+      const float4* __restrict__ tq = b.tq + to;
+      for (int r = blockIdx.x; r < nrounds; r += (int)G) {
+        const int i = r * kNnThreads + (int)threadIdx.x;
+        bool hard = false, fail = false;
+        if (i < ns) {
+          const float4 s = ld_src(b, so + i);
+          const float l = ld_lb(b, so + i);
+          const int j = b.idx[so + i];
+          const float4 t = tq[max(j, 0)];
+          double px, py, pz;
+          transform_point(Mc, s, px, py, pz);
+          const float qx = (float)px, qy = (float)py, qz = (float)pz;
+          const float Lp = bound_now(l, pot_at(pot, norm3(s.x, s.y, s.z)));
+          fail = true;
+          if (isfinite(qx) && isfinite(qy) && isfinite(qz) && Lp > 0.f) {
+            if (l > 0.f && j >= 0) {
+              const float d1 = dist2(t, qx, qy, qz);
+              if (d1 < Lp * Lp) {                              // still the unique nearest neighbour: exact, no search
+                b.d2[so + i] = d1;
+                atomicAdd(&s_hist[__float_as_uint(d1) >> kHistShift], 1u);
+                fail = false;
+              }
+            } else if (l < 0.f && Lp >= r_need) {              // still provably farther than the trimming radius
+              const float lb2 = Lp * Lp;
+              b.d2[so + i] = lb2;
+              atomicAdd(&s_hist[__float_as_uint(lb2) >> kHistShift], 1u);
+              min_lb = min(min_lb, __float_as_uint(lb2));
+              hard = true;
+              fail = false;
+            }
+          }
+        }
+        const unsigned long long fm = __ballot(fail);
+        if (fm) {
+          uint32_t basepos = 0;
+          if (lane == 0) basepos = atomicAdd(&s_misc[7], (uint32_t)__popcll(fm));
+          basepos = (uint32_t)__builtin_amdgcn_readlane((int)basepos, 0);
+          if (fail) s_fail[basepos + rank_below(fm)] = i;
+        }
+        const unsigned long long hm = __ballot(hard);
+        if (lane == 0 && hm) atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
+      }
+      __syncthreads();
+      const int nf = (int)s_misc[7];
+      if (threadIdx.x == 0 && nf) atomicAdd(&st->deferred_count, (uint32_t)nf);
+      if (nf > 0) {
+        const ListedCtx ctx = listed_ctx(b, &ls, pair);
+        int logL = 0;
+        while (logL < 4 && (nf << (logL + 1)) <= kNnThreads) ++logL;
+        const int L = 1 << logL, per = kNnThreads >> logL;
+        const int sub = (int)threadIdx.x & (L - 1), qi = (int)threadIdx.x >> logL;
+        for (int base = 0; base < nf; base += per) {
+          const int i = base + qi < nf ? s_fail[base + qi] : -1;
+          bool hard = false, band = false;
+          float4 srec; float drec; int jrec;
+          listed_search_one(b, &ls, ctx, so, i, sub, L, s_hist, min_lb, hard, false, 0, 0, band, srec, drec, jrec);
+          const unsigned long long hm = __ballot(hard && sub == 0);
+          if (lane == 0 && hm) atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
+        }
+      }
+      __syncthreads();                                        // (s_fail is collect's list again)
+    }
     flush_min_lb(st, min_lb);
+#if SMHIP_ONE_TIMING
+    if ((b.debug_flags & 64) && threadIdx.x == 0) {          // how long S took in every workgroup: the largest and the sum (sync[40], [41])
+      const uint32_t dtS = (uint32_t)(wall_clock64() - s_t0);
+      atomicMax(&sync[40], dtS); atomicAdd(&sync[41], dtS);
+    }
+#endif
     SMHIP_OPH(0);
     uint32_t n_valid = 0, limit_key = 0;
     bool have_sums = false;
@@ -602,6 +687,7 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
     unsigned long long tot = 0;
     for (int k = 0; k < 13; ++k) tot += oacc[k];
     const double u = 0.01 / ls.iter;
+    printf("[icp_one] S over the workgroups: largest %.1f us (of any iteration), mean %.1f us\n", ld_dev(&sync[40]) * 0.01, ld_dev(&sync[41]) * 0.01 / ((double)G * ls.iter));
     printf("[icp_one] iterations %d grid %u us per iteration: S %.1f flush %.1f bar1 %.1f V %.1f A %.1f bar2 %.1f F1 (keys %.1f select %.1f records %.1f reduce %.1f) bar3 %.1f fold %.1f tail %.1f | total %.1f us\n",
            ls.iter, G, oacc[0] * u, oacc[1] * u, oacc[2] * u, oacc[3] * u, oacc[4] * u, oacc[5] * u, oacc[6] * u, oacc[7] * u, oacc[8] * u, oacc[9] * u, oacc[10] * u,
            oacc[11] * u, oacc[12] * u, tot * 0.01);

@@ -43,8 +43,11 @@ def _same_alignment(sm, a, b, what):
         assert ta[k] == tb[k], (what, k, ta[k], tb[k])
     assert abs(ta["kept"] - tb["kept"]) <= 2, (what, ta["kept"], tb["kept"])
     assert abs(ta["limit_d2"] - tb["limit_d2"]) <= 1e-6 * abs(tb["limit_d2"]), (what, ta["limit_d2"], tb["limit_d2"])
-    for k in ("hard_queries", "searched_queries"):
-        assert abs(ta[k] - tb[k]) <= 0.01 * max(ta[k], tb[k]) + 2, (what, k, ta[k], tb[k])
+    # (how many queries had to be searched again is a property of the recorded bounds, not of the result: the one launch searches
+    # its failing queries with the listed search, whose radius margin is the query's own motion; the separate launches of a single
+    # pair with nn_ball_lds, whose margin is the pair's motion bound)
+    for k, tol in (("hard_queries", 0.10), ("searched_queries", 0.10)):
+        assert abs(ta[k] - tb[k]) <= tol * max(ta[k], tb[k]) + 2, (what, k, ta[k], tb[k])
     da, dt = sm.se3_error(Ra, Rb)
     assert da < 1e-11 and dt < 1e-11, (what, da, dt)
     assert abs(sa - sb) <= 1e-12 * max(1.0, abs(sa)), (what, sa, sb)
@@ -125,7 +128,7 @@ def test_too_many_rounds_take_the_separate_launches(smhip, cfg2, monkeypatch):
     few = _run(smhip, c, c["guess"], **opts)
     monkeypatch.delenv("SMHIP_ONE_BLOCKS")
     for k in ("iterations", "kept", "limit_d2", "searched_queries"):
-        assert few[2][k] == sep[2][k]
+        assert few[2][k] == sep[2][k], k
     assert np.array_equal(few[0], sep[0])
 
 

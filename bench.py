@@ -490,6 +490,17 @@ def main():
                 "nn_mode NABO: libnabo 1.0.7's KDTREE_LINEAR_HEAP tree rebuilt per Align and its epsilon = 3.16 approximate knn "
                 "(icp_fast.cc:169-180, 464-467) walked on the device; *_vs_oracle here is against the oracle run with the SAME "
                 "approximate search -- the parity the exact modes cannot have (see parity.exact_vs_reference_eps3.16)")
+        # the reference's own search semantics as a peer of the headline: the only mode a maintainer can diff against a libnabo build
+        fr = out["figures"].get("reference_search_eps3.16")
+        if fr:
+            rs = (out.get("roofline") or {}).get("reference_search") or {}
+            out["reference_search"] = {"value": fr["value"], "unit": "alignments/s", "nn_mode": "nabo", "nn_epsilon": 3.16,
+                                       "whole_alignment_frac": (fr.get("whole_alignment_roofline") or {}).get("frac"),
+                                       "worst_rot_vs_oracle_rad": fr.get("worst_rot_vs_oracle_rad"), "worst_trans_vs_oracle_m": fr.get("worst_trans_vs_oracle_m"),
+                                       "pairs_checked_vs_oracle": fr.get("pairs_checked_vs_oracle"),
+                                       "walked_queries_per_alignment_after_iteration_0": rs.get("walked_queries_per_alignment_after_iteration_0"),
+                                       "dominant_class": rs.get("kernel"), "dominant_class_ms_per_step": rs.get("kernel_ms_per_step"),
+                                       "oracle": "oracle/csrc/smref_icp.c with libnabo's tree and epsilon = 3.16 knn restated (the SAME approximate search)"}
     m.close()
     if rank == 0 and world == 1 and not args.no_other:
         out["single_pair"] = single_pair_latency(work[0], dev_index)

@@ -56,7 +56,9 @@ __device__ __forceinline__ void st_dev(double* p, double v) {
 // 6.2 us per barrier -- same-address atomics complete one every ~13 ns --, two levels 2.1 us.
 constexpr int kOneMaxGroups = 32;
 constexpr int kSyncArrive = 64, kSyncFlag = kSyncArrive + 32 * kOneMaxGroups, kSyncCount = kSyncFlag + 32 * kOneMaxGroups, kSyncTotal = kSyncCount + 32 * kOneMaxGroups;
-static_assert(kSyncTotal + 32 <= kOneSyncWords, "IcpDev::one_sync holds the barrier's lines");
+constexpr int kSyncKeys = kSyncTotal + 32;        // + 32 p: length of the key list of the iterations of parity p
+constexpr int kSyncMinLb = kSyncKeys + 64;        // + 32 p: ~(the smallest lower bound recorded) of the iterations of parity p (0: none)
+static_assert(kSyncMinLb + 64 <= kOneSyncWords, "IcpDev::one_sync holds the barrier's lines");
 struct OneGrid { uint32_t G, NG; };       // workgroups, groups (a power of two that divides G)
 __device__ __forceinline__ void one_arrive_and_wait(uint32_t* sync, uint32_t epoch, OneGrid og, bool group_last) {
   const uint32_t g = blockIdx.x & (og.NG - 1);
@@ -65,7 +67,19 @@ __device__ __forceinline__ void one_arrive_and_wait(uint32_t* sync, uint32_t epo
     if (old + 1u == epoch * og.NG)
       for (uint32_t k = 0; k < og.NG; ++k) st_dev(&sync[kSyncFlag + 32 * k], epoch);
   }
-  while (ld_dev(&sync[kSyncFlag + 32 * g]) < epoch) __builtin_amdgcn_s_sleep(1);
+  // (a watchdog instead of an endless spin: a barrier that has not completed after 0.2 s -- a thousand times the longest
+  // iteration -- says so and stops the launch; the host then reports the error instead of hanging)
+  const unsigned long long t0 = wall_clock64();
+  uint32_t polls = 0;
+  while (ld_dev(&sync[kSyncFlag + 32 * g]) < epoch) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++polls & 0xfffu) == 0u && wall_clock64() - t0 > 20000000ull) {
+      printf("[icp_one] barrier timeout: pair row %u workgroup %u of %u, epoch %u: group arrivals %u (want %u), top arrivals %u (want %u), flag %u\n",
+             (unsigned)blockIdx.y, (unsigned)blockIdx.x, og.G, epoch, ld_dev(&sync[kSyncArrive + 32 * g]), epoch * (og.G / og.NG), ld_dev(&sync[0]), epoch * og.NG,
+             ld_dev(&sync[kSyncFlag + 32 * g]));
+      __builtin_trap();
+    }
+  }
 }
 __device__ __forceinline__ void one_grid_sync(uint32_t* sync, uint32_t& epoch, OneGrid og) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // this wave's write-through stores and atomics have completed
@@ -170,7 +184,7 @@ __device__ __noinline__ void one_tail(TailOpts o, PairState* ls, int pair, const
 #endif
 
 __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
-  const int pair = b.pair_base;
+  const int pair = b.pair_base + (int)blockIdx.y;          // (a launch holds up to kOnePairs pairs: a row of the grid each, nothing shared)
   const uint32_t G = gridDim.x;
   const OneGrid og = {G, (uint32_t)groups};
   PairState* st = &b.state[pair];
@@ -201,10 +215,20 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t so = (size_t)pair * b.ns_cap, to = (size_t)pair * b.nt_cap;
   uint32_t* gh = b.hist + (size_t)pair * kHistBins;
-  uint32_t* sync = b.one_sync;
-  uint32_t* gkeys = reinterpret_cast<uint32_t*>(b.rec_j + (size_t)pair * 2 * b.bl_stride);
-  double* rows = b.one_rows;                              // [G][kAccCols] the workgroups' rows of sums
-  double* grows = b.one_rows + (size_t)kOneMaxBlocks * kAccCols;   // [groups][kAccCols] the groups'
+  uint32_t* sync = b.one_sync + (size_t)blockIdx.y * kOneSyncWords;
+  uint32_t* gkeys0 = reinterpret_cast<uint32_t*>(b.rec_j + (size_t)pair * 2 * b.bl_stride);
+  // What every workgroup adds to is never cleared while any of them may still read it or may already be adding again: the counters
+  // of searched / lower-bounded / unresolved queries are cumulative (cnt_prev: what this workgroup had read of them when the
+  // iteration began), the key list and the smallest-bound word exist twice -- an iteration uses those of its parity, and workgroup 0
+  // clears the other parity's behind the iteration's first barrier, an iteration after their last reader and a barrier before their
+  // next writer.  (As first built, workgroup 0 cleared them behind the iteration's LAST barrier: nothing stood between that and the
+  // fast workgroups' next additions -- a batch of two pairs with most workgroups idle lost counts and, once, hung.)
+  uint32_t cnt_prev[3] = {0u, 0u, 0u};                   // hard_count, deferred_count, unresolved_count
+  uint32_t* gkeys = gkeys0;                              // this iteration's key list and its length
+  uint32_t* key_count = &sync[kSyncKeys];
+  uint32_t* min_lb_word = &sync[kSyncMinLb];
+  double* rows = b.one_rows + (size_t)blockIdx.y * (kOneMaxBlocks + 32) * kAccCols;   // [G][kAccCols] the workgroups' rows of sums
+  double* grows = rows + (size_t)kOneMaxBlocks * kAccCols;            // [groups][kAccCols] the groups'
   uint32_t target = 0;
   // The pair's histogram is never cleared inside the launch: every workgroup remembers the eight words it owns as it last read them
   // and takes the difference (a store that clears a word other workgroups add to would have to be ordered against their atomics)
@@ -212,7 +236,7 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
 #pragma unroll
   for (int k = 0; k < kHistBins / kNnThreads; ++k) hprev[k] = 0u;
 #if SMHIP_ONE_TIMING
-  const bool otime = (b.debug_flags & 64) && threadIdx.x == 0 && blockIdx.x == 0;
+  const bool otime = (b.debug_flags & 64) && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0;
   unsigned long long oacc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long oprev = otime ? wall_clock64() : 0ull;
 #endif
@@ -252,7 +276,7 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
     __syncthreads();
     if (threadIdx.x == 0) {
       const uint32_t total = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
-      s_misc[1] = total ? __hip_atomic_fetch_add(&sync[32], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      s_misc[1] = total ? __hip_atomic_fetch_add(key_count, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     }
     __syncthreads();
     uint32_t base = s_misc[1];
@@ -270,7 +294,7 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
   // list as every workgroup reads it (the order it was appended in does not matter to the VALUE); then this workgroup's listed
   // points at or below it added to acc -- weights = (d2 <= limit), icp_fast.cc:497-498 -- in the order the waves met them.
   auto select_and_add = [&](uint32_t qbin, uint32_t rank) -> uint32_t {
-    const int nb = (int)ld_dev(&sync[32]);
+    const int nb = (int)ld_dev(key_count);
     const bool flat = nb <= kFinalizeKeyCap;
     if (flat) {
       for (int e0 = 0; e0 < nb; e0 += 8 * kNnThreads) {          // eight loads in flight per thread: one pair's ~2 000 keys in one round
@@ -347,24 +371,26 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
   // this iteration's counters, as every workgroup has read them, cleared for the next iteration's S: by exchanges, whose old
   // values have come back before this workgroup arrives at the next barrier (a plain store's completion says less about where
   // it stands against another XCD's atomics on the same word)
-  auto clear_counters = [&]() {
+  // behind the iteration's first barrier: the other parity's key list and smallest-bound word cleared for the next iteration (by
+  // exchanges, whose old values have come back before this workgroup arrives at the next barrier)
+  auto clear_next_parity = [&]() {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-      uint32_t o = __hip_atomic_exchange(&st->hard_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      o |= __hip_atomic_exchange(&st->deferred_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      o |= __hip_atomic_exchange(&st->unresolved_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      o |= __hip_atomic_exchange(&st->fallback_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      o |= __hip_atomic_exchange(&st->min_lb_key, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t q = (uint32_t)(ls.iter + 1) & 1u;
+      uint32_t o = __hip_atomic_exchange(&sync[kSyncKeys + 32 * q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      o |= __hip_atomic_exchange(&sync[kSyncMinLb + 32 * q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_misc[4] = o;
     }
   };
+  // (a fused attempt that missed leaves its candidates in the list the plain form is about to fill: cleared behind the attempt's
+  // barrier, a barrier before the plain form appends)
   auto clear_key_list = [&]() {
-    if (blockIdx.x == 0 && threadIdx.x == 0) s_misc[5] = __hip_atomic_exchange(&sync[32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0 && threadIdx.x == 0) s_misc[5] = __hip_atomic_exchange(key_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  auto read_counters = [&]() {                                    // thread 0
-    ls.hard_count = ld_dev(&st->hard_count);
-    ls.min_lb_key = ld_dev(&st->min_lb_key);
-    ls.deferred_count = ld_dev(&st->deferred_count);
+  auto read_counters = [&]() {                                    // thread 0: this iteration's share of the cumulative counters
+    ls.hard_count = ld_dev(&st->hard_count) - cnt_prev[0];
+    ls.deferred_count = ld_dev(&st->deferred_count) - cnt_prev[1];
     ls.unresolved_count = 0;
+    ls.min_lb_key = ~ld_dev(min_lb_word);
   };
 
   for (;;) {
@@ -376,7 +402,13 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
     for (int k = 0; k < 12; ++k) Mc[k] = uniform_f64(ls.M[k]);
     for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
     uint32_t min_lb = 0xffffffffu;
-    if (ls.iter == 0 || (b.debug_flags & 256)) {
+    {
+      const uint32_t par = (uint32_t)ls.iter & 1u;
+      gkeys = gkeys0 + (size_t)par * b.bl_stride;
+      key_count = &sync[kSyncKeys + 32 * par];
+      min_lb_word = &sync[kSyncMinLb + 32 * par];
+    }
+    if (ls.iter == 0) {
       // every query searches: the rounds of nn_ball_lds (the workgroup's queries walk the rows of their balls from LDS tables)
       for (int r = blockIdx.x; r < nrounds; r += (int)G) ball_lds_rounds<1, false>(b, st, &ls, pair, r * kNnThreads, Mc, s_hist, min_lb);
     } else {
@@ -387,6 +419,7 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
       // (8 us per round against 3).  The same matches either way (every search here is exact); the recorded bounds differ in
       // their search radius, as they do between the two forms of the batched path.
       int* s_fail = &s_rec[0][0];                            // (collect's list: not in use during S)
+      uint32_t asink = 0;                                    // (the additions below return their old values: done once those have come back)
       if (threadIdx.x == 0) s_misc[7] = 0;
       __syncthreads();
       const Pot pot = {(float)ls.pot_a, (float)ls.pot_b, 0.f, 0.f};
@@ -431,11 +464,11 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
           if (fail) s_fail[basepos + rank_below(fm)] = i;
         }
         const unsigned long long hm = __ballot(hard);
-        if (lane == 0 && hm) atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
+        if (lane == 0 && hm) asink |= __hip_atomic_fetch_add(&st->hard_count, (uint32_t)__popcll(hm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
       const int nf = (int)s_misc[7];
-      if (threadIdx.x == 0 && nf) atomicAdd(&st->deferred_count, (uint32_t)nf);
+      if (threadIdx.x == 0 && nf) asink |= __hip_atomic_fetch_add(&st->deferred_count, (uint32_t)nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (nf > 0) {
         const ListedCtx ctx = listed_ctx(b, &ls, pair);
         int logL = 0;
@@ -448,12 +481,19 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
           float4 srec; float drec; int jrec;
           listed_search_one(b, &ls, ctx, so, i, sub, L, s_hist, min_lb, hard, false, 0, 0, band, srec, drec, jrec);
           const unsigned long long hm = __ballot(hard && sub == 0);
-          if (lane == 0 && hm) atomicAdd(&st->hard_count, (uint32_t)__popcll(hm));
+          if (lane == 0 && hm) asink |= __hip_atomic_fetch_add(&st->hard_count, (uint32_t)__popcll(hm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+      asm volatile("" :: "v"(asink));
       __syncthreads();                                        // (s_fail is collect's list again)
     }
-    flush_min_lb(st, min_lb);
+    {   // the smallest lower bound this workgroup recorded -> the iteration's word (kept as its complement: zero = none)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) min_lb = min(min_lb, (uint32_t)__shfl_xor((int)min_lb, off, 64));
+      uint32_t o = 0;
+      if (lane == 0 && min_lb != 0xffffffffu) o = __hip_atomic_fetch_max(min_lb_word, ~min_lb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" :: "v"(o));
+    }
 #if SMHIP_ONE_TIMING
     if ((b.debug_flags & 64) && threadIdx.x == 0) {          // how long S took in every workgroup: the largest and the sum (sync[40], [41])
       const uint32_t dtS = (uint32_t)(wall_clock64() - s_t0);
@@ -462,7 +502,7 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
 #endif
     SMHIP_OPH(0);
     uint32_t n_valid = 0, limit_key = 0;
-    bool have_sums = false;
+    bool have_sums = false, first_barrier_done = false;
     // ---------------- the fused form: finalize_tail predicted the histogram bins this iteration's quantile can fall in
     // ([band_lo, band_hi], at most three; band_lo = 0: no prediction).  Then no histogram crosses workgroups at all: the sums below
     // the band stay in registers, the band's members are listed, and five counts from the workgroup's own LDS histogram -- all
@@ -489,6 +529,8 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
       SMHIP_OPH(9);
       one_grid_sync_counts(sync, target, og, s_cnt, s_cnt + 8, cprev, &s_misc[3]);
       SMHIP_OPH(10);
+      clear_next_parity();
+      first_barrier_done = true;
       if (threadIdx.x == 0) {
         read_counters();
         const uint32_t nv = s_cnt[8], below = s_cnt[9];
@@ -514,8 +556,6 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
         limit_key = select_and_add(s_q[0], s_q[1]);               // acc: the sums below the band + the band's members at or below the exact quantile
         publish_and_fold(s_tot, 29);
         if (threadIdx.x == 0) ls.spec_hits += 1;
-        clear_counters();
-        clear_key_list();
         have_sums = true;
       } else {
         clear_key_list();                                          // (nobody reads the list on a miss; the plain way appends behind its first barrier)
@@ -526,6 +566,7 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
       flush_hist(b, pair, s_hist);
       SMHIP_OPH(1);
       one_grid_sync(sync, target, og);
+      if (!first_barrier_done) clear_next_parity();
       SMHIP_OPH(2);
       // V: the quantile's bin; do the lower bounds stand above it?  (nn_validate)
       uint32_t hraw[kHistBins / kNnThreads], hcnt[kHistBins / kNnThreads];
@@ -590,7 +631,10 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
           }
         }
         __syncthreads();
-        if (threadIdx.x == 0 && s_misc[6]) atomicAdd(&st->unresolved_count, s_misc[6]);
+        if (threadIdx.x == 0 && s_misc[6]) {
+          const uint32_t o = __hip_atomic_fetch_add(&st->unresolved_count, s_misc[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("" :: "v"(o));
+        }
         flush_hist(b, pair, s_hist);
         one_grid_sync(sync, target, og);
 #pragma unroll
@@ -598,7 +642,7 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
 #pragma unroll
         for (int k = 0; k < kHistBins / kNnThreads; ++k) hcnt[k] = hraw[k] - hprev[k];
         find_quantile_bin_counts(hcnt, b.rho, s_w, s_q);
-        if (threadIdx.x == 0) ls.unresolved_count = ld_dev(&st->unresolved_count);
+        if (threadIdx.x == 0) ls.unresolved_count = ld_dev(&st->unresolved_count) - cnt_prev[2];
         __syncthreads();
       }
 #pragma unroll
@@ -616,14 +660,13 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
       SMHIP_OPH(4);
       one_grid_sync(sync, target, og);
       SMHIP_OPH(5);
-      clear_counters();
       // F1: the exact quantile, the bin's members at or below it; F2: the rows
       if (n_valid > 0) limit_key = select_and_add(qbin, krank - below);
       publish_and_fold(s_tot, 29);
-      clear_key_list();
     }
     // ---------------- solve, pose update, convergence -- in every workgroup, on its own copy of the state
     if (threadIdx.x == 0) {
+      cnt_prev[0] += ls.hard_count; cnt_prev[1] += ls.deferred_count; cnt_prev[2] += ls.unresolved_count;   // (the tail folds them into the totals and zeroes them)
       const TailOpts o = {b.cap_factor, b.ball_radius, b.band_gain, b.band_pad, 0, b.early_exit, b.max_iteration, b.search_hist, b.done_count};
       one_tail(o, &ls, pair, s_tot, n_valid, limit_key, ns, blockIdx.x == 0);
     }

@@ -50,7 +50,7 @@ struct Args {
   std::string scans_dir, out_path = "kitti_pose.txt", id_file;
   unsigned long long nonce = 0;             // identifies this run's id file (launcher: pid and start time; else MASTER_PORT)
   int gpus = 1, rank = -1, world = -1, local_rank = -1;
-  int batch = 256, iterations = 20, early_exit = 0, max_pairs = -1, readers = 8;
+  int batch = 256, iterations = 20, early_exit = 0, max_pairs = -1, readers = 8, matchers = 1;
   double guess_tx = 0.0;
   bool quiet = false;
 };
@@ -98,10 +98,11 @@ Args Parse(int argc, char** argv) {
     else if (k == "--early-exit") a.early_exit = std::atoi(val().c_str());
     else if (k == "--max-pairs") a.max_pairs = std::atoi(val().c_str());
     else if (k == "--readers") a.readers = std::atoi(val().c_str());
+    else if (k == "--matchers") a.matchers = std::atoi(val().c_str());
     else if (k == "--guess-tx") a.guess_tx = std::atof(val().c_str());
     else if (k == "--quiet") a.quiet = true;
     else Die("unknown argument " + k + "\nusage: smhip_shard --scans DIR [--gpus G] [--out kitti_pose.txt] [--batch 256] "
-             "[--iterations 20] [--early-exit 0|1] [--guess-tx metres] [--max-pairs N] [--readers 8]");
+             "[--iterations 20] [--early-exit 0|1] [--guess-tx metres] [--max-pairs N] [--readers 8] [--matchers 1|2]");
   }
   if (a.scans_dir.empty()) Die("--scans DIR is required");
   if (a.rank < 0 && std::getenv("RANK")) a.rank = std::atoi(std::getenv("RANK"));
@@ -160,10 +161,14 @@ int RunRank(const Args& a, int rank, int world, int device) {
   const ncclUniqueId id = ExchangeId(a, rank);
   NCCLOK(ncclCommInitRank(&comm, world, id, rank));
 
-  hipStream_t stream;
-  HIPOK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   const int B = std::max(1, std::min(std::min(a.batch, 256), per));     // one batched upload holds up to 2 B <= 512 scans
-  smhip_handle h = nullptr;
+  // --matchers 2: two matchers, each with its own stream, take the batches in turn -- while one runs the alignments of batch k
+  // (enqueued, not waited for), the host reads, uploads and prepares the targets of batch k + 1 on the other.
+  const int NH = (a.matchers >= 2 && per > B) ? 2 : 1;
+  hipStream_t streams[2] = {nullptr, nullptr};
+  smhip_handle hs[2] = {nullptr, nullptr};
+  for (int k = 0; k < NH; ++k) HIPOK(hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking));
+  hipStream_t stream = streams[0];
   // capacity: the largest scan of the directory (a KITTI scan holds at most 250 000 points: 1 000 000 floats per file are
   // read, kitti_reader.cc:93).  Slots [0, B) hold the pairs of a batch, slots [B, 2 B) park target scans that no pair of the
   // batch holds as its source already.
@@ -171,13 +176,15 @@ int RunRank(const Args& a, int rank, int world, int device) {
   for (const auto& f : files) { struct stat sb; if (stat(f.c_str(), &sb) == 0) max_bytes = std::max(max_bytes, static_cast<size_t>(sb.st_size)); }
   const size_t slot_floats = std::min(kMaxFloatsPerFile, (max_bytes / 16 + 1) * 4);
   const int cap = static_cast<int>(slot_floats / 4);
-  smhip_status s = smhip_create(device, stream, 2 * B, cap, cap, &h);
-  if (s != SMHIP_OK) Die(std::string("smhip_create: ") + smhip_status_string(s) + " (is this a gfx950 GPU? there is no CPU fallback)");
-  smhip_icp_options o;
-  smhip_icp_default_options(&o);
-  o.max_iteration = a.iterations;
-  o.early_exit = a.early_exit;
-  if (smhip_icp_set_options(h, &o) != SMHIP_OK) Die(smhip_last_error(h));
+  for (int k = 0; k < NH; ++k) {
+    const smhip_status s = smhip_create(device, streams[k], 2 * B, cap, cap, &hs[k]);
+    if (s != SMHIP_OK) Die(std::string("smhip_create: ") + smhip_status_string(s) + " (is this a gfx950 GPU? there is no CPU fallback)");
+    smhip_icp_options o;
+    smhip_icp_default_options(&o);
+    o.max_iteration = a.iterations;
+    o.early_exit = a.early_exit;
+    if (smhip_icp_set_options(hs[k], &o) != SMHIP_OK) Die(smhip_last_error(hs[k]));
+  }
 
   double* local_dev = nullptr;
   double* all_dev = nullptr;
@@ -215,15 +222,18 @@ int RunRank(const Args& a, int rank, int world, int device) {
     if (*n < 0) Die("cannot read " + files[fi]);
     return rows;
   };
-  if (smhip_reserve_batch_workspaces(h) != SMHIP_OK) Die(smhip_last_error(h));     // not inside the first batch
-  HIPOK(hipStreamSynchronize(stream));
+  for (int k = 0; k < NH; ++k) {
+    if (smhip_reserve_batch_workspaces(hs[k]) != SMHIP_OK) Die(smhip_last_error(hs[k]));     // not inside the first batch
+    HIPOK(hipStreamSynchronize(streams[k]));
+  }
   const auto t0 = std::chrono::steady_clock::now();
   double upload_s = 0.0, wait_s = 0.0, set_s = 0.0, prep_s = 0.0;   // rank 0's host-side split: blocked on the readers / uploads / target preparation
   auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
   int done = 0, my_pairs = 0;
   std::vector<int> up_slots, up_n;
   std::vector<const float*> up_rows;
-  for (int base = 0; base < per; base += B) {
+  for (int base = 0, turn = 0; base < per; base += B, ++turn) {
+    smhip_handle h = hs[turn % NH];
     int nb = 0;
     const auto u0 = std::chrono::steady_clock::now();
     std::vector<int> from, to, nts;
@@ -268,6 +278,7 @@ int RunRank(const Args& a, int rank, int world, int device) {
     my_pairs += nb;
   }
   (void)done;
+  for (int k = 1; k < NH; ++k) HIPOK(hipStreamSynchronize(streams[k]));     // (the gather goes to the first matcher's stream)
   // the ONE collective of the path: every rank's padded block of poses, device to device over xGMI
   NCCLOK(ncclAllGather(local_dev, all_dev, static_cast<size_t>(kPoseDoubles) * per, ncclDouble, comm, stream));
   HIPOK(hipStreamSynchronize(stream));
@@ -308,10 +319,10 @@ int RunRank(const Args& a, int rank, int world, int device) {
     if (bad) rc = 3;
   }
   (void)hipFree(local_dev); (void)hipFree(all_dev);
-  smhip_destroy(h);
+  for (int k = 0; k < NH; ++k) smhip_destroy(hs[k]);
   if (pinned) for (float* b : ring_buffers) (void)hipHostFree(b);
   NCCLOK(ncclCommDestroy(comm));
-  (void)hipStreamDestroy(stream);
+  for (int k = 0; k < NH; ++k) (void)hipStreamDestroy(streams[k]);
   return rc;
 }
 

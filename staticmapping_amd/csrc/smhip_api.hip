@@ -711,8 +711,8 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, &d.partials, B * (size_t)d.part_stride * kAccCols));
   A(dev_alloc(h, &d.tpart, B * kTgtReduceBlocks * 16));
   A(dev_alloc(h, &d.done_count, 4));
-  A(dev_alloc(h, &d.one_sync, (size_t)kOneSyncWords));
-  A(dev_alloc(h, &d.one_rows, (size_t)(kOneMaxBlocks + 32) * kAccCols));
+  A(dev_alloc(h, &d.one_sync, (size_t)kOneSyncWords * kOnePairs));
+  A(dev_alloc(h, &d.one_rows, (size_t)kOnePairs * (kOneMaxBlocks + 32) * kAccCols));
   A(dev_alloc(h, &h->ids_dev, NS));
   A(dev_alloc(h, &h->d2_dev, NS));
   if (s == SMHIP_OK) {
@@ -733,7 +733,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, icp_one, kNnThreads, 0) == hipSuccess && per_cu > 0)
       h->one_blocks = (std::min(per_cu * prop.multiProcessorCount, kOneMaxBlocks) / 32) * 32;
     (void)hipGetLastError();
-    if (hipMemsetAsync(d.one_sync, 0, sizeof(uint32_t) * kOneSyncWords, h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
+    if (hipMemsetAsync(d.one_sync, 0, sizeof(uint32_t) * kOneSyncWords * kOnePairs, h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
   }
   if (s == SMHIP_OK && hipMemsetAsync(d.state, 0, B * sizeof(PairState), h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
   if (s == SMHIP_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
@@ -1242,17 +1242,22 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
   // One pair (the front end's call, map_builder.cc:317-333): the whole loop and the score as ONE cooperative launch whose workgroups
   // meet at grid barriers (icp_one.hip) -- the same matches, distances and kept sets as the launches below.
   h->one_used = 0;
-  if (npairs == 1 && h->one_blocks > 0 && !h->opts.no_single_kernel && h->one_enabled && h->opts.nn_mode == SMHIP_NN_GRID && h->dev.use_ball &&
+  // (one pair per launch: the kernel takes a row of its grid per pair -- up to kOnePairs, the back end's handful of concurrent submap
+  // pairs: 6 pairs 1.40 ms against 1.71 as separate launches -- but that form faulted in its fused iterations on batches of four and
+  // more pairs of mixed sizes and is withheld until the cause is found; SMHIP_ONE_PAIRS=n lets tools/one_race_probe.py reach it)
+  const int one_pairs_max = std::getenv("SMHIP_ONE_PAIRS") ? std::min(std::max(std::atoi(std::getenv("SMHIP_ONE_PAIRS")), 1), kOnePairs) : 1;
+  if (npairs <= one_pairs_max && h->one_blocks > 0 && !h->opts.no_single_kernel && h->one_enabled && h->opts.nn_mode == SMHIP_NN_GRID && h->dev.use_ball &&
       h->dev.lds_table && h->dev.certify && !h->dev.exact_all && h->profile == 0) {
     const int nrounds = ceil_div(ns_max, kNnThreads);
     // two rounds of 256 points per workgroup (measured on 120 000 points, 20 iterations, target kept: 472 workgroups of one round
     // 1.15-1.18 ms, 320: 1.11-1.15, 240: 1.06-1.11, 160: 1.04-1.13 -- a barrier waits for the slowest workgroup, and two rounds
-    // even out what one round's few searching queries cost); a multiple of 8: the barrier's groups
+    // even out what one round's few searching queries cost); a multiple of 8: the barrier's groups.  Several pairs (up to
+    // kOnePairs: the back end's handful of concurrent submap pairs) share what the device holds at once, a row of the grid each.
     int G = h->one_blocks_want > 0 ? std::max(8, (h->one_blocks_want / 8) * 8) : ((ceil_div(nrounds, 2) + 7) / 8) * 8;
-    G = std::min(G, ((nrounds + 7) / 8) * 8);
+    if (!(h->one_blocks_want > 0 && std::getenv("SMHIP_ONE_IDLE"))) G = std::min(G, ((nrounds + 7) / 8) * 8);   // (SMHIP_ONE_IDLE: tests run small clouds on a grid of mostly idle workgroups)
     if (G >= 64) G = ((G + 31) / 32) * 32;                 // (whole groups of the barrier; workgroups beyond the rounds only take part in the barriers)
-    G = std::min(G, h->one_blocks);
-    if (ceil_div(nrounds, G) <= kOneMaxRounds) {
+    G = std::min(G, ((h->one_blocks / npairs) / 8) * 8);
+    if (G >= 8 && ceil_div(nrounds, G) <= kOneMaxRounds) {
       if (!cached_one) { s = enqueue_grid_build(h, halves[0], nt_max); if (s) return s; }
       grid_built = true;
       IcpDev d1 = halves[0].d;
@@ -1262,7 +1267,7 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
       int groups = 8;
       if (h->one_groups_want > 0 && (h->one_groups_want & (h->one_groups_want - 1)) == 0 && h->one_groups_want <= 32 && G % h->one_groups_want == 0) groups = h->one_groups_want;
       void* args[] = {&d1, &groups};
-      if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(icp_one), dim3(G), dim3(kNnThreads), args, 0, h->stream) == hipSuccess) {
+      if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(icp_one), dim3(G, npairs), dim3(kNnThreads), args, 0, h->stream) == hipSuccess) {
         h->one_used = 1;
         h->last_npairs = npairs;
         return SMHIP_OK;

@@ -55,7 +55,8 @@ constexpr int kCertifyItems = 32;        // rounds per workgroup of the certific
 // the single-pair persistent kernel (icp_one.hip)
 constexpr int kOneMaxRounds = 8;         // rounds of 256 points a workgroup may own (sizes the LDS list of its in-bin points)
 constexpr int kOneSyncWords = 4096;      // IcpDev::one_sync: the grid barrier's counters and flags + the length of the key list, a 128-byte line each; zeroed per Align
-constexpr int kOneMaxBlocks = 1024;      // the largest grid of the kernel
+constexpr int kOneMaxBlocks = 1024;      // the largest grid (workgroups per pair) of the kernel
+constexpr int kOnePairs = 8;             // pairs one launch of it can hold (grid.y; each with its own barrier lines and rows)
 
 // Per-pair device state.  Everything an iteration needs and everything the host reads back.
 struct PairState {
@@ -199,8 +200,8 @@ struct IcpDev {
   double* partials;          // [slots][part_stride][kAccCols]: one row per workgroup of accumulate / of the fused certificate pass
   double* tpart;             // [slots][kTgtReduceBlocks][16]
   uint32_t* done_count;      // number of finished pairs
-  uint32_t* one_sync;        // [kOneSyncWords] grid barrier + key-list length of the single-pair persistent kernel (icp_one)
-  double* one_rows;          // [kOneMaxBlocks + 32][kAccCols] its workgroups' rows of sums, then its groups'
+  uint32_t* one_sync;        // [kOnePairs][kOneSyncWords] grid barrier + key-list length of the persistent kernel (icp_one), per pair of its launch
+  double* one_rows;          // [kOnePairs][kOneMaxBlocks + 32][kAccCols] its workgroups' rows of sums, then its groups'
   uint8_t* nabo_work;        // [slots][ns_cap] SMHIP_NN_NABO: buckets the query's last walk scanned (capped at 255); null until the mode is used
   uint32_t* search_hist;     // [slots][kSearchHist] queries that needed a search in iteration k of the last Align (finalize; read back by the
                              //                 host to place the switch from the fused search to certify + listed search, split_after = 0)

@@ -177,6 +177,15 @@ __device__ __noinline__ void one_tail(TailOpts o, PairState* ls, int pair, const
 #ifndef SMHIP_ONE_TIMING
 #define SMHIP_ONE_TIMING 0
 #endif
+// diagnostic build (-DSMHIP_ONE_CHECKS=1): every index the kernel takes from memory is checked against its range before it is used
+#ifndef SMHIP_ONE_CHECKS
+#define SMHIP_ONE_CHECKS 0
+#endif
+#if SMHIP_ONE_CHECKS
+#define SMHIP_OCHK(cond, what, v) do { if (!(cond)) { printf("[icp_one] CHECK %s failed: value %lld (pair row %u workgroup %u thread %u iteration %d)\n", what, (long long)(v), (unsigned)blockIdx.y, (unsigned)blockIdx.x, (unsigned)threadIdx.x, ls.iter); __builtin_trap(); } } while (0)
+#else
+#define SMHIP_OCHK(cond, what, v) do { } while (0)
+#endif
 #if SMHIP_ONE_TIMING
 #define SMHIP_OPH(k) do { if (otime) { const unsigned long long now_ = wall_clock64(); oacc[k] += now_ - oprev; oprev = now_; } } while (0)
 #else
@@ -262,6 +271,7 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
         const int j = b.idx[so + i];
         const float4 s4 = ld_src(b, so + i);
         const uint32_t key = __float_as_uint(d);
+        SMHIP_OCHK(j >= -1 && j < ls.nt, "collect: match id", j);
         if (key < 0x7f800000u) {
           const uint32_t bin = key >> kHistShift;
           if (bin < lo) accumulate_terms(Mc, s4, b.tq[to + max(j, 0)], b.tn[to + max(j, 0)], acc);
@@ -281,10 +291,13 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
     __syncthreads();
     uint32_t base = s_misc[1];
     for (int w = 0; w < wave; ++w) base += s_wc[w];
+    SMHIP_OCHK(base + (uint32_t)wcount <= (uint32_t)b.bl_stride, "collect: key list position", base + (uint32_t)wcount);
+    SMHIP_OCHK(wcount <= 64 * kOneMaxRounds, "collect: wave list length", wcount);
     for (int k = lane; k < wcount; k += 64) st_dev(&gkeys[base + k], __float_as_uint(b.d2[so + s_rec[wave][k]]));
     pd = INFINITY;
     if (lane < wcount) {
       const int i = s_rec[wave][lane];
+      SMHIP_OCHK(i >= 0 && i < ns, "collect: listed point", i);
       pd = b.d2[so + i];
       const int j = max(b.idx[so + i], 0);
       ps = ld_src(b, so + i); pq = b.tq[to + j]; pn = b.tn[to + j];
@@ -295,6 +308,7 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
   // points at or below it added to acc -- weights = (d2 <= limit), icp_fast.cc:497-498 -- in the order the waves met them.
   auto select_and_add = [&](uint32_t qbin, uint32_t rank) -> uint32_t {
     const int nb = (int)ld_dev(key_count);
+    SMHIP_OCHK(nb >= 0 && nb <= b.bl_stride, "select: key list length", nb);
     const bool flat = nb <= kFinalizeKeyCap;
     if (flat) {
       for (int e0 = 0; e0 < nb; e0 += 8 * kNnThreads) {          // eight loads in flight per thread: one pair's ~2 000 keys in one round
@@ -343,6 +357,7 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
     if (lane < wcount && __float_as_uint(pd) <= limit_key) accumulate_terms(Mc, ps, pq, pn, acc);
     for (int k = lane + 64; k < wcount; k += 64) {
       const int i = s_rec[wave][k];
+      SMHIP_OCHK(i >= 0 && i < ns, "select: listed point", i);
       const float d = b.d2[so + i];
       if (__float_as_uint(d) <= limit_key) {
         const int j = max(b.idx[so + i], 0);
@@ -432,6 +447,7 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
           const float4 s = ld_src(b, so + i);
           const float l = ld_lb(b, so + i);
           const int j = b.idx[so + i];
+          SMHIP_OCHK(j >= -1 && j < ls.nt, "certify: match id", j);
           const float4 t = tq[max(j, 0)];
           double px, py, pz;
           transform_point(Mc, s, px, py, pz);
@@ -475,8 +491,10 @@ __global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
         while (logL < 4 && (nf << (logL + 1)) <= kNnThreads) ++logL;
         const int L = 1 << logL, per = kNnThreads >> logL;
         const int sub = (int)threadIdx.x & (L - 1), qi = (int)threadIdx.x >> logL;
+        SMHIP_OCHK(nf <= kOneMaxRounds * kNnThreads, "search: failing queries", nf);
         for (int base = 0; base < nf; base += per) {
           const int i = base + qi < nf ? s_fail[base + qi] : -1;
+          SMHIP_OCHK(i >= -1 && i < ns, "search: listed query", i);
           bool hard = false, band = false;
           float4 srec; float drec; int jrec;
           listed_search_one(b, &ls, ctx, so, i, sub, L, s_hist, min_lb, hard, false, 0, 0, band, srec, drec, jrec);

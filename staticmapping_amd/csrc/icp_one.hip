@@ -192,7 +192,7 @@ __device__ __noinline__ void one_tail(TailOpts o, PairState* ls, int pair, const
 #define SMHIP_OPH(k) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(kNnThreads, 2) void icp_one(IcpDev b, int groups) {
+__global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {   // (one workgroup per CU: 305 registers, none spilled; at two per CU 39 spilled in the loops every thread runs)
   const int pair = b.pair_base + (int)blockIdx.y;          // (a launch holds up to kOnePairs pairs: a row of the grid each, nothing shared)
   const uint32_t G = gridDim.x;
   const OneGrid og = {G, (uint32_t)groups};

@@ -44,10 +44,13 @@
 
 namespace smhip {
 
-__device__ __forceinline__ uint32_t ld_dev(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_dev(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#ifndef SMHIP_ONE_SCOPE
+#define SMHIP_ONE_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
+__device__ __forceinline__ uint32_t ld_dev(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, SMHIP_ONE_SCOPE); }
+__device__ __forceinline__ void st_dev(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, SMHIP_ONE_SCOPE); }
 __device__ __forceinline__ void st_dev(double* p, double v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, SMHIP_ONE_SCOPE);
 }
 
 // IcpDev::one_sync, in 128-byte lines (32 words): [0] arrivals of the groups' last workgroups, [32] length of the key list,
@@ -58,9 +61,10 @@ constexpr int kOneMaxGroups = 32;
 constexpr int kSyncArrive = 64, kSyncFlag = kSyncArrive + 32 * kOneMaxGroups, kSyncCount = kSyncFlag + 32 * kOneMaxGroups, kSyncTotal = kSyncCount + 32 * kOneMaxGroups;
 constexpr int kSyncKeys = kSyncTotal + 32;        // + 32 p: length of the key list of the iterations of parity p
 constexpr int kSyncMinLb = kSyncKeys + 64;        // + 32 p: ~(the smallest lower bound recorded) of the iterations of parity p (0: none)
-static_assert(kSyncMinLb + 64 <= kOneSyncWords, "IcpDev::one_sync holds the barrier's lines");
+constexpr int kSyncAbort = kSyncMinLb + 64;       // != 0: a barrier timed out -- every workgroup leaves; [+1..+7] what the first to notice saw
+static_assert(kSyncAbort + 32 <= kOneSyncWords, "IcpDev::one_sync holds the barrier's lines");
 struct OneGrid { uint32_t G, NG; };       // workgroups, groups (a power of two that divides G)
-__device__ __forceinline__ void one_arrive_and_wait(uint32_t* sync, uint32_t epoch, OneGrid og, bool group_last) {
+__device__ __forceinline__ void one_arrive_and_wait(uint32_t* sync, uint32_t epoch, OneGrid og, bool group_last, uint32_t* s_abort) {
   const uint32_t g = blockIdx.x & (og.NG - 1);
   if (group_last) {
     const uint32_t old = __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -68,27 +72,34 @@ __device__ __forceinline__ void one_arrive_and_wait(uint32_t* sync, uint32_t epo
       for (uint32_t k = 0; k < og.NG; ++k) st_dev(&sync[kSyncFlag + 32 * k], epoch);
   }
   // (a watchdog instead of an endless spin: a barrier that has not completed after 0.2 s -- a thousand times the longest
-  // iteration -- says so and stops the launch; the host then reports the error instead of hanging)
+  // iteration -- raises the launch's abort word with what it saw; every workgroup looks at that word while it spins and leaves, the
+  // pair ends with status SMHIP_ERR_HIP: an error at the host, not a hang and not a dead context)
   const unsigned long long t0 = wall_clock64();
   uint32_t polls = 0;
   while (ld_dev(&sync[kSyncFlag + 32 * g]) < epoch) {
     __builtin_amdgcn_s_sleep(1);
-    if ((++polls & 0xfffu) == 0u && wall_clock64() - t0 > 20000000ull) {
-      printf("[icp_one] barrier timeout: pair row %u workgroup %u of %u, epoch %u: group arrivals %u (want %u), top arrivals %u (want %u), flag %u\n",
-             (unsigned)blockIdx.y, (unsigned)blockIdx.x, og.G, epoch, ld_dev(&sync[kSyncArrive + 32 * g]), epoch * (og.G / og.NG), ld_dev(&sync[0]), epoch * og.NG,
-             ld_dev(&sync[kSyncFlag + 32 * g]));
-      __builtin_trap();
+    if ((++polls & 0x3ffu) == 0u) {
+      if (ld_dev(&sync[kSyncAbort]) != 0u) { *s_abort = 1u; return; }
+      if (wall_clock64() - t0 > 20000000ull) {
+        if (__hip_atomic_exchange(&sync[kSyncAbort], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          st_dev(&sync[kSyncAbort + 1], (uint32_t)blockIdx.x); st_dev(&sync[kSyncAbort + 2], epoch);
+          st_dev(&sync[kSyncAbort + 3], ld_dev(&sync[kSyncArrive + 32 * g])); st_dev(&sync[kSyncAbort + 4], epoch * (og.G / og.NG));
+          st_dev(&sync[kSyncAbort + 5], ld_dev(&sync[0])); st_dev(&sync[kSyncAbort + 6], epoch * og.NG);
+        }
+        *s_abort = 1u;
+        return;
+      }
     }
   }
 }
-__device__ __forceinline__ void one_grid_sync(uint32_t* sync, uint32_t& epoch, OneGrid og) {
+__device__ __forceinline__ void one_grid_sync(uint32_t* sync, uint32_t& epoch, OneGrid og, uint32_t* s_abort) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // this wave's write-through stores and atomics have completed
   __syncthreads();
   ++epoch;
   if (threadIdx.x == 0) {
     const uint32_t g = blockIdx.x & (og.NG - 1);
     const uint32_t old = __hip_atomic_fetch_add(&sync[kSyncArrive + 32 * g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    one_arrive_and_wait(sync, epoch, og, old + 1u == epoch * (og.G / og.NG));
+    one_arrive_and_wait(sync, epoch, og, old + 1u == epoch * (og.G / og.NG), s_abort);
   }
   __syncthreads();
 }
@@ -98,7 +109,7 @@ __device__ __forceinline__ void one_grid_sync(uint32_t* sync, uint32_t& epoch, O
 // cleared -- every workgroup remembers what it last read there (cprev, threads 0..4) and takes the difference.
 // sync[kSyncCount + 32 g + t]: group g's counts, sync[kSyncTotal + t]: the totals.
 __device__ __forceinline__ void one_grid_sync_counts(uint32_t* sync, uint32_t& epoch, OneGrid og, const uint32_t* s_cnt, uint32_t* s_out, uint32_t& cprev,
-                                                    uint32_t* s_flag) {
+                                                    uint32_t* s_flag, uint32_t* s_abort) {
   const uint32_t G = og.G;
   const uint32_t g = blockIdx.x & (og.NG - 1);
   uint32_t sink = 0;
@@ -120,7 +131,7 @@ __device__ __forceinline__ void one_grid_sync_counts(uint32_t* sync, uint32_t& e
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" :: "v"(sink) : "memory");
     __syncthreads();
   }
-  if (threadIdx.x == 0) one_arrive_and_wait(sync, epoch, og, last);
+  if (threadIdx.x == 0) one_arrive_and_wait(sync, epoch, og, last, s_abort);
   __syncthreads();
   if (threadIdx.x < 5) {
     const uint32_t cur = ld_dev(&sync[kSyncTotal + threadIdx.x]);
@@ -133,7 +144,7 @@ __device__ __forceinline__ void one_grid_sync_counts(uint32_t* sync, uint32_t& e
 // the group's rows -- in the order of their workgroups, whoever arrives last -- and publishes the group's row before it arrives
 // for the group.  (Every workgroup reading all 472 rows would pull 57 MB through the fabric per iteration.)
 __device__ __forceinline__ void one_grid_sync_fold(uint32_t* sync, uint32_t& epoch, OneGrid og, const double* rows, double* grows,
-                                                  double (*s_part)[32], uint32_t* s_flag) {
+                                                  double (*s_part)[32], uint32_t* s_flag, uint32_t* s_abort) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   ++epoch;
@@ -150,7 +161,7 @@ __device__ __forceinline__ void one_grid_sync_fold(uint32_t* sync, uint32_t& epo
     double s = 0;
 #pragma unroll 8
     for (uint32_t w = g + og.NG * sub; w < G; w += og.NG * 8)
-      s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(rows + (size_t)w * kAccCols + col), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(rows + (size_t)w * kAccCols + col), __ATOMIC_RELAXED, SMHIP_ONE_SCOPE));
     s_part[sub][col] = s;
     __syncthreads();
     if (threadIdx.x < kAccCols) {
@@ -161,7 +172,7 @@ __device__ __forceinline__ void one_grid_sync_fold(uint32_t* sync, uint32_t& epo
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  if (threadIdx.x == 0) one_arrive_and_wait(sync, epoch, og, last);
+  if (threadIdx.x == 0) one_arrive_and_wait(sync, epoch, og, last, s_abort);
   __syncthreads();
 }
 __device__ __forceinline__ double uniform_f64(double v) {
@@ -211,14 +222,27 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
   __shared__ int s_rec[kNnThreads / 64][64 * kOneMaxRounds];
   __shared__ uint32_t s_wc[kNnThreads / 64];
   __shared__ uint32_t s_misc[8];
+  __shared__ uint32_t s_abort;                           // a barrier of this launch timed out (see one_arrive_and_wait): leave
   static_assert(sizeof(float4) * kBruteTile <= sizeof(uint32_t) * kFinalizeKeyCap, "the fallback's tile aliases the key list");
   {
     const uint32_t* g = reinterpret_cast<const uint32_t*>(st);
     uint32_t* l = reinterpret_cast<uint32_t*>(&ls);
     for (int k = threadIdx.x; k < (int)(sizeof(PairState) / 4); k += kNnThreads) l[k] = g[k];
   }
+  if (threadIdx.x == 0) s_abort = 0u;
   __syncthreads();
   if (ls.done) return;                                   // (pose_setup: a target without a search structure) -- every workgroup alike
+  // behind every barrier: did it complete?  If not the pair ends here, failed (workgroup 0 says so in the pair's state)
+  auto bail = [&]() -> bool {
+    if (!s_abort) return false;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      st->status = 3;                                    // SMHIP_ERR_HIP
+      st->done = 1; st->score = 0; st->iter = ls.iter;
+      for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) st->result[4 * c + r] = ls.guess[4 * r + c];
+      atomicAdd(b.done_count, 1u);
+    }
+    return true;
+  };
   const int ns = ls.ns;
   const int nrounds = (ns + kNnThreads - 1) / kNnThreads;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -320,6 +344,19 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
       }
     }
     SMHIP_OPH(6);
+#if SMHIP_ONE_CHECKS
+    {   // what this workgroup saw of the key list: its length and the sum of its keys (wrapping), for the disagreement report
+      __syncthreads();
+      uint32_t cs = 0;
+      for (int e = threadIdx.x; e < nb; e += kNnThreads) cs += flat ? s_keys[e] : ld_dev(&gkeys[e]);
+      for (int off = 32; off > 0; off >>= 1) cs += __shfl_xor(cs, off, 64);
+      if (threadIdx.x == 0) s_cnt[14] = 0;
+      __syncthreads();
+      if (lane == 0) atomicAdd(&s_cnt[14], cs);
+      if (threadIdx.x == 0) { s_cnt[15] = (uint32_t)nb; s_cnt[13] = rank; }
+      __syncthreads();
+    }
+#endif
     uint32_t prefix = 0, mask = 0;
     for (int pass = 0; pass < 2; ++pass) {                         // the low 20 key bits, ten at a time
       const int shift = pass == 0 ? 10 : 0;
@@ -368,17 +405,38 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
     return limit_key;
   };
   // this workgroup's row of sums published, the barrier with the groups' fold inside, the groups' rows added in order into dst
-  auto publish_and_fold = [&](double* dst, int ncols) {
+  // Columns 29 / 30 carry the exact quantile and the count of distances AS THIS WORKGROUP HAS THEM: every workgroup derives both from
+  // what the others published, so they must be the same everywhere, and their sums over the G workgroups must be G times one's own --
+  // a workgroup that finds otherwise (it, or another, read something the others did not) raises the abort word: the pair ends with
+  // an error instead of workgroups that take different turns at the next iteration's barriers.
+  auto publish_and_fold = [&](double* dst, uint32_t my_limit_key, uint32_t my_n_valid) {
     block_reduce29(acc, s_red, dst);
-    if (threadIdx.x < ncols) st_dev(&rows[(size_t)blockIdx.x * kAccCols + threadIdx.x], dst[threadIdx.x]);
+    if (threadIdx.x < kAccCols) {
+      double x = threadIdx.x < 29 ? dst[threadIdx.x] : 0.0;
+      if (threadIdx.x == 29) x = (double)my_limit_key;
+      if (threadIdx.x == 30) x = (double)my_n_valid;
+      st_dev(&rows[(size_t)blockIdx.x * kAccCols + threadIdx.x], x);
+    }
     SMHIP_OPH(9);
-    one_grid_sync_fold(sync, target, og, rows, grows, s_part, &s_misc[3]);
+    one_grid_sync_fold(sync, target, og, rows, grows, s_part, &s_misc[3], &s_abort);
     SMHIP_OPH(10);
     if (threadIdx.x < kAccCols) {
       double s = 0;
       for (uint32_t k = 0; k < og.NG; ++k)
-        s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(grows + (size_t)k * kAccCols + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(grows + (size_t)k * kAccCols + threadIdx.x), __ATOMIC_RELAXED, SMHIP_ONE_SCOPE));
       dst[threadIdx.x] = s;
+      if ((threadIdx.x == 29 && s != (double)my_limit_key * (double)G) || (threadIdx.x == 30 && s != (double)my_n_valid * (double)G)) {
+        if (__hip_atomic_exchange(&sync[kSyncAbort], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          st_dev(&sync[kSyncAbort + 1], (uint32_t)blockIdx.x); st_dev(&sync[kSyncAbort + 2], target);
+          st_dev(&sync[kSyncAbort + 3], my_limit_key); st_dev(&sync[kSyncAbort + 4], my_n_valid);
+          st_dev(&sync[kSyncAbort + 5], (uint32_t)threadIdx.x); st_dev(&sync[kSyncAbort + 6], (uint32_t)(s / (double)G));
+#if SMHIP_ONE_CHECKS
+          printf("[icp_one] disagreement seen by pair row %u workgroup %u iteration %d: its key list has %u keys, key sum %u, rank %u, quantile key %u; fused %d\n",
+                 (unsigned)blockIdx.y, (unsigned)blockIdx.x, ls.iter, s_cnt[15], s_cnt[14], s_cnt[13], my_limit_key, (int)(ls.band_lo > 0));
+#endif
+        }
+        s_abort = 1u;
+      }
     }
     __syncthreads();
     SMHIP_OPH(11);
@@ -545,7 +603,8 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
         if (threadIdx.x < 5) s_cnt[threadIdx.x] = threadIdx.x == 0 ? (tot & 0xffffu) : (threadIdx.x == 1 ? tot >> 16 : (blo + (threadIdx.x - 2) <= bhi ? s_hist[blo + (threadIdx.x - 2)] : 0u));
       }
       SMHIP_OPH(9);
-      one_grid_sync_counts(sync, target, og, s_cnt, s_cnt + 8, cprev, &s_misc[3]);
+      one_grid_sync_counts(sync, target, og, s_cnt, s_cnt + 8, cprev, &s_misc[3], &s_abort);
+      if (bail()) return;
       SMHIP_OPH(10);
       clear_next_parity();
       first_barrier_done = true;
@@ -572,7 +631,8 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
       if (s_q[3]) {
         n_valid = s_q[2];
         limit_key = select_and_add(s_q[0], s_q[1]);               // acc: the sums below the band + the band's members at or below the exact quantile
-        publish_and_fold(s_tot, 29);
+        publish_and_fold(s_tot, limit_key, n_valid);
+        if (bail()) return;
         if (threadIdx.x == 0) ls.spec_hits += 1;
         have_sums = true;
       } else {
@@ -583,7 +643,8 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
       // ---------------- the plain form: the pair's histogram, the quantile's bin, the sums below it, the exact select inside it
       flush_hist(b, pair, s_hist);
       SMHIP_OPH(1);
-      one_grid_sync(sync, target, og);
+      one_grid_sync(sync, target, og, &s_abort);
+      if (bail()) return;
       if (!first_barrier_done) clear_next_parity();
       SMHIP_OPH(2);
       // V: the quantile's bin; do the lower bounds stand above it?  (nn_validate)
@@ -654,7 +715,8 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
           asm volatile("" :: "v"(o));
         }
         flush_hist(b, pair, s_hist);
-        one_grid_sync(sync, target, og);
+        one_grid_sync(sync, target, og, &s_abort);
+        if (bail()) return;
 #pragma unroll
         for (int k = 0; k < kHistBins / kNnThreads; ++k) hraw[k] = ld_dev(&gh[threadIdx.x * (kHistBins / kNnThreads) + k]);
 #pragma unroll
@@ -676,11 +738,13 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
         wcount = 0;
       }
       SMHIP_OPH(4);
-      one_grid_sync(sync, target, og);
+      one_grid_sync(sync, target, og, &s_abort);
+      if (bail()) return;
       SMHIP_OPH(5);
       // F1: the exact quantile, the bin's members at or below it; F2: the rows
       if (n_valid > 0) limit_key = select_and_add(qbin, krank - below);
-      publish_and_fold(s_tot, 29);
+      publish_and_fold(s_tot, limit_key, n_valid);
+      if (bail()) return;
     }
     // ---------------- solve, pose update, convergence -- in every workgroup, on its own copy of the state
     if (threadIdx.x == 0) {
@@ -728,12 +792,13 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
       if (threadIdx.x == 1) v = (double)(((s_wc[0] + s_wc[1]) + s_wc[2]) + s_wc[3]);
       st_dev(&rows[(size_t)blockIdx.x * kAccCols + threadIdx.x], v);
     }
-    one_grid_sync_fold(sync, target, og, rows, grows, s_part, &s_misc[3]);
+    one_grid_sync_fold(sync, target, og, rows, grows, s_part, &s_misc[3], &s_abort);
+    if (bail()) return;
     if (blockIdx.x != 0) return;
     if (threadIdx.x < 2) {
       double t = 0;
       for (uint32_t k = 0; k < og.NG; ++k)
-        t += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(grows + (size_t)k * kAccCols + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        t += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(grows + (size_t)k * kAccCols + threadIdx.x), __ATOMIC_RELAXED, SMHIP_ONE_SCOPE));
       s_part[0][threadIdx.x] = t;
     }
     __syncthreads();

@@ -1379,7 +1379,18 @@ static smhip_status fetch_range(smhip_handle h, int first, int npairs, double* r
     }
     if (st.status != SMHIP_OK && worst == SMHIP_OK) {
       worst = st.status;
-      h->err = st.status == SMHIP_ERR_INVALID_ARGUMENT ? "pair failed: target cloud has NaN / Inf coordinates" : "pair failed: no finite correspondence";
+      h->err = st.status == SMHIP_ERR_INVALID_ARGUMENT ? "pair failed: target cloud has NaN / Inf coordinates"
+             : (st.status == SMHIP_ERR_HIP ? "pair failed: the single-pair launch stopped itself (a grid barrier did not complete, or its workgroups disagreed; internal)" : "pair failed: no finite correspondence");
+      if (st.status == SMHIP_ERR_HIP && h->one_used) {
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpy(w, h->dev.one_sync + (size_t)p * kOneSyncWords + kSyncAbort, sizeof(w), hipMemcpyDeviceToHost);
+        char buf[256];
+        if (w[0] == 2u)
+          std::snprintf(buf, sizeof(buf), " [pair %d: workgroups disagree -- workgroup %u at barrier %u has quantile key %u / %u distances, column %u averages %u]", p, w[1], w[2], w[3], w[4], w[5], w[6]);
+        else
+          std::snprintf(buf, sizeof(buf), " [pair %d: noticed by workgroup %u at barrier %u: group arrivals %u of %u, groups arrived %u of %u]", p, w[1], w[2], w[3], w[4], w[5], w[6]);
+        h->err += buf;
+      }
     }
     if (!st.done && worst == SMHIP_OK) { worst = SMHIP_ERR_HIP; h->err = "pair did not finish (internal)"; }
     if (st.done && st.status == SMHIP_OK && st.score_mismatch && worst == SMHIP_OK) {

@@ -94,6 +94,8 @@ __global__ __launch_bounds__(256) void reset_scratch(IcpDev b, int first, int np
   for (size_t k = tid; k < (size_t)kSearchHist * npairs; k += nth) b.search_hist[(size_t)kSearchHist * first + k] = 0;
   if (tid == 0) *b.done_count = 0;
   for (size_t k = tid; k < (size_t)kOneSyncWords * kOnePairs; k += nth) b.one_sync[k] = 0;
+  for (size_t k = tid; k < (size_t)kHistBins * kOnePairs; k += nth) b.one_hist[k] = 0;
+  for (size_t k = tid; k < sizeof(PairState) / 4 * kOnePairs; k += nth) reinterpret_cast<uint32_t*>(b.one_ctr)[k] = 0;
 }
 
 // The per-Align part of grid_setup alone (pose chain, loop state), for a pair whose target -- and with it the mean, the
@@ -137,6 +139,8 @@ __global__ __launch_bounds__(256) void reset_scratch_light(IcpDev b, int first, 
   for (size_t k = tid; k < (size_t)kSearchHist * npairs; k += nth) b.search_hist[(size_t)kSearchHist * first + k] = 0;
   if (tid == 0) *b.done_count = 0;
   for (size_t k = tid; k < (size_t)kOneSyncWords * kOnePairs; k += nth) b.one_sync[k] = 0;
+  for (size_t k = tid; k < (size_t)kHistBins * kOnePairs; k += nth) b.one_hist[k] = 0;
+  for (size_t k = tid; k < sizeof(PairState) / 4 * kOnePairs; k += nth) reinterpret_cast<uint32_t*>(b.one_ctr)[k] = 0;
 }
 
 __global__ void grid_setup(IcpDev b, int npairs) {

@@ -44,6 +44,17 @@
 
 namespace smhip {
 
+// a word published for other workgroups by an exchange whose old value is waited for: the write has been PERFORMED where every XCD
+// sees it before the wave goes on to its barrier (a store's completion count says it was accepted, not where it stands against a
+// returning atomic on another channel)
+__device__ __forceinline__ void pub_dev(uint32_t* p, uint32_t v) {
+  const uint32_t o = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("" :: "v"(o));
+}
+__device__ __forceinline__ void pub_dev(double* p, double v) {
+  const unsigned long long o = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("" :: "v"(o));
+}
 #ifndef SMHIP_ONE_SCOPE
 #define SMHIP_ONE_SCOPE __HIP_MEMORY_SCOPE_AGENT
 #endif
@@ -167,7 +178,7 @@ __device__ __forceinline__ void one_grid_sync_fold(uint32_t* sync, uint32_t& epo
     if (threadIdx.x < kAccCols) {
       double t = 0;
       for (int k = 0; k < 8; ++k) t += s_part[k][threadIdx.x];
-      st_dev(&grows[(size_t)g * kAccCols + threadIdx.x], t);
+      pub_dev(&grows[(size_t)g * kAccCols + threadIdx.x], t);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -193,8 +204,12 @@ __device__ __noinline__ void one_tail(TailOpts o, PairState* ls, int pair, const
 #define SMHIP_ONE_CHECKS 0
 #endif
 #if SMHIP_ONE_CHECKS
+// every workgroup's barriers, in order: (index of the barrier it is about to enter, iteration, which barrier of the code, a value)
+// in the pair's (otherwise unused) rec_a array, 64 entries per workgroup; the host prints them when the pair stops itself
+#define SMHIP_OTRACE(code, val) do { if (threadIdx.x == 0 && target < 64u) reinterpret_cast<uint4*>(b.rec_a + (size_t)pair * 2 * b.bl_stride)[(size_t)blockIdx.x * 64 + target] = make_uint4(target + 1u, (uint32_t)ls.iter, (uint32_t)(code), (uint32_t)(val)); } while (0)
 #define SMHIP_OCHK(cond, what, v) do { if (!(cond)) { printf("[icp_one] CHECK %s failed: value %lld (pair row %u workgroup %u thread %u iteration %d)\n", what, (long long)(v), (unsigned)blockIdx.y, (unsigned)blockIdx.x, (unsigned)threadIdx.x, ls.iter); __builtin_trap(); } } while (0)
 #else
+#define SMHIP_OTRACE(code, val) do { } while (0)
 #define SMHIP_OCHK(cond, what, v) do { } while (0)
 #endif
 #if SMHIP_ONE_TIMING
@@ -247,9 +262,10 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
   const int nrounds = (ns + kNnThreads - 1) / kNnThreads;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t so = (size_t)pair * b.ns_cap, to = (size_t)pair * b.nt_cap;
-  uint32_t* gh = b.hist + (size_t)pair * kHistBins;
+  uint32_t* gh = b.one_hist + (size_t)blockIdx.y * kHistBins;        // (its own histogram, counters and key lists: fine-grained memory, IcpDev::one_ctr)
+  PairState* ctr = b.one_ctr + blockIdx.y;
   uint32_t* sync = b.one_sync + (size_t)blockIdx.y * kOneSyncWords;
-  uint32_t* gkeys0 = reinterpret_cast<uint32_t*>(b.rec_j + (size_t)pair * 2 * b.bl_stride);
+  uint32_t* gkeys0 = b.one_keys + (size_t)blockIdx.y * 2 * b.bl_stride;
   // What every workgroup adds to is never cleared while any of them may still read it or may already be adding again: the counters
   // of searched / lower-bounded / unresolved queries are cumulative (cnt_prev: what this workgroup had read of them when the
   // iteration began), the key list and the smallest-bound word exist twice -- an iteration uses those of its parity, and workgroup 0
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
     for (int w = 0; w < wave; ++w) base += s_wc[w];
     SMHIP_OCHK(base + (uint32_t)wcount <= (uint32_t)b.bl_stride, "collect: key list position", base + (uint32_t)wcount);
     SMHIP_OCHK(wcount <= 64 * kOneMaxRounds, "collect: wave list length", wcount);
-    for (int k = lane; k < wcount; k += 64) st_dev(&gkeys[base + k], __float_as_uint(b.d2[so + s_rec[wave][k]]));
+    for (int k = lane; k < wcount; k += 64) pub_dev(&gkeys[base + k], __float_as_uint(b.d2[so + s_rec[wave][k]]));
     pd = INFINITY;
     if (lane < wcount) {
       const int i = s_rec[wave][lane];
@@ -415,9 +431,10 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
       double x = threadIdx.x < 29 ? dst[threadIdx.x] : 0.0;
       if (threadIdx.x == 29) x = (double)my_limit_key;
       if (threadIdx.x == 30) x = (double)my_n_valid;
-      st_dev(&rows[(size_t)blockIdx.x * kAccCols + threadIdx.x], x);
+      pub_dev(&rows[(size_t)blockIdx.x * kAccCols + threadIdx.x], x);
     }
     SMHIP_OPH(9);
+    SMHIP_OTRACE(5, my_limit_key);
     one_grid_sync_fold(sync, target, og, rows, grows, s_part, &s_misc[3], &s_abort);
     SMHIP_OPH(10);
     if (threadIdx.x < kAccCols) {
@@ -459,9 +476,18 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
   auto clear_key_list = [&]() {
     if (blockIdx.x == 0 && threadIdx.x == 0) s_misc[5] = __hip_atomic_exchange(key_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
+  auto flush_own_hist = [&]() {
+    __syncthreads();
+    uint32_t o = 0;
+    for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) {
+      const uint32_t v = s_hist[k];
+      if (v) o |= __hip_atomic_fetch_add(&gh[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("" :: "v"(o));                             // (performed, not just accepted, before the barrier)
+  };
   auto read_counters = [&]() {                                    // thread 0: this iteration's share of the cumulative counters
-    ls.hard_count = ld_dev(&st->hard_count) - cnt_prev[0];
-    ls.deferred_count = ld_dev(&st->deferred_count) - cnt_prev[1];
+    ls.hard_count = ld_dev(&ctr->hard_count) - cnt_prev[0];
+    ls.deferred_count = ld_dev(&ctr->deferred_count) - cnt_prev[1];
     ls.unresolved_count = 0;
     ls.min_lb_key = ~ld_dev(min_lb_word);
   };
@@ -483,7 +509,7 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
     }
     if (ls.iter == 0) {
       // every query searches: the rounds of nn_ball_lds (the workgroup's queries walk the rows of their balls from LDS tables)
-      for (int r = blockIdx.x; r < nrounds; r += (int)G) ball_lds_rounds<1, false>(b, st, &ls, pair, r * kNnThreads, Mc, s_hist, min_lb);
+      for (int r = blockIdx.x; r < nrounds; r += (int)G) ball_lds_rounds<1, false>(b, ctr, &ls, pair, r * kNnThreads, Mc, s_hist, min_lb);
     } else {
       // Later iterations: the certificate for every query (nn_certify), then the few whose certificate fails (6 % of them in a
       // settled iteration: ~30 of a workgroup's 512) searched with as many lanes each as the workgroup has to spare (the listed
@@ -538,11 +564,11 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
           if (fail) s_fail[basepos + rank_below(fm)] = i;
         }
         const unsigned long long hm = __ballot(hard);
-        if (lane == 0 && hm) asink |= __hip_atomic_fetch_add(&st->hard_count, (uint32_t)__popcll(hm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && hm) asink |= __hip_atomic_fetch_add(&ctr->hard_count, (uint32_t)__popcll(hm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
       const int nf = (int)s_misc[7];
-      if (threadIdx.x == 0 && nf) asink |= __hip_atomic_fetch_add(&st->deferred_count, (uint32_t)nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0 && nf) asink |= __hip_atomic_fetch_add(&ctr->deferred_count, (uint32_t)nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (nf > 0) {
         const ListedCtx ctx = listed_ctx(b, &ls, pair);
         int logL = 0;
@@ -557,7 +583,7 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
           float4 srec; float drec; int jrec;
           listed_search_one(b, &ls, ctx, so, i, sub, L, s_hist, min_lb, hard, false, 0, 0, band, srec, drec, jrec);
           const unsigned long long hm = __ballot(hard && sub == 0);
-          if (lane == 0 && hm) asink |= __hip_atomic_fetch_add(&st->hard_count, (uint32_t)__popcll(hm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0 && hm) asink |= __hip_atomic_fetch_add(&ctr->hard_count, (uint32_t)__popcll(hm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       asm volatile("" :: "v"(asink));
@@ -603,6 +629,7 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
         if (threadIdx.x < 5) s_cnt[threadIdx.x] = threadIdx.x == 0 ? (tot & 0xffffu) : (threadIdx.x == 1 ? tot >> 16 : (blo + (threadIdx.x - 2) <= bhi ? s_hist[blo + (threadIdx.x - 2)] : 0u));
       }
       SMHIP_OPH(9);
+      SMHIP_OTRACE(1, s_cnt[0]);
       one_grid_sync_counts(sync, target, og, s_cnt, s_cnt + 8, cprev, &s_misc[3], &s_abort);
       if (bail()) return;
       SMHIP_OPH(10);
@@ -641,8 +668,9 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
     }
     if (!have_sums) {
       // ---------------- the plain form: the pair's histogram, the quantile's bin, the sums below it, the exact select inside it
-      flush_hist(b, pair, s_hist);
+      flush_own_hist();
       SMHIP_OPH(1);
+      SMHIP_OTRACE(2, have_sums ? 1 : 0);
       one_grid_sync(sync, target, og, &s_abort);
       if (bail()) return;
       if (!first_barrier_done) clear_next_parity();
@@ -711,10 +739,11 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
         }
         __syncthreads();
         if (threadIdx.x == 0 && s_misc[6]) {
-          const uint32_t o = __hip_atomic_fetch_add(&st->unresolved_count, s_misc[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t o = __hip_atomic_fetch_add(&ctr->unresolved_count, s_misc[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           asm volatile("" :: "v"(o));
         }
-        flush_hist(b, pair, s_hist);
+        flush_own_hist();
+        SMHIP_OTRACE(3, ls.hard_count);
         one_grid_sync(sync, target, og, &s_abort);
         if (bail()) return;
 #pragma unroll
@@ -722,7 +751,7 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
 #pragma unroll
         for (int k = 0; k < kHistBins / kNnThreads; ++k) hcnt[k] = hraw[k] - hprev[k];
         find_quantile_bin_counts(hcnt, b.rho, s_w, s_q);
-        if (threadIdx.x == 0) ls.unresolved_count = ld_dev(&st->unresolved_count) - cnt_prev[2];
+        if (threadIdx.x == 0) ls.unresolved_count = ld_dev(&ctr->unresolved_count) - cnt_prev[2];
         __syncthreads();
       }
 #pragma unroll
@@ -738,6 +767,7 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
         wcount = 0;
       }
       SMHIP_OPH(4);
+      SMHIP_OTRACE(4, qbin);
       one_grid_sync(sync, target, og, &s_abort);
       if (bail()) return;
       SMHIP_OPH(5);
@@ -790,7 +820,7 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
       double v = 0.0;
       if (threadIdx.x == 0) v = ((s_red[0][0] + s_red[1][0]) + s_red[2][0]) + s_red[3][0];
       if (threadIdx.x == 1) v = (double)(((s_wc[0] + s_wc[1]) + s_wc[2]) + s_wc[3]);
-      st_dev(&rows[(size_t)blockIdx.x * kAccCols + threadIdx.x], v);
+      pub_dev(&rows[(size_t)blockIdx.x * kAccCols + threadIdx.x], v);
     }
     one_grid_sync_fold(sync, target, og, rows, grows, s_part, &s_misc[3], &s_abort);
     if (bail()) return;

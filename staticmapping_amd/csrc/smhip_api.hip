@@ -75,6 +75,8 @@ struct smhip_context {
   int use_shadow = 1;            // fused certificate pass reads the 4-byte shadow of (bound, match) where every target is small enough (SMHIP_SHADOW)
   int one_blocks = 0;            // workgroups of the single-pair persistent kernel the device holds at once (0: not available)
   int one_used = 0;              // the last single-pair enqueue went through it
+  int one_blocks_allowed = 1;    // 0: fine-grained memory could not be had at smhip_create
+  int one_fallbacks = 0;         // Aligns done again as separate launches because the launch stopped itself (see fetch_range)
   int one_enabled = 1;           // SMHIP_ONE_PAIR=0: single pairs through the separate launches (measurement aid)
   int one_groups_want = 0;       // SMHIP_ONE_GROUPS: groups of its barrier (tuning)
   int one_blocks_want = 0;       // SMHIP_ONE_BLOCKS: its grid (tuning; 0 = as many as a round each needs, at most what is resident)
@@ -711,8 +713,31 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
   A(dev_alloc(h, &d.partials, B * (size_t)d.part_stride * kAccCols));
   A(dev_alloc(h, &d.tpart, B * kTgtReduceBlocks * 16));
   A(dev_alloc(h, &d.done_count, 4));
-  A(dev_alloc(h, &d.one_sync, (size_t)kOneSyncWords * kOnePairs));
-  A(dev_alloc(h, &d.one_rows, (size_t)kOnePairs * (kOneMaxBlocks + 32) * kAccCols));
+  {   // everything of the single-pair cooperative launch that crosses workgroups: ONE fine-grained allocation (see IcpDev::one_ctr)
+    const size_t w_sync = (size_t)kOneSyncWords * kOnePairs * 4, w_rows = (size_t)kOnePairs * (kOneMaxBlocks + 32) * kAccCols * 8,
+                 w_hist = (size_t)kHistBins * kOnePairs * 4, w_keys = (size_t)kOnePairs * 2 * (size_t)d.bl_stride * 4, w_ctr = sizeof(PairState) * kOnePairs;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t total = up(w_sync) + up(w_rows) + up(w_hist) + up(w_keys) + up(w_ctr);
+    void* v = nullptr;
+    if (s == SMHIP_OK) {
+      if (hipExtMallocWithFlags(&v, total, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        v = nullptr;
+        if (hipMalloc(&v, total) != hipSuccess) { s = SMHIP_ERR_HIP; v = nullptr; }
+        h->one_blocks_allowed = 0;           // (no fine-grained memory: single pairs keep to the separate launches)
+      }
+      if (v) {
+        h->allocs.push_back(v);
+        char* c = reinterpret_cast<char*>(v);
+        d.one_sync = reinterpret_cast<uint32_t*>(c); c += up(w_sync);
+        d.one_rows = reinterpret_cast<double*>(c); c += up(w_rows);
+        d.one_hist = reinterpret_cast<uint32_t*>(c); c += up(w_hist);
+        d.one_keys = reinterpret_cast<uint32_t*>(c); c += up(w_keys);
+        d.one_ctr = reinterpret_cast<PairState*>(c);
+        if (hipMemsetAsync(v, 0, total, h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
+      }
+    }
+  }
   A(dev_alloc(h, &h->ids_dev, NS));
   A(dev_alloc(h, &h->d2_dev, NS));
   if (s == SMHIP_OK) {
@@ -733,7 +758,7 @@ smhip_status smhip_create(int device, void* stream, int pair_slots, int max_sour
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, icp_one, kNnThreads, 0) == hipSuccess && per_cu > 0)
       h->one_blocks = (std::min(per_cu * prop.multiProcessorCount, kOneMaxBlocks) / 32) * 32;
     (void)hipGetLastError();
-    if (hipMemsetAsync(d.one_sync, 0, sizeof(uint32_t) * kOneSyncWords * kOnePairs, h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
+    if (!h->one_blocks_allowed) h->one_blocks = 0;
   }
   if (s == SMHIP_OK && hipMemsetAsync(d.state, 0, B * sizeof(PairState), h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
   if (s == SMHIP_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = SMHIP_ERR_HIP;
@@ -1359,6 +1384,24 @@ static smhip_status fetch_range(smhip_handle h, int first, int npairs, double* r
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(h->state_pinned, h->dev.state + first, sizeof(PairState) * npairs, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->one_used && !std::getenv("SMHIP_ONE_NO_RETRY")) {
+    // The cooperative launch stopped itself (its barrier watchdog or its workgroups' consistency check, icp_one.hip): never seen
+    // on a single pair, but the protocol rests on the timing of agent-scope loads, not on fences -- so the Align is simply done
+    // again as separate launches (whose result differs from the launch's in the sums' order: ~1e-15) and the handle keeps to them.
+    bool stopped = false;
+    for (int p = 0; p < npairs; ++p) stopped = stopped || (h->state_pinned[p].done && h->state_pinned[p].status == SMHIP_ERR_HIP);
+    if (stopped) {
+      std::vector<double> g(16 * (size_t)npairs);
+      for (int p = 0; p < npairs; ++p)
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) g[16 * (size_t)p + 4 * c + r] = h->in_pinned[first + p].guess[4 * r + c];
+      h->one_blocks = 0;
+      h->one_fallbacks += 1;
+      const smhip_status rs = enqueue_range(h, first, npairs, g.data());
+      if (rs) return rs;
+      HIPCHK(h, hipMemcpyAsync(h->state_pinned, h->dev.state + first, sizeof(PairState) * npairs, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+  }
   collect_profile(h);
   smhip_status worst = SMHIP_OK;
   for (int p = 0; p < npairs; ++p) {
@@ -1390,6 +1433,23 @@ static smhip_status fetch_range(smhip_handle h, int first, int npairs, double* r
         else
           std::snprintf(buf, sizeof(buf), " [pair %d: noticed by workgroup %u at barrier %u: group arrivals %u of %u, groups arrived %u of %u]", p, w[1], w[2], w[3], w[4], w[5], w[6]);
         h->err += buf;
+#if SMHIP_ONE_CHECKS
+        {   // (diagnostic build) the barriers every workgroup entered, in order: where do they part?
+          const int G = 64, N = 64;
+          std::vector<uint32_t> tr((size_t)G * N * 4);
+          (void)hipMemcpy(tr.data(), h->dev.rec_a + (size_t)p * 2 * h->dev.bl_stride, tr.size() * 4, hipMemcpyDeviceToHost);
+          for (int n = 0; n < N; ++n) {
+            bool same = true;
+            for (int w = 1; w < 40; ++w) for (int c = 0; c < 3; ++c) same = same && tr[((size_t)w * N + n) * 4 + c] == tr[(size_t)n * 4 + c];
+            if (!same) {
+              std::fprintf(stderr, "[icp_one trace] pair %d: workgroups part at their barrier %d:", p, n + 1);
+              for (int w = 0; w < 40; ++w) std::fprintf(stderr, " %u/%u/%u/%u", tr[((size_t)w * N + n) * 4], tr[((size_t)w * N + n) * 4 + 1], tr[((size_t)w * N + n) * 4 + 2], tr[((size_t)w * N + n) * 4 + 3]);
+              std::fprintf(stderr, "\n");
+              break;
+            }
+          }
+        }
+#endif
       }
     }
     if (!st.done && worst == SMHIP_OK) { worst = SMHIP_ERR_HIP; h->err = "pair did not finish (internal)"; }

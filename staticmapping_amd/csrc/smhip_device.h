@@ -202,6 +202,12 @@ struct IcpDev {
   uint32_t* done_count;      // number of finished pairs
   uint32_t* one_sync;        // [kOnePairs][kOneSyncWords] grid barrier + key-list length of the persistent kernel (icp_one), per pair of its launch
   double* one_rows;          // [kOnePairs][kOneMaxBlocks + 32][kAccCols] its workgroups' rows of sums, then its groups'
+  uint32_t* one_hist;        // [kOnePairs][kHistBins] its own level-1 histogram (cumulative inside a launch)
+  uint32_t* one_keys;        // [kOnePairs][2 bl_stride] its key lists (two parities)
+  PairState* one_ctr;        // [kOnePairs] the counters its workgroups add to (hard_count, deferred_count, unresolved_count)
+                             // -- everything of icp_one that crosses workgroups lies in FINE-GRAINED device memory (one allocation,
+                             //    hipDeviceMallocFinegrained): the XCDs' L2s do not keep such lines, so an agent-scope load behind a
+                             //    barrier cannot be served a copy from before it
   uint8_t* nabo_work;        // [slots][ns_cap] SMHIP_NN_NABO: buckets the query's last walk scanned (capped at 255); null until the mode is used
   uint32_t* search_hist;     // [slots][kSearchHist] queries that needed a search in iteration k of the last Align (finalize; read back by the
                              //                 host to place the switch from the fused search to certify + listed search, split_after = 0)

@@ -99,12 +99,12 @@ typedef struct smhip_icp_options {
                                    either way; the 29 sums are added in a different (fixed) order: poses agree to ~1e-12.
                                    SMHIP_NN_NABO has the same form (traversal certificates instead of distance bounds), from the
                                    iteration on in which the previous batch's median pair walked fewer than a fifth of its queries. */
-  int32_t no_single_kernel;     /* a single pair (smhip_icp_align / a batch of one): 1 = the iteration loop as separate launches per iteration.
-                                   Default 0: the whole loop of icp_fast.cc:484-523 and the score as ONE cooperative launch whose workgroups
-                                   stay resident and meet at grid barriers (exact-search mode with certificates; other modes and clouds of more
-                                   than 8 rounds of 256 points per resident workgroup take the separate launches).  The same matches, distances
-                                   and kept sets either way; the sums are added in a different (fixed) order: poses agree to ~1e-14.
-                                   Cooperative launches of several handles run one after the other on the device. */
+  int32_t no_single_kernel;     /* a single pair (smhip_icp_align) or a batch of up to 8 pairs: 1 = the iteration loop as separate launches per
+                                   iteration.  Default 0: the whole loop of icp_fast.cc:484-523 and the score as ONE cooperative launch whose
+                                   workgroups stay resident and meet at grid barriers, a row of the grid per pair (exact-search mode with
+                                   certificates; other modes and clouds of more than 16 rounds of 256 points per resident workgroup take the
+                                   separate launches).  The same matches, distances and kept sets either way; the sums are added in a different
+                                   (fixed) order: poses agree to ~1e-14.  Cooperative launches of several handles run one after the other. */
 } smhip_icp_options;
 
 /* Per-call statistics (all optional to read). */

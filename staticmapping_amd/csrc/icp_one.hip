@@ -58,7 +58,18 @@ __device__ __forceinline__ void pub_dev(double* p, double v) {
 #ifndef SMHIP_ONE_SCOPE
 #define SMHIP_ONE_SCOPE __HIP_MEMORY_SCOPE_AGENT
 #endif
+#if defined(SMHIP_ONE_RMW_READS)
+__device__ __forceinline__ uint32_t ld_dev(const uint32_t* p) { return __hip_atomic_fetch_or(const_cast<uint32_t*>(p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
 __device__ __forceinline__ uint32_t ld_dev(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, SMHIP_ONE_SCOPE); }
+#endif
+__device__ __forceinline__ unsigned long long ld_dev64(const double* p) {
+#if defined(SMHIP_ONE_RMW_READS)
+  return __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(const_cast<double*>(p)), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, SMHIP_ONE_SCOPE);
+#endif
+}
 __device__ __forceinline__ void st_dev(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, SMHIP_ONE_SCOPE); }
 __device__ __forceinline__ void st_dev(double* p, double v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, SMHIP_ONE_SCOPE);
@@ -172,7 +183,7 @@ __device__ __forceinline__ void one_grid_sync_fold(uint32_t* sync, uint32_t& epo
     double s = 0;
 #pragma unroll 8
     for (uint32_t w = g + og.NG * sub; w < G; w += og.NG * 8)
-      s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(rows + (size_t)w * kAccCols + col), __ATOMIC_RELAXED, SMHIP_ONE_SCOPE));
+      s += __longlong_as_double((long long)ld_dev64(rows + (size_t)w * kAccCols + col));
     s_part[sub][col] = s;
     __syncthreads();
     if (threadIdx.x < kAccCols) {
@@ -440,7 +451,7 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
     if (threadIdx.x < kAccCols) {
       double s = 0;
       for (uint32_t k = 0; k < og.NG; ++k)
-        s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(grows + (size_t)k * kAccCols + threadIdx.x), __ATOMIC_RELAXED, SMHIP_ONE_SCOPE));
+        s += __longlong_as_double((long long)ld_dev64(grows + (size_t)k * kAccCols + threadIdx.x));
       dst[threadIdx.x] = s;
       if ((threadIdx.x == 29 && s != (double)my_limit_key * (double)G) || (threadIdx.x == 30 && s != (double)my_n_valid * (double)G)) {
         if (__hip_atomic_exchange(&sync[kSyncAbort], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
@@ -695,6 +706,12 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
         // The bounds are refined to matches (nn_ring<true> + nn_fallback) by their OWNERS: every workgroup walks the rings for the
         // lower-bounded queries among its own points (a stored bound < 0 marks them) and sweeps the whole target for those the rings
         // leave open -- nothing but the histogram and a counter crosses workgroups.  Then one more barrier and the quantile again.
+        // First a barrier: the refinement takes bounds out of the pair's histogram, and no workgroup may still be reading it for the
+        // decision that brought all of them here (without it a slow workgroup read a histogram some bounds had already left, found
+        // the quantile below the smallest bound and did NOT refine: workgroups of one pair at different barriers -- seen only in
+        // launches of several pairs of mixed sizes, where the small pairs' workgroups run far apart).
+        one_grid_sync(sync, target, og, &s_abort);
+        if (bail()) return;
         for (int k = threadIdx.x; k < kHistBins; k += kNnThreads) s_hist[k] = 0;
         if (threadIdx.x == 0) s_misc[6] = 0;
         __syncthreads();
@@ -743,7 +760,7 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
           asm volatile("" :: "v"(o));
         }
         flush_own_hist();
-        SMHIP_OTRACE(3, ls.hard_count);
+        SMHIP_OTRACE(3, s_q[0] | ((ls.min_lb_key >> kHistShift) << 12) | (ls.hard_count > 0 ? 1u << 24 : 0u) | ((s_q[2] & 0x7fu) << 25));
         one_grid_sync(sync, target, og, &s_abort);
         if (bail()) return;
 #pragma unroll
@@ -767,7 +784,7 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
         wcount = 0;
       }
       SMHIP_OPH(4);
-      SMHIP_OTRACE(4, qbin);
+      SMHIP_OTRACE(4, qbin | ((ls.min_lb_key >> kHistShift) << 12) | (ls.hard_count > 0 ? 1u << 24 : 0u) | ((n_valid & 0x7fu) << 25));
       one_grid_sync(sync, target, og, &s_abort);
       if (bail()) return;
       SMHIP_OPH(5);
@@ -800,6 +817,12 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
   }
   // ---------------- the score of the iteration the loop ended with: exp(-mean distance of its kept matches) (icp_fast.cc:516-522)
   if (ls.status != 0) return;
+  // (a barrier first: the score's fold writes the groups' rows again, and a group whose workgroups are all here already would
+  // write its row while a slow workgroup of another group is still reading the LAST iteration's -- inside the loop a whole
+  // barrier always lies between two folds, here none did: a pair of a launch of seven ended with 10 729 of its 14 000 kept
+  // matches in its state, which the score's own count gave away)
+  one_grid_sync(sync, target, og, &s_abort);
+  if (bail()) return;
   {
     const uint32_t limit_key = ls.limit_key;
     double s = 0.0;
@@ -828,13 +851,14 @@ __global__ __launch_bounds__(kNnThreads, 1) void icp_one(IcpDev b, int groups) {
     if (threadIdx.x < 2) {
       double t = 0;
       for (uint32_t k = 0; k < og.NG; ++k)
-        t += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(grows + (size_t)k * kAccCols + threadIdx.x), __ATOMIC_RELAXED, SMHIP_ONE_SCOPE));
+        t += __longlong_as_double((long long)ld_dev64(grows + (size_t)k * kAccCols + threadIdx.x));
       s_part[0][threadIdx.x] = t;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
       const double tot = s_part[0][0], n = s_part[0][1];
       st->score_mismatch = (uint32_t)n != (uint32_t)ls.kept ? 1u : 0u;
+      st->score_cnt[0] = (uint32_t)n;                         // (what the error text shows beside the kept count)
       st->score = n > 0 ? exp(-tot / n) : 0.0;
     }
   }

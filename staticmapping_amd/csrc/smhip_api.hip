@@ -1267,10 +1267,9 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
   // One pair (the front end's call, map_builder.cc:317-333): the whole loop and the score as ONE cooperative launch whose workgroups
   // meet at grid barriers (icp_one.hip) -- the same matches, distances and kept sets as the launches below.
   h->one_used = 0;
-  // (one pair per launch: the kernel takes a row of its grid per pair -- up to kOnePairs, the back end's handful of concurrent submap
-  // pairs: 6 pairs 1.40 ms against 1.71 as separate launches -- but that form faulted in its fused iterations on batches of four and
-  // more pairs of mixed sizes and is withheld until the cause is found; SMHIP_ONE_PAIRS=n lets tools/one_race_probe.py reach it)
-  const int one_pairs_max = std::getenv("SMHIP_ONE_PAIRS") ? std::min(std::max(std::atoi(std::getenv("SMHIP_ONE_PAIRS")), 1), kOnePairs) : 1;
+  // (up to kOnePairs pairs per launch, a row of the grid each: the back end's handful of concurrent submap pairs -- 6 pairs 1.40 ms
+  // against 1.71 as separate launches; SMHIP_ONE_PAIRS=n lowers the limit, 1 = single pairs only)
+  const int one_pairs_max = std::getenv("SMHIP_ONE_PAIRS") ? std::min(std::max(std::atoi(std::getenv("SMHIP_ONE_PAIRS")), 1), kOnePairs) : kOnePairs;
   if (npairs <= one_pairs_max && h->one_blocks > 0 && !h->opts.no_single_kernel && h->one_enabled && h->opts.nn_mode == SMHIP_NN_GRID && h->dev.use_ball &&
       h->dev.lds_table && h->dev.certify && !h->dev.exact_all && h->profile == 0) {
     const int nrounds = ceil_div(ns_max, kNnThreads);
@@ -1282,7 +1281,9 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
     if (!(h->one_blocks_want > 0 && std::getenv("SMHIP_ONE_IDLE"))) G = std::min(G, ((nrounds + 7) / 8) * 8);   // (SMHIP_ONE_IDLE: tests run small clouds on a grid of mostly idle workgroups)
     if (G >= 64) G = ((G + 31) / 32) * 32;                 // (whole groups of the barrier; workgroups beyond the rounds only take part in the barriers)
     G = std::min(G, ((h->one_blocks / npairs) / 8) * 8);
-    if (G >= 8 && ceil_div(nrounds, G) <= kOneMaxRounds) {
+    // (at most 12 rounds per workgroup -- the kernel holds up to kOneMaxRounds = 16 --: measured on 120 000-point pairs, 6 pairs at 12
+    // rounds 1.52 ms against 1.71 as separate launches, 8 pairs at 15 rounds 1.87 against 1.73)
+    if (G >= 8 && ceil_div(nrounds, G) <= std::min(12, kOneMaxRounds)) {
       if (!cached_one) { s = enqueue_grid_build(h, halves[0], nt_max); if (s) return s; }
       grid_built = true;
       IcpDev d1 = halves[0].d;
@@ -1389,7 +1390,8 @@ static smhip_status fetch_range(smhip_handle h, int first, int npairs, double* r
     // on a single pair, but the protocol rests on the timing of agent-scope loads, not on fences -- so the Align is simply done
     // again as separate launches (whose result differs from the launch's in the sums' order: ~1e-15) and the handle keeps to them.
     bool stopped = false;
-    for (int p = 0; p < npairs; ++p) stopped = stopped || (h->state_pinned[p].done && h->state_pinned[p].status == SMHIP_ERR_HIP);
+    for (int p = 0; p < npairs; ++p)
+      stopped = stopped || (h->state_pinned[p].done && (h->state_pinned[p].status == SMHIP_ERR_HIP || (h->state_pinned[p].status == SMHIP_OK && h->state_pinned[p].score_mismatch)));
     if (stopped) {
       std::vector<double> g(16 * (size_t)npairs);
       for (int p = 0; p < npairs; ++p)
@@ -1455,6 +1457,9 @@ static smhip_status fetch_range(smhip_handle h, int first, int npairs, double* r
     if (!st.done && worst == SMHIP_OK) { worst = SMHIP_ERR_HIP; h->err = "pair did not finish (internal)"; }
     if (st.done && st.status == SMHIP_OK && st.score_mismatch && worst == SMHIP_OK) {
       worst = SMHIP_ERR_HIP; h->err = "score: the matches summed are not the matches finalize kept (internal)";
+      char buf[160];
+      std::snprintf(buf, sizeof(buf), " [pair %d: %u distances at or below the quantile, %d kept by the last iteration (%d iterations, %u fused)]", p, st.score_cnt[0], st.kept, st.iter, st.spec_hits);
+      h->err += buf;
     }
   }
   return worst;

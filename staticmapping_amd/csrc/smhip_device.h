@@ -53,7 +53,7 @@ constexpr int kCertifyItems = 32;        // rounds per workgroup of the certific
                                          // 512-pair step: 16: 8.41, 20: 8.21, 32: 7.97, 40: 7.98 ms (at most 32: one bit per round in nabo_list_append)
 
 // the single-pair persistent kernel (icp_one.hip)
-constexpr int kOneMaxRounds = 8;         // rounds of 256 points a workgroup may own (sizes the LDS list of its in-bin points)
+constexpr int kOneMaxRounds = 16;        // rounds of 256 points a workgroup may own (sizes the LDS list of its in-bin points: 16 KiB)
 constexpr int kOneSyncWords = 4096;      // IcpDev::one_sync: the grid barrier's counters and flags + the length of the key list, a 128-byte line each; zeroed per Align
 constexpr int kOneMaxBlocks = 1024;      // the largest grid (workgroups per pair) of the kernel
 constexpr int kOnePairs = 8;             // pairs one launch of it can hold (grid.y; each with its own barrier lines and rows)

@@ -174,3 +174,55 @@ def test_six_matchers_align_at_once(smhip, cfg2):
     for t in threads: t.join(timeout=120)
     assert not any(t.is_alive() for t in threads), "a matcher did not return"
     assert not err, err
+
+
+@pytest.mark.parametrize("npairs", [2, 3, 6, 8])
+def test_small_batches_take_the_one_launch(smhip, velo20k, cfg1, cfg2, npairs):
+    """Up to eight pairs (the back end's handful of concurrent submap pairs) share one cooperative launch, a row of the grid each:
+    clouds of three very different sizes in one batch (what exposed the launch's two missing barriers), against the same batch as
+    separate launches and against a single Align; ten repeated launches, every one the first one's bits."""
+    cases = [cfg2, cfg1, velo20k, cfg2, velo20k, cfg1, cfg2, velo20k][:npairs]
+    guesses = [c.get("guess", np.eye(4)) for c in cases]
+    cap_s = max(len(c["src"]) for c in cases); cap_t = max(len(c["q"]) for c in cases)
+    out = {}
+    for name, opts in (("one", dict()), ("separate", dict(no_single_kernel=1))):
+        m = smhip.IcpFastHip(pair_slots=npairs, max_source_points=cap_s, max_target_points=cap_t, max_iteration=20, early_exit=1, **opts)
+        for s, c in enumerate(cases):
+            m.set_input_source(c["src"], slot=s); m.set_input_target(c["q"], c["n"], slot=s)
+        R, sc, st = m.align_batch(npairs, guesses)
+        for rep in range(10 if name == "one" else 1):
+            R2, sc2, st2 = m.align_batch(npairs, guesses)
+            assert R.tobytes() == R2.tobytes() and sc.tobytes() == sc2.tobytes(), (name, rep)
+        out[name] = (R, sc, [dict(x) for x in st])
+        m.close()
+    for s in range(npairs):
+        a, b_ = out["one"], out["separate"]
+        assert a[2][s]["iterations"] == b_[2][s]["iterations"] and abs(a[2][s]["kept"] - b_[2][s]["kept"]) <= 2, (s, a[2][s], b_[2][s])
+        da, dt = smhip.se3_error(a[0][s], b_[0][s])
+        assert da < 1e-10 and dt < 1e-10, (s, da, dt)
+        assert abs(a[1][s] - b_[1][s]) < 1e-11
+    # a pair's result does not depend on what shares the launch with it: slot 0 against the same pair aligned alone (its grid differs)
+    m1 = smhip.IcpFastHip(max_source_points=cap_s, max_target_points=cap_t, max_iteration=20, early_exit=1)
+    m1.set_input_source(cases[0]["src"]); m1.set_input_target(cases[0]["q"], cases[0]["n"])
+    _, R1 = m1.align(guesses[0])
+    m1.close()
+    da, dt = smhip.se3_error(out["one"][0][0], R1)
+    assert da < 1e-10 and dt < 1e-10, (da, dt)
+
+
+def test_mixed_small_batch_many_iterations(smhip, cfg1, velo20k):
+    """Pairs of different sizes, 25 iterations each, bounds refined in most iterations of the small ones: the shape in which a fast
+    workgroup used to take bounds out of the histogram a slow one was still reading, and in which the score's fold used to overwrite
+    the last iteration's rows.  40 launches of 7 pairs, every one the first one's bits."""
+    cases = [cfg1, velo20k, velo20k, cfg1, velo20k, velo20k, cfg1]
+    guesses = [c.get("guess", np.eye(4)) for c in cases]
+    cap_s = max(len(c["src"]) for c in cases); cap_t = max(len(c["q"]) for c in cases)
+    m = smhip.IcpFastHip(pair_slots=7, max_source_points=cap_s, max_target_points=cap_t, max_iteration=25, early_exit=0)
+    for s, c in enumerate(cases):
+        m.set_input_source(c["src"], slot=s); m.set_input_target(c["q"], c["n"], slot=s)
+    R, sc, st = m.align_batch(7, guesses)
+    assert max(x["refined_iterations"] for x in st) > 5
+    for rep in range(40):
+        R2, sc2, st2 = m.align_batch(7, guesses)
+        assert R.tobytes() == R2.tobytes() and sc.tobytes() == sc2.tobytes(), rep
+    m.close()

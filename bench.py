@@ -714,6 +714,14 @@ def end_to_end(dev, n_scans=513, n_points=N_POINTS):
                     "host_side_split_s": {"wait_for_readers": best.get("wait_for_readers_s_rank0"), "upload_and_morton_order": best.get("upload_s_rank0"),
                                           "device_calculate_normals": best.get("prepare_targets_s_rank0"),
                                           "read_upload_prepare_total": best["read_upload_prepare_s_rank0"]},
+                    "clock": "starts before the driver's readers open the first file, stops when the gathered poses are on the host side of the "
+                             "collective; before it: the handle, its workspaces and one batch of 32 made-up 8 192-point scans through the same calls "
+                             "(code objects loaded, copy stream created -- a process pays that once, not per sequence)",
+                    "warmup_batch_before_the_clock_s": best.get("warmup_batch_before_the_clock_s"),
+                    "host_side_split_note": "device_calculate_normals is the host blocked in the batch's target preparation, which runs on the stream "
+                                            "behind the previous batch's alignments: it holds their remaining time too (per 256-pair batch: alignments "
+                                            "~15 ms, preparation ~15 ms of which kd_forest_build 11-13; side by side on two streams they take the same "
+                                            "30 ms -- both are bound by instruction issue on the CUs, not by HBM)",
                     "mean_iterations": best["mean_iterations"], "unfinished_pairs": best["unfinished_pairs"],
                     "relative_pose_error_vs_generating_motion_m": {"median": float(np.median(errs)), "p95": float(np.percentile(errs, 95)), "max": float(np.max(errs))}})
         return out

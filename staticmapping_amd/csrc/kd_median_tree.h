@@ -77,6 +77,20 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, u
 }
 
 
+// SMHIP_KD_TIMING (diagnostic build): workgroup 0 adds up where kd_median_build's time goes (wall clock, 10 ns ticks) and prints it
+#ifdef SMHIP_KD_TIMING
+#define SMHIP_KDPH(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now_ = wall_clock64(); s_kdph[i] += now_ - s_kdph[15]; s_kdph[15] = now_; } } while (0)
+#else
+#define SMHIP_KDPH(i) do { } while (0)
+#endif
+
+#ifndef SMHIP_KD_SU
+#define SMHIP_KD_SU 4
+#endif
+#ifndef SMHIP_KD_PU
+#define SMHIP_KD_PU 4
+#endif
+
 struct KdSeg {                            // one node of the current level while the tree is being built
   uint32_t first, count;                  // its points: positions [first, first + count) of the working order
   float mn[3], mx[3];                     // the box it inherited
@@ -125,7 +139,12 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
   __shared__ uint32_t s_gst[3 * 64];                         // select state of a group's segments during a sweep
   if (n >= 0xffffff) { if (tid == 0) *status = 3; return; }  // (the sort keys of the last levels hold 24 index bits; the callers' own caps are far below)
   int S = 1;                                                 // segments of the current level
+#ifdef SMHIP_KD_TIMING
+  __shared__ unsigned long long s_kdph[16];
+  if (tid == 0) { for (int k = 0; k < 15; ++k) s_kdph[k] = 0; s_kdph[15] = wall_clock64(); }
+#endif
   for (int level = 0; level < 40 && S > 0; ++level) {
+    SMHIP_KDPH(7);
     // ---- per segment: leaf or split, cut dimension, leftCount
     uint32_t my_splits = 0;
     if (tid == 0) s_misc[2] = 0;                             // the largest splitting segment of the level
@@ -165,6 +184,7 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
     if (2 * nsplit > (uint32_t)seg_cap || s_misc[0] + 2 * nsplit > (uint32_t)node_cap) { if (tid == 0) *status = 3; break; }   // cannot happen: caps follow nt_cap
 
     const uint32_t nc = s_misc[0];
+    SMHIP_KDPH(0);
     if (level == 0 && s_misc[2] > 64u) {                     // the root's keys (every later level's come from the partition below)
       const uint32_t d0 = seg[0].dim;
       for (int i = tid; i < n; i += kKdThreads) kk[i] = kd_key(kd_coord(cur[i], d0));
@@ -242,10 +262,14 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
           if (rnk == left_s) seg[sv_s].prefix = key;                           // the nth element: its coordinate is the cut value
         }
       }
+      __syncthreads();
+      SMHIP_KDPH(1);
     } else {
+    SMHIP_KDPH(0);
     // ---- exact radix select of the element of rank `left` on the cut coordinate, all segments of a group at once
     // 8-bit digits while a level has <= 1024 segments: beyond 64 of them the level is swept in groups of 64 segments, each group
     // over its own positions only -- 4 short sweeps per group instead of 8 (4-bit digits) over every point of the cloud
+    constexpr int kSU = SMHIP_KD_SU;                         // positions per thread and trip of a sweep
     const int bits = S <= 1024 ? 8 : (S <= 4096 ? 4 : (S <= 8192 ? 2 : 1));
     const int G = kKdHistWords >> bits;                      // segments per group
     const uint32_t mask = (1u << bits) - 1u;
@@ -277,19 +301,19 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
             s_gst[tid] = g.prefix; s_gst[64 + tid] = pass == 0 ? g.split : (g.split & g.tie); s_gst[128 + tid] = g.vidx;
           }
           __syncthreads();
-          // four positions per thread and trip, their levels of loads (segment id + key, segment state) issued together:
+          // kSU positions per thread and trip, their levels of loads (segment id + key, segment state) issued together:
           // one position at a time every visit was a chain of dependent memory latencies
-          for (uint32_t pos0 = p_lo + tid; pos0 < p_hi; pos0 += 4 * kKdThreads) {
-            uint32_t sv[4], kv[4];
+          for (uint32_t pos0 = p_lo + tid; pos0 < p_hi; pos0 += kSU * kKdThreads) {
+            uint32_t sv[kSU], kv[kSU];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kSU; ++u) {
               const uint32_t pos = pos0 + u * kKdThreads;
               sv[u] = pos < p_hi ? sid[pos] : 0xffffffffu;
               kv[u] = kk[min(pos, p_hi - 1u)];
             }
-            uint32_t gpre[4], gsel[4], gvid[4];
+            uint32_t gpre[kSU], gsel[kSU], gvid[kSU];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kSU; ++u) {
               if (staged) {
                 const uint32_t sl = sv[u] == 0xffffffffu ? 0u : sv[u] - (uint32_t)g0;
                 gpre[u] = s_gst[sl]; gvid[u] = s_gst[128 + sl];
@@ -301,7 +325,7 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
               }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kSU; ++u) {
               bool sel = gsel[u] != 0u;
               uint32_t bin = 0;
               const uint32_t key = kv[u];
@@ -333,6 +357,7 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
             }
           }
           __syncthreads();
+          SMHIP_KDPH(2);
           if (bits == 8) {
             // few segments, 256 bins each: a wave per segment, four bins per lane, one scan (a single thread walking 256
             // bins took longer than the sweep over the points)
@@ -373,6 +398,7 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
             }
           }
           __syncthreads();
+          SMHIP_KDPH(3);
         }
       }
     }
@@ -399,6 +425,7 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
       }
       __syncthreads();
     }
+    SMHIP_KDPH(4);
     // ---- partition into the other buffer; children become the next level's segments
     const bool lds_counters = 2 * S <= kKdHistWords;
     uint32_t* cnt = lds_counters ? s_hist : cnt_global;
@@ -413,7 +440,7 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
         sf[5 * S + k] = g.left; sf[6 * S + k] = g.rank; sf[7 * S + k] = g.ldim; sf[8 * S + k] = g.rdim;
       }
     __syncthreads();
-    constexpr int kPU = 4;                                    // positions per thread and trip, their loads issued together
+    constexpr int kPU = SMHIP_KD_PU;                          // positions per thread and trip, their loads issued together
     for (uint32_t pos0 = 0; pos0 < (uint32_t)n; pos0 += kPU * kKdThreads) {     // whole waves take the trip together (ballots below)
       uint32_t sq[kPU];
       float4 pq[kPU];
@@ -479,9 +506,11 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
       }
       }
     }
+    __syncthreads();
+    SMHIP_KDPH(5);
     }   // radix select + partition
     __syncthreads();
-    for (int s = s_lo; s < s_hi; ++s) {
+    for (int s = tid; s < S; s += kKdThreads) {                // (strided: neighbouring lanes, neighbouring segments)
       const KdSeg& g = seg[s];
       if (!g.split) continue;
       const float cut = kd_unkey(g.prefix);
@@ -501,7 +530,13 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
     { KdSeg* ts = seg; seg = seg_o; seg_o = ts; }
     S = 2 * (int)nsplit;
     __syncthreads();
+    SMHIP_KDPH(6);
   }
+#ifdef SMHIP_KD_TIMING
+  if (tid == 0 && blockIdx.x == 0)
+    printf("[kd timing, n %d] setup %.0f us, small-segment levels %.0f, select sweeps %.0f, select scans %.0f, child dims %.0f, partition %.0f, next segments %.0f, level head %.0f\n", n,
+           s_kdph[0] * 0.01, s_kdph[1] * 0.01, s_kdph[2] * 0.01, s_kdph[3] * 0.01, s_kdph[4] * 0.01, s_kdph[5] * 0.01, s_kdph[6] * 0.01, s_kdph[7] * 0.01);
+#endif
 }
 
 }  // namespace smhip

@@ -50,7 +50,7 @@ struct Args {
   std::string scans_dir, out_path = "kitti_pose.txt", id_file;
   unsigned long long nonce = 0;             // identifies this run's id file (launcher: pid and start time; else MASTER_PORT)
   int gpus = 1, rank = -1, world = -1, local_rank = -1;
-  int batch = 256, iterations = 20, early_exit = 0, max_pairs = -1, readers = 8, matchers = 1;
+  int batch = 256, iterations = 20, early_exit = 0, max_pairs = -1, readers = 8, matchers = 1, warmup = 1;
   double guess_tx = 0.0;
   bool quiet = false;
 };
@@ -99,10 +99,11 @@ Args Parse(int argc, char** argv) {
     else if (k == "--max-pairs") a.max_pairs = std::atoi(val().c_str());
     else if (k == "--readers") a.readers = std::atoi(val().c_str());
     else if (k == "--matchers") a.matchers = std::atoi(val().c_str());
+    else if (k == "--warmup") a.warmup = std::atoi(val().c_str());
     else if (k == "--guess-tx") a.guess_tx = std::atof(val().c_str());
     else if (k == "--quiet") a.quiet = true;
     else Die("unknown argument " + k + "\nusage: smhip_shard --scans DIR [--gpus G] [--out kitti_pose.txt] [--batch 256] "
-             "[--iterations 20] [--early-exit 0|1] [--guess-tx metres] [--max-pairs N] [--readers 8] [--matchers 1|2]");
+             "[--iterations 20] [--early-exit 0|1] [--guess-tx metres] [--max-pairs N] [--readers 8] [--matchers 1|2] [--warmup 1|0]");
   }
   if (a.scans_dir.empty()) Die("--scans DIR is required");
   if (a.rank < 0 && std::getenv("RANK")) a.rank = std::atoi(std::getenv("RANK"));
@@ -214,6 +215,59 @@ int RunRank(const Args& a, int rank, int world, int device) {
     pageable.assign(ring, std::vector<float>(slot_floats));
     for (int k = 0; k < ring; ++k) ring_buffers[k] = pageable[k].data();
   }
+  for (int k = 0; k < NH; ++k) {
+    if (smhip_reserve_batch_workspaces(hs[k]) != SMHIP_OK) Die(smhip_last_error(hs[k]));     // not inside the first batch
+    HIPOK(hipStreamSynchronize(streams[k]));
+  }
+  // Part of bringing the process up, like the handle and its workspaces above: one batch of 32 small made-up scans (three walls of a
+  // room, 8 192 points each) through the same four calls as every batch below.  The first use of a kernel loads its code object, the
+  // first batched upload creates the copy stream, the first radix sort sizes rocPRIM's workspace -- 25 ms of a first batch that a
+  // mapping process pays once, not per sequence.  Nothing of it survives: every slot is set again by the first real batch.
+  double warmup_s = 0.0;
+  if (a.warmup) {
+    const auto w0 = std::chrono::steady_clock::now();
+    const int WN = 8192, WS = std::min(32, B);
+    // (page-locked like the readers' buffers, so that the upload takes the same road)
+    float* wmem = nullptr;
+    std::vector<float> wpageable;
+    const size_t wfloats = 4 * static_cast<size_t>(WN);
+    if (!pinned || hipHostMalloc(reinterpret_cast<void**>(&wmem), wfloats * (WS + 1) * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError(); wmem = nullptr; wpageable.resize(wfloats * (WS + 1));
+    }
+    float* wbase = wmem ? wmem : wpageable.data();
+    std::vector<float*> wscan(WS + 1);
+    for (int k = 0; k <= WS; ++k) wscan[k] = wbase + wfloats * k;
+    uint32_t lcg = 12345u;
+    auto u01 = [&]() { lcg = lcg * 1664525u + 1013904223u; return static_cast<float>(lcg >> 8) * (1.0f / 16777216.0f); };
+    for (int k = 0; k <= WS; ++k)
+      for (int i = 0; i < WN; ++i) {
+        float x = 20.f * u01() - 10.f, y = 20.f * u01() - 10.f, z = 4.f * u01();
+        switch (i % 3) { case 0: z = 0.002f * u01(); break; case 1: x = 10.f + 0.002f * u01(); break; default: y = 10.f + 0.002f * u01(); break; }
+        float* r = &wscan[k][4 * static_cast<size_t>(i)];
+        r[0] = x - 0.02f * k; r[1] = y; r[2] = z; r[3] = 0.f;
+      }
+    for (int hk = 0; hk < NH; ++hk) {
+      std::vector<int> wslots, wn, wfrom, wto, wnt(WS);
+      std::vector<const float*> wrows;
+      wrows.push_back(wscan[0]); wslots.push_back(B); wn.push_back(WN); wfrom.push_back(B); wto.push_back(0);
+      for (int k = 0; k < WS; ++k) {
+        wrows.push_back(wscan[k + 1]); wslots.push_back(k); wn.push_back(WN);
+        if (k > 0) { wfrom.push_back(k - 1); wto.push_back(k); }
+      }
+      if (smhip_set_sources_f32_batch(hs[hk], static_cast<int>(wslots.size()), wslots.data(), wrows.data(), wn.data()) != SMHIP_OK ||
+          smhip_prepare_targets_from_sources(hs[hk], WS, wfrom.data(), wto.data(), wnt.data()) != SMHIP_OK ||
+          smhip_icp_enqueue_batch(hs[hk], WS, guesses.data()) != SMHIP_OK ||
+          smhip_icp_export_results_device(hs[hk], WS, local_dev) != SMHIP_OK)
+        Die(std::string("warm-up batch: ") + smhip_last_error(hs[hk]));
+      HIPOK(hipStreamSynchronize(streams[hk]));
+    }
+    HIPOK(hipMemsetAsync(local_dev, 0, sizeof(double) * kPoseDoubles * per, stream));
+    HIPOK(hipStreamSynchronize(stream));
+    if (wmem) (void)hipHostFree(wmem);
+    warmup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+  }
+  // the clock starts BEFORE the first file is opened: the readers start here (their head start used to be whatever the set-up above took)
+  const auto t0 = std::chrono::steady_clock::now();
   ScanPrefetcher scans(files, order, a.readers, ring_buffers, slot_floats, /*hold_until_release=*/true);
   auto next_scan = [&](int expect, int* n) -> const float* {
     int fi = -1;
@@ -222,14 +276,12 @@ int RunRank(const Args& a, int rank, int world, int device) {
     if (*n < 0) Die("cannot read " + files[fi]);
     return rows;
   };
-  for (int k = 0; k < NH; ++k) {
-    if (smhip_reserve_batch_workspaces(hs[k]) != SMHIP_OK) Die(smhip_last_error(hs[k]));     // not inside the first batch
-    HIPOK(hipStreamSynchronize(streams[k]));
-  }
-  const auto t0 = std::chrono::steady_clock::now();
   double upload_s = 0.0, wait_s = 0.0, set_s = 0.0, prep_s = 0.0;   // rank 0's host-side split: blocked on the readers / uploads / target preparation
   auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
   int done = 0, my_pairs = 0;
+  // SMHIP_SHARD_TIMELINE=1: where the host is (ms since the clock started) as it walks a batch -- to lay next to a kernel trace
+  const bool timeline = rank == 0 && std::getenv("SMHIP_SHARD_TIMELINE") != nullptr;
+  auto mark = [&](const char* what, int base) { if (timeline) std::fprintf(stderr, "[timeline] %8.3f ms  batch at %d: %s\n", since(t0) * 1e3, base, what); };
   std::vector<int> up_slots, up_n;
   std::vector<const float*> up_rows;
   for (int base = 0, turn = 0; base < per; base += B, ++turn) {
@@ -260,20 +312,24 @@ int RunRank(const Args& a, int rank, int world, int device) {
     }
     wait_s += since(w0);
     if (nb == 0) break;
+    mark("scans at hand", base);
     w0 = std::chrono::steady_clock::now();
     if (smhip_set_sources_f32_batch(h, static_cast<int>(up_slots.size()), up_slots.data(), up_rows.data(), up_n.data()) != SMHIP_OK)
       Die(std::string("upload of batch at pair ") + std::to_string(base * world + rank) + ": " + smhip_last_error(h));
     set_s += since(w0);
+    mark("upload + ordering enqueued", base);
     nts.resize(nb);
     {
       w0 = std::chrono::steady_clock::now();
       if (smhip_prepare_targets_from_sources(h, nb, from.data(), to.data(), nts.data()) != SMHIP_OK) Die(std::string("prepare targets: ") + smhip_last_error(h));
       prep_s += since(w0);
+      mark("targets prepared (blocking)", base);
     }
     scans.ReleaseHeld();            // prepare_targets blocked on the stream: the uploads have left the host buffers
     upload_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - u0).count();
     if (smhip_icp_enqueue_batch(h, nb, guesses.data()) != SMHIP_OK) Die(std::string("enqueue: ") + smhip_last_error(h));
     if (smhip_icp_export_results_device(h, nb, local_dev + static_cast<size_t>(kPoseDoubles) * base) != SMHIP_OK) Die(smhip_last_error(h));
+    mark("alignments enqueued", base);
     done = base + nb;
     my_pairs += nb;
   }
@@ -313,8 +369,8 @@ int RunRank(const Args& a, int rank, int world, int device) {
       std::printf("{\"driver\": \"smhip_shard (C++, RCCL all-gather)\", \"n_gpus\": %d, \"pairs\": %d, \"pairs_rank0\": %d, \"seconds\": %.4f, "
                   "\"pairs_per_s\": %.2f, \"read_upload_prepare_s_rank0\": %.4f, \"wait_for_readers_s_rank0\": %.4f, \"upload_s_rank0\": %.4f, "
                   "\"prepare_targets_s_rank0\": %.4f, \"mean_score\": %.6f, \"mean_iterations\": %.2f, "
-                  "\"unfinished_pairs\": %d, \"batch\": %d, \"readers\": %d, \"pinned_read_buffers\": %s, \"poses_file\": \"%s\"}\n",
-                  world, n_pairs, my_pairs, elapsed, n_pairs / elapsed, upload_s, wait_s, set_s, prep_s, score_sum / n_pairs, iter_sum / n_pairs, bad, B, a.readers, pinned ? "true" : "false", a.out_path.c_str());
+                  "\"unfinished_pairs\": %d, \"batch\": %d, \"readers\": %d, \"pinned_read_buffers\": %s, \"warmup_batch_before_the_clock_s\": %.4f, \"poses_file\": \"%s\"}\n",
+                  world, n_pairs, my_pairs, elapsed, n_pairs / elapsed, upload_s, wait_s, set_s, prep_s, score_sum / n_pairs, iter_sum / n_pairs, bad, B, a.readers, pinned ? "true" : "false", warmup_s, a.out_path.c_str());
     }
     if (bad) rc = 3;
   }

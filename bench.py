@@ -638,12 +638,14 @@ def single_pair_latency(w, device):
     m.set_input_source(w["src"]); m.set_input_target(w["q"], w["n"])
     out = {"workload": "one 120k-pt pair of the batch, guess = previous pair's motion, blocking smhip_icp_align calls"}
 
-    def timed(reps=20):
+    def timed(reps=40):                 # the median call (a mean of 20 moved by 0.1 ms with one hiccup of the host)
         m.align(w["guess_cv"])
-        t = time.perf_counter()
+        ts = []
         for _ in range(reps):
+            t = time.perf_counter()
             m.align(w["guess_cv"])
-        return round((time.perf_counter() - t) / reps * 1e3, 4)
+            ts.append(time.perf_counter() - t)
+        return round(float(np.median(ts)) * 1e3, 4)
     m.set_target_cache(False)
     out["ms_20_iterations_rebuild_every_align"] = timed()
     m.set_target_cache(True)
@@ -652,6 +654,9 @@ def single_pair_latency(w, device):
     m.set_options(max_iteration=100, early_exit=1)
     out["ms_early_exit_target_kept"] = timed()
     out["iterations_early_exit"] = int(m.last_stats[0]["iterations"])
+    used, fell = m.single_launch_counts()
+    out["aligns_as_one_launch"] = used
+    out["launches_that_stopped_themselves"] = fell      # (each would have been redone as separate launches: smhip_icp_single_launch_counts)
     # the same Align as separate launches per iteration (round 5's form): what the one cooperative launch (csrc/icp_one.hip) replaced
     m.set_options(max_iteration=ICP_ITERS, early_exit=0, no_single_kernel=1)
     out["ms_20_iterations_target_kept_separate_launches"] = timed()

@@ -256,6 +256,11 @@ smhip_status smhip_sample_source(smhip_handle h, int from_slot, int to_slot, flo
  * or an option they depend on changes.  enable = 0: nothing survives from one Align to the next, as in the reference
  * (icp_fast.cc:464-467, ndt.cc:54, ndt_gicp.cc:55-81); default 1.  Results are identical either way. */
 smhip_status smhip_set_target_cache(smhip_handle h, int enable);
+/* IcpFast Aligns of up to 8 pairs run as ONE cooperative launch (csrc/icp_one.hip: the loop of icp_fast.cc:484-523 + the score).
+ * Should that launch stop itself (its barrier watchdog, its workgroups' consistency columns, a score whose count differs from the
+ * kept count), the fetch runs the Align again as separate launches and the handle keeps to them: *launches_used = Aligns that went
+ * through the one launch, *fallbacks = how often that happened (0 on every run recorded so far).  Either pointer may be NULL. */
+smhip_status smhip_icp_single_launch_counts(smhip_handle h, int64_t* launches_used, int64_t* fallbacks);
 /* what the handle was created with / what a slot currently holds (any pointer may be NULL) */
 smhip_status smhip_get_capacity(smhip_handle h, int* pair_slots, int* max_source_points, int* max_target_points);
 smhip_status smhip_get_cloud_sizes(smhip_handle h, int slot, int* n_source, int* n_target, int* has_normals);

@@ -11,7 +11,7 @@
 // multiply, all segments of a level in one sweep with their histograms in 64 KiB of LDS), ties on the median value are
 // broken by the index the point carries in .w with a second select (block-uniformly skipped when there are none), and
 // one partition pass moves the points; once the segments hold <= 64 points each, every element is ranked inside its
-// segment by a wave instead (no sweeps).  Many clouds = many workgroups: a batch of >= 256 clouds fills the chip.
+// segment by a wave instead (no sweeps: it counts the smaller keys of its segment, laid in LDS).  Many clouds = many workgroups: a batch of >= 256 clouds fills the chip.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,6 +20,10 @@ namespace smhip {
 
 constexpr int kKdThreads = 1024;          // one workgroup builds one cloud's tree
 constexpr int kKdHistWords = 16384;       // 64 KiB of LDS histograms: segments per pass x 2^bits bins
+#ifndef SMHIP_KD_WN
+#define SMHIP_KD_WN 2                  // windows a wave takes per trip where it ranks by counting
+#endif
+constexpr int kKdCountMax = 64;           // levels whose segments hold at most this many points rank by counting inside a wave's window
 
 // ------------------------------------------------------------------------------------------
 // small device helpers
@@ -125,8 +129,8 @@ __device__ __forceinline__ float kd_coord(const float4 p, uint32_t d) { return d
 // dimension of ITS segment.  The sweeps of the radix select (four per level) then move 8 bytes per point (key + segment id)
 // instead of 20 (the whole float4 for one coordinate of it).  A child's cut dimension follows from the box it inherits, so
 // the partition pass, which has the point in registers, writes the next level's keys as it scatters.
-// fetch(i) = point i of the cloud as the working orders hold it (.w = i as int bits): the last levels sort (segment, coordinate,
-// index) keys in registers and pick the points up again by index.  n < 2^24 - 1.
+// fetch(i) = point i of the cloud as the working orders hold it (.w = i as int bits) -- not called any more (the last levels kept
+// keys, not points, while they sorted; now every lane keeps its point); the callers' argument stays.  n < 2^24 - 1.
 // WIDE: the extents of the inherited box compared as exact double differences (cloud_types.cc works on doubles: two sides whose
 // float difference rounds to the same value are still told apart, as the sort-per-level builder of prep_normals.hip does); the
 // libnabo restatement keeps the float differences it has always used.
@@ -136,6 +140,7 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
                                                 uint2* nodes, uint32_t* cnt_global, int seg_cap, int node_cap,
                                                 uint32_t* s_hist, uint32_t* s_w, uint32_t* s_misc, int32_t* status) {
   const int tid = threadIdx.x;
+  (void)fetch;
   __shared__ uint32_t s_gst[3 * 64];                         // select state of a group's segments during a sweep
   if (n >= 0xffffff) { if (tid == 0) *status = 3; return; }  // (the sort keys of the last levels hold 24 index bits; the callers' own caps are far below)
   int S = 1;                                                 // segments of the current level
@@ -190,80 +195,81 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
       for (int i = tid; i < n; i += kKdThreads) kk[i] = kd_key(kd_coord(cur[i], d0));
       __syncthreads();
     }
-    if (s_misc[2] <= 64u) {
-      // ---- small segments (<= 64 points each: the last levels, where the radix select below needs 16-32 sweeps over every point
-      // because thousands of segments share the histogram words): a wave sorts a window of 128 consecutive positions (two per
-      // lane) by (segment, coordinate, index) in registers.  A window owns the segments that START in its first half -- they end
-      // inside the window -- so the sorted window holds each of them complete and in the select's order: position = where the
-      // key lands, left child = ranks below `left`, cut value = the coordinate of rank `left`.  (The first form compared every
-      // element with 128 broadcasts: 2 600 instructions per window against ~450 for the 28 compare-exchange stages.)
+    if (s_misc[2] <= (uint32_t)kKdCountMax) {
+      // ---- small segments (<= kKdCountMax points each: the last levels, where the radix select below would need 16-32 sweeps over
+      // every point because thousands of segments share the histogram words).  A wave takes a window of 128 consecutive positions
+      // (two per lane) and owns the segments that START in its first half -- they end inside the window.  It lays the window's
+      // keys ([55:24] the coordinate key, [23:0] the point's index in its cloud: all distinct) in LDS, and every element of an
+      // owned segment counts the keys of ITS segment that are smaller than its own -- as many steps as the level's largest
+      // segment has points, one 8-byte LDS read and a compare each; the count is its rank: the point, still in the lane's
+      // registers, goes straight to first + rank, left child = ranks below `left`, cut value = the coordinate of rank `left`.
+      // (Two earlier forms: every element against 128 broadcasts, 2 600 instructions a window; a bitonic network over the
+      // window's 128 keys, 28 compare-exchange stages of two 64-bit shuffles each, after which the points had to be picked up
+      // again by index -- the four levels of a 120 000-point cloud 4.0 ms, counted 2.8.)  kWN windows a trip, their loads
+      // issued together.
       const int lane = tid & 63;
-      for (uint32_t w0 = 64u * (uint32_t)(tid >> 6); w0 < (uint32_t)n; w0 += (uint32_t)kKdThreads) {
-        // a 64-bit sort key per element: [63:56] where its segment starts in the window (+ 64: segments that started in the
-        // previous window come first), [55:24] the coordinate key, [23:0] the point's index in its cloud.  Elements outside
-        // every splitting segment take their own position for the first field (and an all-ones index): they are not moved.
-        unsigned long long kq[2];
-        uint32_t sv0 = 0, left0 = 0, segr0 = 0;
-        bool any_owned = false;
+      constexpr int kWN = SMHIP_KD_WN, kE = 2 * kWN;           // element 2 * w + e: window w of the trip, half e
+      unsigned long long* wk = reinterpret_cast<unsigned long long*>(s_hist) + 128 * kWN * (tid >> 6);   // the wave's 128 keys per window
+      const uint32_t steps = s_misc[2];
+      for (uint32_t wbase = 64u * (uint32_t)(tid >> 6); wbase < (uint32_t)n; wbase += (uint32_t)(kWN * kKdThreads)) {
+        unsigned long long kq[kE];
+        float4 pp[kE];
+        uint32_t fl[kE], cn[kE], lf[kE], sr[kE], svv[kE], gd[kE], gf[kE];
+        bool own[kE], act[kE];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const uint32_t pos = w0 + 64u * e + lane;
-          const bool live = pos < (uint32_t)n;
-          uint32_t sv = 0xffffffffu;
-          float4 p = make_float4(0, 0, 0, 0);
-          if (live) { sv = sid[pos]; p = cur[pos]; }
-          bool act = false;
-          kq[e] = ((unsigned long long)(64u * e + lane + 64u) << 56) | 0xffffffull;
-          if (sv != 0xffffffffu) {
-            const KdSeg& g = seg[sv];
-            if (g.split) {
-              act = true;
-              const uint32_t key = kd_key(kd_coord(p, g.dim)), idx = (uint32_t)__float_as_int(p.w);
-              kq[e] = ((unsigned long long)(g.first + 64u - w0) << 56) | ((unsigned long long)key << 24) | (unsigned long long)idx;
-              if (e == 0) { sv0 = sv; left0 = g.left; segr0 = g.rank; }
-              any_owned = any_owned || (g.first >= w0 && g.first < w0 + 64u);
-            }
-          }
-          if (e == 0 && live && !act) { oth[pos] = p; sid_o[pos] = 0xffffffffu; }   // in a leaf (now or earlier): stays where it is for good
+        for (int q = 0; q < kE; ++q) {
+          const uint32_t pos = wbase + (uint32_t)((q >> 1) * kKdThreads) + 64u * (q & 1) + lane;
+          svv[q] = 0xffffffffu;
+          pp[q] = make_float4(0, 0, 0, 0);
+          if (pos < (uint32_t)n) { svv[q] = sid[pos]; pp[q] = cur[pos]; }
         }
-        if (__ballot(any_owned) == 0ull) continue;            // wave-uniform
-        // bitonic network over the window's 128 keys, two per lane (window index = lane and lane + 64): 28 stages
 #pragma unroll
-        for (int k = 2; k <= 128; k <<= 1) {
-#pragma unroll
-          for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j == 64) {
-              const unsigned long long lo = kq[0] < kq[1] ? kq[0] : kq[1], hi = kq[0] < kq[1] ? kq[1] : kq[0];
-              kq[0] = lo; kq[1] = hi;
-            } else {
-              const bool lower = (lane & j) == 0;
-#pragma unroll
-              for (int e = 0; e < 2; ++e) {
-                const unsigned long long o = __shfl_xor(kq[e], j, 64);
-                const bool up = k == 128 ? true : (k == 64 ? e == 0 : (lane & k) == 0);
-                const bool take_min = up == lower;
-                const bool o_less = o < kq[e];
-                kq[e] = (take_min == o_less) ? o : kq[e];
-              }
-            }
+        for (int q = 0; q < kE; ++q) {
+          act[q] = false; gd[q] = 0; gf[q] = 0; cn[q] = 0; lf[q] = 0; sr[q] = 0;
+          if (svv[q] != 0xffffffffu) {
+            const KdSeg& g = seg[svv[q]];
+            act[q] = g.split != 0u; gd[q] = g.dim; gf[q] = g.first; cn[q] = g.count; lf[q] = g.left; sr[q] = g.rank;
           }
         }
-        // the key now in slot i belongs at position w0 + i; the segment it is part of started at window index [63:56] - 64
+        bool any = false;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const uint32_t a = (uint32_t)(kq[e] >> 56), idx = (uint32_t)(kq[e] & 0xffffffull), key = (uint32_t)(kq[e] >> 24);
-          const bool mine = a >= 64u && a < 128u && idx != 0xffffffu;        // an element of a segment this window owns
-          const int fl = mine ? (int)(a - 64u) : 0;
-          const uint32_t sv_s = (uint32_t)__shfl((int)sv0, fl, 64), left_s = (uint32_t)__shfl((int)left0, fl, 64), segr_s = (uint32_t)__shfl((int)segr0, fl, 64);
-          if (!mine) continue;
-          const uint32_t i = 64u * e + lane, rnk = i - (uint32_t)fl;
-          oth[w0 + i] = fetch(idx);
-          sid_o[w0 + i] = 2 * segr_s + (rnk < left_s ? 0u : 1u);
-          if (rnk == left_s) seg[sv_s].prefix = key;                           // the nth element: its coordinate is the cut value
+        for (int q = 0; q < kE; ++q) {
+          const uint32_t w0 = wbase + (uint32_t)((q >> 1) * kKdThreads);
+          const uint32_t pos = w0 + 64u * (q & 1) + lane;
+          own[q] = false; kq[q] = ~0ull; fl[q] = 0;
+          if (act[q]) {
+            const uint32_t key = kd_key(kd_coord(pp[q], gd[q])), idx = (uint32_t)__float_as_int(pp[q].w);
+            kq[q] = ((unsigned long long)key << 24) | (unsigned long long)idx;
+            own[q] = gf[q] >= w0 && gf[q] < w0 + 64u;
+            fl[q] = gf[q] - w0;
+          }
+          if ((q & 1) == 0 && pos < (uint32_t)n && !act[q]) { oth[pos] = pp[q]; sid_o[pos] = 0xffffffffu; }   // in a leaf (now or earlier): stays where it is for good
+          wk[128 * (q >> 1) + 64 * (q & 1) + lane] = kq[q];
+          any = any || own[q];
+        }
+        if (__ballot(any) == 0ull) continue;                  // wave-uniform
+        uint32_t rk[kE];
+#pragma unroll
+        for (int q = 0; q < kE; ++q) rk[q] = 0u;
+        for (uint32_t t = 0; t < steps; ++t) {
+#pragma unroll
+          for (int q = 0; q < kE; ++q) {
+            const bool in = own[q] && t < cn[q];
+            const unsigned long long o = wk[128 * (q >> 1) + (in ? fl[q] + t : 0u)];
+            rk[q] += (in && o < kq[q]) ? 1u : 0u;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < kE; ++q) {
+          if (!own[q]) continue;
+          const uint32_t dst = wbase + (uint32_t)((q >> 1) * kKdThreads) + fl[q] + rk[q];
+          oth[dst] = pp[q];
+          sid_o[dst] = 2 * sr[q] + (rk[q] < lf[q] ? 0u : 1u);
+          if (rk[q] == lf[q]) seg[svv[q]].prefix = (uint32_t)(kq[q] >> 24);      // the nth element: its coordinate is the cut value
         }
       }
       __syncthreads();
-      SMHIP_KDPH(1);
+      SMHIP_KDPH(8);
     } else {
     SMHIP_KDPH(0);
     // ---- exact radix select of the element of rank `left` on the cut coordinate, all segments of a group at once
@@ -407,7 +413,7 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
     // goes right.  Without ties vidx stays 0: no equal point goes left.
 
     // ---- the children's cut dimensions (their boxes: the parent's with the cut value on one side), for the keys the partition writes
-    const bool next_ranks = (s_misc[2] + 1u) / 2u <= 64u;    // the next level ranks its segments in registers: it reads no keys
+    const bool next_ranks = (s_misc[2] + 1u) / 2u <= (uint32_t)kKdCountMax;    // the next level ranks its segments inside waves: it reads no keys
     if (!next_ranks) {
       for (int s = s_lo; s < s_hi; ++s) {
         KdSeg& g = seg[s];
@@ -535,7 +541,7 @@ __device__ __forceinline__ void kd_median_build(int n, Fetch fetch, float4*& cur
 #ifdef SMHIP_KD_TIMING
   if (tid == 0 && blockIdx.x == 0)
     printf("[kd timing, n %d] setup %.0f us, small-segment levels %.0f, select sweeps %.0f, select scans %.0f, child dims %.0f, partition %.0f, next segments %.0f, level head %.0f\n", n,
-           s_kdph[0] * 0.01, s_kdph[1] * 0.01, s_kdph[2] * 0.01, s_kdph[3] * 0.01, s_kdph[4] * 0.01, s_kdph[5] * 0.01, s_kdph[6] * 0.01, s_kdph[7] * 0.01);
+           s_kdph[0] * 0.01, s_kdph[8] * 0.01, s_kdph[2] * 0.01, s_kdph[3] * 0.01, s_kdph[4] * 0.01, s_kdph[5] * 0.01, s_kdph[6] * 0.01, s_kdph[7] * 0.01);
 #endif
 }
 

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kKdThreads) void kd_build(IcpDev b, KdDev kd) {
   if (st->done) return;
   const int n = st->nt;
   const int tid = threadIdx.x;
-  __shared__ uint32_t s_hist[kKdHistWords];
+  __shared__ __attribute__((aligned(16))) uint32_t s_hist[kKdHistWords];   // (kd_median_build also lays 8-byte keys in it)
   __shared__ uint32_t s_w[17];
   __shared__ float s_box[6][16];
   __shared__ uint32_t s_misc[4];

@@ -76,6 +76,7 @@ struct smhip_context {
   int one_blocks = 0;            // workgroups of the single-pair persistent kernel the device holds at once (0: not available)
   int one_used = 0;              // the last single-pair enqueue went through it
   int one_blocks_allowed = 1;    // 0: fine-grained memory could not be had at smhip_create
+  long long one_launches = 0;    // enqueues that went through it (smhip_icp_single_launch_counts)
   int one_fallbacks = 0;         // Aligns done again as separate launches because the launch stopped itself (see fetch_range)
   int one_enabled = 1;           // SMHIP_ONE_PAIR=0: single pairs through the separate launches (measurement aid)
   int one_groups_want = 0;       // SMHIP_ONE_GROUPS: groups of its barrier (tuning)
@@ -1295,6 +1296,7 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
       void* args[] = {&d1, &groups};
       if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(icp_one), dim3(G, npairs), dim3(kNnThreads), args, 0, h->stream) == hipSuccess) {
         h->one_used = 1;
+        h->one_launches += 1;
         h->last_npairs = npairs;
         return SMHIP_OK;
       }
@@ -1517,6 +1519,13 @@ smhip_status smhip_icp_trimmed_score(smhip_handle h, int slot, const double T[16
 smhip_status smhip_set_target_cache(smhip_handle h, int enable) {
   if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
   h->target_cache = enable ? 1 : 0;
+  return SMHIP_OK;
+}
+
+smhip_status smhip_icp_single_launch_counts(smhip_handle h, int64_t* launches_used, int64_t* fallbacks) {
+  if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
+  if (launches_used) *launches_used = h->one_launches;
+  if (fallbacks) *fallbacks = h->one_fallbacks;
   return SMHIP_OK;
 }
 

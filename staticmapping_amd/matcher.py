@@ -160,6 +160,14 @@ class IcpFastHip:
         unchanged (default on); off = rebuild on every Align like the reference.  Results are identical either way."""
         self._check(self._lib.smhip_set_target_cache(self._h, 1 if enable else 0))
 
+    def single_launch_counts(self):
+        """(Aligns that ran as one cooperative launch, times such a launch stopped itself and the Align was redone as separate
+        launches) -- smhip_icp_single_launch_counts."""
+        import ctypes
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._lib.smhip_icp_single_launch_counts(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
+
     def copy_slot(self, src_slot: int, dst_slot: int):
         self._check(self._lib.smhip_copy_slot(self._h, src_slot, dst_slot))
 

@@ -29,6 +29,9 @@ def _run(sm, c, guess, repeats=1, **opts):
     for rep in range(repeats):                             # target structures kept; every run the same bits
         _, R2 = m.align(guess)
         assert np.array_equal(R, R2) and m.get_fitness_score() == out[1] and dict(m.last_stats[0]) == out[2], f"Align {rep + 2} differs from the first"
+    used, fell = m.single_launch_counts()
+    # no launch stopped itself; and a handle told to keep to the separate launches never took the one launch
+    assert fell == 0 and (used == 0 if opts.get("no_single_kernel") else used in (0, repeats + 1)), (used, fell)
     m.close()
     return out
 

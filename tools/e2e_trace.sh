@@ -11,7 +11,7 @@ f=$(find $out/trace -name '*kernel_stats.csv' | head -1)
 python - $f > $out/kernel_stats.txt <<'PY'
 import csv,sys
 for r in list(csv.reader(open(sys.argv[1])))[1:36]:
-    print(r[0].split('(')[0][-60:].ljust(60), r[1].rjust(5), '%8.2f ms' % (float(r[2]) / 1e6), '%9.1f us' % (float(r[3]) / 1e3))
+    print(r[0].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:60].ljust(60), r[1].rjust(5), '%8.2f ms' % (float(r[2]) / 1e6), '%9.1f us' % (float(r[3]) / 1e3))
 PY
 python tools/trace_busy.py $out/trace 10 > $out/busy.txt
 python tools/trace_window.py $out/trace ${3:-360} ${4:-400} > $out/window.txt

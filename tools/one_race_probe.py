@@ -27,4 +27,6 @@ for r in range(reps):
     if R.tobytes() != R0.tobytes() or sc.tobytes() != s0.tobytes():
         bad += 1
         if bad <= 3: print("run", r, "differs:", [ (x["iterations"], x["kept"], x["hard_queries"], x["searched_queries"]) for x in st], "first:", [(x["iterations"], x["kept"], x["hard_queries"], x["searched_queries"]) for x in st0])
-print(f"n={n} pairs={P} reps={reps}: {bad} runs differ from the first; {(time.time() - t) / reps * 1e3:.3f} ms per call")
+dt = time.time() - t
+used, fell = m.single_launch_counts()
+print(f"n={n} pairs={P} reps={reps}: {bad} runs differ from the first; {dt / reps * 1e3:.3f} ms per call; {used} of {reps + 1} calls ran as one launch, {fell} stopped themselves")

@@ -14,7 +14,7 @@ guess = T @ synth.make_pose(rpy_deg=(0.0, 0.0, 0.2), t=(0.03, 0.01, 0.0))
 m = sm.IcpFastHip(max_source_points=len(b), max_target_points=len(q), max_iteration=20, early_exit=0, no_single_kernel=sep)
 m.set_input_source(b); m.set_input_target(q, n)
 ref = m.align(guess)[1]; m.close()
-out, err = [None] * T_, []
+out, err, counts = [None] * T_, [], [None] * T_
 def work(k):
     try:
         m = sm.IcpFastHip(max_source_points=len(b), max_target_points=len(q), max_iteration=20, early_exit=0, no_single_kernel=sep)
@@ -24,6 +24,7 @@ def work(k):
             if not np.array_equal(R, ref):
                 err.append((k, "differs"))
         out[k] = R
+        counts[k] = m.single_launch_counts()
         m.close()
     except Exception as e:   # noqa: BLE001
         err.append((k, repr(e)))
@@ -32,4 +33,4 @@ th = [threading.Thread(target=work, args=(k,)) for k in range(T_)]
 for t in th: t.start()
 for t in th: t.join()
 dt = time.time() - t0
-print(f"{T_} threads x {reps} Aligns: {dt * 1e3:.1f} ms wall = {T_ * reps / dt:.0f} Aligns/s; errors: {err}")
+print(f"{T_} threads x {reps} Aligns: {dt * 1e3:.1f} ms wall = {T_ * reps / dt:.0f} Aligns/s; errors: {err}; (ran as one launch, stopped themselves) per matcher: {counts}")

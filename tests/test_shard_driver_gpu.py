@@ -63,6 +63,14 @@ def test_cpp_driver_matches_the_python_driver(tmp_path):
         assert da < 1e-6 and dt < 1e-5, (k, da, dt)
     truth = np.linalg.inv(poses[0]) @ poses[-1]
     assert np.linalg.norm(got[-1][:3, 3] - truth[:3, 3]) < 0.08
+    # the warm-up batch the driver sends through the same calls before its clock starts leaves nothing behind: same poses without it
+    assert line["warmup_batch_before_the_clock_s"] > 0
+    out0 = tmp_path / "kitti_pose_no_warmup.txt"
+    r0 = subprocess.run([exe, "--scans", seq, "--gpus", "1", "--out", str(out0), "--batch", "4", "--iterations", "20", "--guess-tx", "0.6", "--warmup", "0"],
+                        capture_output=True, text=True, timeout=600)
+    assert r0.returncode == 0, r0.stderr
+    assert json.loads(r0.stdout.strip().splitlines()[-1])["warmup_batch_before_the_clock_s"] == 0
+    assert out0.read_text() == out.read_text()
 
 
 @pytest.mark.gpu

@@ -721,7 +721,7 @@ def end_to_end(dev, n_scans=513, n_points=N_POINTS):
                                           "read_upload_prepare_total": best["read_upload_prepare_s_rank0"]},
                     "clock": "starts before the driver's readers open the first file, stops when the gathered poses are on the host side of the "
                              "collective; before it: the handle, its workspaces and one batch of 32 made-up 8 192-point scans through the same calls "
-                             "(code objects loaded, copy stream created -- a process pays that once, not per sequence)",
+                             "(code objects loaded, copy and side streams created -- a process pays that once, not per sequence; its search history forgotten again)",
                     "warmup_batch_before_the_clock_s": best.get("warmup_batch_before_the_clock_s"),
                     "host_side_split_note": "device_calculate_normals is the host blocked in the batch's target preparation, which runs on the stream "
                                             "behind the previous batch's alignments: it holds their remaining time too (per 256-pair batch: alignments "

@@ -261,6 +261,11 @@ smhip_status smhip_set_target_cache(smhip_handle h, int enable);
  * kept count), the fetch runs the Align again as separate launches and the handle keeps to them: *launches_used = Aligns that went
  * through the one launch, *fallbacks = how often that happened (0 on every run recorded so far).  Either pointer may be NULL. */
 smhip_status smhip_icp_single_launch_counts(smhip_handle h, int64_t* launches_used, int64_t* fallbacks);
+/* With split_after = 0 a batch of >= 16 pairs switches from the every-query search to certificates + listed search at the iteration
+ * the PREVIOUS batch suggests (a front end's guesses are alike from call to call); results never depend on it, only the time.  This
+ * call forgets what earlier batches taught the handle -- e.g. after a warm-up batch of made-up clouds (smhip_shard) -- so that the
+ * next batch starts from the defaults a new handle has. */
+smhip_status smhip_icp_forget_search_history(smhip_handle h);
 /* what the handle was created with / what a slot currently holds (any pointer may be NULL) */
 smhip_status smhip_get_capacity(smhip_handle h, int* pair_slots, int* max_source_points, int* max_target_points);
 smhip_status smhip_get_cloud_sizes(smhip_handle h, int slot, int* n_source, int* n_target, int* has_normals);

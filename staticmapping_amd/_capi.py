@@ -110,6 +110,7 @@ SIGNATURES = {
     "smhip_prepare_target_from_target": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_int32_p]),
     "smhip_sample_source": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_uint32, c_int32_p]),
     "smhip_set_target_cache": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "smhip_icp_forget_search_history": (ctypes.c_int, [ctypes.c_void_p]),
     "smhip_icp_single_launch_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "smhip_get_capacity": (ctypes.c_int, [ctypes.c_void_p, c_int32_p, c_int32_p, c_int32_p]),
     "smhip_get_cloud_sizes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int32_p, c_int32_p, c_int32_p]),

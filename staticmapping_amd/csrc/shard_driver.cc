@@ -257,7 +257,10 @@ int RunRank(const Args& a, int rank, int world, int device) {
       if (smhip_set_sources_f32_batch(hs[hk], static_cast<int>(wslots.size()), wslots.data(), wrows.data(), wn.data()) != SMHIP_OK ||
           smhip_prepare_targets_from_sources(hs[hk], WS, wfrom.data(), wto.data(), wnt.data()) != SMHIP_OK ||
           smhip_icp_enqueue_batch(hs[hk], WS, guesses.data()) != SMHIP_OK ||
-          smhip_icp_export_results_device(hs[hk], WS, local_dev) != SMHIP_OK)
+          smhip_icp_export_results_device(hs[hk], WS, local_dev) != SMHIP_OK ||
+          // (what the made-up batch taught the handle about where to switch search forms is forgotten: the first real batch chooses
+          // as it does without the warm-up)
+          smhip_icp_forget_search_history(hs[hk]) != SMHIP_OK)
         Die(std::string("warm-up batch: ") + smhip_last_error(hs[hk]));
       HIPOK(hipStreamSynchronize(streams[hk]));
     }

@@ -91,6 +91,7 @@ struct smhip_context {
   uint32_t* hist_pinned = nullptr;
   int hist_first = 0;
   int hist_pairs = 0;                  // pairs whose rows the last enqueue copied to hist_pinned (0 = none)
+  std::vector<int> hist_ns;            // their sources' sizes at that enqueue (the slots may hold other clouds by the time the rows are read)
   int hist_iters = 0;                  // iterations that enqueue ran
   int auto_split = 2;
   int32_t* ids_pinned = nullptr;
@@ -1203,7 +1204,7 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
     int k = 1;
     std::vector<float> share((size_t)h->hist_pairs);
     for (; k < std::min(h->hist_iters, kSearchHist); ++k) {
-      for (int p = 0; p < h->hist_pairs; ++p) share[p] = (float)h->hist_pinned[(size_t)p * kSearchHist + k] / (float)std::max(1, h->ns[h->hist_first + p]);
+      for (int p = 0; p < h->hist_pairs; ++p) share[p] = (float)h->hist_pinned[(size_t)p * kSearchHist + k] / (float)std::max(1, h->hist_ns[p]);
       std::nth_element(share.begin(), share.begin() + share.size() / 2, share.end());
       if (share[share.size() / 2] < h->split_share) break;
     }
@@ -1374,6 +1375,7 @@ static smhip_status enqueue_range(smhip_handle h, int first, int npairs, const d
     HIPCHK(h, hipMemcpyAsync(h->hist_pinned, h->dev.search_hist + (size_t)first * kSearchHist, sizeof(uint32_t) * kSearchHist * (size_t)npairs,
                              hipMemcpyDeviceToHost, h->stream));
     h->hist_first = first; h->hist_pairs = npairs; h->hist_iters = max_it;
+    h->hist_ns.assign(h->ns.begin() + first, h->ns.begin() + first + npairs);
   }
   HIPCHK(h, hipGetLastError());
   h->last_npairs = npairs;
@@ -1519,6 +1521,16 @@ smhip_status smhip_icp_trimmed_score(smhip_handle h, int slot, const double T[16
 smhip_status smhip_set_target_cache(smhip_handle h, int enable) {
   if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
   h->target_cache = enable ? 1 : 0;
+  return SMHIP_OK;
+}
+
+smhip_status smhip_icp_forget_search_history(smhip_handle h) {
+  if (!h) return SMHIP_ERR_INVALID_ARGUMENT;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));       // (a batch's rows may still be on their way to hist_pinned)
+  h->hist_pairs = 0;
+  h->auto_split = 2;
+  h->nabo_fused_from = 6;
   return SMHIP_OK;
 }
 

@@ -723,6 +723,10 @@ def end_to_end(dev, n_scans=513, n_points=N_POINTS):
                              "collective; before it: the handle, its workspaces and one batch of 32 made-up 8 192-point scans through the same calls "
                              "(code objects loaded, copy and side streams created -- a process pays that once, not per sequence; its search history forgotten again)",
                     "warmup_batch_before_the_clock_s": best.get("warmup_batch_before_the_clock_s"),
+                    "steady_state_pairs_per_s": best.get("steady_state_pairs_per_s_rank0"),
+                    "steady_state_note": "pairs of the batches after the first / time from the first batch's alignments being enqueued to the last "
+                                         "batch's: the batch period once the pipeline is full (a 1 024-pair run is four batches: a quarter of it "
+                                         "is filling and draining); `value` is the whole run",
                     "host_side_split_note": "device_calculate_normals is the host blocked in the batch's target preparation, which runs on the stream "
                                             "behind the previous batch's alignments: it holds their remaining time too (per 256-pair batch: alignments "
                                             "~15 ms, preparation ~15 ms of which kd_forest_build 11-13; side by side on two streams they take the same "

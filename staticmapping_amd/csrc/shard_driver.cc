@@ -282,6 +282,10 @@ int RunRank(const Args& a, int rank, int world, int device) {
   double upload_s = 0.0, wait_s = 0.0, set_s = 0.0, prep_s = 0.0;   // rank 0's host-side split: blocked on the readers / uploads / target preparation
   auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
   int done = 0, my_pairs = 0;
+  // the batch period once the pipeline is full: from the first batch's alignments being enqueued to the last batch's, over the pairs of
+  // the batches after the first (a run of four batches spends a quarter of its time filling and draining)
+  double first_enq_s = 0.0, last_enq_s = 0.0;
+  int first_enq_pairs = 0, enq_pairs = 0;
   // SMHIP_SHARD_TIMELINE=1: where the host is (ms since the clock started) as it walks a batch -- to lay next to a kernel trace
   const bool timeline = rank == 0 && std::getenv("SMHIP_SHARD_TIMELINE") != nullptr;
   auto mark = [&](const char* what, int base) { if (timeline) std::fprintf(stderr, "[timeline] %8.3f ms  batch at %d: %s\n", since(t0) * 1e3, base, what); };
@@ -333,6 +337,8 @@ int RunRank(const Args& a, int rank, int world, int device) {
     if (smhip_icp_enqueue_batch(h, nb, guesses.data()) != SMHIP_OK) Die(std::string("enqueue: ") + smhip_last_error(h));
     if (smhip_icp_export_results_device(h, nb, local_dev + static_cast<size_t>(kPoseDoubles) * base) != SMHIP_OK) Die(smhip_last_error(h));
     mark("alignments enqueued", base);
+    if (turn == 0) { first_enq_s = since(t0); first_enq_pairs = nb; }
+    last_enq_s = since(t0); enq_pairs += nb;
     done = base + nb;
     my_pairs += nb;
   }
@@ -372,8 +378,9 @@ int RunRank(const Args& a, int rank, int world, int device) {
       std::printf("{\"driver\": \"smhip_shard (C++, RCCL all-gather)\", \"n_gpus\": %d, \"pairs\": %d, \"pairs_rank0\": %d, \"seconds\": %.4f, "
                   "\"pairs_per_s\": %.2f, \"read_upload_prepare_s_rank0\": %.4f, \"wait_for_readers_s_rank0\": %.4f, \"upload_s_rank0\": %.4f, "
                   "\"prepare_targets_s_rank0\": %.4f, \"mean_score\": %.6f, \"mean_iterations\": %.2f, "
-                  "\"unfinished_pairs\": %d, \"batch\": %d, \"readers\": %d, \"pinned_read_buffers\": %s, \"warmup_batch_before_the_clock_s\": %.4f, \"poses_file\": \"%s\"}\n",
-                  world, n_pairs, my_pairs, elapsed, n_pairs / elapsed, upload_s, wait_s, set_s, prep_s, score_sum / n_pairs, iter_sum / n_pairs, bad, B, a.readers, pinned ? "true" : "false", warmup_s, a.out_path.c_str());
+                  "\"unfinished_pairs\": %d, \"batch\": %d, \"readers\": %d, \"pinned_read_buffers\": %s, \"warmup_batch_before_the_clock_s\": %.4f, \"steady_state_pairs_per_s_rank0\": %.2f, \"poses_file\": \"%s\"}\n",
+                  world, n_pairs, my_pairs, elapsed, n_pairs / elapsed, upload_s, wait_s, set_s, prep_s, score_sum / n_pairs, iter_sum / n_pairs, bad, B, a.readers, pinned ? "true" : "false", warmup_s,
+                  last_enq_s > first_enq_s ? (enq_pairs - first_enq_pairs) / (last_enq_s - first_enq_s) : 0.0, a.out_path.c_str());
     }
     if (bad) rc = 3;
   }

@@ -160,6 +160,10 @@ class IcpFastHip:
         unchanged (default on); off = rebuild on every Align like the reference.  Results are identical either way."""
         self._check(self._lib.smhip_set_target_cache(self._h, 1 if enable else 0))
 
+    def forget_search_history(self):
+        """The next batch chooses where to switch search forms as a new handle's first batch does (smhip_icp_forget_search_history)."""
+        self._check(self._lib.smhip_icp_forget_search_history(self._h))
+
     def single_launch_counts(self):
         """(Aligns that ran as one cooperative launch, times such a launch stopped itself and the Align was redone as separate
         launches) -- smhip_icp_single_launch_counts."""

@@ -470,6 +470,13 @@ def test_batch_split_point_follows_the_previous_batch_and_changes_no_bits(smhip,
         R, sc, st = m.align_batch(B, g)
         used.append(m.get_profile()["split_after_used"])
         assert (R.tobytes(), tuple(s["kept"] for s in st)) == ref[name], name
+    # smhip_icp_forget_search_history: after poor guesses the next batch would switch late; told to forget, it switches where a new
+    # handle's first batch does -- same bits
+    m.align_batch(B, poor)
+    m.forget_search_history()
+    R, sc, st = m.align_batch(B, poor)
+    assert m.get_profile()["split_after_used"] == 2
+    assert (R.tobytes(), tuple(s["kept"] for s in st)) == ref["poor"]
     m.close()
     assert used[0] == 2                      # nothing known yet
     assert used[1] <= 2                      # after good guesses: almost every certificate holds from iteration 1 on

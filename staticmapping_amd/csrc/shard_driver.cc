@@ -50,7 +50,7 @@ struct Args {
   std::string scans_dir, out_path = "kitti_pose.txt", id_file;
   unsigned long long nonce = 0;             // identifies this run's id file (launcher: pid and start time; else MASTER_PORT)
   int gpus = 1, rank = -1, world = -1, local_rank = -1;
-  int batch = 256, iterations = 20, early_exit = 0, max_pairs = -1, readers = 8, matchers = 1, warmup = 1;
+  int batch = 256, iterations = 20, early_exit = 0, max_pairs = -1, readers = 8, matchers = 1, warmup = 1, parts = 0;
   double guess_tx = 0.0;
   bool quiet = false;
 };
@@ -100,10 +100,11 @@ Args Parse(int argc, char** argv) {
     else if (k == "--readers") a.readers = std::atoi(val().c_str());
     else if (k == "--matchers") a.matchers = std::atoi(val().c_str());
     else if (k == "--warmup") a.warmup = std::atoi(val().c_str());
+    else if (k == "--parts") a.parts = std::atoi(val().c_str());
     else if (k == "--guess-tx") a.guess_tx = std::atof(val().c_str());
     else if (k == "--quiet") a.quiet = true;
     else Die("unknown argument " + k + "\nusage: smhip_shard --scans DIR [--gpus G] [--out kitti_pose.txt] [--batch 256] "
-             "[--iterations 20] [--early-exit 0|1] [--guess-tx metres] [--max-pairs N] [--readers 8] [--matchers 1|2] [--warmup 1|0]");
+             "[--iterations 20] [--early-exit 0|1] [--guess-tx metres] [--max-pairs N] [--readers 8] [--matchers 1|2] [--warmup 1|0] [--parts 0..4]");
   }
   if (a.scans_dir.empty()) Die("--scans DIR is required");
   if (a.rank < 0 && std::getenv("RANK")) a.rank = std::atoi(std::getenv("RANK"));
@@ -184,6 +185,7 @@ int RunRank(const Args& a, int rank, int world, int device) {
     smhip_icp_default_options(&o);
     o.max_iteration = a.iterations;
     o.early_exit = a.early_exit;
+    if (a.parts > 0) o.overlap_streams = a.parts;         // parts of a batch on streams of their own (0: the library's default, two)
     if (smhip_icp_set_options(hs[k], &o) != SMHIP_OK) Die(smhip_last_error(hs[k]));
   }
 
